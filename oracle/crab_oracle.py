@@ -1,0 +1,594 @@
+"""CPU ORACLE for the Crab inference hot path -- TEST INFRASTRUCTURE ONLY.
+
+A plain PyTorch fp32 restatement of the reference's forward arithmetic for the path named by
+BASELINE.json (BEATs -> CLIP ViT -> Q-Former projectors -> hyper-LoRA Llama/Qwen2 decoder ->
+greedy decode), written from SURVEY.md Appendix B and the cited reference lines.  Nothing under
+crab_amd/ may import this file: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg use it, and only as the checker / CPU baseline, never as the thing measured or shipped.
+
+Pinning: the reference ships no tests and no golden vectors for this path ("parity unpinned" by
+the reference itself).  The pins are therefore the fixtures under tests/golden/*.npz,
+produced by tests/golden/make_golden.py, which imports the reference from /root/reference in the build
+container, loads crab_amd.synth weights into it and records its outputs.  tests/test_oracle_golden.py
+checks every function below against those fixtures (fp32, tolerance 2e-4 abs on O(1) values; the
+reference runs on transformers 5.15 here instead of the pinned 4.37.2, see SURVEY.md 8c caveats).
+
+All weights are addressed by the reference's own state-dict key names (minus PEFT's
+`base_model.model.` prefix), so a `finetune_weights.bin`-style dict drives the oracle directly.
+
+`emulate` argument: when a torch dtype (bf16) is given, activations are rounded to that dtype at the
+same points where the HIP path stores bf16 tensors (GEMM outputs, norm outputs, attention output),
+with all inner arithmetic in fp32.  emulate=None is the exact fp32 path of the reference as shipped
+(scripts/quick_start.sh:42-44 pass --bf16 False).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+WDict = Dict[str, Tensor]
+
+
+def _r(x: Tensor, emulate) -> Tensor:
+    """Round-trip through the emulated storage dtype (identity when emulate is None)."""
+    if emulate is None:
+        return x
+    return x.to(emulate).to(torch.float32)
+
+
+def strip_peft_prefix(sd: WDict) -> WDict:
+    """finetune_weights.bin keys carry PEFT's `base_model.model.` prefix."""
+    out = {}
+    for k, v in sd.items():
+        out[k[len("base_model.model."):] if k.startswith("base_model.model.") else k] = v
+    return out
+
+
+# =====================================================================================
+# B.1 hyper-LoRA Linear                       reference peft_hyper/tuners/lora.py:338-350
+# =====================================================================================
+
+def linear(x: Tensor, W: WDict, prefix: str, emulate=None) -> Tensor:
+    w = W[prefix + ".weight"]
+    b = W.get(prefix + ".bias")
+    return _r(F.linear(x, w, b), emulate)
+
+
+def hyperlora_linear(x: Tensor, W: WDict, prefix: str, scaling: float = 2.0, lora_nums: int = 3,
+                     emulate=None) -> Tensor:
+    """y = x W^T (+b) + sum_i softmax_fp32(x R^T)_i * (B_i (A x)) * scaling   (lora.py:341-350).
+
+    Falls back to a plain Linear when the prefix carries no lora_A (module not wrapped)."""
+    w = W[prefix + ".weight"]
+    b = W.get(prefix + ".bias")
+    y = F.linear(x, w, b)
+    if (prefix + ".lora_A.weight") not in W:
+        return _r(y, emulate)
+    route = torch.softmax(F.linear(x, W[prefix + ".lora_route.weight"]).float(), dim=-1)   # lora.py:346
+    h = F.linear(x, W[prefix + ".lora_A.weight"])                                          # lora.py:349
+    for i in range(lora_nums):
+        y = y + route[..., i:i + 1] * F.linear(h, W[prefix + f".lora_B{i}.weight"]) * scaling
+    return _r(y, emulate)
+
+
+# =====================================================================================
+# B.2 Llama / Qwen2 decoder        reference models/modeling_llama.py, models/qwen/modeling_qwen2.py
+# =====================================================================================
+
+@dataclass
+class DecoderConfig:
+    hidden_size: int = 4096
+    intermediate_size: int = 11008
+    num_hidden_layers: int = 32
+    num_attention_heads: int = 32
+    num_key_value_heads: int = 32
+    vocab_size: int = 32017
+    rms_norm_eps: float = 1e-5
+    rope_theta: float = 10000.0
+    lora_r: int = 8
+    lora_alpha: int = 16
+    lora_nums: int = 3
+
+    @property
+    def head_dim(self) -> int:
+        return self.hidden_size // self.num_attention_heads
+
+    @property
+    def scaling(self) -> float:
+        return self.lora_alpha / self.lora_r
+
+    @staticmethod
+    def llama2_7b() -> "DecoderConfig":
+        return DecoderConfig()
+
+    @staticmethod
+    def qwen2_7b() -> "DecoderConfig":
+        return DecoderConfig(hidden_size=3584, intermediate_size=18944, num_hidden_layers=28,
+                             num_attention_heads=28, num_key_value_heads=4, vocab_size=152064 + 17,
+                             rms_norm_eps=1e-6, rope_theta=1e6)
+
+
+def rmsnorm(x: Tensor, w: Tensor, eps: float, emulate=None) -> Tensor:
+    """modeling_llama.py:112-117: fp32 variance, x_hat cast to input dtype, then * weight."""
+    x32 = x.float()
+    xh = x32 * torch.rsqrt(x32.pow(2).mean(-1, keepdim=True) + eps)
+    return _r(w.float() * _r(xh, emulate), emulate)
+
+
+def rope_cos_sin(positions: Tensor, head_dim: int, theta: float) -> Tuple[Tensor, Tensor]:
+    """modeling_llama.py:130-156: inv_freq_i = theta^(-2i/d); emb = cat(freqs, freqs)."""
+    inv = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float32) / head_dim))
+    fr = positions.float()[..., None] * inv            # [..., d/2]
+    emb = torch.cat([fr, fr], dim=-1)
+    return emb.cos(), emb.sin()
+
+
+def _rot_half(x: Tensor) -> Tensor:
+    h = x.shape[-1] // 2
+    return torch.cat([-x[..., h:], x[..., :h]], dim=-1)   # modeling_llama.py:204-208
+
+
+def apply_rope(q: Tensor, k: Tensor, cos: Tensor, sin: Tensor) -> Tuple[Tensor, Tensor]:
+    """q,k: [b,h,s,d]; cos,sin: [b,s,d] (modeling_llama.py:211-236)."""
+    c, s = cos[:, None], sin[:, None]
+    return q * c + _rot_half(q) * s, k * c + _rot_half(k) * s
+
+
+@dataclass
+class KVCache:
+    """DynamicCache equivalent: per-layer [b,h_kv,t,d] tensors appended after RoPE (:408-412)."""
+    k: List[Optional[Tensor]] = field(default_factory=list)
+    v: List[Optional[Tensor]] = field(default_factory=list)
+
+    def length(self) -> int:
+        return 0 if not self.k or self.k[0] is None else self.k[0].shape[2]
+
+
+def decoder_layer(x: Tensor, W: WDict, i: int, cfg: DecoderConfig, cache: KVCache, positions: Tensor,
+                  emulate=None) -> Tensor:
+    """One Llama/Qwen2 layer (modeling_llama.py:805-827; attention :394-452; MLP :269).
+    x [b,s,D]; positions [b,s] absolute position ids."""
+    p = f"model.layers.{i}"
+    b, s, D = x.shape
+    H, Hk, d = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+    sc, ln = cfg.scaling, cfg.lora_nums
+
+    h = rmsnorm(x, W[p + ".input_layernorm.weight"], cfg.rms_norm_eps, emulate)
+    q = hyperlora_linear(h, W, p + ".self_attn.q_proj", sc, ln, emulate).view(b, s, H, d).transpose(1, 2)
+    k = hyperlora_linear(h, W, p + ".self_attn.k_proj", sc, ln, emulate).view(b, s, Hk, d).transpose(1, 2)
+    v = hyperlora_linear(h, W, p + ".self_attn.v_proj", sc, ln, emulate).view(b, s, Hk, d).transpose(1, 2)
+    cos, sin = rope_cos_sin(positions, d, cfg.rope_theta)
+    q, k = apply_rope(q, k, cos, sin)
+    q, k = _r(q, emulate), _r(k, emulate)
+    while len(cache.k) <= i:
+        cache.k.append(None)
+        cache.v.append(None)
+    if cache.k[i] is None:
+        cache.k[i], cache.v[i] = k, v
+    else:
+        cache.k[i] = torch.cat([cache.k[i], k], dim=2)
+        cache.v[i] = torch.cat([cache.v[i], v], dim=2)
+    kk, vv = cache.k[i], cache.v[i]
+    t = kk.shape[2]
+    if Hk != H:                                           # repeat_kv, modeling_llama.py:274-283
+        g = H // Hk
+        kk = kk[:, :, None].expand(b, Hk, g, t, d).reshape(b, H, t, d)
+        vv = vv[:, :, None].expand(b, Hk, g, t, d).reshape(b, H, t, d)
+    a = torch.matmul(q, kk.transpose(2, 3)) / math.sqrt(d)                    # :417
+    # causal mask: query row r (absolute index t-s+r) sees keys 0..t-s+r       (:420-428)
+    qi = torch.arange(t - s, t)[:, None]
+    kj = torch.arange(t)[None, :]
+    a = a.masked_fill((kj > qi)[None, None], torch.finfo(torch.float32).min)
+    pr = torch.softmax(a.float(), dim=-1)                                      # :431 fp32 softmax
+    o = torch.matmul(_r(pr, emulate), vv).transpose(1, 2).reshape(b, s, H * d)
+    o = _r(o, emulate)
+    x = _r(x + hyperlora_linear(o, W, p + ".self_attn.o_proj", sc, ln, None), emulate)
+
+    h = rmsnorm(x, W[p + ".post_attention_layernorm.weight"], cfg.rms_norm_eps, emulate)
+    g_ = hyperlora_linear(h, W, p + ".mlp.gate_proj", sc, ln, None)
+    u_ = hyperlora_linear(h, W, p + ".mlp.up_proj", sc, ln, None)
+    m = _r(F.silu(g_) * u_, emulate)                                           # :269
+    x = _r(x + hyperlora_linear(m, W, p + ".mlp.down_proj", sc, ln, None), emulate)
+    return x
+
+
+def decoder_forward(embeds: Tensor, W: WDict, cfg: DecoderConfig, cache: Optional[KVCache] = None,
+                    positions: Optional[Tensor] = None, last_only: bool = False, emulate=None
+                    ) -> Tuple[Tensor, Tensor, KVCache]:
+    """LlamaModel.forward + lm_head (modeling_llama.py:989-1124, 1169-1287).
+    Returns (logits fp32, post-final-norm hidden, cache).  `last_only` computes lm_head on the last
+    row only (output-identical for generate())."""
+    b, s, _ = embeds.shape
+    cache = cache if cache is not None else KVCache()
+    past = cache.length()
+    if positions is None:
+        positions = torch.arange(past, past + s)[None].expand(b, s)
+    x = _r(embeds.float(), emulate)
+    for i in range(cfg.num_hidden_layers):
+        x = decoder_layer(x, W, i, cfg, cache, positions, emulate)
+    hn = rmsnorm(x, W["model.norm.weight"], cfg.rms_norm_eps, emulate)
+    hh = hn[:, -1:] if last_only else hn
+    logits = F.linear(hh, W["lm_head.weight"]).float()
+    return logits, hn, cache
+
+
+def greedy_generate(embeds: Tensor, W: WDict, cfg: DecoderConfig, max_new_tokens: int,
+                    eos_token_id: Optional[int] = None, pad_token_id: Optional[int] = None,
+                    min_new_tokens: int = 0, emulate=None, return_hidden: bool = False):
+    """B.3: HF GenerationMixin greedy loop as driven by unified_llama.py:262-267 with only
+    inputs_embeds: positions 0..S-1 (pads attended, no mask forwarded), argmax on fp32 last-row logits,
+    finished rows emit pad, returns ONLY new ids.  Also returns per-step last-row logits."""
+    b = embeds.shape[0]
+    cache = KVCache()
+    logits, hn, cache = decoder_forward(embeds, W, cfg, cache, last_only=True, emulate=emulate)
+    ids, step_logits, hiddens = [], [], []
+    unfinished = torch.ones(b, dtype=torch.bool)
+    pad = pad_token_id if pad_token_id is not None else (eos_token_id if eos_token_id is not None else 0)
+    for step in range(max_new_tokens):
+        lg = logits[:, -1].clone()
+        step_logits.append(lg)
+        hiddens.append(hn[:, -1])
+        if eos_token_id is not None and step < min_new_tokens:
+            lg[:, eos_token_id] = -float("inf")
+        nxt = lg.argmax(-1)
+        nxt = torch.where(unfinished, nxt, torch.full_like(nxt, pad))
+        ids.append(nxt)
+        if eos_token_id is not None:
+            unfinished = unfinished & (nxt != eos_token_id)
+            if not unfinished.any():
+                break
+        if step + 1 == max_new_tokens:
+            break
+        e = W["model.embed_tokens.weight"][nxt][:, None]              # unified_llama.py:125-127
+        logits, hn, cache = decoder_forward(e, W, cfg, cache, last_only=True, emulate=emulate)
+    out = torch.stack(ids, dim=1)
+    sl = torch.stack(step_logits, dim=1)
+    if return_hidden:
+        return out, sl, torch.stack(hiddens, dim=1)
+    return out, sl
+
+
+# =====================================================================================
+# B.4 CLIP ViT vision tower (HF CLIPVisionModel; Crab use: multimodal_encoder.py:52-84)
+# =====================================================================================
+
+@dataclass
+class ClipConfig:
+    hidden_size: int = 1024
+    intermediate_size: int = 4096
+    num_hidden_layers: int = 24
+    num_attention_heads: int = 16
+    image_size: int = 224
+    patch_size: int = 14
+    layer_norm_eps: float = 1e-5
+    select_layers: Tuple[int, ...] = (14, 22, 23)
+
+    @property
+    def num_patches(self) -> int:
+        return (self.image_size // self.patch_size) ** 2
+
+
+def layernorm(x: Tensor, W: WDict, prefix: str, eps: float, emulate=None) -> Tensor:
+    return _r(F.layer_norm(x.float(), (x.shape[-1],), W[prefix + ".weight"].float(), W[prefix + ".bias"].float(), eps),
+              emulate)
+
+
+def _mha(q: Tensor, k: Tensor, v: Tensor, heads: int, scale: float, bias: Optional[Tensor] = None,
+         emulate=None) -> Tensor:
+    """q [b,n,D], k/v [b,m,D] -> [b,n,D]; softmax(q k^T * scale + bias) v."""
+    b, n, D = q.shape
+    m = k.shape[1]
+    d = D // heads
+    qh = q.view(b, n, heads, d).transpose(1, 2)
+    kh = k.view(b, m, heads, d).transpose(1, 2)
+    vh = v.view(b, m, heads, d).transpose(1, 2)
+    a = torch.matmul(qh, kh.transpose(2, 3)) * scale
+    if bias is not None:
+        a = a + bias
+    p = _r(torch.softmax(a.float(), dim=-1), emulate)
+    o = torch.matmul(p, vh).transpose(1, 2).reshape(b, n, D)
+    return _r(o, emulate)
+
+
+def clip_vision(pixels: Tensor, W: WDict, cfg: ClipConfig, prefix: str = "model.visual_encoder.vision_tower.vision_model",
+                emulate=None, max_layer: Optional[int] = None) -> List[Tensor]:
+    """pixels [N,3,H,W] -> hidden_states list h_0..h_L, each [N, 1+P, D] (B.4).
+    Stops after max(select_layers) layers when max_layer is None (layer 24 / post_layernorm are dead,
+    SURVEY.md appendix A.2)."""
+    N = pixels.shape[0]
+    ps = cfg.patch_size
+    w = W[prefix + ".embeddings.patch_embedding.weight"]
+    x = F.conv2d(pixels.float(), w, None, stride=ps)                     # [N,D,g,g], no bias
+    x = _r(x.flatten(2).transpose(1, 2), emulate)                        # [N,P,D]
+    cls = W[prefix + ".embeddings.class_embedding"].float().expand(N, 1, -1)
+    x = torch.cat([cls, x], dim=1) + W[prefix + ".embeddings.position_embedding.weight"].float()[None]
+    x = _r(x, emulate)
+    h = layernorm(x, W, prefix + ".pre_layrnorm", cfg.layer_norm_eps, emulate)
+    hs = [h]
+    H = cfg.num_attention_heads
+    d = cfg.hidden_size // H
+    L = max_layer if max_layer is not None else max(cfg.select_layers)
+    for i in range(L):
+        p = f"{prefix}.encoder.layers.{i}"
+        a = layernorm(h, W, p + ".layer_norm1", cfg.layer_norm_eps, emulate)
+        q = linear(a, W, p + ".self_attn.q_proj", emulate)
+        k = linear(a, W, p + ".self_attn.k_proj", emulate)
+        v = linear(a, W, p + ".self_attn.v_proj", emulate)
+        o = _mha(q, k, v, H, d ** -0.5, None, emulate)
+        h = _r(h + linear(o, W, p + ".self_attn.out_proj", None), emulate)
+        a = layernorm(h, W, p + ".layer_norm2", cfg.layer_norm_eps, emulate)
+        f1 = linear(a, W, p + ".mlp.fc1", None)
+        f1 = _r(f1 * torch.sigmoid(1.702 * f1), emulate)                 # quick_gelu
+        h = _r(h + linear(f1, W, p + ".mlp.fc2", None), emulate)
+        hs.append(h)
+    return hs
+
+
+def visual_encoder(video: Tensor, W: WDict, cfg: ClipConfig, emulate=None,
+                   prefix: str = "model.visual_encoder.vision_tower.vision_model") -> List[Tensor]:
+    """VisualEncoder.forward (multimodal_encoder.py:75-84): video [b,t,3,H,W] -> list of [b,t*P,D],
+    one per select layer, CLS dropped (feature_select :52-63)."""
+    b, t = video.shape[:2]
+    hs = clip_vision(video.reshape(b * t, *video.shape[2:]), W, cfg, prefix, emulate)
+    out = []
+    for lyr in cfg.select_layers:
+        f = hs[lyr][:, 1:]
+        out.append(f.reshape(b, t * f.shape[1], f.shape[2]))
+    return out
+
+
+# =====================================================================================
+# B.5 Q-Former projectors    reference models/Qformer.py, multimodal_encoder.py:119-144,226-262
+# =====================================================================================
+
+@dataclass
+class QFormerConfig:
+    hidden_size: int = 768
+    num_attention_heads: int = 12
+    intermediate_size: int = 3072
+    num_hidden_layers: int = 2
+    layer_norm_eps: float = 1e-12
+    num_query_token: int = 32
+
+
+def _gelu(x: Tensor) -> Tensor:
+    return F.gelu(x)          # exact erf GELU (ACT2FN['gelu'], nn.GELU())
+
+
+def qformer(query: Tensor, enc: Tensor, W: WDict, prefix: str, cfg: QFormerConfig, emulate=None) -> Tensor:
+    """BertModel.forward with query_embeds only (Qformer.py:806-967): query [B,32,h], enc [B,m,enc_w]."""
+    eps = cfg.layer_norm_eps
+    H = cfg.num_attention_heads
+    d = cfg.hidden_size // H
+    z = layernorm(query, W, prefix + ".embeddings.LayerNorm", eps, emulate)          # :105-108
+    for l in range(cfg.num_hidden_layers):
+        p = f"{prefix}.encoder.layer.{l}"
+        # self attention (:171-277), scores / sqrt(d), mask all ones -> additive 0
+        q = linear(z, W, p + ".attention.self.query", emulate)
+        k = linear(z, W, p + ".attention.self.key", emulate)
+        v = linear(z, W, p + ".attention.self.value", emulate)
+        c = _mha(q, k, v, H, 1.0 / math.sqrt(d), None, emulate)
+        z = layernorm(linear(c, W, p + ".attention.output.dense", None) + z, W, p + ".attention.output.LayerNorm",
+                      eps, emulate)                                                    # :287-291
+        # cross attention every layer (cross_attention_freq=1)
+        q = linear(z, W, p + ".crossattention.self.query", emulate)
+        k = linear(enc, W, p + ".crossattention.self.key", emulate)
+        v = linear(enc, W, p + ".crossattention.self.value", emulate)
+        c = _mha(q, k, v, H, 1.0 / math.sqrt(d), None, emulate)
+        z = layernorm(linear(c, W, p + ".crossattention.output.dense", None) + z, W,
+                      p + ".crossattention.output.LayerNorm", eps, emulate)
+        # query FFN (:483-486)
+        f = _r(_gelu(linear(z, W, p + ".intermediate_query.dense", None)), emulate)
+        z = layernorm(linear(f, W, p + ".output_query.dense", None) + z, W, p + ".output_query.LayerNorm", eps,
+                      emulate)
+    return z
+
+
+def vl_projector(feat: Tensor, W: WDict, cfg: QFormerConfig, image_token_nums: int = 256,
+                 prefix: str = "model.vl_projector", emulate=None) -> Tensor:
+    """VLProjector.forward (multimodal_encoder.py:119-144): [b,t*n,enc] -> [b,t*32,D]."""
+    b, tn, dim = feat.shape
+    t = tn // image_token_nums
+    x = feat.reshape(b * t, image_token_nums, dim)
+    x = layernorm(x, W, prefix + ".visual_ln", 1e-5, emulate)
+    qt = W[prefix + ".visual_query_tokens"].float().expand(b * t, -1, -1)
+    z = qformer(qt, x, W, prefix + ".visual_Qformer.bert", cfg, emulate)[:, :cfg.num_query_token]
+    y = _r(_gelu(linear(z, W, prefix + ".visual_proj.0", None)), emulate)
+    y = linear(y, W, prefix + ".visual_proj.2", emulate)
+    return y.reshape(b, t * cfg.num_query_token, -1)
+
+
+def al_projector(feat: Tensor, W: WDict, cfg: QFormerConfig, prefix: str = "model.al_projector",
+                 emulate=None) -> Tensor:
+    """ALProjector.forward 4-D branch (multimodal_encoder.py:226-244): [b,t,n,768] -> [b,t*32,D]."""
+    b, t, n, d = feat.shape
+    x = layernorm(feat.reshape(b * t, n, d), W, prefix + ".audio_ln", 1e-5, emulate)
+    qt = W[prefix + ".audio_query_tokens"].float().expand(b * t, -1, -1)
+    z = qformer(qt, x, W, prefix + ".audio_Qformer.bert", cfg, emulate)[:, :cfg.num_query_token]
+    z = z.reshape(b, t * cfg.num_query_token, -1)
+    y = _r(_gelu(linear(z, W, prefix + ".audio_proj.0", None)), emulate)
+    return linear(y, W, prefix + ".audio_proj.2", emulate)
+
+
+# =====================================================================================
+# B.6 BEATs        reference models/beats/BEATs.py:134-182, backbone.py
+# =====================================================================================
+
+@dataclass
+class BeatsConfig:
+    input_patch_size: int = 16
+    embed_dim: int = 512
+    encoder_embed_dim: int = 768
+    encoder_ffn_embed_dim: int = 3072
+    encoder_attention_heads: int = 12
+    encoder_layers: int = 12
+    conv_pos: int = 128
+    conv_pos_groups: int = 16
+    num_buckets: int = 320
+    max_distance: int = 800
+    deep_norm: bool = True
+    gru_rel_pos: bool = True
+    conv_bias: bool = False
+    layer_norm_eps: float = 1e-5
+
+
+def rel_pos_bucket(qlen: int, klen: int, num_buckets: int, max_distance: int) -> Tensor:
+    """backbone.py:392-430 (bidirectional T5 buckets): int64 [qlen,klen]."""
+    ctx = torch.arange(qlen, dtype=torch.long)[:, None]
+    mem = torch.arange(klen, dtype=torch.long)[None, :]
+    rel = mem - ctx
+    nb = num_buckets // 2
+    out = (rel > 0).to(torch.long) * nb
+    rel = rel.abs()
+    max_exact = nb // 2
+    is_small = rel < max_exact
+    large = max_exact + (torch.log(rel.float() / max_exact) / math.log(max_distance / max_exact)
+                         * (nb - max_exact)).to(torch.long)
+    large = torch.min(large, torch.full_like(large, nb - 1))
+    return out + torch.where(is_small, rel, large)
+
+
+def beats(fbank: Tensor, W: WDict, cfg: BeatsConfig, prefix: str = "model.audio_encoder.audio_encoder",
+          emulate=None) -> Tensor:
+    """BEATs.extract_features(feature_only=True) with an all-False padding mask: [B,L,128] -> [B,n,768]."""
+    B = fbank.shape[0]
+    P = cfg.input_patch_size
+    E = cfg.encoder_embed_dim
+    H = cfg.encoder_attention_heads
+    d = E // H
+    x = F.conv2d(fbank.float()[:, None], W[prefix + ".patch_embedding.weight"],
+                 W.get(prefix + ".patch_embedding.bias"), stride=P)                     # [B,512,L/16,8]
+    x = _r(x.reshape(B, x.shape[1], -1).transpose(1, 2), emulate)                       # time-major tokens
+    x = layernorm(x, W, prefix + ".layer_norm", cfg.layer_norm_eps, emulate)
+    if (prefix + ".post_extract_proj.weight") in W:
+        x = linear(x, W, prefix + ".post_extract_proj", emulate)
+    n = x.shape[1]
+    e = prefix + ".encoder"
+    # pos_conv: weight-normed grouped Conv1d + SamePad + GELU (backbone.py:33-46,114-116)
+    g_, v_ = W[e + ".pos_conv.0.weight_g"].float(), W[e + ".pos_conv.0.weight_v"].float()
+    wn = g_ * v_ / v_.norm(p=2, dim=(0, 1), keepdim=True)                               # weight_norm dim=2
+    pc = F.conv1d(x.transpose(1, 2), wn, W[e + ".pos_conv.0.bias"].float(), padding=cfg.conv_pos // 2,
+                  groups=cfg.conv_pos_groups)
+    if cfg.conv_pos % 2 == 0:
+        pc = pc[:, :, :-1]
+    pc = _gelu(pc).transpose(1, 2)
+    x = layernorm(x + pc, W, e + ".layer_norm", cfg.layer_norm_eps, emulate)            # post-LN variant :118-119
+    alpha = math.pow(2 * cfg.encoder_layers, 0.25) if cfg.deep_norm else 1.0
+    buckets = rel_pos_bucket(n, n, cfg.num_buckets, cfg.max_distance)
+    table = W[e + ".layers.0.self_attn.relative_attention_bias.weight"].float()          # shared (:78-81)
+    pos_bias = table[buckets].permute(2, 0, 1)                                           # [H,n,n]
+    scaling = d ** -0.5
+    for i in range(cfg.encoder_layers):
+        p = f"{e}.layers.{i}"
+        q0 = linear(x, W, p + ".self_attn.q_proj", emulate)                             # un-scaled projection
+        k = linear(x, W, p + ".self_attn.k_proj", emulate)
+        v = linear(x, W, p + ".self_attn.v_proj", emulate)
+        bias = pos_bias[None]
+        if cfg.gru_rel_pos:                                                              # :650-662
+            qh = q0.view(B, n, H, d).transpose(1, 2)                                     # [B,H,n,d]
+            gl = F.linear(qh, W[p + ".self_attn.grep_linear.weight"].float(), W[p + ".self_attn.grep_linear.bias"].float())
+            gsum = torch.sigmoid(gl.view(B, H, n, 2, 4).sum(-1))
+            ga, gb = gsum[..., 0:1], gsum[..., 1:2]
+            gate = ga * (gb * W[p + ".self_attn.grep_a"].float().view(1, H, 1, 1) - 1.0) + 2.0
+            bias = gate * pos_bias[None]
+        # (q*scaling/32 k^T - max)*32 + bias == q k^T scaling + bias up to a per-row shift (:513-515,623-667)
+        o = _mha(q0, k, v, H, scaling, bias, emulate)
+        a = linear(o, W, p + ".self_attn.out_proj", None)
+        x = layernorm(x * alpha + a, W, p + ".self_attn_layer_norm", cfg.layer_norm_eps, emulate)
+        f = _r(_gelu(linear(x, W, p + ".fc1", None)), emulate)
+        f = linear(f, W, p + ".fc2", None)
+        x = layernorm(x * alpha + f, W, p + ".final_layer_norm", cfg.layer_norm_eps, emulate)
+    return x
+
+
+def audio_encoder(audio: Tensor, W: WDict, cfg: BeatsConfig, emulate=None,
+                  prefix: str = "model.audio_encoder.audio_encoder") -> Tensor:
+    """AudioEncoder.forward 4-D branch (multimodal_encoder.py:174-186): [b,t,L,128] -> [b,t,n,768]."""
+    b, t, L, m = audio.shape
+    y = beats(audio.reshape(b * t, L, m), W, cfg, prefix, emulate)
+    return y.reshape(b, t, y.shape[1], y.shape[2])
+
+
+# =====================================================================================
+# B.7 prepare_multimodal_inputs + generate      reference models/unified_arch.py:217-406
+# =====================================================================================
+
+SPECIAL_TOKENS = ['<image>', '<image_start>', '<image_end>', '<video>', '<video_start>', '<video_end>',
+                  '<audio>', '<audio_start>', '<audio_end>', '<mask_start>', '<mask_end>']
+
+
+def special_token_table(vocab_nums: int, mask_token_nums: int = 6) -> Dict[str, int]:
+    """initialize_MM_tokenizer (unified_arch.py:409-459): ids vocab_nums.. in fixed order."""
+    toks = SPECIAL_TOKENS + [f'<mask_{i}>' for i in range(mask_token_nums)]
+    return {t: vocab_nums + i for i, t in enumerate(toks)}
+
+
+@dataclass
+class CrabConfig:
+    decoder: DecoderConfig
+    clip: Optional[ClipConfig] = None
+    beats: Optional[BeatsConfig] = None
+    qformer: QFormerConfig = field(default_factory=QFormerConfig)
+    base_vocab: int = 32000            # len(tokenizer) before the 17 added tokens
+    pad_token_id: int = 2              # tokenizer.pad_token = eos (quick_start.py:501-502)
+    image_token_nums: int = 256
+
+
+def encode_video(video: Tensor, W: WDict, cfg: CrabConfig, emulate=None, all_levels: bool = False):
+    """encode_video live branch (unified_arch.py:144-149).  The reference runs the VLProjector on all
+    three feature levels and consumes only [-1] (:290); all_levels=False skips the dead two."""
+    feats = visual_encoder(video, W, cfg.clip, emulate)
+    levels = feats if all_levels else feats[-1:]
+    q = [vl_projector(f, W, cfg.qformer, cfg.image_token_nums, emulate=emulate) for f in levels]
+    return feats, q
+
+
+def encode_audio(audio: Tensor, W: WDict, cfg: CrabConfig, emulate=None) -> Tensor:
+    return al_projector(audio_encoder(audio, W, cfg.beats, emulate), W, cfg.qformer, emulate=emulate)
+
+
+def prepare_multimodal_inputs(batch_input_ids: Sequence[Tensor], batch_X_modals: Sequence[Dict[str, Tensor]],
+                              W: WDict, cfg: CrabConfig, emulate=None) -> Dict[str, Tensor]:
+    """unified_arch.py:217-406 (NTP branch: no multi-scale features): splice, left-pad, positions."""
+    tab = special_token_table(cfg.base_vocab)
+    keys = {tab['<image>']: '<image>', tab['<video>']: '<video>', tab['<audio>']: '<audio>'}
+    emb = W["model.embed_tokens.weight"].float()
+    seqs = []
+    for ids, mod in zip(batch_input_ids, batch_X_modals):
+        segs, pre = [], 0
+        for pos in [i for i, t in enumerate(ids.tolist()) if t in keys]:
+            segs.append(emb[ids[pre:pos]])
+            key = keys[int(ids[pos])]
+            if key == '<audio>':
+                f = encode_audio(mod[key][None], W, cfg, emulate)[0]
+            else:
+                f = encode_video(mod[key][None], W, cfg, emulate)[1][-1][0]
+            segs.append(f)
+            pre = pos + 1
+        segs.append(emb[ids[pre:]])
+        seqs.append(torch.cat(segs, dim=0))
+    L = max(s.shape[0] for s in seqs)
+    pad_e = emb[cfg.pad_token_id]
+    embeds, mask = [], []
+    for s in seqs:
+        n = L - s.shape[0]
+        embeds.append(torch.cat([pad_e[None].expand(n, -1), s], dim=0))             # left pad :344-348
+        mask.append(torch.cat([torch.zeros(n, dtype=torch.int32), torch.ones(s.shape[0], dtype=torch.int32)]))
+    mask = torch.stack(mask)
+    pos = torch.cumsum(mask, dim=-1) - 1
+    pos[pos == -1] = 0                                                               # :372-373
+    return {"inputs_embeds": _r(torch.stack(embeds), emulate), "attention_mask": mask, "position_ids": pos}
+
+
+def generate(batch_input_ids, batch_X_modals, W: WDict, cfg: CrabConfig, max_new_tokens: int,
+             eos_token_id: Optional[int] = None, min_new_tokens: int = 0, emulate=None):
+    """UnifiedForCausalLM.generate (unified_llama.py:244-267) with greedy decoding forced.
+    attention_mask / position_ids are NOT forwarded by the reference (:261-267), reproduced here."""
+    inp = prepare_multimodal_inputs(batch_input_ids, batch_X_modals, W, cfg, emulate)
+    return greedy_generate(inp["inputs_embeds"], W, cfg.decoder, max_new_tokens, eos_token_id,
+                           cfg.pad_token_id, min_new_tokens, emulate)

@@ -1,0 +1,121 @@
+"""Pins oracle/crab_oracle.py against the reference-generated fixtures (CPU, no GPU needed).
+
+Tolerance: fp32 vs fp32, different op order/library versions -> 2e-4 absolute on O(1) activations
+(treat fp32 oracle outputs as truth to ~1e-5 relative)."""
+import torch
+
+from oracle import crab_oracle as O
+from tests.util import load_fixture, weights_from_table, strip
+
+TOL = 2e-4
+
+
+def _close(a, b, tol=TOL):
+    d = (a.float() - b.float()).abs().max().item()
+    assert d <= tol, f"max abs diff {d}"
+
+
+def test_hyperlora_linear():
+    meta, A = load_fixture("hyperlora_linear")
+    W = weights_from_table(meta)
+    y = O.hyperlora_linear(A["x"], W, "lin", scaling=meta["lora_alpha"] / meta["r"], lora_nums=meta["lora_nums"])
+    _close(y, A["y"], 1e-5)
+
+
+def test_beats_buckets_integer_exact():
+    meta, A = load_fixture("beats_buckets")
+    for n in (48, 96):
+        b = O.rel_pos_bucket(n, n, meta["num_buckets"], meta["max_distance"])
+        assert torch.equal(b.to(torch.int32), A[f"b{n}"])
+
+
+def _beats_cfg(c):
+    keys = O.BeatsConfig.__dataclass_fields__.keys()
+    return O.BeatsConfig(**{k: v for k, v in c.items() if k in keys})
+
+
+def test_beats_tiny():
+    meta, A = load_fixture("beats_tiny")
+    W = weights_from_table(meta)
+    cfg = _beats_cfg(meta["cfg"])
+    for L in (98, 198):
+        y = O.beats(A[f"x{L}"], W, cfg)
+        assert y.shape == A[f"y{L}"].shape
+        _close(y, A[f"y{L}"])
+
+
+def test_clip_tiny():
+    from crab_amd import synth
+    meta, A = load_fixture("clip_tiny")
+    W = weights_from_table(meta)
+    cfg = O.ClipConfig(**meta["cfg"], select_layers=tuple(meta["select"]))
+    video = synth.synth_video(meta["t_v"], seed=meta["seed"], clip=meta["clip"])[None]
+    feats = O.visual_encoder(video, W, cfg)
+    for i in range(3):
+        _close(feats[i], A[f"f{i}"], 5e-4)
+
+
+def test_projectors_tiny():
+    meta, A = load_fixture("projectors_tiny")
+    W = weights_from_table(meta)
+    qf = O.QFormerConfig(hidden_size=meta["qf"]["hidden"], num_attention_heads=meta["qf"]["heads"],
+                         intermediate_size=meta["qf"]["inter"])
+    _close(O.vl_projector(A["vfeat"], W, qf), A["vout"])
+    _close(O.al_projector(A["afeat"], W, qf), A["aout"])
+
+
+def _full_cfg(meta):
+    dec = O.DecoderConfig(**meta["dec"])
+    clip = O.ClipConfig(**meta["clip"], select_layers=tuple(meta["select"]))
+    qf = O.QFormerConfig(hidden_size=meta["qf"]["hidden"], num_attention_heads=meta["qf"]["heads"],
+                         intermediate_size=meta["qf"]["inter"])
+    return O.CrabConfig(decoder=dec, clip=clip, beats=_beats_cfg(meta["beats"]), qformer=qf,
+                        base_vocab=meta["base_vocab"], pad_token_id=meta["pad_token_id"])
+
+
+def _full_inputs(meta):
+    from crab_amd import synth
+    p = meta["prompts"]
+    mods = [{'<video>': synth.synth_video(p["t_v"], seed=meta["seed"], clip=c),
+             '<audio>': synth.synth_audio(p["t_a"], p["l_a"], seed=meta["seed"], clip=c)}
+            for c in (p["clip0"], p["clip1"])]
+    return mods
+
+
+def test_special_token_table():
+    meta, A = load_fixture("full_tiny_llama")
+    assert O.special_token_table(meta["base_vocab"]) == meta["special"]
+
+
+def test_full_tiny_llama_prepare_and_generate():
+    meta, A = load_fixture("full_tiny_llama")
+    W = O.strip_peft_prefix(weights_from_table(meta))
+    cfg = _full_cfg(meta)
+    mods = _full_inputs(meta)
+    inp1 = O.prepare_multimodal_inputs([A["ids0"]], [mods[0]], W, cfg)
+    _close(inp1["inputs_embeds"], A["embeds_bs1"], 5e-4)
+    inp2 = O.prepare_multimodal_inputs([A["ids0"], A["ids1"]], mods, W, cfg)
+    _close(inp2["inputs_embeds"], A["embeds_bs2"], 5e-4)
+    assert torch.equal(inp2["position_ids"].long(), A["pos_bs2"].long())
+    assert torch.equal(inp2["attention_mask"].long(), A["mask_bs2"].long())
+    # prefill, all rows
+    logits, hn, _ = O.decoder_forward(A["embeds_bs1"], W, cfg.decoder)
+    _close(logits, A["prefill_logits_bs1"], 5e-4)
+    _close(hn, A["prefill_hidden_bs1"], 5e-4)
+    # greedy ids + per-step logits, bs=1 and left-padded bs=2 (pads attended, appendix A.1)
+    n = meta["new_tokens"]
+    ids, sl = O.generate([A["ids0"]], [mods[0]], W, cfg, n)
+    assert torch.equal(ids, A["ids_bs1"])
+    _close(sl, A["logits_bs1"], 1e-3)
+    ids, sl = O.generate([A["ids0"], A["ids1"]], mods, W, cfg, n)
+    assert torch.equal(ids, A["ids_bs2"])
+    _close(sl, A["logits_bs2"], 1e-3)
+
+
+def test_decoder_tiny_qwen2_gqa_bias():
+    meta, A = load_fixture("decoder_tiny_qwen2")
+    W = O.strip_peft_prefix(weights_from_table(meta))
+    dec = O.DecoderConfig(**meta["dec"])
+    ids, sl = O.greedy_generate(A["embeds"], W, dec, meta["new_tokens"], eos_token_id=None, pad_token_id=2)
+    assert torch.equal(ids, A["ids"])
+    _close(sl, A["logits"], 1e-3)
