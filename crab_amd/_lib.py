@@ -1,0 +1,117 @@
+"""ctypes loader for libcrab_hip.so (the C-ABI in include/crab_hip.h).
+
+The product path has no CPU or eager-PyTorch fallback: if the HIP library is missing or an entry point
+fails, a CrabHipError is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcrab_hip.so")
+
+
+class CrabHipError(RuntimeError):
+    pass
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p), ("bias", C.c_void_p), ("R", C.c_void_p),
+        ("A2", C.c_void_p), ("B2", C.c_void_p),
+        ("lda", C.c_int64), ("ldb", C.c_int64), ("ldc", C.c_int64), ("ldr", C.c_int64), ("lda2", C.c_int64),
+        ("ldb2", C.c_int64),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("K2", C.c_int32),
+        ("act", C.c_int32), ("c_fp32", C.c_int32), ("res_scale", C.c_float),
+        ("batch", C.c_int32), ("nb0", C.c_int32),
+        ("sA0", C.c_int64), ("sA1", C.c_int64), ("sB0", C.c_int64), ("sB1", C.c_int64), ("sC0", C.c_int64),
+        ("sC1", C.c_int64), ("sR0", C.c_int64), ("sR1", C.c_int64), ("sBias0", C.c_int64), ("sBias1", C.c_int64),
+    ]
+
+
+class AttnDesc(C.Structure):
+    _fields_ = [
+        ("q", C.c_void_p), ("k", C.c_void_p), ("vt", C.c_void_p), ("o", C.c_void_p),
+        ("q_bs", C.c_int64), ("q_hs", C.c_int64), ("q_ss", C.c_int64),
+        ("k_bs", C.c_int64), ("k_hs", C.c_int64), ("k_ss", C.c_int64),
+        ("vt_bs", C.c_int64), ("vt_hs", C.c_int64), ("vt_ds", C.c_int64),
+        ("o_bs", C.c_int64), ("o_ss", C.c_int64),
+        ("bias", C.c_void_p), ("gate", C.c_void_p),
+        ("B", C.c_int32), ("H", C.c_int32), ("Hk", C.c_int32), ("Sq", C.c_int32), ("Skv", C.c_int32),
+        ("head_dim", C.c_int32), ("causal", C.c_int32), ("scale", C.c_float),
+    ]
+
+
+# every symbol include/crab_hip.h declares: name -> (restype, argtypes)
+_vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+SYMBOLS = {
+    "crab_abi_version": (_i, []),
+    "crab_ctx_create": (_i, [_i, C.POINTER(_vp)]),
+    "crab_ctx_destroy": (None, [_vp]),
+    "crab_last_error": (C.c_char_p, [_vp]),
+    "crab_sync": (_i, [_vp, _vp]),
+    "crab_gemm_bf16": (_i, [_vp, _vp, C.POINTER(GemmDesc)]),
+    "crab_hyperlora_mix": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _i64, _i, _i, _i, _i, _i, _f]),
+    "crab_rmsnorm": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _i, _i, _f]),
+    "crab_layernorm": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _f]),
+    "crab_embedding": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i]),
+    "crab_rope_table": (_i, [_vp, _vp, _vp, _i, _i, _f]),
+    "crab_qkv_rope_split": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "crab_attn_fwd": (_i, [_vp, _vp, C.POINTER(AttnDesc)]),
+    "crab_attn_decode": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _vp, _f]),
+    "crab_swiglu": (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _i, _i]),
+    "crab_argmax": (_i, [_vp, _vp, _vp, _i64, _vp, _i, _i, _i]),
+    "crab_im2col_patch": (_i, [_vp, _vp, _vp, _i, _vp, _i64, _i, _i, _i, _i, _i]),
+    "crab_clip_embed_ln": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f]),
+    "crab_beats_posconv_pad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
+    "crab_beats_relpos_bias": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i]),
+    "crab_beats_gru_gate": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i, _i, _i, _i]),
+    "crab_copy_rows": (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _i, _i]),
+    "crab_cast_f32_bf16": (_i, [_vp, _vp, _vp, _vp, _i64]),
+}
+
+_lib = None
+_lock = threading.Lock()
+_ctxs = {}
+
+
+def load() -> C.CDLL:
+    """dlopen the in-tree library and bind every declared symbol.  Raises CrabHipError when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.isfile(LIB_PATH):
+            raise CrabHipError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(crab_amd/csrc/build.sh). There is no fallback path.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name, None)
+            if fn is None:
+                raise CrabHipError(f"libcrab_hip.so does not export {name}")
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def ctx(device: int = 0) -> int:
+    """One crab_ctx per device per process."""
+    lib = load()
+    if device not in _ctxs:
+        h = C.c_void_p()
+        rc = lib.crab_ctx_create(int(device), C.byref(h))
+        if rc != 0:
+            raise CrabHipError(f"crab_ctx_create(device={device}) failed with {rc} (no MI355X visible?)")
+        _ctxs[device] = h
+    return _ctxs[device]
+
+
+def check(rc: int, device: int = 0):
+    if rc != 0:
+        msg = load().crab_last_error(_ctxs.get(device))
+        raise CrabHipError(f"libcrab_hip error {rc}: {msg.decode() if msg else '?'}")

@@ -1,0 +1,320 @@
+// Attention kernels for gfx950.
+//
+// attn_fwd_kernel: flash-style forward, one 256-thread block per (64 query rows, head, batch); each of the
+// 4 waves owns 16 query rows.  K tiles [64 keys][HD] (XOR-swizzled) and V^T tiles [HD][64 keys] (row padded
+// to 68) are staged in LDS; S^T = K.Q^T and O^T = V^T.P^T run on v_mfma_f32_16x16x32_bf16, so that
+//   * each lane's 16 scores of a 64-key tile all belong to ONE query row (col = lane&15): the online
+//     softmax needs two cross-lane shuffles (xor 16, 32) per tile instead of a 16-lane reduction,
+//   * the exponentiated scores already sit in the register layout the P^T (B-operand) fragment needs, and
+//   * the output accumulator holds 4 consecutive head-dim elements of one query row per lane (8-byte stores).
+// The contraction index of the second MFMA is mapped as e -> key 16*(2kk + (e>>2)) + 4*(lane>>4) + (e&3); the
+// V^T fragment is gathered with the same map (two ds_read_b64), so no transpose or LDS round trip of P.
+//
+// attn_decode_kernel: one query row per (b,h) streaming the KV cache once (HBM-bound), 16-lane groups
+// per key row, fp32 online softmax, cross-group merge through LDS.
+#include "common.h"
+#include "crab_internal.h"
+#include <math.h>
+
+namespace {
+
+struct AttnP {
+    const bf16_t* q; const bf16_t* k; const bf16_t* vt; bf16_t* o;
+    long q_bs, q_hs, q_ss, k_bs, k_hs, k_ss, vt_bs, vt_hs, vt_ds, o_bs, o_ss;
+    const float* bias; const float* gate;
+    int B, H, Hk, Sq, Skv, causal;
+    float scale;
+};
+
+constexpr int KT = 64;          // keys per tile
+constexpr int VT_LD = 68;       // padded V^T row (bf16 elements): 136 B, conflict-free ds_read_b64 gathers
+
+template <int HD>
+__device__ __forceinline__ int k_swz(int row, int chunk) {
+    // 16-byte chunk swizzle; HD=128: 16 chunks per 256-B row; HD=64: 8 chunks per 128-B row
+    return HD == 128 ? (chunk ^ (row & 15)) : (chunk ^ ((row >> 1) & 7));
+}
+
+template <int HD, bool CAUSAL, bool BIAS>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
+    constexpr int CPR = HD / 8;             // 16-byte chunks per K row
+    constexpr int KS = HD / 32;             // MFMA k-steps over the head dim
+    constexpr int DT = HD / 16;             // output d tiles
+    __shared__ __attribute__((aligned(16))) bf16_t lk[KT * HD];
+    __shared__ __attribute__((aligned(16))) bf16_t lv[HD * VT_LD];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int hk = h / (p.H / p.Hk);
+    const int q0 = blockIdx.x * 64;
+    const int qrow = q0 + wave * 16 + fr;                       // this lane's query row
+    const int qload = qrow < p.Sq ? qrow : p.Sq - 1;
+    const int koff = p.Skv - p.Sq;                              // causal offset (0 for prefill)
+
+    const bf16_t* qp = p.q + (long)b * p.q_bs + (long)h * p.q_hs + (long)qload * p.q_ss;
+    const bf16_t* kp = p.k + (long)b * p.k_bs + (long)hk * p.k_hs;
+    const bf16_t* vp = p.vt + (long)b * p.vt_bs + (long)hk * p.vt_hs;
+
+    bf16x8_t qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 32 + fg * 8);
+
+    f32x4_t oacc[DT];
+#pragma unroll
+    for (int i = 0; i < DT; ++i) oacc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    float m_run = -1e30f, l_run = 0.f;
+
+    float gate = 1.f;
+    const float* biasrow = nullptr;
+    if (BIAS) {
+        if (p.gate) gate = p.gate[((long)b * p.H + h) * p.Sq + qload];
+        biasrow = p.bias + ((long)h * p.Sq + qload) * p.Skv;
+    }
+
+    int kv_end = p.Skv;
+    if (CAUSAL) {
+        int last = q0 + 63 + koff;                               // last key visible to this block
+        if (last + 1 < kv_end) kv_end = last + 1;
+    }
+    const int ntiles = (kv_end + KT - 1) / KT;
+    const u32x4 z4 = {0u, 0u, 0u, 0u};
+    const u32x2 z2 = {0u, 0u};
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int kv0 = t * KT;
+        __syncthreads();                                         // previous tile fully consumed
+        // ---- stage K tile: KT rows x CPR chunks
+#pragma unroll
+        for (int i = 0; i < (KT * CPR) / 256; ++i) {
+            int idx = tid + i * 256;
+            int row = idx / CPR, c = idx % CPR;
+            int kr = kv0 + row;
+            u32x4 v = kr < p.Skv ? *reinterpret_cast<const u32x4*>(kp + (long)kr * p.k_ss + c * 8) : z4;
+            *reinterpret_cast<u32x4*>(lk + row * HD + (k_swz<HD>(row, c) << 3)) = v;
+        }
+        // ---- stage V^T tile: HD rows x 8 chunks (64 keys); zero beyond Skv so that 0 * pad stays 0
+#pragma unroll
+        for (int i = 0; i < (HD * 8) / 256; ++i) {
+            int idx = tid + i * 256;
+            int row = idx >> 3, c = idx & 7;
+            int kc = kv0 + c * 8;
+            u32x4 v = z4;
+            if (kc + 8 <= p.Skv) {
+                v = *reinterpret_cast<const u32x4*>(vp + (long)row * p.vt_ds + kc);
+            } else if (kc < p.Skv) {
+                const bf16_t* s = vp + (long)row * p.vt_ds + kc;
+                uint32_t w[4] = {0u, 0u, 0u, 0u};
+                for (int e = 0; e < 8 && kc + e < p.Skv; ++e) w[e >> 1] |= ((uint32_t)s[e]) << ((e & 1) * 16);
+                v = u32x4{w[0], w[1], w[2], w[3]};
+            }
+            bf16_t* d = lv + row * VT_LD + c * 8;
+            *reinterpret_cast<u32x2*>(d) = u32x2{v[0], v[1]};
+            *reinterpret_cast<u32x2*>(d + 4) = u32x2{v[2], v[3]};
+        }
+        __syncthreads();
+
+        // ---- S^T = K . Q^T : 4 key sub-tiles of 16
+        f32x4_t s[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                int row = j * 16 + fr;
+                int chunk = ks * 4 + fg;
+                bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(lk + row * HD + (k_swz<HD>(row, chunk) << 3));
+                s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[j], 0, 0, 0);
+            }
+        }
+        // ---- scale, bias, mask; lane holds keys kv0 + 16j + 4fg + r for its query row
+        float tmax = -1e30f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int kv = kv0 + j * 16 + fg * 4 + r;
+                float v = s[j][r] * p.scale;
+                if (BIAS) { if (kv < p.Skv) v += gate * biasrow[kv]; }
+                bool ok = kv < p.Skv;
+                if (CAUSAL) ok = ok && (kv <= qrow + koff);
+                v = ok ? v : -INFINITY;
+                s[j][r] = v;
+                tmax = fmaxf(tmax, v);
+            }
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m_run, tmax);
+        const float alpha = __expf(m_run - m_new);
+        m_run = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float e = __expf(s[j][r] - m_new);
+                s[j][r] = e;
+                psum += e;
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int i = 0; i < DT; ++i) oacc[i] *= alpha;
+
+        // ---- O^T += V^T . P^T : two 32-key contraction chunks
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            union { bf16x8_t v; uint32_t w[4]; } pf;
+            pf.w[0] = pack_bf2(s[2 * kk][0], s[2 * kk][1]);
+            pf.w[1] = pack_bf2(s[2 * kk][2], s[2 * kk][3]);
+            pf.w[2] = pack_bf2(s[2 * kk + 1][0], s[2 * kk + 1][1]);
+            pf.w[3] = pack_bf2(s[2 * kk + 1][2], s[2 * kk + 1][3]);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const bf16_t* vr = lv + (dt * 16 + fr) * VT_LD + kk * 32 + fg * 4;
+                union { bf16x8_t v; u32x2 h[2]; } vf;
+                vf.h[0] = *reinterpret_cast<const u32x2*>(vr);
+                vf.h[1] = *reinterpret_cast<const u32x2*>(vr + 16);
+                oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf.v, oacc[dt], 0, 0, 0);
+            }
+        }
+    }
+    // ---- finish: total row sum over the 4 lane groups, normalise, store 4 consecutive d per lane
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_run;
+    if (qrow < p.Sq) {
+        bf16_t* op = p.o + (long)b * p.o_bs + (long)qrow * p.o_ss + (long)h * HD;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            u32x2 w;
+            w[0] = pack_bf2(oacc[dt][0] * inv, oacc[dt][1] * inv);
+            w[1] = pack_bf2(oacc[dt][2] * inv, oacc[dt][3] * inv);
+            *reinterpret_cast<u32x2*>(op + dt * 16 + fg * 4) = w;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- decode
+// block = 256 threads = 16 groups of 16 lanes; group gidx handles keys gidx, gidx+16, ...; each lane owns
+// EPL = HD/16 consecutive head-dim elements.
+template <int HD>
+__global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restrict__ q, long ldq, const bf16_t* __restrict__ kc,
+                                                          const bf16_t* __restrict__ vc, bf16_t* __restrict__ o, long ldo, int H, int Hk,
+                                                          int Tmax, int ctx_host, const int* __restrict__ ctx_dev, float scale) {
+    constexpr int EPL = HD / 16;
+    __shared__ float sm[16], sl[16];
+    __shared__ float so[16][HD];
+    const int tid = threadIdx.x;
+    const int grp = tid >> 4, sub = tid & 15;
+    const int b = blockIdx.y, h = blockIdx.x;
+    const int hk = h / (H / Hk);
+    const int ctx = ctx_host + (ctx_dev ? ctx_dev[0] : 0);
+    const bf16_t* qp = q + (long)b * ldq + (long)h * HD + sub * EPL;
+    float qv[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) qv[e] = bf2f(qp[e]) * scale;
+    const bf16_t* kb = kc + ((long)b * Hk + hk) * (long)Tmax * HD + sub * EPL;
+    const bf16_t* vb = vc + ((long)b * Hk + hk) * (long)Tmax * HD + sub * EPL;
+    float m = -1e30f, l = 0.f, acc[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
+
+    for (int j = grp; j < ctx; j += 16) {
+        float kx[EPL], vx[EPL];
+        if (EPL == 8) {
+            u32x4 kw = *reinterpret_cast<const u32x4*>(kb + (long)j * HD);
+            u32x4 vw = *reinterpret_cast<const u32x4*>(vb + (long)j * HD);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { kx[2 * e] = lo_bf(kw[e]); kx[2 * e + 1] = hi_bf(kw[e]); vx[2 * e] = lo_bf(vw[e]); vx[2 * e + 1] = hi_bf(vw[e]); }
+        } else {
+            u32x2 kw = *reinterpret_cast<const u32x2*>(kb + (long)j * HD);
+            u32x2 vw = *reinterpret_cast<const u32x2*>(vb + (long)j * HD);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) { kx[2 * e] = lo_bf(kw[e]); kx[2 * e + 1] = hi_bf(kw[e]); vx[2 * e] = lo_bf(vw[e]); vx[2 * e + 1] = hi_bf(vw[e]); }
+        }
+        float sdot = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) sdot += qv[e] * kx[e];
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) sdot += __shfl_xor(sdot, off, 64);
+        float mn = fmaxf(m, sdot);
+        float a = __expf(m - mn), pw = __expf(sdot - mn);
+        l = l * a + pw;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) acc[e] = acc[e] * a + pw * vx[e];
+        m = mn;
+    }
+    if (sub == 0) { sm[grp] = m; sl[grp] = l; }
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) so[grp][sub * EPL + e] = acc[e];
+    __syncthreads();
+    if (tid < HD) {
+        float M = -1e30f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) M = fmaxf(M, sm[g]);
+        float L = 0.f, O = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            float w = __expf(sm[g] - M);
+            L += sl[g] * w;
+            O += so[g][tid] * w;
+        }
+        o[(long)b * ldo + (long)h * HD + tid] = f2bf(O / L);
+    }
+}
+
+}  // namespace
+
+extern "C" int crab_attn_fwd(crab_ctx* ctx, void* stream, const crab_attn_desc* d) {
+    if (!ctx) return CRAB_E_INVALID;
+    if (!d || !d->q || !d->k || !d->vt || !d->o) return crab_fail(ctx, CRAB_E_INVALID, "attn_fwd: null operand");
+    if (d->B <= 0 || d->H <= 0 || d->Hk <= 0 || d->H % d->Hk || d->Sq <= 0 || d->Skv <= 0)
+        return crab_fail(ctx, CRAB_E_INVALID, "attn_fwd: bad shape");
+    if (d->head_dim != 64 && d->head_dim != 128) return crab_fail(ctx, CRAB_E_UNSUPPORTED, "attn_fwd: head_dim must be 64 or 128");
+    if ((d->q_ss & 7) || (d->q_hs & 7) || (d->q_bs & 7) || (d->k_ss & 7) || (d->k_hs & 7) || (d->k_bs & 7) || (d->vt_ds & 7) ||
+        (d->vt_hs & 7) || (d->vt_bs & 7) || (d->o_ss & 3) || (d->o_bs & 3))
+        return crab_fail(ctx, CRAB_E_INVALID, "attn_fwd: strides must keep 16-byte alignment");
+    if (((uintptr_t)d->q & 15) || ((uintptr_t)d->k & 15) || ((uintptr_t)d->vt & 15) || ((uintptr_t)d->o & 7))
+        return crab_fail(ctx, CRAB_E_INVALID, "attn_fwd: pointer alignment");
+    if (d->causal && d->Skv < d->Sq) return crab_fail(ctx, CRAB_E_INVALID, "attn_fwd: causal needs Skv >= Sq");
+    if ((d->bias == nullptr) && d->gate) return crab_fail(ctx, CRAB_E_INVALID, "attn_fwd: gate without bias");
+    AttnP p;
+    p.q = (const bf16_t*)d->q; p.k = (const bf16_t*)d->k; p.vt = (const bf16_t*)d->vt; p.o = (bf16_t*)d->o;
+    p.q_bs = d->q_bs; p.q_hs = d->q_hs; p.q_ss = d->q_ss; p.k_bs = d->k_bs; p.k_hs = d->k_hs; p.k_ss = d->k_ss;
+    p.vt_bs = d->vt_bs; p.vt_hs = d->vt_hs; p.vt_ds = d->vt_ds; p.o_bs = d->o_bs; p.o_ss = d->o_ss;
+    p.bias = d->bias; p.gate = d->gate; p.B = d->B; p.H = d->H; p.Hk = d->Hk; p.Sq = d->Sq; p.Skv = d->Skv;
+    p.causal = d->causal; p.scale = d->scale;
+    dim3 grid((d->Sq + 63) / 64, d->H, d->B), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    const bool hb = d->bias != nullptr;
+    if (d->causal && hb) return crab_fail(ctx, CRAB_E_UNSUPPORTED, "attn_fwd: causal + bias not instantiated");
+    if (d->head_dim == 128) {
+        if (d->causal) hipLaunchKernelGGL((attn_fwd_kernel<128, true, false>), grid, block, 0, s, p);
+        else if (hb) hipLaunchKernelGGL((attn_fwd_kernel<128, false, true>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((attn_fwd_kernel<128, false, false>), grid, block, 0, s, p);
+    } else {
+        if (d->causal) hipLaunchKernelGGL((attn_fwd_kernel<64, true, false>), grid, block, 0, s, p);
+        else if (hb) hipLaunchKernelGGL((attn_fwd_kernel<64, false, true>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((attn_fwd_kernel<64, false, false>), grid, block, 0, s, p);
+    }
+    return crab_check_launch(ctx, "attn_fwd");
+}
+
+extern "C" int crab_attn_decode(crab_ctx* ctx, void* stream, const void* q, int64_t ldq, const void* k_cache, const void* v_cache,
+                                void* o, int64_t ldo, int B, int H, int Hk, int d, int Tmax, int ctx_len_host, const int32_t* ctx_dev,
+                                float scale) {
+    if (!ctx) return CRAB_E_INVALID;
+    if (!q || !k_cache || !v_cache || !o || B <= 0 || H <= 0 || Hk <= 0 || H % Hk) return crab_fail(ctx, CRAB_E_INVALID, "attn_decode: bad argument");
+    if (d != 64 && d != 128) return crab_fail(ctx, CRAB_E_UNSUPPORTED, "attn_decode: head_dim must be 64 or 128");
+    if (!ctx_dev && (ctx_len_host <= 0 || ctx_len_host > Tmax)) return crab_fail(ctx, CRAB_E_INVALID, "attn_decode: ctx_len out of range");
+    dim3 grid(H, B), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (d == 128)
+        hipLaunchKernelGGL((attn_decode_kernel<128>), grid, block, 0, s, (const bf16_t*)q, (long)ldq, (const bf16_t*)k_cache,
+                           (const bf16_t*)v_cache, (bf16_t*)o, (long)ldo, H, Hk, Tmax, ctx_len_host, ctx_dev, scale);
+    else
+        hipLaunchKernelGGL((attn_decode_kernel<64>), grid, block, 0, s, (const bf16_t*)q, (long)ldq, (const bf16_t*)k_cache,
+                           (const bf16_t*)v_cache, (bf16_t*)o, (long)ldo, H, Hk, Tmax, ctx_len_host, ctx_dev, scale);
+    return crab_check_launch(ctx, "attn_decode");
+}

@@ -1,0 +1,18 @@
+#!/bin/bash
+# Build libcrab_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU).
+set -e
+cd "$(dirname "$0")"
+OUT=../libcrab_hip.so
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result"
+mkdir -p build
+pids=()
+for f in *.hip; do
+  o=build/${f%.hip}.o
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ common.h -nt "$o" ] || [ crab_internal.h -nt "$o" ] || [ ../../include/crab_hip.h -nt "$o" ]; then
+    /opt/rocm/bin/hipcc $FLAGS -c "$f" -o "$o" &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]}"; do wait "$p"; done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC build/*.o -o "$OUT"
+echo "built $(realpath $OUT)"

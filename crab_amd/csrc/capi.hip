@@ -1,0 +1,32 @@
+// Context management for libcrab_hip.so (see include/crab_hip.h).
+#include "crab_internal.h"
+#include <stdlib.h>
+
+extern "C" {
+
+int crab_abi_version(void) { return 1; }
+
+int crab_ctx_create(int device, crab_ctx** out) {
+    if (!out) return CRAB_E_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return CRAB_E_HIP;
+    crab_ctx* c = (crab_ctx*)calloc(1, sizeof(crab_ctx));
+    if (!c) return CRAB_E_INVALID;
+    c->device = device;
+    c->err[0] = 0;
+    *out = c;
+    return CRAB_OK;
+}
+
+void crab_ctx_destroy(crab_ctx* ctx) { free(ctx); }
+
+const char* crab_last_error(crab_ctx* ctx) { return ctx ? ctx->err : "null context"; }
+
+int crab_sync(crab_ctx* ctx, void* stream) {
+    if (!ctx) return CRAB_E_INVALID;
+    CRAB_HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)stream));
+    return CRAB_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,61 @@
+// Shared device helpers for the Crab gfx950 kernels (bf16 storage, fp32 arithmetic).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;   // raw bfloat16 bits; torch.bfloat16 storage is passed as-is
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;   // MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;    // MFMA 16x16 C/D fragment
+
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;   // 16-byte vector load/store unit
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+// round-to-nearest-even, NaN preserved: identical to torch's float -> bfloat16
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+__device__ __forceinline__ float lo_bf(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float hi_bf(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// activations selectable in GEMM epilogues / elementwise kernels
+enum CrabAct { ACT_NONE = 0, ACT_GELU = 1, ACT_QUICK_GELU = 2, ACT_RELU = 3, ACT_SILU = 4 };
+
+__device__ __forceinline__ float apply_act(float x, int act) {
+    switch (act) {
+        case ACT_GELU: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));   // exact erf GELU
+        case ACT_QUICK_GELU: return x / (1.0f + __expf(-1.702f * x));                // x*sigmoid(1.702x)
+        case ACT_RELU: return fmaxf(x, 0.0f);
+        case ACT_SILU: return x / (1.0f + __expf(-x));
+        default: return x;
+    }
+}
+
+// bijective XCD-aware block remap: consecutive logical ids land on the same XCD (private L2),
+// valid for any grid size (cdna guide 5.5 T1 bijective form).  Placement is a speed hint only.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int NX = 8;
+    int q = nwg / NX, r = nwg % NX;
+    int xcd = bid % NX, idx = bid / NX;
+    int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}

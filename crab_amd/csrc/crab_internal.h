@@ -1,0 +1,36 @@
+// Host-side internals shared by the C-ABI translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/crab_hip.h"
+
+struct crab_ctx {
+    int device;
+    char err[512];
+};
+
+static inline int crab_fail(crab_ctx* ctx, int code, const char* msg) {
+    if (ctx) { strncpy(ctx->err, msg, sizeof(ctx->err) - 1); ctx->err[sizeof(ctx->err) - 1] = 0; }
+    return code;
+}
+
+// Launch-configuration errors surface immediately; asynchronous faults surface at the next call or crab_sync
+// (SURVEY.md 8b "Errors").  hipGetLastError is capture-safe.
+static inline int crab_check_launch(crab_ctx* ctx, const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        if (ctx) snprintf(ctx->err, sizeof(ctx->err), "%s: %s", what, hipGetErrorString(e));
+        return CRAB_E_HIP;
+    }
+    return CRAB_OK;
+}
+
+#define CRAB_HIP_TRY(ctx, expr)                                                                  \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess) {                                                                  \
+            if (ctx) snprintf((ctx)->err, sizeof((ctx)->err), "%s: %s", #expr, hipGetErrorString(_e)); \
+            return CRAB_E_HIP;                                                                   \
+        }                                                                                        \
+    } while (0)

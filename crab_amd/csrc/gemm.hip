@@ -1,0 +1,228 @@
+// bf16 MFMA GEMM for gfx950:  C = res_scale*R + act(A.B^T + A2.B2^T + bias)
+//
+// Both operands are K-contiguous ("x @ W^T", W as stored by nn.Linear), so A and B fragments are both
+// 16-byte row reads.  The MFMA is issued with the WEIGHT tile as the A operand and the ACTIVATION tile
+// as the B operand (computing C^T tiles): with v_mfma_f32_16x16x32_bf16 each lane then owns 4
+// consecutive output columns n of one row m, which gives packed 8-byte bf16 / 16-byte fp32 stores.
+//
+// Tile BMxBNx64, 256 threads = 4 waves (2x2), each wave (BM/2)x(BN/2) as 16x16 MFMA tiles.
+// LDS: two stages of [BM+BN][64] bf16, XOR-swizzled at 16-byte granularity (chunk ^ ((row>>1)&7)) so
+// the ds_read_b128 fragment reads of 16 consecutive rows hit 16 distinct 16-byte bank slots.
+// Global->register->LDS prefetch of tile t+1 overlaps the MFMAs of tile t; one barrier per K tile.
+#include "common.h"
+#include "crab_internal.h"
+
+namespace {
+
+struct GemmP {
+    const bf16_t* A; const bf16_t* B; void* C; const bf16_t* bias; const bf16_t* R;
+    const bf16_t* A2; const bf16_t* B2;
+    long lda, ldb, ldc, ldr, lda2, ldb2;
+    int M, N, K, K2, act, c_fp32;
+    float res_scale;
+    int nb0;
+    long sA0, sA1, sB0, sB1, sC0, sC1, sR0, sR1, sBias0, sBias1;
+    int tiles_m, tiles_n;
+};
+
+constexpr int BK = 64;
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_bt_kernel(GemmP p) {
+    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int TM = WM / 16, TN = WN / 16;
+    constexpr int CA = BM / 32, CB = BN / 32;          // 16-byte chunks per thread per tile
+    __shared__ __attribute__((aligned(16))) bf16_t lds[2][(BM + BN) * BK];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int z = blockIdx.y;
+    const int z0 = z % p.nb0, z1 = z / p.nb0;
+    const bf16_t* A = p.A + z0 * p.sA0 + z1 * p.sA1;
+    const bf16_t* B = p.B + z0 * p.sB0 + z1 * p.sB1;
+    const bf16_t* A2 = p.A2 ? p.A2 + z0 * p.sA0 + z1 * p.sA1 : nullptr;
+    const bf16_t* B2 = p.B2 ? p.B2 + z0 * p.sB0 + z1 * p.sB1 : nullptr;
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int bid = xcd_remap(blockIdx.x, nwg);
+    const int tm = bid % p.tiles_m, tn = bid / p.tiles_m;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int nk1 = (p.K + BK - 1) / BK;
+    const int nk2 = A2 ? (p.K2 + BK - 1) / BK : 0;
+    const int nk = nk1 + nk2;
+
+    u32x4 ra[CA], rb[CB];
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+
+    // per-thread staging coordinates (constant over the K loop)
+    const int lrow = tid >> 3, lc = tid & 7;            // chunk i covers row lrow + 32*i, 16-byte column lc
+
+#define GLOAD(T_)                                                                                        \
+    {                                                                                                    \
+        const int t_ = (T_);                                                                             \
+        const bool s2_ = t_ >= nk1;                                                                      \
+        const bf16_t* Ap_ = s2_ ? A2 : A;                                                                \
+        const bf16_t* Bp_ = s2_ ? B2 : B;                                                                \
+        const long la_ = s2_ ? p.lda2 : p.lda, lb_ = s2_ ? p.ldb2 : p.ldb;                              \
+        const int Ks_ = s2_ ? p.K2 : p.K;                                                                \
+        const int k_ = (s2_ ? (t_ - nk1) : t_) * BK + lc * 8;                                            \
+        _Pragma("unroll") for (int i = 0; i < CA; ++i) {                                                 \
+            const int gr = m0 + lrow + 32 * i;                                                           \
+            ra[i] = (gr < p.M && k_ < Ks_) ? *reinterpret_cast<const u32x4*>(Ap_ + (long)gr * la_ + k_) : zero4; \
+        }                                                                                                \
+        _Pragma("unroll") for (int i = 0; i < CB; ++i) {                                                 \
+            const int gr = n0 + lrow + 32 * i;                                                           \
+            rb[i] = (gr < p.N && k_ < Ks_) ? *reinterpret_cast<const u32x4*>(Bp_ + (long)gr * lb_ + k_) : zero4; \
+        }                                                                                                \
+    }
+#define LSTORE(BUF_)                                                                                     \
+    {                                                                                                    \
+        bf16_t* sa_ = &lds[(BUF_)][0];                                                                   \
+        bf16_t* sb_ = &lds[(BUF_)][BM * BK];                                                             \
+        _Pragma("unroll") for (int i = 0; i < CA; ++i) {                                                 \
+            const int row = lrow + 32 * i;                                                               \
+            *reinterpret_cast<u32x4*>(sa_ + row * BK + ((lc ^ ((row >> 1) & 7)) << 3)) = ra[i];          \
+        }                                                                                                \
+        _Pragma("unroll") for (int i = 0; i < CB; ++i) {                                                 \
+            const int row = lrow + 32 * i;                                                               \
+            *reinterpret_cast<u32x4*>(sb_ + row * BK + ((lc ^ ((row >> 1) & 7)) << 3)) = rb[i];          \
+        }                                                                                                \
+    }
+
+    f32x4_t acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    GLOAD(0);
+    LSTORE(0);
+    __syncthreads();
+
+    const int fr = lane & 15, fg = lane >> 4;
+    for (int t = 0; t < nk; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nk) GLOAD(t + 1);
+        const bf16_t* la_ = &lds[cur][0];
+        const bf16_t* lb_ = &lds[cur][BM * BK];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8_t wf[TN], xf[TM];
+            const int chunk = ks * 4 + fg;
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+                int row = wn * WN + ni * 16 + fr;
+                wf[ni] = *reinterpret_cast<const bf16x8_t*>(lb_ + row * BK + ((chunk ^ ((row >> 1) & 7)) << 3));
+            }
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi) {
+                int row = wm * WM + mi * 16 + fr;
+                xf[mi] = *reinterpret_cast<const bf16x8_t*>(la_ + row * BK + ((chunk ^ ((row >> 1) & 7)) << 3));
+            }
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
+        }
+        if (t + 1 < nk) LSTORE(cur ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: lane owns row m = ..+fr, columns n = ..+fg*4 .. +3 of each 16x16 tile
+    const bf16_t* bias = p.bias ? p.bias + z0 * p.sBias0 + z1 * p.sBias1 : nullptr;
+    const bf16_t* R = p.R ? p.R + z0 * p.sR0 + z1 * p.sR1 : nullptr;
+    const long coff = z0 * p.sC0 + z1 * p.sC1;
+    const bool vec_ok = ((p.ldc & 3) == 0) && ((coff & 3) == 0) && (!R || ((p.ldr & 3) == 0));
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+        const int m = m0 + wm * WM + mi * 16 + fr;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+            const int n = n0 + wn * WN + ni * 16 + fg * 4;
+            if (n >= p.N) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float x = acc[ni][mi][r];
+                if (bias && n + r < p.N) x += bf2f(bias[n + r]);
+                x = apply_act(x, p.act);
+                v[r] = x;
+            }
+            if (n + 3 < p.N && vec_ok) {
+                if (R) {
+                    u32x2 rr = *reinterpret_cast<const u32x2*>(R + (long)m * p.ldr + n);
+                    v[0] += p.res_scale * lo_bf(rr.x); v[1] += p.res_scale * hi_bf(rr.x);
+                    v[2] += p.res_scale * lo_bf(rr.y); v[3] += p.res_scale * hi_bf(rr.y);
+                }
+                if (p.c_fp32) {
+                    float* C = reinterpret_cast<float*>(p.C) + coff + (long)m * p.ldc + n;
+                    *reinterpret_cast<float4*>(C) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    bf16_t* C = reinterpret_cast<bf16_t*>(p.C) + coff + (long)m * p.ldc + n;
+                    u32x2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
+                    *reinterpret_cast<u32x2*>(C) = o;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (n + r >= p.N) break;
+                    float x = v[r];
+                    if (R) x += p.res_scale * bf2f(R[(long)m * p.ldr + n + r]);
+                    if (p.c_fp32) reinterpret_cast<float*>(p.C)[coff + (long)m * p.ldc + n + r] = x;
+                    else reinterpret_cast<bf16_t*>(p.C)[coff + (long)m * p.ldc + n + r] = f2bf(x);
+                }
+            }
+        }
+    }
+}
+
+#undef GLOAD
+#undef LSTORE
+}  // namespace
+
+extern "C" int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc* d) {
+    if (!ctx) return CRAB_E_INVALID;
+    if (!d || !d->A || !d->B || !d->C) return crab_fail(ctx, CRAB_E_INVALID, "gemm: null operand");
+    if (d->M <= 0 || d->N <= 0 || d->K <= 0) return crab_fail(ctx, CRAB_E_INVALID, "gemm: non-positive dimension");
+    if ((d->K & 7) || (d->lda & 7) || (d->ldb & 7)) return crab_fail(ctx, CRAB_E_INVALID, "gemm: K/lda/ldb must be multiples of 8");
+    if (((uintptr_t)d->A & 15) || ((uintptr_t)d->B & 15)) return crab_fail(ctx, CRAB_E_INVALID, "gemm: A/B must be 16-byte aligned");
+    if ((d->A2 != nullptr) != (d->B2 != nullptr)) return crab_fail(ctx, CRAB_E_INVALID, "gemm: A2/B2 must be given together");
+    if (d->A2) {
+        if (d->K2 <= 0 || (d->K2 & 7) || (d->lda2 & 7) || (d->ldb2 & 7))
+            return crab_fail(ctx, CRAB_E_INVALID, "gemm: K2/lda2/ldb2 must be positive multiples of 8");
+        if (((uintptr_t)d->A2 & 15) || ((uintptr_t)d->B2 & 15)) return crab_fail(ctx, CRAB_E_INVALID, "gemm: A2/B2 alignment");
+        if (d->batch > 1) return crab_fail(ctx, CRAB_E_UNSUPPORTED, "gemm: second K segment is not batched");
+    }
+    GemmP p;
+    p.A = (const bf16_t*)d->A; p.B = (const bf16_t*)d->B; p.C = d->C;
+    p.bias = (const bf16_t*)d->bias; p.R = (const bf16_t*)d->R;
+    p.A2 = (const bf16_t*)d->A2; p.B2 = (const bf16_t*)d->B2;
+    p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc; p.ldr = d->ldr; p.lda2 = d->lda2; p.ldb2 = d->ldb2;
+    p.M = d->M; p.N = d->N; p.K = d->K; p.K2 = d->A2 ? d->K2 : 0; p.act = d->act; p.c_fp32 = d->c_fp32;
+    p.res_scale = d->res_scale;
+    int batch = d->batch > 1 ? d->batch : 1;
+    p.nb0 = (batch > 1 && d->nb0 > 0) ? d->nb0 : 1;
+    p.sA0 = d->sA0; p.sA1 = d->sA1; p.sB0 = d->sB0; p.sB1 = d->sB1; p.sC0 = d->sC0; p.sC1 = d->sC1;
+    p.sR0 = d->sR0; p.sR1 = d->sR1; p.sBias0 = d->sBias0; p.sBias1 = d->sBias1;
+    if (batch == 1) { p.sA0 = p.sA1 = p.sB0 = p.sB1 = p.sC0 = p.sC1 = p.sR0 = p.sR1 = p.sBias0 = p.sBias1 = 0; }
+    hipStream_t s = (hipStream_t)stream;
+    // tile choice: 128x128 when it fills the chip, 64x64 for small / skinny problems
+    long big_tiles = (long)((d->M + 127) / 128) * ((d->N + 127) / 128) * batch;
+    bool small = (d->M <= 64) || (d->N <= 64) || big_tiles < 192;
+    if (!small) {
+        p.tiles_m = (d->M + 127) / 128; p.tiles_n = (d->N + 127) / 128;
+        dim3 grid(p.tiles_m * p.tiles_n, batch);
+        hipLaunchKernelGGL((gemm_bt_kernel<128, 128>), grid, dim3(256), 0, s, p);
+    } else {
+        p.tiles_m = (d->M + 63) / 64; p.tiles_n = (d->N + 63) / 64;
+        dim3 grid(p.tiles_m * p.tiles_n, batch);
+        hipLaunchKernelGGL((gemm_bt_kernel<64, 64>), grid, dim3(256), 0, s, p);
+    }
+    return crab_check_launch(ctx, "gemm_bt_kernel");
+}

@@ -1,0 +1,520 @@
+// HBM-bound helper kernels of the Crab forward path (norms, RoPE/KV scatter, embeddings, hyper-LoRA
+// routing mix, SwiGLU, argmax, patch im2col, BEATs relative-position helpers).  All of them stream bf16
+// with 16-byte (8 x bf16) vector accesses where the layout allows and do their arithmetic in fp32.
+#include "common.h"
+#include "crab_internal.h"
+#include <math.h>
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ norms
+// One wave per row (4 rows per 256-thread block); the row stays in registers between the two passes.
+template <bool RMS>
+__global__ __launch_bounds__(256) void norm_kernel(const bf16_t* __restrict__ x, long ldx, const bf16_t* __restrict__ w,
+                                                   const bf16_t* __restrict__ b, bf16_t* __restrict__ y, long ldy,
+                                                   int M, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const bf16_t* xr = x + (long)row * ldx;
+    bf16_t* yr = y + (long)row * ldy;
+    constexpr int MAXV = 16;                       // up to 16 vectors of 8 per lane: D <= 8192
+    u32x4 v[MAXV];
+    const int nvec = D >> 3;                       // D % 8 == 0 (checked on the host)
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        int vi = lane + i * 64;
+        if (vi < nvec) {
+            v[i] = *reinterpret_cast<const u32x4*>(xr + vi * 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float a = lo_bf(v[i][j]), c = hi_bf(v[i][j]);
+                s1 += a + c;
+                s2 += a * a + c * c;
+            }
+        }
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    float mean = 0.f, rstd;
+    if (RMS) {
+        rstd = rsqrtf(s2 / (float)D + eps);
+    } else {
+        mean = s1 / (float)D;
+        // second pass over registers for the centred variance (matches torch's numerics better than E[x^2]-m^2)
+        float sv = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            int vi = lane + i * 64;
+            if (vi < nvec) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float a = lo_bf(v[i][j]) - mean, c = hi_bf(v[i][j]) - mean;
+                    sv += a * a + c * c;
+                }
+            }
+        }
+        sv = wave_sum(sv);
+        rstd = rsqrtf(sv / (float)D + eps);
+    }
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        int vi = lane + i * 64;
+        if (vi < nvec) {
+            u32x4 wv = *reinterpret_cast<const u32x4*>(w + vi * 8);
+            u32x4 bv = {0u, 0u, 0u, 0u};
+            if (!RMS && b) bv = *reinterpret_cast<const u32x4*>(b + vi * 8);
+            u32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float a = (lo_bf(v[i][j]) - mean) * rstd, c = (hi_bf(v[i][j]) - mean) * rstd;
+                if (RMS) {   // modeling_llama.py:116-117: weight * x_hat.to(input_dtype)
+                    a = bf2f(f2bf(a)); c = bf2f(f2bf(c));
+                }
+                a = a * lo_bf(wv[j]) + lo_bf(bv[j]);
+                c = c * hi_bf(wv[j]) + hi_bf(bv[j]);
+                o[j] = pack_bf2(a, c);
+            }
+            *reinterpret_cast<u32x4*>(yr + vi * 8) = o;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ embedding
+__global__ void embedding_kernel(const int64_t* __restrict__ ids, const bf16_t* __restrict__ table, bf16_t* __restrict__ out,
+                                 long ldo, int T, int D, int vocab) {
+    const int t = blockIdx.x;
+    long id = ids[t];
+    if (id < 0) id = 0;
+    if (id >= vocab) id = vocab - 1;
+    const bf16_t* src = table + id * (long)D;
+    bf16_t* dst = out + (long)t * ldo;
+    for (int i = threadIdx.x; i < (D >> 3); i += blockDim.x)
+        *reinterpret_cast<u32x4*>(dst + i * 8) = *reinterpret_cast<const u32x4*>(src + i * 8);
+}
+
+// ------------------------------------------------------------------------------------------------ RoPE
+__global__ void rope_table_kernel(float* tab, int max_pos, int half, float theta, int d) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= max_pos * half) return;
+    int pos = idx / half, i = idx % half;
+    // inv_freq = 1 / theta^(2i/d) evaluated in fp32 like torch (modeling_llama.py:130-136), angle = pos*inv_freq
+    float inv = 1.0f / powf(theta, (float)(2 * i) / (float)d);
+    float ang = (float)pos * inv;
+    tab[2 * idx] = cosf(ang);
+    tab[2 * idx + 1] = sinf(ang);
+}
+
+// grid (T, H + 2*Hk); block d/2 threads... one thread handles the pair (i, i+d/2)
+__global__ void qkv_rope_split_kernel(bf16_t* __restrict__ qkv, long ldqkv, const float* __restrict__ tab,
+                                      bf16_t* __restrict__ kc, bf16_t* __restrict__ vc, bf16_t* __restrict__ vt, long vt_ld,
+                                      int S, int H, int Hk, int d, int Tmax, int pos0, const int* __restrict__ pos_dev) {
+    const int t = blockIdx.x;            // token index b*S + s
+    const int hh = blockIdx.y;           // 0..H-1 q heads, H..H+Hk-1 k heads, H+Hk.. v heads
+    const int b = t / S, s = t % S;
+    const int half = d >> 1;
+    const int i = threadIdx.x;
+    if (i >= half) return;
+    const int pos = (pos_dev ? pos_dev[0] : 0) + pos0 + s;
+    bf16_t* src = qkv + (long)t * ldqkv + (long)hh * d;
+    if (hh < H + Hk) {
+        float x1 = bf2f(src[i]), x2 = bf2f(src[i + half]);
+        float o1 = x1, o2 = x2;
+        if (tab) {
+            float c = tab[2 * ((long)pos * half + i)], sn = tab[2 * ((long)pos * half + i) + 1];
+            // q*cos + rotate_half(q)*sin, each product rounded as in the bf16 reference? fp32 here, one rounding
+            o1 = x1 * c - x2 * sn;
+            o2 = x2 * c + x1 * sn;
+        }
+        if (hh < H) {
+            src[i] = f2bf(o1);
+            src[i + half] = f2bf(o2);
+        } else if (kc) {
+            const int hk = hh - H;
+            bf16_t* dst = kc + (((long)b * Hk + hk) * Tmax + pos) * d;
+            dst[i] = f2bf(o1);
+            dst[i + half] = f2bf(o2);
+        }
+    } else {
+        const int hk = hh - H - Hk;
+        bf16_t v1 = src[i], v2 = src[i + half];
+        if (vc) {
+            bf16_t* dst = vc + (((long)b * Hk + hk) * Tmax + pos) * d;
+            dst[i] = v1;
+            dst[i + half] = v2;
+        }
+        if (vt) {
+            bf16_t* dt = vt + ((long)b * Hk + hk) * d * vt_ld;
+            dt[(long)i * vt_ld + s] = v1;
+            dt[(long)(i + half) * vt_ld + s] = v2;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ hyper-LoRA mix
+// one thread per (row, projection): softmax over nl route logits, then scaling * p_i * h_j
+template <typename TT>
+__global__ void hyperlora_mix_kernel(const TT* __restrict__ T, long ldt, bf16_t* __restrict__ U, long ldu, int M,
+                                     int nproj, int nl, int r, int ucols, float scaling) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int used = nproj * nl * r;
+    const int per_row = nproj + 1;                 // last slot zero-fills the padding columns
+    if (idx >= M * per_row) return;
+    int m = idx / per_row, p = idx % per_row;
+    bf16_t* u = U + (long)m * ldu;
+    if (p == nproj) {
+        for (int c = used; c < ucols; ++c) u[c] = 0;
+        return;
+    }
+    const TT* t = T + (long)m * ldt + p * (nl + r);
+    float lg[8], mx = -INFINITY;
+    for (int i = 0; i < nl; ++i) {
+        lg[i] = sizeof(TT) == 4 ? (float)((const float*)t)[i] : bf2f(((const bf16_t*)t)[i]);
+        mx = fmaxf(mx, lg[i]);
+    }
+    float sum = 0.f;
+    for (int i = 0; i < nl; ++i) { lg[i] = expf(lg[i] - mx); sum += lg[i]; }
+    float inv = 1.0f / sum;
+    for (int i = 0; i < nl; ++i) {
+        float pi = lg[i] * inv;
+        for (int j = 0; j < r; ++j) {
+            float h = sizeof(TT) == 4 ? (float)((const float*)t)[nl + j] : bf2f(((const bf16_t*)t)[nl + j]);
+            u[p * nl * r + i * r + j] = f2bf(scaling * pi * h);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ SwiGLU
+__global__ void swiglu_kernel(const bf16_t* __restrict__ gu, long ldgu, bf16_t* __restrict__ y, long ldy, int M, int I) {
+    const int nv = I >> 3;
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)M * nv) return;
+    int m = idx / nv, c = idx % nv;
+    u32x4 g = *reinterpret_cast<const u32x4*>(gu + (long)m * ldgu + c * 8);
+    u32x4 u = *reinterpret_cast<const u32x4*>(gu + (long)m * ldgu + I + c * 8);
+    u32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float g0 = lo_bf(g[j]), g1 = hi_bf(g[j]);
+        o[j] = pack_bf2(g0 / (1.f + __expf(-g0)) * lo_bf(u[j]), g1 / (1.f + __expf(-g1)) * hi_bf(u[j]));
+    }
+    *reinterpret_cast<u32x4*>(y + (long)m * ldy + c * 8) = o;
+}
+
+// ------------------------------------------------------------------------------------------------ argmax
+__global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ logits, long ldl, int64_t* __restrict__ ids,
+                                                      int V, int suppress) {
+    __shared__ float sv[16];
+    __shared__ int si[16];
+    const int b = blockIdx.x;
+    const float* row = logits + (long)b * ldl;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < V; i += blockDim.x) {
+        float v = (i == suppress) ? -INFINITY : row[i];
+        if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float ov = __shfl_xor(best, o, 64);
+        int oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { sv[wave] = best; si[wave] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int nw = blockDim.x >> 6;
+        for (int w = 1; w < nw; ++w)
+            if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
+        ids[b] = (bi == 0x7fffffff) ? 0 : bi;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ im2col (stride == kernel)
+template <typename TI>
+__global__ void im2col_patch_kernel(const TI* __restrict__ in, bf16_t* __restrict__ out, long ldo, int N, int C, int Hh, int Ww,
+                                    int P, int gh, int gw) {
+    const int tok = blockIdx.x;                     // (n, gy, gx)
+    const int n = tok / (gh * gw), g = tok % (gh * gw), gy = g / gw, gx = g % gw;
+    const int Kp = C * P * P;
+    bf16_t* o = out + (long)tok * ldo;
+    for (int k = threadIdx.x; k < ldo; k += blockDim.x) {
+        float v = 0.f;
+        if (k < Kp) {
+            int c = k / (P * P), rr = k % (P * P), ky = rr / P, kx = rr % P;
+            TI x = in[(((long)n * C + c) * Hh + gy * P + ky) * Ww + gx * P + kx];
+            v = sizeof(TI) == 4 ? (float)*reinterpret_cast<const float*>(&x) : bf2f(*reinterpret_cast<const bf16_t*>(&x));
+        }
+        o[k] = f2bf(v);
+    }
+}
+
+// CLIP: assemble [cls | patches] + position embedding, then pre_layrnorm; one wave per token row
+__global__ __launch_bounds__(256) void clip_embed_ln_kernel(const bf16_t* __restrict__ patch, const bf16_t* __restrict__ cls,
+                                                            const bf16_t* __restrict__ pos, const bf16_t* __restrict__ lnw,
+                                                            const bf16_t* __restrict__ lnb, bf16_t* __restrict__ y, int N, int P,
+                                                            int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (long)N * (P + 1)) return;
+    const int n = row / (P + 1), tk = row % (P + 1);
+    const bf16_t* src = tk == 0 ? cls : patch + ((long)n * P + (tk - 1)) * D;
+    const bf16_t* pe = pos + (long)tk * D;
+    constexpr int MAXE = 32;                        // D <= 2048
+    float v[MAXE];
+    float s1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXE; ++i) {
+        int e = lane + i * 64;
+        if (e < D) {
+            // bf16 reference rounds the sum of two bf16 tensors to bf16 before the LayerNorm
+            v[i] = bf2f(f2bf(bf2f(src[e]) + bf2f(pe[e])));
+            s1 += v[i];
+        }
+    }
+    float mean = wave_sum(s1) / (float)D;
+    float sv = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXE; ++i) {
+        int e = lane + i * 64;
+        if (e < D) { float a = v[i] - mean; sv += a * a; }
+    }
+    float rstd = rsqrtf(wave_sum(sv) / (float)D + eps);
+    bf16_t* yr = y + row * D;
+#pragma unroll
+    for (int i = 0; i < MAXE; ++i) {
+        int e = lane + i * 64;
+        if (e < D) yr[e] = f2bf((v[i] - mean) * rstd * bf2f(lnw[e]) + bf2f(lnb[e]));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ BEATs helpers
+// x[B,n,E] -> xp[G][B][n+Kc-1][E/G], Kc/2 zero rows in front (Conv1d padding=Kc/2) and Kc/2-1 behind
+// (the even-kernel conv emits n+1 steps of which SamePad drops the last, backbone.py:33-46, modules.py:29-40)
+__global__ void beats_posconv_pad_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ xp, int B, int n, int E, int G, int Kc) {
+    const int cg = E / G;
+    const int np = n + Kc - 1;
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long total = (long)G * B * np * cg;
+    if (idx >= total) return;
+    int c = idx % cg;
+    long r = idx / cg;
+    int tp = r % np; r /= np;
+    int b = r % B;
+    int g = r / B;
+    int t = tp - Kc / 2;
+    bf16_t v = 0;
+    if (t >= 0 && t < n) v = x[((long)b * n + t) * E + g * cg + c];
+    xp[idx] = v;
+}
+
+// bias[h,i,j] = table[bucket(j - i)][h], bidirectional T5 buckets (backbone.py:392-430)
+__global__ void beats_relpos_bias_kernel(const bf16_t* __restrict__ table, float* __restrict__ bias, int n, int H, int num_buckets,
+                                         int max_distance) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * n) return;
+    int i = idx / n, j = idx % n;
+    int rel = j - i;
+    int nb = num_buckets / 2;
+    int bucket = rel > 0 ? nb : 0;
+    int a = rel < 0 ? -rel : rel;
+    int max_exact = nb / 2;
+    if (a < max_exact) {
+        bucket += a;
+    } else {
+        // torch: (log(a / max_exact) / log(max_distance / max_exact) * (nb - max_exact)).to(long), fp32 arithmetic
+        float v = logf((float)a / (float)max_exact) / (float)log((double)max_distance / (double)max_exact) * (float)(nb - max_exact);
+        int large = max_exact + (int)v;
+        bucket += large < nb - 1 ? large : nb - 1;
+    }
+    for (int h = 0; h < H; ++h) bias[((long)h * n + i) * n + j] = bf2f(table[(long)bucket * H + h]);
+}
+
+// gate[b,h,i] from the un-scaled q projection (backbone.py:650-662): grep_linear d->8, view(2,4).sum, sigmoid
+__global__ void beats_gru_gate_kernel(const bf16_t* __restrict__ q, long ldq, const bf16_t* __restrict__ gw, const bf16_t* __restrict__ gb,
+                                      const bf16_t* __restrict__ grep_a, float* __restrict__ gate, int B, int n, int H, int d) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * H * n) return;
+    int i = idx % n, h = (idx / n) % H, b = idx / (n * H);
+    const bf16_t* qr = q + ((long)b * n + i) * ldq + h * d;
+    float o[8];
+    for (int k = 0; k < 8; ++k) {
+        float s = bf2f(gb[k]);
+        for (int e = 0; e < d; ++e) s += bf2f(qr[e]) * bf2f(gw[k * d + e]);
+        o[k] = s;
+    }
+    float sa = o[0] + o[1] + o[2] + o[3], sb = o[4] + o[5] + o[6] + o[7];
+    float ga = 1.f / (1.f + expf(-sa)), gb_ = 1.f / (1.f + expf(-sb));
+    gate[idx] = ga * (gb_ * bf2f(grep_a[h]) - 1.0f) + 2.0f;
+}
+
+__global__ void copy_rows_kernel(const bf16_t* __restrict__ src, long lds_, bf16_t* __restrict__ dst, long ldd, int rows, int cols) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if ((cols & 7) == 0 && (lds_ & 7) == 0 && (ldd & 7) == 0) {
+        int nv = cols >> 3;
+        if (idx >= (long)rows * nv) return;
+        int r = idx / nv, c = idx % nv;
+        *reinterpret_cast<u32x4*>(dst + (long)r * ldd + c * 8) = *reinterpret_cast<const u32x4*>(src + (long)r * lds_ + c * 8);
+    } else {
+        if (idx >= (long)rows * cols) return;
+        int r = idx / cols, c = idx % cols;
+        dst[(long)r * ldd + c] = src[(long)r * lds_ + c];
+    }
+}
+
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long n) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = f2bf(src[i]);
+}
+
+}  // namespace
+
+#define S_(x) ((hipStream_t)(x))
+static inline unsigned cdiv(long a, long b) { return (unsigned)((a + b - 1) / b); }
+
+extern "C" {
+
+int crab_rmsnorm(crab_ctx* ctx, void* stream, const void* x, int64_t ldx, const void* w, void* y, int64_t ldy, int M, int D, float eps) {
+    if (!ctx) return CRAB_E_INVALID;
+    if (!x || !w || !y || M <= 0) return crab_fail(ctx, CRAB_E_INVALID, "rmsnorm: bad argument");
+    if ((D & 7) || D > 8192 || (ldx & 7) || (ldy & 7)) return crab_fail(ctx, CRAB_E_INVALID, "rmsnorm: D must be a multiple of 8 and <= 8192");
+    hipLaunchKernelGGL((norm_kernel<true>), dim3(cdiv(M, 4)), dim3(256), 0, S_(stream), (const bf16_t*)x, (long)ldx, (const bf16_t*)w,
+                       (const bf16_t*)nullptr, (bf16_t*)y, (long)ldy, M, D, eps);
+    return crab_check_launch(ctx, "rmsnorm");
+}
+
+int crab_layernorm(crab_ctx* ctx, void* stream, const void* x, int64_t ldx, const void* w, const void* b, void* y, int64_t ldy, int M,
+                   int D, float eps) {
+    if (!ctx) return CRAB_E_INVALID;
+    if (!x || !w || !y || M <= 0) return crab_fail(ctx, CRAB_E_INVALID, "layernorm: bad argument");
+    if ((D & 7) || D > 8192 || (ldx & 7) || (ldy & 7)) return crab_fail(ctx, CRAB_E_INVALID, "layernorm: D must be a multiple of 8 and <= 8192");
+    hipLaunchKernelGGL((norm_kernel<false>), dim3(cdiv(M, 4)), dim3(256), 0, S_(stream), (const bf16_t*)x, (long)ldx, (const bf16_t*)w,
+                       (const bf16_t*)b, (bf16_t*)y, (long)ldy, M, D, eps);
+    return crab_check_launch(ctx, "layernorm");
+}
+
+int crab_embedding(crab_ctx* ctx, void* stream, const int64_t* ids, const void* table, void* out, int64_t ldo, int T, int D, int vocab) {
+    if (!ctx) return CRAB_E_INVALID;
+    if (!ids || !table || !out || T <= 0 || (D & 7) || (ldo & 7)) return crab_fail(ctx, CRAB_E_INVALID, "embedding: bad argument");
+    hipLaunchKernelGGL(embedding_kernel, dim3(T), dim3(128), 0, S_(stream), ids, (const bf16_t*)table, (bf16_t*)out, (long)ldo, T, D, vocab);
+    return crab_check_launch(ctx, "embedding");
+}
+
+int crab_rope_table(crab_ctx* ctx, void* stream, float* tab, int max_pos, int head_dim, float theta) {
+    if (!ctx) return CRAB_E_INVALID;
+    if (!tab || max_pos <= 0 || (head_dim & 1)) return crab_fail(ctx, CRAB_E_INVALID, "rope_table: bad argument");
+    int half = head_dim / 2;
+    hipLaunchKernelGGL(rope_table_kernel, dim3(cdiv((long)max_pos * half, 256)), dim3(256), 0, S_(stream), tab, max_pos, half, theta, head_dim);
+    return crab_check_launch(ctx, "rope_table");
+}
+
+int crab_qkv_rope_split(crab_ctx* ctx, void* stream, void* qkv, int64_t ldqkv, const float* rope_tab, void* k_cache, void* v_cache,
+                        void* vt, int64_t vt_ld, int B, int S, int H, int Hk, int d, int Tmax, int pos0, const int32_t* pos_dev) {
+    if (!ctx) return CRAB_E_INVALID;
+    if (!qkv || B <= 0 || S <= 0 || d > 2048 || (d & 1)) return crab_fail(ctx, CRAB_E_INVALID, "qkv_rope_split: bad argument");
+    if ((k_cache || v_cache) && !pos_dev && pos0 + S > Tmax) return crab_fail(ctx, CRAB_E_INVALID, "qkv_rope_split: KV cache overflow");
+    int threads = ((d / 2 + 63) / 64) * 64;
+    hipLaunchKernelGGL(qkv_rope_split_kernel, dim3(B * S, H + 2 * Hk), dim3(threads), 0, S_(stream), (bf16_t*)qkv, (long)ldqkv, rope_tab,
+                       (bf16_t*)k_cache, (bf16_t*)v_cache, (bf16_t*)vt, (long)vt_ld, S, H, Hk, d, Tmax, pos0, pos_dev);
+    return crab_check_launch(ctx, "qkv_rope_split");
+}
+
+int crab_hyperlora_mix(crab_ctx* ctx, void* stream, const void* T, int64_t ldt, int t_fp32, void* U, int64_t ldu, int M, int nproj,
+                       int nl, int r, int ucols, float scaling) {
+    if (!ctx) return CRAB_E_INVALID;
+    if (!T || !U || M <= 0 || nproj <= 0 || nl <= 0 || nl > 8 || r <= 0 || ucols < nproj * nl * r)
+        return crab_fail(ctx, CRAB_E_INVALID, "hyperlora_mix: bad argument");
+    unsigned blocks = cdiv((long)M * (nproj + 1), 256);
+    if (t_fp32)
+        hipLaunchKernelGGL((hyperlora_mix_kernel<float>), dim3(blocks), dim3(256), 0, S_(stream), (const float*)T, (long)ldt, (bf16_t*)U,
+                           (long)ldu, M, nproj, nl, r, ucols, scaling);
+    else
+        hipLaunchKernelGGL((hyperlora_mix_kernel<bf16_t>), dim3(blocks), dim3(256), 0, S_(stream), (const bf16_t*)T, (long)ldt,
+                           (bf16_t*)U, (long)ldu, M, nproj, nl, r, ucols, scaling);
+    return crab_check_launch(ctx, "hyperlora_mix");
+}
+
+int crab_swiglu(crab_ctx* ctx, void* stream, const void* gu, int64_t ldgu, void* y, int64_t ldy, int M, int I) {
+    if (!ctx) return CRAB_E_INVALID;
+    if (!gu || !y || M <= 0 || (I & 7) || (ldgu & 7) || (ldy & 7)) return crab_fail(ctx, CRAB_E_INVALID, "swiglu: bad argument");
+    hipLaunchKernelGGL(swiglu_kernel, dim3(cdiv((long)M * (I >> 3), 256)), dim3(256), 0, S_(stream), (const bf16_t*)gu, (long)ldgu,
+                       (bf16_t*)y, (long)ldy, M, I);
+    return crab_check_launch(ctx, "swiglu");
+}
+
+int crab_argmax(crab_ctx* ctx, void* stream, const float* logits, int64_t ldl, int64_t* ids, int B, int V, int suppress) {
+    if (!ctx) return CRAB_E_INVALID;
+    if (!logits || !ids || B <= 0 || V <= 0) return crab_fail(ctx, CRAB_E_INVALID, "argmax: bad argument");
+    hipLaunchKernelGGL(argmax_kernel, dim3(B), dim3(1024), 0, S_(stream), logits, (long)ldl, ids, V, suppress);
+    return crab_check_launch(ctx, "argmax");
+}
+
+int crab_im2col_patch(crab_ctx* ctx, void* stream, const void* in, int in_fp32, void* out, int64_t ldo, int N, int C, int Hh, int Ww,
+                      int P) {
+    if (!ctx) return CRAB_E_INVALID;
+    if (!in || !out || N <= 0 || P <= 0 || Hh < P || Ww < P || ldo < (int64_t)C * P * P)
+        return crab_fail(ctx, CRAB_E_INVALID, "im2col_patch: bad argument");
+    int gh = Hh / P, gw = Ww / P;
+    if (in_fp32)
+        hipLaunchKernelGGL((im2col_patch_kernel<float>), dim3(N * gh * gw), dim3(256), 0, S_(stream), (const float*)in, (bf16_t*)out,
+                           (long)ldo, N, C, Hh, Ww, P, gh, gw);
+    else
+        hipLaunchKernelGGL((im2col_patch_kernel<bf16_t>), dim3(N * gh * gw), dim3(256), 0, S_(stream), (const bf16_t*)in, (bf16_t*)out,
+                           (long)ldo, N, C, Hh, Ww, P, gh, gw);
+    return crab_check_launch(ctx, "im2col_patch");
+}
+
+int crab_clip_embed_ln(crab_ctx* ctx, void* stream, const void* patch, const void* cls, const void* pos, const void* lnw, const void* lnb,
+                       void* y, int N, int P, int D, float eps) {
+    if (!ctx) return CRAB_E_INVALID;
+    if (!patch || !cls || !pos || !lnw || !lnb || !y || D > 2048) return crab_fail(ctx, CRAB_E_INVALID, "clip_embed_ln: bad argument");
+    hipLaunchKernelGGL(clip_embed_ln_kernel, dim3(cdiv((long)N * (P + 1), 4)), dim3(256), 0, S_(stream), (const bf16_t*)patch,
+                       (const bf16_t*)cls, (const bf16_t*)pos, (const bf16_t*)lnw, (const bf16_t*)lnb, (bf16_t*)y, N, P, D, eps);
+    return crab_check_launch(ctx, "clip_embed_ln");
+}
+
+int crab_beats_posconv_pad(crab_ctx* ctx, void* stream, const void* x, void* xp, int B, int n, int E, int G, int Kc) {
+    if (!ctx) return CRAB_E_INVALID;
+    if (!x || !xp || E % G) return crab_fail(ctx, CRAB_E_INVALID, "beats_posconv_pad: bad argument");
+    long total = (long)G * B * (n + Kc - 1) * (E / G);
+    hipLaunchKernelGGL(beats_posconv_pad_kernel, dim3(cdiv(total, 256)), dim3(256), 0, S_(stream), (const bf16_t*)x, (bf16_t*)xp, B, n, E, G, Kc);
+    return crab_check_launch(ctx, "beats_posconv_pad");
+}
+
+int crab_beats_relpos_bias(crab_ctx* ctx, void* stream, const void* table, float* bias, int n, int H, int num_buckets, int max_distance) {
+    if (!ctx) return CRAB_E_INVALID;
+    if (!table || !bias || n <= 0) return crab_fail(ctx, CRAB_E_INVALID, "beats_relpos_bias: bad argument");
+    hipLaunchKernelGGL(beats_relpos_bias_kernel, dim3(cdiv((long)n * n, 256)), dim3(256), 0, S_(stream), (const bf16_t*)table, bias, n, H,
+                       num_buckets, max_distance);
+    return crab_check_launch(ctx, "beats_relpos_bias");
+}
+
+int crab_beats_gru_gate(crab_ctx* ctx, void* stream, const void* q, int64_t ldq, const void* gw, const void* gb, const void* grep_a,
+                        float* gate, int B, int n, int H, int d) {
+    if (!ctx) return CRAB_E_INVALID;
+    if (!q || !gw || !gb || !grep_a || !gate) return crab_fail(ctx, CRAB_E_INVALID, "beats_gru_gate: bad argument");
+    hipLaunchKernelGGL(beats_gru_gate_kernel, dim3(cdiv((long)B * H * n, 128)), dim3(128), 0, S_(stream), (const bf16_t*)q, (long)ldq,
+                       (const bf16_t*)gw, (const bf16_t*)gb, (const bf16_t*)grep_a, gate, B, n, H, d);
+    return crab_check_launch(ctx, "beats_gru_gate");
+}
+
+int crab_copy_rows(crab_ctx* ctx, void* stream, const void* src, int64_t lds_, void* dst, int64_t ldd, int rows, int cols) {
+    if (!ctx) return CRAB_E_INVALID;
+    if (!src || !dst || rows <= 0 || cols <= 0) return crab_fail(ctx, CRAB_E_INVALID, "copy_rows: bad argument");
+    bool vec = (cols & 7) == 0 && (lds_ & 7) == 0 && (ldd & 7) == 0;
+    long total = vec ? (long)rows * (cols >> 3) : (long)rows * cols;
+    hipLaunchKernelGGL(copy_rows_kernel, dim3(cdiv(total, 256)), dim3(256), 0, S_(stream), (const bf16_t*)src, (long)lds_, (bf16_t*)dst,
+                       (long)ldd, rows, cols);
+    return crab_check_launch(ctx, "copy_rows");
+}
+
+int crab_cast_f32_bf16(crab_ctx* ctx, void* stream, const float* src, void* dst, int64_t n) {
+    if (!ctx) return CRAB_E_INVALID;
+    if (!src || !dst || n <= 0) return crab_fail(ctx, CRAB_E_INVALID, "cast: bad argument");
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(cdiv(n, 256)), dim3(256), 0, S_(stream), src, (bf16_t*)dst, (long)n);
+    return crab_check_launch(ctx, "cast_f32_bf16");
+}
+
+}  // extern "C"

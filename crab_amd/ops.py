@@ -1,0 +1,233 @@
+"""Thin tensor-level wrappers over the C-ABI (plumbing only: pointers, strides, the current HIP stream).
+
+Every function launches HIP kernels from libcrab_hip.so on torch's current stream and returns/fills
+caller-visible torch tensors.  No arithmetic happens in PyTorch here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import AttnDesc, GemmDesc
+
+ACT = {"none": 0, None: 0, "gelu": 1, "quick_gelu": 2, "relu": 3, "silu": 4}
+BF16 = torch.bfloat16
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t: torch.Tensor) -> int:
+    if not t.is_cuda:
+        raise _lib.CrabHipError("crab_amd ops need CUDA/HIP tensors (no CPU fallback exists)")
+    return t.device.index or 0
+
+
+def _p(t: Optional[torch.Tensor]):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _chk_bf16(*ts):
+    for t in ts:
+        if t is not None and t.dtype != BF16:
+            raise _lib.CrabHipError(f"expected bfloat16 storage, got {t.dtype}")
+
+
+def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act: str = "none",
+         residual: Optional[torch.Tensor] = None, res_scale: float = 1.0, x2: Optional[torch.Tensor] = None,
+         w2: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, out_fp32: bool = False) -> torch.Tensor:
+    """out[M,N] = res_scale*residual + act(x[M,K] @ w[N,K]^T + x2 @ w2^T + bias).  2-D row-strided operands."""
+    _chk_bf16(x, w, bias, residual, x2, w2)
+    d = _dev(x)
+    M, K = x.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and x.stride(1) == 1 and w.stride(1) == 1
+    if out is None:
+        out = torch.empty((M, N), device=x.device, dtype=torch.float32 if out_fp32 else BF16)
+    g = GemmDesc()
+    g.A, g.B, g.C = x.data_ptr(), w.data_ptr(), out.data_ptr()
+    g.bias = bias.data_ptr() if bias is not None else None
+    g.R = residual.data_ptr() if residual is not None else None
+    g.lda, g.ldb, g.ldc = x.stride(0), w.stride(0), out.stride(0)
+    g.ldr = residual.stride(0) if residual is not None else 0
+    if x2 is not None:
+        assert w2 is not None and x2.shape[1] == w2.shape[1] and x2.shape[0] == M and w2.shape[0] == N
+        g.A2, g.B2, g.lda2, g.ldb2, g.K2 = x2.data_ptr(), w2.data_ptr(), x2.stride(0), w2.stride(0), x2.shape[1]
+    g.M, g.N, g.K = M, N, K
+    g.act = ACT[act]
+    g.c_fp32 = 1 if out.dtype == torch.float32 else 0
+    g.res_scale = res_scale
+    g.batch, g.nb0 = 1, 1
+    _lib.check(_lib.load().crab_gemm_bf16(_lib.ctx(d), _stream(), C.byref(g)), d)
+    return out
+
+
+def gemm_desc(desc: GemmDesc, device: int = 0):
+    """Raw descriptor launch (batched / strided forms)."""
+    _lib.check(_lib.load().crab_gemm_bf16(_lib.ctx(device), _stream(), C.byref(desc)), device)
+
+
+def hyperlora_mix(t: torch.Tensor, nproj: int, nl: int, r: int, ucols: int, scaling: float,
+                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    d = _dev(t)
+    M = t.shape[0]
+    if out is None:
+        out = torch.empty((M, ucols), device=t.device, dtype=BF16)
+    _lib.check(_lib.load().crab_hyperlora_mix(_lib.ctx(d), _stream(), _p(t), t.stride(0), 1 if t.dtype == torch.float32 else 0,
+                                              _p(out), out.stride(0), M, nproj, nl, r, ucols, scaling), d)
+    return out
+
+
+def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _chk_bf16(x, w)
+    d = _dev(x)
+    M, D = x.shape
+    if out is None:
+        out = torch.empty((M, D), device=x.device, dtype=BF16)
+    _lib.check(_lib.load().crab_rmsnorm(_lib.ctx(d), _stream(), _p(x), x.stride(0), _p(w), _p(out), out.stride(0), M, D, eps), d)
+    return out
+
+
+def layernorm(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], eps: float,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _chk_bf16(x, w, b)
+    d = _dev(x)
+    M, D = x.shape
+    if out is None:
+        out = torch.empty((M, D), device=x.device, dtype=BF16)
+    _lib.check(_lib.load().crab_layernorm(_lib.ctx(d), _stream(), _p(x), x.stride(0), _p(w), _p(b), _p(out), out.stride(0), M, D, eps), d)
+    return out
+
+
+def embedding(ids: torch.Tensor, table: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _chk_bf16(table)
+    d = _dev(table)
+    ids = ids.reshape(-1).to(device=table.device, dtype=torch.int64).contiguous()
+    T, D = ids.numel(), table.shape[1]
+    if out is None:
+        out = torch.empty((T, D), device=table.device, dtype=BF16)
+    if T:
+        _lib.check(_lib.load().crab_embedding(_lib.ctx(d), _stream(), _p(ids), _p(table), _p(out), out.stride(0), T, D, table.shape[0]), d)
+    return out
+
+
+def rope_table(max_pos: int, head_dim: int, theta: float, device) -> torch.Tensor:
+    tab = torch.empty((max_pos, head_dim // 2, 2), device=device, dtype=torch.float32)
+    d = _dev(tab)
+    _lib.check(_lib.load().crab_rope_table(_lib.ctx(d), _stream(), _p(tab), max_pos, head_dim, theta), d)
+    return tab
+
+
+def qkv_rope_split(qkv: torch.Tensor, rope_tab: Optional[torch.Tensor], k_cache: Optional[torch.Tensor],
+                   v_cache: Optional[torch.Tensor], vt: Optional[torch.Tensor], B: int, S: int, H: int, Hk: int, d_: int,
+                   Tmax: int, pos0: int = 0, pos_dev: Optional[torch.Tensor] = None):
+    d = _dev(qkv)
+    vt_ld = vt.stride(-2) if vt is not None else 0
+    _lib.check(_lib.load().crab_qkv_rope_split(_lib.ctx(d), _stream(), _p(qkv), qkv.stride(0), _p(rope_tab), _p(k_cache), _p(v_cache),
+                                               _p(vt), vt_ld, B, S, H, Hk, d_, Tmax, pos0, _p(pos_dev)), d)
+
+
+def attn_fwd(q, k, vt, o, *, q_strides, k_strides, vt_strides, o_strides, B, H, Hk, Sq, Skv, head_dim, scale, causal=False,
+             bias=None, gate=None):
+    """Strided flash attention; *_strides = (batch, head, row) element strides, o_strides = (batch, row)."""
+    d = _dev(q)
+    a = AttnDesc()
+    a.q, a.k, a.vt, a.o = q.data_ptr(), k.data_ptr(), vt.data_ptr(), o.data_ptr()
+    a.q_bs, a.q_hs, a.q_ss = q_strides
+    a.k_bs, a.k_hs, a.k_ss = k_strides
+    a.vt_bs, a.vt_hs, a.vt_ds = vt_strides
+    a.o_bs, a.o_ss = o_strides
+    a.bias = bias.data_ptr() if bias is not None else None
+    a.gate = gate.data_ptr() if gate is not None else None
+    a.B, a.H, a.Hk, a.Sq, a.Skv, a.head_dim, a.causal, a.scale = B, H, Hk, Sq, Skv, head_dim, 1 if causal else 0, scale
+    _lib.check(_lib.load().crab_attn_fwd(_lib.ctx(d), _stream(), C.byref(a)), d)
+    return o
+
+
+def attn_decode(q, k_cache, v_cache, o, B, H, Hk, head_dim, Tmax, ctx_len, scale, ctx_dev=None):
+    d = _dev(q)
+    _lib.check(_lib.load().crab_attn_decode(_lib.ctx(d), _stream(), _p(q), q.stride(0), _p(k_cache), _p(v_cache), _p(o), o.stride(0),
+                                            B, H, Hk, head_dim, Tmax, ctx_len, _p(ctx_dev), scale), d)
+    return o
+
+
+def swiglu(gu: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    d = _dev(gu)
+    M, I2 = gu.shape
+    if out is None:
+        out = torch.empty((M, I2 // 2), device=gu.device, dtype=BF16)
+    _lib.check(_lib.load().crab_swiglu(_lib.ctx(d), _stream(), _p(gu), gu.stride(0), _p(out), out.stride(0), M, I2 // 2), d)
+    return out
+
+
+def argmax(logits: torch.Tensor, out: Optional[torch.Tensor] = None, suppress: int = -1) -> torch.Tensor:
+    d = _dev(logits)
+    assert logits.dtype == torch.float32
+    B, V = logits.shape
+    if out is None:
+        out = torch.empty((B,), device=logits.device, dtype=torch.int64)
+    _lib.check(_lib.load().crab_argmax(_lib.ctx(d), _stream(), _p(logits), logits.stride(0), _p(out), B, V, suppress), d)
+    return out
+
+
+def im2col_patch(x: torch.Tensor, P: int, ldo: int) -> torch.Tensor:
+    """x [N,C,H,W] fp32/bf16 contiguous -> [N*gh*gw, ldo] bf16 patches (k = c,ky,kx)."""
+    d = _dev(x)
+    x = x.contiguous()
+    N, Cc, Hh, Ww = x.shape
+    out = torch.empty((N * (Hh // P) * (Ww // P), ldo), device=x.device, dtype=BF16)
+    _lib.check(_lib.load().crab_im2col_patch(_lib.ctx(d), _stream(), _p(x), 1 if x.dtype == torch.float32 else 0, _p(out), ldo, N, Cc, Hh, Ww, P), d)
+    return out
+
+
+def clip_embed_ln(patch, cls, pos, lnw, lnb, N, P, D, eps):
+    d = _dev(patch)
+    out = torch.empty((N * (P + 1), D), device=patch.device, dtype=BF16)
+    _lib.check(_lib.load().crab_clip_embed_ln(_lib.ctx(d), _stream(), _p(patch), _p(cls), _p(pos), _p(lnw), _p(lnb), _p(out), N, P, D, eps), d)
+    return out
+
+
+def beats_posconv_pad(x: torch.Tensor, B: int, n: int, E: int, G: int, Kc: int) -> torch.Tensor:
+    d = _dev(x)
+    out = torch.empty((G, B, n + Kc - 1, E // G), device=x.device, dtype=BF16)
+    _lib.check(_lib.load().crab_beats_posconv_pad(_lib.ctx(d), _stream(), _p(x), _p(out), B, n, E, G, Kc), d)
+    return out
+
+
+def beats_relpos_bias(table: torch.Tensor, n: int, H: int, num_buckets: int, max_distance: int) -> torch.Tensor:
+    d = _dev(table)
+    out = torch.empty((H, n, n), device=table.device, dtype=torch.float32)
+    _lib.check(_lib.load().crab_beats_relpos_bias(_lib.ctx(d), _stream(), _p(table), _p(out), n, H, num_buckets, max_distance), d)
+    return out
+
+
+def beats_gru_gate(q: torch.Tensor, gw, gb, grep_a, B: int, n: int, H: int, d_: int) -> torch.Tensor:
+    d = _dev(q)
+    out = torch.empty((B, H, n), device=q.device, dtype=torch.float32)
+    _lib.check(_lib.load().crab_beats_gru_gate(_lib.ctx(d), _stream(), _p(q), q.stride(0), _p(gw), _p(gb), _p(grep_a), _p(out), B, n, H, d_), d)
+    return out
+
+
+def copy_rows(src: torch.Tensor, dst: torch.Tensor, rows: int, cols: int):
+    d = _dev(src)
+    _lib.check(_lib.load().crab_copy_rows(_lib.ctx(d), _stream(), _p(src), src.stride(0), _p(dst), dst.stride(0), rows, cols), d)
+
+
+def cast_bf16(x: torch.Tensor) -> torch.Tensor:
+    """fp32 -> bf16 on device (harness-side cast of modality inputs)."""
+    if x.dtype == BF16:
+        return x
+    d = _dev(x)
+    x = x.contiguous()
+    out = torch.empty(x.shape, device=x.device, dtype=BF16)
+    _lib.check(_lib.load().crab_cast_f32_bf16(_lib.ctx(d), _stream(), _p(x), _p(out), x.numel()), d)
+    return out
+
+
+def sync():
+    d = torch.cuda.current_device()
+    _lib.check(_lib.load().crab_sync(_lib.ctx(d), _stream()), d)

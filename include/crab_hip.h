@@ -1,0 +1,163 @@
+/*
+ * crab_hip.h -- C ABI of libcrab_hip.so, the MI355X (gfx950) forward path for Crab's multimodal
+ * inference stack.  Plain pointers and sizes only; no torch types.  All pointers are DEVICE pointers
+ * unless a parameter says "host".  Every entry point returns 0 on success or a negative CRAB_E_* code,
+ * never throws and never exits; crab_last_error() gives the message.  The library never allocates,
+ * frees or retains caller memory: inputs, outputs, KV caches and workspaces are caller-owned
+ * (SURVEY.md 8b "Ownership").  `stream` is a hipStream_t (torch.cuda.current_stream().cuda_stream).
+ *
+ * The reference (GeWu-Lab/Crab) is 100% Python and has no FFI; each entry point cites the reference
+ * module whose arithmetic it replaces, i.e. what a maintainer would bind instead of the eager
+ * PyTorch op sequence (see INTEGRATION.md for the ctypes stubs).
+ *
+ * Storage dtype is bf16 (uint16 raw bits == torch.bfloat16); accumulation and softmax/norm math are fp32.
+ */
+#ifndef CRAB_HIP_H
+#define CRAB_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CRAB_OK 0
+#define CRAB_E_INVALID (-1)   /* bad argument (shape, alignment, null pointer) */
+#define CRAB_E_HIP (-2)       /* a HIP runtime call or kernel launch failed */
+#define CRAB_E_UNSUPPORTED (-3)
+#define CRAB_E_WORKSPACE (-4) /* caller workspace too small */
+
+typedef struct crab_ctx crab_ctx;
+
+int crab_ctx_create(int device, crab_ctx** out);
+void crab_ctx_destroy(crab_ctx* ctx);
+const char* crab_last_error(crab_ctx* ctx);
+int crab_sync(crab_ctx* ctx, void* stream);
+int crab_abi_version(void);
+
+/* activation codes for epilogues */
+enum { CRAB_ACT_NONE = 0, CRAB_ACT_GELU = 1, CRAB_ACT_QUICK_GELU = 2, CRAB_ACT_RELU = 3, CRAB_ACT_SILU = 4 };
+
+/* ---------------------------------------------------------------------------------------------
+ * GEMM:  C[M,N] = res_scale * R[M,N] + act( A[M,K] . B[N,K]^T + A2[M,K2] . B2[N,K2]^T + bias[N] )
+ * A, B (and A2, B2) are K-contiguous bf16 ("x @ W^T" with W stored [out,in] exactly as
+ * torch.nn.Linear.weight).  fp32 MFMA accumulation.  C is bf16, or fp32 when c_fp32 != 0.
+ * The optional second K segment carries the hyper-LoRA update (A2 = routed rank-24 activations,
+ * B2 = concatenated lora_B), see crab_hyperlora_mix.
+ * Replaces: every nn.Linear / F.linear on the path -- peft_hyper/tuners/lora.py:341 (base linear),
+ * transformers CLIP/Llama/Qwen2 projections, models/Qformer.py dense layers, models/beats/backbone.py
+ * q/k/v/out/fc1/fc2, and the patch-embedding convolutions once im2col'ed.
+ * Batched form: z in [0,batch): z0 = z % nb0, z1 = z / nb0; X += z0*sX0 + z1*sX1 (elements).
+ * Requirements: K, K2, lda, ldb, lda2, ldb2 multiples of 8; A/B 16-byte aligned.
+ */
+typedef struct {
+    const void* A; const void* B; void* C;
+    const void* bias;  /* bf16 [N] or NULL */
+    const void* R;     /* bf16 [M,N] residual or NULL */
+    const void* A2; const void* B2; /* optional second K segment, or NULL */
+    int64_t lda, ldb, ldc, ldr, lda2, ldb2;
+    int32_t M, N, K, K2;
+    int32_t act;       /* CRAB_ACT_* applied to (acc + bias) before the residual */
+    int32_t c_fp32;
+    float res_scale;   /* multiplies R (BEATs deep-norm alpha); 1.0 for a plain residual */
+    int32_t batch, nb0;   /* batch <= 1 means unbatched */
+    int64_t sA0, sA1, sB0, sB1, sC0, sC1, sR0, sR1, sBias0, sBias1;
+} crab_gemm_desc;
+
+int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc* d);
+
+/* ---------------------------------------------------------------------------------------------
+ * hyper-LoRA routing mix (peft_hyper/tuners/lora.py:346-350).
+ * T[M, ldt] holds, for each of `nproj` projections sharing the same input x, the skinny product
+ * x.[R;A]^T : columns p*(nl+r) .. +nl-1 = route logits, then r columns of lora_A(x).
+ * Writes U[M, ldu] bf16 with U[m, p*nl*r + i*r + j] = scaling * softmax_fp32(route)_i * h_j ;
+ * columns [nproj*nl*r, ucols) are zero-filled (K padding of the second GEMM segment).
+ */
+int crab_hyperlora_mix(crab_ctx* ctx, void* stream, const void* T, int64_t ldt, int t_fp32, void* U, int64_t ldu,
+                       int M, int nproj, int nl, int r, int ucols, float scaling);
+
+/* RMSNorm (models/modeling_llama.py:112-117) and LayerNorm (torch.nn.LayerNorm) over the last dim, bf16 in/out. */
+int crab_rmsnorm(crab_ctx* ctx, void* stream, const void* x, int64_t ldx, const void* w, void* y, int64_t ldy,
+                 int M, int D, float eps);
+int crab_layernorm(crab_ctx* ctx, void* stream, const void* x, int64_t ldx, const void* w, const void* b, void* y,
+                   int64_t ldy, int M, int D, float eps);
+
+/* out[t,:] = table[ids[t],:]  (embed_tokens; unified_arch.py:213-214, unified_llama.py:125-127) */
+int crab_embedding(crab_ctx* ctx, void* stream, const int64_t* ids, const void* table, void* out, int64_t ldo,
+                   int T, int D, int vocab);
+
+/* rope table: tab[pos][i] = (cos, sin)(pos * theta^(-2i/d)), fp32 pairs, i < d/2  (modeling_llama.py:130-156) */
+int crab_rope_table(crab_ctx* ctx, void* stream, float* tab, int max_pos, int head_dim, float theta);
+
+/* Split a packed projection qkv[T, (H+2Hk)*d] (T = B*S tokens, row stride ldqkv), apply RoPE to q and k
+ * (modeling_llama.py:204-236), and scatter:
+ *   q  -> rotated in place inside qkv
+ *   k  -> k_cache[b, hk, pos, :]      (cache layout [B, Hk, Tmax, d], appended AFTER RoPE, :408-412)
+ *   v  -> v_cache[b, hk, pos, :]
+ *   v^T-> vt[b, hk, :, s]  ([B, Hk, d, vt_ld]) when vt != NULL (prefill attention operand)
+ * pos = pos0 + s, or pos_dev[0] + s when pos_dev != NULL (device-resident decode position).
+ * rope_tab == NULL skips the rotation (encoders). */
+int crab_qkv_rope_split(crab_ctx* ctx, void* stream, void* qkv, int64_t ldqkv, const float* rope_tab,
+                        void* k_cache, void* v_cache, void* vt, int64_t vt_ld, int B, int S, int H, int Hk, int d,
+                        int Tmax, int pos0, const int32_t* pos_dev);
+
+/* Encoder-side split: qkv[T, 3*H*d] -> kbuf[B,H,S,d], vt[B,H,d,vt_ld]; q stays in place (no RoPE). */
+
+/* Flash attention forward (MFMA, LDS-staged K / V^T tiles, fp32 online softmax).
+ *   O[b, i, h*d + :] = softmax_j( scale * q_i.k_j + gate[b,h,i] * bias[h,i,j] + mask ) . v_j
+ * q: element (b,h,i,:) at q + b*q_bs + h*q_hs + i*q_ss ; k likewise ; vt: (b,h,dd,j) at vt + b*vt_bs + h*vt_hs + dd*vt_ds + j
+ * H query heads, Hk key/value heads (GQA: kv head = h / (H/Hk)).  causal != 0 masks j > i + (Skv - Sq).
+ * bias (fp32 [H,Sq,Skv]) and gate (fp32 [B,H,Sq]) may be NULL.  head_dim in {64,128}.
+ * Replaces: modeling_llama.py:417-445 (prefill), CLIP / Q-Former (Qformer.py:171-277) / BEATs
+ * (backbone.py:621-670, gated relative position bias) eager attention.
+ */
+typedef struct {
+    const void* q; const void* k; const void* vt; void* o;
+    int64_t q_bs, q_hs, q_ss, k_bs, k_hs, k_ss, vt_bs, vt_hs, vt_ds, o_bs, o_ss;
+    const float* bias; const float* gate;
+    int32_t B, H, Hk, Sq, Skv, head_dim, causal;
+    float scale;
+} crab_attn_desc;
+int crab_attn_fwd(crab_ctx* ctx, void* stream, const crab_attn_desc* d);
+
+/* Decode attention: one query row per (b,h) against the KV cache [B,Hk,Tmax,d] (modeling_llama.py:394-445
+ * with q_len == 1).  ctx_len keys are visible: ctx_len = ctx_len_host, or ctx_dev[0] + ctx_len_host when
+ * ctx_dev != NULL.  q: [B, ldq] row per sequence with head h at column h*d; o likewise. */
+int crab_attn_decode(crab_ctx* ctx, void* stream, const void* q, int64_t ldq, const void* k_cache, const void* v_cache,
+                     void* o, int64_t ldo, int B, int H, int Hk, int d, int Tmax, int ctx_len_host,
+                     const int32_t* ctx_dev, float scale);
+
+/* y[M, I] = silu(gu[:, :I]) * gu[:, I:2I]   (modeling_llama.py:269; gate and up packed side by side) */
+int crab_swiglu(crab_ctx* ctx, void* stream, const void* gu, int64_t ldgu, void* y, int64_t ldy, int M, int I);
+
+/* ids[b] = argmax_v logits[b, v] (fp32, first maximum wins, like torch.argmax). suppress >= 0 masks that id. */
+int crab_argmax(crab_ctx* ctx, void* stream, const float* logits, int64_t ldl, int64_t* ids, int B, int V, int suppress);
+
+/* Non-overlapping patch im2col: in[N,C,Hh,Ww] (fp32 or bf16) -> out[N*gh*gw, ldo] bf16, k = (c*P + ky)*P + kx,
+ * token = (n, gy, gx) row-major; columns [C*P*P, ldo) zero.  CLIP: conv14/14 (HF CLIPVisionEmbeddings),
+ * BEATs: conv16/16 on [B,1,L,128] (BEATs.py:148-151; rows beyond gh*P are dropped like the conv does). */
+int crab_im2col_patch(crab_ctx* ctx, void* stream, const void* in, int in_fp32, void* out, int64_t ldo, int N, int C,
+                      int Hh, int Ww, int P);
+
+/* CLIP token assembly + pre_layrnorm: x[n,0]=cls+pos[0], x[n,1+p]=patch[n,p]+pos[1+p]; y = LN(x) */
+int crab_clip_embed_ln(crab_ctx* ctx, void* stream, const void* patch, const void* cls, const void* pos, const void* lnw,
+                       const void* lnb, void* y, int N, int P, int D, float eps);
+
+/* BEATs helpers (models/beats/backbone.py):
+ *  posconv_pad: x[B,n,E] -> xp[G][B][n+Kc-1][E/G] zero padded (Kc/2 in front), the sliding-window GEMM operand
+ *  relpos_bias: bias[h,i,j] = table[bucket(j-i)][h]   (:392-430), fp32 out
+ *  gru_gate:    gate[b,h,i] = ga*(gb*grep_a[h]-1)+2 from the un-scaled q projection (:650-662), fp32 out */
+int crab_beats_posconv_pad(crab_ctx* ctx, void* stream, const void* x, void* xp, int B, int n, int E, int G, int Kc);
+int crab_beats_relpos_bias(crab_ctx* ctx, void* stream, const void* table, float* bias, int n, int H, int num_buckets,
+                           int max_distance);
+int crab_beats_gru_gate(crab_ctx* ctx, void* stream, const void* q, int64_t ldq, const void* gw, const void* gb,
+                        const void* grep_a, float* gate, int B, int n, int H, int d);
+
+/* Strided row copy / dtype cast helpers: dst[r, 0:cols] = src[r, 0:cols] */
+int crab_copy_rows(crab_ctx* ctx, void* stream, const void* src, int64_t lds, void* dst, int64_t ldd, int rows, int cols);
+int crab_cast_f32_bf16(crab_ctx* ctx, void* stream, const float* src, void* dst, int64_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

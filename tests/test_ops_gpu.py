@@ -1,0 +1,286 @@
+"""GPU parity tests of the individual HIP kernels, called through the C-ABI (crab_amd.ops -> ctypes).
+
+Reference for each op: fp32 CPU arithmetic on the SAME bf16-rounded inputs (oracle/crab_oracle.py where a
+restatement exists, otherwise the plain torch fp32 op).  Tolerances: fp32 outputs differ only by
+accumulation order (<= 2e-3 relative to the output scale for K up to 11k); bf16 outputs additionally carry one
+rounding (2^-8 relative)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(BF)
+
+
+def _cmp(got, ref, rel=2e-2, what=""):
+    got = got.float().cpu()
+    ref = ref.float()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    assert torch.isfinite(got).all(), f"{what}: non-finite output"
+    err = (got - ref).abs().max().item()
+    scale = ref.abs().max().item() + 1e-6
+    assert err <= rel * scale, f"{what}: max err {err:.4g} vs scale {scale:.4g}"
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (16, 16, 32), (130, 200, 72), (702, 512, 1024), (257, 136, 592),
+                                   (64, 4104, 256), (300, 48, 6144), (1, 320, 128), (2056, 1024, 1024)])
+def test_gemm_shapes_fp32_out(M, N, K):
+    from crab_amd import ops
+    x, w = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=1 / math.sqrt(K))
+    y = ops.gemm(x.cuda(), w.cuda(), out_fp32=True)
+    _cmp(y, x.float() @ w.float().t(), 2e-3, f"gemm {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("act", ["none", "gelu", "quick_gelu", "relu", "silu"])
+def test_gemm_epilogue(act):
+    from crab_amd import ops
+    M, N, K = 200, 264, 328
+    x, w, b, r = _rand(M, K, seed=3), _rand(N, K, seed=4, scale=1 / math.sqrt(K)), _rand(N, seed=5), _rand(M, N, seed=6)
+    y = ops.gemm(x.cuda(), w.cuda(), bias=b.cuda(), act=act, residual=r.cuda(), res_scale=2.2133)
+    z = x.float() @ w.float().t() + b.float()
+    z = {"none": z, "gelu": F.gelu(z), "quick_gelu": z * torch.sigmoid(1.702 * z), "relu": F.relu(z), "silu": F.silu(z)}[act]
+    _cmp(y, z + 2.2133 * r.float(), 1.2e-2, act)
+    assert y.dtype == BF
+
+
+def test_gemm_second_k_segment_and_odd_ldc():
+    from crab_amd import ops
+    M, N, K, K2 = 70, 321, 128, 32           # N odd -> scalar store path
+    x, w = _rand(M, K, seed=7), _rand(N, K, seed=8, scale=0.1)
+    x2, w2 = _rand(M, K2, seed=9), _rand(N, K2, seed=10, scale=0.1)
+    y = ops.gemm(x.cuda(), w.cuda(), x2=x2.cuda(), w2=w2.cuda(), out_fp32=True)
+    _cmp(y, x.float() @ w.float().t() + x2.float() @ w2.float().t(), 2e-3, "2-seg")
+
+
+def test_gemm_batched_sliding_window():
+    """BEATs pos-conv form: overlapping A rows (lda < K), two-level batch strides."""
+    import ctypes as C
+    from crab_amd import ops, _lib
+    G, B, n, cg, Kc = 4, 3, 20, 8, 16
+    np_ = n + Kc - 1
+    xp = _rand(G, B, np_, cg, seed=11)
+    w = _rand(G, cg, Kc * cg, seed=12, scale=0.1)       # [G][co][(k,ci)]
+    bias = _rand(G * cg, seed=13)
+    res = _rand(B, n, G * cg, seed=14)
+    out = torch.empty(B, n, G * cg, dtype=BF, device="cuda")
+    xp_d, w_d, b_d, r_d = xp.cuda(), w.cuda(), bias.cuda(), res.cuda()
+    g = _lib.GemmDesc()
+    g.A, g.B, g.C, g.bias, g.R = xp_d.data_ptr(), w_d.data_ptr(), out.data_ptr(), b_d.data_ptr(), r_d.data_ptr()
+    g.lda, g.ldb, g.ldc, g.ldr = cg, Kc * cg, G * cg, G * cg
+    g.M, g.N, g.K = n, cg, Kc * cg
+    g.act, g.c_fp32, g.res_scale = 1, 0, 1.0
+    g.batch, g.nb0 = G * B, B                     # z0 = b, z1 = g
+    g.sA0, g.sA1 = np_ * cg, B * np_ * cg
+    g.sB0, g.sB1 = 0, cg * Kc * cg
+    g.sC0, g.sC1 = n * G * cg, cg
+    g.sR0, g.sR1 = n * G * cg, cg
+    g.sBias0, g.sBias1 = 0, cg
+    ops.gemm_desc(g)
+    ref = torch.empty(B, n, G * cg)
+    for gi in range(G):
+        for b in range(B):
+            A = torch.stack([xp[gi, b, t:t + Kc].reshape(-1) for t in range(n)]).float()
+            z = F.gelu(A @ w[gi].float().t() + bias[gi * cg:(gi + 1) * cg].float())
+            ref[b, :, gi * cg:(gi + 1) * cg] = z + res[b, :, gi * cg:(gi + 1) * cg].float()
+    _cmp(out, ref, 1.2e-2, "sliding-window batched gemm")
+
+
+def test_rmsnorm_layernorm():
+    from crab_amd import ops
+    from oracle import crab_oracle as O
+    for D in (128, 1024, 4096, 3584):
+        x, w, b = _rand(37, D, seed=D), (1 + 0.1 * torch.randn(D)).to(BF), (0.1 * torch.randn(D)).to(BF)
+        y = ops.rmsnorm(x.cuda(), w.cuda(), 1e-5)
+        _cmp(y, O.rmsnorm(x.float(), w.float(), 1e-5), 1e-2, f"rmsnorm {D}")
+        y = ops.layernorm(x.cuda(), w.cuda(), b.cuda(), 1e-5)
+        _cmp(y, F.layer_norm(x.float(), (D,), w.float(), b.float(), 1e-5), 1e-2, f"layernorm {D}")
+
+
+def test_embedding_swiglu_argmax_cast():
+    from crab_amd import ops
+    tab = _rand(50, 128, seed=1)
+    ids = torch.tensor([3, 49, 0, 7, 7])
+    assert torch.equal(ops.embedding(ids.cuda(), tab.cuda()).cpu(), tab[ids])
+    gu = _rand(33, 2 * 264, seed=2)
+    _cmp(ops.swiglu(gu.cuda()), F.silu(gu[:, :264].float()) * gu[:, 264:].float(), 1e-2, "swiglu")
+    lg = torch.randn(5, 32017)
+    lg[2, 100] = lg[2, 5000] = 50.0          # tie -> first index
+    assert torch.equal(ops.argmax(lg.cuda()).cpu(), lg.argmax(-1))
+    sup = int(lg[0].argmax())
+    l2 = lg.clone(); l2[:, sup] = -float("inf")
+    assert torch.equal(ops.argmax(lg.cuda(), suppress=sup).cpu(), l2.argmax(-1))
+    x = torch.randn(1000)
+    assert torch.equal(ops.cast_bf16(x.cuda()).cpu(), x.to(BF))
+
+
+def test_hyperlora_mix_matches_reference_formula():
+    from crab_amd import ops
+    M, nproj, nl, r = 19, 3, 3, 8
+    t = torch.randn(M, 40)
+    u = ops.hyperlora_mix(t.cuda(), nproj, nl, r, 96, 2.0).cpu().float()
+    ref = torch.zeros(M, 96)
+    for p in range(nproj):
+        seg = t[:, p * 11:(p + 1) * 11]
+        pr = torch.softmax(seg[:, :3], -1)
+        for i in range(3):
+            ref[:, p * 24 + i * 8:p * 24 + (i + 1) * 8] = 2.0 * pr[:, i:i + 1] * seg[:, 3:]
+    _cmp(u, ref, 1e-2, "mix")
+    assert (u[:, 72:] == 0).all()
+
+
+def test_hyperlora_linear_fused_matches_golden():
+    """Full fused path (skinny [R;A] GEMM -> mix -> two-segment GEMM) against the reference-generated fixture."""
+    from crab_amd import ops
+    from tests.util import load_fixture, weights_from_table
+    meta, A = load_fixture("hyperlora_linear")
+    W = {k: v.to(BF) for k, v in weights_from_table(meta).items()}
+    x = A["x"].reshape(-1, 128).to(BF)
+    ra = torch.cat([W["lin.lora_route.weight"], W["lin.lora_A.weight"]], 0)
+    ra = torch.cat([ra, torch.zeros(16 - ra.shape[0], 128, dtype=BF)], 0)
+    bcat = torch.cat([W[f"lin.lora_B{i}.weight"] for i in range(3)], 1)
+    bcat = torch.cat([bcat, torch.zeros(256, 8, dtype=BF)], 1)
+    t = ops.gemm(x.cuda(), ra.cuda(), out_fp32=True)
+    u = ops.hyperlora_mix(t, 1, 3, 8, 32, 2.0)
+    y = ops.gemm(x.cuda(), W["lin.weight"].cuda(), bias=W["lin.bias"].cuda(), x2=u, w2=bcat.cuda(), out_fp32=True)
+    _cmp(y, A["y"].reshape(-1, 256), 1.5e-2, "hyper-LoRA linear vs reference")
+
+
+def _attn_ref(q, k, v, scale, causal=False, bias=None):
+    # q [B,H,Sq,d], k/v [B,Hk,Skv,d]
+    B, H, Sq, d = q.shape
+    Hk, Skv = k.shape[1], k.shape[2]
+    g = H // Hk
+    k = k[:, :, None].expand(B, Hk, g, Skv, d).reshape(B, H, Skv, d)
+    v = v[:, :, None].expand(B, Hk, g, Skv, d).reshape(B, H, Skv, d)
+    a = q.float() @ k.float().transpose(2, 3) * scale
+    if bias is not None:
+        a = a + bias
+    if causal:
+        i = torch.arange(Sq)[:, None] + (Skv - Sq)
+        j = torch.arange(Skv)[None]
+        a = a.masked_fill(j > i, float("-inf"))
+    return torch.softmax(a, -1) @ v.float()
+
+
+@pytest.mark.parametrize("hd,B,H,Hk,Sq,Skv,causal", [
+    (128, 2, 4, 4, 150, 150, True), (128, 1, 4, 2, 702, 702, True), (64, 3, 2, 2, 257, 257, False),
+    (64, 2, 12, 12, 32, 256, False), (64, 2, 2, 2, 32, 48, False), (128, 1, 2, 2, 1, 70, False), (64, 1, 4, 1, 65, 129, True)])
+def test_attn_fwd(hd, B, H, Hk, Sq, Skv, causal):
+    from crab_amd import ops
+    q, k, v = _rand(B, H, Sq, hd, seed=1), _rand(B, Hk, Skv, hd, seed=2), _rand(B, Hk, Skv, hd, seed=3)
+    Sp = (Skv + 7) // 8 * 8
+    vt = torch.zeros(B, Hk, hd, Sp, dtype=BF)
+    vt[..., :Skv] = v.transpose(2, 3)
+    # q laid out token-major [B,Sq,H*hd] like a projection output; k head-major like the KV cache
+    qt = q.transpose(1, 2).reshape(B, Sq, H * hd).contiguous().cuda()
+    kd, vtd = k.cuda(), vt.cuda()
+    o = torch.zeros(B, Sq, H * hd, dtype=BF, device="cuda")
+    scale = hd ** -0.5
+    ops.attn_fwd(qt, kd, vtd, o, q_strides=(Sq * H * hd, hd, H * hd), k_strides=(Hk * Skv * hd, Skv * hd, hd),
+                 vt_strides=(Hk * hd * Sp, hd * Sp, Sp), o_strides=(Sq * H * hd, H * hd), B=B, H=H, Hk=Hk, Sq=Sq, Skv=Skv,
+                 head_dim=hd, scale=scale, causal=causal)
+    ref = _attn_ref(q, k, v, scale, causal).transpose(1, 2).reshape(B, Sq, H * hd)
+    _cmp(o, ref, 1.5e-2, "attn_fwd")
+
+
+def test_attn_fwd_gated_bias():
+    from crab_amd import ops
+    B, H, n, hd = 3, 2, 48, 64
+    q, k, v = _rand(B, H, n, hd, seed=1), _rand(B, H, n, hd, seed=2), _rand(B, H, n, hd, seed=3)
+    bias, gate = torch.randn(H, n, n), 1 + torch.rand(B, H, n)
+    vt = v.transpose(2, 3).contiguous()
+    qt = q.transpose(1, 2).reshape(B, n, H * hd).contiguous().cuda()
+    o = torch.zeros(B, n, H * hd, dtype=BF, device="cuda")
+    ops.attn_fwd(qt, k.cuda(), vt.cuda(), o, q_strides=(n * H * hd, hd, H * hd), k_strides=(H * n * hd, n * hd, hd),
+                 vt_strides=(H * hd * n, hd * n, n), o_strides=(n * H * hd, H * hd), B=B, H=H, Hk=H, Sq=n, Skv=n, head_dim=hd,
+                 scale=hd ** -0.5, bias=bias.cuda(), gate=gate.cuda())
+    ref = _attn_ref(q, k, v, hd ** -0.5, False, gate[..., None] * bias[None]).transpose(1, 2).reshape(B, n, H * hd)
+    _cmp(o, ref, 1.5e-2, "gated-bias attention")
+
+
+@pytest.mark.parametrize("hd,H,Hk", [(128, 4, 4), (64, 4, 2)])
+def test_rope_split_and_decode_attention(hd, H, Hk):
+    from crab_amd import ops
+    from oracle import crab_oracle as O
+    B, S, Tmax = 2, 37, 64
+    theta = 10000.0
+    qkv = _rand(B * S, (H + 2 * Hk) * hd, seed=5)
+    tab = ops.rope_table(Tmax, hd, theta, "cuda")
+    kc = torch.zeros(B, Hk, Tmax, hd, dtype=BF, device="cuda")
+    vc = torch.zeros_like(kc)
+    Sp = 40
+    vt = torch.zeros(B, Hk, hd, Sp, dtype=BF, device="cuda")
+    qd = qkv.cuda()
+    ops.qkv_rope_split(qd, tab, kc, vc, vt, B, S, H, Hk, hd, Tmax, pos0=0)
+    q = qkv[:, :H * hd].float().view(B, S, H, hd).transpose(1, 2)
+    k = qkv[:, H * hd:(H + Hk) * hd].float().view(B, S, Hk, hd).transpose(1, 2)
+    v = qkv[:, (H + Hk) * hd:].view(B, S, Hk, hd).transpose(1, 2)
+    cos, sin = O.rope_cos_sin(torch.arange(S)[None].expand(B, S), hd, theta)
+    qr, kr = O.apply_rope(q, k, cos, sin)
+    _cmp(qd[:, :H * hd].view(B, S, H, hd).transpose(1, 2), qr, 1e-2, "rope q")
+    _cmp(kc[:, :, :S], kr, 1e-2, "rope k -> cache")
+    assert torch.equal(vc[:, :, :S].cpu(), v)
+    assert torch.equal(vt[..., :S].cpu(), v.transpose(2, 3))
+    # decode step at position S (device-resident position word)
+    pos = torch.tensor([S], dtype=torch.int32, device="cuda")
+    q1 = _rand(B, (H + 2 * Hk) * hd, seed=6)
+    q1d = q1.cuda()
+    ops.qkv_rope_split(q1d, tab, kc, vc, None, B, 1, H, Hk, hd, Tmax, pos0=0, pos_dev=pos)
+    o = torch.zeros(B, H * hd, dtype=BF, device="cuda")
+    ops.attn_decode(q1d, kc, vc, o, B, H, Hk, hd, Tmax, 1, hd ** -0.5, ctx_dev=pos)
+    qn = q1d[:, :H * hd].cpu().view(B, 1, H, hd).transpose(1, 2)
+    ref = _attn_ref(qn, kc[:, :, :S + 1].cpu(), vc[:, :, :S + 1].cpu(), hd ** -0.5).transpose(1, 2).reshape(B, H * hd)
+    _cmp(o, ref, 1.5e-2, "decode attention")
+
+
+def test_im2col_and_clip_embed():
+    from crab_amd import ops
+    x = torch.randn(2, 3, 28, 42)
+    p = ops.im2col_patch(x.cuda(), 14, 592).cpu().float()
+    ref = F.unfold(x, 14, stride=14).transpose(1, 2).reshape(-1, 588)
+    _cmp(p[:, :588], ref.to(BF), 1e-6, "im2col")
+    assert (p[:, 588:] == 0).all()
+    # BEATs shape: [B,1,L,128] with L=98 -> 6 time patches (rows 96,97 dropped)
+    a = torch.randn(2, 1, 98, 128)
+    pa = ops.im2col_patch(a.cuda(), 16, 256).cpu().float()
+    assert pa.shape == (2 * 6 * 8, 256)
+    _cmp(pa, F.unfold(a, 16, stride=16).transpose(1, 2).reshape(-1, 256).to(BF), 1e-6, "im2col beats")
+    N, P, D = 2, 6, 128
+    patch, cls, pos, w, b = _rand(N * P, D, seed=1), _rand(D, seed=2), _rand(P + 1, D, seed=3), _rand(D, seed=4), _rand(D, seed=5)
+    y = ops.clip_embed_ln(patch.cuda(), cls.cuda(), pos.cuda(), w.cuda(), b.cuda(), N, P, D, 1e-5)
+    xx = torch.cat([cls.float().expand(N, 1, D), patch.float().view(N, P, D)], 1) + pos.float()
+    _cmp(y, F.layer_norm(xx.to(BF).float(), (D,), w.float(), b.float(), 1e-5).reshape(-1, D), 1e-2, "clip embed ln")
+
+
+def test_beats_helpers_match_golden_buckets():
+    from crab_amd import ops
+    from oracle import crab_oracle as O
+    from tests.util import load_fixture
+    meta, A = load_fixture("beats_buckets")
+    H = 12
+    table = torch.arange(320, dtype=torch.float32)[:, None].expand(320, H).contiguous().to(BF)   # exact in bf16 up to 256..
+    table = (torch.arange(320) % 251).float()[:, None].expand(320, H).contiguous().to(BF)
+    for n in (48, 96):
+        bias = ops.beats_relpos_bias(table.cuda(), n, H, 320, 800).cpu()
+        ref = (A[f"b{n}"].long() % 251).float()
+        assert torch.equal(bias[0], ref) and torch.equal(bias[H - 1], ref)
+    B, n, d = 2, 48, 64
+    q, gw, gb, ga = _rand(B * n, H * d, seed=1), _rand(8, d, seed=2, scale=0.2), _rand(8, seed=3), (1 + 0.1 * torch.randn(H)).to(BF)
+    gate = ops.beats_gru_gate(q.cuda(), gw.cuda(), gb.cuda(), ga.cuda(), B, n, H, d).cpu()
+    qh = q.float().view(B, n, H, d).transpose(1, 2)
+    gl = torch.sigmoid(F.linear(qh, gw.float(), gb.float()).view(B, H, n, 2, 4).sum(-1))
+    ref = gl[..., 0] * (gl[..., 1] * ga.float().view(1, H, 1) - 1.0) + 2.0
+    _cmp(gate, ref, 1e-4, "gru gate")
+    x = _rand(B, n, 128, seed=9)
+    xp = ops.beats_posconv_pad(x.cuda(), B, n, 128, 16, 128).cpu()
+    ref = torch.zeros(16, B, n + 127, 8, dtype=BF)
+    ref[:, :, 64:64 + n] = x.view(B, n, 16, 8).permute(2, 0, 1, 3)
+    assert torch.equal(xp, ref)
