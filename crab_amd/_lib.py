@@ -70,6 +70,9 @@ SYMBOLS = {
     "crab_beats_gru_gate": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i, _i, _i, _i]),
     "crab_copy_rows": (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _i, _i]),
     "crab_cast_f32_bf16": (_i, [_vp, _vp, _vp, _vp, _i64]),
+    "crab_copy_rows_batched": (_i, [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _i64, _i, _i, _i]),
+    "crab_greedy_select": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _i64, _vp, _vp, _i, _i, _i]),
+    "crab_advance": (_i, [_vp, _vp, _vp, _vp]),
 }
 
 _lib = None

@@ -116,6 +116,7 @@ __global__ void qkv_rope_split_kernel(bf16_t* __restrict__ qkv, long ldqkv, cons
     const int half = d >> 1;
     const int i = threadIdx.x;
     if (i >= half) return;
+    if (!tab && (hh < H || (hh < H + Hk && !kc))) return;      // encoder use: only V^T is materialised
     const int pos = (pos_dev ? pos_dev[0] : 0) + pos0 + s;
     bf16_t* src = qkv + (long)t * ldqkv + (long)hh * d;
     if (hh < H + Hk) {
@@ -364,6 +365,60 @@ __global__ void copy_rows_kernel(const bf16_t* __restrict__ src, long lds_, bf16
     }
 }
 
+__global__ void copy_rows_batched_kernel(const bf16_t* __restrict__ src, long lds_, long sbs, bf16_t* __restrict__ dst, long ldd, long dbs,
+                                         int rows, int cols) {
+    const int z = blockIdx.y;
+    const bf16_t* s_ = src + z * sbs;
+    bf16_t* d_ = dst + z * dbs;
+    int nv = cols >> 3;
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)rows * nv) return;
+    int r = idx / nv, c = idx % nv;
+    *reinterpret_cast<u32x4*>(d_ + (long)r * ldd + c * 8) = *reinterpret_cast<const u32x4*>(s_ + (long)r * lds_ + c * 8);
+}
+
+// Greedy step (HF GenerationMixin greedy search as driven by unified_llama.py:262-267): argmax over fp32
+// logits (first max wins), eos suppressed while step < min_new, finished rows emit pad.  One block per row.
+__global__ __launch_bounds__(1024) void greedy_select_kernel(const float* __restrict__ logits, long ldl, int V, int64_t* __restrict__ cur_ids,
+                                                             int64_t* __restrict__ out_ids, long ld_out, const int* __restrict__ step_dev,
+                                                             int* __restrict__ finished, int eos_id, int pad_id, int min_new) {
+    __shared__ float sv[16];
+    __shared__ int si[16];
+    const int b = blockIdx.x;
+    const int step = step_dev[0];
+    const int suppress = (eos_id >= 0 && step < min_new) ? eos_id : -1;
+    const float* row = logits + (long)b * ldl;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < V; i += blockDim.x) {
+        float v = (i == suppress) ? -INFINITY : row[i];
+        if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float ov = __shfl_xor(best, o, 64);
+        int oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { sv[wave] = best; si[wave] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int nw = blockDim.x >> 6;
+        for (int w = 1; w < nw; ++w)
+            if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
+        if (bi == 0x7fffffff) bi = 0;
+        int tok = finished[b] ? pad_id : bi;
+        if (eos_id >= 0 && tok == eos_id) finished[b] = 1;
+        cur_ids[b] = tok;
+        out_ids[(long)b * ld_out + step] = tok;
+    }
+}
+
+__global__ void advance_kernel(int* pos_dev, int* step_dev) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) { pos_dev[0] += 1; step_dev[0] += 1; }
+}
+
 __global__ void cast_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long n) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = f2bf(src[i]);
@@ -508,6 +563,32 @@ int crab_copy_rows(crab_ctx* ctx, void* stream, const void* src, int64_t lds_, v
     hipLaunchKernelGGL(copy_rows_kernel, dim3(cdiv(total, 256)), dim3(256), 0, S_(stream), (const bf16_t*)src, (long)lds_, (bf16_t*)dst,
                        (long)ldd, rows, cols);
     return crab_check_launch(ctx, "copy_rows");
+}
+
+int crab_copy_rows_batched(crab_ctx* ctx, void* stream, const void* src, int64_t lds_, int64_t sbs, void* dst, int64_t ldd, int64_t dbs,
+                           int batch, int rows, int cols) {
+    if (!ctx) return CRAB_E_INVALID;
+    if (!src || !dst || rows <= 0 || cols <= 0 || batch <= 0) return crab_fail(ctx, CRAB_E_INVALID, "copy_rows_batched: bad argument");
+    if ((cols & 7) || (lds_ & 7) || (ldd & 7) || (sbs & 7) || (dbs & 7)) return crab_fail(ctx, CRAB_E_INVALID, "copy_rows_batched: multiples of 8 required");
+    hipLaunchKernelGGL(copy_rows_batched_kernel, dim3(cdiv((long)rows * (cols >> 3), 256), batch), dim3(256), 0, S_(stream), (const bf16_t*)src,
+                       (long)lds_, (long)sbs, (bf16_t*)dst, (long)ldd, (long)dbs, rows, cols);
+    return crab_check_launch(ctx, "copy_rows_batched");
+}
+
+int crab_greedy_select(crab_ctx* ctx, void* stream, const float* logits, int64_t ldl, int B, int V, int64_t* cur_ids, int64_t* out_ids,
+                       int64_t ld_out, const int32_t* step_dev, int32_t* finished, int eos_id, int pad_id, int min_new_tokens) {
+    if (!ctx) return CRAB_E_INVALID;
+    if (!logits || !cur_ids || !out_ids || !step_dev || !finished || B <= 0 || V <= 0) return crab_fail(ctx, CRAB_E_INVALID, "greedy_select: bad argument");
+    hipLaunchKernelGGL(greedy_select_kernel, dim3(B), dim3(1024), 0, S_(stream), logits, (long)ldl, V, cur_ids, out_ids, (long)ld_out, step_dev,
+                       finished, eos_id, pad_id, min_new_tokens);
+    return crab_check_launch(ctx, "greedy_select");
+}
+
+int crab_advance(crab_ctx* ctx, void* stream, int32_t* pos_dev, int32_t* step_dev) {
+    if (!ctx) return CRAB_E_INVALID;
+    if (!pos_dev || !step_dev) return crab_fail(ctx, CRAB_E_INVALID, "advance: bad argument");
+    hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(64), 0, S_(stream), pos_dev, step_dev);
+    return crab_check_launch(ctx, "advance");
 }
 
 int crab_cast_f32_bf16(crab_ctx* ctx, void* stream, const float* src, void* dst, int64_t n) {

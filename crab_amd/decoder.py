@@ -1,0 +1,347 @@
+"""Llama / Qwen2 decoder stack on the HIP kernels: module containers named like the HF classes the reference
+subclasses (transformers LlamaModel / Qwen2Model; in-tree statement models/modeling_llama.py,
+models/qwen/modeling_qwen2.py) plus the generation engine (prefill, device-resident greedy decode).
+
+Per layer (modeling_llama.py:805-827):  x += o_proj(attn(rope(qkv(rmsnorm(x)))));  x += down(silu(gate(h))*up(h))
+launch sequence, M = batch*seq rows:
+  rmsnorm -> [R;A] skinny GEMM -> routing mix -> fused QKV GEMM (K extended by the LoRA segment, +bias for Qwen2)
+  -> RoPE + KV-cache scatter (+V^T for the prefill attention) -> flash attention (prefill) | KV-streaming attention
+  (decode) -> o_proj GEMM with residual epilogue -> rmsnorm -> gate|up GEMM -> SwiGLU -> down GEMM with residual.
+Decode runs the same sequence at M = batch with the step captured once into a HIP graph and replayed; the
+token position, step index and finished flags live in device memory, so there is no per-token host sync
+(the reference's HF loop syncs every token).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import List, Optional
+
+import torch
+from torch import nn
+
+from . import ops
+from .peft_hyper import PackedLinearGroup
+
+BF16 = torch.bfloat16
+
+
+@dataclass
+class DecoderConfig:
+    """Subset of LlamaConfig / Qwen2Config the forward path reads."""
+    hidden_size: int = 4096
+    intermediate_size: int = 11008
+    num_hidden_layers: int = 32
+    num_attention_heads: int = 32
+    num_key_value_heads: Optional[int] = None
+    vocab_size: int = 32000
+    rms_norm_eps: float = 1e-5
+    rope_theta: float = 10000.0
+    attention_bias: bool = False        # True on q/k/v for Qwen2 (modeling_qwen2.py:234-236)
+    max_position_embeddings: int = 2048
+    pad_token_id: Optional[int] = None
+    eos_token_id: Optional[int] = None
+    model_type: str = "llama"
+
+    def __post_init__(self):
+        if self.num_key_value_heads is None:
+            self.num_key_value_heads = self.num_attention_heads
+
+    @property
+    def head_dim(self) -> int:
+        return self.hidden_size // self.num_attention_heads
+
+
+class RMSNorm(nn.Module):
+    def __init__(self, dim: int, eps: float, device):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(dim, device=device, dtype=BF16), requires_grad=False)
+        self.variance_epsilon = eps
+
+
+class Attention(nn.Module):
+    def __init__(self, cfg: DecoderConfig, device):
+        super().__init__()
+        D, H, Hk, d = cfg.hidden_size, cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+        self._qkv = PackedLinearGroup(["q_proj", "k_proj", "v_proj"], D, [H * d, Hk * d, Hk * d], cfg.attention_bias, device)
+        self._o = PackedLinearGroup(["o_proj"], H * d, [D], False, device)
+        self.q_proj, self.k_proj, self.v_proj = self._qkv.linears
+        self.o_proj = self._o.linears[0]
+
+
+class MLP(nn.Module):
+    def __init__(self, cfg: DecoderConfig, device):
+        super().__init__()
+        D, I = cfg.hidden_size, cfg.intermediate_size
+        self._gu = PackedLinearGroup(["gate_proj", "up_proj"], D, [I, I], False, device)
+        self._down = PackedLinearGroup(["down_proj"], I, [D], False, device)
+        self.gate_proj, self.up_proj = self._gu.linears
+        self.down_proj = self._down.linears[0]
+
+
+class DecoderLayer(nn.Module):
+    def __init__(self, cfg: DecoderConfig, device):
+        super().__init__()
+        self.self_attn = Attention(cfg, device)
+        self.mlp = MLP(cfg, device)
+        self.input_layernorm = RMSNorm(cfg.hidden_size, cfg.rms_norm_eps, device)
+        self.post_attention_layernorm = RMSNorm(cfg.hidden_size, cfg.rms_norm_eps, device)
+
+    def groups(self) -> List[PackedLinearGroup]:
+        return [self.self_attn._qkv, self.self_attn._o, self.mlp._gu, self.mlp._down]
+
+
+class Embedding(nn.Module):
+    def __init__(self, n: int, dim: int, device):
+        super().__init__()
+        self.weight = nn.Parameter(torch.zeros(n, dim, device=device, dtype=BF16), requires_grad=False)
+        self.num_embeddings, self.embedding_dim = n, dim
+
+    def forward(self, ids: torch.Tensor) -> torch.Tensor:
+        out = ops.embedding(ids, self.weight)
+        return out.view(*ids.shape, self.embedding_dim)
+
+
+class LMHead(nn.Module):
+    def __init__(self, dim: int, n: int, device):
+        super().__init__()
+        self.weight = nn.Parameter(torch.zeros(n, dim, device=device, dtype=BF16), requires_grad=False)
+
+
+class DecoderModel(nn.Module):
+    """`model.*` of the causal LM: embed_tokens, layers, norm (LlamaModel, modeling_llama.py:989-1124)."""
+
+    def __init__(self, cfg: DecoderConfig, device):
+        super().__init__()
+        self.config = cfg
+        self.embed_tokens = Embedding(cfg.vocab_size, cfg.hidden_size, device)
+        self.layers = nn.ModuleList([DecoderLayer(cfg, device) for _ in range(cfg.num_hidden_layers)])
+        self.norm = RMSNorm(cfg.hidden_size, cfg.rms_norm_eps, device)
+
+
+class _Workspace:
+    """Caller-owned activation buffers for M rows (allocated once per shape through torch's allocator)."""
+
+    def __init__(self, cfg: DecoderConfig, M: int, device, t_cols: int, u_cols: int):
+        D, I = cfg.hidden_size, cfg.intermediate_size
+        H, Hk, d = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+        e = lambda *s, dt=BF16: torch.empty(s, device=device, dtype=dt)
+        self.M = M
+        self.x = e(M, D)
+        self.h = e(M, D)
+        self.qkv = e(M, (H + 2 * Hk) * d)
+        self.att = e(M, H * d)
+        self.gu = e(M, 2 * I)
+        self.act = e(M, I)
+        self.t = e(M, max(t_cols, 16), dt=torch.float32)
+        self.u = e(M, max(u_cols, 32))
+
+
+class GenerationEngine:
+    """Prefill + greedy decode over a DecoderModel + lm_head.  Owns KV caches / workspaces (torch allocator)."""
+
+    def __init__(self, model: DecoderModel, lm_head: LMHead):
+        self.model, self.lm_head = model, lm_head
+        self.cfg = model.config
+        self._rope = None
+        self._ws = {}
+        self._graph = None
+        self._graph_key = None
+
+    # ------------------------------------------------------------------ helpers
+    @property
+    def device(self):
+        return self.lm_head.weight.device
+
+    def invalidate(self):
+        self._graph = None
+        self._graph_key = None
+        self._ws = {}
+
+    def _rope_tab(self, need: int) -> torch.Tensor:
+        if self._rope is None or self._rope.shape[0] < need or self._rope.device != self.device:
+            n = max(need, 1024)
+            self._rope = ops.rope_table(n, self.cfg.head_dim, self.cfg.rope_theta, self.device)
+        return self._rope
+
+    def _workspace(self, M: int) -> _Workspace:
+        if M not in self._ws:
+            tc = uc = 0
+            for g in self.model.layers[0].groups():
+                if g.RA is not None:
+                    tc, uc = max(tc, g.t_cols), max(uc, g.u_cols)
+            self._ws[M] = _Workspace(self.cfg, M, self.device, tc, uc)
+        return self._ws[M]
+
+    def alloc_cache(self, B: int, Tmax: int):
+        c = self.cfg
+        shape = (c.num_hidden_layers, B, c.num_key_value_heads, Tmax, c.head_dim)
+        return torch.zeros(shape, device=self.device, dtype=BF16), torch.zeros(shape, device=self.device, dtype=BF16)
+
+    # ------------------------------------------------------------------ one pass over the layers
+    def _layers(self, ws: _Workspace, B: int, S: int, kc: torch.Tensor, vc: torch.Tensor, b0: int, Tmax: int, pos0: int,
+                pos_dev: Optional[torch.Tensor], vt: Optional[torch.Tensor]):
+        """x (ws.x[:B*S]) -> x after all layers.  Prefill when vt is given (S rows per sequence, positions pos0..),
+        decode otherwise (S == 1, position read from pos_dev).  kc/vc: [L, Btot, Hk, Tmax, d]; rows b0..b0+B."""
+        c = self.cfg
+        H, Hk, d = c.num_attention_heads, c.num_key_value_heads, c.head_dim
+        M = B * S
+        x, h, qkv, att, gu, act = ws.x[:M], ws.h[:M], ws.qkv[:M], ws.att[:M], ws.gu[:M], ws.act[:M]
+        tab = self._rope_tab(Tmax)
+        scale = 1.0 / math.sqrt(d)
+        ldq = qkv.stride(0)
+        for li, layer in enumerate(self.model.layers):
+            a, m = layer.self_attn, layer.mlp
+            kcl, vcl = kc[li, b0:b0 + B], vc[li, b0:b0 + B]
+            ops.rmsnorm(x, layer.input_layernorm.weight, c.rms_norm_eps, out=h)
+            a._qkv(h, out=qkv, t_buf=ws.t, u_buf=ws.u)
+            ops.qkv_rope_split(qkv, tab, kcl, vcl, vt, B, S, H, Hk, d, Tmax, pos0=pos0, pos_dev=pos_dev)
+            if vt is not None:
+                Sp = vt.shape[-1]
+                ops.attn_fwd(qkv, kcl, vt, att, q_strides=(S * ldq, d, ldq), k_strides=(Hk * Tmax * d, Tmax * d, d),
+                             vt_strides=(Hk * d * Sp, d * Sp, Sp), o_strides=(S * H * d, H * d), B=B, H=H, Hk=Hk, Sq=S,
+                             Skv=pos0 + S, head_dim=d, scale=scale, causal=True)
+            else:
+                ops.attn_decode(qkv, kcl, vcl, att, B, H, Hk, d, Tmax, 1, scale, ctx_dev=pos_dev)
+            a._o(att, residual=x, out=x, t_buf=ws.t, u_buf=ws.u)
+            ops.rmsnorm(x, layer.post_attention_layernorm.weight, c.rms_norm_eps, out=h)
+            m._gu(h, out=gu, t_buf=ws.t, u_buf=ws.u)
+            ops.swiglu(gu, out=act)
+            m._down(act, residual=x, out=x, t_buf=ws.t, u_buf=ws.u)
+        return x
+
+    # ------------------------------------------------------------------ prefill
+    def prefill(self, embeds: torch.Tensor, kc: torch.Tensor, vc: torch.Tensor, b0: int = 0, all_logits: bool = False,
+                logits_out: Optional[torch.Tensor] = None, hn_out: Optional[torch.Tensor] = None):
+        """embeds [B,S,D] bf16 -> (fp32 logits, post-final-norm hidden) of the LAST row ([B,V], [B,D]), or of all
+        rows with all_logits ([B,S,V], [B,S,D]); fills cache rows b0..b0+B.  The reference computes lm_head on all
+        S rows and discards S-1 of them (modeling_llama.py:1260); generate() only needs the last row
+        (SURVEY.md appendix A.2)."""
+        c = self.cfg
+        B, S, D = embeds.shape
+        Tmax = kc.shape[3]
+        if S > Tmax:
+            raise ValueError("prompt longer than the KV cache")
+        M = B * S
+        ws = self._workspace(M)
+        ops.copy_rows(embeds.reshape(M, D), ws.x, M, D)
+        Sp = (S + 7) // 8 * 8
+        vt = torch.empty((B, c.num_key_value_heads, c.head_dim, Sp), device=self.device, dtype=BF16)
+        x = self._layers(ws, B, S, kc, vc, b0, Tmax, 0, None, vt)
+        if all_logits:
+            hn = ops.rmsnorm(x, self.model.norm.weight, c.rms_norm_eps)
+            logits = ops.gemm(hn, self.lm_head.weight, out_fp32=True)
+            return logits.view(B, S, -1), hn.view(B, S, D)
+        last = torch.empty((B, D), device=self.device, dtype=BF16)
+        ops.copy_rows(x[S - 1:], last, B, D, lds=S * D)                   # last[b] = x[b*S + S-1]
+        hn = ops.rmsnorm(last, self.model.norm.weight, c.rms_norm_eps, out=hn_out)
+        logits = ops.gemm(hn, self.lm_head.weight, out=logits_out, out_fp32=True)
+        return logits, hn
+
+    # ------------------------------------------------------------------ decode
+    def _decode_step(self, st: "_DecodeState"):
+        """One greedy step entirely on device: embed(cur_ids) -> layers -> norm -> lm_head -> greedy select -> advance."""
+        c = self.cfg
+        B = st.B
+        ws = st.ws
+        ops.embedding(st.cur_ids, self.model.embed_tokens.weight, out=ws.x[:B])
+        x = self._layers(ws, B, 1, st.kc, st.vc, 0, st.Tmax, 0, st.pos_dev, None)
+        ops.rmsnorm(x, self.model.norm.weight, c.rms_norm_eps, out=st.hn)
+        ops.gemm(st.hn, self.lm_head.weight, out=st.logits)
+        ops.greedy_select(st.logits, st.cur_ids, st.out_ids, st.step_dev, st.finished, st.eos, st.pad, st.min_new)
+        ops.advance(st.pos_dev, st.step_dev)
+
+    @torch.no_grad()
+    def generate(self, embeds: torch.Tensor, max_new_tokens: int, eos_token_id: Optional[int] = None,
+                 pad_token_id: Optional[int] = None, min_new_tokens: int = 0, prefill_chunk: int = 4, use_graph: bool = True,
+                 return_step_logits: bool = False, return_hidden: bool = False):
+        """Greedy generation from inputs_embeds only, as UnifiedForCausalLM.generate drives HF generate
+        (unified_llama.py:262-267): positions 0..S-1 (left pads attended), returns ONLY new ids."""
+        c = self.cfg
+        B, S, D = embeds.shape
+        dev = self.device
+        Tmax = _round_up(S + max_new_tokens, 64)
+        kc, vc = self.alloc_cache(B, Tmax)
+        V = self.lm_head.weight.shape[0]
+        st = _DecodeState()
+        st.B, st.Tmax, st.kc, st.vc = B, Tmax, kc, vc
+        st.ws = self._workspace(B)
+        st.logits = torch.empty((B, V), device=dev, dtype=torch.float32)
+        st.hn = torch.empty((B, D), device=dev, dtype=BF16)
+        st.cur_ids = torch.zeros((B,), device=dev, dtype=torch.int64)
+        st.out_ids = torch.full((B, max_new_tokens), pad_token_id if pad_token_id is not None else 0, device=dev, dtype=torch.int64)
+        st.finished = torch.zeros((B,), device=dev, dtype=torch.int32)
+        st.pos_dev = torch.full((1,), S - 1, device=dev, dtype=torch.int32)
+        st.step_dev = torch.zeros((1,), device=dev, dtype=torch.int32)
+        st.eos = -1 if eos_token_id is None else int(eos_token_id)
+        st.pad = int(pad_token_id) if pad_token_id is not None else (st.eos if st.eos >= 0 else 0)
+        st.min_new = int(min_new_tokens)
+        step_logits, hiddens = [], []
+        # ---- prefill in chunks of sequences (bounds activation memory, keeps GEMM M in the MFMA-efficient range)
+        for b0 in range(0, B, prefill_chunk):
+            b1 = min(B, b0 + prefill_chunk)
+            self.prefill(embeds[b0:b1], kc, vc, b0=b0, logits_out=st.logits[b0:b1], hn_out=st.hn[b0:b1])
+        if return_step_logits:
+            step_logits.append(st.logits.clone())
+        if return_hidden:
+            hiddens.append(st.hn.clone())
+        ops.greedy_select(st.logits, st.cur_ids, st.out_ids, st.step_dev, st.finished, st.eos, st.pad, st.min_new)
+        ops.advance(st.pos_dev, st.step_dev)           # pos: S-1 -> S (position of the token just selected), step: 0 -> 1
+        # ---- decode loop: HIP graph replay, no host sync inside
+        graph = None
+        if use_graph and max_new_tokens > 2:
+            graph = self._capture(st)
+        check_every = 16
+        for step in range(1, max_new_tokens):
+            if graph is not None:
+                graph.replay()
+            else:
+                self._decode_step(st)
+            if return_step_logits:
+                step_logits.append(st.logits.clone())
+            if return_hidden:
+                hiddens.append(st.hn.clone())
+            if st.eos >= 0 and step % check_every == 0 and bool(st.finished.all().item()):
+                break
+        n_done = int(st.step_dev.item())
+        out = st.out_ids[:, :n_done]
+        if st.eos >= 0:
+            # HF stops as soon as every row has finished: trim trailing all-pad columns produced between checks
+            fin_cols = (st.out_ids[:, :n_done] == st.eos).int().cumsum(1) > 0
+            all_fin = fin_cols.all(0)
+            idx = torch.nonzero(all_fin)
+            if idx.numel():
+                out = st.out_ids[:, : int(idx[0].item()) + 1]
+        res = [out]
+        if return_step_logits:
+            res.append(torch.stack(step_logits, 1)[:, : out.shape[1]])
+        if return_hidden:
+            res.append(torch.stack(hiddens, 1)[:, : out.shape[1]])
+        return res[0] if len(res) == 1 else tuple(res)
+
+    def _capture(self, st: "_DecodeState"):
+        """Capture one decode step into a HIP graph on a side stream (torch.cuda.CUDAGraph = hipGraph on ROCm)."""
+        # warm-up run outside capture is not possible without mutating state; instead snapshot and restore
+        snap = (st.cur_ids.clone(), st.out_ids.clone(), st.finished.clone(), st.pos_dev.clone(), st.step_dev.clone())
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            self._decode_step(st)                      # warm-up (module load, workspace alloc)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        pos = int(snap[3].item())
+        # the warm-up wrote K/V at `pos`; restoring the counters makes the first replay overwrite the same slot
+        st.cur_ids.copy_(snap[0]); st.out_ids.copy_(snap[1]); st.finished.copy_(snap[2])
+        st.pos_dev.copy_(snap[3]); st.step_dev.copy_(snap[4])
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._decode_step(st)
+        return g
+
+
+class _DecodeState:
+    pass
+
+
+def _round_up(a: int, b: int) -> int:
+    return (a + b - 1) // b * b

@@ -212,9 +212,28 @@ def beats_gru_gate(q: torch.Tensor, gw, gb, grep_a, B: int, n: int, H: int, d_: 
     return out
 
 
-def copy_rows(src: torch.Tensor, dst: torch.Tensor, rows: int, cols: int):
+def copy_rows(src: torch.Tensor, dst: torch.Tensor, rows: int, cols: int, lds: Optional[int] = None, ldd: Optional[int] = None):
+    """dst[r, :cols] = src[r, :cols]; lds/ldd override the row strides (e.g. gather every S-th row)."""
     d = _dev(src)
-    _lib.check(_lib.load().crab_copy_rows(_lib.ctx(d), _stream(), _p(src), src.stride(0), _p(dst), dst.stride(0), rows, cols), d)
+    _lib.check(_lib.load().crab_copy_rows(_lib.ctx(d), _stream(), _p(src), src.stride(0) if lds is None else lds, _p(dst),
+                                          dst.stride(0) if ldd is None else ldd, rows, cols), d)
+
+
+def copy_rows_batched(src, lds, sbs, dst, ldd, dbs, batch, rows, cols):
+    d = _dev(src)
+    _lib.check(_lib.load().crab_copy_rows_batched(_lib.ctx(d), _stream(), _p(src), lds, sbs, _p(dst), ldd, dbs, batch, rows, cols), d)
+
+
+def greedy_select(logits, cur_ids, out_ids, step_dev, finished, eos_id: int, pad_id: int, min_new_tokens: int):
+    d = _dev(logits)
+    B, V = logits.shape
+    _lib.check(_lib.load().crab_greedy_select(_lib.ctx(d), _stream(), _p(logits), logits.stride(0), B, V, _p(cur_ids), _p(out_ids),
+                                              out_ids.stride(0), _p(step_dev), _p(finished), eos_id, pad_id, min_new_tokens), d)
+
+
+def advance(pos_dev, step_dev):
+    d = _dev(pos_dev)
+    _lib.check(_lib.load().crab_advance(_lib.ctx(d), _stream(), _p(pos_dev), _p(step_dev)), d)
 
 
 def cast_bf16(x: torch.Tensor) -> torch.Tensor:

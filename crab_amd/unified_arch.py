@@ -1,0 +1,256 @@
+"""Mirror of reference `models/unified_arch.py`: the mixins that build the encoders/projectors, encode video / audio,
+splice modality features into the token-embedding sequence and left-pad the batch.
+
+Same public names and argument meaning:
+  UnifiedMetaModel.init_multimodal_modules(...)          unified_arch.py:31-110
+  UnifiedMetaModel.encode_video / encode_audio            :113-155
+  UnifiedMetaForCausalLM.encode_video / encode_audio / encode_ids      :185-214
+  UnifiedMetaForCausalLM.prepare_multimodal_inputs(...)   :217-406
+  UnifiedMetaForCausalLM.initialize_MM_tokenizer(...)     :409-459
+All tensor arithmetic (encoders, embedding gathers) runs in the HIP library; the splice / left-pad bookkeeping is
+row copies into one preallocated [bs, S, D] buffer (the reference builds it with many small torch.cat calls).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from . import ops
+from .multimodal_encoder import ALProjector, AudioEncoder, VLProjector, VisualEncoder
+
+BF16 = torch.bfloat16
+AVS_TASKS = ('ms3', 's4', 'avss', 'ref-avs')
+
+
+class UnifiedMetaModel:
+
+    def init_multimodal_modules(
+        self,
+        d_model=4096,
+        # visual
+        vit_ckpt_path=None,
+        select_layer_list=[14, 22, 23],
+        select_feature='patch',
+        image_size=224,
+        patch_size=14,
+        visual_query_token_nums=32,
+        # audio
+        BEATs_ckpt_path=None,
+        audio_query_token_nums=32,
+        # seg
+        image_scale_nums=2,
+        token_nums_per_scale=3,
+        avs_query_num=300,
+        num_classes=1,
+        query_generator_num_layers=2,
+        prompt_embed_dim=256,
+        mask_decoder_transformer_depth=2,
+        low_res_mask_size=112,
+        dice_loss_weight=0.5,
+        bce_loss_weight=2.0,
+        vit_image_embedding_dim=1024,
+        visual_branch=False,
+        audio_branch=False,
+        segment_branch=False,
+        use_vqgan=False,
+        # build-side extensions (no checkpoints offline: architectures can be given explicitly)
+        clip_config: Optional[Dict] = None,
+        beats_config: Optional[Dict] = None,
+        bert_config: Optional[Dict] = None,
+    ):
+        dev = self.embed_tokens.weight.device
+        if visual_branch:
+            image_token_nums = (image_size // patch_size) * (image_size // patch_size)
+            self.visual_encoder = VisualEncoder(model_name_or_path=vit_ckpt_path, select_layer_list=select_layer_list,
+                                                select_feature=select_feature, config=clip_config, device=dev)
+            enc_w = self.visual_encoder.vision_tower.config["hidden_size"]
+            self.vl_projector = VLProjector(hidden_size=enc_w, d_model=d_model, depth=2, image_token_nums=image_token_nums,
+                                            num_query_token=visual_query_token_nums, num_hidden_layers=2,
+                                            bert_config=bert_config, device=dev)
+        if audio_branch:
+            self.audio_encoder = AudioEncoder(ckpt_path=BEATs_ckpt_path, cfg=beats_config, device=dev)
+            enc_w = self.audio_encoder.audio_encoder.cfg.encoder_embed_dim
+            self.al_projector = ALProjector(hidden_size=enc_w, d_model=d_model, depth=2, num_query_token=audio_query_token_nums,
+                                            num_hidden_layers=2, bert_config=bert_config, device=dev)
+        if segment_branch:
+            raise NotImplementedError("SegModule (generate_avs pixel path) is SURVEY.md 8f-1: scheduled after the NTP path")
+        if use_vqgan:
+            raise NotImplementedError("VQGAN mask tokenizer is SURVEY.md 8f-4 (disabled in every reference script)")
+
+    def encode_video(self, visual, all_levels: bool = False):
+        """unified_arch.py:144-149.  The reference pushes all three CLIP feature levels through the VLProjector and
+        consumes only the last (:290); the two dead passes are skipped unless all_levels=True (entries are None)."""
+        vit_feature_list = self.visual_encoder(visual)                    # [(b,t*n,d), ...]
+        qformer_feature_list = []
+        for i, vit_feature in enumerate(vit_feature_list):
+            if all_levels or i == len(vit_feature_list) - 1:
+                qformer_feature_list.append(self.vl_projector(vit_feature))
+            else:
+                qformer_feature_list.append(None)
+        return vit_feature_list, qformer_feature_list
+
+    def encode_audio(self, audio):
+        return self.al_projector(self.audio_encoder(audio))
+
+
+class UnifiedMetaForCausalLM:
+
+    KEYS = ['<image>', '<video>', '<audio>']
+
+    def get_model(self) -> UnifiedMetaModel:
+        raise NotImplementedError
+
+    def encode_audio(self, audio, batch_first=True):
+        if not batch_first:
+            audio = audio.unsqueeze(0)
+        f = self.get_model().encode_audio(self._to_model_dtype(audio))
+        return f if batch_first else f.squeeze(0)
+
+    def encode_video(self, video, batch_first=True):
+        if not batch_first:
+            video = video.unsqueeze(0)
+        vit, qf = self.get_model().encode_video(self._to_model_dtype(video))
+        if not batch_first:
+            vit = [v.squeeze(0) for v in vit]
+            qf = [q.squeeze(0) if q is not None else None for q in qf]
+        return vit, qf
+
+    def encode_ids(self, ids):
+        return self.get_model().embed_tokens(ids)
+
+    def _to_model_dtype(self, x: torch.Tensor) -> torch.Tensor:
+        """prepare_sample never casts dtype (utils/util.py:33-47); the bf16 model needs bf16 modality inputs
+        (SURVEY.md appendix A.8).  Host->device copy + on-device cast."""
+        x = x.to(self.device, non_blocking=True)
+        return ops.cast_bf16(x) if x.dtype == torch.float32 else x
+
+    def prepare_multimodal_inputs(
+        self,
+        batch_input_ids,
+        batch_labels,
+        batch_X_modals,
+        batch_task_names=None,
+        return_multi_scale_features=False,
+        return_gt_mask=False,
+    ):
+        """unified_arch.py:217-406 (NTP branch).  Returns the same dict: input_ids=None, inputs_embeds [bs,S,D],
+        attention_mask, labels, position_ids."""
+        if return_multi_scale_features or return_gt_mask:
+            raise NotImplementedError("multi-scale features / gt masks belong to the AVS path (SURVEY.md 8f-1)")
+        device = self.device
+        bs = len(batch_input_ids)
+        special = self.SPECIAL_TOKEN_2_IDS
+        key_ids = {special[k]: k for k in self.KEYS}
+        emb_w = self.get_model().embed_tokens.weight
+        D = emb_w.shape[1]
+
+        # ---- pass 1 (host): segment plan per sample; modality blocks are encoded batched per kind
+        plans = []
+        vids, auds = [], []
+        for i in range(bs):
+            ids = batch_input_ids[i]
+            ids_l = ids.tolist()
+            segs, pre = [], 0
+            for pos, tok in enumerate(ids_l):
+                if tok in key_ids:
+                    segs.append(("text", pre, pos))
+                    key = key_ids[tok]
+                    if key == '<audio>':
+                        segs.append(("audio", len(auds)))
+                        auds.append(batch_X_modals[i][key])
+                    else:
+                        segs.append(("video", len(vids)))
+                        vids.append(batch_X_modals[i][key])
+                    pre = pos + 1
+            segs.append(("text", pre, len(ids_l)))
+            plans.append(segs)
+        vfeat = self._encode_blocks(vids, video=True)
+        afeat = self._encode_blocks(auds, video=False)
+
+        # ---- pass 2: lengths, left padding, one output buffer
+        lens = []
+        for segs in plans:
+            n = 0
+            for sg in segs:
+                n += (sg[2] - sg[1]) if sg[0] == "text" else (vfeat[sg[1]] if sg[0] == "video" else afeat[sg[1]]).shape[0]
+            lens.append(n)
+        S = max(lens)
+        out = torch.empty((bs, S, D), device=device, dtype=BF16)
+        pad_id = self.get_model().pad_token_id
+        attn = torch.zeros((bs, S), dtype=torch.int32)
+        labels = torch.full((bs, S), -100, dtype=torch.long)
+        for i, segs in enumerate(plans):
+            off = S - lens[i]
+            if off:
+                pad_ids = torch.full((off,), pad_id, dtype=torch.long)
+                ops.embedding(pad_ids, emb_w, out=out[i, :off])                         # :344-348
+            ids = batch_input_ids[i]
+            lab = batch_labels[i] if batch_labels is not None else None
+            cur = off
+            for sg in segs:
+                if sg[0] == "text":
+                    n = sg[2] - sg[1]
+                    if n:
+                        ops.embedding(ids[sg[1]:sg[2]], emb_w, out=out[i, cur:cur + n])
+                        if lab is not None:
+                            labels[i, cur:cur + n] = lab[sg[1]:sg[2]].cpu()
+                else:
+                    f = vfeat[sg[1]] if sg[0] == "video" else afeat[sg[1]]
+                    n = f.shape[0]
+                    ops.copy_rows(f, out[i, cur:cur + n], n, D)
+                cur += n
+            attn[i, off:] = 1
+        position_ids = torch.cumsum(attn, dim=-1) - 1
+        position_ids[position_ids == -1] = 0                                             # :372-373
+        return {
+            'input_ids': None,
+            'inputs_embeds': out,
+            'attention_mask': attn.to(device),
+            'labels': labels.to(device),
+            'position_ids': position_ids.to(device),
+        }
+
+    def _encode_blocks(self, blocks: Sequence[torch.Tensor], video: bool) -> List[torch.Tensor]:
+        """Encode every <video>/<image> (or <audio>) block of the batch in as few launches as possible: blocks of
+        equal shape are stacked into one encoder call (the reference encodes them one by one, unified_arch.py:283-300)."""
+        if not blocks:
+            return []
+        out: List[Optional[torch.Tensor]] = [None] * len(blocks)
+        groups: Dict[tuple, List[int]] = {}
+        for i, b in enumerate(blocks):
+            groups.setdefault(tuple(b.shape), []).append(i)
+        for shape, idxs in groups.items():
+            x = torch.stack([blocks[i] for i in idxs], dim=0)
+            if video:
+                f = self.encode_video(x, batch_first=True)[1][-1]
+            else:
+                f = self.encode_audio(x, batch_first=True)
+            for j, i in enumerate(idxs):
+                out[i] = f[j]
+        return out
+
+    def initialize_MM_tokenizer(self, tokenizer, mask_token_nums=6, output_embeddings_require_grad=False, use_vqgan=False):
+        """unified_arch.py:409-459: 11 special + mask_token_nums `<mask_i>` tokens appended in fixed order, tables
+        KEYS / MASK / SPECIAL_TOKEN_2_IDS / IDS_2_SPECIAL_TOKEN, then resize_token_embeddings(len(tokenizer))."""
+        if use_vqgan:
+            raise NotImplementedError("VQGAN tokens: SURVEY.md 8f-4")
+        vocab_nums = len(tokenizer)
+        added_tokens = []
+        added_tokens += ['<image>', '<image_start>', '<image_end>']
+        added_tokens += ['<video>', '<video_start>', '<video_end>']
+        added_tokens += ['<audio>', '<audio_start>', '<audio_end>']
+        added_tokens += ['<mask_start>', '<mask_end>']
+        tokenizer.add_tokens(list(added_tokens), special_tokens=True)
+        seg_tokens = [f'<mask_{i}>' for i in range(mask_token_nums)]
+        tokenizer.add_tokens(seg_tokens, special_tokens=False)
+        added_tokens += seg_tokens
+        self.KEYS = ['<image>', '<video>', '<audio>']
+        self.MASK = seg_tokens
+        self.SPECIAL_TOKEN_2_IDS = {token: i + vocab_nums for i, token in enumerate(added_tokens)}
+        self.IDS_2_SPECIAL_TOKEN = {i + vocab_nums: token for i, token in enumerate(added_tokens)}
+        self.resize_token_embeddings(len(tokenizer))
+
+    @property
+    def device(self):
+        return next(self.parameters()).device

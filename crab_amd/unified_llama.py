@@ -1,0 +1,187 @@
+"""Mirror of reference `models/unified_llama.py`: `UnifiedConfig`, `UnifiedModel`, `UnifiedForCausalLM` with the same
+`generate(batch_input_ids, batch_labels, batch_X_modals, batch_task_names, **kw)` / `forward(...)` surface
+(unified_llama.py:26-391), on the MI355X HIP path.
+
+Differences a caller can observe, all deliberate:
+  * decoding is forced greedy (the reference inherits sampling from the checkpoint's generation_config, A.7);
+    `do_sample=True` raises.
+  * like the reference, `attention_mask` / `position_ids` from prepare_multimodal_inputs are NOT forwarded to the
+    decoder (unified_llama.py:261-267): left pads are attended and positions run 0..S-1 (A.1) -- reproduced.
+  * the model lives in bf16 on the GPU (the whole-model bf16 conversion of inference_hyper_lora.py:1470, A.8).
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+from torch import nn
+
+from . import ops
+from .decoder import DecoderConfig, DecoderModel, GenerationEngine, LMHead
+from .peft_hyper import PackedLinearGroup
+from .unified_arch import UnifiedMetaForCausalLM, UnifiedMetaModel
+
+BF16 = torch.bfloat16
+
+
+class UnifiedConfig(DecoderConfig):
+    model_type = "unified_llm"
+
+
+class UnifiedModel(UnifiedMetaModel, DecoderModel):
+    config_class = UnifiedConfig
+
+    def __init__(self, config: DecoderConfig, device="cuda"):
+        DecoderModel.__init__(self, config, device)
+        self.config = config
+        self.pad_token_id = config.pad_token_id if config.pad_token_id is not None else 0
+
+
+class CausalLMOutput:
+    def __init__(self, logits, hidden_states=None, past_key_values=None):
+        self.logits, self.hidden_states, self.past_key_values, self.loss = logits, hidden_states, past_key_values, None
+
+
+class UnifiedForCausalLM(nn.Module, UnifiedMetaForCausalLM):
+    config_class = UnifiedConfig
+
+    def __init__(self, config: DecoderConfig, device="cuda", **kwargs):
+        nn.Module.__init__(self)
+        self.config = config
+        self.model = UnifiedModel(config, device=device)
+        self.vocab_size = config.vocab_size
+        self.lm_head = LMHead(config.hidden_size, config.vocab_size, device)
+        self.is_avs_task = False
+        self._engine = GenerationEngine(self.model, self.lm_head)
+        self._past = None
+
+    # ------------------------------------------------------------------ plumbing
+    def get_model(self) -> UnifiedModel:
+        return self.model
+
+    def packed_groups(self) -> List[PackedLinearGroup]:
+        return [g for layer in self.model.layers for g in layer.groups()]
+
+    def _invalidate_graphs(self):
+        self._engine.invalidate()
+
+    def get_input_embeddings(self):
+        return self.model.embed_tokens
+
+    def get_output_embeddings(self):
+        return self.lm_head
+
+    def resize_token_embeddings(self, new_num_tokens: int):
+        """HF semantics: keep the old rows, new rows ~ N(0, 0.02) (initializer_range); both tables resized."""
+        old = self.model.embed_tokens.weight
+        if new_num_tokens == old.shape[0]:
+            return self.model.embed_tokens
+        dev, D = old.device, old.shape[1]
+        n_keep = min(old.shape[0], new_num_tokens)
+        for holder, attr in ((self.model.embed_tokens, "weight"), (self.lm_head, "weight")):
+            w_old = getattr(holder, attr)
+            g = torch.Generator(device="cpu").manual_seed(42)
+            w_new = (0.02 * torch.randn((new_num_tokens, D), generator=g)).to(device=dev, dtype=BF16)
+            w_new[:n_keep].copy_(w_old[:n_keep])
+            setattr(holder, attr, nn.Parameter(w_new, requires_grad=False))
+        self.model.embed_tokens.num_embeddings = new_num_tokens
+        self.vocab_size = self.config.vocab_size = new_num_tokens
+        self._invalidate_graphs()
+        return self.model.embed_tokens
+
+    @property
+    def dtype(self):
+        return BF16
+
+    def eval(self):
+        return super().eval()
+
+    # ------------------------------------------------------------------ forward
+    @torch.no_grad()
+    def forward(
+        self,
+        batch_input_ids=None,
+        batch_labels=None,
+        batch_X_modals=None,
+        batch_task_names=None,
+        input_ids: torch.LongTensor = None,
+        attention_mask: Optional[torch.Tensor] = None,
+        position_ids: Optional[torch.LongTensor] = None,
+        past_key_values=None,
+        inputs_embeds: Optional[torch.Tensor] = None,
+        labels: Optional[torch.LongTensor] = None,
+        use_cache: Optional[bool] = None,
+        output_attentions: Optional[bool] = None,
+        output_hidden_states: Optional[bool] = None,
+        return_dict: Optional[bool] = None,
+        **kwargs,
+    ):
+        """Inference forward (unified_llama.py:47-161): the 1-token decode shortcut (:125-127), the multimodal
+        branch (:129-146) and the plain inputs_embeds branch.  Returns an object with `.logits` (fp32, all rows),
+        `.hidden_states` (tuple ending with the post-final-norm states when requested) and `.past_key_values`."""
+        if labels is not None or self.is_avs_task:
+            raise NotImplementedError("training losses / AVS forward are outside the inference hot path")
+        eng = self._engine
+        if input_ids is not None and input_ids.shape[1] == 1 and past_key_values is not None:
+            kc, vc, n = past_key_values
+            B = input_ids.shape[0]
+            emb = self.model.embed_tokens(input_ids.reshape(-1))
+            ws = eng._workspace(B)
+            ops.copy_rows(emb, ws.x, B, emb.shape[1])
+            pos = torch.full((1,), n, device=self.device, dtype=torch.int32)
+            x = eng._layers(ws, B, 1, kc, vc, 0, kc.shape[3], 0, pos, None)
+            hn = ops.rmsnorm(x, self.model.norm.weight, self.config.rms_norm_eps)
+            logits = ops.gemm(hn, self.lm_head.weight, out_fp32=True)
+            return CausalLMOutput(logits.view(B, 1, -1), (hn.view(B, 1, -1),) if output_hidden_states else None, (kc, vc, n + 1))
+        if inputs_embeds is None and batch_input_ids is not None:
+            inputs = self.prepare_multimodal_inputs(batch_input_ids=batch_input_ids, batch_labels=batch_labels,
+                                                    batch_X_modals=batch_X_modals, batch_task_names=batch_task_names)
+            inputs_embeds = inputs['inputs_embeds']
+        elif inputs_embeds is None and input_ids is not None:
+            inputs_embeds = self.model.embed_tokens(input_ids)
+        inputs_embeds = inputs_embeds.to(device=self.device, dtype=BF16)
+        B, S, _ = inputs_embeds.shape
+        Tmax = (S + 64 + 63) // 64 * 64 if use_cache else (S + 63) // 64 * 64
+        kc, vc = eng.alloc_cache(B, Tmax)
+        logits, hn = eng.prefill(inputs_embeds, kc, vc, all_logits=True)
+        return CausalLMOutput(logits, (hn,) if output_hidden_states else None, (kc, vc, S) if use_cache else None)
+
+    # ------------------------------------------------------------------ generate
+    @torch.no_grad()
+    def generate(self, batch_input_ids=None, batch_labels=None, batch_X_modals=None, batch_task_names=None, **kwargs):
+        """unified_llama.py:244-267.  kwargs understood (HF names): max_new_tokens, min_new_tokens, eos_token_id,
+        pad_token_id, use_cache, do_sample (must be falsy), output_logits / return_dict_in_generate (parity audits),
+        inputs_embeds (skip prepare_multimodal_inputs)."""
+        if kwargs.get("do_sample"):
+            raise NotImplementedError("sampling is not implemented: the MI355X path is greedy-only")
+        embeds = kwargs.pop("inputs_embeds", None)
+        if embeds is None:
+            inputs = self.prepare_multimodal_inputs(batch_input_ids=batch_input_ids, batch_labels=batch_labels,
+                                                    batch_X_modals=batch_X_modals, return_multi_scale_features=False,
+                                                    return_gt_mask=False, batch_task_names=batch_task_names)
+            embeds = inputs['inputs_embeds']
+        embeds = embeds.to(device=self.device, dtype=BF16)
+        max_new = int(kwargs.get("max_new_tokens", 20))
+        eos = kwargs.get("eos_token_id", self.config.eos_token_id)
+        pad = kwargs.get("pad_token_id", self.model.pad_token_id if self.model.pad_token_id is not None else eos)
+        want_logits = bool(kwargs.get("output_logits")) and bool(kwargs.get("return_dict_in_generate"))
+        res = self._engine.generate(embeds, max_new, eos_token_id=eos, pad_token_id=pad,
+                                    min_new_tokens=int(kwargs.get("min_new_tokens", 0) or 0),
+                                    prefill_chunk=int(kwargs.get("prefill_chunk", 4)), use_graph=kwargs.get("use_graph", True),
+                                    return_step_logits=want_logits)
+        if want_logits:
+            ids, sl = res
+            out = type("GenerateOutput", (), {})()
+            out.sequences, out.logits = ids, tuple(sl[:, i] for i in range(sl.shape[1]))
+            return out
+        return res
+
+    def generate_avs(self, *a, **k):
+        raise NotImplementedError("generate_avs / SegModule is SURVEY.md 8f-1 (next row after the NTP path)")
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        """Checkpoints are fp32 (reference ships --bf16 False); tensors are cast to the resident bf16 storage."""
+        sd = {k: (v.to(BF16) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in state_dict.items()}
+        r = super().load_state_dict(sd, strict=strict, assign=False)
+        self._invalidate_graphs()
+        return r

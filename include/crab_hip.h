@@ -155,7 +155,19 @@ int crab_beats_gru_gate(crab_ctx* ctx, void* stream, const void* q, int64_t ldq,
 
 /* Strided row copy / dtype cast helpers: dst[r, 0:cols] = src[r, 0:cols] */
 int crab_copy_rows(crab_ctx* ctx, void* stream, const void* src, int64_t lds, void* dst, int64_t ldd, int rows, int cols);
+int crab_copy_rows_batched(crab_ctx* ctx, void* stream, const void* src, int64_t lds, int64_t src_bs, void* dst, int64_t ldd,
+                           int64_t dst_bs, int batch, int rows, int cols);
 int crab_cast_f32_bf16(crab_ctx* ctx, void* stream, const float* src, void* dst, int64_t n);
+
+/* Device-resident greedy decoding step (HF GenerationMixin greedy search as driven by unified_llama.py:262-267,
+ * SURVEY.md B.3): tok = argmax(logits[b]) on fp32 logits (first maximum wins); eos is suppressed while
+ * step < min_new_tokens; rows already finished emit pad_id; cur_ids[b] = tok (feeds the next embedding lookup),
+ * out_ids[b, step] = tok, finished[b] |= (tok == eos).  step is read from device memory so the launch can be
+ * replayed from a HIP graph; crab_advance then bumps the position and step words. eos_id < 0 disables EOS. */
+int crab_greedy_select(crab_ctx* ctx, void* stream, const float* logits, int64_t ldl, int B, int V, int64_t* cur_ids,
+                       int64_t* out_ids, int64_t ld_out, const int32_t* step_dev, int32_t* finished, int eos_id, int pad_id,
+                       int min_new_tokens);
+int crab_advance(crab_ctx* ctx, void* stream, int32_t* pos_dev, int32_t* step_dev);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,180 @@
+"""End-to-end GPU parity: the product modules (crab_amd.*, HIP kernels through the C-ABI) against
+  (1) the reference-generated golden fixtures (fp32 reference outputs), and
+  (2) the oracle on the same seeded weights, in fp32 and in bf16-storage emulation.
+
+Tolerances (stated per north_star "within 1e-3 bf16"; what bf16 storage can actually deliver is measured and
+written in DESIGN.md):
+  * vs the oracle emulating bf16 storage at the same points: the two paths differ only by accumulation order and
+    rare 1-ulp rounding flips -> REL_EMU of the output scale.
+  * vs the fp32 reference fixture: bf16 storage noise of the whole stack -> REL_F32 of the output scale.
+  * greedy token ids: exact wherever the fp32 reference's top-2 logit margin exceeds the measured logit error.
+"""
+import pytest
+import torch
+
+from tests.util import build_tiny_crab, load_fixture, weights_from_table, bert_cfg
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+REL_EMU = 2.5e-2
+REL_F32 = 4e-2
+
+
+def _rel(got, ref):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    assert torch.isfinite(got).all()
+    return (got - ref).abs().max().item() / (ref.abs().max().item() + 1e-9)
+
+
+def _bf(W):
+    return {k: v.to(BF).float() for k, v in W.items()}
+
+
+def test_clip_tower_vs_reference_fixture_and_oracle():
+    from crab_amd import synth
+    from crab_amd.multimodal_encoder import VisualEncoder
+    from oracle import crab_oracle as O
+    meta, A = load_fixture("clip_tiny")
+    W = weights_from_table(meta)
+    ve = VisualEncoder(select_layer_list=meta["select"], config=meta["cfg"], device="cuda")
+    missing = ve.load_state_dict({k[len("model.visual_encoder."):]: v for k, v in W.items()}, strict=False)
+    assert not missing.unexpected_keys
+    video = synth.synth_video(meta["t_v"], seed=meta["seed"], clip=meta["clip"])[None]
+    from crab_amd import ops
+    feats = ve(ops.cast_bf16(video.cuda()))
+    cfg = O.ClipConfig(**meta["cfg"], select_layers=tuple(meta["select"]))
+    emu = O.visual_encoder(video.to(BF).float(), _bf(W), cfg, emulate=BF)
+    for i in range(3):
+        assert _rel(feats[i], A[f"f{i}"]) < REL_F32, f"level {i} vs reference"
+        assert _rel(feats[i], emu[i]) < REL_EMU, f"level {i} vs bf16-emulating oracle"
+
+
+def test_beats_vs_reference_fixture_and_oracle():
+    from crab_amd import ops
+    from crab_amd.multimodal_encoder import AudioEncoder
+    from oracle import crab_oracle as O
+    meta, A = load_fixture("beats_tiny")
+    W = weights_from_table(meta)
+    ae = AudioEncoder(cfg=meta["cfg"], device="cuda")
+    r = ae.load_state_dict({k[len("model.audio_encoder."):]: v for k, v in W.items()}, strict=False)
+    assert not r.unexpected_keys and not r.missing_keys, r
+    keys = O.BeatsConfig.__dataclass_fields__.keys()
+    cfg = O.BeatsConfig(**{k: v for k, v in meta["cfg"].items() if k in keys})
+    for L in (98, 198):
+        x = A[f"x{L}"]
+        y = ae(ops.cast_bf16(x.cuda()))
+        assert _rel(y, A[f"y{L}"]) < REL_F32, f"L={L} vs reference"
+        assert _rel(y, O.beats(x.to(BF).float(), _bf(W), cfg, emulate=BF)) < REL_EMU, f"L={L} vs emulating oracle"
+
+
+def test_projectors_vs_reference_fixture():
+    from crab_amd.multimodal_encoder import ALProjector, VLProjector
+    meta, A = load_fixture("projectors_tiny")
+    W = weights_from_table(meta)
+    bc = bert_cfg(meta["qf"])
+    vl = VLProjector(hidden_size=128, image_token_nums=256, num_query_token=32, num_hidden_layers=2, d_model=meta["d_model"],
+                     depth=2, bert_config=bc, device="cuda")
+    r = vl.load_state_dict({k[len("model.vl_projector."):]: v for k, v in W.items() if k.startswith("model.vl_projector.")}, strict=False)
+    assert not r.missing_keys, r.missing_keys
+    assert _rel(vl(A["vfeat"].to(BF).cuda()), A["vout"]) < REL_F32
+    al = ALProjector(hidden_size=128, num_query_token=32, num_hidden_layers=2, d_model=meta["d_model"], depth=2, bert_config=bc,
+                     device="cuda")
+    r = al.load_state_dict({k[len("model.al_projector."):]: v for k, v in W.items() if k.startswith("model.al_projector.")}, strict=False)
+    assert not r.missing_keys, r.missing_keys
+    assert _rel(al(A["afeat"].to(BF).cuda()), A["aout"]) < REL_F32
+
+
+def _inputs(meta):
+    from crab_amd import synth
+    p = meta["prompts"]
+    return [{'<video>': synth.synth_video(p["t_v"], seed=meta["seed"], clip=c),
+             '<audio>': synth.synth_audio(p["t_a"], p["l_a"], seed=meta["seed"], clip=c)} for c in (p["clip0"], p["clip1"])]
+
+
+def _check_ids(ids, ref_ids, ref_logits, got_logits):
+    """ids must agree up to (and including) every step whose reference top-2 margin exceeds 4x the measured
+    max logit error; after a sub-margin step the sequences may legitimately diverge."""
+    err = (got_logits.float().cpu() - ref_logits).abs().max().item()
+    top2 = ref_logits.topk(2, dim=-1).values
+    margin = top2[..., 0] - top2[..., 1]
+    ids = ids.cpu()
+    for b in range(ref_ids.shape[0]):
+        for s in range(ref_ids.shape[1]):
+            if margin[b, s] <= 4 * err:
+                break
+            assert ids[b, s] == ref_ids[b, s], f"row {b} step {s}: {ids[b].tolist()} vs {ref_ids[b].tolist()} (err {err:.4f})"
+    return err
+
+
+def test_full_tiny_llama_generate_matches_reference():
+    meta, A = load_fixture("full_tiny_llama")
+    W = weights_from_table(meta)
+    model = build_tiny_crab(meta)
+    r = model.load_state_dict(W, strict=False)
+    assert not r.missing_keys, r.missing_keys[:5]
+    assert model.SPECIAL_TOKEN_2_IDS == meta["special"]
+    mods = _inputs(meta)
+    lab = [torch.full_like(A["ids0"], -100), torch.full_like(A["ids1"], -100)]
+    inp1 = model.prepare_multimodal_inputs([A["ids0"]], [lab[0]], [mods[0]], ['avqa'])
+    assert _rel(inp1["inputs_embeds"], A["embeds_bs1"]) < REL_F32
+    inp2 = model.prepare_multimodal_inputs([A["ids0"], A["ids1"]], lab, mods, ['avqa', 'avqa'])
+    assert _rel(inp2["inputs_embeds"], A["embeds_bs2"]) < REL_F32
+    assert torch.equal(inp2["position_ids"].cpu().long(), A["pos_bs2"].long())
+    assert torch.equal(inp2["attention_mask"].cpu().long(), A["mask_bs2"].long())
+    # prefill, all rows (LlamaForCausalLM.forward)
+    out = model.base_model.model(inputs_embeds=A["embeds_bs1"].to(BF).cuda(), output_hidden_states=True)
+    assert _rel(out.logits, A["prefill_logits_bs1"]) < REL_F32
+    assert _rel(out.hidden_states[-1], A["prefill_hidden_bs1"]) < REL_F32
+    # generate: public API, bs=1 and left-padded bs=2, graph replay and plain launches must agree bit for bit
+    n = meta["new_tokens"]
+    kw = dict(use_cache=True, max_new_tokens=n, do_sample=False, pad_token_id=2, eos_token_id=None,
+              output_logits=True, return_dict_in_generate=True)
+    for bs, key in ((1, "bs1"), (2, "bs2")):
+        bi = [A["ids0"], A["ids1"]][:bs]
+        r1 = model.generate(batch_input_ids=bi, batch_labels=lab[:bs], batch_X_modals=mods[:bs], batch_task_names=['avqa'] * bs, **kw)
+        r2 = model.generate(batch_input_ids=bi, batch_labels=lab[:bs], batch_X_modals=mods[:bs], batch_task_names=['avqa'] * bs,
+                            use_graph=False, **kw)
+        assert torch.equal(r1.sequences, r2.sequences), "HIP-graph replay differs from plain launches"
+        got = torch.stack(r1.logits, 1)
+        assert torch.equal(got, torch.stack(r2.logits, 1))
+        err = _check_ids(r1.sequences, A[f"ids_{key}"], A[f"logits_{key}"], got)
+        assert err < REL_F32 * A[f"logits_{key}"].abs().max().item(), err
+        plain = model.generate(batch_input_ids=bi, batch_labels=lab[:bs], batch_X_modals=mods[:bs], batch_task_names=['avqa'] * bs,
+                               use_cache=True, max_new_tokens=n, pad_token_id=2, eos_token_id=None)
+        assert torch.equal(plain, r1.sequences) and plain.shape == (bs, n)
+
+
+def test_tiny_qwen2_gqa_bias_generate_matches_reference():
+    from crab_amd.peft_hyper import LoraConfig, get_peft_model
+    from crab_amd.unified_qwen import UnifiedConfig, UnifiedForCausalLM
+    meta, A = load_fixture("decoder_tiny_qwen2")
+    W = weights_from_table(meta)
+    cfg = UnifiedConfig(**meta["dec"], attention_bias=True, pad_token_id=2)
+    model = get_peft_model(UnifiedForCausalLM(cfg, device="cuda"), LoraConfig())
+    r = model.load_state_dict(W, strict=False)
+    assert not r.missing_keys and not r.unexpected_keys, r
+    res = model.generate(inputs_embeds=A["embeds"].to(BF).cuda(), max_new_tokens=meta["new_tokens"], pad_token_id=2,
+                         eos_token_id=None, output_logits=True, return_dict_in_generate=True)
+    got = torch.stack(res.logits, 1)
+    err = _check_ids(res.sequences, A["ids"], A["logits"], got)
+    assert err < REL_F32 * A["logits"].abs().max().item(), err
+
+
+def test_eos_and_min_new_tokens_semantics():
+    """Finished rows emit pad, generation stops when every row hit EOS, min_new_tokens suppresses EOS."""
+    from oracle import crab_oracle as O
+    meta, A = load_fixture("full_tiny_llama")
+    W = weights_from_table(meta)
+    model = build_tiny_crab(meta)
+    model.load_state_dict(W, strict=False)
+    emb = A["embeds_bs2"].to(BF).cuda()
+    ref_ids = A["ids_bs2"]
+    eos = int(ref_ids[0, 3])                      # make the 4th token of row 0 the EOS
+    ids = model.generate(inputs_embeds=emb, max_new_tokens=12, eos_token_id=eos, pad_token_id=2)
+    Wo = O.strip_peft_prefix({k: v.to(BF).float() for k, v in W.items()})
+    dec = O.DecoderConfig(**meta["dec"])
+    exp, _ = O.greedy_generate(A["embeds_bs2"].to(BF).float(), Wo, dec, 12, eos_token_id=eos, pad_token_id=2, emulate=BF)
+    assert ids.shape == exp.shape and torch.equal(ids.cpu(), exp), (ids.tolist(), exp.tolist())
+    ids2 = model.generate(inputs_embeds=emb, max_new_tokens=12, eos_token_id=eos, pad_token_id=2, min_new_tokens=12)
+    assert ids2.shape[1] == 12 and not (ids2 == eos).any()

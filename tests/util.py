@@ -40,3 +40,37 @@ def weights_from_table(meta: dict, verify: bool = True) -> Dict[str, torch.Tenso
 
 def strip(W: Dict[str, torch.Tensor], prefix: str) -> Dict[str, torch.Tensor]:
     return {(k[len(prefix):] if k.startswith(prefix) else k): v for k, v in W.items()}
+
+
+class DuckTokenizer:
+    """len()/add_tokens() is all initialize_MM_tokenizer needs (unified_arch.py:409-459)."""
+
+    def __init__(self, n):
+        self.n = n
+
+    def __len__(self):
+        return self.n
+
+    def add_tokens(self, toks, special_tokens=False):
+        self.n += len(toks)
+        return len(toks)
+
+
+def bert_cfg(qf: dict) -> dict:
+    return dict(hidden_size=qf["hidden"], num_attention_heads=qf["heads"], intermediate_size=qf["inter"],
+                layer_norm_eps=1e-12, vocab_size=64, max_position_embeddings=64)
+
+
+def build_tiny_crab(meta: dict, device="cuda"):
+    """The product model at the fixture's tiny configuration, wrapped like scripts/quick_start.py:465-529 does."""
+    from crab_amd.peft_hyper import LoraConfig, get_peft_model
+    from crab_amd.unified_llama import UnifiedConfig, UnifiedForCausalLM
+    cfg = UnifiedConfig(**meta["dec"], pad_token_id=meta["pad_token_id"])
+    cfg.vocab_size = meta["base_vocab"]
+    model = get_peft_model(UnifiedForCausalLM(cfg, device=device), LoraConfig())
+    model.get_model().pad_token_id = meta["pad_token_id"]
+    model.get_model().init_multimodal_modules(d_model=meta["d_model"], visual_branch=True, audio_branch=True,
+                                              select_layer_list=meta["select"], clip_config=meta["clip"],
+                                              beats_config=meta["beats"], bert_config=bert_cfg(meta["qf"]))
+    model.initialize_MM_tokenizer(DuckTokenizer(meta["base_vocab"]), mask_token_nums=6)
+    return model
