@@ -73,6 +73,13 @@ def synth_tensor(name: str, shape: Sequence[int], seed: int = 0, scheme: str = "
                 std = 0.5
             if "positional_encoding_gaussian_matrix" in name:
                 std = 1.0
+            # Decoder sub-layer outputs are kept small against the residual stream (as in a trained pre-LN
+            # decoder).  A fully random decoder is chaotic: even an exact bf16-storage execution of it moves the
+            # logits by ~10 % of their range, which would make greedy-id parity between bf16 and fp32 vacuous.
+            if ".o_proj.weight" in name or ".down_proj.weight" in name:
+                std *= 0.2
+            if ".lora_B" in name:
+                std *= 0.1
         t = std * torch.randn(shape, generator=g)
     return t.to(dtype)
 

@@ -95,16 +95,24 @@ def _inputs(meta):
 def _check_ids(ids, ref_ids, ref_logits, got_logits):
     """ids must agree up to (and including) every step whose reference top-2 margin exceeds 4x the measured
     max logit error; after a sub-margin step the sequences may legitimately diverge."""
-    err = (got_logits.float().cpu() - ref_logits).abs().max().item()
+    ids = ids.cpu()
+    got_logits = got_logits.float().cpu()
     top2 = ref_logits.topk(2, dim=-1).values
     margin = top2[..., 0] - top2[..., 1]
-    ids = ids.cpu()
+    worst, checked, total = 0.0, 0, 0
     for b in range(ref_ids.shape[0]):
         for s in range(ref_ids.shape[1]):
-            if margin[b, s] <= 4 * err:
-                break
-            assert ids[b, s] == ref_ids[b, s], f"row {b} step {s}: {ids[b].tolist()} vs {ref_ids[b].tolist()} (err {err:.4f})"
-    return err
+            total += 1
+            # contexts are identical up to here, so the logits are comparable
+            err = (got_logits[b, s] - ref_logits[b, s]).abs().max().item()
+            worst = max(worst, err)
+            if ids[b, s] != ref_ids[b, s]:
+                assert margin[b, s] <= 2 * err, (f"row {b} step {s}: id {ids[b, s]} vs {ref_ids[b, s]} although the reference margin "
+                                                 f"{margin[b, s]:.4f} exceeds twice the logit error {err:.4f}")
+                break          # legitimately diverged at a sub-noise margin: later steps see different contexts
+            checked += 1
+    assert checked >= 0.5 * total, f"greedy-id parity covered only {checked}/{total} steps"
+    return worst
 
 
 def test_full_tiny_llama_generate_matches_reference():
@@ -163,7 +171,6 @@ def test_tiny_qwen2_gqa_bias_generate_matches_reference():
 
 def test_eos_and_min_new_tokens_semantics():
     """Finished rows emit pad, generation stops when every row hit EOS, min_new_tokens suppresses EOS."""
-    from oracle import crab_oracle as O
     meta, A = load_fixture("full_tiny_llama")
     W = weights_from_table(meta)
     model = build_tiny_crab(meta)
@@ -171,10 +178,16 @@ def test_eos_and_min_new_tokens_semantics():
     emb = A["embeds_bs2"].to(BF).cuda()
     ref_ids = A["ids_bs2"]
     eos = int(ref_ids[0, 3])                      # make the 4th token of row 0 the EOS
-    ids = model.generate(inputs_embeds=emb, max_new_tokens=12, eos_token_id=eos, pad_token_id=2)
-    Wo = O.strip_peft_prefix({k: v.to(BF).float() for k, v in W.items()})
-    dec = O.DecoderConfig(**meta["dec"])
-    exp, _ = O.greedy_generate(A["embeds_bs2"].to(BF).float(), Wo, dec, 12, eos_token_id=eos, pad_token_id=2, emulate=BF)
-    assert ids.shape == exp.shape and torch.equal(ids.cpu(), exp), (ids.tolist(), exp.tolist())
+    ids = model.generate(inputs_embeds=emb, max_new_tokens=12, eos_token_id=eos, pad_token_id=2).cpu()
+    # expected from the reference's greedy ids: rows are independent, a finished row emits pad, stop when all finished
+    exp = ref_ids.clone()
+    done_at = []
+    for b in range(exp.shape[0]):
+        hit = (exp[b] == eos).nonzero()
+        k = int(hit[0]) if hit.numel() else exp.shape[1] - 1
+        exp[b, k + 1:] = 2
+        done_at.append(k if hit.numel() else exp.shape[1] - 1)
+    exp = exp[:, : max(done_at) + 1]
+    assert ids.shape == exp.shape and torch.equal(ids, exp), (ids.tolist(), exp.tolist())
     ids2 = model.generate(inputs_embeds=emb, max_new_tokens=12, eos_token_id=eos, pad_token_id=2, min_new_tokens=12)
     assert ids2.shape[1] == 12 and not (ids2 == eos).any()
