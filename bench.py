@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""Benchmark of the Crab inference hot path on MI355X:  clips/sec, prefill + decode, AVQA-shaped clip.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 launched with torch.distributed.run,
+one rank per GPU over RCCL.  One "step" = one pass of the hot path over one batch of synthetic clips per GPU:
+encoders (CLIP ViT-L/14 on 8 frames, BEATs on ten 1-s fbank windows, both Q-Former projectors) ->
+prepare_multimodal_inputs (S = 702) -> hyper-LoRA Llama-2-7B prefill -> 256 greedy tokens (EOS suppressed) ->
+RCCL gather of {token ids, first-step logits} to rank 0.  Per-clip sharding: every rank holds a full weight
+replica and its own clips (weak scaling: clips per GPU fixed).
+
+Workload = BASELINE.json configs[1] ("AVQA eval, Llama-2-7B + BEATs + CLIP-ViT-L/14, bf16, 1xMI355X") at the shape the
+metric is quoted on (10 s clip, 8 frames, 256 output tokens, 128-token prompt).  Weights are seeded N(0,0.02)
+(no checkpoints offline), inputs synthetic and already resident in HBM when the timed region starts.
+
+The JSON line carries
+  roofline     : the dominant prefill kernel (bf16 MFMA GEMM): algorithmic FLOPs of the profiled launches / their
+                 HIP-event time, against the 2.5 PFLOP/s dense bf16 peak,
+  cpu_baseline : the CPU oracle (oracle/crab_oracle.py, fp32 PyTorch eager, kind "port") timed on this host on a bounded
+                 sample of the same workload and extrapolated linearly in layers / frames / tokens (rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = 2500.0        # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def flops_per_clip(T_v=8, T_a=10, n_a=48, S=702, V=32017):
+    """SURVEY.md 8d parametric form (minimal work)."""
+    f_beats = 12 * 0.687e9 * (n_a / 48) + 0.453e9 + 0.050e9
+    return (T_v * (155.3e9 + 4.0e9) + T_a * (f_beats + 2.57e9) + S * (2 * 6.476e9 + 90.3e6) + 2 * S * S * 131072 + 2 * V * 4096)
+
+
+def decode_bytes_per_step(B, ctx, V=32017):
+    return (6.476e9 + V * 4096) * 2 + 45e6 * 2 + B * 2 * 32 * 4096 * 2 * ctx
+
+
+def cpu_baseline(args):
+    """Bounded CPU sample (target ~10-30 s): 1 CLIP frame (23 layers), 1 BEATs segment, both projectors on 1 block,
+    a 2-layer full-width decoder: prefill S=702 + 4 decode tokens.  Extrapolation: x8 frames, x10 segments,
+    x(32/2) layers, x(256/4) tokens; lm_head timed once per token."""
+    from crab_amd import synth
+    from oracle import crab_oracle as O
+    torch.manual_seed(0)
+    nth = torch.get_num_threads()
+    g = torch.Generator().manual_seed(1)
+
+    def rnd(*s):
+        return torch.randn(*s, generator=g) * 0.02
+
+    t = {}
+    # --- CLIP 1 frame
+    D, I = 1024, 4096
+    W = {}
+    p = "model.visual_encoder.vision_tower.vision_model"
+    W[p + ".embeddings.patch_embedding.weight"] = rnd(D, 3, 14, 14)
+    W[p + ".embeddings.class_embedding"] = rnd(D)
+    W[p + ".embeddings.position_embedding.weight"] = rnd(257, D)
+    for n in ("pre_layrnorm",):
+        W[f"{p}.{n}.weight"], W[f"{p}.{n}.bias"] = torch.ones(D), torch.zeros(D)
+    for i in range(23):
+        q = f"{p}.encoder.layers.{i}"
+        for n, (o, k) in {"self_attn.q_proj": (D, D), "self_attn.k_proj": (D, D), "self_attn.v_proj": (D, D), "self_attn.out_proj": (D, D),
+                          "mlp.fc1": (I, D), "mlp.fc2": (D, I)}.items():
+            W[f"{q}.{n}.weight"], W[f"{q}.{n}.bias"] = rnd(o, k), torch.zeros(o)
+        for n in ("layer_norm1", "layer_norm2"):
+            W[f"{q}.{n}.weight"], W[f"{q}.{n}.bias"] = torch.ones(D), torch.zeros(D)
+    cc = O.ClipConfig()
+    video = synth.synth_video(1)[None]
+    t0 = time.perf_counter(); feats = O.visual_encoder(video, W, cc); t["clip_frame"] = time.perf_counter() - t0
+    del W
+    # --- decoder, 2 layers full width
+    dec = O.DecoderConfig(num_hidden_layers=2)
+    Wd = {"model.embed_tokens.weight": rnd(dec.vocab_size, 4096), "lm_head.weight": rnd(dec.vocab_size, 4096),
+          "model.norm.weight": torch.ones(4096)}
+    for i in range(2):
+        q = f"model.layers.{i}"
+        Wd[q + ".input_layernorm.weight"] = torch.ones(4096)
+        Wd[q + ".post_attention_layernorm.weight"] = torch.ones(4096)
+        for n, (o, k) in {"self_attn.q_proj": (4096, 4096), "self_attn.k_proj": (4096, 4096), "self_attn.v_proj": (4096, 4096),
+                          "self_attn.o_proj": (4096, 4096), "mlp.gate_proj": (11008, 4096), "mlp.up_proj": (11008, 4096),
+                          "mlp.down_proj": (4096, 11008)}.items():
+            Wd[f"{q}.{n}.weight"] = rnd(o, k)
+            Wd[f"{q}.{n}.lora_route.weight"], Wd[f"{q}.{n}.lora_A.weight"] = rnd(3, k), rnd(8, k)
+            for j in range(3):
+                Wd[f"{q}.{n}.lora_B{j}.weight"] = rnd(o, 8)
+    emb = rnd(1, 702, 4096) * 50
+    t0 = time.perf_counter(); logits, hn, cache = O.decoder_forward(emb, Wd, dec, last_only=True); t["prefill_2l"] = time.perf_counter() - t0
+    e1 = rnd(1, 1, 4096) * 50
+    t0 = time.perf_counter()
+    for _ in range(4):
+        logits, hn, cache = O.decoder_forward(e1, Wd, dec, cache, last_only=True)
+    t["decode4_2l"] = time.perf_counter() - t0
+    h = rnd(1, 4096)
+    t0 = time.perf_counter(); _ = torch.nn.functional.linear(h, Wd["lm_head.weight"]); t["lm_head"] = time.perf_counter() - t0
+    del Wd
+    # lm_head is inside decoder_forward timings (last row): separate it out before scaling by layers
+    pre = (t["prefill_2l"] - t["lm_head"]) * 16 + t["lm_head"]
+    dec_tok = (t["decode4_2l"] / 4 - t["lm_head"]) * 16 + t["lm_head"]
+    # encoders: BEATs + projectors are ~8 % of encoder FLOPs; scale the CLIP time by the FLOP ratio
+    enc = t["clip_frame"] * 8 * (1.242 + 0.0875 + 0.032 + 0.0257) / 1.242
+    per_clip = enc + pre + 256 * dec_tok
+    return {"value": 1.0 / per_clip, "unit": "clips/s", "cores": nth, "kind": "port",
+            "sample": ("oracle fp32 eager: 1 CLIP frame x23 layers (x8, +7.5% for BEATs/Q-Formers by FLOPs), 2-layer full-width "
+                       "hyper-LoRA decoder prefill S=702 (x16 layers) and 4 decode tokens (x64 tokens, x16 layers); "
+                       f"raw s: {json.dumps({k: round(v, 3) for k, v in t.items()})}")}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--clips", type=int, default=int(os.environ.get("CRAB_BENCH_CLIPS", "32")), help="clips per GPU per step")
+    ap.add_argument("--new-tokens", type=int, default=256)
+    ap.add_argument("--frames", type=int, default=8)
+    ap.add_argument("--prefill-chunk", type=int, default=4)
+    ap.add_argument("--llm", default="llama")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    from crab_amd import ops, synth
+    from crab_amd.build_model import build_crab
+    from crab_amd.parallel import gather_results
+
+    model = build_crab(args.llm, device=torch.device("cuda", local), seed=42)
+    um = model.base_model.model
+    tab = um.SPECIAL_TOKEN_2_IDS
+    B = args.clips
+    clip0 = rank * B
+    ids = [synth.synth_prompt_ids(128, model.base_vocab, tab, clip=clip0 + i) for i in range(B)]
+    mods = [{'<video>': synth.synth_video(args.frames, clip=clip0 + i).cuda(), '<audio>': synth.synth_audio(10, 98, clip=clip0 + i).cuda()}
+            for i in range(B)]
+    lab = [torch.full_like(i, -100) for i in ids]
+    ids = [i.cuda() for i in ids]
+    eos = um.config.eos_token_id
+    V = um.lm_head.weight.shape[0]
+
+    def step():
+        out = model.generate(batch_input_ids=ids, batch_labels=lab, batch_X_modals=mods, batch_task_names=['avqa'] * B,
+                             use_cache=True, max_new_tokens=args.new_tokens, min_new_tokens=args.new_tokens, eos_token_id=eos,
+                             pad_token_id=um.model.pad_token_id, prefill_chunk=args.prefill_chunk, output_logits=False)
+        return gather_results(out, clip0, world, rank)
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    prof = ops.GemmProfiler(min_m=512)
+    ops.PROFILER = prof
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    sync()
+    dt = time.perf_counter() - t0
+    ops.PROFILER = None
+    if dist is not None:
+        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    psum = prof.summary()
+
+    if rank == 0:
+        n_clips = world * B * args.steps
+        S = 126 + 32 * args.frames + 320
+        dom = max(psum.items(), key=lambda kv: kv[1]["ms"]) if psum else None
+        roof = None
+        if dom:
+            ach = dom[1]["flops"] / (dom[1]["ms"] * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": dom[0], "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None, "launches": dom[1]["launches"],
+                    "avg_launch_us": round(dom[1]["ms"] * 1e3 / dom[1]["launches"], 1)}
+        line = {
+            "metric": "clips/sec prefill+decode (AVQA 10s clip, 8 frames, 256 out tok)",
+            "value": round(n_clips / dt, 4), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic (seeded N(0,0.02) weights, synthetic 8x224x224 frames, 10x98x128 fbank, 128-token prompt)",
+            "config": {"workload": "AVQA eval, Llama-2-7B + BEATs + CLIP-ViT-L/14, bf16 (BASELINE configs[1])", "clips_per_gpu_per_step": B,
+                       "frames": args.frames, "audio_segments": 10, "prompt_tokens": 128, "prefill_len": S, "new_tokens": args.new_tokens,
+                       "decode": "greedy, EOS suppressed, device-resident HIP-graph loop", "parallelism": f"per-clip x{world}, RCCL gather"},
+            "prefill_tflop_per_clip": round(flops_per_clip(args.frames, 10, 48, S, V) / 1e12, 3),
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(args)
+            except Exception as e:      # the GPU number must still be reported
+                line["cpu_baseline"] = {"value": None, "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
+                                        "sample": f"failed: {type(e).__name__}: {e}"}
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -37,6 +37,34 @@ def _chk_bf16(*ts):
             raise _lib.CrabHipError(f"expected bfloat16 storage, got {t.dtype}")
 
 
+class GemmProfiler:
+    """Optional HIP-event timing of GEMM launches on the current stream (bench.py roofline leg).  Only used outside
+    graph capture; adds two event records per profiled launch.  Launches are bucketed by kernel variant."""
+
+    def __init__(self, min_m: int = 512):
+        self.min_m = min_m
+        self.records = []          # (variant, flops, start_event, end_event)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for variant, flops, e0, e1 in self.records:
+            d = out.setdefault(variant, {"launches": 0, "flops": 0.0, "ms": 0.0})
+            d["launches"] += 1
+            d["flops"] += flops
+            d["ms"] += e0.elapsed_time(e1)
+        return out
+
+
+PROFILER: Optional[GemmProfiler] = None
+
+
+def _variant(M: int, N: int, batch: int = 1) -> str:
+    """Mirror of the tile choice in csrc/gemm.hip (crab_gemm_bf16)."""
+    big = ((M + 127) // 128) * ((N + 127) // 128) * batch
+    return "gemm_bt_kernel<64,64>" if (M <= 64 or N <= 64 or big < 192) else "gemm_bt_kernel<128,128>"
+
+
 def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act: str = "none",
          residual: Optional[torch.Tensor] = None, res_scale: float = 1.0, x2: Optional[torch.Tensor] = None,
          w2: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, out_fp32: bool = False) -> torch.Tensor:
@@ -62,6 +90,14 @@ def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     g.c_fp32 = 1 if out.dtype == torch.float32 else 0
     g.res_scale = res_scale
     g.batch, g.nb0 = 1, 1
+    prof = PROFILER
+    if prof is not None and M >= prof.min_m and not torch.cuda.is_current_stream_capturing():
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.check(_lib.load().crab_gemm_bf16(_lib.ctx(d), _stream(), C.byref(g)), d)
+        e1.record()
+        prof.records.append((_variant(M, N), 2.0 * M * N * (K + (x2.shape[1] if x2 is not None else 0)), e0, e1))
+        return out
     _lib.check(_lib.load().crab_gemm_bf16(_lib.ctx(d), _stream(), C.byref(g)), d)
     return out
 
