@@ -186,6 +186,8 @@ __global__ __launch_bounds__(256) void gemm_bt_kernel(GemmP p) {
 #undef LSTORE
 }  // namespace
 
+int crab_gemm_skinny_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* d);   // skinny.hip
+
 extern "C" int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc* d) {
     if (!ctx) return CRAB_E_INVALID;
     if (!d || !d->A || !d->B || !d->C) return crab_fail(ctx, CRAB_E_INVALID, "gemm: null operand");
@@ -199,6 +201,7 @@ extern "C" int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc*
         if (((uintptr_t)d->A2 & 15) || ((uintptr_t)d->B2 & 15)) return crab_fail(ctx, CRAB_E_INVALID, "gemm: A2/B2 alignment");
         if (d->batch > 1) return crab_fail(ctx, CRAB_E_UNSUPPORTED, "gemm: second K segment is not batched");
     }
+    if (d->batch <= 1 && d->M <= 128) return crab_gemm_skinny_launch(ctx, (hipStream_t)stream, d);   // weight-streaming regime
     GemmP p;
     p.A = (const bf16_t*)d->A; p.B = (const bf16_t*)d->B; p.C = d->C;
     p.bias = (const bf16_t*)d->bias; p.R = (const bf16_t*)d->R;

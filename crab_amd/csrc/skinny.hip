@@ -1,0 +1,233 @@
+// Weight-streaming kernels for the decode regime (M = clips in flight, <= 128 rows) and for the hyper-LoRA
+// router, where the work is HBM-bound on the weight matrix and a tiled GEMM grid cannot fill 256 CUs.
+//
+// gemm_skinny_kernel<MT>:  C[M,N] = res_scale*R + act(A.B^T + A2.B2^T + bias),  M <= 16*MT.
+//   One block per 16 weight rows (N/16 blocks: 256 for N=4096, i.e. one per CU, 768/1376/2001 for the wider
+//   projections), 8 waves per block splitting K between them.  Each wave streams its K-slice of the 16 weight
+//   rows straight into MFMA A-fragments (global_load_dwordx4, no LDS: every weight byte is used exactly once) and
+//   the matching activation columns into B-fragments (L2-resident, M*K*2 bytes), accumulating 16 x 16*MT fp32.
+//   The 8 partial tiles are reduced through LDS and the epilogue (bias, activation, residual, bf16/fp32 store)
+//   runs once.  No split-K partials ever travel through HBM and the summation order is fixed (deterministic).
+//
+// lora_t_partial_kernel + lora_mix_reduce_kernel: the hyper-LoRA router
+//   T = x.[R;A]^T (N <= 48) is far too skinny for either GEMM grid; it is split over K into `nslices` partial
+//   products (grid nslices x M/64), and the second kernel sums the slices in a fixed order, applies the fp32
+//   softmax over the route logits and writes U = scaling * p_i * h_j in bf16 (peft_hyper/tuners/lora.py:346-350).
+#include "common.h"
+#include "crab_internal.h"
+
+namespace {
+
+struct SkinnyP {
+    const bf16_t* A; const bf16_t* B; void* C; const bf16_t* bias; const bf16_t* R;
+    const bf16_t* A2; const bf16_t* B2;
+    long lda, ldb, ldc, ldr, lda2, ldb2;
+    int M, N, K, K2, act, c_fp32;
+    float res_scale;
+};
+
+constexpr int SK_WAVES = 8;
+
+template <int MT>
+__global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(SkinnyP p) {
+    __shared__ __attribute__((aligned(16))) float red[SK_WAVES][MT][64][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int nrow = min(n0 + fr, p.N - 1);                       // clamped: rows >= N are computed but never stored
+
+    const int ks1 = (p.K + 31) >> 5;
+    const int ks2 = p.A2 ? (p.K2 + 31) >> 5 : 0;
+    const int ks = ks1 + ks2;
+    const int s_begin = (int)((long)ks * wave / SK_WAVES), s_end = (int)((long)ks * (wave + 1) / SK_WAVES);
+
+    f32x4_t acc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    int mrow[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) mrow[i] = min(i * 16 + fr, p.M - 1);
+
+    const u32x4 z4 = {0u, 0u, 0u, 0u};
+    constexpr int U = 4;                                           // k-steps in flight per wave
+    for (int s = s_begin; s < s_end; s += U) {
+        u32x4 wv[U], xv[U][MT];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int st = s + u;
+            const bool live = st < s_end;
+            const bool seg2 = live && st >= ks1;
+            const bf16_t* Bp = seg2 ? p.B2 : p.B;
+            const bf16_t* Ap = seg2 ? p.A2 : p.A;
+            const long lb = seg2 ? p.ldb2 : p.ldb, la = seg2 ? p.lda2 : p.lda;
+            const int Kseg = seg2 ? p.K2 : p.K;
+            const int k = ((seg2 ? st - ks1 : st) << 5) + fg * 8;
+            const bool ok = live && k < Kseg;
+            const int kc = ok ? k : 0;
+            u32x4 w = *reinterpret_cast<const u32x4*>(Bp + (long)nrow * lb + kc);
+            wv[u] = ok ? w : z4;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) xv[u][i] = *reinterpret_cast<const u32x4*>(Ap + (long)mrow[i] * la + kc);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            union { u32x4 r; bf16x8_t f; } wf;
+            wf.r = wv[u];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                union { u32x4 r; bf16x8_t f; } xf;
+                xf.r = xv[u][i];
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf.f, xf.f, acc[i], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) *reinterpret_cast<f32x4_t*>(&red[wave][i][lane][0]) = acc[i];
+    __syncthreads();
+
+    // reduce over waves in fixed order + epilogue: thread -> (m-tile i, lane l): row m = 16i + (l&15), cols n0 + 4*(l>>4) + r
+    for (int idx = tid; idx < MT * 64; idx += SK_WAVES * 64) {
+        const int i = idx >> 6, l = idx & 63;
+        const int m = i * 16 + (l & 15);
+        const int n = n0 + (l >> 4) * 4;
+        if (m >= p.M || n >= p.N) continue;
+        f32x4_t v = *reinterpret_cast<const f32x4_t*>(&red[0][i][l][0]);
+#pragma unroll
+        for (int w = 1; w < SK_WAVES; ++w) v += *reinterpret_cast<const f32x4_t*>(&red[w][i][l][0]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (n + r >= p.N) break;
+            float x = v[r];
+            if (p.bias) x += bf2f(p.bias[n + r]);
+            x = apply_act(x, p.act);
+            if (p.R) x += p.res_scale * bf2f(p.R[(long)m * p.ldr + n + r]);
+            if (p.c_fp32) reinterpret_cast<float*>(p.C)[(long)m * p.ldc + n + r] = x;
+            else reinterpret_cast<bf16_t*>(p.C)[(long)m * p.ldc + n + r] = f2bf(x);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- hyper-LoRA router
+// grid (nslices, ceil(M/64)); 4 waves, wave w owns rows 16w..16w+15 of the block's 64; all waves share the K slice.
+template <int NT>
+__global__ __launch_bounds__(256) void lora_t_partial_kernel(const bf16_t* __restrict__ X, long ldx, const bf16_t* __restrict__ RA, long ldra,
+                                                             float* __restrict__ part, int M, int K, int kslice) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int sl = blockIdx.x;
+    const int m0 = blockIdx.y * 64 + wave * 16;
+    if (m0 >= M) return;
+    const int mrow = min(m0 + fr, M - 1);
+    const int k_begin = sl * kslice, k_end = min(K, k_begin + kslice);
+    f32x4_t acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const u32x4 z4 = {0u, 0u, 0u, 0u};
+    for (int k0 = k_begin; k0 < k_end; k0 += 32) {
+        const int k = k0 + fg * 8;
+        const bool ok = k < k_end;
+        const int kc = ok ? k : 0;
+        union { u32x4 r; bf16x8_t f; } xf;
+        xf.r = *reinterpret_cast<const u32x4*>(X + (long)mrow * ldx + kc);
+        if (!ok) xf.r = z4;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            union { u32x4 r; bf16x8_t f; } wf;
+            wf.r = *reinterpret_cast<const u32x4*>(RA + (long)(j * 16 + fr) * ldra + kc);
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf.f, xf.f, acc[j], 0, 0, 0);
+        }
+    }
+    // D[row = t-col 4fg+r][col = m fr]; part layout [slice][m][NT*16]
+    const int m = m0 + fr;
+    if (m < M) {
+        float* o = part + ((long)sl * M + m) * (NT * 16);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) *reinterpret_cast<f32x4_t*>(o + j * 16 + fg * 4) = acc[j];
+    }
+}
+
+__global__ void lora_mix_reduce_kernel(const float* __restrict__ part, int nslices, int tcols, bf16_t* __restrict__ U, long ldu, int M,
+                                       int nproj, int nl, int r, int ucols, float scaling) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int per_row = nproj + 1;
+    if (idx >= M * per_row) return;
+    const int m = idx / per_row, pj = idx % per_row;
+    bf16_t* u = U + (long)m * ldu;
+    const int used = nproj * nl * r;
+    if (pj == nproj) {
+        for (int c = used; c < ucols; ++c) u[c] = 0;
+        return;
+    }
+    float t[16];
+    const int w = nl + r;                                         // <= 16 (checked on the host)
+    for (int c = 0; c < w; ++c) t[c] = 0.f;
+    for (int s = 0; s < nslices; ++s) {                           // fixed summation order
+        const float* q = part + ((long)s * M + m) * tcols + pj * w;
+        for (int c = 0; c < w; ++c) t[c] += q[c];
+    }
+    float mx = -INFINITY;
+    for (int i = 0; i < nl; ++i) mx = fmaxf(mx, t[i]);
+    float sum = 0.f;
+    for (int i = 0; i < nl; ++i) { t[i] = expf(t[i] - mx); sum += t[i]; }
+    const float inv = 1.0f / sum;
+    for (int i = 0; i < nl; ++i)
+        for (int j = 0; j < r; ++j) u[pj * nl * r + i * r + j] = f2bf(scaling * t[i] * inv * t[nl + j]);
+}
+
+}  // namespace
+
+// called from crab_gemm_bf16 (gemm.hip) for unbatched problems with M <= 128
+int crab_gemm_skinny_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* d) {
+    SkinnyP p;
+    p.A = (const bf16_t*)d->A; p.B = (const bf16_t*)d->B; p.C = d->C; p.bias = (const bf16_t*)d->bias; p.R = (const bf16_t*)d->R;
+    p.A2 = (const bf16_t*)d->A2; p.B2 = (const bf16_t*)d->B2;
+    p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc; p.ldr = d->ldr; p.lda2 = d->lda2; p.ldb2 = d->ldb2;
+    p.M = d->M; p.N = d->N; p.K = d->K; p.K2 = d->A2 ? d->K2 : 0; p.act = d->act; p.c_fp32 = d->c_fp32; p.res_scale = d->res_scale;
+    dim3 grid((d->N + 15) / 16), block(SK_WAVES * 64);
+    if (d->M <= 16) hipLaunchKernelGGL((gemm_skinny_kernel<1>), grid, block, 0, s, p);
+    else if (d->M <= 32) hipLaunchKernelGGL((gemm_skinny_kernel<2>), grid, block, 0, s, p);
+    else if (d->M <= 64) hipLaunchKernelGGL((gemm_skinny_kernel<4>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((gemm_skinny_kernel<8>), grid, block, 0, s, p);
+    return crab_check_launch(ctx, "gemm_skinny_kernel");
+}
+
+extern "C" int64_t crab_hyperlora_route_workspace(int M, int K, int tcols) {
+    int mblocks = (M + 63) / 64;
+    int nslices = 256 / (mblocks > 0 ? mblocks : 1);
+    int maxs = (K + 127) / 128;
+    if (nslices > maxs) nslices = maxs;
+    if (nslices < 1) nslices = 1;
+    if (nslices > 64) nslices = 64;
+    return (int64_t)nslices * M * tcols * (int64_t)sizeof(float);
+}
+
+extern "C" int crab_hyperlora_route(crab_ctx* ctx, void* stream, const void* X, int64_t ldx, const void* RA, int64_t ldra, int M, int K,
+                                    int nproj, int nl, int r, void* U, int64_t ldu, int ucols, float scaling, void* workspace,
+                                    int64_t workspace_bytes) {
+    if (!ctx) return CRAB_E_INVALID;
+    if (!X || !RA || !U || !workspace || M <= 0 || K <= 0 || (K & 7) || (ldx & 7) || (ldra & 7))
+        return crab_fail(ctx, CRAB_E_INVALID, "hyperlora_route: bad argument");
+    if (nl + r > 16 || nproj < 1 || nproj > 3 || ucols < nproj * nl * r) return crab_fail(ctx, CRAB_E_UNSUPPORTED, "hyperlora_route: nl+r <= 16, nproj <= 3");
+    const int tcols = ((nproj * (nl + r) + 15) / 16) * 16;        // RA must hold tcols rows (zero padded)
+    if (crab_hyperlora_route_workspace(M, K, tcols) > workspace_bytes) return crab_fail(ctx, CRAB_E_WORKSPACE, "hyperlora_route: workspace too small");
+    int mblocks = (M + 63) / 64;
+    int nslices = 256 / mblocks;
+    int maxs = (K + 127) / 128;
+    if (nslices > maxs) nslices = maxs;
+    if (nslices < 1) nslices = 1;
+    if (nslices > 64) nslices = 64;
+    int kslice = (((K + nslices - 1) / nslices) + 31) / 32 * 32;
+    nslices = (K + kslice - 1) / kslice;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(nslices, mblocks), block(256);
+    float* part = (float*)workspace;
+    const int NT = tcols / 16;
+    if (NT == 1) hipLaunchKernelGGL((lora_t_partial_kernel<1>), grid, block, 0, s, (const bf16_t*)X, (long)ldx, (const bf16_t*)RA, (long)ldra, part, M, K, kslice);
+    else if (NT == 2) hipLaunchKernelGGL((lora_t_partial_kernel<2>), grid, block, 0, s, (const bf16_t*)X, (long)ldx, (const bf16_t*)RA, (long)ldra, part, M, K, kslice);
+    else hipLaunchKernelGGL((lora_t_partial_kernel<3>), grid, block, 0, s, (const bf16_t*)X, (long)ldx, (const bf16_t*)RA, (long)ldra, part, M, K, kslice);
+    int rc = crab_check_launch(ctx, "lora_t_partial_kernel");
+    if (rc) return rc;
+    unsigned blocks = (unsigned)(((long)M * (nproj + 1) + 255) / 256);
+    hipLaunchKernelGGL(lora_mix_reduce_kernel, dim3(blocks), dim3(256), 0, s, part, nslices, tcols, (bf16_t*)U, (long)ldu, M, nproj, nl, r, ucols, scaling);
+    return crab_check_launch(ctx, "lora_mix_reduce_kernel");
+}

@@ -133,7 +133,7 @@ class _Workspace:
         self.att = e(M, H * d)
         self.gu = e(M, 2 * I)
         self.act = e(M, I)
-        self.t = e(M, max(t_cols, 16), dt=torch.float32)
+        self.t = torch.empty((max(ops.hyperlora_route_workspace(M, max(D, I), max(t_cols, 16)), 16),), device=device, dtype=torch.uint8)
         self.u = e(M, max(u_cols, 32))
 
 

@@ -118,6 +118,27 @@ def hyperlora_mix(t: torch.Tensor, nproj: int, nl: int, r: int, ucols: int, scal
     return out
 
 
+def hyperlora_route_workspace(M: int, K: int, tcols: int) -> int:
+    return int(_lib.load().crab_hyperlora_route_workspace(M, K, tcols))
+
+
+def hyperlora_route(x: torch.Tensor, ra: torch.Tensor, nproj: int, nl: int, r: int, ucols: int, scaling: float,
+                    out: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """U[M,ucols] = routing mix of x @ [R;A]^T (split-K skinny product + fixed-order reduce + fp32 softmax)."""
+    _chk_bf16(x, ra)
+    d = _dev(x)
+    M, K = x.shape
+    if out is None:
+        out = torch.empty((M, ucols), device=x.device, dtype=BF16)
+    need = hyperlora_route_workspace(M, K, ra.shape[0])
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = torch.empty((need,), device=x.device, dtype=torch.uint8)
+    _lib.check(_lib.load().crab_hyperlora_route(_lib.ctx(d), _stream(), _p(x), x.stride(0), _p(ra), ra.stride(0), M, K, nproj, nl, r,
+                                                _p(out), out.stride(0), ucols, scaling, _p(workspace),
+                                                workspace.numel() * workspace.element_size()), d)
+    return out
+
+
 def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _chk_bf16(x, w)
     d = _dev(x)

@@ -144,10 +144,9 @@ class PackedLinearGroup:
         M = x.shape[0]
         if self.RA is None:
             return ops.gemm(x, self.W, bias=self.bias, residual=residual, out=out)
-        t = t_buf[:M, :self.t_cols] if t_buf is not None else None
-        t = ops.gemm(x, self.RA, out=t, out_fp32=True)                                   # route logits | lora_A(x)
-        u = ops.hyperlora_mix(t, len(self.names), self.nl, self.r, self.u_cols, self.scaling,
-                              out=u_buf[:M, :self.u_cols] if u_buf is not None else None)
+        # route logits | lora_A(x) -> softmax mix, K split over blocks (skinny.hip); t_buf is the partial-sum workspace
+        u = ops.hyperlora_route(x, self.RA, len(self.names), self.nl, self.r, self.u_cols, self.scaling,
+                                out=u_buf[:M, :self.u_cols] if u_buf is not None else None, workspace=t_buf)
         return ops.gemm(x, self.W, bias=self.bias, residual=residual, x2=u, w2=self.B2, out=out)
 
 

@@ -76,6 +76,14 @@ int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc* d);
 int crab_hyperlora_mix(crab_ctx* ctx, void* stream, const void* T, int64_t ldt, int t_fp32, void* U, int64_t ldu,
                        int M, int nproj, int nl, int r, int ucols, float scaling);
 
+/* Fused router: U = mix(x . [R;A]^T) without materialising T through a GEMM grid.  RA is [tcols, K] bf16 with
+ * tcols = round_up(nproj*(nl+r), 16) rows (zero padded).  K is split across blocks, partial products are summed in a
+ * fixed order (deterministic).  workspace: crab_hyperlora_route_workspace(M, K, tcols) bytes, caller-owned. */
+int64_t crab_hyperlora_route_workspace(int M, int K, int tcols);
+int crab_hyperlora_route(crab_ctx* ctx, void* stream, const void* X, int64_t ldx, const void* RA, int64_t ldra, int M, int K,
+                         int nproj, int nl, int r, void* U, int64_t ldu, int ucols, float scaling, void* workspace,
+                         int64_t workspace_bytes);
+
 /* RMSNorm (models/modeling_llama.py:112-117) and LayerNorm (torch.nn.LayerNorm) over the last dim, bf16 in/out. */
 int crab_rmsnorm(crab_ctx* ctx, void* stream, const void* x, int64_t ldx, const void* w, void* y, int64_t ldy,
                  int M, int D, float eps);

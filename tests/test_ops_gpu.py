@@ -284,3 +284,39 @@ def test_beats_helpers_match_golden_buckets():
     ref = torch.zeros(16, B, n + 127, 8, dtype=BF)
     ref[:, :, 64:64 + n] = x.view(B, n, 16, 8).permute(2, 0, 1, 3)
     assert torch.equal(xp, ref)
+
+
+@pytest.mark.parametrize("M,K,nproj", [(8, 4096, 3), (64, 11008, 1), (70, 128, 2), (2808, 4096, 3), (1, 256, 1)])
+def test_hyperlora_route_matches_gemm_plus_mix(M, K, nproj):
+    """Split-K router kernel == (skinny GEMM -> mix) and is run-to-run deterministic."""
+    from crab_amd import ops
+    tcols = (nproj * 11 + 15) // 16 * 16
+    ucols = (nproj * 24 + 31) // 32 * 32
+    x = _rand(M, K, seed=1)
+    ra = _rand(tcols, K, seed=2, scale=K ** -0.5)
+    ra[nproj * 11:] = 0
+    xd, rad = x.cuda(), ra.cuda()
+    u1 = ops.hyperlora_route(xd, rad, nproj, 3, 8, ucols, 2.0)
+    u2 = ops.hyperlora_route(xd, rad, nproj, 3, 8, ucols, 2.0)
+    assert torch.equal(u1, u2)
+    t = x.float() @ ra.float().t()
+    ref = torch.zeros(M, ucols)
+    for p in range(nproj):
+        seg = t[:, p * 11:(p + 1) * 11]
+        pr = torch.softmax(seg[:, :3], -1)
+        for i in range(3):
+            ref[:, p * 24 + i * 8:p * 24 + (i + 1) * 8] = 2.0 * pr[:, i:i + 1] * seg[:, 3:]
+    _cmp(u1, ref, 1.2e-2, "route")
+    assert (u1[:, nproj * 24:] == 0).all()
+
+
+@pytest.mark.parametrize("M", [1, 8, 17, 33, 64, 100, 128])
+def test_gemm_skinny_regime(M):
+    """M <= 128 dispatches to the weight-streaming kernel (all MT variants, N tail, K tail, second segment)."""
+    from crab_amd import ops
+    N, K, K2 = 1000 + 9, 1096, 32
+    x, w, b, r = _rand(M, K, seed=3), _rand(N, K, seed=4, scale=K ** -0.5), _rand(N, seed=5), _rand(M, N, seed=6)
+    x2, w2 = _rand(M, K2, seed=7), _rand(N, K2, seed=8, scale=0.1)
+    y = ops.gemm(x.cuda(), w.cuda(), bias=b.cuda(), act="silu", residual=r.cuda(), x2=x2.cuda(), w2=w2.cuda(), out_fp32=True)
+    z = F.silu(x.float() @ w.float().t() + x2.float() @ w2.float().t() + b.float()) + r.float()
+    _cmp(y, z, 3e-3, f"skinny M={M}")
