@@ -28,35 +28,48 @@ struct SkinnyP {
 
 constexpr int SK_WAVES = 8;
 
-template <int MT>
+// MT: 16-row activation tiles (M <= 16*MT).  NT: 16-row weight tiles per block (block covers 16*NT rows of W).
+// Every wave covers all NT weight tiles and all MT activation tiles over its own K slice, so per k-step it issues
+// NT weight loads (HBM) + MT activation loads (L2) for NT*MT MFMAs: NT trades grid size (N/(16 NT) blocks) against
+// L2 request pressure of the replicated activation reads (MT/NT activation bytes per weight byte).
+template <int MT, int NT>
 __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(SkinnyP p) {
-    __shared__ __attribute__((aligned(16))) float red[SK_WAVES][MT][64][4];
+    constexpr int U = (NT + MT) <= 3 ? 4 : ((NT + MT) <= 6 ? 2 : 1);       // k-steps in flight per wave
+    __shared__ __attribute__((aligned(16))) float red[SK_WAVES][NT * MT][64][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
-    const int n0 = blockIdx.x * 16;
-    const int nrow = min(n0 + fr, p.N - 1);                       // clamped: rows >= N are computed but never stored
+    const int n0 = blockIdx.x * 16 * NT;
 
     const int ks1 = (p.K + 31) >> 5;
     const int ks2 = p.A2 ? (p.K2 + 31) >> 5 : 0;
     const int ks = ks1 + ks2;
     const int s_begin = (int)((long)ks * wave / SK_WAVES), s_end = (int)((long)ks * (wave + 1) / SK_WAVES);
+    const int nst = s_end - s_begin;
+    // rotate the k-step order per block: concurrent blocks then touch different activation lines at any instant
+    const int rot = nst > 0 ? (int)(blockIdx.x % (unsigned)nst) : 0;
 
-    f32x4_t acc[MT];
+    f32x4_t acc[NT][MT];
 #pragma unroll
-    for (int i = 0; i < MT; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    long woff[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) woff[j] = min(n0 + j * 16 + fr, p.N - 1);      // clamped: rows >= N are never stored
     int mrow[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) mrow[i] = min(i * 16 + fr, p.M - 1);
 
     const u32x4 z4 = {0u, 0u, 0u, 0u};
-    constexpr int U = 4;                                           // k-steps in flight per wave
-    for (int s = s_begin; s < s_end; s += U) {
-        u32x4 wv[U], xv[U][MT];
+    for (int s = 0; s < nst; s += U) {
+        u32x4 wv[U][NT], xv[U][MT];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int st = s + u;
-            const bool live = st < s_end;
-            const bool seg2 = live && st >= ks1;
+            const bool live = s + u < nst;
+            int q = s + u + rot;
+            if (q >= nst) q -= nst;
+            const int st = live ? s_begin + q : s_begin;
+            const bool seg2 = st >= ks1;
             const bf16_t* Bp = seg2 ? p.B2 : p.B;
             const bf16_t* Ap = seg2 ? p.A2 : p.A;
             const long lb = seg2 ? p.ldb2 : p.ldb, la = seg2 ? p.lda2 : p.lda;
@@ -64,36 +77,45 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(SkinnyP p) {
             const int k = ((seg2 ? st - ks1 : st) << 5) + fg * 8;
             const bool ok = live && k < Kseg;
             const int kc = ok ? k : 0;
-            u32x4 w = *reinterpret_cast<const u32x4*>(Bp + (long)nrow * lb + kc);
-            wv[u] = ok ? w : z4;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                u32x4 w = *reinterpret_cast<const u32x4*>(Bp + woff[j] * lb + kc);
+                wv[u][j] = ok ? w : z4;
+            }
 #pragma unroll
             for (int i = 0; i < MT; ++i) xv[u][i] = *reinterpret_cast<const u32x4*>(Ap + (long)mrow[i] * la + kc);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            union { u32x4 r; bf16x8_t f; } wf;
-            wf.r = wv[u];
 #pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                union { u32x4 r; bf16x8_t f; } xf;
-                xf.r = xv[u][i];
-                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf.f, xf.f, acc[i], 0, 0, 0);
+            for (int j = 0; j < NT; ++j) {
+                union { u32x4 r; bf16x8_t f; } wf;
+                wf.r = wv[u][j];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    union { u32x4 r; bf16x8_t f; } xf;
+                    xf.r = xv[u][i];
+                    acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf.f, xf.f, acc[j][i], 0, 0, 0);
+                }
             }
         }
     }
 #pragma unroll
-    for (int i = 0; i < MT; ++i) *reinterpret_cast<f32x4_t*>(&red[wave][i][lane][0]) = acc[i];
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) *reinterpret_cast<f32x4_t*>(&red[wave][j * MT + i][lane][0]) = acc[j][i];
     __syncthreads();
 
-    // reduce over waves in fixed order + epilogue: thread -> (m-tile i, lane l): row m = 16i + (l&15), cols n0 + 4*(l>>4) + r
-    for (int idx = tid; idx < MT * 64; idx += SK_WAVES * 64) {
-        const int i = idx >> 6, l = idx & 63;
+    // reduce over waves in fixed order + epilogue: (tile t = j*MT+i, lane l): row m = 16i + (l&15), cols n0+16j+4*(l>>4)+r
+    for (int idx = tid; idx < NT * MT * 64; idx += SK_WAVES * 64) {
+        const int t = idx >> 6, l = idx & 63;
+        const int j = t / MT, i = t % MT;
         const int m = i * 16 + (l & 15);
-        const int n = n0 + (l >> 4) * 4;
+        const int n = n0 + j * 16 + (l >> 4) * 4;
         if (m >= p.M || n >= p.N) continue;
-        f32x4_t v = *reinterpret_cast<const f32x4_t*>(&red[0][i][l][0]);
+        f32x4_t v = *reinterpret_cast<const f32x4_t*>(&red[0][t][l][0]);
 #pragma unroll
-        for (int w = 1; w < SK_WAVES; ++w) v += *reinterpret_cast<const f32x4_t*>(&red[w][i][l][0]);
+        for (int w = 1; w < SK_WAVES; ++w) v += *reinterpret_cast<const f32x4_t*>(&red[w][t][l][0]);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             if (n + r >= p.N) break;
@@ -146,32 +168,43 @@ __global__ __launch_bounds__(256) void lora_t_partial_kernel(const bf16_t* __res
     }
 }
 
-__global__ void lora_mix_reduce_kernel(const float* __restrict__ part, int nslices, int tcols, bf16_t* __restrict__ U, long ldu, int M,
-                                       int nproj, int nl, int r, int ucols, float scaling) {
-    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+// one block per 4 rows: phase 1 sums the K-slices (thread per (row, t-column), fixed order, coalesced over columns),
+// phase 2 = softmax over the route logits and the rank-r mix, one thread per (row, projection)
+__global__ __launch_bounds__(256) void lora_mix_reduce_kernel(const float* __restrict__ part, int nslices, int tcols, bf16_t* __restrict__ U,
+                                                              long ldu, int M, int nproj, int nl, int r, int ucols, float scaling) {
+    __shared__ float T[4][64];
+    const int m0 = blockIdx.x * 4;
+    const int tid = threadIdx.x;
+    {
+        const int row = tid >> 6, c = tid & 63;
+        const int m = m0 + row;
+        if (m < M && c < tcols) {
+            float acc = 0.f;
+            const float* q = part + (long)m * tcols + c;
+            for (int s = 0; s < nslices; ++s) acc += q[(long)s * M * tcols];
+            T[row][c] = acc;
+        }
+    }
+    __syncthreads();
     const int per_row = nproj + 1;
-    if (idx >= M * per_row) return;
-    const int m = idx / per_row, pj = idx % per_row;
+    if (tid >= 4 * per_row) return;
+    const int row = tid / per_row, pj = tid % per_row;
+    const int m = m0 + row;
+    if (m >= M) return;
     bf16_t* u = U + (long)m * ldu;
     const int used = nproj * nl * r;
     if (pj == nproj) {
         for (int c = used; c < ucols; ++c) u[c] = 0;
         return;
     }
-    float t[16];
-    const int w = nl + r;                                         // <= 16 (checked on the host)
-    for (int c = 0; c < w; ++c) t[c] = 0.f;
-    for (int s = 0; s < nslices; ++s) {                           // fixed summation order
-        const float* q = part + ((long)s * M + m) * tcols + pj * w;
-        for (int c = 0; c < w; ++c) t[c] += q[c];
-    }
-    float mx = -INFINITY;
+    const float* t = &T[row][pj * (nl + r)];
+    float e[8], mx = -INFINITY;
     for (int i = 0; i < nl; ++i) mx = fmaxf(mx, t[i]);
     float sum = 0.f;
-    for (int i = 0; i < nl; ++i) { t[i] = expf(t[i] - mx); sum += t[i]; }
+    for (int i = 0; i < nl; ++i) { e[i] = expf(t[i] - mx); sum += e[i]; }
     const float inv = 1.0f / sum;
     for (int i = 0; i < nl; ++i)
-        for (int j = 0; j < r; ++j) u[pj * nl * r + i * r + j] = f2bf(scaling * t[i] * inv * t[nl + j]);
+        for (int j = 0; j < r; ++j) u[pj * nl * r + i * r + j] = f2bf(scaling * e[i] * inv * t[nl + j]);
 }
 
 }  // namespace
@@ -183,11 +216,25 @@ int crab_gemm_skinny_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* 
     p.A2 = (const bf16_t*)d->A2; p.B2 = (const bf16_t*)d->B2;
     p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc; p.ldr = d->ldr; p.lda2 = d->lda2; p.ldb2 = d->ldb2;
     p.M = d->M; p.N = d->N; p.K = d->K; p.K2 = d->A2 ? d->K2 : 0; p.act = d->act; p.c_fp32 = d->c_fp32; p.res_scale = d->res_scale;
-    dim3 grid((d->N + 15) / 16), block(SK_WAVES * 64);
-    if (d->M <= 16) hipLaunchKernelGGL((gemm_skinny_kernel<1>), grid, block, 0, s, p);
-    else if (d->M <= 32) hipLaunchKernelGGL((gemm_skinny_kernel<2>), grid, block, 0, s, p);
-    else if (d->M <= 64) hipLaunchKernelGGL((gemm_skinny_kernel<4>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((gemm_skinny_kernel<8>), grid, block, 0, s, p);
+    // NT (weight tiles per block): bigger NT = fewer replicated activation reads but a smaller grid.  d->tune forces it.
+    int mt = d->M <= 16 ? 1 : (d->M <= 32 ? 2 : (d->M <= 64 ? 4 : 8));
+    int nt = d->tune > 0 ? d->tune : 0;
+    if (nt == 0) {
+        nt = 1;
+        if (mt >= 2 && d->N >= 8192) nt = 2;
+        if (mt >= 4 && d->N >= 16384) nt = 4;
+    }
+    if (nt != 1 && nt != 2 && nt != 4) nt = 1;
+    if (mt == 8 && nt == 4) nt = 2;                                  // 64 KiB static LDS limit for the reduction buffer
+    dim3 grid((d->N + 16 * nt - 1) / (16 * nt)), block(SK_WAVES * 64);
+#define SK_LAUNCH(MT_, NT_) hipLaunchKernelGGL((gemm_skinny_kernel<MT_, NT_>), grid, block, 0, s, p)
+#define SK_NT(MT_) do { if (nt == 1) SK_LAUNCH(MT_, 1); else if (nt == 2) SK_LAUNCH(MT_, 2); else SK_LAUNCH(MT_, 4); } while (0)
+    if (mt == 1) SK_NT(1);
+    else if (mt == 2) SK_NT(2);
+    else if (mt == 4) SK_NT(4);
+    else { if (nt == 1) SK_LAUNCH(8, 1); else SK_LAUNCH(8, 2); }
+#undef SK_NT
+#undef SK_LAUNCH
     return crab_check_launch(ctx, "gemm_skinny_kernel");
 }
 
@@ -227,7 +274,8 @@ extern "C" int crab_hyperlora_route(crab_ctx* ctx, void* stream, const void* X, 
     else hipLaunchKernelGGL((lora_t_partial_kernel<3>), grid, block, 0, s, (const bf16_t*)X, (long)ldx, (const bf16_t*)RA, (long)ldra, part, M, K, kslice);
     int rc = crab_check_launch(ctx, "lora_t_partial_kernel");
     if (rc) return rc;
-    unsigned blocks = (unsigned)(((long)M * (nproj + 1) + 255) / 256);
+    if (tcols > 64) return crab_fail(ctx, CRAB_E_UNSUPPORTED, "hyperlora_route: tcols <= 64");
+    unsigned blocks = (unsigned)((M + 3) / 4);
     hipLaunchKernelGGL(lora_mix_reduce_kernel, dim3(blocks), dim3(256), 0, s, part, nslices, tcols, (bf16_t*)U, (long)ldu, M, nproj, nl, r, ucols, scaling);
     return crab_check_launch(ctx, "lora_mix_reduce_kernel");
 }

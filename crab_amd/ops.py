@@ -67,7 +67,7 @@ def _variant(M: int, N: int, batch: int = 1) -> str:
 
 def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act: str = "none",
          residual: Optional[torch.Tensor] = None, res_scale: float = 1.0, x2: Optional[torch.Tensor] = None,
-         w2: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, out_fp32: bool = False) -> torch.Tensor:
+         w2: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, out_fp32: bool = False, tune: int = 0) -> torch.Tensor:
     """out[M,N] = res_scale*residual + act(x[M,K] @ w[N,K]^T + x2 @ w2^T + bias).  2-D row-strided operands."""
     _chk_bf16(x, w, bias, residual, x2, w2)
     d = _dev(x)
@@ -90,6 +90,7 @@ def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     g.c_fp32 = 1 if out.dtype == torch.float32 else 0
     g.res_scale = res_scale
     g.batch, g.nb0 = 1, 1
+    g.tune = tune
     prof = PROFILER
     if prof is not None and M >= prof.min_m and not torch.cuda.is_current_stream_capturing():
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
