@@ -28,7 +28,7 @@ class GemmDesc(C.Structure):
         ("batch", C.c_int32), ("nb0", C.c_int32),
         ("sA0", C.c_int64), ("sA1", C.c_int64), ("sB0", C.c_int64), ("sB1", C.c_int64), ("sC0", C.c_int64),
         ("sC1", C.c_int64), ("sR0", C.c_int64), ("sR1", C.c_int64), ("sBias0", C.c_int64), ("sBias1", C.c_int64),
-        ("tune", C.c_int32),
+        ("tune", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
     ]
 
 

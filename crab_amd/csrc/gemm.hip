@@ -23,6 +23,8 @@ struct GemmP {
     int nb0;
     long sA0, sA1, sB0, sB1, sC0, sC1, sR0, sR1, sBias0, sBias1;
     int tiles_m, tiles_n;
+    int splitk;          // > 1: blockIdx.y = K slice, raw fp32 partial tiles go to `part` [slice][M][N]
+    float* part;
 };
 
 constexpr int BK = 64;
@@ -39,7 +41,7 @@ __global__ __launch_bounds__(256) void gemm_bt_kernel(GemmP p) {
     const int wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 
-    const int z = blockIdx.y;
+    const int z = p.splitk > 1 ? 0 : blockIdx.y;
     const int z0 = z % p.nb0, z1 = z / p.nb0;
     const bf16_t* A = p.A + z0 * p.sA0 + z1 * p.sA1;
     const bf16_t* B = p.B + z0 * p.sB0 + z1 * p.sB1;
@@ -54,6 +56,11 @@ __global__ __launch_bounds__(256) void gemm_bt_kernel(GemmP p) {
     const int nk1 = (p.K + BK - 1) / BK;
     const int nk2 = A2 ? (p.K2 + BK - 1) / BK : 0;
     const int nk = nk1 + nk2;
+    int t_begin = 0, t_end = nk;
+    if (p.splitk > 1) {
+        t_begin = (int)((long)nk * blockIdx.y / p.splitk);
+        t_end = (int)((long)nk * (blockIdx.y + 1) / p.splitk);
+    }
 
     u32x4 ra[CA], rb[CB];
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
@@ -99,14 +106,16 @@ __global__ __launch_bounds__(256) void gemm_bt_kernel(GemmP p) {
 #pragma unroll
         for (int j = 0; j < TM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    GLOAD(0);
-    LSTORE(0);
+    if (t_begin < t_end) {
+        GLOAD(t_begin);
+        LSTORE(0);
+    }
     __syncthreads();
 
     const int fr = lane & 15, fg = lane >> 4;
-    for (int t = 0; t < nk; ++t) {
-        const int cur = t & 1;
-        if (t + 1 < nk) GLOAD(t + 1);
+    for (int t = t_begin; t < t_end; ++t) {
+        const int cur = (t - t_begin) & 1;
+        if (t + 1 < t_end) GLOAD(t + 1);
         const bf16_t* la_ = &lds[cur][0];
         const bf16_t* lb_ = &lds[cur][BM * BK];
 #pragma unroll
@@ -129,10 +138,29 @@ __global__ __launch_bounds__(256) void gemm_bt_kernel(GemmP p) {
                 for (int mi = 0; mi < TM; ++mi)
                     acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
         }
-        if (t + 1 < nk) LSTORE(cur ^ 1);
+        if (t + 1 < t_end) LSTORE(cur ^ 1);
         __syncthreads();
     }
 
+    if (p.splitk > 1) {          // raw partial tile, reduced by splitk_epilogue_kernel in a fixed slice order
+        float* part = p.part + (long)blockIdx.y * p.M * p.N;
+        const bool v4 = (p.N & 3) == 0;
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+            const int m = m0 + wm * WM + mi * 16 + fr;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+                const int n = n0 + wn * WN + ni * 16 + fg * 4;
+                if (n >= p.N) continue;
+                float* o = part + (long)m * p.N + n;
+                if (v4) *reinterpret_cast<f32x4_t*>(o) = acc[ni][mi];
+                else
+                    for (int r = 0; r < 4 && n + r < p.N; ++r) o[r] = acc[ni][mi][r];
+            }
+        }
+        return;
+    }
     // epilogue: lane owns row m = ..+fr, columns n = ..+fg*4 .. +3 of each 16x16 tile
     const bf16_t* bias = p.bias ? p.bias + z0 * p.sBias0 + z1 * p.sBias1 : nullptr;
     const bf16_t* R = p.R ? p.R + z0 * p.sR0 + z1 * p.sR1 : nullptr;
@@ -184,6 +212,36 @@ __global__ __launch_bounds__(256) void gemm_bt_kernel(GemmP p) {
 
 #undef GLOAD
 #undef LSTORE
+
+// sum of the K-slice partials (fixed order) + bias / activation / residual epilogue; one thread per 4 columns
+__global__ void splitk_epilogue_kernel(const float* __restrict__ part, int S, int M, int N, const bf16_t* __restrict__ bias, int act,
+                                       const bf16_t* __restrict__ R, long ldr, float res_scale, void* __restrict__ C, long ldc, int c_fp32) {
+    const int nq = (N + 3) >> 2;
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)M * nq) return;
+    const int m = idx / nq, n = (idx % nq) * 4;
+    const long MN = (long)M * N;
+    const float* q = part + (long)m * N + n;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    const int w = min(4, N - n);
+    if (w == 4 && (N & 3) == 0) {
+        for (int s = 0; s < S; ++s) {
+            f32x4_t t = *reinterpret_cast<const f32x4_t*>(q + s * MN);
+            v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
+        }
+    } else {
+        for (int s = 0; s < S; ++s)
+            for (int r = 0; r < w; ++r) v[r] += q[s * MN + r];
+    }
+    for (int r = 0; r < w; ++r) {
+        float x = v[r];
+        if (bias) x += bf2f(bias[n + r]);
+        x = apply_act(x, act);
+        if (R) x += res_scale * bf2f(R[(long)m * ldr + n + r]);
+        if (c_fp32) reinterpret_cast<float*>(C)[(long)m * ldc + n + r] = x;
+        else reinterpret_cast<bf16_t*>(C)[(long)m * ldc + n + r] = f2bf(x);
+    }
+}
 }  // namespace
 
 int crab_gemm_skinny_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* d);   // skinny.hip
@@ -201,8 +259,31 @@ extern "C" int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc*
         if (((uintptr_t)d->A2 & 15) || ((uintptr_t)d->B2 & 15)) return crab_fail(ctx, CRAB_E_INVALID, "gemm: A2/B2 alignment");
         if (d->batch > 1) return crab_fail(ctx, CRAB_E_UNSUPPORTED, "gemm: second K segment is not batched");
     }
-    if (d->batch <= 1 && d->M <= 128) return crab_gemm_skinny_launch(ctx, (hipStream_t)stream, d);   // weight-streaming regime
+    // ---- weight-streaming regime (decode): M <= 128 rows
+    //   M <= 16          : LDS-free skinny kernel (skinny.hip), activations replicated per 16 weight rows
+    //   16 < M <= 128    : tiled kernel with split-K over blockIdx.y (needs the caller's workspace) so that
+    //                      >= ~2 blocks/CU stream disjoint weight panels; partials reduced in a fixed order
+    int splitk = 1, sk_bm = 0, sk_bn = 0;
+    if (d->batch <= 1 && d->M <= 128) {
+        const int nk_all = (d->K + 63) / 64 + (d->A2 ? (d->K2 + 63) / 64 : 0);
+        bool want_split = d->M > 16 && d->workspace != nullptr && nk_all >= 8;
+        if (d->tune >= 1 && d->tune <= 4) want_split = false;                      // forced skinny NT
+        if (d->tune >= 100) want_split = d->workspace != nullptr;
+        if (!want_split) return crab_gemm_skinny_launch(ctx, (hipStream_t)stream, d);
+        sk_bm = d->M <= 64 ? 64 : 128;
+        sk_bn = 128;
+        if (d->tune >= 200) sk_bn = 64;
+        if (sk_bm == 128 && sk_bn == 64) sk_bn = 128;
+        long tiles = (long)((d->N + sk_bn - 1) / sk_bn) * ((d->M + sk_bm - 1) / sk_bm);
+        splitk = (int)((640 + tiles - 1) / tiles);
+        if (d->tune >= 100) splitk = d->tune % 100;
+        if (splitk > nk_all / 4) splitk = nk_all / 4;
+        if (splitk < 1) splitk = 1;
+        if (splitk > 32) splitk = 32;
+        while (splitk > 1 && (int64_t)splitk * d->M * d->N * 4 > d->workspace_bytes) --splitk;
+    }
     GemmP p;
+    p.splitk = splitk; p.part = (float*)d->workspace;
     p.A = (const bf16_t*)d->A; p.B = (const bf16_t*)d->B; p.C = d->C;
     p.bias = (const bf16_t*)d->bias; p.R = (const bf16_t*)d->R;
     p.A2 = (const bf16_t*)d->A2; p.B2 = (const bf16_t*)d->B2;
@@ -215,6 +296,19 @@ extern "C" int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc*
     p.sR0 = d->sR0; p.sR1 = d->sR1; p.sBias0 = d->sBias0; p.sBias1 = d->sBias1;
     if (batch == 1) { p.sA0 = p.sA1 = p.sB0 = p.sB1 = p.sC0 = p.sC1 = p.sR0 = p.sR1 = p.sBias0 = p.sBias1 = 0; }
     hipStream_t s = (hipStream_t)stream;
+    if (sk_bm) {
+        p.tiles_m = (d->M + sk_bm - 1) / sk_bm; p.tiles_n = (d->N + sk_bn - 1) / sk_bn;
+        dim3 grid(p.tiles_m * p.tiles_n, splitk);
+        if (sk_bm == 64 && sk_bn == 128) hipLaunchKernelGGL((gemm_bt_kernel<64, 128>), grid, dim3(256), 0, s, p);
+        else if (sk_bm == 64) hipLaunchKernelGGL((gemm_bt_kernel<64, 64>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((gemm_bt_kernel<128, 128>), grid, dim3(256), 0, s, p);
+        int rc = crab_check_launch(ctx, "gemm_bt_kernel(split-K)");
+        if (rc || splitk == 1) return rc;
+        long nthr = (long)d->M * ((d->N + 3) / 4);
+        hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, p.part, splitk, d->M, d->N, p.bias, d->act,
+                           p.R, (long)d->ldr, d->res_scale, d->C, (long)d->ldc, d->c_fp32);
+        return crab_check_launch(ctx, "splitk_epilogue_kernel");
+    }
     // tile choice: 128x128 when it fills the chip, 64x64 for small / skinny problems
     long big_tiles = (long)((d->M + 127) / 128) * ((d->N + 127) / 128) * batch;
     bool small = (d->M <= 64) || (d->N <= 64) || big_tiles < 192;

@@ -65,6 +65,17 @@ def _variant(M: int, N: int, batch: int = 1) -> str:
     return "gemm_bt_kernel<64,64>" if (M <= 64 or N <= 64 or big < 192) else "gemm_bt_kernel<128,128>"
 
 
+_SPLITK_WS = {}
+
+
+def _splitk_workspace(device) -> torch.Tensor:
+    """One caller-owned split-K scratch per device (stable address: safe under HIP-graph capture)."""
+    key = device.index or 0
+    if key not in _SPLITK_WS:
+        _SPLITK_WS[key] = torch.empty((96 << 20,), device=device, dtype=torch.uint8)
+    return _SPLITK_WS[key]
+
+
 def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act: str = "none",
          residual: Optional[torch.Tensor] = None, res_scale: float = 1.0, x2: Optional[torch.Tensor] = None,
          w2: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, out_fp32: bool = False, tune: int = 0) -> torch.Tensor:
@@ -91,6 +102,9 @@ def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     g.res_scale = res_scale
     g.batch, g.nb0 = 1, 1
     g.tune = tune
+    if M <= 128:
+        ws = _splitk_workspace(x.device)
+        g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel()
     prof = PROFILER
     if prof is not None and M >= prof.min_m and not torch.cuda.is_current_stream_capturing():
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

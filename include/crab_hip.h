@@ -63,6 +63,8 @@ typedef struct {
     int32_t batch, nb0;   /* batch <= 1 means unbatched */
     int64_t sA0, sA1, sB0, sB1, sC0, sC1, sR0, sR1, sBias0, sBias1;
     int32_t tune;      /* 0 = automatic kernel choice; >0 forces a variant (benchmarking only) */
+    void* workspace;   /* optional caller-owned scratch for split-K partials (decode regime, 16 < M <= 128); NULL = none */
+    int64_t workspace_bytes;
 } crab_gemm_desc;
 
 int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc* d);

@@ -26,15 +26,16 @@ for M in Ms:
         w2 = torch.randn(N, K2, device="cuda", dtype=BF) if K2 else None
         out = torch.empty(M, N, device="cuda", dtype=BF)
         res = []
-        for tune in (1, 2, 4):
+        for tune in (0, 1, 2, 4, 102, 104, 108, 116, 204, 208):
             if M > 64 and tune == 4: continue
+            if M <= 16 and tune >= 100: continue
             i = [0]
             def fn():
                 i[0] = (i[0] + 1) % ncopy
                 ops.gemm(x, Ws[i[0]], x2=x2, w2=w2, out=out, tune=tune)
             us = timeit(fn)
-            res.append(f"NT={tune}: {us:7.1f} us {N*K*2/us/1e6:5.2f} TB/s")
-        print(f"M={M:4d} {name:8s} N={N:6d} K={K:6d} | " + " | ".join(res), flush=True)
+            res.append(f"t{tune}:{us:6.1f}us")
+        print(f"M={M:4d} {name:8s} ideal@5TB/s {N*K*2/5e6:5.1f}us | " + " ".join(res), flush=True)
         del Ws
     # router
     for K, nproj in ((4096, 3), (4096, 1), (11008, 1)):

@@ -320,3 +320,20 @@ def test_gemm_skinny_regime(M):
     y = ops.gemm(x.cuda(), w.cuda(), bias=b.cuda(), act="silu", residual=r.cuda(), x2=x2.cuda(), w2=w2.cuda(), out_fp32=True)
     z = F.silu(x.float() @ w.float().t() + x2.float() @ w2.float().t() + b.float()) + r.float()
     _cmp(y, z, 3e-3, f"skinny M={M}")
+
+
+@pytest.mark.parametrize("M,tune", [(17, 0), (64, 0), (64, 104), (64, 208), (128, 0), (100, 103), (33, 102)])
+def test_gemm_splitk_decode_regime(M, tune):
+    """16 < M <= 128 with the caller workspace: split-K tiled kernel + fixed-order reduce epilogue."""
+    from crab_amd import ops
+    N, K, K2 = 1000 + 9, 1096, 32
+    x, w, b, r = _rand(M, K, seed=3), _rand(N, K, seed=4, scale=K ** -0.5), _rand(N, seed=5), _rand(M, N, seed=6)
+    x2, w2 = _rand(M, K2, seed=7), _rand(N, K2, seed=8, scale=0.1)
+    args = dict(bias=b.cuda(), act="gelu", residual=r.cuda(), x2=x2.cuda(), w2=w2.cuda(), tune=tune)
+    y = ops.gemm(x.cuda(), w.cuda(), out_fp32=True, **args)
+    z = F.gelu(x.float() @ w.float().t() + x2.float() @ w2.float().t() + b.float()) + r.float()
+    _cmp(y, z, 3e-3, f"split-K M={M} tune={tune}")
+    y2 = ops.gemm(x.cuda(), w.cuda(), out_fp32=True, **args)
+    assert torch.equal(y, y2), "split-K reduction must be deterministic"
+    yb = ops.gemm(x.cuda(), w.cuda(), **args)
+    _cmp(yb, z, 1.2e-2, "bf16 out")
