@@ -57,6 +57,7 @@ SYMBOLS = {
     "crab_hyperlora_mix": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _i64, _i, _i, _i, _i, _i, _f]),
     "crab_hyperlora_route_workspace": (_i64, [_i, _i, _i]),
     "crab_hyperlora_route": (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _vp, _i64, _i, _f, _vp, _i64]),
+    "crab_rms_route": (_i, [_vp, _vp, _vp, _i64, _vp, _f, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _vp, _i64, _i, _f]),
     "crab_rmsnorm": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _i, _i, _f]),
     "crab_layernorm": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _f]),
     "crab_embedding": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i]),

@@ -193,8 +193,7 @@ class GenerationEngine:
         for li, layer in enumerate(self.model.layers):
             a, m = layer.self_attn, layer.mlp
             kcl, vcl = kc[li, b0:b0 + B], vc[li, b0:b0 + B]
-            ops.rmsnorm(x, layer.input_layernorm.weight, c.rms_norm_eps, out=h)
-            a._qkv(h, out=qkv, t_buf=ws.t, u_buf=ws.u)
+            a._qkv(x, out=qkv, t_buf=ws.t, u_buf=ws.u, norm=(layer.input_layernorm.weight, c.rms_norm_eps, ws.h))
             ops.qkv_rope_split(qkv, tab, kcl, vcl, vt, B, S, H, Hk, d, Tmax, pos0=pos0, pos_dev=pos_dev)
             if vt is not None:
                 Sp = vt.shape[-1]
@@ -204,8 +203,7 @@ class GenerationEngine:
             else:
                 ops.attn_decode(qkv, kcl, vcl, att, B, H, Hk, d, Tmax, 1, scale, ctx_dev=pos_dev)
             a._o(att, residual=x, out=x, t_buf=ws.t, u_buf=ws.u)
-            ops.rmsnorm(x, layer.post_attention_layernorm.weight, c.rms_norm_eps, out=h)
-            m._gu(h, out=gu, t_buf=ws.t, u_buf=ws.u)
+            m._gu(x, out=gu, t_buf=ws.t, u_buf=ws.u, norm=(layer.post_attention_layernorm.weight, c.rms_norm_eps, ws.h))
             ops.swiglu(gu, out=act)
             m._down(act, residual=x, out=x, t_buf=ws.t, u_buf=ws.u)
         return x

@@ -154,6 +154,18 @@ def hyperlora_route(x: torch.Tensor, ra: torch.Tensor, nproj: int, nl: int, r: i
     return out
 
 
+def rms_route(x: torch.Tensor, ra: torch.Tensor, nproj: int, nl: int, r: int, ucols: int, scaling: float, out: torch.Tensor,
+              norm_w: Optional[torch.Tensor] = None, eps: float = 0.0, h_out: Optional[torch.Tensor] = None):
+    """Fused (RMSNorm ->) router for small M (one block per row): writes h_out (if norm_w) and U = out."""
+    _chk_bf16(x, ra, norm_w, h_out, out)
+    d = _dev(x)
+    M, K = x.shape
+    _lib.check(_lib.load().crab_rms_route(_lib.ctx(d), _stream(), _p(x), x.stride(0), _p(norm_w), eps, _p(h_out),
+                                          h_out.stride(0) if h_out is not None else 0, _p(ra), ra.stride(0), M, K, nproj, nl, r,
+                                          _p(out), out.stride(0), ucols, scaling), d)
+    return out
+
+
 def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _chk_bf16(x, w)
     d = _dev(x)

@@ -87,6 +87,13 @@ int crab_hyperlora_route(crab_ctx* ctx, void* stream, const void* X, int64_t ldx
                          int nproj, int nl, int r, void* U, int64_t ldu, int ucols, float scaling, void* workspace,
                          int64_t workspace_bytes);
 
+/* Decode-regime fusion of (optional) RMSNorm + router, one block per row: h = rmsnorm(x)*w (written to h_out, bf16, when
+ * norm_w != NULL; otherwise h = x), U = routing mix of h.[R;A]^T.  RA is [>= nproj*(nl+r), K] bf16.  Replaces
+ * LlamaRMSNorm (modeling_llama.py:112-117) + lora_route/lora_A/softmax (lora.py:346-349) for small M. */
+int crab_rms_route(crab_ctx* ctx, void* stream, const void* x, int64_t ldx, const void* norm_w, float eps, void* h_out, int64_t ldh,
+                   const void* RA, int64_t ldra, int M, int K, int nproj, int nl, int r, void* U, int64_t ldu, int ucols,
+                   float scaling);
+
 /* RMSNorm (models/modeling_llama.py:112-117) and LayerNorm (torch.nn.LayerNorm) over the last dim, bf16 in/out. */
 int crab_rmsnorm(crab_ctx* ctx, void* stream, const void* x, int64_t ldx, const void* w, void* y, int64_t ldy,
                  int M, int D, float eps);

@@ -337,3 +337,33 @@ def test_gemm_splitk_decode_regime(M, tune):
     assert torch.equal(y, y2), "split-K reduction must be deterministic"
     yb = ops.gemm(x.cuda(), w.cuda(), **args)
     _cmp(yb, z, 1.2e-2, "bf16 out")
+
+
+@pytest.mark.parametrize("M,K,nproj,norm", [(8, 4096, 3, True), (64, 11008, 1, False), (5, 128, 2, True), (64, 4096, 2, True), (1, 256, 1, False)])
+def test_rms_route_fused(M, K, nproj, norm):
+    from crab_amd import ops
+    from oracle import crab_oracle as O
+    tcols = (nproj * 11 + 15) // 16 * 16
+    ucols = (nproj * 24 + 31) // 32 * 32
+    x = _rand(M, K, seed=1)
+    ra = _rand(tcols, K, seed=2, scale=K ** -0.5)
+    w = (1 + 0.1 * torch.randn(K)).to(BF)
+    u = torch.full((M, ucols), 7.0, dtype=BF, device="cuda")
+    h = torch.empty(M, K, dtype=BF, device="cuda")
+    if norm:
+        ops.rms_route(x.cuda(), ra.cuda(), nproj, 3, 8, ucols, 2.0, out=u, norm_w=w.cuda(), eps=1e-5, h_out=h)
+        href = O.rmsnorm(x.float(), w.float(), 1e-5, emulate=BF)
+        _cmp(h, href, 1e-2, "fused rmsnorm")
+        hin = h.cpu().float()
+    else:
+        ops.rms_route(x.cuda(), ra.cuda(), nproj, 3, 8, ucols, 2.0, out=u)
+        hin = x.float()
+    t = hin @ ra.float().t()
+    ref = torch.zeros(M, ucols)
+    for p in range(nproj):
+        seg = t[:, p * 11:(p + 1) * 11]
+        pr = torch.softmax(seg[:, :3], -1)
+        for i in range(3):
+            ref[:, p * 24 + i * 8:p * 24 + (i + 1) * 8] = 2.0 * pr[:, i:i + 1] * seg[:, 3:]
+    _cmp(u, ref, 1.2e-2, "fused route")
+    assert (u[:, nproj * 24:] == 0).all()
