@@ -29,6 +29,7 @@ class GemmDesc(C.Structure):
         ("sA0", C.c_int64), ("sA1", C.c_int64), ("sB0", C.c_int64), ("sB1", C.c_int64), ("sC0", C.c_int64),
         ("sC1", C.c_int64), ("sR0", C.c_int64), ("sR1", C.c_int64), ("sBias0", C.c_int64), ("sBias1", C.c_int64),
         ("tune", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
+        ("norm_w", C.c_void_p), ("norm_out", C.c_void_p), ("ld_norm", C.c_int64), ("norm_eps", C.c_float),
     ]
 
 
@@ -57,7 +58,6 @@ SYMBOLS = {
     "crab_hyperlora_mix": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _i64, _i, _i, _i, _i, _i, _f]),
     "crab_hyperlora_route_workspace": (_i64, [_i, _i, _i]),
     "crab_hyperlora_route": (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _vp, _i64, _i, _f, _vp, _i64]),
-    "crab_rms_route": (_i, [_vp, _vp, _vp, _i64, _vp, _f, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _vp, _i64, _i, _f]),
     "crab_rmsnorm": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _i, _i, _f]),
     "crab_layernorm": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _f]),
     "crab_embedding": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i]),

@@ -242,12 +242,78 @@ __global__ void splitk_epilogue_kernel(const float* __restrict__ part, int S, in
         else reinterpret_cast<bf16_t*>(C)[(long)m * ldc + n + r] = f2bf(x);
     }
 }
+
+// Row-owning variant of the split-K epilogue: one block per output row sums the K-slice partials (fixed order), applies
+// bias / activation / residual, writes C (bf16) AND the RMS-normalised row rmsnorm(C)*w for the next projection
+// (LlamaRMSNorm, modeling_llama.py:112-117, fused behind o_proj / down_proj in the decode regime).  N <= 8192.
+__global__ __launch_bounds__(256) void splitk_epilogue_norm_kernel(const float* __restrict__ part, int S, int M, int N,
+                                                                    const bf16_t* __restrict__ bias, int act, const bf16_t* __restrict__ R,
+                                                                    long ldr, float res_scale, bf16_t* __restrict__ C, long ldc,
+                                                                    const bf16_t* __restrict__ nw, float eps, bf16_t* __restrict__ H, long ldh) {
+    __shared__ float red[4];
+    const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long MN = (long)M * N;
+    constexpr int MAXQ = 8;                                   // 8 float4 per thread: N <= 8192
+    float xv[MAXQ][4];
+    float ss = 0.f;
+#pragma unroll
+    for (int q = 0; q < MAXQ; ++q) {
+        const int n = (tid + q * 256) * 4;
+        if (n < N) {
+            f32x4_t v = {0.f, 0.f, 0.f, 0.f};
+            const float* pp = part + (long)m * N + n;
+            for (int s = 0; s < S; ++s) v += *reinterpret_cast<const f32x4_t*>(pp + s * MN);
+            u32x2 rr = {0u, 0u};
+            if (R) rr = *reinterpret_cast<const u32x2*>(R + (long)m * ldr + n);
+            float rv[4] = {lo_bf(rr[0]), hi_bf(rr[0]), lo_bf(rr[1]), hi_bf(rr[1])};
+            u32x2 o;
+            float t[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float x = v[r];
+                if (bias) x += bf2f(bias[n + r]);
+                x = apply_act(x, act);
+                if (R) x += res_scale * rv[r];
+                t[r] = bf2f(f2bf(x));                          // the norm sees the stored bf16 value
+                xv[q][r] = t[r];
+                ss += t[r] * t[r];
+            }
+            o[0] = pack_bf2(t[0], t[1]); o[1] = pack_bf2(t[2], t[3]);
+            *reinterpret_cast<u32x2*>(C + (long)m * ldc + n) = o;
+        }
+    }
+    ss = wave_sum(ss);
+    if (lane == 0) red[wave] = ss;
+    __syncthreads();
+    const float rstd = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)N + eps);
+#pragma unroll
+    for (int q = 0; q < MAXQ; ++q) {
+        const int n = (tid + q * 256) * 4;
+        if (n < N) {
+            u32x2 wv = *reinterpret_cast<const u32x2*>(nw + n);
+            float w4[4] = {lo_bf(wv[0]), hi_bf(wv[0]), lo_bf(wv[1]), hi_bf(wv[1])};
+            float h4[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h4[r] = bf2f(f2bf(xv[q][r] * rstd)) * w4[r];
+            u32x2 o;
+            o[0] = pack_bf2(h4[0], h4[1]); o[1] = pack_bf2(h4[2], h4[3]);
+            *reinterpret_cast<u32x2*>(H + (long)m * ldh + n) = o;
+        }
+    }
+}
 }  // namespace
 
 int crab_gemm_skinny_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* d);   // skinny.hip
 
+// unfused form of the optional post-RMSNorm (paths whose epilogue does not own whole rows)
+static int post_norm(crab_ctx* ctx, void* stream, const crab_gemm_desc* d) {
+    if (!d->norm_w) return CRAB_OK;
+    return crab_rmsnorm(ctx, stream, d->C, d->ldc, d->norm_w, d->norm_out, d->ld_norm, d->M, d->N, d->norm_eps);
+}
+
 extern "C" int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc* d) {
     if (!ctx) return CRAB_E_INVALID;
+    if (d && d->norm_w && (!d->norm_out || d->c_fp32 || d->batch > 1)) return crab_fail(ctx, CRAB_E_INVALID, "gemm: post-norm needs norm_out, bf16 C, no batch");
     if (!d || !d->A || !d->B || !d->C) return crab_fail(ctx, CRAB_E_INVALID, "gemm: null operand");
     if (d->M <= 0 || d->N <= 0 || d->K <= 0) return crab_fail(ctx, CRAB_E_INVALID, "gemm: non-positive dimension");
     if ((d->K & 7) || (d->lda & 7) || (d->ldb & 7)) return crab_fail(ctx, CRAB_E_INVALID, "gemm: K/lda/ldb must be multiples of 8");
@@ -269,7 +335,10 @@ extern "C" int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc*
         bool want_split = d->M > 16 && d->workspace != nullptr && nk_all >= 8;
         if (d->tune >= 1 && d->tune <= 4) want_split = false;                      // forced skinny NT
         if (d->tune >= 100) want_split = d->workspace != nullptr;
-        if (!want_split) return crab_gemm_skinny_launch(ctx, (hipStream_t)stream, d);
+        if (!want_split) {
+            int rc = crab_gemm_skinny_launch(ctx, (hipStream_t)stream, d);
+            return rc ? rc : post_norm(ctx, stream, d);
+        }
         sk_bm = d->M <= 64 ? 64 : 128;
         sk_bn = 128;
         if (d->tune >= 200) sk_bn = 64;
@@ -303,11 +372,21 @@ extern "C" int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc*
         else if (sk_bm == 64) hipLaunchKernelGGL((gemm_bt_kernel<64, 64>), grid, dim3(256), 0, s, p);
         else hipLaunchKernelGGL((gemm_bt_kernel<128, 128>), grid, dim3(256), 0, s, p);
         int rc = crab_check_launch(ctx, "gemm_bt_kernel(split-K)");
-        if (rc || splitk == 1) return rc;
+        if (rc) return rc;
+        if (splitk == 1) return post_norm(ctx, stream, d);
+        if (d->norm_w && !d->c_fp32 && (d->N & 3) == 0 && d->N <= 8192 && (d->ldc & 3) == 0 && (d->ld_norm & 3) == 0 &&
+            (!d->R || (d->ldr & 3) == 0)) {
+            hipLaunchKernelGGL(splitk_epilogue_norm_kernel, dim3(d->M), dim3(256), 0, s, p.part, splitk, d->M, d->N, p.bias, d->act, p.R,
+                               (long)d->ldr, d->res_scale, (bf16_t*)d->C, (long)d->ldc, (const bf16_t*)d->norm_w, d->norm_eps,
+                               (bf16_t*)d->norm_out, (long)d->ld_norm);
+            return crab_check_launch(ctx, "splitk_epilogue_norm_kernel");
+        }
         long nthr = (long)d->M * ((d->N + 3) / 4);
         hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, p.part, splitk, d->M, d->N, p.bias, d->act,
                            p.R, (long)d->ldr, d->res_scale, d->C, (long)d->ldc, d->c_fp32);
-        return crab_check_launch(ctx, "splitk_epilogue_kernel");
+        rc = crab_check_launch(ctx, "splitk_epilogue_kernel");
+        if (rc) return rc;
+        return post_norm(ctx, stream, d);
     }
     // tile choice: 128x128 when it fills the chip, 64x64 for small / skinny problems
     long big_tiles = (long)((d->M + 127) / 128) * ((d->N + 127) / 128) * batch;
@@ -321,5 +400,6 @@ extern "C" int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc*
         dim3 grid(p.tiles_m * p.tiles_n, batch);
         hipLaunchKernelGGL((gemm_bt_kernel<64, 64>), grid, dim3(256), 0, s, p);
     }
-    return crab_check_launch(ctx, "gemm_bt_kernel");
+    int rc = crab_check_launch(ctx, "gemm_bt_kernel");
+    return rc ? rc : post_norm(ctx, stream, d);
 }

@@ -279,143 +279,3 @@ extern "C" int crab_hyperlora_route(crab_ctx* ctx, void* stream, const void* X, 
     hipLaunchKernelGGL(lora_mix_reduce_kernel, dim3(blocks), dim3(256), 0, s, part, nslices, tcols, (bf16_t*)U, (long)ldu, M, nproj, nl, r, ucols, scaling);
     return crab_check_launch(ctx, "lora_mix_reduce_kernel");
 }
-
-// ================================================================================================
-// Fused (RMSNorm ->) hyper-LoRA router for the decode regime: one block per activation row.
-//   h = rmsnorm(x) * w (optional, written out in bf16 for the following GEMM), t = h . [R;A]^T (nt <= 33 dot products
-//   of length K against an L2-resident matrix), p = softmax_fp32(route logits), u = scaling * p_i * (A h)_j in bf16.
-// Replaces norm_kernel + lora_t_partial_kernel + lora_mix_reduce_kernel (3 launches, 2 round trips through HBM/L2)
-// by one launch whose row never leaves registers.
-// ================================================================================================
-namespace {
-
-template <int CH, bool NORM>
-__global__ __launch_bounds__(256) void rms_route_kernel(const bf16_t* __restrict__ x, long ldx, const bf16_t* __restrict__ nw, float eps,
-                                                        bf16_t* __restrict__ hout, long ldh, const bf16_t* __restrict__ RA, long ldra,
-                                                        int K, int nproj, int nl, int r, bf16_t* __restrict__ U, long ldu, int ucols,
-                                                        float scaling) {
-    constexpr int NTMAX = 33;
-    __shared__ float red[4][NTMAX + 1];
-    __shared__ float tsum[NTMAX + 1];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m = blockIdx.x;
-    const int nchunk = K >> 3;
-    const bf16_t* xr = x + (long)m * ldx;
-    float h[CH][8];
-    float ss = 0.f;
-#pragma unroll
-    for (int c = 0; c < CH; ++c) {
-        const int ci = tid + c * 256;
-        if (ci < nchunk) {
-            u32x4 v = *reinterpret_cast<const u32x4*>(xr + ci * 8);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                h[c][2 * e] = lo_bf(v[e]);
-                h[c][2 * e + 1] = hi_bf(v[e]);
-                ss += h[c][2 * e] * h[c][2 * e] + h[c][2 * e + 1] * h[c][2 * e + 1];
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) h[c][e] = 0.f;
-        }
-    }
-    if (NORM) {
-        ss = wave_sum(ss);
-        if (lane == 0) red[wave][0] = ss;
-        __syncthreads();
-        const float rstd = rsqrtf((red[0][0] + red[1][0] + red[2][0] + red[3][0]) / (float)K + eps);
-        __syncthreads();
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-            const int ci = tid + c * 256;
-            if (ci < nchunk) {
-                u32x4 wv = *reinterpret_cast<const u32x4*>(nw + ci * 8);
-                u32x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    // modeling_llama.py:116-117: weight * x_hat.to(bf16); the product is stored in bf16 as well
-                    float a = bf2f(f2bf(h[c][2 * e] * rstd)) * lo_bf(wv[e]);
-                    float b = bf2f(f2bf(h[c][2 * e + 1] * rstd)) * hi_bf(wv[e]);
-                    o[e] = pack_bf2(a, b);
-                    h[c][2 * e] = lo_bf(o[e]);
-                    h[c][2 * e + 1] = hi_bf(o[e]);
-                }
-                if (hout) *reinterpret_cast<u32x4*>(hout + (long)m * ldh + ci * 8) = o;
-            }
-        }
-    }
-    const int w = nl + r;
-    const int nt = nproj * w;                       // <= 33
-    float acc[NTMAX];
-#pragma unroll
-    for (int j = 0; j < NTMAX; ++j) acc[j] = 0.f;
-#pragma unroll
-    for (int c = 0; c < CH; ++c) {
-        const int ci = tid + c * 256;
-        if (ci < nchunk) {
-#pragma unroll
-            for (int j = 0; j < NTMAX; ++j) {
-                if (j < nt) {
-                    u32x4 rv = *reinterpret_cast<const u32x4*>(RA + (long)j * ldra + ci * 8);
-                    float s = 0.f;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) s += h[c][2 * e] * lo_bf(rv[e]) + h[c][2 * e + 1] * hi_bf(rv[e]);
-                    acc[j] += s;
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < NTMAX; ++j) {
-        if (j < nt) {
-            float v = wave_sum(acc[j]);
-            if (lane == 0) red[wave][j] = v;
-        }
-    }
-    __syncthreads();
-    if (tid < nt) tsum[tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
-    __syncthreads();
-    bf16_t* u = U + (long)m * ldu;
-    if (tid < nproj) {
-        const float* t = &tsum[tid * w];
-        float e[8], mx = -INFINITY;
-        for (int i = 0; i < nl; ++i) mx = fmaxf(mx, t[i]);
-        float sum = 0.f;
-        for (int i = 0; i < nl; ++i) { e[i] = expf(t[i] - mx); sum += e[i]; }
-        const float inv = 1.0f / sum;
-        for (int i = 0; i < nl; ++i)
-            for (int j = 0; j < r; ++j) u[tid * nl * r + i * r + j] = f2bf(scaling * e[i] * inv * t[nl + j]);
-    } else if (tid >= 64 && tid - 64 < ucols - nproj * nl * r) {
-        u[nproj * nl * r + tid - 64] = 0;
-    }
-}
-
-}  // namespace
-
-extern "C" int crab_rms_route(crab_ctx* ctx, void* stream, const void* x, int64_t ldx, const void* norm_w, float eps, void* h_out,
-                              int64_t ldh, const void* RA, int64_t ldra, int M, int K, int nproj, int nl, int r, void* U, int64_t ldu,
-                              int ucols, float scaling) {
-    if (!ctx) return CRAB_E_INVALID;
-    if (!x || !RA || !U || M <= 0 || K <= 0 || (K & 7) || (ldx & 7) || (ldra & 7) || (h_out && (ldh & 7)))
-        return crab_fail(ctx, CRAB_E_INVALID, "rms_route: bad argument");
-    if (nproj < 1 || nproj > 3 || nl < 1 || nl > 8 || nproj * (nl + r) > 33 || ucols < nproj * nl * r || ucols - nproj * nl * r > 192)
-        return crab_fail(ctx, CRAB_E_UNSUPPORTED, "rms_route: nproj*(nl+r) <= 33");
-    if (K > 16384) return crab_fail(ctx, CRAB_E_UNSUPPORTED, "rms_route: K <= 16384");
-    hipStream_t s = (hipStream_t)stream;
-    const int ch = ((K >> 3) + 255) / 256;
-    dim3 grid(M), block(256);
-#define RR_ARGS (const bf16_t*)x, (long)ldx, (const bf16_t*)norm_w, eps, (bf16_t*)h_out, (long)ldh, (const bf16_t*)RA, (long)ldra, K, nproj, nl, r, \
-                (bf16_t*)U, (long)ldu, ucols, scaling
-#define RR_LAUNCH(CH_)                                                                                      \
-    do {                                                                                                    \
-        if (norm_w) hipLaunchKernelGGL((rms_route_kernel<CH_, true>), grid, block, 0, s, RR_ARGS);          \
-        else hipLaunchKernelGGL((rms_route_kernel<CH_, false>), grid, block, 0, s, RR_ARGS);                \
-    } while (0)
-    if (ch <= 2) RR_LAUNCH(2);
-    else if (ch <= 4) RR_LAUNCH(4);
-    else if (ch <= 6) RR_LAUNCH(6);
-    else RR_LAUNCH(8);
-#undef RR_LAUNCH
-#undef RR_ARGS
-    return crab_check_launch(ctx, "rms_route_kernel");
-}

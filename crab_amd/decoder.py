@@ -190,10 +190,12 @@ class GenerationEngine:
         tab = self._rope_tab(Tmax)
         scale = 1.0 / math.sqrt(d)
         ldq = qkv.stride(0)
-        for li, layer in enumerate(self.model.layers):
+        layers = self.model.layers
+        ops.rmsnorm(x, layers[0].input_layernorm.weight, c.rms_norm_eps, out=h)
+        for li, layer in enumerate(layers):
             a, m = layer.self_attn, layer.mlp
             kcl, vcl = kc[li, b0:b0 + B], vc[li, b0:b0 + B]
-            a._qkv(x, out=qkv, t_buf=ws.t, u_buf=ws.u, norm=(layer.input_layernorm.weight, c.rms_norm_eps, ws.h))
+            a._qkv(h, out=qkv, t_buf=ws.t, u_buf=ws.u)
             ops.qkv_rope_split(qkv, tab, kcl, vcl, vt, B, S, H, Hk, d, Tmax, pos0=pos0, pos_dev=pos_dev)
             if vt is not None:
                 Sp = vt.shape[-1]
@@ -202,11 +204,14 @@ class GenerationEngine:
                              Skv=pos0 + S, head_dim=d, scale=scale, causal=True)
             else:
                 ops.attn_decode(qkv, kcl, vcl, att, B, H, Hk, d, Tmax, 1, scale, ctx_dev=pos_dev)
-            a._o(att, residual=x, out=x, t_buf=ws.t, u_buf=ws.u)
-            m._gu(x, out=gu, t_buf=ws.t, u_buf=ws.u, norm=(layer.post_attention_layernorm.weight, c.rms_norm_eps, ws.h))
+            # x += o_proj(att); h = rmsnorm(x) * post_attention_layernorm  (norm fused into the GEMM epilogue for small M)
+            a._o(att, residual=x, out=x, t_buf=ws.t, u_buf=ws.u, post_norm=(layer.post_attention_layernorm.weight, c.rms_norm_eps, h))
+            m._gu(h, out=gu, t_buf=ws.t, u_buf=ws.u)
             ops.swiglu(gu, out=act)
-            m._down(act, residual=x, out=x, t_buf=ws.t, u_buf=ws.u)
-        return x
+            # x += down(act); h = rmsnorm(x) * (next layer's input_layernorm | the final model.norm)
+            nxt = layers[li + 1].input_layernorm.weight if li + 1 < len(layers) else self.model.norm.weight
+            m._down(act, residual=x, out=x, t_buf=ws.t, u_buf=ws.u, post_norm=(nxt, c.rms_norm_eps, h))
+        return x, h
 
     # ------------------------------------------------------------------ prefill
     def prefill(self, embeds: torch.Tensor, kc: torch.Tensor, vc: torch.Tensor, b0: int = 0, all_logits: bool = False,
@@ -225,14 +230,13 @@ class GenerationEngine:
         ops.copy_rows(embeds.reshape(M, D), ws.x, M, D)
         Sp = (S + 7) // 8 * 8
         vt = torch.empty((B, c.num_key_value_heads, c.head_dim, Sp), device=self.device, dtype=BF16)
-        x = self._layers(ws, B, S, kc, vc, b0, Tmax, 0, None, vt)
+        x, hfin = self._layers(ws, B, S, kc, vc, b0, Tmax, 0, None, vt)        # hfin = model.norm(x), all rows
         if all_logits:
-            hn = ops.rmsnorm(x, self.model.norm.weight, c.rms_norm_eps)
+            hn = hfin.clone()
             logits = ops.gemm(hn, self.lm_head.weight, out_fp32=True)
             return logits.view(B, S, -1), hn.view(B, S, D)
-        last = torch.empty((B, D), device=self.device, dtype=BF16)
-        ops.copy_rows(x[S - 1:], last, B, D, lds=S * D)                   # last[b] = x[b*S + S-1]
-        hn = ops.rmsnorm(last, self.model.norm.weight, c.rms_norm_eps, out=hn_out)
+        hn = hn_out if hn_out is not None else torch.empty((B, D), device=self.device, dtype=BF16)
+        ops.copy_rows(hfin[S - 1:], hn, B, D, lds=S * D)                  # hn[b] = hfin[b*S + S-1]
         logits = ops.gemm(hn, self.lm_head.weight, out=logits_out, out_fp32=True)
         return logits, hn
 
@@ -243,9 +247,10 @@ class GenerationEngine:
         B = st.B
         ws = st.ws
         ops.embedding(st.cur_ids, self.model.embed_tokens.weight, out=ws.x[:B])
-        x = self._layers(ws, B, 1, st.kc, st.vc, 0, st.Tmax, 0, st.pos_dev, None)
-        ops.rmsnorm(x, self.model.norm.weight, c.rms_norm_eps, out=st.hn)
-        ops.gemm(st.hn, self.lm_head.weight, out=st.logits)
+        x, hfin = self._layers(ws, B, 1, st.kc, st.vc, 0, st.Tmax, 0, st.pos_dev, None)
+        ops.gemm(hfin, self.lm_head.weight, out=st.logits)
+        if st.want_hidden:
+            ops.copy_rows(hfin, st.hn, B, hfin.shape[1])
         ops.greedy_select(st.logits, st.cur_ids, st.out_ids, st.step_dev, st.finished, st.eos, st.pad, st.min_new)
         ops.advance(st.pos_dev, st.step_dev)
 
@@ -274,6 +279,7 @@ class GenerationEngine:
         st.eos = -1 if eos_token_id is None else int(eos_token_id)
         st.pad = int(pad_token_id) if pad_token_id is not None else (st.eos if st.eos >= 0 else 0)
         st.min_new = int(min_new_tokens)
+        st.want_hidden = bool(return_hidden)
         step_logits, hiddens = [], []
         # ---- prefill in chunks of sequences (bounds activation memory, keeps GEMM M in the MFMA-efficient range)
         for b0 in range(0, B, prefill_chunk):

@@ -78,7 +78,8 @@ def _splitk_workspace(device) -> torch.Tensor:
 
 def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act: str = "none",
          residual: Optional[torch.Tensor] = None, res_scale: float = 1.0, x2: Optional[torch.Tensor] = None,
-         w2: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, out_fp32: bool = False, tune: int = 0) -> torch.Tensor:
+         w2: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, out_fp32: bool = False, tune: int = 0,
+         post_norm=None) -> torch.Tensor:
     """out[M,N] = res_scale*residual + act(x[M,K] @ w[N,K]^T + x2 @ w2^T + bias).  2-D row-strided operands."""
     _chk_bf16(x, w, bias, residual, x2, w2)
     d = _dev(x)
@@ -102,6 +103,8 @@ def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     g.res_scale = res_scale
     g.batch, g.nb0 = 1, 1
     g.tune = tune
+    if post_norm is not None:                      # (weight, eps, out): out = rmsnorm(result) * weight, fused when possible
+        g.norm_w, g.norm_eps, g.norm_out, g.ld_norm = post_norm[0].data_ptr(), post_norm[1], post_norm[2].data_ptr(), post_norm[2].stride(0)
     if M <= 128:
         ws = _splitk_workspace(x.device)
         g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel()
@@ -151,18 +154,6 @@ def hyperlora_route(x: torch.Tensor, ra: torch.Tensor, nproj: int, nl: int, r: i
     _lib.check(_lib.load().crab_hyperlora_route(_lib.ctx(d), _stream(), _p(x), x.stride(0), _p(ra), ra.stride(0), M, K, nproj, nl, r,
                                                 _p(out), out.stride(0), ucols, scaling, _p(workspace),
                                                 workspace.numel() * workspace.element_size()), d)
-    return out
-
-
-def rms_route(x: torch.Tensor, ra: torch.Tensor, nproj: int, nl: int, r: int, ucols: int, scaling: float, out: torch.Tensor,
-              norm_w: Optional[torch.Tensor] = None, eps: float = 0.0, h_out: Optional[torch.Tensor] = None):
-    """Fused (RMSNorm ->) router for small M (one block per row): writes h_out (if norm_w) and U = out."""
-    _chk_bf16(x, ra, norm_w, h_out, out)
-    d = _dev(x)
-    M, K = x.shape
-    _lib.check(_lib.load().crab_rms_route(_lib.ctx(d), _stream(), _p(x), x.stride(0), _p(norm_w), eps, _p(h_out),
-                                          h_out.stride(0) if h_out is not None else 0, _p(ra), ra.stride(0), M, K, nproj, nl, r,
-                                          _p(out), out.stride(0), ucols, scaling), d)
     return out
 
 

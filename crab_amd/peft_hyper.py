@@ -139,32 +139,17 @@ class PackedLinearGroup:
             if self.RA is not None:
                 lin._attach_lora()
 
-    FUSED_ROUTE_MAX_M = 256      # below this the one-block-per-row fused norm+router wins over the split-K router
-
     def __call__(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-                 t_buf: Optional[torch.Tensor] = None, u_buf: Optional[torch.Tensor] = None, norm=None) -> torch.Tensor:
-        """y = group(x) (+residual).  norm = (rms_weight, eps, h_buf): the input is RMS-normalised first (LlamaRMSNorm
-        in front of q/k/v and gate/up); in the decode regime norm + router run as ONE launch."""
+                 t_buf: Optional[torch.Tensor] = None, u_buf: Optional[torch.Tensor] = None, post_norm=None) -> torch.Tensor:
+        """y = group(x) (+residual).  post_norm = (rms_weight, eps, h_out): additionally h_out = rmsnorm(y) * rms_weight
+        (the LlamaRMSNorm that follows o_proj / down_proj), fused into the GEMM epilogue in the decode regime."""
         M = x.shape[0]
         if self.RA is None:
-            if norm is not None:
-                x = ops.rmsnorm(x, norm[0], norm[1], out=norm[2][:M] if norm[2] is not None else None)
-            return ops.gemm(x, self.W, bias=self.bias, residual=residual, out=out)
+            return ops.gemm(x, self.W, bias=self.bias, residual=residual, out=out, post_norm=post_norm)
         u = u_buf[:M, :self.u_cols] if u_buf is not None else torch.empty((M, self.u_cols), device=x.device, dtype=BF16)
-        if M <= self.FUSED_ROUTE_MAX_M and len(self.names) * (self.nl + self.r) <= 33:
-            h = x
-            if norm is not None:
-                h = norm[2][:M] if norm[2] is not None else torch.empty_like(x)
-                ops.rms_route(x, self.RA, len(self.names), self.nl, self.r, self.u_cols, self.scaling, out=u, norm_w=norm[0],
-                              eps=norm[1], h_out=h)
-            else:
-                ops.rms_route(x, self.RA, len(self.names), self.nl, self.r, self.u_cols, self.scaling, out=u)
-            return ops.gemm(h, self.W, bias=self.bias, residual=residual, x2=u, w2=self.B2, out=out)
-        if norm is not None:
-            x = ops.rmsnorm(x, norm[0], norm[1], out=norm[2][:M] if norm[2] is not None else None)
         # route logits | lora_A(x) -> softmax mix, K split over blocks (skinny.hip); t_buf is the partial-sum workspace
         ops.hyperlora_route(x, self.RA, len(self.names), self.nl, self.r, self.u_cols, self.scaling, out=u, workspace=t_buf)
-        return ops.gemm(x, self.W, bias=self.bias, residual=residual, x2=u, w2=self.B2, out=out)
+        return ops.gemm(x, self.W, bias=self.bias, residual=residual, x2=u, w2=self.B2, out=out, post_norm=post_norm)
 
 
 class PeftModelForCausalLM(nn.Module):

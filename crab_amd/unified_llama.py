@@ -129,8 +129,8 @@ class UnifiedForCausalLM(nn.Module, UnifiedMetaForCausalLM):
             ws = eng._workspace(B)
             ops.copy_rows(emb, ws.x, B, emb.shape[1])
             pos = torch.full((1,), n, device=self.device, dtype=torch.int32)
-            x = eng._layers(ws, B, 1, kc, vc, 0, kc.shape[3], 0, pos, None)
-            hn = ops.rmsnorm(x, self.model.norm.weight, self.config.rms_norm_eps)
+            x, hfin = eng._layers(ws, B, 1, kc, vc, 0, kc.shape[3], 0, pos, None)
+            hn = hfin.clone()
             logits = ops.gemm(hn, self.lm_head.weight, out_fp32=True)
             return CausalLMOutput(logits.view(B, 1, -1), (hn.view(B, 1, -1),) if output_hidden_states else None, (kc, vc, n + 1))
         if inputs_embeds is None and batch_input_ids is not None:

@@ -65,6 +65,8 @@ typedef struct {
     int32_t tune;      /* 0 = automatic kernel choice; >0 forces a variant (benchmarking only) */
     void* workspace;   /* optional caller-owned scratch for split-K partials (decode regime, 16 < M <= 128); NULL = none */
     int64_t workspace_bytes;
+    /* optional fused post-RMSNorm: norm_out[M,N] = rmsnorm(C) * norm_w (LlamaRMSNorm behind o_proj / down_proj); bf16 C only */
+    const void* norm_w; void* norm_out; int64_t ld_norm; float norm_eps;
 } crab_gemm_desc;
 
 int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc* d);
@@ -86,13 +88,6 @@ int64_t crab_hyperlora_route_workspace(int M, int K, int tcols);
 int crab_hyperlora_route(crab_ctx* ctx, void* stream, const void* X, int64_t ldx, const void* RA, int64_t ldra, int M, int K,
                          int nproj, int nl, int r, void* U, int64_t ldu, int ucols, float scaling, void* workspace,
                          int64_t workspace_bytes);
-
-/* Decode-regime fusion of (optional) RMSNorm + router, one block per row: h = rmsnorm(x)*w (written to h_out, bf16, when
- * norm_w != NULL; otherwise h = x), U = routing mix of h.[R;A]^T.  RA is [>= nproj*(nl+r), K] bf16.  Replaces
- * LlamaRMSNorm (modeling_llama.py:112-117) + lora_route/lora_A/softmax (lora.py:346-349) for small M. */
-int crab_rms_route(crab_ctx* ctx, void* stream, const void* x, int64_t ldx, const void* norm_w, float eps, void* h_out, int64_t ldh,
-                   const void* RA, int64_t ldra, int M, int K, int nproj, int nl, int r, void* U, int64_t ldu, int ucols,
-                   float scaling);
 
 /* RMSNorm (models/modeling_llama.py:112-117) and LayerNorm (torch.nn.LayerNorm) over the last dim, bf16 in/out. */
 int crab_rmsnorm(crab_ctx* ctx, void* stream, const void* x, int64_t ldx, const void* w, void* y, int64_t ldy,

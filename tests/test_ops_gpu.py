@@ -339,31 +339,17 @@ def test_gemm_splitk_decode_regime(M, tune):
     _cmp(yb, z, 1.2e-2, "bf16 out")
 
 
-@pytest.mark.parametrize("M,K,nproj,norm", [(8, 4096, 3, True), (64, 11008, 1, False), (5, 128, 2, True), (64, 4096, 2, True), (1, 256, 1, False)])
-def test_rms_route_fused(M, K, nproj, norm):
+@pytest.mark.parametrize("M,N", [(64, 4096), (8, 512), (40, 1024), (300, 512)])
+def test_gemm_fused_post_rmsnorm(M, N):
+    """C = x W^T + R and norm_out = rmsnorm(C)*w: fused split-K epilogue (16 < M <= 128), unfused elsewhere."""
     from crab_amd import ops
     from oracle import crab_oracle as O
-    tcols = (nproj * 11 + 15) // 16 * 16
-    ucols = (nproj * 24 + 31) // 32 * 32
-    x = _rand(M, K, seed=1)
-    ra = _rand(tcols, K, seed=2, scale=K ** -0.5)
-    w = (1 + 0.1 * torch.randn(K)).to(BF)
-    u = torch.full((M, ucols), 7.0, dtype=BF, device="cuda")
-    h = torch.empty(M, K, dtype=BF, device="cuda")
-    if norm:
-        ops.rms_route(x.cuda(), ra.cuda(), nproj, 3, 8, ucols, 2.0, out=u, norm_w=w.cuda(), eps=1e-5, h_out=h)
-        href = O.rmsnorm(x.float(), w.float(), 1e-5, emulate=BF)
-        _cmp(h, href, 1e-2, "fused rmsnorm")
-        hin = h.cpu().float()
-    else:
-        ops.rms_route(x.cuda(), ra.cuda(), nproj, 3, 8, ucols, 2.0, out=u)
-        hin = x.float()
-    t = hin @ ra.float().t()
-    ref = torch.zeros(M, ucols)
-    for p in range(nproj):
-        seg = t[:, p * 11:(p + 1) * 11]
-        pr = torch.softmax(seg[:, :3], -1)
-        for i in range(3):
-            ref[:, p * 24 + i * 8:p * 24 + (i + 1) * 8] = 2.0 * pr[:, i:i + 1] * seg[:, 3:]
-    _cmp(u, ref, 1.2e-2, "fused route")
-    assert (u[:, nproj * 24:] == 0).all()
+    K = 1024
+    x, w, r = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=K ** -0.5), _rand(M, N, seed=3)
+    nw = (1 + 0.1 * torch.randn(N)).to(BF)
+    xd = r.cuda().clone()                       # in-place residual: out == residual buffer
+    h = torch.empty(M, N, dtype=BF, device="cuda")
+    ops.gemm(x.cuda(), w.cuda(), residual=xd, out=xd, post_norm=(nw.cuda(), 1e-5, h))
+    c_ref = (x.float() @ w.float().t() + r.float())
+    _cmp(xd, c_ref, 1.2e-2, "C")
+    _cmp(h, O.rmsnorm(xd.cpu().float(), nw.float(), 1e-5, emulate=BF), 1e-2, "post-norm")
