@@ -262,7 +262,15 @@ __global__ __launch_bounds__(256) void splitk_epilogue_norm_kernel(const float* 
         if (n < N) {
             f32x4_t v = {0.f, 0.f, 0.f, 0.f};
             const float* pp = part + (long)m * N + n;
-            for (int s = 0; s < S; ++s) v += *reinterpret_cast<const f32x4_t*>(pp + s * MN);
+            int s = 0;
+            for (; s + 4 <= S; s += 4) {                          // 4 slices in flight, summed in slice order
+                f32x4_t t0 = *reinterpret_cast<const f32x4_t*>(pp + (s + 0) * MN);
+                f32x4_t t1 = *reinterpret_cast<const f32x4_t*>(pp + (s + 1) * MN);
+                f32x4_t t2 = *reinterpret_cast<const f32x4_t*>(pp + (s + 2) * MN);
+                f32x4_t t3 = *reinterpret_cast<const f32x4_t*>(pp + (s + 3) * MN);
+                v += t0; v += t1; v += t2; v += t3;
+            }
+            for (; s < S; ++s) v += *reinterpret_cast<const f32x4_t*>(pp + s * MN);
             u32x2 rr = {0u, 0u};
             if (R) rr = *reinterpret_cast<const u32x2*>(R + (long)m * ldr + n);
             float rv[4] = {lo_bf(rr[0]), hi_bf(rr[0]), lo_bf(rr[1]), hi_bf(rr[1])};
@@ -340,14 +348,16 @@ extern "C" int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc*
             return rc ? rc : post_norm(ctx, stream, d);
         }
         sk_bm = d->M <= 64 ? 64 : 128;
-        sk_bn = 128;
+        sk_bn = (sk_bm == 64 && d->N <= 4096) ? 64 : 128;          // narrow outputs: 64-wide tiles double the grid instead of the split
         if (d->tune >= 200) sk_bn = 64;
+        else if (d->tune >= 100) sk_bn = 128;
         if (sk_bm == 128 && sk_bn == 64) sk_bn = 128;
         long tiles = (long)((d->N + sk_bn - 1) / sk_bn) * ((d->M + sk_bm - 1) / sk_bm);
         splitk = (int)((640 + tiles - 1) / tiles);
         if (d->tune >= 100) splitk = d->tune % 100;
         if (splitk > nk_all / 4) splitk = nk_all / 4;
         if (splitk < 1) splitk = 1;
+        if (splitk > 8 && d->tune < 100) splitk = 8;               // partial slabs: S*M*N*4 bytes written and re-read
         if (splitk > 32) splitk = 32;
         while (splitk > 1 && (int64_t)splitk * d->M * d->N * 4 > d->workspace_bytes) --splitk;
     }

@@ -181,7 +181,16 @@ __global__ __launch_bounds__(256) void lora_mix_reduce_kernel(const float* __res
         if (m < M && c < tcols) {
             float acc = 0.f;
             const float* q = part + (long)m * tcols + c;
-            for (int s = 0; s < nslices; ++s) acc += q[(long)s * M * tcols];
+            const long st = (long)M * tcols;
+            int s = 0;
+            for (; s + 8 <= nslices; s += 8) {                    // 8 independent loads in flight, summed in slice order
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = q[(s + i) * st];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc += v[i];
+            }
+            for (; s < nslices; ++s) acc += q[s * st];
             T[row][c] = acc;
         }
     }
@@ -244,7 +253,7 @@ extern "C" int64_t crab_hyperlora_route_workspace(int M, int K, int tcols) {
     int maxs = (K + 127) / 128;
     if (nslices > maxs) nslices = maxs;
     if (nslices < 1) nslices = 1;
-    if (nslices > 64) nslices = 64;
+    if (nslices > 16) nslices = 16;
     return (int64_t)nslices * M * tcols * (int64_t)sizeof(float);
 }
 
@@ -262,7 +271,7 @@ extern "C" int crab_hyperlora_route(crab_ctx* ctx, void* stream, const void* X, 
     int maxs = (K + 127) / 128;
     if (nslices > maxs) nslices = maxs;
     if (nslices < 1) nslices = 1;
-    if (nslices > 64) nslices = 64;
+    if (nslices > 16) nslices = 16;
     int kslice = (((K + nslices - 1) / nslices) + 31) / 32 * 32;
     nslices = (K + kslice - 1) / kslice;
     hipStream_t s = (hipStream_t)stream;
