@@ -312,6 +312,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_norm_kernel(const float* 
 }  // namespace
 
 int crab_gemm_skinny_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* d);   // skinny.hip
+int crab_gemm_glds_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* d);     // gemm_glds.hip
 
 // unfused form of the optional post-RMSNorm (paths whose epilogue does not own whole rows)
 static int post_norm(crab_ctx* ctx, void* stream, const crab_gemm_desc* d) {
@@ -401,6 +402,11 @@ extern "C" int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc*
     // tile choice: 128x128 when it fills the chip, 64x64 for small / skinny problems
     long big_tiles = (long)((d->M + 127) / 128) * ((d->N + 127) / 128) * batch;
     bool small = (d->M <= 64) || (d->N <= 64) || big_tiles < 192;
+    if (!small && d->tune != 300) {
+        // 128x128 tiles: LDS-DMA staged kernel (gemm_glds.hip); tune == 300 keeps the register-staged variant for A/B runs
+        int rc = crab_gemm_glds_launch(ctx, s, d);
+        return rc ? rc : post_norm(ctx, stream, d);
+    }
     if (!small) {
         p.tiles_m = (d->M + 127) / 128; p.tiles_n = (d->N + 127) / 128;
         dim3 grid(p.tiles_m * p.tiles_n, batch);

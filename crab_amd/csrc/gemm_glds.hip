@@ -1,0 +1,212 @@
+// bf16 MFMA GEMM, direct-to-LDS staging variant (prefill / encoder regime, M > 128).
+//
+// Same math, tile (128x128x64, 4 waves of 64x64) and LDS image as gemm_bt_kernel in gemm.hip, but the global->LDS
+// copy is done by the LDS-DMA path (`global_load_lds_dwordx4`, 16 B per lane): no staging VGPRs, no ds_write pass, no
+// address VALU in the loop.  An LDS-DMA instruction writes wave-uniform base + lane*16, i.e. one linear 1-KiB piece
+// (8 tile rows of 128 B) per wave instruction, so the 16-byte XOR swizzle (chunk ^ ((row>>1)&7)) that keeps the
+// ds_read_b128 fragment reads conflict-free is applied to the per-lane SOURCE address (lane l of a piece fetches
+// logical chunk (l&7) ^ swz(row)) and again on the read side (cdna guide 5.4 rule 21: linear dest + inverse-swizzled
+// source + swizzled read).  Out-of-range rows / K tails fetch from a zero page instead, so any M, N and K % 8 == 0
+// work without a register path.
+//
+// Pipeline: two LDS stages; the DMA of tile t+1 is issued before the MFMAs of tile t and drained (vmcnt(0)) at the
+// single barrier per K tile.  Two blocks per CU (64 KiB LDS each) overlap one block's drain with the other's MFMAs.
+#include "common.h"
+#include "crab_internal.h"
+
+namespace {
+
+struct GemmGP {
+    const bf16_t* A; const bf16_t* B; void* C; const bf16_t* bias; const bf16_t* R;
+    const bf16_t* A2; const bf16_t* B2;
+    long lda, ldb, ldc, ldr, lda2, ldb2;
+    int M, N, K, K2, act, c_fp32;
+    float res_scale;
+    int nb0;
+    long sA0, sA1, sB0, sB1, sC0, sC1, sR0, sR1, sBias0, sBias1;
+    int tiles_m, tiles_n;
+};
+
+__device__ __attribute__((aligned(16))) uint32_t g_zero_page[64];      // zero-initialised device memory (256 B)
+
+typedef __attribute__((address_space(3))) void* lds_vptr;
+typedef const __attribute__((address_space(1))) void* gbl_vptr;
+
+constexpr int GBK = 64;
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_bt_glds_kernel(GemmGP p) {
+    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int TM = WM / 16, TN = WN / 16;
+    constexpr int PA = BM / 8, PB = BN / 8;                  // 1-KiB pieces per operand tile
+    constexpr int PPW = (PA + PB) / 4;                       // pieces per wave per K tile
+    __shared__ __attribute__((aligned(16))) bf16_t lds[2][(BM + BN) * GBK];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int z = blockIdx.y;
+    const int z0 = z % p.nb0, z1 = z / p.nb0;
+    const bf16_t* A = p.A + z0 * p.sA0 + z1 * p.sA1;
+    const bf16_t* B = p.B + z0 * p.sB0 + z1 * p.sB1;
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int bid = xcd_remap(blockIdx.x, nwg);
+    const int tm = bid % p.tiles_m, tn = bid / p.tiles_m;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int nk1 = (p.K + GBK - 1) / GBK;
+    const int nk2 = p.A2 ? (p.K2 + GBK - 1) / GBK : 0;
+    const int nk = nk1 + nk2;
+
+    // per-lane staging coordinates, hoisted out of the K loop.  With PA == PB (square tile) waves 0,1 stage the
+    // activation tile and waves 2,3 the weight tile, so the operand choice is wave-uniform.
+    static_assert(PA == PB && PA % PPW == 0, "operand choice must be uniform per wave");
+    const bool isA = wave * PPW < PA;
+    const int prow = lane >> 3, pc = lane & 7;
+    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page);
+    const bf16_t* base1 = isA ? A + (long)m0 * p.lda : B + (long)n0 * p.ldb;
+    const bf16_t* base2 = p.A2 ? (isA ? p.A2 + (long)m0 * p.lda2 : p.B2 + (long)n0 * p.ldb2) : zero;
+    const int ld1 = (int)(isA ? p.lda : p.ldb), ld2 = (int)(isA ? p.lda2 : p.ldb2);
+    const int lim = isA ? p.M - m0 : p.N - n0;              // valid rows of this operand tile
+    int off1[PPW], off2[PPW], kc[PPW], ldso[PPW];
+    bool rok[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int q = wave * PPW + i;
+        const int pr0 = (isA ? q : q - PA) * 8;               // first tile row of the piece
+        const int row = pr0 + prow;
+        const int c = pc ^ ((row >> 1) & 7);                 // logical chunk this lane fetches (inverse swizzle)
+        kc[i] = c * 8;
+        rok[i] = row < lim;
+        off1[i] = row * ld1 + c * 8;
+        off2[i] = row * ld2 + c * 8;
+        ldso[i] = (isA ? 0 : BM * GBK) + pr0 * GBK;           // wave-uniform LDS element offset of the piece
+    }
+
+#define STAGE(T_, BUF_)                                                                                   \
+    {                                                                                                     \
+        const int t_ = (T_);                                                                              \
+        const bool s2_ = t_ >= nk1;                                                                       \
+        const int k0_ = (s2_ ? t_ - nk1 : t_) * GBK;                                                      \
+        const int Ks_ = s2_ ? p.K2 : p.K;                                                                 \
+        const bf16_t* bs_ = (s2_ ? base2 : base1) + k0_;                                                  \
+        _Pragma("unroll") for (int i = 0; i < PPW; ++i) {                                                 \
+            const bool ok_ = rok[i] && (k0_ + kc[i] < Ks_);                                               \
+            const bf16_t* src_ = bs_ + (s2_ ? off2[i] : off1[i]);                                         \
+            src_ = ok_ ? src_ : zero;                                                                     \
+            bf16_t* dst_ = &lds[(BUF_)][__builtin_amdgcn_readfirstlane(ldso[i])];                         \
+            __builtin_amdgcn_global_load_lds((gbl_vptr)src_, (lds_vptr)dst_, 16, 0, 0);                   \
+        }                                                                                                 \
+    }
+
+    f32x4_t acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    STAGE(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int fr = lane & 15, fg = lane >> 4;
+    for (int t = 0; t < nk; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nk) STAGE(t + 1, cur ^ 1);
+        const bf16_t* la_ = &lds[cur][0];
+        const bf16_t* lb_ = &lds[cur][BM * GBK];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8_t wf[TN], xf[TM];
+            const int chunk = ks * 4 + fg;
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+                int row = wn * WN + ni * 16 + fr;
+                wf[ni] = *reinterpret_cast<const bf16x8_t*>(lb_ + row * GBK + ((chunk ^ ((row >> 1) & 7)) << 3));
+            }
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi) {
+                int row = wm * WM + mi * 16 + fr;
+                xf[mi] = *reinterpret_cast<const bf16x8_t*>(la_ + row * GBK + ((chunk ^ ((row >> 1) & 7)) << 3));
+            }
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // epilogue (identical to gemm_bt_kernel): lane owns row m = ..+fr, columns n = ..+fg*4 .. +3 of each 16x16 tile
+    const bf16_t* bias = p.bias ? p.bias + z0 * p.sBias0 + z1 * p.sBias1 : nullptr;
+    const bf16_t* R = p.R ? p.R + z0 * p.sR0 + z1 * p.sR1 : nullptr;
+    const long coff = z0 * p.sC0 + z1 * p.sC1;
+    const bool vec_ok = ((p.ldc & 3) == 0) && ((coff & 3) == 0) && (!R || ((p.ldr & 3) == 0));
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+        const int m = m0 + wm * WM + mi * 16 + fr;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+            const int n = n0 + wn * WN + ni * 16 + fg * 4;
+            if (n >= p.N) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float x = acc[ni][mi][r];
+                if (bias && n + r < p.N) x += bf2f(bias[n + r]);
+                v[r] = apply_act(x, p.act);
+            }
+            if (n + 3 < p.N && vec_ok) {
+                if (R) {
+                    u32x2 rr = *reinterpret_cast<const u32x2*>(R + (long)m * p.ldr + n);
+                    v[0] += p.res_scale * lo_bf(rr.x); v[1] += p.res_scale * hi_bf(rr.x);
+                    v[2] += p.res_scale * lo_bf(rr.y); v[3] += p.res_scale * hi_bf(rr.y);
+                }
+                if (p.c_fp32) {
+                    float* C = reinterpret_cast<float*>(p.C) + coff + (long)m * p.ldc + n;
+                    *reinterpret_cast<float4*>(C) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    bf16_t* C = reinterpret_cast<bf16_t*>(p.C) + coff + (long)m * p.ldc + n;
+                    u32x2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
+                    *reinterpret_cast<u32x2*>(C) = o;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (n + r >= p.N) break;
+                    float x = v[r];
+                    if (R) x += p.res_scale * bf2f(R[(long)m * p.ldr + n + r]);
+                    if (p.c_fp32) reinterpret_cast<float*>(p.C)[coff + (long)m * p.ldc + n + r] = x;
+                    else reinterpret_cast<bf16_t*>(p.C)[coff + (long)m * p.ldc + n + r] = f2bf(x);
+                }
+            }
+        }
+    }
+}
+
+#undef STAGE
+}  // namespace
+
+// called from crab_gemm_bf16 (gemm.hip) for the 128x128 tile regime
+int crab_gemm_glds_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* d) {
+    GemmGP p;
+    p.A = (const bf16_t*)d->A; p.B = (const bf16_t*)d->B; p.C = d->C; p.bias = (const bf16_t*)d->bias; p.R = (const bf16_t*)d->R;
+    p.A2 = (const bf16_t*)d->A2; p.B2 = (const bf16_t*)d->B2;
+    p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc; p.ldr = d->ldr; p.lda2 = d->lda2; p.ldb2 = d->ldb2;
+    p.M = d->M; p.N = d->N; p.K = d->K; p.K2 = d->A2 ? d->K2 : 0; p.act = d->act; p.c_fp32 = d->c_fp32; p.res_scale = d->res_scale;
+    int batch = d->batch > 1 ? d->batch : 1;
+    p.nb0 = (batch > 1 && d->nb0 > 0) ? d->nb0 : 1;
+    p.sA0 = d->sA0; p.sA1 = d->sA1; p.sB0 = d->sB0; p.sB1 = d->sB1; p.sC0 = d->sC0; p.sC1 = d->sC1;
+    p.sR0 = d->sR0; p.sR1 = d->sR1; p.sBias0 = d->sBias0; p.sBias1 = d->sBias1;
+    if (batch == 1) { p.sA0 = p.sA1 = p.sB0 = p.sB1 = p.sC0 = p.sC1 = p.sR0 = p.sR1 = p.sBias0 = p.sBias1 = 0; }
+    p.tiles_m = (d->M + 127) / 128; p.tiles_n = (d->N + 127) / 128;
+    dim3 grid(p.tiles_m * p.tiles_n, batch);
+    hipLaunchKernelGGL((gemm_bt_glds_kernel<128, 128>), grid, dim3(256), 0, s, p);
+    return crab_check_launch(ctx, "gemm_bt_glds_kernel");
+}
