@@ -124,7 +124,7 @@ def main():
     ap.add_argument("--clips", type=int, default=int(os.environ.get("CRAB_BENCH_CLIPS", "64")), help="clips per GPU per step")
     ap.add_argument("--new-tokens", type=int, default=256)
     ap.add_argument("--frames", type=int, default=8)
-    ap.add_argument("--prefill-chunk", type=int, default=4)
+    ap.add_argument("--prefill-chunk", type=int, default=8)
     ap.add_argument("--llm", default="llama")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()

@@ -30,9 +30,9 @@ print(f"encoders+splice B={B}: {t*1e3:.1f} ms  ({t/B*1e3:.2f} ms/clip)  S={emb.s
 eng = um._engine
 S = emb.shape[1]
 kc, vc = eng.alloc_cache(B, 1024)
-t, _ = timed(lambda: eng.prefill(emb[:4], kc, vc, b0=0))
-fl = 4 * (S * (2 * 6.476e9 + 90.3e6) + 2 * S * S * 131072)
-print(f"prefill 4 clips: {t*1e3:.1f} ms -> {fl/t/1e12:.1f} TFLOP/s ({fl/t/2.5e15*100:.1f}% of 2.5PF)", flush=True)
+t, _ = timed(lambda: eng.prefill(emb[:8], kc, vc, b0=0))
+fl = 8 * (S * (2 * 6.476e9 + 90.3e6) + 2 * S * S * 131072)
+print(f"prefill 8 clips: {t*1e3:.1f} ms -> {fl/t/1e12:.1f} TFLOP/s ({fl/t/2.5e15*100:.1f}% of 2.5PF)", flush=True)
 t, out = timed(lambda: um.generate(inputs_embeds=emb, max_new_tokens=NEW, min_new_tokens=NEW, eos_token_id=2, pad_token_id=2), n=2)
 print(f"generate B={B} new={NEW}: {t*1e3:.1f} ms", flush=True)
 t2, out = timed(lambda: um.generate(inputs_embeds=emb, max_new_tokens=2 * NEW, min_new_tokens=2 * NEW, eos_token_id=2, pad_token_id=2), n=2)
