@@ -191,6 +191,177 @@ __global__ __launch_bounds__(256) void gemm_bt_glds_kernel(GemmGP p) {
 }
 
 #undef STAGE
+
+// ------------------------------------------------------------------------------------------------------------
+// Ring variant: BK = 32, four LDS stages (4 x 16 KiB = 64 KiB, two blocks per CU), LDS-DMA issued THREE K tiles
+// ahead and retired with a COUNTED wait (s_waitcnt vmcnt(8): the two youngest tiles stay in flight across the
+// barrier), so HBM/L2 latency is covered by ~3 tiles of MFMA work instead of one.  One raw s_barrier per K tile.
+//   LDS image per stage: [BM + BN rows][32 k] bf16, 64-B rows, 16-B chunk swizzle pc = c ^ P[(row>>2)&3], P = {0,2,3,1}
+//   (conflict-free for the 16-lane ds_read_b128 groups {0-3,12-15,20-27}, ... of gfx950).
+//   RAW: a tile is read one iteration after the vmcnt+barrier that retired it.  WAR: the stage refilled in iteration
+//   t was last read in iteration t-1, whose reads are drained (lgkmcnt(0)) before that iteration's barrier.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int RBK = 32, RNS = 4;
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_bt_ring_kernel(GemmGP p) {
+    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int TM = WM / 16, TN = WN / 16;
+    constexpr int PA = BM / 16, PB = BN / 16;                // 1-KiB pieces (16 rows x 64 B) per operand tile
+    constexpr int PPW = (PA + PB) / 4;                       // pieces per wave per K tile (4)
+    constexpr int STAGE_ELEMS = (BM + BN) * RBK;
+    __shared__ __attribute__((aligned(16))) bf16_t lds[RNS * STAGE_ELEMS];
+    static_assert(PA == PB && PA % PPW == 0, "operand choice must be uniform per wave");
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int z = blockIdx.y;
+    const int z0 = z % p.nb0, z1 = z / p.nb0;
+    const bf16_t* A = p.A + z0 * p.sA0 + z1 * p.sA1;
+    const bf16_t* B = p.B + z0 * p.sB0 + z1 * p.sB1;
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int bid = xcd_remap(blockIdx.x, nwg);
+    const int tm = bid % p.tiles_m, tn = bid / p.tiles_m;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int nk1 = (p.K + RBK - 1) / RBK;
+    const int nk2 = p.A2 ? (p.K2 + RBK - 1) / RBK : 0;
+    const int nk = nk1 + nk2;
+
+    const bool isA = wave * PPW < PA;
+    const int prow = lane >> 2, pc = lane & 3;
+    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page);
+    const bf16_t* base1 = isA ? A + (long)m0 * p.lda : B + (long)n0 * p.ldb;
+    const bf16_t* base2 = p.A2 ? (isA ? p.A2 + (long)m0 * p.lda2 : p.B2 + (long)n0 * p.ldb2) : zero;
+    const int ld1 = (int)(isA ? p.lda : p.ldb), ld2 = (int)(isA ? p.lda2 : p.ldb2);
+    const int lim = isA ? p.M - m0 : p.N - n0;
+    int off1[PPW], off2[PPW], kc[PPW], ldso[PPW];
+    bool rok[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int q = wave * PPW + i;
+        const int pr0 = (isA ? q : q - PA) * 16;
+        const int row = pr0 + prow;
+        const int c = pc ^ ((0x78 >> (((row >> 2) & 3) * 2)) & 3);
+        kc[i] = c * 8;
+        rok[i] = row < lim;
+        off1[i] = row * ld1 + c * 8;
+        off2[i] = row * ld2 + c * 8;
+        ldso[i] = (isA ? 0 : BM * RBK) + pr0 * RBK;
+    }
+#define RSTAGE(T_)                                                                                        \
+    {                                                                                                     \
+        const int t_ = (T_);                                                                              \
+        const int sb_ = (t_ & (RNS - 1)) * STAGE_ELEMS;                                                   \
+        const bool s2_ = t_ >= nk1;                                                                       \
+        const int k0_ = (s2_ ? t_ - nk1 : t_) * RBK;                                                      \
+        const int Ks_ = s2_ ? p.K2 : p.K;                                                                 \
+        const bf16_t* bs_ = (s2_ ? base2 : base1) + k0_;                                                  \
+        _Pragma("unroll") for (int i = 0; i < PPW; ++i) {                                                 \
+            const bool ok_ = rok[i] && (k0_ + kc[i] < Ks_);                                               \
+            const bf16_t* src_ = bs_ + (s2_ ? off2[i] : off1[i]);                                         \
+            src_ = ok_ ? src_ : zero;                                                                     \
+            bf16_t* dst_ = &lds[sb_ + __builtin_amdgcn_readfirstlane(ldso[i])];                           \
+            __builtin_amdgcn_global_load_lds((gbl_vptr)src_, (lds_vptr)dst_, 16, 0, 0);                   \
+        }                                                                                                 \
+    }
+
+    f32x4_t acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // prologue: tiles 0..2 in flight, tile 0 retired
+    RSTAGE(0);
+    if (nk > 1) RSTAGE(1);
+    if (nk > 2) RSTAGE(2);
+    if (nk > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    const int fr = lane & 15, fg = lane >> 4;
+    // fragment byte offsets inside a stage (constant over the loop)
+    int wofs[TN], xofs[TM];
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) {
+        const int row = wn * WN + ni * 16 + fr;
+        wofs[ni] = BM * RBK + row * RBK + ((fg ^ ((0x78 >> (((row >> 2) & 3) * 2)) & 3)) << 3);
+    }
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+        const int row = wm * WM + mi * 16 + fr;
+        xofs[mi] = row * RBK + ((fg ^ ((0x78 >> (((row >> 2) & 3) * 2)) & 3)) << 3);
+    }
+
+    for (int t = 0; t < nk; ++t) {
+        if (t + 3 < nk) RSTAGE(t + 3);
+        const bf16_t* st = &lds[(t & (RNS - 1)) * STAGE_ELEMS];
+        bf16x8_t wf[TN], xf[TM];
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) wf[ni] = *reinterpret_cast<const bf16x8_t*>(st + wofs[ni]);
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) xf[mi] = *reinterpret_cast<const bf16x8_t*>(st + xofs[mi]);
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
+        // retire tile t+1 (keep the two youngest tiles in flight), drain this tile's LDS reads, one barrier per tile
+        if (t + 3 < nk) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+#undef RSTAGE
+    // epilogue (identical to gemm_bt_kernel): lane owns row m = ..+fr, columns n = ..+fg*4 .. +3 of each 16x16 tile
+    const bf16_t* bias = p.bias ? p.bias + z0 * p.sBias0 + z1 * p.sBias1 : nullptr;
+    const bf16_t* R = p.R ? p.R + z0 * p.sR0 + z1 * p.sR1 : nullptr;
+    const long coff = z0 * p.sC0 + z1 * p.sC1;
+    const bool vec_ok = ((p.ldc & 3) == 0) && ((coff & 3) == 0) && (!R || ((p.ldr & 3) == 0));
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+        const int m = m0 + wm * WM + mi * 16 + fr;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+            const int n = n0 + wn * WN + ni * 16 + fg * 4;
+            if (n >= p.N) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float x = acc[ni][mi][r];
+                if (bias && n + r < p.N) x += bf2f(bias[n + r]);
+                v[r] = apply_act(x, p.act);
+            }
+            if (n + 3 < p.N && vec_ok) {
+                if (R) {
+                    u32x2 rr = *reinterpret_cast<const u32x2*>(R + (long)m * p.ldr + n);
+                    v[0] += p.res_scale * lo_bf(rr.x); v[1] += p.res_scale * hi_bf(rr.x);
+                    v[2] += p.res_scale * lo_bf(rr.y); v[3] += p.res_scale * hi_bf(rr.y);
+                }
+                if (p.c_fp32) {
+                    float* C = reinterpret_cast<float*>(p.C) + coff + (long)m * p.ldc + n;
+                    *reinterpret_cast<float4*>(C) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    bf16_t* C = reinterpret_cast<bf16_t*>(p.C) + coff + (long)m * p.ldc + n;
+                    u32x2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
+                    *reinterpret_cast<u32x2*>(C) = o;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (n + r >= p.N) break;
+                    float x = v[r];
+                    if (R) x += p.res_scale * bf2f(R[(long)m * p.ldr + n + r]);
+                    if (p.c_fp32) reinterpret_cast<float*>(p.C)[coff + (long)m * p.ldc + n + r] = x;
+                    else reinterpret_cast<bf16_t*>(p.C)[coff + (long)m * p.ldc + n + r] = f2bf(x);
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 // called from crab_gemm_bf16 (gemm.hip) for the 128x128 tile regime
@@ -207,6 +378,7 @@ int crab_gemm_glds_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* d)
     if (batch == 1) { p.sA0 = p.sA1 = p.sB0 = p.sB1 = p.sC0 = p.sC1 = p.sR0 = p.sR1 = p.sBias0 = p.sBias1 = 0; }
     p.tiles_m = (d->M + 127) / 128; p.tiles_n = (d->N + 127) / 128;
     dim3 grid(p.tiles_m * p.tiles_n, batch);
-    hipLaunchKernelGGL((gemm_bt_glds_kernel<128, 128>), grid, dim3(256), 0, s, p);
-    return crab_check_launch(ctx, "gemm_bt_glds_kernel");
+    if (d->tune == 301) hipLaunchKernelGGL((gemm_bt_glds_kernel<128, 128>), grid, dim3(256), 0, s, p);   // 2-stage variant, A/B runs
+    else hipLaunchKernelGGL((gemm_bt_ring_kernel<128, 128>), grid, dim3(256), 0, s, p);
+    return crab_check_launch(ctx, "gemm_bt_ring_kernel");
 }
