@@ -193,9 +193,12 @@ __global__ __launch_bounds__(256) void gemm_bt_glds_kernel(GemmGP p) {
 #undef STAGE
 
 // ------------------------------------------------------------------------------------------------------------
-// Ring variant: BK = 32, four LDS stages (4 x 16 KiB = 64 KiB, two blocks per CU), LDS-DMA issued THREE K tiles
-// ahead and retired with a COUNTED wait (s_waitcnt vmcnt(8): the two youngest tiles stay in flight across the
-// barrier), so HBM/L2 latency is covered by ~3 tiles of MFMA work instead of one.  One raw s_barrier per K tile.
+// Ring variant for large problems: 256x256 tile, 8 waves (2 x 4, 128x64 per wave, two waves per SIMD), BK = 32, four
+// LDS stages (4 x 32 KiB = 128 KiB, one block per CU).  A 256^2 tile halves the L2->LDS bytes per FLOP of the 128^2
+// tile (the 128^2 kernel is bound by LDS-DMA latency/L2 bandwidth: ~13 TB/s of L2 traffic at 860 TFLOP/s); the
+// LDS-DMA is issued THREE K tiles ahead and retired with a COUNTED wait (s_waitcnt vmcnt(8): the two youngest tiles
+// stay in flight across the barrier), so L2/HBM latency is covered by ~3 tiles (~1.3 us) of MFMA work.
+// One raw s_barrier per K tile (32 MFMAs per wave).
 //   LDS image per stage: [BM + BN rows][32 k] bf16, 64-B rows, 16-B chunk swizzle pc = c ^ P[(row>>2)&3], P = {0,2,3,1}
 //   (conflict-free for the 16-lane ds_read_b128 groups {0-3,12-15,20-27}, ... of gfx950).
 //   RAW: a tile is read one iteration after the vmcnt+barrier that retired it.  WAR: the stage refilled in iteration
@@ -203,12 +206,13 @@ __global__ __launch_bounds__(256) void gemm_bt_glds_kernel(GemmGP p) {
 // ------------------------------------------------------------------------------------------------------------
 constexpr int RBK = 32, RNS = 4;
 
-template <int BM, int BN>
-__global__ __launch_bounds__(256) void gemm_bt_ring_kernel(GemmGP p) {
-    constexpr int WM = BM / 2, WN = BN / 2;
+template <int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(WGM * WGN * 64) void gemm_bt_ring_kernel(GemmGP p) {
+    constexpr int NW = WGM * WGN;
+    constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int TM = WM / 16, TN = WN / 16;
     constexpr int PA = BM / 16, PB = BN / 16;                // 1-KiB pieces (16 rows x 64 B) per operand tile
-    constexpr int PPW = (PA + PB) / 4;                       // pieces per wave per K tile (4)
+    constexpr int PPW = (PA + PB) / NW;                      // pieces per wave per K tile (4)
     constexpr int STAGE_ELEMS = (BM + BN) * RBK;
     __shared__ __attribute__((aligned(16))) bf16_t lds[RNS * STAGE_ELEMS];
     static_assert(PA == PB && PA % PPW == 0, "operand choice must be uniform per wave");
@@ -216,7 +220,7 @@ __global__ __launch_bounds__(256) void gemm_bt_ring_kernel(GemmGP p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WGN, wn = wave % WGN;
     const int z = blockIdx.y;
     const int z0 = z % p.nb0, z1 = z / p.nb0;
     const bf16_t* A = p.A + z0 * p.sA0 + z1 * p.sA1;
@@ -277,6 +281,7 @@ __global__ __launch_bounds__(256) void gemm_bt_ring_kernel(GemmGP p) {
     RSTAGE(0);
     if (nk > 1) RSTAGE(1);
     if (nk > 2) RSTAGE(2);
+    static_assert(PPW == 4, "vmcnt(8) below = two tiles of 4 LDS-DMA instructions per wave");
     if (nk > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -376,9 +381,19 @@ int crab_gemm_glds_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* d)
     p.sA0 = d->sA0; p.sA1 = d->sA1; p.sB0 = d->sB0; p.sB1 = d->sB1; p.sC0 = d->sC0; p.sC1 = d->sC1;
     p.sR0 = d->sR0; p.sR1 = d->sR1; p.sBias0 = d->sBias0; p.sBias1 = d->sBias1;
     if (batch == 1) { p.sA0 = p.sA1 = p.sB0 = p.sB1 = p.sC0 = p.sC1 = p.sR0 = p.sR1 = p.sBias0 = p.sBias1 = 0; }
+    // 256x256 ring kernel when the problem fills the chip with big tiles; 128x128 two-stage kernel otherwise
+    const long big = (long)((d->M + 255) / 256) * ((d->N + 255) / 256) * batch;
+    bool use_big = big >= 192 && d->M >= 1024 && d->N >= 1024;
+    if (d->tune == 301) use_big = false;
+    if (d->tune == 302) use_big = true;
+    if (use_big) {
+        p.tiles_m = (d->M + 255) / 256; p.tiles_n = (d->N + 255) / 256;
+        dim3 grid(p.tiles_m * p.tiles_n, batch);
+        hipLaunchKernelGGL((gemm_bt_ring_kernel<256, 256, 2, 4>), grid, dim3(512), 0, s, p);
+        return crab_check_launch(ctx, "gemm_bt_ring_kernel");
+    }
     p.tiles_m = (d->M + 127) / 128; p.tiles_n = (d->N + 127) / 128;
     dim3 grid(p.tiles_m * p.tiles_n, batch);
-    if (d->tune == 301) hipLaunchKernelGGL((gemm_bt_glds_kernel<128, 128>), grid, dim3(256), 0, s, p);   // 2-stage variant, A/B runs
-    else hipLaunchKernelGGL((gemm_bt_ring_kernel<128, 128>), grid, dim3(256), 0, s, p);
-    return crab_check_launch(ctx, "gemm_bt_ring_kernel");
+    hipLaunchKernelGGL((gemm_bt_glds_kernel<128, 128>), grid, dim3(256), 0, s, p);
+    return crab_check_launch(ctx, "gemm_bt_glds_kernel");
 }

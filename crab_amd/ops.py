@@ -62,7 +62,10 @@ PROFILER: Optional[GemmProfiler] = None
 def _variant(M: int, N: int, batch: int = 1) -> str:
     """Mirror of the tile choice in csrc/gemm.hip (crab_gemm_bf16)."""
     big = ((M + 127) // 128) * ((N + 127) // 128) * batch
-    return "gemm_bt_kernel<64,64>" if (M <= 64 or N <= 64 or big < 192) else "gemm_bt_ring_kernel<128,128>"
+    if M <= 64 or N <= 64 or big < 192:
+        return "gemm_bt_kernel<64,64>"
+    big256 = ((M + 255) // 256) * ((N + 255) // 256) * batch
+    return "gemm_bt_ring_kernel<256,256>" if (big256 >= 192 and M >= 1024 and N >= 1024) else "gemm_bt_glds_kernel<128,128>"
 
 
 _SPLITK_WS = {}
