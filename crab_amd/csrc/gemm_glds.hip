@@ -300,7 +300,14 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bt_ring_kernel(GemmGP p) 
         xofs[mi] = row * RBK + ((fg ^ ((0x78 >> (((row >> 2) & 3) * 2)) & 3)) << 3);
     }
 
+    // Two wave groups run ONE barrier apart (waves w and w+4 share a SIMD): while one group issues its LDS-DMA and
+    // fragment reads, the other runs its 32 MFMAs, so the memory-instruction issue time of one wave is hidden under
+    // the MFMAs of its SIMD partner instead of idling the matrix pipe (role split as in the cdna guide's 8-phase
+    // schedule, at K-tile granularity).  Every wave executes the same number of barriers.
+    const int grp = wave / (NW / 2);
+    if (grp == 1) __builtin_amdgcn_s_barrier();
     for (int t = 0; t < nk; ++t) {
+        // ---- LOAD segment: DMA for tile t+3, fragments of tile t
         if (t + 3 < nk) RSTAGE(t + 3);
         const bf16_t* st = &lds[(t & (RNS - 1)) * STAGE_ELEMS];
         bf16x8_t wf[TN], xf[TM];
@@ -308,16 +315,26 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bt_ring_kernel(GemmGP p) 
         for (int ni = 0; ni < TN; ++ni) wf[ni] = *reinterpret_cast<const bf16x8_t*>(st + wofs[ni]);
 #pragma unroll
         for (int mi = 0; mi < TM; ++mi) xf[mi] = *reinterpret_cast<const bf16x8_t*>(st + xofs[mi]);
+        // retire tile t+1 (the two youngest tiles stay in flight) and drain this tile's LDS reads BEFORE the barrier:
+        // after it the partner group may refill the stage these reads came from
+        if (t + 3 < nk) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- MFMA segment
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
             for (int mi = 0; mi < TM; ++mi)
                 acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
-        // retire tile t+1 (keep the two youngest tiles in flight), drain this tile's LDS reads, one barrier per tile
-        if (t + 3 < nk) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
     }
+    if (grp == 0) __builtin_amdgcn_s_barrier();
 #undef RSTAGE
     // epilogue (identical to gemm_bt_kernel): lane owns row m = ..+fr, columns n = ..+fg*4 .. +3 of each 16x16 tile
     const bf16_t* bias = p.bias ? p.bias + z0 * p.sBias0 + z1 * p.sBias1 : nullptr;
