@@ -400,7 +400,9 @@ int crab_gemm_glds_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* d)
     if (batch == 1) { p.sA0 = p.sA1 = p.sB0 = p.sB1 = p.sC0 = p.sC1 = p.sR0 = p.sR1 = p.sBias0 = p.sBias1 = 0; }
     // 256x256 ring kernel when the problem fills the chip with big tiles; 128x128 two-stage kernel otherwise
     const long big = (long)((d->M + 255) / 256) * ((d->N + 255) / 256) * batch;
-    bool use_big = big >= 192 && d->M >= 1024 && d->N >= 1024;
+    // measured (profiles/README.md): the ring kernel wins once the grid is >= ~6 full waves of 256 blocks (gate|up
+    // projection, square 4k), the 128x128 kernel wins on the narrower projections where big tiles leave a partial wave
+    bool use_big = big >= 1536 && d->M >= 1024 && d->N >= 1024;
     if (d->tune == 301) use_big = false;
     if (d->tune == 302) use_big = true;
     if (use_big) {

@@ -65,7 +65,7 @@ def _variant(M: int, N: int, batch: int = 1) -> str:
     if M <= 64 or N <= 64 or big < 192:
         return "gemm_bt_kernel<64,64>"
     big256 = ((M + 255) // 256) * ((N + 255) // 256) * batch
-    return "gemm_bt_ring_kernel<256,256>" if (big256 >= 192 and M >= 1024 and N >= 1024) else "gemm_bt_glds_kernel<128,128>"
+    return "gemm_bt_ring_kernel<256,256>" if (big256 >= 1536 and M >= 1024 and N >= 1024) else "gemm_bt_glds_kernel<128,128>"
 
 
 _SPLITK_WS = {}
