@@ -334,21 +334,23 @@ extern "C" int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc*
         if (((uintptr_t)d->A2 & 15) || ((uintptr_t)d->B2 & 15)) return crab_fail(ctx, CRAB_E_INVALID, "gemm: A2/B2 alignment");
         if (d->batch > 1) return crab_fail(ctx, CRAB_E_UNSUPPORTED, "gemm: second K segment is not batched");
     }
-    // ---- weight-streaming regime (decode): M <= 128 rows
+    // ---- weight-streaming regime (decode): M <= 256 rows
     //   M <= 16          : LDS-free skinny kernel (skinny.hip), activations replicated per 16 weight rows
-    //   16 < M <= 128    : tiled kernel with split-K over blockIdx.y (needs the caller's workspace) so that
+    //   16 < M <= 256    : tiled kernel with split-K over blockIdx.y (needs the caller's workspace) so that
     //                      >= ~2 blocks/CU stream disjoint weight panels; partials reduced in a fixed order
     int splitk = 1, sk_bm = 0, sk_bn = 0;
-    if (d->batch <= 1 && d->M <= 128) {
-        const int nk_all = (d->K + 63) / 64 + (d->A2 ? (d->K2 + 63) / 64 : 0);
+    const int nk_all = (d->K + 63) / 64 + (d->A2 ? (d->K2 + 63) / 64 : 0);
+    if (d->batch <= 1 && d->M <= 256 && (d->M <= 128 || d->workspace != nullptr)) {
         bool want_split = d->M > 16 && d->workspace != nullptr && nk_all >= 8;
         if (d->tune >= 1 && d->tune <= 4) want_split = false;                      // forced skinny NT
         if (d->tune >= 100) want_split = d->workspace != nullptr;
-        if (!want_split) {
+        if (!want_split && d->M <= 128) {
             int rc = crab_gemm_skinny_launch(ctx, (hipStream_t)stream, d);
             return rc ? rc : post_norm(ctx, stream, d);
         }
-        sk_bm = d->M <= 64 ? 64 : 128;
+        if (want_split) sk_bm = d->M <= 64 ? 64 : 128;
+    }
+    if (sk_bm) {
         sk_bn = (sk_bm == 64 && d->N <= 4096) ? 64 : 128;          // narrow outputs: 64-wide tiles double the grid instead of the split
         if (d->tune >= 200) sk_bn = 64;
         else if (d->tune >= 100) sk_bn = 128;

@@ -75,7 +75,7 @@ def _splitk_workspace(device) -> torch.Tensor:
     """One caller-owned split-K scratch per device (stable address: safe under HIP-graph capture)."""
     key = device.index or 0
     if key not in _SPLITK_WS:
-        _SPLITK_WS[key] = torch.empty((96 << 20,), device=device, dtype=torch.uint8)
+        _SPLITK_WS[key] = torch.empty((256 << 20,), device=device, dtype=torch.uint8)
     return _SPLITK_WS[key]
 
 
@@ -108,7 +108,7 @@ def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     g.tune = tune
     if post_norm is not None:                      # (weight, eps, out): out = rmsnorm(result) * weight, fused when possible
         g.norm_w, g.norm_eps, g.norm_out, g.ld_norm = post_norm[0].data_ptr(), post_norm[1], post_norm[2].data_ptr(), post_norm[2].stride(0)
-    if M <= 128:
+    if M <= 256:
         ws = _splitk_workspace(x.device)
         g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel()
     prof = PROFILER
