@@ -121,7 +121,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--clips", type=int, default=int(os.environ.get("CRAB_BENCH_CLIPS", "64")), help="clips per GPU per step")
+    ap.add_argument("--clips", type=int, default=int(os.environ.get("CRAB_BENCH_CLIPS", "256")), help="clips per GPU per step")
     ap.add_argument("--new-tokens", type=int, default=256)
     ap.add_argument("--frames", type=int, default=8)
     ap.add_argument("--prefill-chunk", type=int, default=8)
