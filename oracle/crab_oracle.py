@@ -592,3 +592,158 @@ def generate(batch_input_ids, batch_X_modals, W: WDict, cfg: CrabConfig, max_new
     inp = prepare_multimodal_inputs(batch_input_ids, batch_X_modals, W, cfg, emulate)
     return greedy_generate(inp["inputs_embeds"], W, cfg.decoder, max_new_tokens, eos_token_id,
                            cfg.pad_token_id, min_new_tokens, emulate)
+
+
+# =====================================================================================
+# B.8 SegModule (generate_avs pixel path)     reference models/multimodal_encoder.py:268-543, 891-1444
+# =====================================================================================
+
+def _ln2d(x: Tensor, W: WDict, prefix: str, eps: float = 1e-6) -> Tensor:
+    """LayerNorm2d (:606-618): per-pixel LayerNorm over channels of [B,C,H,W]."""
+    u = x.mean(1, keepdim=True)
+    s = (x - u).pow(2).mean(1, keepdim=True)
+    x = (x - u) / torch.sqrt(s + eps)
+    return W[prefix + ".weight"].float()[None, :, None, None] * x + W[prefix + ".bias"].float()[None, :, None, None]
+
+
+def _dense_pe(G: Tensor, h: int, w: int) -> Tensor:
+    """PositionEmbeddingRandom.forward (:825-839): [C,h,w], C = 2*G.shape[1]."""
+    ys = (torch.arange(h, dtype=torch.float32) + 0.5) / h
+    xs = (torch.arange(w, dtype=torch.float32) + 0.5) / w
+    coords = torch.stack([xs[None, :].expand(h, w), ys[:, None].expand(h, w)], dim=-1)
+    c = (2 * coords - 1) @ G.float()
+    c = 2 * math.pi * c
+    return torch.cat([torch.sin(c), torch.cos(c)], dim=-1).permute(2, 0, 1)
+
+
+def _sam_attention(q: Tensor, k: Tensor, v: Tensor, W: WDict, p: str, heads: int = 8) -> Tensor:
+    """Attention (:1333-1390): separate q/k/v Linear to internal_dim, heads, /sqrt(c_per_head), softmax, out Linear."""
+    q = linear(q, W, p + ".q_proj")
+    k = linear(k, W, p + ".k_proj")
+    v = linear(v, W, p + ".v_proj")
+    d = q.shape[-1] // heads
+    o = _mha(q, k, v, heads, 1.0 / math.sqrt(d))
+    return linear(o, W, p + ".out_proj")
+
+
+def _torch_mha(q: Tensor, kv: Tensor, W: WDict, p: str, heads: int = 8) -> Tensor:
+    """nn.MultiheadAttention(batch_first) with packed in_proj (query generator, :1397-1419)."""
+    E = q.shape[-1]
+    wi, bi = W[p + ".in_proj_weight"].float(), W[p + ".in_proj_bias"].float()
+    qq = F.linear(q, wi[:E], bi[:E])
+    kk = F.linear(kv, wi[E:2 * E], bi[E:2 * E])
+    vv = F.linear(kv, wi[2 * E:], bi[2 * E:])
+    o = _mha(qq, kk, vv, heads, 1.0 / math.sqrt(E // heads))
+    return linear(o, W, p + ".out_proj")
+
+
+def _query_generator(avs_query: Tensor, sparse: Tensor, W: WDict, p: str, num_layers: int) -> Tensor:
+    """QueryGenerator.forward (:1441-1444): EVERY layer is fed the original avs_query, so only the last layer's
+    output survives (reference quirk) -- reproduced."""
+    query = None
+    for l in range(num_layers):
+        q = avs_query
+        lp = f"{p}.layers.{l}"
+        q = layernorm(q + _torch_mha(q, q, W, lp + ".self_attn"), W, lp + ".norm1", 1e-5)
+        q = layernorm(q + _torch_mha(q, sparse, W, lp + ".cross_attn"), W, lp + ".norm2", 1e-5)
+        f = linear(_gelu(linear(q, W, lp + ".ffn.0")), W, lp + ".ffn.2")
+        query = layernorm(q + f, W, lp + ".norm3", 1e-5)
+    return query
+
+
+def _two_way_transformer(src: Tensor, pos: Tensor, tokens: Tensor, W: WDict, p: str, depth: int) -> Tuple[Tensor, Tensor]:
+    """TwoWayTransformer.forward (:1209-1254) + TwoWayAttentionBlock.forward (:1299-1330)."""
+    b, c, h, w = src.shape
+    keys = src.flatten(2).permute(0, 2, 1)
+    key_pe = pos.flatten(2).permute(0, 2, 1)
+    queries, query_pe = tokens, tokens
+    for i in range(depth):
+        lp = f"{p}.layers.{i}"
+        if i == 0:
+            queries = _sam_attention(queries, queries, queries, W, lp + ".self_attn")
+        else:
+            q = queries + query_pe
+            queries = queries + _sam_attention(q, q, queries, W, lp + ".self_attn")
+        queries = layernorm(queries, W, lp + ".norm1", 1e-5)
+        q, k = queries + query_pe, keys + key_pe
+        queries = layernorm(queries + _sam_attention(q, k, keys, W, lp + ".cross_attn_token_to_image"), W, lp + ".norm2", 1e-5)
+        m = linear(F.relu(linear(queries, W, lp + ".mlp.lin1")), W, lp + ".mlp.lin2")
+        queries = layernorm(queries + m, W, lp + ".norm3", 1e-5)
+        q, k = queries + query_pe, keys + key_pe
+        keys = layernorm(keys + _sam_attention(k, q, queries, W, lp + ".cross_attn_image_to_token"), W, lp + ".norm4", 1e-5)
+    q, k = queries + query_pe, keys + key_pe
+    queries = layernorm(queries + _sam_attention(q, k, keys, W, p + ".final_attn_token_to_image"), W, p + ".norm_final_attn", 1e-5)
+    return queries, keys
+
+
+def _mlp3(x: Tensor, W: WDict, p: str) -> Tensor:
+    x = F.relu(linear(x, W, p + ".layers.0"))
+    x = F.relu(linear(x, W, p + ".layers.1"))
+    return linear(x, W, p + ".layers.2")
+
+
+def _predict_masks(img: Tensor, image_pe: Tensor, sparse: Tensor, dense: Tensor, level: int, prev: Optional[Tensor], task: str,
+                   W: WDict, p: str, depth: int, qg_layers: int, nq: int) -> Tensor:
+    """MaskDecoderMultiScale.predict_masks (:1083-1143)."""
+    tokens = _query_generator(W[p + ".avs_query_tokens.weight"].float()[None], sparse, W, p + ".query_generator", qg_layers)
+    tokens = tokens + W[p + ".level_embed.weight"].float()[level][None, None]
+    src = img
+    if level > 0:
+        up = F.conv_transpose2d(src, W[p + ".upsample_2x.0.weight"].float(), W[p + ".upsample_2x.0.bias"].float(), stride=2)
+        src = _gelu(_ln2d(up, W, p + ".upsample_2x.1"))
+        pm = prev.mean(dim=1)
+        src = (torch.sigmoid(pm)[:, None] + 1) * src
+        image_pe = _dense_pe(W[p + ".pe1.positional_encoding_gaussian_matrix"], src.shape[2], src.shape[3])[None]
+        dense = F.interpolate(dense.float(), size=src.shape[2:], mode="bilinear", align_corners=False)
+    src = src + dense
+    b, c, h, w = src.shape
+    hs, keys = _two_way_transformer(src, image_pe, tokens, W, f"{p}.transformer.{level}", depth)
+    t = _mlp3(hs[:, :nq], W, p + ".hyper_mlp")
+    src = keys.transpose(1, 2).reshape(b, c, h, w)
+    up = F.conv_transpose2d(src, W[p + ".output_upscaling.0.weight"].float(), W[p + ".output_upscaling.0.bias"].float(), stride=2)
+    up = _gelu(_ln2d(up, W, p + ".output_upscaling.1"))
+    b, c2, h2, w2 = up.shape
+    masks = (t @ up.view(b, c2, h2 * w2)).view(b, -1, h2, w2)
+    x = masks
+    for i in range(3):
+        x = F.conv2d(x, W[f"{p}.hyper_mlp_out.layers.{i}.weight"].float(), W[f"{p}.hyper_mlp_out.layers.{i}.bias"].float())
+        if i < 2:
+            x = F.relu(x)
+    cls = p + (".avss_classifier.weight" if task == 'avss' else ".ms3_s4_classfier.weight")
+    return F.conv2d(x, W[cls].float())
+
+
+def seg_module(pred_embeddings: Tensor, feats: Sequence[Tensor], task_names: Sequence[str], W: WDict,
+               prefix: str = "model.seg_module", emb_size: int = 16, low_res: int = 112, image_size: int = 224,
+               scales: int = 2, toks: int = 3, depth: int = 2, qg_layers: int = 2, nq: int = 300) -> List[Tensor]:
+    """SegModule.forward inference branch (:368-448): pred_embeddings [bs, scales*toks, D], feats = per level
+    [bs, emb_size^2, C] -> list of [num_classes, image_size, image_size] (71 for 'avss', else 1)."""
+    p = prefix
+    e = linear(F.relu(linear(pred_embeddings.float(), W, p + ".text_hidden_fcs.0.0")), W, p + ".text_hidden_fcs.0.2")
+    bs, n, dim = e.shape
+    obj = n // (scales * toks)
+    e = e.reshape(bs, obj, scales, toks, dim)
+    fused = sum((1.0 / toks) * e[:, :, :, i] for i in range(toks))                       # multiseg_scalar: plain list, 1/3
+    grid = []
+    for f in feats:
+        g = f.float().reshape(bs, -1, emb_size, emb_size, f.shape[-1]).permute(0, 1, 4, 2, 3)[:, 0]
+        grid.append(g)
+    grid = torch.stack(grid, dim=1)                                                        # [bs, level, C, s, s]
+    pe = _dense_pe(W[p + ".pe_layer.positional_encoding_gaussian_matrix"], emb_size, emb_size)[None]
+    out = []
+    for i in range(bs):
+        sparse = fused[i]                                                                  # [obj, scales, 256]
+        dense = W[p + ".no_mask_embed.weight"].float().reshape(1, -1, 1, 1).expand(sparse.shape[0], -1, emb_size, emb_size)
+        x = F.conv2d(grid[i], W[p + ".image_feature_neck.0.weight"].float())
+        x = _ln2d(x, W, p + ".image_feature_neck.1")
+        x = F.conv2d(x, W[p + ".image_feature_neck.2.weight"].float(), padding=1)
+        img = _ln2d(x, W, p + ".image_feature_neck.3")                                    # [level, 256, s, s]
+        low = None
+        lm = None
+        for l in range(scales):
+            lm = _predict_masks(img[l][None], pe, sparse[:, l][:, None], dense, l, lm, task_names[i], W, p + ".mask_decoder",
+                                depth, qg_layers, nq)
+            up = (1.0 / scales) * F.interpolate(lm.float(), (low_res, low_res), mode="bilinear", align_corners=False)
+            low = up if low is None else low + up
+        out.append(F.interpolate(low, (image_size, image_size), mode="bilinear", align_corners=False)[0])
+    return out

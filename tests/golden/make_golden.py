@@ -324,10 +324,30 @@ def golden_qwen(me):
          embeds=emb, ids=r.sequences, logits=lg)
 
 
+def golden_seg(me):
+    D = 128
+    seg = me.SegModule(d_model=D, vit_image_embedding_dim=128, prompt_embed_dim=256, image_scale_nums=2,
+                       mask_decoder_transformer_depth=2, token_nums_per_scale=3, avs_query_num=300, num_classes=1,
+                       query_generator_num_layers=2, image_size=224, patch_size=14, image_embedding_size=16).eval()
+    table = load_synth(seg, "model.seg_module.")
+    g = torch.Generator().manual_seed(31)
+    pred = torch.randn(2, 6, D, generator=g)
+    feats = [torch.randn(2, 256, 128, generator=g) for _ in range(2)]
+    tasks = ['avss', 's4']
+    out = seg(pred_embeddings=pred, multi_scale_image_feature_list=feats, low_res_mask_size=112, gt_mask=None,
+              batch_task_names=tasks)['pred_masks']
+    print("seg shapes", [tuple(o.shape) for o in out], float(out[0].abs().max()), float(out[1].abs().max()))
+    # fixtures stay small: inputs are regenerated from the seed (same generator call order), outputs are strided samples
+    # of both masks plus order-sensitive checksums of the full tensors
+    save("seg_tiny", dict(seed=SEED, d_model=D, table=table, tasks=tasks, pseed=31,
+                          cks=[synth.checksum(out[0]), synth.checksum(out[1])]),
+         avss_sub=out[0][:, 3::8, 5::8].contiguous(), s4_sub=out[1][:, 1::2, ::2].contiguous())
+
+
 def main():
     ref_shims.install()
     me = ref_shims.patch_bert_config(lambda: ref_shims.tiny_bert_config(**TINY_QF))
-    which = sys.argv[1:] or ["lora", "beats", "clip", "proj", "full", "qwen"]
+    which = sys.argv[1:] or ["lora", "beats", "clip", "proj", "full", "qwen", "seg"]
     if "lora" in which:
         build_lora_linear()
     if "beats" in which:
@@ -340,6 +360,8 @@ def main():
         golden_full(me)
     if "qwen" in which:
         golden_qwen(me)
+    if "seg" in which:
+        golden_seg(me)
 
 
 if __name__ == "__main__":

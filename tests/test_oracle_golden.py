@@ -119,3 +119,17 @@ def test_decoder_tiny_qwen2_gqa_bias():
     ids, sl = O.greedy_generate(A["embeds"], W, dec, meta["new_tokens"], eos_token_id=None, pad_token_id=2)
     assert torch.equal(ids, A["ids"])
     _close(sl, A["logits"], 1e-3)
+
+
+def test_seg_module_tiny():
+    from crab_amd import synth
+    from tests.util import seg_inputs
+    meta, A = load_fixture("seg_tiny")
+    W = weights_from_table(meta)
+    pred, feats = seg_inputs(meta)
+    out = O.seg_module(pred, feats, meta["tasks"], W)
+    assert tuple(out[0].shape) == (71, 224, 224) and tuple(out[1].shape) == (1, 224, 224)
+    _close(out[0][:, 3::8, 5::8], A["avss_sub"], 5e-4)
+    _close(out[1][:, 1::2, ::2], A["s4_sub"], 5e-4)
+    for o, c in zip(out, meta["cks"]):
+        assert abs(synth.checksum(o) - c) <= 2e-4 * max(1.0, abs(c))

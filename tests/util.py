@@ -74,3 +74,12 @@ def build_tiny_crab(meta: dict, device="cuda"):
                                               beats_config=meta["beats"], bert_config=bert_cfg(meta["qf"]))
     model.initialize_MM_tokenizer(DuckTokenizer(meta["base_vocab"]), mask_token_nums=6)
     return model
+
+
+def seg_inputs(meta):
+    """Inputs of the seg_tiny fixture, regenerated with the generator call order of make_golden.golden_seg."""
+    g = torch.Generator().manual_seed(meta["pseed"])
+    D = meta["d_model"]
+    pred = torch.randn(2, 6, D, generator=g)
+    feats = [torch.randn(2, 256, 128, generator=g) for _ in range(2)]
+    return pred, feats
