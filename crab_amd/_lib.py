@@ -77,6 +77,14 @@ SYMBOLS = {
     "crab_copy_rows_batched": (_i, [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _i64, _i, _i, _i]),
     "crab_greedy_select": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _i64, _vp, _vp, _i, _i, _i]),
     "crab_advance": (_i, [_vp, _vp, _vp, _vp]),
+    "crab_im2col3x3": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i]),
+    "crab_pixel_shuffle2x": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i]),
+    "crab_bilinear": (_i, [_vp, _vp, _vp, _i, _i64, _i64, _i64, _i, _i, _i, _vp, _i, _i, _f, _f]),
+    "crab_dense_pe": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i]),
+    "crab_add_rows": (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _i, _vp, _i64, _i, _i]),
+    "crab_mask_gate": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _i64, _i, _i]),
+    "crab_act_inplace": (_i, [_vp, _vp, _vp, _i64, _i]),
+    "crab_group_mean": (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _i, _i, _i, _f]),
 }
 
 _lib = None

@@ -31,8 +31,9 @@ constexpr int VT_LD = 68;       // padded V^T row (bf16 elements): 136 B, confli
 
 template <int HD>
 __device__ __forceinline__ int k_swz(int row, int chunk) {
-    // 16-byte chunk swizzle; HD=128: 16 chunks per 256-B row; HD=64: 8 chunks per 128-B row
-    return HD == 128 ? (chunk ^ (row & 15)) : (chunk ^ ((row >> 1) & 7));
+    // 16-byte chunk swizzle; HD=128: 16 chunks per 256-B row; HD=64: 8 chunks per 128-B row; HD=32: 4 chunks per 64-B
+    // row with the permutation P = {0,2,3,1} of (row>>2)&3 (conflict-free for the gfx950 ds_read_b128 lane groups)
+    return HD == 128 ? (chunk ^ (row & 15)) : (HD == 64 ? (chunk ^ ((row >> 1) & 7)) : (chunk ^ ((0x78 >> (((row >> 2) & 3) * 2)) & 3)));
 }
 
 template <int HD, bool CAUSAL, bool BIAS>
@@ -271,7 +272,8 @@ extern "C" int crab_attn_fwd(crab_ctx* ctx, void* stream, const crab_attn_desc* 
     if (!d || !d->q || !d->k || !d->vt || !d->o) return crab_fail(ctx, CRAB_E_INVALID, "attn_fwd: null operand");
     if (d->B <= 0 || d->H <= 0 || d->Hk <= 0 || d->H % d->Hk || d->Sq <= 0 || d->Skv <= 0)
         return crab_fail(ctx, CRAB_E_INVALID, "attn_fwd: bad shape");
-    if (d->head_dim != 64 && d->head_dim != 128) return crab_fail(ctx, CRAB_E_UNSUPPORTED, "attn_fwd: head_dim must be 64 or 128");
+    if (d->head_dim != 32 && d->head_dim != 64 && d->head_dim != 128) return crab_fail(ctx, CRAB_E_UNSUPPORTED, "attn_fwd: head_dim must be 32, 64 or 128");
+    if (d->head_dim == 32 && (d->causal || d->bias)) return crab_fail(ctx, CRAB_E_UNSUPPORTED, "attn_fwd: head_dim 32 only without mask/bias");
     if ((d->q_ss & 7) || (d->q_hs & 7) || (d->q_bs & 7) || (d->k_ss & 7) || (d->k_hs & 7) || (d->k_bs & 7) || (d->vt_ds & 7) ||
         (d->vt_hs & 7) || (d->vt_bs & 7) || (d->o_ss & 3) || (d->o_bs & 3))
         return crab_fail(ctx, CRAB_E_INVALID, "attn_fwd: strides must keep 16-byte alignment");
@@ -289,7 +291,9 @@ extern "C" int crab_attn_fwd(crab_ctx* ctx, void* stream, const crab_attn_desc* 
     hipStream_t s = (hipStream_t)stream;
     const bool hb = d->bias != nullptr;
     if (d->causal && hb) return crab_fail(ctx, CRAB_E_UNSUPPORTED, "attn_fwd: causal + bias not instantiated");
-    if (d->head_dim == 128) {
+    if (d->head_dim == 32) {
+        hipLaunchKernelGGL((attn_fwd_kernel<32, false, false>), grid, block, 0, s, p);
+    } else if (d->head_dim == 128) {
         if (d->causal) hipLaunchKernelGGL((attn_fwd_kernel<128, true, false>), grid, block, 0, s, p);
         else if (hb) hipLaunchKernelGGL((attn_fwd_kernel<128, false, true>), grid, block, 0, s, p);
         else hipLaunchKernelGGL((attn_fwd_kernel<128, false, false>), grid, block, 0, s, p);

@@ -314,6 +314,71 @@ def advance(pos_dev, step_dev):
     _lib.check(_lib.load().crab_advance(_lib.ctx(d), _stream(), _p(pos_dev), _p(step_dev)), d)
 
 
+def im2col3x3(x: torch.Tensor, B: int, h: int, w: int) -> torch.Tensor:
+    """x [B*h*w, C] token-major -> [B*h*w, 9*C] (Conv2d k=3 pad=1 operand)."""
+    d = _dev(x)
+    Cc = x.shape[1]
+    out = torch.empty((B * h * w, 9 * Cc), device=x.device, dtype=BF16)
+    _lib.check(_lib.load().crab_im2col3x3(_lib.ctx(d), _stream(), _p(x), _p(out), B, h, w, Cc), d)
+    return out
+
+
+def pixel_shuffle2x(g: torch.Tensor, bias: Optional[torch.Tensor], h: int, w: int, Co: int) -> torch.Tensor:
+    d = _dev(g)
+    out = torch.empty((4 * h * w, Co), device=g.device, dtype=BF16)
+    _lib.check(_lib.load().crab_pixel_shuffle2x(_lib.ctx(d), _stream(), _p(g), _p(bias), _p(out), h, w, Co), d)
+    return out
+
+
+def bilinear(x: torch.Tensor, strides, Cc: int, h: int, w: int, out: torch.Tensor, alpha: float = 1.0, beta: float = 0.0):
+    """x element (c,y,x) at x.data + c*strides[0] + y*strides[1] + x*strides[2]; out fp32 [C,H,W] (accumulates when beta != 0)."""
+    d = _dev(x)
+    _lib.check(_lib.load().crab_bilinear(_lib.ctx(d), _stream(), _p(x), 1 if x.dtype == torch.float32 else 0, strides[0], strides[1], strides[2],
+                                         Cc, h, w, _p(out), out.shape[-2], out.shape[-1], alpha, beta), d)
+    return out
+
+
+def dense_pe(G: torch.Tensor, h: int, w: int) -> torch.Tensor:
+    d = _dev(G)
+    assert G.dtype == torch.float32 and G.is_contiguous()
+    Fq = G.shape[1]
+    pe = torch.empty((h * w, 2 * Fq), device=G.device, dtype=BF16)
+    _lib.check(_lib.load().crab_dense_pe(_lib.ctx(d), _stream(), _p(G), _p(pe), h, w, Fq), d)
+    return pe
+
+
+def add_rows(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[m] = a[m] + b[m % b.shape[0]] (2-D, bf16)."""
+    d = _dev(a)
+    M, D = a.shape
+    if out is None:
+        out = torch.empty((M, D), device=a.device, dtype=BF16)
+    _lib.check(_lib.load().crab_add_rows(_lib.ctx(d), _stream(), _p(a), a.stride(0), _p(b), b.stride(0), b.shape[0], _p(out), out.stride(0), M, D), d)
+    return out
+
+
+def mask_gate(prev: torch.Tensor, src: torch.Tensor):
+    d = _dev(src)
+    _lib.check(_lib.load().crab_mask_gate(_lib.ctx(d), _stream(), _p(prev), prev.stride(0), prev.shape[1], _p(src), src.stride(0), src.shape[0], src.shape[1]), d)
+    return src
+
+
+def group_mean(x: torch.Tensor, G: int, T: int, scale: float) -> torch.Tensor:
+    """out[g] = scale * sum_{k<T} x[g*T + k]  (bf16 rows)."""
+    d = _dev(x)
+    D = x.shape[1]
+    out = torch.empty((G, D), device=x.device, dtype=BF16)
+    _lib.check(_lib.load().crab_group_mean(_lib.ctx(d), _stream(), _p(x), x.stride(0), _p(out), out.stride(0), G, T, D, scale), d)
+    return out
+
+
+def act_inplace(x: torch.Tensor, act: str):
+    d = _dev(x)
+    assert x.is_contiguous()
+    _lib.check(_lib.load().crab_act_inplace(_lib.ctx(d), _stream(), _p(x), x.numel(), ACT[act]), d)
+    return x
+
+
 def cast_bf16(x: torch.Tensor) -> torch.Tensor:
     """fp32 -> bf16 on device (harness-side cast of modality inputs)."""
     if x.dtype == BF16:

@@ -181,7 +181,6 @@ class UnifiedForCausalLM(nn.Module, UnifiedMetaForCausalLM):
 
     def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
         """Checkpoints are fp32 (reference ships --bf16 False); tensors are cast to the resident bf16 storage."""
-        sd = {k: (v.to(BF16) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in state_dict.items()}
-        r = super().load_state_dict(sd, strict=strict, assign=False)
+        r = super().load_state_dict(state_dict, strict=strict, assign=False)      # copy_ casts to each parameter's dtype
         self._invalidate_graphs()
         return r

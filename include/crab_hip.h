@@ -120,7 +120,7 @@ int crab_qkv_rope_split(crab_ctx* ctx, void* stream, void* qkv, int64_t ldqkv, c
  *   O[b, i, h*d + :] = softmax_j( scale * q_i.k_j + gate[b,h,i] * bias[h,i,j] + mask ) . v_j
  * q: element (b,h,i,:) at q + b*q_bs + h*q_hs + i*q_ss ; k likewise ; vt: (b,h,dd,j) at vt + b*vt_bs + h*vt_hs + dd*vt_ds + j
  * H query heads, Hk key/value heads (GQA: kv head = h / (H/Hk)).  causal != 0 masks j > i + (Skv - Sq).
- * bias (fp32 [H,Sq,Skv]) and gate (fp32 [B,H,Sq]) may be NULL.  head_dim in {64,128}.
+ * bias (fp32 [H,Sq,Skv]) and gate (fp32 [B,H,Sq]) may be NULL.  head_dim in {32,64,128} (32: no causal/bias form).
  * Replaces: modeling_llama.py:417-445 (prefill), CLIP / Q-Former (Qformer.py:171-277) / BEATs
  * (backbone.py:621-670, gated relative position bias) eager attention.
  */
@@ -181,6 +181,28 @@ int crab_greedy_select(crab_ctx* ctx, void* stream, const float* logits, int64_t
                        int64_t* out_ids, int64_t ld_out, const int32_t* step_dev, int32_t* finished, int eos_id, int pad_id,
                        int min_new_tokens);
 int crab_advance(crab_ctx* ctx, void* stream, int32_t* pos_dev, int32_t* step_dev);
+
+/* ---------------------------------------------------------------------------------------------
+ * SegModule pixel path (models/multimodal_encoder.py:268-543, 891-1444).  Feature maps are token-major [h*w, C] bf16.
+ *  im2col3x3       : Conv2d(k=3,pad=1) operand, out[(b,y,x), (ky*3+kx)*C + c]                      (image_feature_neck :316-332)
+ *  pixel_shuffle2x : ConvTranspose2d(k=2,s=2) after its GEMM: g[h*w, (dy,dx,co)] -> out[(2h)(2w), Co] + bias  (:937-949)
+ *  bilinear        : F.interpolate(mode='bilinear', align_corners=False); strided input (bf16|fp32), fp32 [C,H,W] out,
+ *                    out = beta*out + alpha*interp                                                  (:436, :523-531)
+ *  dense_pe        : PositionEmbeddingRandom.forward (:825-839), G = positional_encoding_gaussian_matrix fp32 [2,F] -> pe[h*w, 2F]
+ *  group_mean      : out[g] = scale * sum_{k<T} in[g*T+k]  (fused_pred_embeddings :388-393)
+ *  add_rows        : out[m] = a[m] + b[m % brows]  (queries+query_pe, keys+key_pe, +level_embed, +no_mask_embed)
+ *  mask_gate       : src[m,:] *= sigmoid(mean_c prev[m,c]) + 1                                     (:1112-1114)
+ *  act_inplace     : x = act(x), CRAB_ACT_* */
+int crab_im2col3x3(crab_ctx* ctx, void* stream, const void* in, void* out, int B, int h, int w, int C);
+int crab_pixel_shuffle2x(crab_ctx* ctx, void* stream, const void* g, const void* bias, void* out, int h, int w, int Co);
+int crab_bilinear(crab_ctx* ctx, void* stream, const void* in, int in_fp32, int64_t sc, int64_t sy, int64_t sx, int C, int h, int w,
+                  float* out, int H, int W, float alpha, float beta);
+int crab_dense_pe(crab_ctx* ctx, void* stream, const void* G, void* pe, int h, int w, int F);
+int crab_add_rows(crab_ctx* ctx, void* stream, const void* a, int64_t lda, const void* b, int64_t ldb, int brows, void* out, int64_t ldo,
+                  int M, int D);
+int crab_mask_gate(crab_ctx* ctx, void* stream, const void* prev, int64_t ldp, int ncls, void* src, int64_t lds, int M, int D);
+int crab_group_mean(crab_ctx* ctx, void* stream, const void* in, int64_t ldi, void* out, int64_t ldo, int G, int T, int D, float scale);
+int crab_act_inplace(crab_ctx* ctx, void* stream, void* x, int64_t n, int act);
 
 #ifdef __cplusplus
 }

@@ -191,3 +191,24 @@ def test_eos_and_min_new_tokens_semantics():
     assert ids.shape == exp.shape and torch.equal(ids, exp), (ids.tolist(), exp.tolist())
     ids2 = model.generate(inputs_embeds=emb, max_new_tokens=12, eos_token_id=eos, pad_token_id=2, min_new_tokens=12)
     assert ids2.shape[1] == 12 and not (ids2 == eos).any()
+
+
+def test_seg_module_vs_reference_fixture_and_oracle():
+    """SegModule (generate_avs pixel path, BASELINE config 5) at the fixture configuration: avss (71 classes) and s4."""
+    from crab_amd import synth
+    from crab_amd.seg_module import SegModule
+    from oracle import crab_oracle as O
+    from tests.util import seg_inputs
+    meta, A = load_fixture("seg_tiny")
+    W = weights_from_table(meta)
+    seg = SegModule(d_model=meta["d_model"], vit_image_embedding_dim=128, device="cuda")
+    r = seg.load_state_dict({k[len("model.seg_module."):]: v for k, v in W.items()}, strict=True)
+    pred, feats = seg_inputs(meta)
+    out = seg(pred_embeddings=pred.to(BF).cuda(), multi_scale_image_feature_list=[f.to(BF).cuda() for f in feats],
+              low_res_mask_size=112, gt_mask=None, batch_task_names=meta["tasks"])['pred_masks']
+    assert tuple(out[0].shape) == (71, 224, 224) and tuple(out[1].shape) == (1, 224, 224)
+    ref = O.seg_module(pred.to(BF).float(), [f.to(BF).float() for f in feats], meta["tasks"], _bf(W))
+    for i in range(2):
+        assert _rel(out[i], ref[i]) < 6e-2, f"sample {i} vs oracle on bf16-rounded weights"
+    assert _rel(out[0][:, 3::8, 5::8], A["avss_sub"]) < 8e-2
+    assert _rel(out[1][:, 1::2, ::2], A["s4_sub"]) < 8e-2
