@@ -571,6 +571,14 @@ class BEATs(nn.Module):
         return x.view(B, n, E), padding_mask
 
 
+def __getattr__(name):
+    """`SegModule` lives in seg_module.py but is reachable as crab_amd.multimodal_encoder.SegModule like in the reference."""
+    if name == "SegModule":
+        from .seg_module import SegModule
+        return SegModule
+    raise AttributeError(name)
+
+
 class AudioEncoder(nn.Module):
     """multimodal_encoder.py:148-186.  `ckpt_path` may be None (weights arrive via load_state_dict) or a BEATs
     checkpoint ({'cfg','model'}) loaded like the reference does (:157-161)."""

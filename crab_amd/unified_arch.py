@@ -74,7 +74,15 @@ class UnifiedMetaModel:
             self.al_projector = ALProjector(hidden_size=enc_w, d_model=d_model, depth=2, num_query_token=audio_query_token_nums,
                                             num_hidden_layers=2, bert_config=bert_config, device=dev)
         if segment_branch:
-            raise NotImplementedError("SegModule (generate_avs pixel path) is SURVEY.md 8f-1: scheduled after the NTP path")
+            from .seg_module import SegModule
+            self.low_res_mask_size = low_res_mask_size
+            self.seg_module = SegModule(
+                d_model=d_model, prompt_embed_dim=prompt_embed_dim, image_scale_nums=image_scale_nums,
+                token_nums_per_scale=token_nums_per_scale, mask_decoder_transformer_depth=mask_decoder_transformer_depth,
+                vit_image_embedding_dim=vit_image_embedding_dim, avs_query_num=avs_query_num, num_classes=num_classes,
+                query_generator_num_layers=query_generator_num_layers, image_size=image_size, patch_size=patch_size,
+                image_embedding_size=(image_size // patch_size), dice_loss_weight=dice_loss_weight,
+                bce_loss_weight=bce_loss_weight, device=dev)
         if use_vqgan:
             raise NotImplementedError("VQGAN mask tokenizer is SURVEY.md 8f-4 (disabled in every reference script)")
 
@@ -92,6 +100,11 @@ class UnifiedMetaModel:
 
     def encode_audio(self, audio):
         return self.al_projector(self.audio_encoder(audio))
+
+    def postprocess_seg(self, pred_embeddings, multi_scale_image_feature_list, gt_mask=None, batch_task_names=[]):
+        """unified_arch.py:162-176."""
+        return self.seg_module(pred_embeddings=pred_embeddings, multi_scale_image_feature_list=multi_scale_image_feature_list,
+                               low_res_mask_size=self.low_res_mask_size, gt_mask=gt_mask, batch_task_names=batch_task_names)
 
 
 class UnifiedMetaForCausalLM:
@@ -134,10 +147,9 @@ class UnifiedMetaForCausalLM:
         return_multi_scale_features=False,
         return_gt_mask=False,
     ):
-        """unified_arch.py:217-406 (NTP branch).  Returns the same dict: input_ids=None, inputs_embeds [bs,S,D],
-        attention_mask, labels, position_ids."""
-        if return_multi_scale_features or return_gt_mask:
-            raise NotImplementedError("multi-scale features / gt masks belong to the AVS path (SURVEY.md 8f-1)")
+        """unified_arch.py:217-406.  Returns the same dict: input_ids=None, inputs_embeds [bs,S,D], attention_mask,
+        labels, position_ids (+ multi_scale_image_features, mask_token_mask, gt_mask on the AVS path).
+        The AVS `<image>` is encoded ONCE (the reference encodes it twice, :244 and :297)."""
         device = self.device
         bs = len(batch_input_ids)
         special = self.SPECIAL_TOKEN_2_IDS
@@ -165,8 +177,18 @@ class UnifiedMetaForCausalLM:
                     pre = pos + 1
             segs.append(("text", pre, len(ids_l)))
             plans.append(segs)
-        vfeat = self._encode_blocks(vids, video=True)
-        afeat = self._encode_blocks(auds, video=False)
+        vfeat, vvit = self._encode_blocks(vids, video=True, want_vit=return_multi_scale_features)
+        afeat, _ = self._encode_blocks(auds, video=False)
+        img_block = {}                                   # sample -> index of its <image> block (multi-scale features)
+        if return_multi_scale_features:
+            for i, segs in enumerate(plans):
+                ids_l = batch_input_ids[i].tolist()
+                k = 0
+                for pos, tok in enumerate(ids_l):
+                    if tok in key_ids:
+                        if key_ids[tok] == '<image>' and i not in img_block:
+                            img_block[i] = [sg for sg in segs if sg[0] in ("video", "audio")][k][1]
+                        k += 1
 
         # ---- pass 2: lengths, left padding, one output buffer
         lens = []
@@ -203,32 +225,72 @@ class UnifiedMetaForCausalLM:
             attn[i, off:] = 1
         position_ids = torch.cumsum(attn, dim=-1) - 1
         position_ids[position_ids == -1] = 0                                             # :372-373
-        return {
+        dict_data = {
             'input_ids': None,
             'inputs_embeds': out,
             'attention_mask': attn.to(device),
             'labels': labels.to(device),
             'position_ids': position_ids.to(device),
         }
+        if return_multi_scale_features:
+            scale = 2
+            ms = [[] for _ in range(scale)]
+            mtm = torch.zeros((bs, S), dtype=torch.bool)
+            mask_ids = {special[m] for m in self.MASK}
+            for i in range(bs):
+                is_avs = batch_task_names[i] in AVS_TASKS
+                ids_l = batch_input_ids[i].tolist()
+                if is_avs and i in img_block:
+                    for sc in range(scale):
+                        ms[sc].append(vvit[img_block[i]][sc])
+                else:                                                                      # :235-239 zeros for non-AVS rows
+                    for sc in range(scale):
+                        ms[sc].append(torch.zeros((256, 1024), device=device, dtype=BF16))
+                # mask-token positions (:266-271, :310-311, :361): every index is shifted by (block_len - 1) at EVERY
+                # placeholder and by (S - L - 1) after left padding ("note: -1") -- reproduced as written
+                idx = [p for p, t in enumerate(ids_l) if t in mask_ids] if is_avs else list(range(2, 8))
+                for sg in plans[i]:
+                    if sg[0] != "text":
+                        blk = (vfeat[sg[1]] if sg[0] == "video" else afeat[sg[1]]).shape[0]
+                        idx = [j + blk - 1 for j in idx]
+                idx = [j + S - lens[i] - 1 for j in idx]
+                for j in idx:
+                    if 0 <= j < S:
+                        mtm[i, j] = True
+            dict_data['multi_scale_image_features'] = [torch.stack(m, dim=0) for m in ms if len(m) > 0]
+            dict_data['mask_token_mask'] = mtm.to(device)
+        if return_gt_mask:
+            gts = []
+            for i in range(bs):
+                g = batch_X_modals[i].get('<mask>') if batch_task_names[i] in AVS_TASKS else None
+                gts.append(g.to(device).float() if g is not None else torch.zeros((1, 224, 224), device=device))
+            dict_data['gt_mask'] = torch.stack(gts, dim=0)
+        return dict_data
 
-    def _encode_blocks(self, blocks: Sequence[torch.Tensor], video: bool) -> List[torch.Tensor]:
+    def _encode_blocks(self, blocks: Sequence[torch.Tensor], video: bool, want_vit: bool = False):
         """Encode every <video>/<image> (or <audio>) block of the batch in as few launches as possible: blocks of
-        equal shape are stacked into one encoder call (the reference encodes them one by one, unified_arch.py:283-300)."""
+        equal shape are stacked into one encoder call (the reference encodes them one by one, unified_arch.py:283-300).
+        Returns (projector features per block, per-block list of CLIP feature levels when want_vit)."""
         if not blocks:
-            return []
+            return [], []
         out: List[Optional[torch.Tensor]] = [None] * len(blocks)
+        vit_out: List[Optional[List[torch.Tensor]]] = [None] * len(blocks)
         groups: Dict[tuple, List[int]] = {}
         for i, b in enumerate(blocks):
             groups.setdefault(tuple(b.shape), []).append(i)
         for shape, idxs in groups.items():
             x = torch.stack([blocks[i] for i in idxs], dim=0)
             if video:
-                f = self.encode_video(x, batch_first=True)[1][-1]
+                vit, qf = self.encode_video(x, batch_first=True)
+                f = qf[-1]
+                if want_vit:
+                    for j, i in enumerate(idxs):
+                        vit_out[i] = [v[j] for v in vit]
             else:
                 f = self.encode_audio(x, batch_first=True)
             for j, i in enumerate(idxs):
                 out[i] = f[j]
-        return out
+        return out, vit_out
 
     def initialize_MM_tokenizer(self, tokenizer, mask_token_nums=6, output_embeddings_require_grad=False, use_vqgan=False):
         """unified_arch.py:409-459: 11 special + mask_token_nums `<mask_i>` tokens appended in fixed order, tables

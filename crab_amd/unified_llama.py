@@ -176,8 +176,42 @@ class UnifiedForCausalLM(nn.Module, UnifiedMetaForCausalLM):
             return out
         return res
 
-    def generate_avs(self, *a, **k):
-        raise NotImplementedError("generate_avs / SegModule is SURVEY.md 8f-1 (next row after the NTP path)")
+    @torch.no_grad()
+    def generate_avs(self, batch_input_ids, batch_labels, batch_X_modals, batch_task_names, **kwargs):
+        """unified_llama.py:270-361: greedy generation with the post-final-norm hidden state of every step kept; the states
+        of the steps j with output_ids[0, j+1] in {<mask_0..5>} (bs == 1 assumed, :338) become the 6 prompt embeddings
+        of the SegModule.  Returns {'output_ids', 'pred_masks'} (only 'output_ids' when != 6 mask tokens were produced).
+        One deviation: step 0 contributes its LAST-row state (the reference's step-0 entry holds all S prompt rows)."""
+        if kwargs.get("do_sample"):
+            raise NotImplementedError("sampling is not implemented: the MI355X path is greedy-only")
+        inputs = self.prepare_multimodal_inputs(batch_input_ids=batch_input_ids, batch_labels=batch_labels,
+                                                batch_X_modals=batch_X_modals, return_multi_scale_features=True,
+                                                return_gt_mask=True, batch_task_names=batch_task_names)
+        embeds = inputs['inputs_embeds']
+        eos = kwargs.get("eos_token_id", self.config.eos_token_id)
+        pad = kwargs.get("pad_token_id", self.model.pad_token_id if self.model.pad_token_id is not None else eos)
+        ids, hidden = self._engine.generate(embeds, int(kwargs.get("max_new_tokens", 20)), eos_token_id=eos, pad_token_id=pad,
+                                            min_new_tokens=int(kwargs.get("min_new_tokens", 0) or 0),
+                                            use_graph=kwargs.get("use_graph", True), return_hidden=True)
+        result = {'output_ids': ids}
+        seg_ids = {self.SPECIAL_TOKEN_2_IDS[f'<mask_{i}>'] for i in range(6)}
+        row0 = ids[0].tolist()
+        picks = [j for j in range(len(row0) - 1) if row0[j + 1] in seg_ids]
+        if len(picks) == 0:
+            print('len(pred_embeddings) == 0')
+            return result
+        if len(picks) > 6:
+            print(f'pred_embeddings.shape[1] > 6, shape: {len(picks)}')
+            picks = picks[-6:]
+        elif len(picks) < 6:
+            print(f'pred_embeddings.shape[1] < 6, shape: {len(picks)}')
+            return result
+        pred_embeddings = torch.stack([hidden[:, j] for j in picks], dim=1)              # [bs, 6, D]
+        result = self.model.postprocess_seg(pred_embeddings=pred_embeddings,
+                                            multi_scale_image_feature_list=inputs['multi_scale_image_features'],
+                                            gt_mask=None, batch_task_names=batch_task_names)
+        result['output_ids'] = ids
+        return result
 
     def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
         """Checkpoints are fp32 (reference ships --bf16 False); tensors are cast to the resident bf16 storage."""

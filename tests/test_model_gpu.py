@@ -212,3 +212,60 @@ def test_seg_module_vs_reference_fixture_and_oracle():
         assert _rel(out[i], ref[i]) < 6e-2, f"sample {i} vs oracle on bf16-rounded weights"
     assert _rel(out[0][:, 3::8, 5::8], A["avss_sub"]) < 8e-2
     assert _rel(out[1][:, 1::2, ::2], A["s4_sub"]) < 8e-2
+
+
+def test_generate_avs_pipeline_vs_oracle():
+    """generate_avs (unified_llama.py:270-361): <image> prompt -> greedy ids + per-step hidden states -> the states of the
+    steps followed by a <mask_i> token -> SegModule masks.  The tiny random decoder never emits real mask tokens, so the six
+    <mask_i> ids are re-pointed at the tokens it does emit at steps 1..6 (the selection logic is what is under test)."""
+    from crab_amd import synth
+    from oracle import crab_oracle as O
+    from tests.test_oracle_golden import _full_cfg
+    from tests.util import DuckTokenizer, bert_cfg
+    from crab_amd.peft_hyper import LoraConfig, get_peft_model
+    from crab_amd.unified_llama import UnifiedConfig, UnifiedForCausalLM
+    meta, A = load_fixture("full_tiny_llama")
+    smeta, _ = load_fixture("seg_tiny")
+    W = weights_from_table(meta)
+    Wseg = weights_from_table(smeta)
+    W.update({"base_model.model." + k: v for k, v in Wseg.items()})
+    cfg = UnifiedConfig(**meta["dec"], pad_token_id=meta["pad_token_id"])
+    cfg.vocab_size = meta["base_vocab"]
+    model = get_peft_model(UnifiedForCausalLM(cfg, device="cuda"), LoraConfig())
+    model.get_model().pad_token_id = meta["pad_token_id"]
+    model.get_model().init_multimodal_modules(d_model=meta["d_model"], visual_branch=True, audio_branch=True, segment_branch=True,
+                                              select_layer_list=meta["select"], clip_config=meta["clip"], beats_config=meta["beats"],
+                                              bert_config=bert_cfg(meta["qf"]), vit_image_embedding_dim=meta["clip"]["hidden_size"])
+    model.initialize_MM_tokenizer(DuckTokenizer(meta["base_vocab"]), mask_token_nums=6)
+    r = model.load_state_dict(W, strict=False)
+    assert not r.missing_keys, r.missing_keys[:5]
+    sp = model.SPECIAL_TOKEN_2_IDS
+    ids = A["ids0"].clone()
+    for a_, b_ in (("<video_start>", "<image_start>"), ("<video>", "<image>"), ("<video_end>", "<image_end>")):
+        ids[ids == sp[a_]] = sp[b_]
+    p = meta["prompts"]
+    image = synth.synth_video(1, seed=meta["seed"], clip=p["clip0"])
+    mods = [{'<image>': image, '<audio>': synth.synth_audio(p["t_a"], p["l_a"], seed=meta["seed"], clip=p["clip0"])}]
+    lab = [torch.full_like(ids, -100)]
+    n = 8
+    plain = model.generate(batch_input_ids=[ids], batch_labels=lab, batch_X_modals=mods, batch_task_names=['s4'], max_new_tokens=n,
+                           pad_token_id=2, eos_token_id=None).cpu()
+    for i in range(6):
+        sp[f'<mask_{i}>'] = int(plain[0, 1 + i])
+    res = model.generate_avs(batch_input_ids=[ids], batch_labels=lab, batch_X_modals=mods, batch_task_names=['s4'], max_new_tokens=n,
+                             pad_token_id=2, eos_token_id=None)
+    assert torch.equal(res['output_ids'].cpu(), plain)
+    assert len(res['pred_masks']) == 1 and tuple(res['pred_masks'][0].shape) == (1, 224, 224)
+    # oracle pipeline on bf16-rounded weights
+    Wo = _bf(O.strip_peft_prefix(W))
+    ocfg = _full_cfg(meta)
+    inp = O.prepare_multimodal_inputs([ids], mods, Wo, ocfg)
+    oids, _, ohid = O.greedy_generate(inp["inputs_embeds"], Wo, ocfg.decoder, n, pad_token_id=2, return_hidden=True)
+    row = plain[0].tolist()
+    seg_ids = {sp[f'<mask_{i}>'] for i in range(6)}
+    picks = [j for j in range(n - 1) if row[j + 1] in seg_ids][-6:]
+    assert len(picks) == 6
+    feats = O.visual_encoder(image[None].to(BF).float(), Wo, ocfg.clip)
+    ref = O.seg_module(torch.stack([ohid[:, j] for j in picks], 1), feats[:2], ['s4'], Wo)
+    if torch.equal(oids, plain):                   # identical contexts -> the masks are comparable
+        assert _rel(res['pred_masks'][0], ref[0]) < 1e-1
