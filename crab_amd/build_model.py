@@ -32,8 +32,11 @@ class CountingTokenizer:
 
 
 @torch.no_grad()
-def randomize_(model: torch.nn.Module, seed: int = 42, std: float = 0.02):
-    """In-place synthetic weights: matrices ~ N(0, std^2), 1-D norm weights = 1, biases ~ N(0, std^2)."""
+def randomize_(model: torch.nn.Module, seed: int = 42, std: float = 0.02, conditioned: bool = False):
+    """In-place synthetic weights: matrices ~ N(0, std^2), 1-D norm weights = 1, biases ~ N(0, std^2).
+    conditioned=True keeps the decoder's sub-layer outputs small against the residual stream (embeddings ~ N(0,1),
+    o_proj / down_proj / lora_B x0.1) like a trained pre-LN decoder: used by the full-size parity-property tests, where
+    a fully random 32-layer decoder would amplify bf16 rounding chaotically."""
     dev = next(model.parameters()).device
     g = torch.Generator(device=dev).manual_seed(seed)
     for name, p in model.named_parameters():
@@ -44,13 +47,19 @@ def randomize_(model: torch.nn.Module, seed: int = 42, std: float = 0.02):
         elif leaf in ("grep_a", "weight_g"):
             p.fill_(1.0)
         else:
-            tmp = torch.empty(p.shape, device=dev, dtype=torch.float32).normal_(0.0, std, generator=g)
+            sd_ = std
+            if conditioned:
+                if "embed_tokens" in name:
+                    sd_ = 1.0
+                elif ".o_proj.weight" in name or ".down_proj.weight" in name or ".lora_B" in name:
+                    sd_ = std * 0.1
+            tmp = torch.empty(p.shape, device=dev, dtype=torch.float32).normal_(0.0, sd_, generator=g)
             p.copy_(tmp)
     return model
 
 
 def build_crab(llm: str = "llama", device="cuda", num_hidden_layers: Optional[int] = None, seed: int = 42,
-               visual: bool = True, audio: bool = True, randomize: bool = True):
+               visual: bool = True, audio: bool = True, randomize: bool = True, conditioned: bool = False):
     """Full-size Crab (Llama-2-7B or Qwen2-7B decoder + CLIP ViT-L/14 + BEATs iter3+ + Q-Former projectors)."""
     if llm == "llama":
         from .unified_llama import UnifiedConfig, UnifiedForCausalLM
@@ -72,6 +81,6 @@ def build_crab(llm: str = "llama", device="cuda", num_hidden_layers: Optional[in
     model.initialize_MM_tokenizer(CountingTokenizer(base_vocab), mask_token_nums=6)
     model.base_vocab = base_vocab
     if randomize:
-        randomize_(model, seed)
+        randomize_(model, seed, conditioned=conditioned)
     model.eval()
     return model
