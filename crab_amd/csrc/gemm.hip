@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_norm_kernel(const float* 
 }  // namespace
 
 int crab_gemm_skinny_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* d);   // skinny.hip
-int crab_gemm_glds_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* d);     // gemm_glds.hip
+int crab_gemm_glds_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* d, int splitk, float* part);     // gemm_glds.hip
 
 // unfused form of the optional post-RMSNorm (paths whose epilogue does not own whole rows)
 static int post_norm(crab_ctx* ctx, void* stream, const crab_gemm_desc* d) {
@@ -383,7 +383,11 @@ extern "C" int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc*
         dim3 grid(p.tiles_m * p.tiles_n, splitk);
         if (sk_bm == 64 && sk_bn == 128) hipLaunchKernelGGL((gemm_bt_kernel<64, 128>), grid, dim3(256), 0, s, p);
         else if (sk_bm == 64) hipLaunchKernelGGL((gemm_bt_kernel<64, 64>), grid, dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((gemm_bt_kernel<128, 128>), grid, dim3(256), 0, s, p);
+        else if (d->tune == 300) hipLaunchKernelGGL((gemm_bt_kernel<128, 128>), grid, dim3(256), 0, s, p);
+        else {                                                        // 128-row tiles: LDS-DMA staged kernel, K split over blockIdx.y
+            int rc2 = crab_gemm_glds_launch(ctx, s, d, splitk, p.part);
+            if (rc2) return rc2;
+        }
         int rc = crab_check_launch(ctx, "gemm_bt_kernel(split-K)");
         if (rc) return rc;
         if (splitk == 1) return post_norm(ctx, stream, d);
@@ -406,7 +410,7 @@ extern "C" int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc*
     bool small = (d->M <= 64) || (d->N <= 64) || big_tiles < 192;
     if (!small && d->tune != 300) {
         // 128x128 tiles: LDS-DMA staged kernel (gemm_glds.hip); tune == 300 keeps the register-staged variant for A/B runs
-        int rc = crab_gemm_glds_launch(ctx, s, d);
+        int rc = crab_gemm_glds_launch(ctx, s, d, 1, nullptr);
         return rc ? rc : post_norm(ctx, stream, d);
     }
     if (!small) {

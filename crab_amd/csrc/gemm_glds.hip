@@ -25,6 +25,8 @@ struct GemmGP {
     int nb0;
     long sA0, sA1, sB0, sB1, sC0, sC1, sR0, sR1, sBias0, sBias1;
     int tiles_m, tiles_n;
+    int splitk;          // > 1: blockIdx.y = K slice (unbatched), raw fp32 partial tiles to `part` [slice][M][N]
+    float* part;
 };
 
 __device__ __attribute__((aligned(16))) uint32_t g_zero_page[64];      // zero-initialised device memory (256 B)
@@ -47,7 +49,7 @@ __global__ __launch_bounds__(256) void gemm_bt_glds_kernel(GemmGP p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
 
-    const int z = blockIdx.y;
+    const int z = p.splitk > 1 ? 0 : blockIdx.y;
     const int z0 = z % p.nb0, z1 = z / p.nb0;
     const bf16_t* A = p.A + z0 * p.sA0 + z1 * p.sA1;
     const bf16_t* B = p.B + z0 * p.sB0 + z1 * p.sB1;
@@ -60,6 +62,11 @@ __global__ __launch_bounds__(256) void gemm_bt_glds_kernel(GemmGP p) {
     const int nk1 = (p.K + GBK - 1) / GBK;
     const int nk2 = p.A2 ? (p.K2 + GBK - 1) / GBK : 0;
     const int nk = nk1 + nk2;
+    int t_begin = 0, t_end = nk;
+    if (p.splitk > 1) {
+        t_begin = (int)((long)nk * blockIdx.y / p.splitk);
+        t_end = (int)((long)nk * (blockIdx.y + 1) / p.splitk);
+    }
 
     // per-lane staging coordinates, hoisted out of the K loop.  With PA == PB (square tile) waves 0,1 stage the
     // activation tile and waves 2,3 the weight tile, so the operand choice is wave-uniform.
@@ -108,14 +115,14 @@ __global__ __launch_bounds__(256) void gemm_bt_glds_kernel(GemmGP p) {
 #pragma unroll
         for (int j = 0; j < TM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    STAGE(0, 0);
+    if (t_begin < t_end) STAGE(t_begin, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     const int fr = lane & 15, fg = lane >> 4;
-    for (int t = 0; t < nk; ++t) {
-        const int cur = t & 1;
-        if (t + 1 < nk) STAGE(t + 1, cur ^ 1);
+    for (int t = t_begin; t < t_end; ++t) {
+        const int cur = (t - t_begin) & 1;
+        if (t + 1 < t_end) STAGE(t + 1, cur ^ 1);
         const bf16_t* la_ = &lds[cur][0];
         const bf16_t* lb_ = &lds[cur][BM * GBK];
 #pragma unroll
@@ -142,6 +149,25 @@ __global__ __launch_bounds__(256) void gemm_bt_glds_kernel(GemmGP p) {
         __syncthreads();
     }
 
+    if (p.splitk > 1) {          // raw partial tile; reduced (fixed slice order) by the split-K epilogue kernels in gemm.hip
+        float* part = p.part + (long)blockIdx.y * p.M * p.N;
+        const bool v4 = (p.N & 3) == 0;
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+            const int m = m0 + wm * WM + mi * 16 + fr;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+                const int n = n0 + wn * WN + ni * 16 + fg * 4;
+                if (n >= p.N) continue;
+                float* o = part + (long)m * p.N + n;
+                if (v4) *reinterpret_cast<f32x4_t*>(o) = acc[ni][mi];
+                else
+                    for (int r = 0; r < 4 && n + r < p.N; ++r) o[r] = acc[ni][mi][r];
+            }
+        }
+        return;
+    }
     // epilogue (identical to gemm_bt_kernel): lane owns row m = ..+fr, columns n = ..+fg*4 .. +3 of each 16x16 tile
     const bf16_t* bias = p.bias ? p.bias + z0 * p.sBias0 + z1 * p.sBias1 : nullptr;
     const bf16_t* R = p.R ? p.R + z0 * p.sR0 + z1 * p.sR1 : nullptr;
@@ -387,8 +413,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bt_ring_kernel(GemmGP p) 
 }  // namespace
 
 // called from crab_gemm_bf16 (gemm.hip) for the 128x128 tile regime
-int crab_gemm_glds_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* d) {
+int crab_gemm_glds_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* d, int splitk, float* part) {
     GemmGP p;
+    p.splitk = splitk > 1 ? splitk : 1; p.part = part;
     p.A = (const bf16_t*)d->A; p.B = (const bf16_t*)d->B; p.C = d->C; p.bias = (const bf16_t*)d->bias; p.R = (const bf16_t*)d->R;
     p.A2 = (const bf16_t*)d->A2; p.B2 = (const bf16_t*)d->B2;
     p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc; p.ldr = d->ldr; p.lda2 = d->lda2; p.ldb2 = d->ldb2;
@@ -402,7 +429,7 @@ int crab_gemm_glds_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* d)
     const long big = (long)((d->M + 255) / 256) * ((d->N + 255) / 256) * batch;
     // measured (profiles/README.md): the ring kernel wins once the grid is >= ~6 full waves of 256 blocks (gate|up
     // projection, square 4k), the 128x128 kernel wins on the narrower projections where big tiles leave a partial wave
-    bool use_big = big >= 1536 && d->M >= 1024 && d->N >= 1024;
+    bool use_big = big >= 1536 && d->M >= 1024 && d->N >= 1024 && p.splitk == 1;
     if (d->tune == 301) use_big = false;
     if (d->tune == 302) use_big = true;
     if (use_big) {
@@ -412,7 +439,7 @@ int crab_gemm_glds_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* d)
         return crab_check_launch(ctx, "gemm_bt_ring_kernel");
     }
     p.tiles_m = (d->M + 127) / 128; p.tiles_n = (d->N + 127) / 128;
-    dim3 grid(p.tiles_m * p.tiles_n, batch);
+    dim3 grid(p.tiles_m * p.tiles_n, p.splitk > 1 ? p.splitk : batch);
     hipLaunchKernelGGL((gemm_bt_glds_kernel<128, 128>), grid, dim3(256), 0, s, p);
     return crab_check_launch(ctx, "gemm_bt_glds_kernel");
 }
