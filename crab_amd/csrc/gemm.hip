@@ -356,7 +356,7 @@ extern "C" int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc*
         else if (d->tune >= 100) sk_bn = 128;
         if (sk_bm == 128 && sk_bn == 64) sk_bn = 128;
         long tiles = (long)((d->N + sk_bn - 1) / sk_bn) * ((d->M + sk_bm - 1) / sk_bm);
-        splitk = (int)((640 + tiles - 1) / tiles);
+        splitk = tiles >= 300 ? 1 : (int)((640 + tiles - 1) / tiles);        // a full wave of blocks needs no split (and no partial traffic)
         if (d->tune >= 100) splitk = d->tune % 100;
         if (splitk > nk_all / 4) splitk = nk_all / 4;
         if (splitk < 1) splitk = 1;
