@@ -153,6 +153,73 @@ __global__ void qkv_rope_split_kernel(bf16_t* __restrict__ qkv, long ldqkv, cons
     }
 }
 
+
+// Tiled variant for S >= 16 (prefill / encoders): one block per (64 tokens, head).  16-byte vector loads/stores for the
+// rotation and the cache scatter; V^T goes through an LDS transpose so that vt rows are written as 16-byte pieces
+// (the element-wise kernel above writes V^T with 2-byte stores at a stride of vt_ld elements).
+template <int D>
+__global__ __launch_bounds__(256) void qkv_rope_split_tile_kernel(bf16_t* __restrict__ qkv, long ldqkv, const float* __restrict__ tab,
+                                                                  bf16_t* __restrict__ kc, bf16_t* __restrict__ vc, bf16_t* __restrict__ vt,
+                                                                  long vt_ld, int S, int H, int Hk, int Tmax, int pos0) {
+    constexpr int HALF = D / 2, CH = D / 8;                     // 16-byte chunks per head row
+    __shared__ bf16_t tile[64][D + 2];                          // +2: odd word stride for the transposed reads
+    const int tid = threadIdx.x;
+    const int s0 = blockIdx.x * 64, hh = blockIdx.y, b = blockIdx.z;
+    const long tok0 = (long)b * S + s0;
+    if (hh < H + Hk) {
+        if (!tab && (hh < H || !kc)) return;                     // encoder use: nothing to do for q / k heads
+        const int hk = hh - H;
+        for (int idx = tid; idx < 64 * (CH / 2); idx += 256) {   // (token, chunk pair i0..i0+7 | HALF+i0..)
+            const int tk = idx / (CH / 2), c = idx % (CH / 2);
+            const int s = s0 + tk;
+            if (s >= S) continue;
+            bf16_t* src = qkv + (tok0 + tk) * ldqkv + (long)hh * D + c * 8;
+            u32x4 lo = *reinterpret_cast<const u32x4*>(src);
+            u32x4 hi = *reinterpret_cast<const u32x4*>(src + HALF);
+            u32x4 olo = lo, ohi = hi;
+            const int pos = pos0 + s;
+            if (tab) {
+                const float* cs = tab + 2 * ((long)pos * HALF + c * 8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float x1a = lo_bf(lo[e]), x1b = hi_bf(lo[e]), x2a = lo_bf(hi[e]), x2b = hi_bf(hi[e]);
+                    float ca = cs[4 * e], sa = cs[4 * e + 1], cb = cs[4 * e + 2], sb = cs[4 * e + 3];
+                    olo[e] = pack_bf2(x1a * ca - x2a * sa, x1b * cb - x2b * sb);
+                    ohi[e] = pack_bf2(x2a * ca + x1a * sa, x2b * cb + x1b * sb);
+                }
+            }
+            bf16_t* dst = hh < H ? src : kc + (((long)b * Hk + hk) * Tmax + pos) * D + c * 8;
+            *reinterpret_cast<u32x4*>(dst) = olo;
+            *reinterpret_cast<u32x4*>(dst + HALF) = ohi;
+        }
+        return;
+    }
+    const int hk = hh - H - Hk;
+    for (int idx = tid; idx < 64 * CH; idx += 256) {
+        const int tk = idx / CH, c = idx % CH;
+        const int s = s0 + tk;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (s < S) {
+            v = *reinterpret_cast<const u32x4*>(qkv + (tok0 + tk) * ldqkv + (long)hh * D + c * 8);
+            if (vc) *reinterpret_cast<u32x4*>(vc + (((long)b * Hk + hk) * Tmax + pos0 + s) * D + c * 8) = v;
+        }
+        uint32_t* t32 = reinterpret_cast<uint32_t*>(&tile[tk][c * 8]);
+        t32[0] = v[0]; t32[1] = v[1]; t32[2] = v[2]; t32[3] = v[3];
+    }
+    if (!vt) return;
+    __syncthreads();
+    bf16_t* vtb = vt + ((long)b * Hk + hk) * D * vt_ld;
+    for (int idx = tid; idx < D * 8; idx += 256) {               // (d, group of 8 tokens)
+        const int dd = idx >> 3, g = idx & 7;
+        const int s = s0 + g * 8;
+        if (s >= vt_ld) continue;
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (uint32_t)tile[g * 8 + 2 * e][dd] | ((uint32_t)tile[g * 8 + 2 * e + 1][dd] << 16);
+        if (s + 8 <= vt_ld) *reinterpret_cast<u32x4*>(vtb + (long)dd * vt_ld + s) = o;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ hyper-LoRA mix
 // one thread per (row, projection): softmax over nl route logits, then scaling * p_i * h_j
 template <typename TT>
@@ -470,6 +537,15 @@ int crab_qkv_rope_split(crab_ctx* ctx, void* stream, void* qkv, int64_t ldqkv, c
     if (!ctx) return CRAB_E_INVALID;
     if (!qkv || B <= 0 || S <= 0 || d > 2048 || (d & 1)) return crab_fail(ctx, CRAB_E_INVALID, "qkv_rope_split: bad argument");
     if ((k_cache || v_cache) && !pos_dev && pos0 + S > Tmax) return crab_fail(ctx, CRAB_E_INVALID, "qkv_rope_split: KV cache overflow");
+    if (S >= 16 && !pos_dev && (d == 32 || d == 64 || d == 128) && (ldqkv & 7) == 0 && (vt == nullptr || (vt_ld & 7) == 0)) {
+        dim3 grid((S + 63) / 64, H + 2 * Hk, B);
+#define RS_ARGS (bf16_t*)qkv, (long)ldqkv, rope_tab, (bf16_t*)k_cache, (bf16_t*)v_cache, (bf16_t*)vt, (long)vt_ld, S, H, Hk, Tmax, pos0
+        if (d == 128) hipLaunchKernelGGL((qkv_rope_split_tile_kernel<128>), grid, dim3(256), 0, S_(stream), RS_ARGS);
+        else if (d == 64) hipLaunchKernelGGL((qkv_rope_split_tile_kernel<64>), grid, dim3(256), 0, S_(stream), RS_ARGS);
+        else hipLaunchKernelGGL((qkv_rope_split_tile_kernel<32>), grid, dim3(256), 0, S_(stream), RS_ARGS);
+#undef RS_ARGS
+        return crab_check_launch(ctx, "qkv_rope_split_tile");
+    }
     int threads = ((d / 2 + 63) / 64) * 64;
     hipLaunchKernelGGL(qkv_rope_split_kernel, dim3(B * S, H + 2 * Hk), dim3(threads), 0, S_(stream), (bf16_t*)qkv, (long)ldqkv, rope_tab,
                        (bf16_t*)k_cache, (bf16_t*)v_cache, (bf16_t*)vt, (long)vt_ld, S, H, Hk, d, Tmax, pos0, pos_dev);
