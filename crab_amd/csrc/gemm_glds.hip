@@ -474,7 +474,8 @@ int crab_gemm_glds_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* d,
     const long big = (long)((d->M + 255) / 256) * ((d->N + 255) / 256) * batch;
     // measured (profiles/README.md): the ring kernel wins once the grid is >= ~6 full waves of 256 blocks (gate|up
     // projection, square 4k), the 128x128 kernel wins on the narrower projections where big tiles leave a partial wave
-    bool use_big = big >= 1536 && d->M >= 1024 && d->N >= 1024 && p.splitk == 1;
+    // (short K: the one-block-per-CU ring kernel cannot hide its ~20k-cycle prologue + epilogue behind another block)
+    bool use_big = big >= 1536 && d->M >= 1024 && d->N >= 1024 && d->K >= 2048 && p.splitk == 1;
     if (d->tune == 301) use_big = false;
     if (d->tune == 302) use_big = true;
     if (use_big) {

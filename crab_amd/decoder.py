@@ -297,7 +297,14 @@ class GenerationEngine:
             graph = self._capture(st)
         check_every = 16
         for step in range(1, max_new_tokens):
-            if graph is not None:
+            prof = ops.PROFILER
+            if graph is not None and prof is not None and prof.decode_every and step % prof.decode_every == prof.decode_every // 2:
+                # roofline sampling (bench.py): this step runs the same launches eagerly with HIP events around the
+                # decode-attention kernel; state is device-resident, so graph replays continue seamlessly after it
+                prof.decode_eager, prof.decode_ctx = True, S + step
+                self._decode_step(st)
+                prof.decode_eager = False
+            elif graph is not None:
                 graph.replay()
             else:
                 self._decode_step(st)

@@ -37,35 +37,43 @@ def _chk_bf16(*ts):
             raise _lib.CrabHipError(f"expected bfloat16 storage, got {t.dtype}")
 
 
-class GemmProfiler:
-    """Optional HIP-event timing of GEMM launches on the current stream (bench.py roofline leg).  Only used outside
-    graph capture; adds two event records per profiled launch.  Launches are bucketed by kernel variant."""
+class KernelProfiler:
+    """Optional HIP-event timing of kernel launches on the current stream (bench.py roofline leg).  Only used outside
+    graph capture; adds two event records per profiled launch.  GEMM launches (M >= min_m) are bucketed by kernel
+    variant with their algorithmic FLOPs; the decode-attention kernel is sampled with its algorithmic KV bytes on the
+    decode steps GenerationEngine.generate runs eagerly (every `decode_every`-th step; the eager step is bit-identical
+    to the HIP-graph replay it stands in for, tests/test_model_gpu.py)."""
 
-    def __init__(self, min_m: int = 512):
+    def __init__(self, min_m: int = 512, decode_every: int = 32):
         self.min_m = min_m
-        self.records = []          # (variant, flops, start_event, end_event)
+        self.decode_every = decode_every
+        self.decode_ctx = 0          # live KV length of the sampled step (host mirror of the device position word)
+        self.decode_eager = False    # set by GenerationEngine.generate around a sampled eager decode step
+        self.records = []            # (variant, work, start_event, end_event); work = FLOPs ("gemm*") or bytes ("attn_decode*")
 
     def summary(self):
         torch.cuda.synchronize()
         out = {}
-        for variant, flops, e0, e1 in self.records:
-            d = out.setdefault(variant, {"launches": 0, "flops": 0.0, "ms": 0.0})
+        for variant, work, e0, e1 in self.records:
+            d = out.setdefault(variant, {"launches": 0, "work": 0.0, "ms": 0.0})
             d["launches"] += 1
-            d["flops"] += flops
+            d["work"] += work
             d["ms"] += e0.elapsed_time(e1)
         return out
 
 
-PROFILER: Optional[GemmProfiler] = None
+GemmProfiler = KernelProfiler
+
+PROFILER: Optional[KernelProfiler] = None
 
 
-def _variant(M: int, N: int, batch: int = 1) -> str:
+def _variant(M: int, N: int, batch: int = 1, K: int = 4096) -> str:
     """Mirror of the tile choice in csrc/gemm.hip (crab_gemm_bf16)."""
     big = ((M + 127) // 128) * ((N + 127) // 128) * batch
     if M <= 64 or N <= 64 or big < 192:
         return "gemm_bt_kernel<64,64>"
     big256 = ((M + 255) // 256) * ((N + 255) // 256) * batch
-    return "gemm_bt_ring_kernel<256,256>" if (big256 >= 1536 and M >= 1024 and N >= 1024) else "gemm_bt_glds_kernel<128,128>"
+    return "gemm_bt_ring_kernel<256,256>" if (big256 >= 1536 and M >= 1024 and N >= 1024 and K >= 2048) else "gemm_bt_glds_kernel<128,128>"
 
 
 _SPLITK_WS = {}
@@ -117,7 +125,7 @@ def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
         e0.record()
         _lib.check(_lib.load().crab_gemm_bf16(_lib.ctx(d), _stream(), C.byref(g)), d)
         e1.record()
-        prof.records.append((_variant(M, N), 2.0 * M * N * (K + (x2.shape[1] if x2 is not None else 0)), e0, e1))
+        prof.records.append((_variant(M, N, 1, K), 2.0 * M * N * (K + (x2.shape[1] if x2 is not None else 0)), e0, e1))
         return out
     _lib.check(_lib.load().crab_gemm_bf16(_lib.ctx(d), _stream(), C.byref(g)), d)
     return out
@@ -228,8 +236,18 @@ def attn_fwd(q, k, vt, o, *, q_strides, k_strides, vt_strides, o_strides, B, H, 
 
 def attn_decode(q, k_cache, v_cache, o, B, H, Hk, head_dim, Tmax, ctx_len, scale, ctx_dev=None):
     d = _dev(q)
+    prof = PROFILER
+    sample = prof is not None and prof.decode_eager and prof.decode_ctx > 0 and not torch.cuda.is_current_stream_capturing()
+    if sample:
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
     _lib.check(_lib.load().crab_attn_decode(_lib.ctx(d), _stream(), _p(q), q.stride(0), _p(k_cache), _p(v_cache), _p(o), o.stride(0),
                                             B, H, Hk, head_dim, Tmax, ctx_len, _p(ctx_dev), scale), d)
+    if sample:
+        e1.record()
+        # algorithmic bytes (DESIGN.md kernel table): every live K and V row once + q in + o out
+        nbytes = 2.0 * B * prof.decode_ctx * Hk * head_dim * 2 + 2.0 * B * H * head_dim * 2
+        prof.records.append((f"attn_decode_kernel<{head_dim}>", nbytes, e0, e1))
     return o
 
 

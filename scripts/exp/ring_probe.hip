@@ -334,15 +334,11 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bt_ring_kernel(GemmGP p) 
     // schedule, at K-tile granularity).  Every wave executes the same number of barriers.
     const long long t_l0 = __builtin_readcyclecounter();
     const int grp = wave / (NW / 2);
-    const bool rec = p.dbg && blockIdx.x == 7 && (wave == 0 || wave == 4) && lane == 0;
-    long long tsb[6];
-    long long acc_t[6] = {0,0,0,0,0,0};
     if (grp == 1) __builtin_amdgcn_s_barrier();
     for (int t = 0; t < nk; ++t) {
         // ---- LOAD segment: fragments of tile t first (12 ds_read_b128 issue in ~50 cycles), THEN the DMA for tile t+3:
         // an LDS-DMA instruction costs ~100 issue cycles (measured with s_memtime stamps), so the fragment reads
         // complete underneath the four DMA issues instead of after them
-        tsb[0] = __builtin_readcyclecounter();
         const bf16_t* st = &lds[(t & (RNS - 1)) * STAGE_ELEMS];
         bf16x8_t wf[TN], xf[TM];
 #pragma unroll
@@ -350,19 +346,14 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bt_ring_kernel(GemmGP p) 
 #pragma unroll
         for (int mi = 0; mi < TM; ++mi) xf[mi] = *reinterpret_cast<const bf16x8_t*>(st + xofs[mi]);
         __builtin_amdgcn_sched_barrier(0);
-        tsb[1] = __builtin_readcyclecounter();
         if (t + 3 < nk) RSTAGE(t + 3);
-        __builtin_amdgcn_sched_barrier(0);
-        tsb[2] = __builtin_readcyclecounter();
         // retire tile t+1 (the two youngest tiles stay in flight) and drain this tile's LDS reads BEFORE the barrier:
         // after it the partner group may refill the stage these reads came from
         if (t + 3 < nk) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        tsb[3] = __builtin_readcyclecounter();
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        tsb[4] = __builtin_readcyclecounter();
         // ---- MFMA segment
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -372,16 +363,55 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bt_ring_kernel(GemmGP p) 
                 acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
-        tsb[5] = __builtin_readcyclecounter();
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        long long te = __builtin_readcyclecounter();
-        if (t >= 8 && t < 120) { acc_t[0] += tsb[1]-tsb[0]; acc_t[1] += tsb[2]-tsb[1]; acc_t[2] += tsb[3]-tsb[2]; acc_t[3] += tsb[4]-tsb[3]; acc_t[4] += tsb[5]-tsb[4]; acc_t[5] += te-tsb[5]; }
     }
-    const long long t_l1 = __builtin_readcyclecounter();
-    if (rec) { for (int i = 0; i < 6; ++i) p.dbg[(wave == 4 ? 8 : 0) + i] = acc_t[i]; p.dbg[16 + (wave==4?4:0)] = t_l0 - t_k0; p.dbg[17 + (wave==4?4:0)] = t_l1 - t_l0; p.dbg[18 + (wave==4?4:0)] = t_k0; }
     if (grp == 0) __builtin_amdgcn_s_barrier();
+    const long long t_l1 = __builtin_readcyclecounter();
 #undef RSTAGE
+    // ---- fast epilogue: the whole 256x256 tile is in range and 8-byte aligned -> no per-element guards, fully unrolled,
+    // accumulators stay in registers (the generic path below indexes them dynamically and is only taken on ragged edges)
+    {
+        const bf16_t* bias_f = p.bias ? p.bias + z0 * p.sBias0 + z1 * p.sBias1 : nullptr;
+        const bf16_t* R_f = p.R ? p.R + z0 * p.sR0 + z1 * p.sR1 : nullptr;
+        const long coff_f = z0 * p.sC0 + z1 * p.sC1;
+        const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N) && ((p.ldc & 3) == 0) && ((coff_f & 3) == 0) && (!R_f || ((p.ldr & 3) == 0));
+        if (full) {
+            const int mb = m0 + wm * WM + fr, nb = n0 + wn * WN + fg * 4;
+            float bv[TN][4];
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+                u32x2 bw = {0u, 0u};
+                if (bias_f) bw = *reinterpret_cast<const u32x2*>(bias_f + nb + ni * 16);
+                bv[ni][0] = lo_bf(bw.x); bv[ni][1] = hi_bf(bw.x); bv[ni][2] = lo_bf(bw.y); bv[ni][3] = hi_bf(bw.y);
+            }
+            const int act = p.act;
+            const float rs = p.res_scale;
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi) {
+                const long rowC = coff_f + (long)(mb + mi * 16) * p.ldc + nb;
+                const long rowR = (long)(mb + mi * 16) * p.ldr + nb;
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni) {
+                    float v0 = acc[ni][mi][0] + bv[ni][0], v1 = acc[ni][mi][1] + bv[ni][1];
+                    float v2 = acc[ni][mi][2] + bv[ni][2], v3 = acc[ni][mi][3] + bv[ni][3];
+                    if (act != ACT_NONE) { v0 = apply_act(v0, act); v1 = apply_act(v1, act); v2 = apply_act(v2, act); v3 = apply_act(v3, act); }
+                    if (R_f) {
+                        u32x2 rr = *reinterpret_cast<const u32x2*>(R_f + rowR + ni * 16);
+                        v0 += rs * lo_bf(rr.x); v1 += rs * hi_bf(rr.x); v2 += rs * lo_bf(rr.y); v3 += rs * hi_bf(rr.y);
+                    }
+                    if (p.c_fp32) {
+                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + rowC + ni * 16) = make_float4(v0, v1, v2, v3);
+                    } else {
+                        u32x2 o; o.x = pack_bf2(v0, v1); o.y = pack_bf2(v2, v3);
+                        *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.C) + rowC + ni * 16) = o;
+                    }
+                }
+            }
+            if (p.dbg && blockIdx.x == 7 && (threadIdx.x == 0 || threadIdx.x == 256)) { long long* q = p.dbg + (threadIdx.x == 256 ? 4 : 0); q[0] = t_l0 - t_k0; q[1] = t_l1 - t_l0; q[2] = __builtin_readcyclecounter() - t_l1; }
+            return;
+        }
+    }
     // epilogue (identical to gemm_bt_kernel): lane owns row m = ..+fr, columns n = ..+fg*4 .. +3 of each 16x16 tile
     const bf16_t* bias = p.bias ? p.bias + z0 * p.sBias0 + z1 * p.sBias1 : nullptr;
     const bf16_t* R = p.R ? p.R + z0 * p.sR0 + z1 * p.sR1 : nullptr;
@@ -428,7 +458,6 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bt_ring_kernel(GemmGP p) 
             }
         }
     }
-    if (p.dbg && blockIdx.x == 7 && (threadIdx.x == 0 || threadIdx.x == 256)) p.dbg[19 + (threadIdx.x==256?4:0)] = __builtin_readcyclecounter() - t_k0;
 }
 
 }  // namespace

@@ -14,10 +14,7 @@ for _ in range(3):
     lib.probe_launch(C.c_void_p(torch.cuda.current_stream().cuda_stream), C.byref(g), C.c_void_p(dbg.data_ptr()))
 torch.cuda.synchronize()
 d = dbg.cpu()
-names = ["ds_read_issue", "glds_issue", "waits(vm+lgkm)", "barrier1", "mfma", "barrier2"]
-for wv, off in ((0, 0), (4, 8)):
-    print("wave", wv, " ".join(f"{n}={d[off + i].item() / 112:.0f}" for i, n in enumerate(names)), "sum", sum(d[off + i].item() for i in range(6)) / 112)
-print("wave0: prologue", d[16].item(), "loop", d[17].item(), "kernel total", d[19].item(), "| wave4:", d[20].item(), d[21].item(), d[23].item())
+print("wave0: prologue", d[0].item(), "loop", d[1].item(), "epilogue", d[2].item(), "| wave4:", d[4].item(), d[5].item(), d[6].item())
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(20):
