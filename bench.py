@@ -128,7 +128,9 @@ def main():
     ap.add_argument("--clips", type=int, default=int(os.environ.get("CRAB_BENCH_CLIPS", "256")), help="clips per GPU per step")
     ap.add_argument("--new-tokens", type=int, default=256)
     ap.add_argument("--frames", type=int, default=8)
-    ap.add_argument("--prefill-chunk", type=int, default=8)
+    ap.add_argument("--prefill-chunk", type=int, default=16)
+    ap.add_argument("--decode-streams", type=int, default=int(os.environ.get("CRAB_DECODE_STREAMS", "1")),
+                    help="decode groups replayed on separate HIP streams (KV-cache attention of one overlaps projections of another)")
     ap.add_argument("--llm", default="llama")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -163,7 +165,8 @@ def main():
     def step():
         out = model.generate(batch_input_ids=ids, batch_labels=lab, batch_X_modals=mods, batch_task_names=['avqa'] * B,
                              use_cache=True, max_new_tokens=args.new_tokens, min_new_tokens=args.new_tokens, eos_token_id=eos,
-                             pad_token_id=um.model.pad_token_id, prefill_chunk=args.prefill_chunk, output_logits=False)
+                             pad_token_id=um.model.pad_token_id, prefill_chunk=args.prefill_chunk, output_logits=False,
+                             decode_streams=args.decode_streams)
         return gather_results(out, clip0, world, rank)
 
     def sync():

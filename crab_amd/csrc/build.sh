@@ -3,12 +3,14 @@
 set -e
 cd "$(dirname "$0")"
 OUT=../libcrab_hip.so
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result"
+# -pragma-unroll-threshold: "#pragma unroll" is silently dropped above 16k instructions; a dropped unroll turns the
+# compile-time accumulator indices of the GEMM epilogues into scratch accesses
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -mllvm -pragma-unroll-threshold=200000"
 mkdir -p build
 pids=()
 for f in *.hip; do
   o=build/${f%.hip}.o
-  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ common.h -nt "$o" ] || [ crab_internal.h -nt "$o" ] || [ ../../include/crab_hip.h -nt "$o" ]; then
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ common.h -nt "$o" ] || [ crab_internal.h -nt "$o" ] || [ gemm_epilogue.h -nt "$o" ] || [ build.sh -nt "$o" ] || [ ../../include/crab_hip.h -nt "$o" ]; then
     /opt/rocm/bin/hipcc $FLAGS -c "$f" -o "$o" &
     pids+=($!)
   fi

@@ -14,15 +14,16 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
 // round-to-nearest-even, NaN preserved: identical to torch's float -> bfloat16
-__device__ __forceinline__ bf16_t f2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
-}
+// fp32 -> bf16, round to nearest even: gfx950's packed hardware conversion (v_cvt_pk_bf16_f32, one instruction per
+// PAIR; the software add-0x7fff sequence costs ~8 VALU instructions per value and made the 256x256 GEMM epilogue
+// VALU-bound: 18k of its 25k cycles, profiles/README.md)
+typedef float cvt_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 cvt_bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
-    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+    cvt_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, cvt_bf16x2));
 }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf2(f, 0.f) & 0xffffu); }
 __device__ __forceinline__ float lo_bf(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float hi_bf(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 

@@ -11,6 +11,7 @@
 // Global->register->LDS prefetch of tile t+1 overlaps the MFMAs of tile t; one barrier per K tile.
 #include "common.h"
 #include "crab_internal.h"
+#include "gemm_epilogue.h"
 
 namespace {
 
@@ -161,53 +162,9 @@ __global__ __launch_bounds__(256) void gemm_bt_kernel(GemmP p) {
         }
         return;
     }
-    // epilogue: lane owns row m = ..+fr, columns n = ..+fg*4 .. +3 of each 16x16 tile
-    const bf16_t* bias = p.bias ? p.bias + z0 * p.sBias0 + z1 * p.sBias1 : nullptr;
-    const bf16_t* R = p.R ? p.R + z0 * p.sR0 + z1 * p.sR1 : nullptr;
-    const long coff = z0 * p.sC0 + z1 * p.sC1;
-    const bool vec_ok = ((p.ldc & 3) == 0) && ((coff & 3) == 0) && (!R || ((p.ldr & 3) == 0));
-#pragma unroll
-    for (int mi = 0; mi < TM; ++mi) {
-        const int m = m0 + wm * WM + mi * 16 + fr;
-        if (m >= p.M) continue;
-#pragma unroll
-        for (int ni = 0; ni < TN; ++ni) {
-            const int n = n0 + wn * WN + ni * 16 + fg * 4;
-            if (n >= p.N) continue;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float x = acc[ni][mi][r];
-                if (bias && n + r < p.N) x += bf2f(bias[n + r]);
-                x = apply_act(x, p.act);
-                v[r] = x;
-            }
-            if (n + 3 < p.N && vec_ok) {
-                if (R) {
-                    u32x2 rr = *reinterpret_cast<const u32x2*>(R + (long)m * p.ldr + n);
-                    v[0] += p.res_scale * lo_bf(rr.x); v[1] += p.res_scale * hi_bf(rr.x);
-                    v[2] += p.res_scale * lo_bf(rr.y); v[3] += p.res_scale * hi_bf(rr.y);
-                }
-                if (p.c_fp32) {
-                    float* C = reinterpret_cast<float*>(p.C) + coff + (long)m * p.ldc + n;
-                    *reinterpret_cast<float4*>(C) = make_float4(v[0], v[1], v[2], v[3]);
-                } else {
-                    bf16_t* C = reinterpret_cast<bf16_t*>(p.C) + coff + (long)m * p.ldc + n;
-                    u32x2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
-                    *reinterpret_cast<u32x2*>(C) = o;
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (n + r >= p.N) break;
-                    float x = v[r];
-                    if (R) x += p.res_scale * bf2f(R[(long)m * p.ldr + n + r]);
-                    if (p.c_fp32) reinterpret_cast<float*>(p.C)[coff + (long)m * p.ldc + n + r] = x;
-                    else reinterpret_cast<bf16_t*>(p.C)[coff + (long)m * p.ldc + n + r] = f2bf(x);
-                }
-            }
-        }
-    }
+    // output stage shared with the LDS-DMA kernels (gemm_epilogue.h): unguarded + activation-specialised on interior sub-tiles
+    gemm_epilogue<TM, TN>(acc, p.act, m0 + wm * WM, n0 + wn * WN, fr, fg, p.M, p.N, p.bias ? p.bias + z0 * p.sBias0 + z1 * p.sBias1 : nullptr,
+                          p.R ? p.R + z0 * p.sR0 + z1 * p.sR1 : nullptr, p.ldr, p.res_scale, p.C, z0 * p.sC0 + z1 * p.sC1, p.ldc, p.c_fp32);
 }
 
 #undef GLOAD

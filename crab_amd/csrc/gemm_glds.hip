@@ -13,6 +13,7 @@
 // single barrier per K tile.  Two blocks per CU (64 KiB LDS each) overlap one block's drain with the other's MFMAs.
 #include "common.h"
 #include "crab_internal.h"
+#include "gemm_epilogue.h"
 
 namespace {
 
@@ -168,52 +169,9 @@ __global__ __launch_bounds__(256) void gemm_bt_glds_kernel(GemmGP p) {
         }
         return;
     }
-    // epilogue (identical to gemm_bt_kernel): lane owns row m = ..+fr, columns n = ..+fg*4 .. +3 of each 16x16 tile
-    const bf16_t* bias = p.bias ? p.bias + z0 * p.sBias0 + z1 * p.sBias1 : nullptr;
-    const bf16_t* R = p.R ? p.R + z0 * p.sR0 + z1 * p.sR1 : nullptr;
-    const long coff = z0 * p.sC0 + z1 * p.sC1;
-    const bool vec_ok = ((p.ldc & 3) == 0) && ((coff & 3) == 0) && (!R || ((p.ldr & 3) == 0));
-#pragma unroll
-    for (int mi = 0; mi < TM; ++mi) {
-        const int m = m0 + wm * WM + mi * 16 + fr;
-        if (m >= p.M) continue;
-#pragma unroll
-        for (int ni = 0; ni < TN; ++ni) {
-            const int n = n0 + wn * WN + ni * 16 + fg * 4;
-            if (n >= p.N) continue;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float x = acc[ni][mi][r];
-                if (bias && n + r < p.N) x += bf2f(bias[n + r]);
-                v[r] = apply_act(x, p.act);
-            }
-            if (n + 3 < p.N && vec_ok) {
-                if (R) {
-                    u32x2 rr = *reinterpret_cast<const u32x2*>(R + (long)m * p.ldr + n);
-                    v[0] += p.res_scale * lo_bf(rr.x); v[1] += p.res_scale * hi_bf(rr.x);
-                    v[2] += p.res_scale * lo_bf(rr.y); v[3] += p.res_scale * hi_bf(rr.y);
-                }
-                if (p.c_fp32) {
-                    float* C = reinterpret_cast<float*>(p.C) + coff + (long)m * p.ldc + n;
-                    *reinterpret_cast<float4*>(C) = make_float4(v[0], v[1], v[2], v[3]);
-                } else {
-                    bf16_t* C = reinterpret_cast<bf16_t*>(p.C) + coff + (long)m * p.ldc + n;
-                    u32x2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
-                    *reinterpret_cast<u32x2*>(C) = o;
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (n + r >= p.N) break;
-                    float x = v[r];
-                    if (R) x += p.res_scale * bf2f(R[(long)m * p.ldr + n + r]);
-                    if (p.c_fp32) reinterpret_cast<float*>(p.C)[coff + (long)m * p.ldc + n + r] = x;
-                    else reinterpret_cast<bf16_t*>(p.C)[coff + (long)m * p.ldc + n + r] = f2bf(x);
-                }
-            }
-        }
-    }
+    // output stage shared with gemm_bt_kernel (gemm_epilogue.h): unguarded + activation-specialised on interior sub-tiles
+    gemm_epilogue<TM, TN>(acc, p.act, m0 + wm * WM, n0 + wn * WN, fr, fg, p.M, p.N, p.bias ? p.bias + z0 * p.sBias0 + z1 * p.sBias1 : nullptr,
+                          p.R ? p.R + z0 * p.sR0 + z1 * p.sR1 : nullptr, p.ldr, p.res_scale, p.C, z0 * p.sC0 + z1 * p.sC1, p.ldc, p.c_fp32);
 }
 
 #undef STAGE
@@ -365,94 +323,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bt_ring_kernel(GemmGP p) 
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();
 #undef RSTAGE
-    // ---- fast epilogue: the whole 256x256 tile is in range and 8-byte aligned -> no per-element guards, fully unrolled,
-    // accumulators stay in registers (the generic path below indexes them dynamically and is only taken on ragged edges)
-    {
-        const bf16_t* bias_f = p.bias ? p.bias + z0 * p.sBias0 + z1 * p.sBias1 : nullptr;
-        const bf16_t* R_f = p.R ? p.R + z0 * p.sR0 + z1 * p.sR1 : nullptr;
-        const long coff_f = z0 * p.sC0 + z1 * p.sC1;
-        const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N) && ((p.ldc & 3) == 0) && ((coff_f & 3) == 0) && (!R_f || ((p.ldr & 3) == 0));
-        if (full) {
-            const int mb = m0 + wm * WM + fr, nb = n0 + wn * WN + fg * 4;
-            float bv[TN][4];
-#pragma unroll
-            for (int ni = 0; ni < TN; ++ni) {
-                u32x2 bw = {0u, 0u};
-                if (bias_f) bw = *reinterpret_cast<const u32x2*>(bias_f + nb + ni * 16);
-                bv[ni][0] = lo_bf(bw.x); bv[ni][1] = hi_bf(bw.x); bv[ni][2] = lo_bf(bw.y); bv[ni][3] = hi_bf(bw.y);
-            }
-            const int act = p.act;
-            const float rs = p.res_scale;
-#pragma unroll
-            for (int mi = 0; mi < TM; ++mi) {
-                const long rowC = coff_f + (long)(mb + mi * 16) * p.ldc + nb;
-                const long rowR = (long)(mb + mi * 16) * p.ldr + nb;
-#pragma unroll
-                for (int ni = 0; ni < TN; ++ni) {
-                    float v0 = acc[ni][mi][0] + bv[ni][0], v1 = acc[ni][mi][1] + bv[ni][1];
-                    float v2 = acc[ni][mi][2] + bv[ni][2], v3 = acc[ni][mi][3] + bv[ni][3];
-                    if (act != ACT_NONE) { v0 = apply_act(v0, act); v1 = apply_act(v1, act); v2 = apply_act(v2, act); v3 = apply_act(v3, act); }
-                    if (R_f) {
-                        u32x2 rr = *reinterpret_cast<const u32x2*>(R_f + rowR + ni * 16);
-                        v0 += rs * lo_bf(rr.x); v1 += rs * hi_bf(rr.x); v2 += rs * lo_bf(rr.y); v3 += rs * hi_bf(rr.y);
-                    }
-                    if (p.c_fp32) {
-                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + rowC + ni * 16) = make_float4(v0, v1, v2, v3);
-                    } else {
-                        u32x2 o; o.x = pack_bf2(v0, v1); o.y = pack_bf2(v2, v3);
-                        *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.C) + rowC + ni * 16) = o;
-                    }
-                }
-            }
-            return;
-        }
-    }
-    // epilogue (identical to gemm_bt_kernel): lane owns row m = ..+fr, columns n = ..+fg*4 .. +3 of each 16x16 tile
-    const bf16_t* bias = p.bias ? p.bias + z0 * p.sBias0 + z1 * p.sBias1 : nullptr;
-    const bf16_t* R = p.R ? p.R + z0 * p.sR0 + z1 * p.sR1 : nullptr;
-    const long coff = z0 * p.sC0 + z1 * p.sC1;
-    const bool vec_ok = ((p.ldc & 3) == 0) && ((coff & 3) == 0) && (!R || ((p.ldr & 3) == 0));
-#pragma unroll
-    for (int mi = 0; mi < TM; ++mi) {
-        const int m = m0 + wm * WM + mi * 16 + fr;
-        if (m >= p.M) continue;
-#pragma unroll
-        for (int ni = 0; ni < TN; ++ni) {
-            const int n = n0 + wn * WN + ni * 16 + fg * 4;
-            if (n >= p.N) continue;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float x = acc[ni][mi][r];
-                if (bias && n + r < p.N) x += bf2f(bias[n + r]);
-                v[r] = apply_act(x, p.act);
-            }
-            if (n + 3 < p.N && vec_ok) {
-                if (R) {
-                    u32x2 rr = *reinterpret_cast<const u32x2*>(R + (long)m * p.ldr + n);
-                    v[0] += p.res_scale * lo_bf(rr.x); v[1] += p.res_scale * hi_bf(rr.x);
-                    v[2] += p.res_scale * lo_bf(rr.y); v[3] += p.res_scale * hi_bf(rr.y);
-                }
-                if (p.c_fp32) {
-                    float* C = reinterpret_cast<float*>(p.C) + coff + (long)m * p.ldc + n;
-                    *reinterpret_cast<float4*>(C) = make_float4(v[0], v[1], v[2], v[3]);
-                } else {
-                    bf16_t* C = reinterpret_cast<bf16_t*>(p.C) + coff + (long)m * p.ldc + n;
-                    u32x2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
-                    *reinterpret_cast<u32x2*>(C) = o;
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (n + r >= p.N) break;
-                    float x = v[r];
-                    if (R) x += p.res_scale * bf2f(R[(long)m * p.ldr + n + r]);
-                    if (p.c_fp32) reinterpret_cast<float*>(p.C)[coff + (long)m * p.ldc + n + r] = x;
-                    else reinterpret_cast<bf16_t*>(p.C)[coff + (long)m * p.ldc + n + r] = f2bf(x);
-                }
-            }
-        }
-    }
+    // output stage shared with gemm_bt_kernel (gemm_epilogue.h): unguarded + activation-specialised on interior sub-tiles
+    gemm_epilogue<TM, TN>(acc, p.act, m0 + wm * WM, n0 + wn * WN, fr, fg, p.M, p.N, p.bias ? p.bias + z0 * p.sBias0 + z1 * p.sBias1 : nullptr,
+                          p.R ? p.R + z0 * p.sR0 + z1 * p.sR1 : nullptr, p.ldr, p.res_scale, p.C, z0 * p.sC0 + z1 * p.sC1, p.ldc, p.c_fp32);
 }
 
 }  // namespace
@@ -472,10 +345,12 @@ int crab_gemm_glds_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* d,
     if (batch == 1) { p.sA0 = p.sA1 = p.sB0 = p.sB1 = p.sC0 = p.sC1 = p.sR0 = p.sR1 = p.sBias0 = p.sBias1 = 0; }
     // 256x256 ring kernel when the problem fills the chip with big tiles; 128x128 two-stage kernel otherwise
     const long big = (long)((d->M + 255) / 256) * ((d->N + 255) / 256) * batch;
-    // measured (profiles/README.md): the ring kernel wins once the grid is >= ~6 full waves of 256 blocks (gate|up
-    // projection, square 4k), the 128x128 kernel wins on the narrower projections where big tiles leave a partial wave
-    // (short K: the one-block-per-CU ring kernel cannot hide its ~20k-cycle prologue + epilogue behind another block)
-    bool use_big = big >= 1536 && d->M >= 1024 && d->N >= 1024 && d->K >= 2048 && p.splitk == 1;
+    // measured (profiles/README.md): the one-block-per-CU ring kernel wins when (a) its grid fills whole rounds of 256
+    // blocks (a 1.1-round grid costs 2 rounds: M = 5616 x N = 4096 is 352 tiles = 69 % of 2 rounds and loses to the
+    // 128x128 kernel, M = 11232 is 704 tiles = 92 % of 3 rounds and wins by 18 %), and (b) K is long enough to amortise
+    // its ~20k-cycle prologue + epilogue, which no second resident block hides
+    const long rounds = (big + 255) / 256;
+    bool use_big = big >= 230 && big * 100 >= rounds * 256 * 85 && d->M >= 1024 && d->N >= 1024 && d->K >= 2048 && p.splitk == 1;
     if (d->tune == 301) use_big = false;
     if (d->tune == 302) use_big = true;
     if (use_big) {

@@ -164,7 +164,13 @@ class GenerationEngine:
             self._rope = ops.rope_table(n, self.cfg.head_dim, self.cfg.rope_theta, self.device)
         return self._rope
 
-    def _workspace(self, M: int) -> _Workspace:
+    def _workspace(self, M: int, slot: int = 0) -> _Workspace:
+        """Activation buffers for M rows; `slot` separates the groups that decode concurrently on different streams."""
+        if slot:
+            key = (M, slot)
+            if key not in self._ws:
+                self._ws[key] = _Workspace(self.cfg, M, self.device, self._ws_cols()[0], self._ws_cols()[1])
+            return self._ws[key]
         if M not in self._ws:
             tc = uc = 0
             for g in self.model.layers[0].groups():
@@ -172,6 +178,13 @@ class GenerationEngine:
                     tc, uc = max(tc, g.t_cols), max(uc, g.u_cols)
             self._ws[M] = _Workspace(self.cfg, M, self.device, tc, uc)
         return self._ws[M]
+
+    def _ws_cols(self):
+        tc = uc = 0
+        for g in self.model.layers[0].groups():
+            if g.RA is not None:
+                tc, uc = max(tc, g.t_cols), max(uc, g.u_cols)
+        return tc, uc
 
     def alloc_cache(self, B: int, Tmax: int):
         c = self.cfg
@@ -254,21 +267,17 @@ class GenerationEngine:
         ops.greedy_select(st.logits, st.cur_ids, st.out_ids, st.step_dev, st.finished, st.eos, st.pad, st.min_new)
         ops.advance(st.pos_dev, st.step_dev)
 
-    @torch.no_grad()
-    def generate(self, embeds: torch.Tensor, max_new_tokens: int, eos_token_id: Optional[int] = None,
-                 pad_token_id: Optional[int] = None, min_new_tokens: int = 0, prefill_chunk: int = 8, use_graph: bool = True,
-                 return_step_logits: bool = False, return_hidden: bool = False):
-        """Greedy generation from inputs_embeds only, as UnifiedForCausalLM.generate drives HF generate
-        (unified_llama.py:262-267): positions 0..S-1 (left pads attended), returns ONLY new ids."""
-        c = self.cfg
+    def _start(self, embeds: torch.Tensor, max_new_tokens: int, eos_token_id, pad_token_id, min_new_tokens: int, prefill_chunk: int,
+               return_hidden: bool, slot: int, sink=None) -> "_DecodeState":
+        """Allocate the decode state of one group of sequences, prefill it and select its first token."""
         B, S, D = embeds.shape
         dev = self.device
         Tmax = _round_up(S + max_new_tokens, 64)
         kc, vc = self.alloc_cache(B, Tmax)
         V = self.lm_head.weight.shape[0]
         st = _DecodeState()
-        st.B, st.Tmax, st.kc, st.vc = B, Tmax, kc, vc
-        st.ws = self._workspace(B)
+        st.B, st.S, st.Tmax, st.kc, st.vc, st.slot = B, S, Tmax, kc, vc, slot
+        st.ws = self._workspace(B, slot)
         st.logits = torch.empty((B, V), device=dev, dtype=torch.float32)
         st.hn = torch.empty((B, D), device=dev, dtype=BF16)
         st.cur_ids = torch.zeros((B,), device=dev, dtype=torch.int64)
@@ -280,49 +289,94 @@ class GenerationEngine:
         st.pad = int(pad_token_id) if pad_token_id is not None else (st.eos if st.eos >= 0 else 0)
         st.min_new = int(min_new_tokens)
         st.want_hidden = bool(return_hidden)
-        step_logits, hiddens = [], []
         # ---- prefill in chunks of sequences (bounds activation memory, keeps GEMM M in the MFMA-efficient range)
         for b0 in range(0, B, prefill_chunk):
             b1 = min(B, b0 + prefill_chunk)
             self.prefill(embeds[b0:b1], kc, vc, b0=b0, logits_out=st.logits[b0:b1], hn_out=st.hn[b0:b1])
-        if return_step_logits:
-            step_logits.append(st.logits.clone())
-        if return_hidden:
-            hiddens.append(st.hn.clone())
+        if sink is not None:
+            sink(st)
         ops.greedy_select(st.logits, st.cur_ids, st.out_ids, st.step_dev, st.finished, st.eos, st.pad, st.min_new)
         ops.advance(st.pos_dev, st.step_dev)           # pos: S-1 -> S (position of the token just selected), step: 0 -> 1
-        # ---- decode loop: HIP graph replay, no host sync inside
-        graph = None
-        if use_graph and max_new_tokens > 2:
-            graph = self._capture(st)
-        check_every = 16
-        for step in range(1, max_new_tokens):
-            prof = ops.PROFILER
-            if graph is not None and prof is not None and prof.decode_every and step % prof.decode_every == prof.decode_every // 2:
-                # roofline sampling (bench.py): this step runs the same launches eagerly with HIP events around the
-                # decode-attention kernel; state is device-resident, so graph replays continue seamlessly after it
-                prof.decode_eager, prof.decode_ctx = True, S + step
-                self._decode_step(st)
-                prof.decode_eager = False
-            elif graph is not None:
-                graph.replay()
-            else:
-                self._decode_step(st)
+        return st
+
+    @torch.no_grad()
+    def generate(self, embeds: torch.Tensor, max_new_tokens: int, eos_token_id: Optional[int] = None,
+                 pad_token_id: Optional[int] = None, min_new_tokens: int = 0, prefill_chunk: int = 8, use_graph: bool = True,
+                 return_step_logits: bool = False, return_hidden: bool = False, decode_streams: int = 1):
+        """Greedy generation from inputs_embeds only, as UnifiedForCausalLM.generate drives HF generate
+        (unified_llama.py:262-267): positions 0..S-1 (left pads attended), returns ONLY new ids.
+
+        decode_streams > 1 splits the batch into that many groups whose decode steps (one HIP graph each) replay on
+        separate HIP streams: the HBM-bound KV-cache attention of one group overlaps the MFMA-bound projections of
+        another.  Rows never interact, so the split only changes which M the projection kernels see."""
+        B, S, D = embeds.shape
+        graphed = use_graph and max_new_tokens > 2
+        G = decode_streams if (decode_streams > 1 and graphed and B >= decode_streams and
+                               not return_step_logits and not return_hidden) else 1
+        step_logits, hiddens = [], []
+
+        def sink(st):
             if return_step_logits:
                 step_logits.append(st.logits.clone())
             if return_hidden:
                 hiddens.append(st.hn.clone())
-            if st.eos >= 0 and step % check_every == 0 and bool(st.finished.all().item()):
-                break
-        n_done = int(st.step_dev.item())
-        out = st.out_ids[:, :n_done]
-        if st.eos >= 0:
+
+        main = torch.cuda.current_stream()
+        sts, graphs, streams = [], [], []
+        for g in range(G):
+            b0, b1 = B * g // G, B * (g + 1) // G
+            ops.WS_SLOT = g
+            sts.append(self._start(embeds[b0:b1], max_new_tokens, eos_token_id, pad_token_id, min_new_tokens, prefill_chunk,
+                                   return_hidden, g, sink))
+        # ---- decode loop: HIP graph replay, no host sync inside
+        for g, st in enumerate(sts):
+            ops.WS_SLOT = g
+            graphs.append(self._capture(st) if graphed else None)
+            streams.append(torch.cuda.Stream() if G > 1 else main)
+        ops.WS_SLOT = 0
+        if G > 1:
+            for sg in streams:
+                sg.wait_stream(main)
+        eos_on = sts[0].eos >= 0
+        check_every = 16
+        for step in range(1, max_new_tokens):
+            prof = ops.PROFILER
+            sample = graphed and prof is not None and prof.decode_every and step % prof.decode_every == prof.decode_every // 2
+            for g, st in enumerate(sts):
+                with torch.cuda.stream(streams[g]):
+                    if sample and g == 0:
+                        # roofline sampling (bench.py): this step runs the same launches eagerly with HIP events around the
+                        # decode-attention kernel; state is device-resident, so graph replays continue seamlessly after it
+                        ops.WS_SLOT = g
+                        prof.decode_eager, prof.decode_ctx = True, S + step
+                        self._decode_step(st)
+                        prof.decode_eager = False
+                        ops.WS_SLOT = 0
+                    elif graphs[g] is not None:
+                        graphs[g].replay()
+                    else:
+                        self._decode_step(st)
+            sink(sts[0])
+            if eos_on and step % check_every == 0:
+                done = True
+                for g, st in enumerate(sts):
+                    with torch.cuda.stream(streams[g]):
+                        done = done and bool(st.finished.all().item())
+                if done:
+                    break
+        if G > 1:
+            for sg in streams:
+                main.wait_stream(sg)
+        n_done = int(sts[0].step_dev.item())
+        out_ids = sts[0].out_ids if G == 1 else torch.cat([st.out_ids for st in sts], 0)
+        out = out_ids[:, :n_done]
+        if eos_on:
             # HF stops as soon as every row has finished: trim trailing all-pad columns produced between checks
-            fin_cols = (st.out_ids[:, :n_done] == st.eos).int().cumsum(1) > 0
+            fin_cols = (out_ids[:, :n_done] == sts[0].eos).int().cumsum(1) > 0
             all_fin = fin_cols.all(0)
             idx = torch.nonzero(all_fin)
             if idx.numel():
-                out = st.out_ids[:, : int(idx[0].item()) + 1]
+                out = out_ids[:, : int(idx[0].item()) + 1]
         res = [out]
         if return_step_logits:
             res.append(torch.stack(step_logits, 1)[:, : out.shape[1]])

@@ -73,15 +73,19 @@ def _variant(M: int, N: int, batch: int = 1, K: int = 4096) -> str:
     if M <= 64 or N <= 64 or big < 192:
         return "gemm_bt_kernel<64,64>"
     big256 = ((M + 255) // 256) * ((N + 255) // 256) * batch
-    return "gemm_bt_ring_kernel<256,256>" if (big256 >= 1536 and M >= 1024 and N >= 1024 and K >= 2048) else "gemm_bt_glds_kernel<128,128>"
+    rounds = (big256 + 255) // 256
+    ring = big256 >= 230 and big256 * 100 >= rounds * 256 * 85 and M >= 1024 and N >= 1024 and K >= 2048
+    return "gemm_bt_ring_kernel<256,256>" if ring else "gemm_bt_glds_kernel<128,128>"
 
 
 _SPLITK_WS = {}
+WS_SLOT = 0      # scratch slot of the launches being issued/captured: groups decoding concurrently on different HIP streams
+                 # (GenerationEngine.generate, decode_streams > 1) must not share the split-K partial slabs
 
 
 def _splitk_workspace(device) -> torch.Tensor:
     """One caller-owned split-K scratch per device (stable address: safe under HIP-graph capture)."""
-    key = device.index or 0
+    key = (device.index or 0, WS_SLOT)
     if key not in _SPLITK_WS:
         _SPLITK_WS[key] = torch.empty((256 << 20,), device=device, dtype=torch.uint8)
     return _SPLITK_WS[key]

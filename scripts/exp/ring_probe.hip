@@ -28,6 +28,7 @@ struct GemmGP {
     int splitk;
     float* part;
     long long* dbg;
+    int mode;
 };
 
 __device__ __attribute__((aligned(16))) uint32_t g_zero_page[64];      // zero-initialised device memory (256 B)
@@ -404,7 +405,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bt_ring_kernel(GemmGP p) 
                         *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + rowC + ni * 16) = make_float4(v0, v1, v2, v3);
                     } else {
                         u32x2 o; o.x = pack_bf2(v0, v1); o.y = pack_bf2(v2, v3);
-                        *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.C) + rowC + ni * 16) = o;
+                        if (p.mode == 0 || v0 == 1.2345e30f) *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.C) + rowC + ni * 16) = o;
                     }
                 }
             }
@@ -465,7 +466,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bt_ring_kernel(GemmGP p) 
 // called from crab_gemm_bf16 (gemm.hip) for the 128x128 tile regime
 extern "C" int probe_launch(hipStream_t s, const crab_gemm_desc* d, long long* dbg) {
     crab_ctx* ctx = nullptr; int splitk = 1; float* part = nullptr;
-    GemmGP p; p.dbg = dbg;
+    GemmGP p; p.dbg = dbg; p.mode = d->tune == 399;
     p.splitk = splitk > 1 ? splitk : 1; p.part = part;
     p.A = (const bf16_t*)d->A; p.B = (const bf16_t*)d->B; p.C = d->C; p.bias = (const bf16_t*)d->bias; p.R = (const bf16_t*)d->R;
     p.A2 = (const bf16_t*)d->A2; p.B2 = (const bf16_t*)d->B2;
@@ -482,7 +483,7 @@ extern "C" int probe_launch(hipStream_t s, const crab_gemm_desc* d, long long* d
     // projection, square 4k), the 128x128 kernel wins on the narrower projections where big tiles leave a partial wave
     bool use_big = big >= 1536 && d->M >= 1024 && d->N >= 1024 && p.splitk == 1;
     if (d->tune == 301) use_big = false;
-    if (d->tune == 302) use_big = true;
+    if (d->tune == 302 || d->tune == 399) use_big = true;
     if (use_big) {
         p.tiles_m = (d->M + 255) / 256; p.tiles_n = (d->N + 255) / 256;
         dim3 grid(p.tiles_m * p.tiles_n, batch);

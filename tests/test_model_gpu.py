@@ -191,6 +191,11 @@ def test_eos_and_min_new_tokens_semantics():
     assert ids.shape == exp.shape and torch.equal(ids, exp), (ids.tolist(), exp.tolist())
     ids2 = model.generate(inputs_embeds=emb, max_new_tokens=12, eos_token_id=eos, pad_token_id=2, min_new_tokens=12)
     assert ids2.shape[1] == 12 and not (ids2 == eos).any()
+    # decode groups on separate HIP streams (one graph each): rows never interact, same ids and same EOS trimming
+    ids3 = model.generate(inputs_embeds=emb, max_new_tokens=12, eos_token_id=eos, pad_token_id=2, decode_streams=2).cpu()
+    assert ids3.shape == exp.shape and torch.equal(ids3, exp), (ids3.tolist(), exp.tolist())
+    ids4 = model.generate(inputs_embeds=emb, max_new_tokens=12, eos_token_id=eos, pad_token_id=2, min_new_tokens=12, decode_streams=2)
+    assert torch.equal(ids4, ids2)
 
 
 def test_seg_module_vs_reference_fixture_and_oracle():
