@@ -37,6 +37,10 @@ sys.path.insert(0, ROOT)
 
 MFMA_PEAK_TFLOPS = 2500.0        # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
+# HBM bytes per algorithmic byte of attn_decode_kernel, from a separate `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` pass at
+# the benchmark shape (profiles/r01_pmc_attn_decode.txt, scripts/pmc_attn.sh): FETCH_SIZE 1.7009e6 KiB x 2 (the guide's
+# gfx950 correction for wide coalesced reads) + WRITE_SIZE 2048 KiB = 3.4856 GB against 3.4850 GB algorithmic
+ATTN_DECODE_TRAFFIC_PER_ALGO_BYTE = 1.0002
 
 
 def flops_per_clip(T_v=8, T_a=10, n_a=48, S=702, V=32017):
@@ -206,7 +210,10 @@ def main():
                 total_launches = args.steps * (args.new_tokens - 1) * n_layers
                 ach = d["work"] / (d["ms"] * 1e-3) / 1e9
                 e = {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None}
+                     "frac": round(ach / HBM_PEAK_GBS, 4),
+                     "traffic": round(d["work"] / d["launches"] * ATTN_DECODE_TRAFFIC_PER_ALGO_BYTE),
+                     "algorithmic_bytes_per_launch": round(d["work"] / d["launches"]),
+                     "traffic_source": "PMC ratio from profiles/r01_pmc_attn_decode.txt (separate --pmc pass) x this run's bytes"}
             else:
                 total_launches = d["launches"]
                 ach = d["work"] / (d["ms"] * 1e-3) / 1e12
