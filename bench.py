@@ -230,7 +230,8 @@ def main():
             "value": round(n_clips / dt, 4), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic (seeded N(0,0.02) weights, synthetic 8x224x224 frames, 10x98x128 fbank, 128-token prompt)",
-            "config": {"workload": "AVQA eval, Llama-2-7B + BEATs + CLIP-ViT-L/14, bf16 (BASELINE configs[1])", "clips_per_gpu_per_step": B,
+            "config": {"workload": ("AVQA eval, Llama-2-7B + BEATs + CLIP-ViT-L/14, bf16 (BASELINE configs[1])" if args.llm == "llama" else
+                                     "AVQA eval, Qwen2-7B + BEATs + CLIP-ViT-L/14, bf16 (BASELINE configs[3] decoder variant)"), "clips_per_gpu_per_step": B,
                        "frames": args.frames, "audio_segments": 10, "prompt_tokens": 128, "prefill_len": S, "new_tokens": args.new_tokens,
                        "decode": "greedy, EOS suppressed, device-resident HIP-graph loop", "parallelism": f"per-clip x{world}, RCCL gather"},
             "prefill_tflop_per_clip": round(flops_per_clip(args.frames, 10, 48, S, V) / 1e12, 3),

@@ -265,6 +265,151 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------- decode, grouped-query
+// One block per (b, kv head): every K and V row is read ONCE for the G query heads that share it (the per-(b,h) kernel
+// above re-reads it G times; Qwen2-7B: G = 7).  Keys are processed in chunks of GQ_CH:
+//   A. each 16-lane group takes a key row (16 B per lane), forms the G partial dots and reduces them with an 8-shuffle
+//      transpose-butterfly (8 values x 16 lanes -> lane pair (2g, 2g+1) holds head g's score) -> scores[key][8] in LDS
+//   B. per head: chunk max, running max / rescale factor, p = exp(s - m) in place, running sum (once per chunk)
+//   C. each 16-lane group takes a V row, reads its 8 probabilities (two broadcast float4 LDS reads) and accumulates
+//      acc[g][8 dims] += p[g] * v: no per-key exponentials or rescales
+// and the 16 groups are merged through LDS at the end.
+constexpr int GQ_CH = 1024;
+
+template <int HD, int G>
+__global__ __launch_bounds__(256) void attn_decode_gqa_kernel(const bf16_t* __restrict__ q, long ldq, const bf16_t* __restrict__ kc,
+                                                              const bf16_t* __restrict__ vc, bf16_t* __restrict__ o, long ldo, int Hk,
+                                                              int Tmax, int ctx_host, const int* __restrict__ ctx_dev, float scale) {
+    static_assert(HD == 128 && G >= 2 && G <= 8, "grouped decode: head_dim 128, 2..8 query heads per kv head");
+    constexpr int EPL = 8;
+    // scores [GQ_CH][8] fp32 (32 KB) during the chunks, reused as the merge buffer [16][G][HD] fp32 at the end
+    constexpr int SMEM_F = (16 * G * HD > GQ_CH * 8) ? 16 * G * HD : GQ_CH * 8;
+    __shared__ __attribute__((aligned(16))) float sbuf[SMEM_F];
+    __shared__ float red[4][8];
+    __shared__ float m_run[8], l_run[8], alpha_s[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = tid >> 4, sub = tid & 15;
+    const int b = blockIdx.y, hk = blockIdx.x;
+    const int ctx = ctx_host + (ctx_dev ? ctx_dev[0] : 0);
+    float qv[G][EPL];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const u32x4 w = *reinterpret_cast<const u32x4*>(q + (long)b * ldq + (long)(hk * G + g) * HD + sub * EPL);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { qv[g][2 * e] = lo_bf(w[e]) * scale; qv[g][2 * e + 1] = hi_bf(w[e]) * scale; }
+    }
+    const bf16_t* kb = kc + ((long)b * Hk + hk) * (long)Tmax * HD + sub * EPL;
+    const bf16_t* vb = vc + ((long)b * Hk + hk) * (long)Tmax * HD + sub * EPL;
+    float acc[G][EPL];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) acc[g][e] = 0.f;
+    if (tid < 8) { m_run[tid] = -1e30f; l_run[tid] = 0.f; }
+    const bool up8 = sub & 8, up4 = sub & 4, up2 = sub & 2;
+
+    for (int c0 = 0; c0 < ctx; c0 += GQ_CH) {
+        const int cn = min(GQ_CH, ctx - c0);
+        __syncthreads();                                  // previous chunk's probabilities consumed, m_run/l_run visible
+        // ---- A: scores
+        for (int j = grp; j < cn; j += 16) {
+            const u32x4 kw = *reinterpret_cast<const u32x4*>(kb + (long)(c0 + j) * HD);
+            float kx[EPL];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { kx[2 * e] = lo_bf(kw[e]); kx[2 * e + 1] = hi_bf(kw[e]); }
+            float v8[8];
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                float d = 0.f;
+                if (g < G) {
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) d += qv[g < G ? g : 0][e] * kx[e];
+                }
+                v8[g] = d;
+            }
+            float w4[4], x2[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float keep = up8 ? v8[4 + i] : v8[i], send = up8 ? v8[i] : v8[4 + i];
+                w4[i] = keep + __shfl_xor(send, 8, 64);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float keep = up4 ? w4[2 + i] : w4[i], send = up4 ? w4[i] : w4[2 + i];
+                x2[i] = keep + __shfl_xor(send, 4, 64);
+            }
+            float y = (up2 ? x2[1] : x2[0]) + __shfl_xor(up2 ? x2[0] : x2[1], 2, 64);
+            y += __shfl_xor(y, 1, 64);
+            if ((sub & 1) == 0) sbuf[j * 8 + (sub >> 1)] = y;            // head g = sub >> 1 (columns >= G hold zeros)
+        }
+        __syncthreads();
+        // ---- B: per-head chunk max -> running max, p = exp(s - m) in place, running sum
+        {
+            const int g = tid & 7;
+            float mx = -1e30f;
+            for (int j = tid >> 3; j < cn; j += 32) mx = fmaxf(mx, sbuf[j * 8 + g]);
+            mx = fmaxf(mx, __shfl_xor(mx, 8, 64)); mx = fmaxf(mx, __shfl_xor(mx, 16, 64)); mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            if (lane < 8) red[wave][lane] = mx;
+            __syncthreads();
+            const float m_old = m_run[g];
+            const float m_new = fmaxf(fmaxf(fmaxf(red[0][g], red[1][g]), fmaxf(red[2][g], red[3][g])), m_old);
+            float sum = 0.f;
+            for (int j = tid >> 3; j < cn; j += 32) {
+                const float pv = __expf(sbuf[j * 8 + g] - m_new);
+                sbuf[j * 8 + g] = pv;
+                sum += pv;
+            }
+            sum += __shfl_xor(sum, 8, 64); sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);
+            __syncthreads();                                             // red[] max values consumed
+            if (lane < 8) red[wave][lane] = sum;
+            __syncthreads();
+            if (tid < 8) {
+                const float a = __expf(m_old - m_new);
+                alpha_s[tid] = a;
+                l_run[tid] = l_run[tid] * a + red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+                m_run[tid] = m_new;
+            }
+            __syncthreads();
+        }
+        // ---- C: rescale (once per chunk) and accumulate P.V
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const float a = alpha_s[g];
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) acc[g][e] *= a;
+        }
+        for (int j = grp; j < cn; j += 16) {
+            const u32x4 vw = *reinterpret_cast<const u32x4*>(vb + (long)(c0 + j) * HD);
+            const f32x4_t p0 = *reinterpret_cast<const f32x4_t*>(sbuf + j * 8);
+            const f32x4_t p1 = *reinterpret_cast<const f32x4_t*>(sbuf + j * 8 + 4);
+            float vx[EPL];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { vx[2 * e] = lo_bf(vw[e]); vx[2 * e + 1] = hi_bf(vw[e]); }
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const float pg = g < 4 ? p0[g & 3] : p1[g & 3];
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) acc[g][e] += pg * vx[e];
+            }
+        }
+    }
+    __syncthreads();
+    // ---- merge the 16 key groups (all share the running max): plain sums, then normalise
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) sbuf[(grp * G + g) * HD + sub * EPL + e] = acc[g][e];
+    __syncthreads();
+    for (int idx = tid; idx < G * HD; idx += 256) {
+        float O = 0.f;
+#pragma unroll
+        for (int gr = 0; gr < 16; ++gr) O += sbuf[gr * G * HD + idx];
+        const int g = idx / HD;
+        o[(long)b * ldo + (long)(hk * G) * HD + idx] = f2bf(O / l_run[g]);
+    }
+}
+
 }  // namespace
 
 extern "C" int crab_attn_fwd(crab_ctx* ctx, void* stream, const crab_attn_desc* d) {
@@ -314,6 +459,17 @@ extern "C" int crab_attn_decode(crab_ctx* ctx, void* stream, const void* q, int6
     if (!ctx_dev && (ctx_len_host <= 0 || ctx_len_host > Tmax)) return crab_fail(ctx, CRAB_E_INVALID, "attn_decode: ctx_len out of range");
     dim3 grid(H, B), block(256);
     hipStream_t s = (hipStream_t)stream;
+    // grouped-query heads: read each K/V row once per kv head when there are enough (b, kv head) blocks to fill the chip
+    const int G = H / Hk;
+    if (d == 128 && (G == 2 || G == 4 || G == 7 || G == 8) && (long)B * Hk >= 256 && (ldq & 7) == 0 && ((uintptr_t)q & 15) == 0) {
+        dim3 gg(Hk, B);
+#define CRAB_GQA(G_)                                                                                                             \
+    hipLaunchKernelGGL((attn_decode_gqa_kernel<128, G_>), gg, block, 0, s, (const bf16_t*)q, (long)ldq, (const bf16_t*)k_cache,   \
+                       (const bf16_t*)v_cache, (bf16_t*)o, (long)ldo, Hk, Tmax, ctx_len_host, ctx_dev, scale)
+        if (G == 2) CRAB_GQA(2); else if (G == 4) CRAB_GQA(4); else if (G == 7) CRAB_GQA(7); else CRAB_GQA(8);
+#undef CRAB_GQA
+        return crab_check_launch(ctx, "attn_decode_gqa");
+    }
     if (d == 128)
         hipLaunchKernelGGL((attn_decode_kernel<128>), grid, block, 0, s, (const bf16_t*)q, (long)ldq, (const bf16_t*)k_cache,
                            (const bf16_t*)v_cache, (bf16_t*)o, (long)ldo, H, Hk, Tmax, ctx_len_host, ctx_dev, scale);

@@ -301,7 +301,7 @@ class GenerationEngine:
 
     @torch.no_grad()
     def generate(self, embeds: torch.Tensor, max_new_tokens: int, eos_token_id: Optional[int] = None,
-                 pad_token_id: Optional[int] = None, min_new_tokens: int = 0, prefill_chunk: int = 8, use_graph: bool = True,
+                 pad_token_id: Optional[int] = None, min_new_tokens: int = 0, prefill_chunk: int = 16, use_graph: bool = True,
                  return_step_logits: bool = False, return_hidden: bool = False, decode_streams: int = 1):
         """Greedy generation from inputs_embeds only, as UnifiedForCausalLM.generate drives HF generate
         (unified_llama.py:262-267): positions 0..S-1 (left pads attended), returns ONLY new ids.

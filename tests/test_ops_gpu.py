@@ -241,6 +241,28 @@ def test_rope_split_and_decode_attention(hd, H, Hk):
     _cmp(o, ref, 1.5e-2, "decode attention")
 
 
+@pytest.mark.parametrize("G,ctx", [(7, 830), (7, 1100), (4, 333), (2, 64), (8, 1025)])
+def test_decode_attention_grouped_query(G, ctx):
+    """GQA decode kernel (one block per (b, kv head), K/V rows read once for the G query heads) vs fp32 arithmetic and vs
+    the per-(b,h) kernel it replaces (taken when B*Hk < 256)."""
+    from crab_amd import ops
+    hd, Hk, B, Tmax = 128, 4, 64, 1152
+    H = G * Hk
+    g = torch.Generator().manual_seed(100 + G)
+    kc = (torch.randn(B, Hk, Tmax, hd, generator=g) * 0.7).to(BF).cuda()
+    vc = (torch.randn(B, Hk, Tmax, hd, generator=g) * 0.7).to(BF).cuda()
+    q = (torch.randn(B, H * hd, generator=g) * 1.5).to(BF).cuda()
+    pos = torch.tensor([ctx - 1], dtype=torch.int32, device="cuda")
+    o = torch.zeros(B, H * hd, dtype=BF, device="cuda")
+    ops.attn_decode(q, kc, vc, o, B, H, Hk, hd, Tmax, 1, hd ** -0.5, ctx_dev=pos)          # B*Hk = 256 -> grouped kernel
+    qn = q.cpu().view(B, 1, H, hd).transpose(1, 2)
+    ref = _attn_ref(qn, kc[:, :, :ctx].cpu(), vc[:, :, :ctx].cpu(), hd ** -0.5).transpose(1, 2).reshape(B, H * hd)
+    _cmp(o, ref, 1.5e-2, "grouped decode attention")
+    o2 = torch.zeros(3, H * hd, dtype=BF, device="cuda")
+    ops.attn_decode(q[:3].contiguous(), kc[:3].contiguous(), vc[:3].contiguous(), o2, 3, H, Hk, hd, Tmax, ctx, hd ** -0.5)   # per-head kernel
+    _cmp(o[:3], o2.float().cpu(), 1e-2, "grouped vs per-head decode kernel")
+
+
 def test_im2col_and_clip_embed():
     from crab_amd import ops
     x = torch.randn(2, 3, 28, 42)
