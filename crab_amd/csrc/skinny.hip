@@ -247,14 +247,21 @@ int crab_gemm_skinny_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* 
     return crab_check_launch(ctx, "gemm_skinny_kernel");
 }
 
-extern "C" int64_t crab_hyperlora_route_workspace(int M, int K, int tcols) {
+// K slices of the router product: enough (slice, 64-row block) pairs for ~4 blocks per CU.  Decode (M <= 256) is capped
+// by the 16-slab limit; prefill (M = 11232: 176 row blocks) gets 6 slices - with a single slice its 176 four-wave blocks
+// ran one dependent load->MFMA chain per wave over the whole K (111 us per launch, 5 % of the prefill phase).
+static int route_slices(int M, int K) {
     int mblocks = (M + 63) / 64;
-    int nslices = 256 / (mblocks > 0 ? mblocks : 1);
+    int nslices = (1024 + mblocks - 1) / (mblocks > 0 ? mblocks : 1);
     int maxs = (K + 127) / 128;
     if (nslices > maxs) nslices = maxs;
     if (nslices < 1) nslices = 1;
     if (nslices > 16) nslices = 16;
-    return (int64_t)nslices * M * tcols * (int64_t)sizeof(float);
+    return nslices;
+}
+
+extern "C" int64_t crab_hyperlora_route_workspace(int M, int K, int tcols) {
+    return (int64_t)route_slices(M, K) * M * tcols * (int64_t)sizeof(float);
 }
 
 extern "C" int crab_hyperlora_route(crab_ctx* ctx, void* stream, const void* X, int64_t ldx, const void* RA, int64_t ldra, int M, int K,
@@ -267,11 +274,7 @@ extern "C" int crab_hyperlora_route(crab_ctx* ctx, void* stream, const void* X, 
     const int tcols = ((nproj * (nl + r) + 15) / 16) * 16;        // RA must hold tcols rows (zero padded)
     if (crab_hyperlora_route_workspace(M, K, tcols) > workspace_bytes) return crab_fail(ctx, CRAB_E_WORKSPACE, "hyperlora_route: workspace too small");
     int mblocks = (M + 63) / 64;
-    int nslices = 256 / mblocks;
-    int maxs = (K + 127) / 128;
-    if (nslices > maxs) nslices = maxs;
-    if (nslices < 1) nslices = 1;
-    if (nslices > 16) nslices = 16;
+    int nslices = route_slices(M, K);
     int kslice = (((K + nslices - 1) / nslices) + 31) / 32 * 32;
     nslices = (K + kslice - 1) / kslice;
     hipStream_t s = (hipStream_t)stream;

@@ -328,6 +328,8 @@ class GenerationEngine:
             ops.WS_SLOT = g
             sts.append(self._start(embeds[b0:b1], max_new_tokens, eos_token_id, pad_token_id, min_new_tokens, prefill_chunk,
                                    return_hidden, g, sink))
+        if ops.PROFILER is not None:
+            ops.PROFILER.mark("prefill_end")
         # ---- decode loop: HIP graph replay, no host sync inside
         for g, st in enumerate(sts):
             ops.WS_SLOT = g
@@ -367,6 +369,8 @@ class GenerationEngine:
         if G > 1:
             for sg in streams:
                 main.wait_stream(sg)
+        if ops.PROFILER is not None:
+            ops.PROFILER.mark("decode_end")
         n_done = int(sts[0].step_dev.item())
         out_ids = sts[0].out_ids if G == 1 else torch.cat([st.out_ids for st in sts], 0)
         out = out_ids[:, :n_done]

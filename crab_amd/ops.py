@@ -49,7 +49,27 @@ class KernelProfiler:
         self.decode_every = decode_every
         self.decode_ctx = 0          # live KV length of the sampled step (host mirror of the device position word)
         self.decode_eager = False    # set by GenerationEngine.generate around a sampled eager decode step
+        self.marks = []              # (phase name, event)
         self.records = []            # (variant, work, start_event, end_event); work = FLOPs ("gemm*") or bytes ("attn_decode*")
+
+    def mark(self, name: str):
+        """Phase boundary on the current stream (encode_begin / prefill_end / decode_end of one generate call)."""
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        self.marks.append((name, e))
+
+    def phase_ms(self):
+        """Sum over generate calls of (encoders + prefill) and decode time, from the phase marks."""
+        torch.cuda.synchronize()
+        pre = dec = 0.0
+        last = {}
+        for name, e in self.marks:
+            if name == "prefill_end" and "encode_begin" in last:
+                pre += last["encode_begin"].elapsed_time(e)
+            if name == "decode_end" and "prefill_end" in last:
+                dec += last["prefill_end"].elapsed_time(e)
+            last[name] = e
+        return pre, dec
 
     def summary(self):
         torch.cuda.synchronize()
@@ -74,7 +94,7 @@ def _variant(M: int, N: int, batch: int = 1, K: int = 4096) -> str:
         return "gemm_bt_kernel<64,64>"
     big256 = ((M + 255) // 256) * ((N + 255) // 256) * batch
     rounds = (big256 + 255) // 256
-    ring = big256 >= 230 and big256 * 100 >= rounds * 256 * 85 and M >= 1024 and N >= 1024 and K >= 2048
+    ring = big256 >= 120 and big256 * 100 >= rounds * 256 * 55 and M >= 1024 and N >= 1024 and K >= 1024
     return "gemm_bt_ring_kernel<256,256>" if ring else "gemm_bt_glds_kernel<128,128>"
 
 

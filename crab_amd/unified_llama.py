@@ -155,6 +155,8 @@ class UnifiedForCausalLM(nn.Module, UnifiedMetaForCausalLM):
         if kwargs.get("do_sample"):
             raise NotImplementedError("sampling is not implemented: the MI355X path is greedy-only")
         embeds = kwargs.pop("inputs_embeds", None)
+        if ops.PROFILER is not None:
+            ops.PROFILER.mark("encode_begin")
         if embeds is None:
             inputs = self.prepare_multimodal_inputs(batch_input_ids=batch_input_ids, batch_labels=batch_labels,
                                                     batch_X_modals=batch_X_modals, return_multi_scale_features=False,
