@@ -85,6 +85,12 @@ SYMBOLS = {
     "crab_mask_gate": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _i64, _i, _i]),
     "crab_act_inplace": (_i, [_vp, _vp, _vp, _i64, _i]),
     "crab_group_mean": (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _i, _i, _i, _f]),
+    "crab_bicubic_ksize": (_i, [_i, _i]),
+    "crab_bicubic_coeffs": (_i, [_i, _i, _vp, _vp, _i]),
+    "crab_resample_u8": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _i]),
+    "crab_clip_normalize": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _f]),
+    "crab_kaldi_fbank_frames": (_i, [_i]),
+    "crab_kaldi_fbank": (_i, [_vp, _vp, _vp, _i64, _i, _i, _f, _f, _vp, _vp, _vp, _f, _f]),
 }
 
 _lib = None

@@ -15,6 +15,7 @@ import math
 import zlib
 from typing import Dict, Iterable, Sequence, Tuple
 
+import numpy as np
 import torch
 
 CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
@@ -128,3 +129,20 @@ def synth_prompt_ids(n_text: int, vocab: int, special: Dict[str, int], seed: int
     ids[v0:v0 + 3] = torch.tensor([special["<video_start>"], special["<video>"], special["<video_end>"]])
     ids[a0:a0 + 3] = torch.tensor([special["<audio_start>"], special["<audio>"], special["<audio_end>"]])
     return ids
+
+
+def synth_image(h: int, w: int, seed: int) -> np.ndarray:
+    """Deterministic uint8 test image with smooth structure + noise (so the bicubic taps matter); regenerated by the tests."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    base = np.stack([127 + 120 * np.sin(xx / 7.0 + c) * np.cos(yy / (5.0 + c)) for c in range(3)], -1)
+    return np.clip(base + rng.normal(0, 25, (h, w, 3)), 0, 255).astype(np.uint8)
+
+
+def synth_waveform(seconds: float, seed: int, sr: int = 16000) -> np.ndarray:
+    """Deterministic float32 waveform in [-1, 1]: a few drifting tones + noise (front-end tests / probes)."""
+    rng = np.random.default_rng(seed)
+    t = np.arange(int(seconds * sr), dtype=np.float64) / sr
+    x = sum(a * np.sin(2 * np.pi * (f + 40 * np.sin(0.7 * t + p)) * t + p)
+            for a, f, p in ((0.3, 220.0, 0.1), (0.2, 1333.0, 1.0), (0.1, 4100.0, 2.0)))
+    return np.clip(x + rng.normal(0, 0.05, t.shape), -1, 1).astype(np.float32)

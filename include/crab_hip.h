@@ -204,6 +204,31 @@ int crab_mask_gate(crab_ctx* ctx, void* stream, const void* prev, int64_t ldp, i
 int crab_group_mean(crab_ctx* ctx, void* stream, const void* in, int64_t ldi, void* out, int64_t ldo, int G, int T, int D, float scale);
 int crab_act_inplace(crab_ctx* ctx, void* stream, void* x, int64_t n, int act);
 
+/* ---------------------------------------------------------------------------------------------
+ * Input front-end: what the reference's dataset code does on the CPU right before generate().
+ *  crab_bicubic_ksize / crab_bicubic_coeffs (HOST arrays): Pillow 10.4 Resample.c precompute_coeffs + normalize_coeffs_8bpc
+ *      for BICUBIC over the whole image: bounds[out][2] = {first tap, tap count}, kk[out][ksize] 22-bit fixed-point taps.
+ *      Replaces the coefficient set-up inside `Image.resize` called by transformers' CLIPImageProcessor.resize
+ *      (dataset/quick_start_dataset.py:315 `self.video_processor.preprocess(frames, return_tensors='pt')`).
+ *  crab_resample_u8 : one separable 8-bit pass (ImagingResampleHorizontal_8bpc / Vertical_8bpc), uint8 [N,H,W,C] -> uint8
+ *      [N,H,out,C] (horizontal) or [N,out,W,C]; bounds / kk are DEVICE copies.  Bit-exact with Pillow.
+ *  crab_clip_normalize : centre crop + rescale + normalize + HWC->CHW: out[n,c,y,x] = (src[n,top+y,left+x,c]*rescale - mean[c]) / std[c],
+ *      fp32 or bf16 (image_processing_clip.py center_crop / rescale / normalize).  mean3 / std3 are HOST arrays.
+ *  crab_kaldi_fbank : torchaudio.compliance.kaldi.fbank as called by dataset/audio_processor.py:29-41 (25 ms / 10 ms frames
+ *      at 16 kHz, dither 0, DC removal, pre-emphasis, povey window, 512-point FFT, power, 128 mel bins 20..8000 Hz, log),
+ *      then (x - out_sub) * out_scale.  wave fp32 [n_wave][ldw], scaled by in_scale (2^15); window400 [400] and
+ *      mel_t [257][128] (transposed filterbank incl. the zero Nyquist row) are DEVICE fp32 arrays owned by the caller;
+ *      out fp32 [n_wave][frames][128], frames = crab_kaldi_fbank_frames(n_samples) = 1 + (n - 400) / 160. */
+int crab_bicubic_ksize(int in_size, int out_size);
+int crab_bicubic_coeffs(int in_size, int out_size, int32_t* bounds, int32_t* kk, int ksize);
+int crab_resample_u8(crab_ctx* ctx, void* stream, const void* src, int N, int H, int W, int C, void* dst, int out_size, int horizontal,
+                     const int32_t* bounds, const int32_t* kk, int ksize);
+int crab_clip_normalize(crab_ctx* ctx, void* stream, const void* src, int N, int H, int W, int top, int left, int size, void* out,
+                        int out_bf16, const float* mean3, const float* std3, float rescale);
+int crab_kaldi_fbank_frames(int n_samples);
+int crab_kaldi_fbank(crab_ctx* ctx, void* stream, const float* wave, int64_t ldw, int n_wave, int n_samples, float in_scale,
+                     float preemphasis, const float* window400, const float* mel_t, float* out, float out_sub, float out_scale);
+
 #ifdef __cplusplus
 }
 #endif

@@ -344,6 +344,30 @@ def golden_seg(me):
          avss_sub=out[0][:, 3::8, 5::8].contiguous(), s4_sub=out[1][:, 1::2, ::2].contiguous())
 
 
+FRONTEND_SHAPES = [(224, 224), (320, 480), (180, 150), (500, 333), (37, 91), (224, 398), (1080, 1920)]
+
+
+def golden_frontend():
+    """The reference's image path: `self.video_processor.preprocess(frames, return_tensors='pt')['pixel_values']`
+    (dataset/quick_start_dataset.py:315,457) with the CLIPImageProcessor of openai/clip-vit-large-patch14 (the defaults of
+    the class: shortest edge 224 BICUBIC, centre crop 224, 1/255, CLIP mean / std).  Stored: for every shape the uint8
+    resized + cropped image (processor with do_rescale = do_normalize = False) and, for two shapes, the float output."""
+    from PIL import Image
+    from transformers import CLIPImageProcessor
+    proc = CLIPImageProcessor()
+    arrays, meta = {}, dict(shapes=FRONTEND_SHAPES, seed0=700, mean=list(proc.image_mean), std=list(proc.image_std))
+    for i, (h, w) in enumerate(FRONTEND_SHAPES):
+        img = synth.synth_image(h, w, 700 + i)
+        frames = [Image.fromarray(img)]
+        u8 = proc.preprocess(frames, do_rescale=False, do_normalize=False, return_tensors='np')['pixel_values'][0]
+        assert u8.shape == (3, 224, 224)
+        arrays[f"u8_{i}"] = np.asarray(u8).round().astype(np.uint8)
+        if i in (0, 1):
+            arrays[f"px_{i}"] = proc.preprocess(frames, return_tensors='np')['pixel_values'][0].astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, "frontend_clip.npz"), meta=json.dumps(meta), **arrays)
+    print("frontend_clip.npz", {k: v.shape for k, v in arrays.items()})
+
+
 def main():
     ref_shims.install()
     me = ref_shims.patch_bert_config(lambda: ref_shims.tiny_bert_config(**TINY_QF))
@@ -362,6 +386,8 @@ def main():
         golden_qwen(me)
     if "seg" in which:
         golden_seg(me)
+    if "frontend" in which:
+        golden_frontend()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,111 @@
+"""Input front-end: host coefficient helper on CPU, device kernels against the reference-recorded
+fixture (tests/golden/frontend_clip.npz, made by the reference's own CLIPImageProcessor call) and the oracle."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from crab_amd import synth
+from oracle import frontend_oracle as FO
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _fixture():
+    z = np.load(os.path.join(HERE, "golden", "frontend_clip.npz"))
+    return json.loads(str(z["meta"])), z
+
+
+@pytest.mark.parametrize("in_size,out_size", [(480, 336), (150, 224), (1920, 398), (224, 224), (37, 224), (91, 550), (5, 3)])
+def test_bicubic_coeffs_host_helper_matches_pillow_restatement(in_size, out_size):
+    """crab_bicubic_coeffs (C, host) == oracle restatement of Pillow's precompute_coeffs / normalize_coeffs_8bpc."""
+    from crab_amd import _lib
+    lib = _lib.load()
+    ks = lib.crab_bicubic_ksize(in_size, out_size)
+    b_ref, k_ref = FO.pil_bicubic_coeffs(in_size, out_size)
+    assert ks == k_ref.shape[1]
+    bounds = np.zeros((out_size, 2), np.int32)
+    kk = np.zeros((out_size, ks), np.int32)
+    assert lib.crab_bicubic_coeffs(in_size, out_size, bounds.ctypes.data_as(C.c_void_p), kk.ctypes.data_as(C.c_void_p), ks) == ks
+    assert np.array_equal(bounds, b_ref) and np.array_equal(kk, k_ref)
+    assert lib.crab_bicubic_coeffs(in_size, out_size, bounds.ctypes.data_as(C.c_void_p), kk.ctypes.data_as(C.c_void_p), ks - 1) < 0
+    assert lib.crab_kaldi_fbank_frames(32000) == 198 and lib.crab_kaldi_fbank_frames(399) == 0 and lib.crab_kaldi_fbank_frames(400) == 1
+
+
+def test_mel_banks_and_window_match_oracle():
+    from crab_amd import frontend
+    assert np.array_equal(frontend.mel_banks_t(), FO.mel_banks().T)
+    assert np.array_equal(frontend.povey_window(), FO.povey_window())
+    assert frontend.CLIPImageProcessor.resize_size(500, 333, 224) == FO.clip_resize_size(500, 333) == (336, 224)
+
+
+@pytest.mark.gpu
+def test_clip_image_processor_matches_reference_fixture():
+    """Device resize + crop is BIT-EXACT with the reference's processor (Pillow bicubic); float output within fp32 rounding."""
+    from crab_amd.frontend import CLIPImageProcessor
+    meta, z = _fixture()
+    proc = CLIPImageProcessor()
+    imgs = [synth.synth_image(h, w, meta["seed0"] + i) for i, (h, w) in enumerate(meta["shapes"])]
+    for i, img in enumerate(imgs):
+        x = torch.from_numpy(img)[None].cuda()
+        r, top, left = proc.resize_crop(x)
+        got = r[0, top:top + 224, left:left + 224].permute(2, 0, 1).cpu().numpy()
+        assert np.array_equal(got, z[f"u8_{i}"]), (meta["shapes"][i], int(np.abs(got.astype(int) - z[f"u8_{i}"].astype(int)).max()))
+    # public call, mixed sizes in one list (numpy, torch and PIL inputs), order preserved
+    from PIL import Image
+    mixed = [imgs[0], torch.from_numpy(imgs[1]), Image.fromarray(imgs[2]), imgs[0]]
+    px = proc.preprocess(mixed, return_tensors="pt")["pixel_values"]
+    assert px.shape == (4, 3, 224, 224) and px.dtype == torch.float32 and px.is_cuda
+    assert np.abs(px[0].cpu().numpy() - z["px_0"]).max() < 2e-6
+    assert np.abs(px[1].cpu().numpy() - z["px_1"]).max() < 2e-6
+    assert torch.equal(px[0], px[3])
+    ref2 = FO.clip_preprocess([imgs[2]])[0]
+    assert np.abs(px[2].cpu().numpy() - ref2).max() < 2e-6
+    # bf16 output for the bf16 model
+    pb = CLIPImageProcessor(dtype=torch.bfloat16).preprocess(imgs[1])["pixel_values"]
+    assert pb.dtype == torch.bfloat16 and (pb.float().cpu() - torch.from_numpy(z["px_1"])).abs().max() < 1.6e-2
+
+
+@pytest.mark.gpu
+def test_full_hd_frames_round_trip_properties():
+    """1080p frames (the reference decodes at 224 through decord; images arrive at native size): constant images stay
+    constant (taps sum to 2^22), and a batch equals its frames processed one by one."""
+    from crab_amd.frontend import CLIPImageProcessor
+    proc = CLIPImageProcessor()
+    const = np.full((1080, 1920, 3), 137, np.uint8)
+    r, top, left = proc.resize_crop(torch.from_numpy(const)[None].cuda())
+    assert r.shape == (1, 224, 398, 3) and int(r.min()) == 137 and int(r.max()) == 137
+    frames = [synth.synth_image(360, 640, 900 + i) for i in range(3)]
+    both = proc.preprocess(frames)["pixel_values"]
+    for i, f in enumerate(frames):
+        assert torch.equal(both[i], proc.preprocess(f)["pixel_values"][0])
+
+
+@pytest.mark.gpu
+def test_kaldi_fbank_matches_oracle():
+    """fp32 FFT on the device vs the oracle (float64 rfft): log-mel within 2e-3 absolute wherever the mel energy is not
+    vanishing, normalised output as dataset/audio_processor.py:preprocess."""
+    from crab_amd import frontend
+    waves = np.stack([synth.synth_waveform(2.0, 11), synth.synth_waveform(2.0, 12) * 0.01, np.zeros(32000, np.float32)])
+    out = frontend.preprocess(torch.from_numpy(waves))
+    ref = FO.audio_preprocess(waves)
+    assert out.shape == (3, 198, 128) and out.dtype == torch.float32
+    err = np.abs(out.cpu().numpy() - ref)
+    assert err[:2].max() < 2e-3 / (2 * 6.55582) * 4, err[:2].max()
+    # silence: every mel energy floors at eps -> log(eps) exactly as the reference computes it
+    assert np.abs(out[2].cpu().numpy() - ref[2]).max() < 1e-5
+    # AVQA slicing: ten 2 s windows of a 60 s clip
+    audio = torch.from_numpy(synth.synth_waveform(60.0, 13))
+    segs = frontend.avqa_audio_segments(audio)
+    ref_segs = np.stack(FO.avqa_audio_segments(audio.numpy()))
+    assert np.array_equal(segs.numpy(), ref_segs)
+    fb = frontend.preprocess(segs)
+    assert fb.shape == (10, 198, 128)
+    # short input / ragged length
+    one = frontend.kaldi_fbank(torch.from_numpy(waves[0][:400]).cuda())
+    assert one.shape == (1, 1, 128)
+    with pytest.raises(ValueError):
+        frontend.kaldi_fbank(torch.zeros(399).cuda())

@@ -133,3 +133,56 @@ def test_seg_module_tiny():
     _close(out[1][:, 1::2, ::2], A["s4_sub"], 5e-4)
     for o, c in zip(out, meta["cks"]):
         assert abs(synth.checksum(o) - c) <= 2e-4 * max(1.0, abs(c))
+
+
+def test_frontend_clip_preprocess_bit_exact_vs_reference_call():
+    import os
+    """Pillow's bicubic resample + HF CLIPImageProcessor restated in oracle/frontend_oracle.py against the recorded outputs
+    of the reference's own call (make_golden.py frontend): uint8 resize+crop bit-exact, float output to fp32 rounding."""
+    import json
+    import numpy as np
+    from crab_amd import synth
+    from oracle import frontend_oracle as FO
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "frontend_clip.npz"))
+    meta = json.loads(str(z["meta"]))
+    for i, (h, w) in enumerate(meta["shapes"]):
+        img = synth.synth_image(h, w, meta["seed0"] + i)
+        got = FO.clip_resize_crop(img).transpose(2, 0, 1)
+        assert np.array_equal(got, z[f"u8_{i}"]), (h, w, int(np.abs(got.astype(int) - z[f"u8_{i}"].astype(int)).max()))
+        if f"px_{i}" in z:
+            px = FO.clip_preprocess([img])[0]
+            assert np.abs(px - z[f"px_{i}"]).max() < 2e-6
+
+
+def test_frontend_kaldi_fbank_restatement_self_consistent():
+    """torchaudio is absent (parity unpinned): cross-check the restatement against an independent float64 formulation
+    (explicit DFT matrix, mel weights rebuilt from the triangle definition) and pin shapes / framing."""
+    import numpy as np
+    from crab_amd import synth
+    from oracle import frontend_oracle as FO
+    x = synth.synth_waveform(2.0, 5)
+    fb = FO.kaldi_fbank(x * np.float32(2 ** 15))
+    assert fb.shape == (198, 128) and fb.dtype == np.float32
+    # independent: float64 everywhere, direct DFT
+    xs = x.astype(np.float64) * 2 ** 15
+    n = np.arange(400)
+    win = (0.5 - 0.5 * np.cos(2 * np.pi * n / 399)) ** 0.85
+    k = np.arange(257)[:, None] * np.arange(512)[None]
+    Wc, Ws = np.cos(2 * np.pi * k / 512), np.sin(2 * np.pi * k / 512)
+    mel = lambda f: 1127.0 * np.log(1 + f / 700.0)
+    edges = mel(20.0) + np.arange(130) * (mel(8000.0) - mel(20.0)) / 129
+    fm = mel(np.arange(256) * 31.25)
+    tri = np.maximum(0, np.minimum((fm[None] - edges[:-2, None]) / (edges[1:-1, None] - edges[:-2, None]),
+                                   (edges[2:, None] - fm[None]) / (edges[2:, None] - edges[1:-1, None])))
+    for f in (0, 57, 197):
+        fr = xs[f * 160: f * 160 + 400]
+        fr = fr - fr.mean()
+        fr = fr - 0.97 * np.concatenate([fr[:1], fr[:-1]])
+        fr = np.pad(fr * win, (0, 112))
+        p = (Wc @ fr) ** 2 + (Ws @ fr) ** 2
+        ref = np.log(np.maximum(tri @ p[:256], np.finfo(np.float32).eps))
+        assert np.abs(fb[f] - ref).max() < 2e-3, np.abs(fb[f] - ref).max()
+    out = FO.audio_preprocess(np.stack([x, x[::-1].copy()]))
+    assert out.shape == (2, 198, 128)
+    segs = FO.avqa_audio_segments(synth.synth_waveform(60.0, 6))
+    assert len(segs) == 10 and all(len(s) == 32000 for s in segs)
