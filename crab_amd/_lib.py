@@ -89,6 +89,13 @@ SYMBOLS = {
     "crab_bicubic_coeffs": (_i, [_i, _i, _vp, _vp, _i]),
     "crab_resample_u8": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _i]),
     "crab_clip_normalize": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _f]),
+    "crab_im2col3x3_strided": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i]),
+    "crab_groupnorm_workspace": (_i64, [_i, _i, _i]),
+    "crab_groupnorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _i, _vp, _i64]),
+    "crab_upsample_nearest2x": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i]),
+    "crab_softmax_rows": (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _i, _i, _f]),
+    "crab_row_sqnorm": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp]),
+    "crab_vq_argmin": (_i, [_vp, _vp, _vp, _i64, _vp, _i, _i, _vp, _i64]),
     "crab_kaldi_fbank_frames": (_i, [_i]),
     "crab_kaldi_fbank": (_i, [_vp, _vp, _vp, _i64, _i, _i, _f, _f, _vp, _vp, _vp, _f, _f]),
 }

@@ -1,0 +1,242 @@
+// Kernels of the VQGAN mask tokenizer (reference models/taming_transformer/modules.py, quantize.py:272-330,
+// vqgan.py:54-99) that the GEMM / attention / embedding kernels do not already cover.  Feature maps are token-major
+// [b, h*w, C] bf16 like the SegModule path, so every convolution is im2col + MFMA GEMM:
+//   im2col3x3s_kernel      3x3 window with stride and top/left padding (Downsample: pad (0,1,0,1), stride 2, modules.py:66-72)
+//   groupnorm stats/apply  GroupNorm(32, C, eps 1e-6) (+ swish), two passes: per-(batch, pixel chunk, group) partial sums in a
+//                          caller workspace, summed in a FIXED order by the apply pass (deterministic, no atomics)
+//   upsample_nearest2x     F.interpolate(scale_factor=2, mode="nearest") (modules.py:50)
+//   softmax_rows           AttnBlock softmax over keys (single head of C = 512 channels: scores come from the GEMM)
+//   row_sqnorm / vq_argmin nearest codebook entry: argmin_n |e_n|^2 - 2 z.e_n (the |z|^2 term of quantize.py:286-288 is
+//                          constant per row), first minimum wins like torch.argmin
+#include "common.h"
+#include "crab_internal.h"
+#include <math.h>
+
+namespace {
+
+__global__ void im2col3x3s_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int h, int w, int C, int stride, int pt, int pl,
+                                  int oh, int ow) {
+    const int pix = blockIdx.x;                       // b*oh*ow + oy*ow + ox
+    const int b = pix / (oh * ow), r = pix % (oh * ow), oy = r / ow, ox = r % ow;
+    const int nv = C >> 3;
+    for (int i = threadIdx.x; i < 9 * nv; i += blockDim.x) {
+        const int tap = i / nv, c8 = i % nv;
+        const int yy = oy * stride + tap / 3 - pt, xx = ox * stride + tap % 3 - pl;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (yy >= 0 && yy < h && xx >= 0 && xx < w) v = *reinterpret_cast<const u32x4*>(in + (((long)b * h + yy) * w + xx) * C + c8 * 8);
+        *reinterpret_cast<u32x4*>(out + (long)pix * 9 * C + tap * C + c8 * 8) = v;
+    }
+}
+
+constexpr int GN_MAXC = 1024;                          // channels per block pass (4 per thread)
+
+// grid (chunks, B); partial[b][chunk][g] = {sum, sum of squares} over the chunk's pixels and the group's channels
+__global__ __launch_bounds__(256) void groupnorm_stats_kernel(const bf16_t* __restrict__ x, int HW, int C, int G, int rows_per_chunk,
+                                                              float* __restrict__ partial) {
+    __shared__ float cs[GN_MAXC], cq[GN_MAXC];
+    const int tid = threadIdx.x, b = blockIdx.y, ch = blockIdx.x;
+    const int p0 = ch * rows_per_chunk, p1 = min(HW, p0 + rows_per_chunk);
+    float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+    const bf16_t* xb = x + (long)b * HW * C;
+    for (int p = p0; p < p1; ++p) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = tid + j * 256;
+            if (c < C) { const float v = bf2f(xb[(long)p * C + c]); s[j] += v; q[j] += v * v; }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int c = tid + j * 256; if (c < C) { cs[c] = s[j]; cq[c] = q[j]; } }
+    __syncthreads();
+    if (tid < G) {
+        const int cpg = C / G;
+        float a = 0.f, bq = 0.f;
+        for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { a += cs[c]; bq += cq[c]; }
+        float* o = partial + (((long)b * gridDim.x + ch) * G + tid) * 2;
+        o[0] = a; o[1] = bq;
+    }
+}
+
+// grid (ceil(HW*C/8/256), B)
+__global__ __launch_bounds__(256) void groupnorm_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, int HW, int C, int G,
+                                                              int chunks, const float* __restrict__ partial, const bf16_t* __restrict__ weight,
+                                                              const bf16_t* __restrict__ bias, float eps, int swish) {
+    __shared__ float mean_s[64], rstd_s[64];
+    const int tid = threadIdx.x, b = blockIdx.y;
+    if (tid < G) {
+        float a = 0.f, q = 0.f;
+        for (int ch = 0; ch < chunks; ++ch) { const float* o = partial + (((long)b * chunks + ch) * G + tid) * 2; a += o[0]; q += o[1]; }
+        const float n = (float)HW * (float)(C / G);
+        const float m = a / n;
+        const float var = fmaxf(q / n - m * m, 0.f);
+        mean_s[tid] = m; rstd_s[tid] = rsqrtf(var + eps);
+    }
+    __syncthreads();
+    const long v8 = (long)blockIdx.x * 256 + tid;
+    const long nv = (long)HW * C / 8;
+    if (v8 >= nv) return;
+    const int c0 = (int)((v8 * 8) % C);
+    const long off = (long)b * HW * C + v8 * 8;
+    const u32x4 xv = *reinterpret_cast<const u32x4*>(x + off);
+    const u32x4 wv = *reinterpret_cast<const u32x4*>(weight + c0);
+    const u32x4 bv = *reinterpret_cast<const u32x4*>(bias + c0);
+    const int cpg = C / G;
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float y[2];
+#pragma unroll
+        for (int hlf = 0; hlf < 2; ++hlf) {
+            const int c = c0 + 2 * e + hlf, g = c / cpg;
+            const float xx = hlf ? hi_bf(xv[e]) : lo_bf(xv[e]);
+            const float ww = hlf ? hi_bf(wv[e]) : lo_bf(wv[e]);
+            const float bb = hlf ? hi_bf(bv[e]) : lo_bf(bv[e]);
+            float v = (xx - mean_s[g]) * rstd_s[g] * ww + bb;
+            if (swish) v = v / (1.0f + __expf(-v));
+            y[hlf] = v;
+        }
+        o[e] = pack_bf2(y[0], y[1]);
+    }
+    *reinterpret_cast<u32x4*>(out + off) = o;
+}
+
+__global__ void upsample_nearest2x_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int h, int w, int C, long total8) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total8) return;
+    const int nv = C >> 3;
+    const int c8 = (int)(i % nv);
+    long r = i / nv;
+    const int X = (int)(r % (2 * w)); r /= (2 * w);
+    const int Y = (int)(r % (2 * h));
+    const long b = r / (2 * h);
+    *reinterpret_cast<u32x4*>(out + i * 8) = *reinterpret_cast<const u32x4*>(in + (((b * h + (Y >> 1)) * w + (X >> 1)) * (long)C) + c8 * 8);
+}
+
+// one block per row: out = softmax(scale * in)
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ in, long ldi, bf16_t* __restrict__ out, long ldo, int N,
+                                                           float scale) {
+    __shared__ float red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const float* x = in + (long)blockIdx.x * ldi;
+    float mx = -INFINITY;
+    for (int i = tid; i < N; i += 256) mx = fmaxf(mx, x[i] * scale);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if (lane == 0) red[wv] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float s = 0.f;
+    for (int i = tid; i < N; i += 256) s += __expf(x[i] * scale - mx);
+    s = wave_sum(s);
+    if (lane == 0) red[wv] = s;
+    __syncthreads();
+    const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
+    bf16_t* o = out + (long)blockIdx.x * ldo;
+    for (int i = tid; i < N; i += 256) o[i] = f2bf(__expf(x[i] * scale - mx) * inv);
+}
+
+__global__ void row_sqnorm_kernel(const bf16_t* __restrict__ e, long lde, int N, int D, float* __restrict__ out) {
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int i = lane; i < D; i += 64) { const float v = bf2f(e[(long)n * lde + i]); s += v * v; }
+    s = wave_sum(s);
+    if (lane == 0) out[n] = s;
+}
+
+// one block per row: idx = first argmin_n (e2[n] - 2 dots[m][n])
+__global__ __launch_bounds__(256) void vq_argmin_kernel(const float* __restrict__ dots, long ldd, const float* __restrict__ e2, int N,
+                                                        int64_t* __restrict__ idx, int64_t offset) {
+    __shared__ float bv[4];
+    __shared__ int bi[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const float* d = dots + (long)blockIdx.x * ldd;
+    float best = INFINITY; int besti = 0x7fffffff;
+    for (int n = tid; n < N; n += 256) {
+        const float v = e2[n] - 2.0f * d[n];
+        if (v < best) { best = v; besti = n; }                    // ascending n per thread: first minimum kept
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(besti, o, 64);
+        if (ov < best || (ov == best && oi < besti)) { best = ov; besti = oi; }
+    }
+    if (lane == 0) { bv[wv] = best; bi[wv] = besti; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int k = 1; k < 4; ++k)
+            if (bv[k] < best || (bv[k] == best && bi[k] < besti)) { best = bv[k]; besti = bi[k]; }
+        idx[blockIdx.x] = (int64_t)besti + offset;
+    }
+}
+
+}  // namespace
+
+#define S_(x) ((hipStream_t)(x))
+static inline unsigned cdiv_(long a, long b) { return (unsigned)((a + b - 1) / b); }
+
+extern "C" int crab_im2col3x3_strided(crab_ctx* ctx, void* stream, const void* in, void* out, int B, int h, int w, int C, int stride, int pad_top,
+                                      int pad_left, int oh, int ow) {
+    if (!ctx) return CRAB_E_INVALID;
+    if (!in || !out || B <= 0 || h <= 0 || w <= 0 || C <= 0 || (C & 7) || stride <= 0 || oh <= 0 || ow <= 0)
+        return crab_fail(ctx, CRAB_E_INVALID, "im2col3x3_strided: bad argument (C must be a multiple of 8)");
+    hipLaunchKernelGGL(im2col3x3s_kernel, dim3(B * oh * ow), dim3(256), 0, S_(stream), (const bf16_t*)in, (bf16_t*)out, h, w, C, stride, pad_top,
+                       pad_left, oh, ow);
+    return crab_check_launch(ctx, "im2col3x3_strided");
+}
+
+extern "C" int64_t crab_groupnorm_workspace(int B, int HW, int G) {
+    int chunks = (HW + 63) / 64;
+    if (chunks > 64) chunks = 64;
+    return (int64_t)B * chunks * G * 2 * (int64_t)sizeof(float);
+}
+
+extern "C" int crab_groupnorm(crab_ctx* ctx, void* stream, const void* x, void* out, int B, int HW, int C, int G, float eps, const void* weight,
+                              const void* bias, int swish, void* workspace, int64_t workspace_bytes) {
+    if (!ctx) return CRAB_E_INVALID;
+    if (!x || !out || !weight || !bias || !workspace || B <= 0 || HW <= 0 || C <= 0 || G <= 0 || G > 64 || C % G || (C & 7) || C > GN_MAXC)
+        return crab_fail(ctx, CRAB_E_INVALID, "groupnorm: bad argument (C % 8 == 0, C <= 1024, G <= 64)");
+    if (workspace_bytes < crab_groupnorm_workspace(B, HW, G)) return crab_fail(ctx, CRAB_E_WORKSPACE, "groupnorm: workspace too small");
+    int chunks = (HW + 63) / 64;
+    if (chunks > 64) chunks = 64;
+    const int rows = (HW + chunks - 1) / chunks;
+    chunks = (HW + rows - 1) / rows;
+    hipLaunchKernelGGL(groupnorm_stats_kernel, dim3(chunks, B), dim3(256), 0, S_(stream), (const bf16_t*)x, HW, C, G, rows, (float*)workspace);
+    int rc = crab_check_launch(ctx, "groupnorm_stats_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(groupnorm_apply_kernel, dim3(cdiv_((long)HW * C / 8, 256), B), dim3(256), 0, S_(stream), (const bf16_t*)x, (bf16_t*)out, HW, C,
+                       G, chunks, (const float*)workspace, (const bf16_t*)weight, (const bf16_t*)bias, eps, swish);
+    return crab_check_launch(ctx, "groupnorm_apply_kernel");
+}
+
+extern "C" int crab_upsample_nearest2x(crab_ctx* ctx, void* stream, const void* in, void* out, int B, int h, int w, int C) {
+    if (!ctx) return CRAB_E_INVALID;
+    if (!in || !out || B <= 0 || h <= 0 || w <= 0 || C <= 0 || (C & 7)) return crab_fail(ctx, CRAB_E_INVALID, "upsample_nearest2x: bad argument");
+    const long total8 = (long)B * 4 * h * w * (C / 8);
+    hipLaunchKernelGGL(upsample_nearest2x_kernel, dim3(cdiv_(total8, 256)), dim3(256), 0, S_(stream), (const bf16_t*)in, (bf16_t*)out, h, w, C, total8);
+    return crab_check_launch(ctx, "upsample_nearest2x");
+}
+
+extern "C" int crab_softmax_rows(crab_ctx* ctx, void* stream, const float* in, int64_t ldi, void* out, int64_t ldo, int M, int N, float scale) {
+    if (!ctx) return CRAB_E_INVALID;
+    if (!in || !out || M <= 0 || N <= 0) return crab_fail(ctx, CRAB_E_INVALID, "softmax_rows: bad argument");
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3(M), dim3(256), 0, S_(stream), in, (long)ldi, (bf16_t*)out, (long)ldo, N, scale);
+    return crab_check_launch(ctx, "softmax_rows");
+}
+
+extern "C" int crab_row_sqnorm(crab_ctx* ctx, void* stream, const void* e, int64_t lde, int N, int D, float* out) {
+    if (!ctx) return CRAB_E_INVALID;
+    if (!e || !out || N <= 0 || D <= 0) return crab_fail(ctx, CRAB_E_INVALID, "row_sqnorm: bad argument");
+    hipLaunchKernelGGL(row_sqnorm_kernel, dim3(cdiv_(N, 4)), dim3(256), 0, S_(stream), (const bf16_t*)e, (long)lde, N, D, out);
+    return crab_check_launch(ctx, "row_sqnorm");
+}
+
+extern "C" int crab_vq_argmin(crab_ctx* ctx, void* stream, const float* dots, int64_t ldd, const float* e2, int M, int N, int64_t* idx,
+                              int64_t offset) {
+    if (!ctx) return CRAB_E_INVALID;
+    if (!dots || !e2 || !idx || M <= 0 || N <= 0) return crab_fail(ctx, CRAB_E_INVALID, "vq_argmin: bad argument");
+    hipLaunchKernelGGL(vq_argmin_kernel, dim3(M), dim3(256), 0, S_(stream), dots, (long)ldd, e2, N, idx, offset);
+    return crab_check_launch(ctx, "vq_argmin");
+}

@@ -435,3 +435,63 @@ def cast_bf16(x: torch.Tensor) -> torch.Tensor:
 def sync():
     d = torch.cuda.current_device()
     _lib.check(_lib.load().crab_sync(_lib.ctx(d), _stream()), d)
+
+
+# ------------------------------------------------------------------------------------------------ VQGAN (csrc/vq_ops.hip)
+def im2col3x3_strided(x: torch.Tensor, B: int, h: int, w: int, stride: int, pad_top: int, pad_left: int, oh: int, ow: int) -> torch.Tensor:
+    """x [B*h*w, C] token-major -> [B*oh*ow, 9*C] window operand (zero outside the image)."""
+    d = _dev(x)
+    Cc = x.shape[1]
+    out = torch.empty((B * oh * ow, 9 * Cc), device=x.device, dtype=BF16)
+    _lib.check(_lib.load().crab_im2col3x3_strided(_lib.ctx(d), _stream(), _p(x), _p(out), B, h, w, Cc, stride, pad_top, pad_left, oh, ow), d)
+    return out
+
+
+def groupnorm(x: torch.Tensor, B: int, HW: int, G: int, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-6, swish: bool = False,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x [B*HW, C] token-major bf16 -> GroupNorm(G, C) (+ swish)."""
+    d = _dev(x)
+    Cc = x.shape[1]
+    if out is None:
+        out = torch.empty_like(x)
+    need = int(_lib.load().crab_groupnorm_workspace(B, HW, G))
+    ws = torch.empty((need,), device=x.device, dtype=torch.uint8)
+    _lib.check(_lib.load().crab_groupnorm(_lib.ctx(d), _stream(), _p(x), _p(out), B, HW, Cc, G, eps, _p(weight), _p(bias), 1 if swish else 0,
+                                          _p(ws), need), d)
+    return out
+
+
+def upsample_nearest2x(x: torch.Tensor, B: int, h: int, w: int) -> torch.Tensor:
+    d = _dev(x)
+    Cc = x.shape[1]
+    out = torch.empty((B * 4 * h * w, Cc), device=x.device, dtype=BF16)
+    _lib.check(_lib.load().crab_upsample_nearest2x(_lib.ctx(d), _stream(), _p(x), _p(out), B, h, w, Cc), d)
+    return out
+
+
+def softmax_rows(x: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
+    """x fp32 [M,N] -> bf16 softmax(scale * x) per row."""
+    d = _dev(x)
+    assert x.dtype == torch.float32 and x.stride(1) == 1
+    M, N = x.shape
+    out = torch.empty((M, N), device=x.device, dtype=BF16)
+    _lib.check(_lib.load().crab_softmax_rows(_lib.ctx(d), _stream(), _p(x), x.stride(0), _p(out), out.stride(0), M, N, scale), d)
+    return out
+
+
+def row_sqnorm(e: torch.Tensor) -> torch.Tensor:
+    d = _dev(e)
+    N, D = e.shape
+    out = torch.empty((N,), device=e.device, dtype=torch.float32)
+    _lib.check(_lib.load().crab_row_sqnorm(_lib.ctx(d), _stream(), _p(e), e.stride(0), N, D, _p(out)), d)
+    return out
+
+
+def vq_argmin(dots: torch.Tensor, e2: torch.Tensor, offset: int = 0) -> torch.Tensor:
+    """dots fp32 [M,N] = z . e^T, e2 fp32 [N] -> int64 [M]: offset + first argmin_n (e2[n] - 2 dots[m,n])."""
+    d = _dev(dots)
+    assert dots.dtype == torch.float32 and e2.dtype == torch.float32 and dots.stride(1) == 1
+    M, N = dots.shape
+    out = torch.empty((M,), device=dots.device, dtype=torch.int64)
+    _lib.check(_lib.load().crab_vq_argmin(_lib.ctx(d), _stream(), _p(dots), dots.stride(0), _p(e2), M, N, _p(out), offset), d)
+    return out

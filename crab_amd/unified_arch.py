@@ -58,6 +58,7 @@ class UnifiedMetaModel:
         clip_config: Optional[Dict] = None,
         beats_config: Optional[Dict] = None,
         bert_config: Optional[Dict] = None,
+        vqgan_config: Optional[Dict] = None,
     ):
         dev = self.embed_tokens.weight.device
         if visual_branch:
@@ -84,7 +85,15 @@ class UnifiedMetaModel:
                 image_embedding_size=(image_size // patch_size), dice_loss_weight=dice_loss_weight,
                 bce_loss_weight=bce_loss_weight, device=dev)
         if use_vqgan:
-            raise NotImplementedError("VQGAN mask tokenizer is SURVEY.md 8f-4 (disabled in every reference script)")
+            # unified_arch.py:109-110; `vqgan_config` (build-side extension) overrides the taming f16/16384 architecture
+            from .vqgan import MaskEncoder
+            vq = dict(vqgan_config or {})
+            self.mask_encoder = MaskEncoder(token_shift=32000 + 20, device=dev, ddconfig=vq.get("ddconfig"), n_embed=vq.get("n_embed", 16384),
+                                            embed_dim=vq.get("embed_dim", 256))
+
+    def encode_mask(self, mask):
+        """unified_arch.py:158-159."""
+        return self.mask_encoder(mask)
 
     def encode_video(self, visual, all_levels: bool = False):
         """unified_arch.py:144-149.  The reference pushes all three CLIP feature levels through the VLProjector and
@@ -129,6 +138,13 @@ class UnifiedMetaForCausalLM:
             qf = [q.squeeze(0) if q is not None else None for q in qf]
         return vit, qf
 
+    def encode_mask(self, mask, batch_first=False):
+        """unified_arch.py:204-210: mask image [3,H,W] (or [b,3,H,W]) -> VQGAN token ids (already shifted into the LLM vocab)."""
+        if not batch_first:
+            mask = mask.unsqueeze(0)
+        indices = self.get_model().encode_mask(mask)
+        return indices if batch_first else indices.squeeze(0)
+
     def encode_ids(self, ids):
         return self.get_model().embed_tokens(ids)
 
@@ -159,7 +175,7 @@ class UnifiedMetaForCausalLM:
 
         # ---- pass 1 (host): segment plan per sample; modality blocks are encoded batched per kind
         plans = []
-        vids, auds = [], []
+        vids, auds, msks = [], [], []
         for i in range(bs):
             ids = batch_input_ids[i]
             ids_l = ids.tolist()
@@ -171,6 +187,9 @@ class UnifiedMetaForCausalLM:
                     if key == '<audio>':
                         segs.append(("audio", len(auds)))
                         auds.append(batch_X_modals[i][key])
+                    elif key == '<mask>':                                                # VQGAN mask image -> 256 token ids (:303-307)
+                        segs.append(("mask", len(msks)))
+                        msks.append(batch_X_modals[i][key])
                     else:
                         segs.append(("video", len(vids)))
                         vids.append(batch_X_modals[i][key])
@@ -179,6 +198,7 @@ class UnifiedMetaForCausalLM:
             plans.append(segs)
         vfeat, vvit = self._encode_blocks(vids, video=True, want_vit=return_multi_scale_features)
         afeat, _ = self._encode_blocks(auds, video=False)
+        mids = [self.encode_mask(m, batch_first=False) for m in msks]
         img_block = {}                                   # sample -> index of its <image> block (multi-scale features)
         if return_multi_scale_features:
             for i, segs in enumerate(plans):
@@ -187,7 +207,7 @@ class UnifiedMetaForCausalLM:
                 for pos, tok in enumerate(ids_l):
                     if tok in key_ids:
                         if key_ids[tok] == '<image>' and i not in img_block:
-                            img_block[i] = [sg for sg in segs if sg[0] in ("video", "audio")][k][1]
+                            img_block[i] = [sg for sg in segs if sg[0] in ("video", "audio", "mask")][k][1]
                         k += 1
 
         # ---- pass 2: lengths, left padding, one output buffer
@@ -195,7 +215,8 @@ class UnifiedMetaForCausalLM:
         for segs in plans:
             n = 0
             for sg in segs:
-                n += (sg[2] - sg[1]) if sg[0] == "text" else (vfeat[sg[1]] if sg[0] == "video" else afeat[sg[1]]).shape[0]
+                n += (sg[2] - sg[1]) if sg[0] == "text" else (mids[sg[1]] if sg[0] == "mask" else
+                                                              (vfeat[sg[1]] if sg[0] == "video" else afeat[sg[1]])).shape[0]
             lens.append(n)
         S = max(lens)
         out = torch.empty((bs, S, D), device=device, dtype=BF16)
@@ -217,6 +238,10 @@ class UnifiedMetaForCausalLM:
                         ops.embedding(ids[sg[1]:sg[2]], emb_w, out=out[i, cur:cur + n])
                         if lab is not None:
                             labels[i, cur:cur + n] = lab[sg[1]:sg[2]].cpu()
+                elif sg[0] == "mask":
+                    n = mids[sg[1]].shape[0]
+                    ops.embedding(mids[sg[1]], emb_w, out=out[i, cur:cur + n])          # encode_ids(indices), labels = indices
+                    labels[i, cur:cur + n] = mids[sg[1]].cpu()
                 else:
                     f = vfeat[sg[1]] if sg[0] == "video" else afeat[sg[1]]
                     n = f.shape[0]
@@ -295,8 +320,6 @@ class UnifiedMetaForCausalLM:
     def initialize_MM_tokenizer(self, tokenizer, mask_token_nums=6, output_embeddings_require_grad=False, use_vqgan=False):
         """unified_arch.py:409-459: 11 special + mask_token_nums `<mask_i>` tokens appended in fixed order, tables
         KEYS / MASK / SPECIAL_TOKEN_2_IDS / IDS_2_SPECIAL_TOKEN, then resize_token_embeddings(len(tokenizer))."""
-        if use_vqgan:
-            raise NotImplementedError("VQGAN tokens: SURVEY.md 8f-4")
         vocab_nums = len(tokenizer)
         added_tokens = []
         added_tokens += ['<image>', '<image_start>', '<image_end>']
@@ -304,6 +327,12 @@ class UnifiedMetaForCausalLM:
         added_tokens += ['<audio>', '<audio_start>', '<audio_end>']
         added_tokens += ['<mask_start>', '<mask_end>']
         tokenizer.add_tokens(list(added_tokens), special_tokens=True)
+        if use_vqgan:
+            # reproduced as shipped (:422-426): the 3 + 16384 VQGAN tokens get ids in the TABLES only - they are never added
+            # to the tokenizer, so resize_token_embeddings below does not grow for them - and the KEYS.append('<mask>') of
+            # the reference is overwritten by the KEYS assignment further down (the '<mask>' branch of
+            # prepare_multimodal_inputs is only reachable if a caller extends KEYS afterwards)
+            added_tokens += ['<mask>', '<vqgan_start>', '<vqgan_end>'] + [f'<vqgan_{i}>' for i in range(16384)]
         seg_tokens = [f'<mask_{i}>' for i in range(mask_token_nums)]
         tokenizer.add_tokens(seg_tokens, special_tokens=False)
         added_tokens += seg_tokens

@@ -229,6 +229,27 @@ int crab_kaldi_fbank_frames(int n_samples);
 int crab_kaldi_fbank(crab_ctx* ctx, void* stream, const float* wave, int64_t ldw, int n_wave, int n_samples, float in_scale,
                      float preemphasis, const float* window400, const float* mel_t, float* out, float out_sub, float out_scale);
 
+/* ---------------------------------------------------------------------------------------------
+ * VQGAN mask tokenizer (models/multimodal_encoder.py:546-601 MaskEncoder, taming_transformer/modules.py,
+ * quantize.py:272-330, vqgan.py:54-99).  Token-major [b, h*w, C] bf16 feature maps; convolutions = im2col + crab_gemm_bf16.
+ *  im2col3x3_strided : out[(b,oy,ox), (ky*3+kx)*C + c] = in[b, oy*stride+ky-pad_top, ox*stride+kx-pad_left, c] (0 outside);
+ *                      Downsample (modules.py:66-72: F.pad (0,1,0,1) + Conv2d(k3, s2)) is stride 2, pads 0.
+ *  groupnorm         : GroupNorm(G, C, eps) over (h*w, C/G) per (b, g) (+ x*sigmoid(x) when swish): Normalize / nonlinearity
+ *                      (modules.py:29-35); workspace = crab_groupnorm_workspace bytes (fixed-order partial sums).
+ *  upsample_nearest2x: F.interpolate(scale_factor=2, mode="nearest") (modules.py:50).
+ *  softmax_rows      : out bf16 = softmax(scale * in fp32) per row (AttnBlock, modules.py:176-178).
+ *  row_sqnorm        : out[n] = sum_d e[n,d]^2 (codebook norms, quantize.py:287).
+ *  vq_argmin         : idx[m] = offset + first argmin_n (e2[n] - 2 dots[m,n])  (quantize.py:286-290; dots = z . e^T from the GEMM). */
+int crab_im2col3x3_strided(crab_ctx* ctx, void* stream, const void* in, void* out, int B, int h, int w, int C, int stride, int pad_top,
+                           int pad_left, int oh, int ow);
+int64_t crab_groupnorm_workspace(int B, int HW, int G);
+int crab_groupnorm(crab_ctx* ctx, void* stream, const void* x, void* out, int B, int HW, int C, int G, float eps, const void* weight,
+                   const void* bias, int swish, void* workspace, int64_t workspace_bytes);
+int crab_upsample_nearest2x(crab_ctx* ctx, void* stream, const void* in, void* out, int B, int h, int w, int C);
+int crab_softmax_rows(crab_ctx* ctx, void* stream, const float* in, int64_t ldi, void* out, int64_t ldo, int M, int N, float scale);
+int crab_row_sqnorm(crab_ctx* ctx, void* stream, const void* e, int64_t lde, int N, int D, float* out);
+int crab_vq_argmin(crab_ctx* ctx, void* stream, const float* dots, int64_t ldd, const float* e2, int M, int N, int64_t* idx, int64_t offset);
+
 #ifdef __cplusplus
 }
 #endif

@@ -368,6 +368,34 @@ def golden_frontend():
     print("frontend_clip.npz", {k: v.shape for k, v in arrays.items()})
 
 
+TINY_VQ = dict(ch=32, ch_mult=(1, 2, 2), num_res_blocks=1, attn_resolutions=(8,), resolution=32, z_channels=32, n_embed=64, embed_dim=32)
+
+
+def golden_vqgan():
+    """models/taming_transformer/vqgan.py VQModel (the class MaskEncoder wraps, multimodal_encoder.py:546-601) at a tiny
+    configuration: get_codebook_indices / decode_code outputs and the pre-quantisation latents."""
+    from models.taming_transformer.vqgan import VQModel
+    c = TINY_VQ
+    dd = dict(double_z=False, z_channels=c["z_channels"], resolution=c["resolution"], in_channels=3, out_ch=3, ch=c["ch"],
+              ch_mult=c["ch_mult"], num_res_blocks=c["num_res_blocks"], attn_resolutions=c["attn_resolutions"], dropout=0.0)
+    m = VQModel(ddconfig=dd, lossconfig=None, n_embed=c["n_embed"], embed_dim=c["embed_dim"]).eval()
+    table = load_synth(m, "mask_encoder.vqgan.")
+    g = torch.Generator().manual_seed(SEED + 77)
+    x = torch.randn(2, 3, c["resolution"], c["resolution"], generator=g)
+    with torch.no_grad():
+        lat = m.quant_conv(m.encoder(x))
+        idx = m.get_codebook_indices(x)
+        dec = m.decode_code(idx)
+    e = m.quantize.embedding.weight
+    z = lat.permute(0, 2, 3, 1).reshape(-1, e.shape[1])
+    d = (z ** 2).sum(1, keepdim=True) + (e ** 2).sum(1) - 2 * z @ e.t()
+    top2 = d.topk(2, dim=1, largest=False).values
+    print("vqgan idx", idx.shape, "latent absmax", float(lat.abs().max()), "min margin", float((top2[:, 1] - top2[:, 0]).min()),
+          "dec absmax", float(dec.abs().max()))
+    save("vqgan_tiny", dict(seed=SEED, cfg={k: (list(v) if isinstance(v, tuple) else v) for k, v in c.items()}, table=table, xseed=SEED + 77),
+         latents=lat, indices=idx, margin=(top2[:, 1] - top2[:, 0]).reshape(2, -1), decoded=dec)
+
+
 def main():
     ref_shims.install()
     me = ref_shims.patch_bert_config(lambda: ref_shims.tiny_bert_config(**TINY_QF))
@@ -388,6 +416,8 @@ def main():
         golden_seg(me)
     if "frontend" in which:
         golden_frontend()
+    if "vqgan" in which:
+        golden_vqgan()
 
 
 if __name__ == "__main__":
