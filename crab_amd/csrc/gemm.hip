@@ -314,6 +314,21 @@ extern "C" int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc*
         if (sk_bm == 128 && sk_bn == 64) sk_bn = 128;
         long tiles = (long)((d->N + sk_bn - 1) / sk_bn) * ((d->M + sk_bm - 1) / sk_bm);
         splitk = tiles >= 300 ? 1 : (int)((640 + tiles - 1) / tiles);        // a full wave of blocks needs no split (and no partial traffic)
+        if (sk_bm == 128 && d->tune < 100) {
+            // 128-row tiles (64 < M <= 256): pick the split from a cost model calibrated on the four decoder projections at
+            // M = 256 (profiles/README.md): two blocks are resident per CU (512 slots), a K tile of 64 costs ~1.35 us per
+            // block when two share a CU, ~6 us of prologue + epilogue per block, and the reduction kernel ~4 us + one pass
+            // over each fp32 slab.  qkv (192 tiles): split 4 = 768 blocks = 1.5 rounds -> 66 us, split 2 = 384 blocks -> 59 us.
+            double best = 1e30;
+            const double slab_us = (double)d->M * d->N * 4.0 / 5.0e6;             // one slab at ~5 TB/s, in us
+            for (int sp = 1; sp <= 8 && sp <= nk_all / 4 + (nk_all < 4); ++sp) {
+                const long blocks = tiles * sp;
+                const double rounds = (double)((blocks + 511) / 512);
+                double t = rounds * (6.0 + 1.35 * (double)((nk_all + sp - 1) / sp)) + (sp > 1 ? 4.0 + 0.7 * sp * slab_us : 0.0);
+                if (blocks < 256) t *= 256.0 / (double)blocks * 0.5 + 0.5;        // too few blocks: weight panels stream too slowly
+                if (t < best) { best = t; splitk = sp; }
+            }
+        }
         if (d->tune >= 100) splitk = d->tune % 100;
         if (splitk > nk_all / 4) splitk = nk_all / 4;
         if (splitk < 1) splitk = 1;
