@@ -271,7 +271,9 @@ def attn_decode(q, k_cache, v_cache, o, B, H, Hk, head_dim, Tmax, ctx_len, scale
         e1.record()
         # algorithmic bytes (DESIGN.md kernel table): every live K and V row once + q in + o out
         nbytes = 2.0 * B * prof.decode_ctx * Hk * head_dim * 2 + 2.0 * B * H * head_dim * 2
-        prof.records.append((f"attn_decode_kernel<{head_dim}>", nbytes, e0, e1))
+        G = H // Hk                                   # mirror of the kernel choice in csrc/attn.hip (crab_attn_decode)
+        gqa = head_dim == 128 and G in (2, 4, 7, 8) and B * Hk >= 256
+        prof.records.append((f"attn_decode_gqa_kernel<{head_dim},{G}>" if gqa else f"attn_decode_kernel<{head_dim}>", nbytes, e0, e1))
     return o
 
 

@@ -1,0 +1,18 @@
+"""Experiment: achievable read-only HBM bandwidth (torch reductions over a 4 GiB buffer) vs the decode-attention kernel."""
+import torch, time
+x = torch.empty(1 << 30, device="cuda", dtype=torch.float32).normal_()
+def t(fn, n=10):
+    for _ in range(2): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+ms = t(lambda: x.sum())
+print(f"torch sum fp32 4 GiB: {ms:.3f} ms -> {x.numel()*4/ms/1e6:.0f} GB/s")
+ms = t(lambda: x.max())
+print(f"torch max fp32 4 GiB: {ms:.3f} ms -> {x.numel()*4/ms/1e6:.0f} GB/s")
+y = torch.empty_like(x)
+ms = t(lambda: y.copy_(x))
+print(f"torch copy 4 GiB: {ms:.3f} ms -> {2*x.numel()*4/ms/1e6:.0f} GB/s (read+write)")
