@@ -128,7 +128,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--clips", type=int, default=int(os.environ.get("CRAB_BENCH_CLIPS", "256")), help="clips per GPU per step")
     ap.add_argument("--new-tokens", type=int, default=256)
     ap.add_argument("--frames", type=int, default=8)
@@ -185,8 +185,11 @@ def main():
     ops.PROFILER = prof
     sync()
     t0 = time.perf_counter()
+    step_ms = []
     for _ in range(args.steps):
-        res = step()
+        ts = time.perf_counter()
+        res = step()                       # generate() ends with a device->host read of the step count: the step is complete
+        step_ms.append(round((time.perf_counter() - ts) * 1e3, 1))
     sync()
     dt = time.perf_counter() - t0
     ops.PROFILER = None
@@ -243,6 +246,7 @@ def main():
                        "frames": args.frames, "audio_segments": 10, "prompt_tokens": 128, "prefill_len": S, "new_tokens": args.new_tokens,
                        "decode": "greedy, EOS suppressed, device-resident HIP-graph loop", "parallelism": f"per-clip x{world}, RCCL gather"},
             "prefill_tflop_per_clip": round(flops_per_clip(args.frames, 10, 48, S, V) / 1e12, 3),
+            "step_ms": step_ms,
             "prefill_roofline": prefill_roof,
             "roofline": roof,
             "roofline_mfma": roof_mfma,

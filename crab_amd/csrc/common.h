@@ -39,7 +39,9 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // activations selectable in GEMM epilogues / elementwise kernels
-enum CrabAct { ACT_NONE = 0, ACT_GELU = 1, ACT_QUICK_GELU = 2, ACT_RELU = 3, ACT_SILU = 4 };
+// ACT_SWIGLU_PAIR: the weight rows are INTERLEAVED (gate_i, up_i): out[m, j] = silu(v[m, 2j]) * v[m, 2j+1], C has N/2 columns
+// (the SwiGLU of `down(silu(gate(x)) * up(x))`, modeling_llama.py:269, fused into the gate|up projection)
+enum CrabAct { ACT_NONE = 0, ACT_GELU = 1, ACT_QUICK_GELU = 2, ACT_RELU = 3, ACT_SILU = 4, ACT_SWIGLU_PAIR = 5 };
 
 __device__ __forceinline__ float apply_act(float x, int act) {
     switch (act) {

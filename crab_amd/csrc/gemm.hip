@@ -190,6 +190,14 @@ __global__ void splitk_epilogue_kernel(const float* __restrict__ part, int S, in
         for (int s = 0; s < S; ++s)
             for (int r = 0; r < w; ++r) v[r] += q[s * MN + r];
     }
+    if (act == ACT_SWIGLU_PAIR) {                         // interleaved (gate, up) columns -> N/2 outputs (N % 4 == 0, no residual)
+        if (bias) { for (int r = 0; r < 4; ++r) v[r] += bf2f(bias[n + r]); }
+        const float o0 = v[0] / (1.0f + __expf(-v[0])) * v[1], o1 = v[2] / (1.0f + __expf(-v[2])) * v[3];
+        const long oc = (long)m * ldc + (n >> 1);
+        if (c_fp32) { reinterpret_cast<float*>(C)[oc] = o0; reinterpret_cast<float*>(C)[oc + 1] = o1; }
+        else { reinterpret_cast<bf16_t*>(C)[oc] = f2bf(o0); reinterpret_cast<bf16_t*>(C)[oc + 1] = f2bf(o1); }
+        return;
+    }
     for (int r = 0; r < w; ++r) {
         float x = v[r];
         if (bias) x += bf2f(bias[n + r]);
@@ -281,6 +289,8 @@ extern "C" int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc*
     if (!ctx) return CRAB_E_INVALID;
     if (d && d->norm_w && (!d->norm_out || d->c_fp32 || d->batch > 1)) return crab_fail(ctx, CRAB_E_INVALID, "gemm: post-norm needs norm_out, bf16 C, no batch");
     if (!d || !d->A || !d->B || !d->C) return crab_fail(ctx, CRAB_E_INVALID, "gemm: null operand");
+    if (d->act == ACT_SWIGLU_PAIR && ((d->N & 3) || d->R || d->norm_w || d->batch > 1 || (d->ldc & 1)))
+        return crab_fail(ctx, CRAB_E_INVALID, "gemm: swiglu-pair epilogue needs N % 4 == 0, even ldc, no residual / post-norm / batch");
     if (d->M <= 0 || d->N <= 0 || d->K <= 0) return crab_fail(ctx, CRAB_E_INVALID, "gemm: non-positive dimension");
     if ((d->K & 7) || (d->lda & 7) || (d->ldb & 7)) return crab_fail(ctx, CRAB_E_INVALID, "gemm: K/lda/ldb must be multiples of 8");
     if (((uintptr_t)d->A & 15) || ((uintptr_t)d->B & 15)) return crab_fail(ctx, CRAB_E_INVALID, "gemm: A/B must be 16-byte aligned");

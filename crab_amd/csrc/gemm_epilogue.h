@@ -41,6 +41,15 @@ __device__ __forceinline__ void full_impl(const f32x4_t (&acc)[TN][TM], int m_la
         const long rowR = (long)(m_lane + mi * 16) * ldr + n_lane;
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni) {
+            if (ACT == ACT_SWIGLU_PAIR) {              // columns (gate, up, gate, up) -> two outputs at column n/2 (no residual)
+                const float g0 = acc[ni][mi][0] + bv[ni][0], u0 = acc[ni][mi][1] + bv[ni][1];
+                const float g1 = acc[ni][mi][2] + bv[ni][2], u1 = acc[ni][mi][3] + bv[ni][3];
+                const float o0 = g0 / (1.0f + __expf(-g0)) * u0, o1 = g1 / (1.0f + __expf(-g1)) * u1;
+                const long oc = coff + (long)(m_lane + mi * 16) * ldc + ((n_lane + ni * 16) >> 1);
+                if (c_fp32) *reinterpret_cast<float2*>(reinterpret_cast<float*>(Cv) + oc) = make_float2(o0, o1);
+                else *reinterpret_cast<uint32_t*>(reinterpret_cast<bf16_t*>(Cv) + oc) = pack_bf2(o0, o1);
+                continue;
+            }
             float v0 = act_c<ACT>(acc[ni][mi][0] + bv[ni][0]), v1 = act_c<ACT>(acc[ni][mi][1] + bv[ni][1]);
             float v2 = act_c<ACT>(acc[ni][mi][2] + bv[ni][2]), v3 = act_c<ACT>(acc[ni][mi][3] + bv[ni][3]);
             if (R) {
@@ -68,6 +77,7 @@ __device__ __forceinline__ void gemm_epilogue_full(const f32x4_t (&acc)[TN][TM],
         case ACT_GELU: crab_epi::full_impl<TM, TN, ACT_GELU>(acc, m_lane, n_lane, bias, R, ldr, rs, C, coff, ldc, c_fp32); break;
         case ACT_QUICK_GELU: crab_epi::full_impl<TM, TN, ACT_QUICK_GELU>(acc, m_lane, n_lane, bias, R, ldr, rs, C, coff, ldc, c_fp32); break;
         case ACT_RELU: crab_epi::full_impl<TM, TN, ACT_RELU>(acc, m_lane, n_lane, bias, R, ldr, rs, C, coff, ldc, c_fp32); break;
+        case ACT_SWIGLU_PAIR: crab_epi::full_impl<TM, TN, ACT_SWIGLU_PAIR>(acc, m_lane, n_lane, bias, R, ldr, rs, C, coff, ldc, c_fp32); break;
         default: crab_epi::full_impl<TM, TN, ACT_SILU>(acc, m_lane, n_lane, bias, R, ldr, rs, C, coff, ldc, c_fp32); break;
     }
 }
@@ -86,6 +96,16 @@ __device__ __forceinline__ void guarded_impl(const f32x4_t (&acc)[TN][TM], int m
         for (int ni = 0; ni < TN; ++ni) {
             const int n = n_lane + ni * 16;
             if (n >= N) continue;
+            if (ACT == ACT_SWIGLU_PAIR) {              // N % 4 == 0 is checked by the dispatcher: all four columns are in range
+                float t[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) t[r] = acc[ni][mi][r] + (bias ? bf2f(bias[n + r]) : 0.f);
+                const float o0 = t[0] / (1.0f + __expf(-t[0])) * t[1], o1 = t[2] / (1.0f + __expf(-t[2])) * t[3];
+                const long oc = coff + (long)m * ldc + (n >> 1);
+                if (c_fp32) { reinterpret_cast<float*>(Cv)[oc] = o0; reinterpret_cast<float*>(Cv)[oc + 1] = o1; }
+                else { reinterpret_cast<bf16_t*>(Cv)[oc] = f2bf(o0); reinterpret_cast<bf16_t*>(Cv)[oc + 1] = f2bf(o1); }
+                continue;
+            }
             float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -128,6 +148,7 @@ __device__ __forceinline__ void gemm_epilogue_guarded(const f32x4_t (&acc)[TN][T
         case ACT_GELU: crab_epi::guarded_impl<TM, TN, ACT_GELU>(acc, m_lane, n_lane, M, N, bias, R, ldr, rs, C, coff, ldc, c_fp32); break;
         case ACT_QUICK_GELU: crab_epi::guarded_impl<TM, TN, ACT_QUICK_GELU>(acc, m_lane, n_lane, M, N, bias, R, ldr, rs, C, coff, ldc, c_fp32); break;
         case ACT_RELU: crab_epi::guarded_impl<TM, TN, ACT_RELU>(acc, m_lane, n_lane, M, N, bias, R, ldr, rs, C, coff, ldc, c_fp32); break;
+        case ACT_SWIGLU_PAIR: crab_epi::guarded_impl<TM, TN, ACT_SWIGLU_PAIR>(acc, m_lane, n_lane, M, N, bias, R, ldr, rs, C, coff, ldc, c_fp32); break;
         default: crab_epi::guarded_impl<TM, TN, ACT_SILU>(acc, m_lane, n_lane, M, N, bias, R, ldr, rs, C, coff, ldc, c_fp32); break;
     }
 }

@@ -116,6 +116,16 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(SkinnyP p) {
         f32x4_t v = *reinterpret_cast<const f32x4_t*>(&red[0][t][l][0]);
 #pragma unroll
         for (int w = 1; w < SK_WAVES; ++w) v += *reinterpret_cast<const f32x4_t*>(&red[w][t][l][0]);
+        if (p.act == ACT_SWIGLU_PAIR) {                 // interleaved (gate, up) columns -> two outputs at column n/2
+            float t[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t[r] = v[r] + (p.bias ? bf2f(p.bias[n + r]) : 0.f);
+            const float o0 = t[0] / (1.0f + __expf(-t[0])) * t[1], o1 = t[2] / (1.0f + __expf(-t[2])) * t[3];
+            const long oc = (long)m * p.ldc + (n >> 1);
+            if (p.c_fp32) { reinterpret_cast<float*>(p.C)[oc] = o0; reinterpret_cast<float*>(p.C)[oc + 1] = o1; }
+            else { reinterpret_cast<bf16_t*>(p.C)[oc] = f2bf(o0); reinterpret_cast<bf16_t*>(p.C)[oc + 1] = f2bf(o1); }
+            continue;
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             if (n + r >= p.N) break;

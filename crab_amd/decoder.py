@@ -73,7 +73,8 @@ class MLP(nn.Module):
     def __init__(self, cfg: DecoderConfig, device):
         super().__init__()
         D, I = cfg.hidden_size, cfg.intermediate_size
-        self._gu = PackedLinearGroup(["gate_proj", "up_proj"], D, [I, I], False, device)
+        # gate / up rows interleaved: the gate|up GEMM epilogue applies SwiGLU itself (no [M, 2I] round trip, one launch less)
+        self._gu = PackedLinearGroup(["gate_proj", "up_proj"], D, [I, I], False, device, interleave=True)
         self._down = PackedLinearGroup(["down_proj"], I, [D], False, device)
         self.gate_proj, self.up_proj = self._gu.linears
         self.down_proj = self._down.linears[0]
@@ -131,7 +132,6 @@ class _Workspace:
         self.h = e(M, D)
         self.qkv = e(M, (H + 2 * Hk) * d)
         self.att = e(M, H * d)
-        self.gu = e(M, 2 * I)
         self.act = e(M, I)
         self.t = torch.empty((max(ops.hyperlora_route_workspace(M, max(D, I), max(t_cols, 16)), 16),), device=device, dtype=torch.uint8)
         self.u = e(M, max(u_cols, 32))
@@ -199,7 +199,7 @@ class GenerationEngine:
         c = self.cfg
         H, Hk, d = c.num_attention_heads, c.num_key_value_heads, c.head_dim
         M = B * S
-        x, h, qkv, att, gu, act = ws.x[:M], ws.h[:M], ws.qkv[:M], ws.att[:M], ws.gu[:M], ws.act[:M]
+        x, h, qkv, att, act = ws.x[:M], ws.h[:M], ws.qkv[:M], ws.att[:M], ws.act[:M]
         tab = self._rope_tab(Tmax)
         scale = 1.0 / math.sqrt(d)
         ldq = qkv.stride(0)
@@ -219,8 +219,7 @@ class GenerationEngine:
                 ops.attn_decode(qkv, kcl, vcl, att, B, H, Hk, d, Tmax, 1, scale, ctx_dev=pos_dev)
             # x += o_proj(att); h = rmsnorm(x) * post_attention_layernorm  (norm fused into the GEMM epilogue for small M)
             a._o(att, residual=x, out=x, t_buf=ws.t, u_buf=ws.u, post_norm=(layer.post_attention_layernorm.weight, c.rms_norm_eps, h))
-            m._gu(h, out=gu, t_buf=ws.t, u_buf=ws.u)
-            ops.swiglu(gu, out=act)
+            m._gu(h, out=act, t_buf=ws.t, u_buf=ws.u, act="swiglu_pair")              # act = silu(gate(h)) * up(h)
             # x += down(act); h = rmsnorm(x) * (next layer's input_layernorm | the final model.norm)
             nxt = layers[li + 1].input_layernorm.weight if li + 1 < len(layers) else self.model.norm.weight
             m._down(act, residual=x, out=x, t_buf=ws.t, u_buf=ws.u, post_norm=(nxt, c.rms_norm_eps, h))

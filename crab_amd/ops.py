@@ -13,7 +13,7 @@ import torch
 from . import _lib
 from ._lib import AttnDesc, GemmDesc
 
-ACT = {"none": 0, None: 0, "gelu": 1, "quick_gelu": 2, "relu": 3, "silu": 4}
+ACT = {"none": 0, None: 0, "gelu": 1, "quick_gelu": 2, "relu": 3, "silu": 4, "swiglu_pair": 5}
 BF16 = torch.bfloat16
 
 
@@ -115,14 +115,15 @@ def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
          residual: Optional[torch.Tensor] = None, res_scale: float = 1.0, x2: Optional[torch.Tensor] = None,
          w2: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, out_fp32: bool = False, tune: int = 0,
          post_norm=None) -> torch.Tensor:
-    """out[M,N] = res_scale*residual + act(x[M,K] @ w[N,K]^T + x2 @ w2^T + bias).  2-D row-strided operands."""
+    """out[M,N] = res_scale*residual + act(x[M,K] @ w[N,K]^T + x2 @ w2^T + bias).  2-D row-strided operands.
+    act == "swiglu_pair": w rows are interleaved (gate_i, up_i) and out is [M, N/2] = silu(gate) * up."""
     _chk_bf16(x, w, bias, residual, x2, w2)
     d = _dev(x)
     M, K = x.shape
     N = w.shape[0]
     assert w.shape[1] == K and x.stride(1) == 1 and w.stride(1) == 1
     if out is None:
-        out = torch.empty((M, N), device=x.device, dtype=torch.float32 if out_fp32 else BF16)
+        out = torch.empty((M, N // 2 if act == "swiglu_pair" else N), device=x.device, dtype=torch.float32 if out_fp32 else BF16)
     g = GemmDesc()
     g.A, g.B, g.C = x.data_ptr(), w.data_ptr(), out.data_ptr()
     g.bias = bias.data_ptr() if bias is not None else None

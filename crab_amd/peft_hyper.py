@@ -66,9 +66,9 @@ class Linear(nn.Module):
         self._index = index
         n0, n1 = group.row_range(index)
         self.in_features, self.out_features = group.K, n1 - n0
-        self.weight = nn.Parameter(group.W[n0:n1], requires_grad=False)
+        self.weight = nn.Parameter(group.rows(group.W, index), requires_grad=False)
         if group.bias is not None:
-            self.bias = nn.Parameter(group.bias[n0:n1], requires_grad=False)
+            self.bias = nn.Parameter(group.rows(group.bias, index), requires_grad=False)
         else:
             self.register_parameter("bias", None)
         self.r = 0
@@ -82,7 +82,7 @@ class Linear(nn.Module):
         self.lora_route = _W(g.RA[base:base + nl])
         self.lora_A = _W(g.RA[base + nl:base + nl + r])
         for i in range(nl):
-            setattr(self, f"lora_B{i}", _W(g.B2[n0:n1, p * nl * r + i * r: p * nl * r + (i + 1) * r]))
+            setattr(self, f"lora_B{i}", _W(g.rows(g.B2, p)[:, p * nl * r + i * r: p * nl * r + (i + 1) * r]))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """Standalone use (tests / odd callers): runs the group's fused path and slices this projection."""
@@ -90,16 +90,23 @@ class Linear(nn.Module):
         n0, n1 = g.row_range(self._index)
         shp = x.shape
         y = g(x.reshape(-1, shp[-1]))
-        return y[:, n0:n1].reshape(*shp[:-1], n1 - n0)
+        return g.rows(y.t(), self._index).t().reshape(*shp[:-1], n1 - n0)
 
 
 class PackedLinearGroup:
     """Linears sharing one input, packed for the fused hyper-LoRA GEMM.  Not an nn.Module: its member
     `Linear`s own the Parameters (as views).  `__call__(x[M,K]) -> y[M, sum N_i]` launches the HIP path."""
 
-    def __init__(self, names: Sequence[str], in_features: int, out_features: Sequence[int], bias: bool, device, dtype=BF16):
+    def __init__(self, names: Sequence[str], in_features: int, out_features: Sequence[int], bias: bool, device, dtype=BF16,
+                 interleave: bool = False):
+        """interleave: the rows of two equal-width members alternate (gate_0, up_0, gate_1, ...) instead of being
+        stacked, so that the GEMM epilogue sees (gate_i, up_i) in adjacent columns and can apply SwiGLU itself
+        (`__call__(..., act="swiglu_pair")`).  The member Parameters are then stride-2 row views."""
         if dtype != BF16:
             raise ValueError("the MI355X path stores weights in bfloat16")
+        if interleave and (len(names) != 2 or out_features[0] != out_features[1]):
+            raise ValueError("interleave needs two members of equal width")
+        self.interleave = interleave
         self.names = list(names)
         self.K = in_features
         self.outs = list(out_features)
@@ -114,6 +121,13 @@ class PackedLinearGroup:
     def row_range(self, i: int):
         n0 = sum(self.outs[:i])
         return n0, n0 + self.outs[i]
+
+    def rows(self, t: torch.Tensor, i: int) -> torch.Tensor:
+        """The rows of packed tensor `t` ([N, ...]) that belong to member i (a view)."""
+        if self.interleave:
+            return t[i::2]
+        n0, n1 = self.row_range(i)
+        return t[n0:n1]
 
     def attach_lora(self, r: int, lora_alpha: int, lora_nums: int):
         nproj = len(self.names)
@@ -132,24 +146,26 @@ class PackedLinearGroup:
             return None if t is None else t.to(device)
         self.W, self.bias, self.RA, self.B2 = mv(self.W), mv(self.bias), mv(self.RA), mv(self.B2)
         for i, lin in enumerate(self.linears):
-            n0, n1 = self.row_range(i)
-            lin.weight = nn.Parameter(self.W[n0:n1], requires_grad=False)
+            lin.weight = nn.Parameter(self.rows(self.W, i), requires_grad=False)
             if self.bias is not None:
-                lin.bias = nn.Parameter(self.bias[n0:n1], requires_grad=False)
+                lin.bias = nn.Parameter(self.rows(self.bias, i), requires_grad=False)
             if self.RA is not None:
                 lin._attach_lora()
 
     def __call__(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-                 t_buf: Optional[torch.Tensor] = None, u_buf: Optional[torch.Tensor] = None, post_norm=None) -> torch.Tensor:
+                 t_buf: Optional[torch.Tensor] = None, u_buf: Optional[torch.Tensor] = None, post_norm=None, act: str = "none") -> torch.Tensor:
         """y = group(x) (+residual).  post_norm = (rms_weight, eps, h_out): additionally h_out = rmsnorm(y) * rms_weight
-        (the LlamaRMSNorm that follows o_proj / down_proj), fused into the GEMM epilogue in the decode regime."""
+        (the LlamaRMSNorm that follows o_proj / down_proj), fused into the GEMM epilogue in the decode regime.
+        act = "swiglu_pair" (interleaved groups): returns silu(member0(x)) * member1(x), [M, N/2]."""
         M = x.shape[0]
+        if act == "swiglu_pair" and not self.interleave:
+            raise ValueError("swiglu_pair needs an interleaved group")
         if self.RA is None:
-            return ops.gemm(x, self.W, bias=self.bias, residual=residual, out=out, post_norm=post_norm)
+            return ops.gemm(x, self.W, bias=self.bias, residual=residual, out=out, post_norm=post_norm, act=act)
         u = u_buf[:M, :self.u_cols] if u_buf is not None else torch.empty((M, self.u_cols), device=x.device, dtype=BF16)
         # route logits | lora_A(x) -> softmax mix, K split over blocks (skinny.hip); t_buf is the partial-sum workspace
         ops.hyperlora_route(x, self.RA, len(self.names), self.nl, self.r, self.u_cols, self.scaling, out=u, workspace=t_buf)
-        return ops.gemm(x, self.W, bias=self.bias, residual=residual, x2=u, w2=self.B2, out=out, post_norm=post_norm)
+        return ops.gemm(x, self.W, bias=self.bias, residual=residual, x2=u, w2=self.B2, out=out, post_norm=post_norm, act=act)
 
 
 class PeftModelForCausalLM(nn.Module):

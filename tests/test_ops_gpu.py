@@ -378,6 +378,27 @@ def test_gemm_fused_post_rmsnorm(M, N):
     _cmp(h, O.rmsnorm(xd.cpu().float(), nw.float(), 1e-5, emulate=BF), 1e-2, "post-norm")
 
 
+@pytest.mark.parametrize("M,tune", [(5, 0), (16, 0), (64, 0), (200, 0), (256, 0), (700, 0), (1500, 302), (1500, 301), (1500, 300)])
+def test_gemm_swiglu_pair_epilogue(M, tune):
+    """Interleaved (gate_i, up_i) weight rows + SwiGLU in the GEMM epilogue == silu(x Wg^T) * (x Wu^T) in every kernel
+    regime (skinny, split-K + reduction kernel, 128^2 two-stage, 256^2 ring, register-staged), with the LoRA K segment."""
+    from crab_amd import ops
+    K, I, K2 = 512, 1376, 32
+    x, wg, wu = _rand(M, K, seed=1), _rand(I, K, seed=2, scale=K ** -0.5), _rand(I, K, seed=3, scale=K ** -0.5)
+    x2, bg, bu = _rand(M, K2, seed=4), _rand(I, K2, seed=5, scale=0.1), _rand(I, K2, seed=6, scale=0.1)
+    w = torch.stack([wg, wu], 1).reshape(2 * I, K).contiguous()
+    w2 = torch.stack([bg, bu], 1).reshape(2 * I, K2).contiguous()
+    y = ops.gemm(x.cuda(), w.cuda(), x2=x2.cuda(), w2=w2.cuda(), act="swiglu_pair", tune=tune)
+    assert y.shape == (M, I)
+    g = x.float() @ wg.float().t() + x2.float() @ bg.float().t()
+    u = x.float() @ wu.float().t() + x2.float() @ bu.float().t()
+    _cmp(y, F.silu(g) * u, 1.2e-2, "swiglu pair")
+    y32 = ops.gemm(x.cuda(), w.cuda(), x2=x2.cuda(), w2=w2.cuda(), act="swiglu_pair", out_fp32=True, tune=tune)
+    _cmp(y32, F.silu(g) * u, 3e-3, "swiglu pair fp32")
+    with pytest.raises(Exception):
+        ops.gemm(x.cuda(), w.cuda(), act="swiglu_pair", residual=y)          # no residual with the pair epilogue
+
+
 @pytest.mark.parametrize("tune", [302, 303])
 @pytest.mark.parametrize("M,N,K,K2", [(2808, 4096, 1024, 96), (1100, 1300, 520, 0), (5616, 2048, 256, 32), (6000, 11000, 72, 0),
                                       (300, 256, 4096, 0)])
