@@ -30,6 +30,8 @@ class GemmDesc(C.Structure):
         ("sC1", C.c_int64), ("sR0", C.c_int64), ("sR1", C.c_int64), ("sBias0", C.c_int64), ("sBias1", C.c_int64),
         ("tune", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
         ("norm_w", C.c_void_p), ("norm_out", C.c_void_p), ("ld_norm", C.c_int64), ("norm_eps", C.c_float),
+        ("rope_tab", C.c_void_p), ("rope_k_cache", C.c_void_p), ("rope_v_cache", C.c_void_p), ("rope_pos_dev", C.c_void_p),
+        ("rope_H", C.c_int32), ("rope_Hk", C.c_int32), ("rope_d", C.c_int32), ("rope_Tmax", C.c_int32), ("rope_pos0", C.c_int32),
     ]
 
 

@@ -53,6 +53,12 @@ __device__ __forceinline__ float apply_act(float x, int act) {
     }
 }
 
+// RoPE rotation of one (x1, x2) = (x[i], x[i + d/2]) pair, fp32, with the operation order PINNED (one product rounded, then one
+// fma): every kernel that rotates (prefill tile kernel, decode kernel, the fused q|k|v split-K reduction) must produce
+// bit-identical q / k for identical inputs, and the compiler's free choice of which product to contract differs per kernel.
+__device__ __forceinline__ float rope_lo(float x1, float x2, float c, float sn) { return __fmaf_rn(x1, c, -__fmul_rn(x2, sn)); }
+__device__ __forceinline__ float rope_hi(float x1, float x2, float c, float sn) { return __fmaf_rn(x2, c, __fmul_rn(x1, sn)); }
+
 // bijective XCD-aware block remap: consecutive logical ids land on the same XCD (private L2),
 // valid for any grid size (cdna guide 5.5 T1 bijective form).  Placement is a speed hint only.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

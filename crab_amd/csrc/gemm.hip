@@ -279,8 +279,71 @@ __global__ __launch_bounds__(256) void splitk_epilogue_norm_kernel(const float* 
 int crab_gemm_skinny_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* d);   // skinny.hip
 int crab_gemm_glds_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* d, int splitk, float* part);     // gemm_glds.hip
 
+
+// Split-K reduction of the packed q|k|v projection fused with RoPE and the KV-cache append (decode: one row per sequence).
+// One thread per (row, head, 4 dims of the first half): it also owns the matching 4 dims of the second half, i.e. the
+// rotation partners.  Sums are rounded to bf16 before the rotation, exactly like the unfused pair (reduction kernel ->
+// bf16 C -> qkv_rope_split_kernel), so prefill and decode see identical k / q values for identical inputs.
+__global__ __launch_bounds__(256) void splitk_epilogue_rope_kernel(const float* __restrict__ part, int S, int M, int N,
+                                                                    const bf16_t* __restrict__ bias, bf16_t* __restrict__ C, long ldc,
+                                                                    const float* __restrict__ tab, bf16_t* __restrict__ kc,
+                                                                    bf16_t* __restrict__ vc, const int* __restrict__ pos_dev, int pos0,
+                                                                    int H, int Hk, int d, int Tmax) {
+    const int half = d >> 1, gpd = half >> 2;                   // 4-dim groups per half head
+    const int nh = H + 2 * Hk;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)M * nh * gpd) return;
+    const int j = (int)(idx % gpd);
+    const int hh = (int)((idx / gpd) % nh);
+    const int m = (int)(idx / ((long)gpd * nh));
+    const int n1 = hh * d + 4 * j, n2 = n1 + half;
+    const long MN = (long)M * N;
+    const float* q = part + (long)m * N;
+    f32x4_t a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < S; ++s) {
+        a += *reinterpret_cast<const f32x4_t*>(q + s * MN + n1);
+        b += *reinterpret_cast<const f32x4_t*>(q + s * MN + n2);
+    }
+    float x1[4], x2[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        x1[r] = bf2f(f2bf(a[r] + (bias ? bf2f(bias[n1 + r]) : 0.f)));
+        x2[r] = bf2f(f2bf(b[r] + (bias ? bf2f(bias[n2 + r]) : 0.f)));
+    }
+    const int pos = (pos_dev ? pos_dev[0] : 0) + pos0;
+    bf16_t* dst1; bf16_t* dst2;
+    if (hh < H) { dst1 = C + (long)m * ldc + n1; dst2 = C + (long)m * ldc + n2; }
+    else {
+        const int hk = (hh - H) % Hk;
+        bf16_t* cache = hh < H + Hk ? kc : vc;
+        dst1 = cache + (((long)m * Hk + hk) * Tmax + pos) * d + 4 * j;
+        dst2 = dst1 + half;
+    }
+    float o1[4], o2[4];
+    if (hh < H + Hk) {
+        const float* t = tab + 2 * ((long)pos * half + 4 * j);   // (cos, sin) pairs of dims 4j .. 4j+3
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float c = t[2 * r], sn = t[2 * r + 1];
+            o1[r] = rope_lo(x1[r], x2[r], c, sn);
+            o2[r] = rope_hi(x1[r], x2[r], c, sn);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { o1[r] = x1[r]; o2[r] = x2[r]; }
+    }
+    u32x2 w1, w2;
+    w1.x = pack_bf2(o1[0], o1[1]); w1.y = pack_bf2(o1[2], o1[3]);
+    w2.x = pack_bf2(o2[0], o2[1]); w2.y = pack_bf2(o2[2], o2[3]);
+    *reinterpret_cast<u32x2*>(dst1) = w1;
+    *reinterpret_cast<u32x2*>(dst2) = w2;
+}
+
 // unfused form of the optional post-RMSNorm (paths whose epilogue does not own whole rows)
 static int post_norm(crab_ctx* ctx, void* stream, const crab_gemm_desc* d) {
+    if (d->rope_tab)          // paths whose epilogue did not fuse the RoPE / KV append: the separate pass over C
+        return crab_qkv_rope_split(ctx, stream, d->C, d->ldc, d->rope_tab, d->rope_k_cache, d->rope_v_cache, nullptr, 0, d->M, 1, d->rope_H,
+                                   d->rope_Hk, d->rope_d, d->rope_Tmax, d->rope_pos0, d->rope_pos_dev);
     if (!d->norm_w) return CRAB_OK;
     return crab_rmsnorm(ctx, stream, d->C, d->ldc, d->norm_w, d->norm_out, d->ld_norm, d->M, d->N, d->norm_eps);
 }
@@ -289,6 +352,11 @@ extern "C" int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc*
     if (!ctx) return CRAB_E_INVALID;
     if (d && d->norm_w && (!d->norm_out || d->c_fp32 || d->batch > 1)) return crab_fail(ctx, CRAB_E_INVALID, "gemm: post-norm needs norm_out, bf16 C, no batch");
     if (!d || !d->A || !d->B || !d->C) return crab_fail(ctx, CRAB_E_INVALID, "gemm: null operand");
+    if (d->rope_tab) {
+        if (d->c_fp32 || d->act != ACT_NONE || d->R || d->norm_w || d->batch > 1 || !d->rope_k_cache || !d->rope_v_cache ||
+            d->rope_H <= 0 || d->rope_Hk <= 0 || d->rope_d <= 0 || d->N != (d->rope_H + 2 * d->rope_Hk) * d->rope_d)
+            return crab_fail(ctx, CRAB_E_INVALID, "gemm: fused rope needs bf16 C, N == (H + 2 Hk) d, caches, no act / residual / post-norm / batch");
+    }
     if (d->act == ACT_SWIGLU_PAIR && ((d->N & 3) || d->R || d->norm_w || d->batch > 1 || (d->ldc & 1)))
         return crab_fail(ctx, CRAB_E_INVALID, "gemm: swiglu-pair epilogue needs N % 4 == 0, even ldc, no residual / post-norm / batch");
     if (d->M <= 0 || d->N <= 0 || d->K <= 0) return crab_fail(ctx, CRAB_E_INVALID, "gemm: non-positive dimension");
@@ -373,6 +441,13 @@ extern "C" int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc*
         int rc = crab_check_launch(ctx, "gemm_bt_kernel(split-K)");
         if (rc) return rc;
         if (splitk == 1) return post_norm(ctx, stream, d);
+        if (d->rope_tab && (d->rope_d & 7) == 0 && (d->ldc & 3) == 0 && (d->N & 3) == 0) {
+            const long nthr = (long)d->M * (d->rope_H + 2 * d->rope_Hk) * (d->rope_d >> 3);
+            hipLaunchKernelGGL(splitk_epilogue_rope_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, p.part, splitk, d->M, d->N, p.bias,
+                               (bf16_t*)d->C, (long)d->ldc, d->rope_tab, (bf16_t*)d->rope_k_cache, (bf16_t*)d->rope_v_cache, d->rope_pos_dev,
+                               d->rope_pos0, d->rope_H, d->rope_Hk, d->rope_d, d->rope_Tmax);
+            return crab_check_launch(ctx, "splitk_epilogue_rope_kernel");
+        }
         if (d->norm_w && !d->c_fp32 && (d->N & 3) == 0 && d->N <= 8192 && (d->ldc & 3) == 0 && (d->ld_norm & 3) == 0 &&
             (!d->R || (d->ldr & 3) == 0)) {
             hipLaunchKernelGGL(splitk_epilogue_norm_kernel, dim3(d->M), dim3(256), 0, s, p.part, splitk, d->M, d->N, p.bias, d->act, p.R,

@@ -125,8 +125,8 @@ __global__ void qkv_rope_split_kernel(bf16_t* __restrict__ qkv, long ldqkv, cons
         if (tab) {
             float c = tab[2 * ((long)pos * half + i)], sn = tab[2 * ((long)pos * half + i) + 1];
             // q*cos + rotate_half(q)*sin, each product rounded as in the bf16 reference? fp32 here, one rounding
-            o1 = x1 * c - x2 * sn;
-            o2 = x2 * c + x1 * sn;
+            o1 = rope_lo(x1, x2, c, sn);
+            o2 = rope_hi(x1, x2, c, sn);
         }
         if (hh < H) {
             src[i] = f2bf(o1);
@@ -184,8 +184,8 @@ __global__ __launch_bounds__(256) void qkv_rope_split_tile_kernel(bf16_t* __rest
                 for (int e = 0; e < 4; ++e) {
                     float x1a = lo_bf(lo[e]), x1b = hi_bf(lo[e]), x2a = lo_bf(hi[e]), x2b = hi_bf(hi[e]);
                     float ca = cs[4 * e], sa = cs[4 * e + 1], cb = cs[4 * e + 2], sb = cs[4 * e + 3];
-                    olo[e] = pack_bf2(x1a * ca - x2a * sa, x1b * cb - x2b * sb);
-                    ohi[e] = pack_bf2(x2a * ca + x1a * sa, x2b * cb + x1b * sb);
+                    olo[e] = pack_bf2(rope_lo(x1a, x2a, ca, sa), rope_lo(x1b, x2b, cb, sb));
+                    ohi[e] = pack_bf2(rope_hi(x1a, x2a, ca, sa), rope_hi(x1b, x2b, cb, sb));
                 }
             }
             bf16_t* dst = hh < H ? src : kc + (((long)b * Hk + hk) * Tmax + pos) * D + c * 8;

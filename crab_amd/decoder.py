@@ -208,8 +208,12 @@ class GenerationEngine:
         for li, layer in enumerate(layers):
             a, m = layer.self_attn, layer.mlp
             kcl, vcl = kc[li, b0:b0 + B], vc[li, b0:b0 + B]
-            a._qkv(h, out=qkv, t_buf=ws.t, u_buf=ws.u)
-            ops.qkv_rope_split(qkv, tab, kcl, vcl, vt, B, S, H, Hk, d, Tmax, pos0=pos0, pos_dev=pos_dev)
+            if vt is None and S == 1 and kcl.is_contiguous():
+                # decode: RoPE + KV append ride on the q|k|v projection (fused into its split-K reduction when it has one)
+                a._qkv(h, out=qkv, t_buf=ws.t, u_buf=ws.u, rope=(tab, kcl, vcl, H, Hk, d, Tmax, pos0, pos_dev))
+            else:
+                a._qkv(h, out=qkv, t_buf=ws.t, u_buf=ws.u)
+                ops.qkv_rope_split(qkv, tab, kcl, vcl, vt, B, S, H, Hk, d, Tmax, pos0=pos0, pos_dev=pos_dev)
             if vt is not None:
                 Sp = vt.shape[-1]
                 ops.attn_fwd(qkv, kcl, vt, att, q_strides=(S * ldq, d, ldq), k_strides=(Hk * Tmax * d, Tmax * d, d),

@@ -153,7 +153,7 @@ class PackedLinearGroup:
                 lin._attach_lora()
 
     def __call__(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-                 t_buf: Optional[torch.Tensor] = None, u_buf: Optional[torch.Tensor] = None, post_norm=None, act: str = "none") -> torch.Tensor:
+                 t_buf: Optional[torch.Tensor] = None, u_buf: Optional[torch.Tensor] = None, post_norm=None, act: str = "none", rope=None) -> torch.Tensor:
         """y = group(x) (+residual).  post_norm = (rms_weight, eps, h_out): additionally h_out = rmsnorm(y) * rms_weight
         (the LlamaRMSNorm that follows o_proj / down_proj), fused into the GEMM epilogue in the decode regime.
         act = "swiglu_pair" (interleaved groups): returns silu(member0(x)) * member1(x), [M, N/2]."""
@@ -161,11 +161,11 @@ class PackedLinearGroup:
         if act == "swiglu_pair" and not self.interleave:
             raise ValueError("swiglu_pair needs an interleaved group")
         if self.RA is None:
-            return ops.gemm(x, self.W, bias=self.bias, residual=residual, out=out, post_norm=post_norm, act=act)
+            return ops.gemm(x, self.W, bias=self.bias, residual=residual, out=out, post_norm=post_norm, act=act, rope=rope)
         u = u_buf[:M, :self.u_cols] if u_buf is not None else torch.empty((M, self.u_cols), device=x.device, dtype=BF16)
         # route logits | lora_A(x) -> softmax mix, K split over blocks (skinny.hip); t_buf is the partial-sum workspace
         ops.hyperlora_route(x, self.RA, len(self.names), self.nl, self.r, self.u_cols, self.scaling, out=u, workspace=t_buf)
-        return ops.gemm(x, self.W, bias=self.bias, residual=residual, x2=u, w2=self.B2, out=out, post_norm=post_norm, act=act)
+        return ops.gemm(x, self.W, bias=self.bias, residual=residual, x2=u, w2=self.B2, out=out, post_norm=post_norm, act=act, rope=rope)
 
 
 class PeftModelForCausalLM(nn.Module):

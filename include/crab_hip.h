@@ -67,6 +67,13 @@ typedef struct {
     int64_t workspace_bytes;
     /* optional fused post-RMSNorm: norm_out[M,N] = rmsnorm(C) * norm_w (LlamaRMSNorm behind o_proj / down_proj); bf16 C only */
     const void* norm_w; void* norm_out; int64_t ld_norm; float norm_eps;
+    /* optional fused RoPE + KV-cache append behind the packed q|k|v projection, ONE ROW PER SEQUENCE (decode): the result
+     * is what crab_gemm_bf16 followed by crab_qkv_rope_split(B = M, S = 1) on C would leave - C[:, :H*d] = RoPE(q), the
+     * k / v rows stored at k_cache / v_cache[b, hk, pos, :], pos = rope_pos0 + rope_pos_dev[0] (modeling_llama.py:204-236,
+     * 408-412) - in the split-K regime without a separate pass over C.  rope_tab == NULL disables it.  Needs
+     * N == (rope_H + 2*rope_Hk) * rope_d, bf16 C, no activation / residual / post-norm. */
+    const float* rope_tab; void* rope_k_cache; void* rope_v_cache; const int32_t* rope_pos_dev;
+    int32_t rope_H, rope_Hk, rope_d, rope_Tmax, rope_pos0;
 } crab_gemm_desc;
 
 int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc* d);

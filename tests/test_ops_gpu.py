@@ -378,6 +378,33 @@ def test_gemm_fused_post_rmsnorm(M, N):
     _cmp(h, O.rmsnorm(xd.cpu().float(), nw.float(), 1e-5, emulate=BF), 1e-2, "post-norm")
 
 
+@pytest.mark.parametrize("M", [3, 40, 256])
+@pytest.mark.parametrize("H,Hk,bias", [(4, 4, False), (8, 2, True)])
+def test_gemm_fused_rope_kv_append_equals_unfused_pair(M, H, Hk, bias):
+    """q|k|v projection with the fused RoPE + KV-cache append (decode: one row per sequence) must leave exactly what the
+    projection followed by qkv_rope_split(S = 1) leaves: skinny kernel (fallback pass), split-K + fused reduction kernel."""
+    from crab_amd import ops
+    d, K, Tmax, K2 = 128, 1024, 64, 32
+    N = (H + 2 * Hk) * d
+    x, w = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=K ** -0.5)
+    x2, w2 = _rand(M, K2, seed=3), _rand(N, K2, seed=4, scale=0.1)
+    b = _rand(N, seed=5).cuda() if bias else None
+    tab = ops.rope_table(Tmax, d, 10000.0, "cuda")
+    pos = torch.tensor([17], dtype=torch.int32, device="cuda")
+    outs = []
+    for fused in (False, True):
+        kc = torch.zeros(M, Hk, Tmax, d, dtype=BF, device="cuda")
+        vc = torch.zeros_like(kc)
+        rope = (tab, kc, vc, H, Hk, d, Tmax, 0, pos)
+        y = ops.gemm(x.cuda(), w.cuda(), bias=b, x2=x2.cuda(), w2=w2.cuda(), rope=rope if fused else None)
+        if not fused:
+            ops.qkv_rope_split(y, tab, kc, vc, None, M, 1, H, Hk, d, Tmax, pos0=0, pos_dev=pos)
+        outs.append((y[:, :H * d].clone(), kc, vc))
+    for a, b_ in zip(outs[0], outs[1]):
+        assert torch.equal(a, b_)
+    assert outs[1][1][:, :, 17].abs().sum() > 0 and outs[1][1][:, :, 16].abs().sum() == 0
+
+
 @pytest.mark.parametrize("M,tune", [(5, 0), (16, 0), (64, 0), (200, 0), (256, 0), (700, 0), (1500, 302), (1500, 301), (1500, 300)])
 def test_gemm_swiglu_pair_epilogue(M, tune):
     """Interleaved (gate_i, up_i) weight rows + SwiGLU in the GEMM epilogue == silu(x Wg^T) * (x Wu^T) in every kernel
