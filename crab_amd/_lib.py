@@ -32,6 +32,8 @@ class GemmDesc(C.Structure):
         ("norm_w", C.c_void_p), ("norm_out", C.c_void_p), ("ld_norm", C.c_int64), ("norm_eps", C.c_float),
         ("rope_tab", C.c_void_p), ("rope_k_cache", C.c_void_p), ("rope_v_cache", C.c_void_p), ("rope_pos_dev", C.c_void_p),
         ("rope_H", C.c_int32), ("rope_Hk", C.c_int32), ("rope_d", C.c_int32), ("rope_Tmax", C.c_int32), ("rope_pos0", C.c_int32),
+        ("route_RA", C.c_void_p), ("route_U", C.c_void_p), ("route_ldra", C.c_int64), ("route_ldu", C.c_int64),
+        ("route_nproj", C.c_int32), ("route_nl", C.c_int32), ("route_r", C.c_int32), ("route_ucols", C.c_int32), ("route_scaling", C.c_float),
     ]
 
 

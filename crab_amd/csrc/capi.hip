@@ -4,7 +4,7 @@
 
 extern "C" {
 
-int crab_abi_version(void) { return 2; }   // 2: crab_gemm_desc gained the fused RoPE / KV-append fields
+int crab_abi_version(void) { return 3; }   // 2: fused RoPE / KV-append fields in crab_gemm_desc; 3: next-group router fields
 
 int crab_ctx_create(int device, crab_ctx** out) {
     if (!out) return CRAB_E_INVALID;

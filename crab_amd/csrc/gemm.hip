@@ -208,13 +208,18 @@ __global__ void splitk_epilogue_kernel(const float* __restrict__ part, int S, in
     }
 }
 
+struct RouteP {                                   // router of the next projection group (crab_gemm_desc.route_*)
+    const bf16_t* RA; bf16_t* U; long ldra, ldu; int nproj, nl, r, ucols; float scaling;
+};
+
 // Row-owning variant of the split-K epilogue: one block per output row sums the K-slice partials (fixed order), applies
 // bias / activation / residual, writes C (bf16) AND the RMS-normalised row rmsnorm(C)*w for the next projection
 // (LlamaRMSNorm, modeling_llama.py:112-117, fused behind o_proj / down_proj in the decode regime).  N <= 8192.
 __global__ __launch_bounds__(256) void splitk_epilogue_norm_kernel(const float* __restrict__ part, int S, int M, int N,
                                                                     const bf16_t* __restrict__ bias, int act, const bf16_t* __restrict__ R,
                                                                     long ldr, float res_scale, bf16_t* __restrict__ C, long ldc,
-                                                                    const bf16_t* __restrict__ nw, float eps, bf16_t* __restrict__ H, long ldh) {
+                                                                    const bf16_t* __restrict__ nw, float eps, bf16_t* __restrict__ H, long ldh,
+                                                                    RouteP rt) {
     __shared__ float red[4];
     const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long MN = (long)M * N;
@@ -271,8 +276,61 @@ __global__ __launch_bounds__(256) void splitk_epilogue_norm_kernel(const float* 
             u32x2 o;
             o[0] = pack_bf2(h4[0], h4[1]); o[1] = pack_bf2(h4[2], h4[3]);
             *reinterpret_cast<u32x2*>(H + (long)m * ldh + n) = o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xv[q][r] = bf2f(f2bf(h4[r]));          // the router sees the stored bf16 row
         }
     }
+    if (!rt.RA) return;
+    // ---- hyper-LoRA router of the next projection group on this row (peft_hyper/tuners/lora.py:346-350): t = h . [R;A]^T,
+    // u = scaling * softmax(t_route) (x) t_A.  Partials per thread -> LDS -> fixed-order sums (deterministic).
+    __shared__ float tp[64][257];
+    __shared__ float tq[64][4];
+    __shared__ float T[64];
+    const int tcols = ((rt.nproj * (rt.nl + rt.r) + 15) / 16) * 16;
+    for (int c0 = 0; c0 < tcols; c0 += 16) {                 // 16 router rows per trip: 16 x MAXQ independent loads in flight
+        float p[16];
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc) p[cc] = 0.f;
+#pragma unroll
+        for (int q = 0; q < MAXQ; ++q) {
+            const int n = (tid + q * 256) * 4;
+            if (n < N) {
+                u32x2 w[16];
+#pragma unroll
+                for (int cc = 0; cc < 16; ++cc) w[cc] = *reinterpret_cast<const u32x2*>(rt.RA + (long)(c0 + cc) * rt.ldra + n);
+#pragma unroll
+                for (int cc = 0; cc < 16; ++cc)
+                    p[cc] += xv[q][0] * lo_bf(w[cc][0]) + xv[q][1] * hi_bf(w[cc][0]) + xv[q][2] * lo_bf(w[cc][1]) + xv[q][3] * hi_bf(w[cc][1]);
+            }
+        }
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc) tp[c0 + cc][tid] = p[cc];
+    }
+    __syncthreads();
+    if (tid < tcols * 4) {
+        const int c = tid >> 2, qt = tid & 3;
+        float a = 0.f;
+        for (int i = qt * 64; i < qt * 64 + 64; ++i) a += tp[c][i];
+        tq[c][qt] = a;
+    }
+    __syncthreads();
+    if (tid < tcols) T[tid] = (tq[tid][0] + tq[tid][1]) + (tq[tid][2] + tq[tid][3]);
+    __syncthreads();
+    if (tid > rt.nproj) return;
+    bf16_t* u = rt.U + (long)m * rt.ldu;
+    const int used = rt.nproj * rt.nl * rt.r;
+    if (tid == rt.nproj) {
+        for (int c = used; c < rt.ucols; ++c) u[c] = 0;
+        return;
+    }
+    const float* t = &T[tid * (rt.nl + rt.r)];
+    float e[8], mx = -INFINITY;
+    for (int i = 0; i < rt.nl; ++i) mx = fmaxf(mx, t[i]);
+    float sum = 0.f;
+    for (int i = 0; i < rt.nl; ++i) { e[i] = expf(t[i] - mx); sum += e[i]; }
+    const float inv = 1.0f / sum;
+    for (int i = 0; i < rt.nl; ++i)
+        for (int j = 0; j < rt.r; ++j) u[tid * rt.nl * rt.r + i * rt.r + j] = f2bf(rt.scaling * e[i] * inv * t[rt.nl + j]);
 }
 }  // namespace
 
@@ -345,13 +403,18 @@ static int post_norm(crab_ctx* ctx, void* stream, const crab_gemm_desc* d) {
         return crab_qkv_rope_split(ctx, stream, d->C, d->ldc, d->rope_tab, d->rope_k_cache, d->rope_v_cache, nullptr, 0, d->M, 1, d->rope_H,
                                    d->rope_Hk, d->rope_d, d->rope_Tmax, d->rope_pos0, d->rope_pos_dev);
     if (!d->norm_w) return CRAB_OK;
-    return crab_rmsnorm(ctx, stream, d->C, d->ldc, d->norm_w, d->norm_out, d->ld_norm, d->M, d->N, d->norm_eps);
+    int rc = crab_rmsnorm(ctx, stream, d->C, d->ldc, d->norm_w, d->norm_out, d->ld_norm, d->M, d->N, d->norm_eps);
+    if (rc || !d->route_RA) return rc;
+    return crab_hyperlora_route(ctx, stream, d->norm_out, d->ld_norm, d->route_RA, d->route_ldra, d->M, d->N, d->route_nproj, d->route_nl,
+                                d->route_r, d->route_U, d->route_ldu, d->route_ucols, d->route_scaling, d->workspace, d->workspace_bytes);
 }
 
 extern "C" int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc* d) {
     if (!ctx) return CRAB_E_INVALID;
     if (d && d->norm_w && (!d->norm_out || d->c_fp32 || d->batch > 1)) return crab_fail(ctx, CRAB_E_INVALID, "gemm: post-norm needs norm_out, bf16 C, no batch");
     if (!d || !d->A || !d->B || !d->C) return crab_fail(ctx, CRAB_E_INVALID, "gemm: null operand");
+    if (d->route_RA && (!d->norm_w || !d->route_U || d->route_nproj < 1 || d->route_nl < 1 || d->route_r < 1))
+        return crab_fail(ctx, CRAB_E_INVALID, "gemm: the next-group router needs the fused post-norm, route_U and positive nproj / nl / r");
     if (d->rope_tab) {
         if (d->c_fp32 || d->act != ACT_NONE || d->R || d->norm_w || d->batch > 1 || !d->rope_k_cache || !d->rope_v_cache ||
             d->rope_H <= 0 || d->rope_Hk <= 0 || d->rope_d <= 0 || d->N != (d->rope_H + 2 * d->rope_Hk) * d->rope_d)
@@ -449,10 +512,14 @@ extern "C" int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc*
             return crab_check_launch(ctx, "splitk_epilogue_rope_kernel");
         }
         if (d->norm_w && !d->c_fp32 && (d->N & 3) == 0 && d->N <= 8192 && (d->ldc & 3) == 0 && (d->ld_norm & 3) == 0 &&
-            (!d->R || (d->ldr & 3) == 0)) {
+            (!d->R || (d->ldr & 3) == 0) && (!d->route_RA || ((d->route_ldra & 3) == 0 && d->route_nl <= 8 &&
+                                                             d->route_nproj * (d->route_nl + d->route_r) <= 64))) {
+            RouteP rt;
+            rt.RA = (const bf16_t*)d->route_RA; rt.U = (bf16_t*)d->route_U; rt.ldra = d->route_ldra; rt.ldu = d->route_ldu;
+            rt.nproj = d->route_nproj; rt.nl = d->route_nl; rt.r = d->route_r; rt.ucols = d->route_ucols; rt.scaling = d->route_scaling;
             hipLaunchKernelGGL(splitk_epilogue_norm_kernel, dim3(d->M), dim3(256), 0, s, p.part, splitk, d->M, d->N, p.bias, d->act, p.R,
                                (long)d->ldr, d->res_scale, (bf16_t*)d->C, (long)d->ldc, (const bf16_t*)d->norm_w, d->norm_eps,
-                               (bf16_t*)d->norm_out, (long)d->ld_norm);
+                               (bf16_t*)d->norm_out, (long)d->ld_norm, rt);
             return crab_check_launch(ctx, "splitk_epilogue_norm_kernel");
         }
         long nthr = (long)d->M * ((d->N + 3) / 4);

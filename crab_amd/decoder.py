@@ -135,6 +135,7 @@ class _Workspace:
         self.act = e(M, I)
         self.t = torch.empty((max(ops.hyperlora_route_workspace(M, max(D, I), max(t_cols, 16)), 16),), device=device, dtype=torch.uint8)
         self.u = e(M, max(u_cols, 32))
+        self.u2 = e(M, max(u_cols, 32))       # router output produced ahead by a fused post-norm epilogue
 
 
 class GenerationEngine:
@@ -205,14 +206,15 @@ class GenerationEngine:
         ldq = qkv.stride(0)
         layers = self.model.layers
         ops.rmsnorm(x, layers[0].input_layernorm.weight, c.rms_norm_eps, out=h)
+        u_qkv = None                                   # router output for the q|k|v group when a producer epilogue made it
         for li, layer in enumerate(layers):
             a, m = layer.self_attn, layer.mlp
             kcl, vcl = kc[li, b0:b0 + B], vc[li, b0:b0 + B]
             if vt is None and S == 1 and kcl.is_contiguous():
                 # decode: RoPE + KV append ride on the q|k|v projection (fused into its split-K reduction when it has one)
-                a._qkv(h, out=qkv, t_buf=ws.t, u_buf=ws.u, rope=(tab, kcl, vcl, H, Hk, d, Tmax, pos0, pos_dev))
+                a._qkv(h, out=qkv, t_buf=ws.t, u_buf=ws.u, u_ready=u_qkv, rope=(tab, kcl, vcl, H, Hk, d, Tmax, pos0, pos_dev))
             else:
-                a._qkv(h, out=qkv, t_buf=ws.t, u_buf=ws.u)
+                a._qkv(h, out=qkv, t_buf=ws.t, u_buf=ws.u, u_ready=u_qkv)
                 ops.qkv_rope_split(qkv, tab, kcl, vcl, vt, B, S, H, Hk, d, Tmax, pos0=pos0, pos_dev=pos_dev)
             if vt is not None:
                 Sp = vt.shape[-1]
@@ -222,11 +224,19 @@ class GenerationEngine:
             else:
                 ops.attn_decode(qkv, kcl, vcl, att, B, H, Hk, d, Tmax, 1, scale, ctx_dev=pos_dev)
             # x += o_proj(att); h = rmsnorm(x) * post_attention_layernorm  (norm fused into the GEMM epilogue for small M)
-            a._o(att, residual=x, out=x, t_buf=ws.t, u_buf=ws.u, post_norm=(layer.post_attention_layernorm.weight, c.rms_norm_eps, h))
-            m._gu(h, out=act, t_buf=ws.t, u_buf=ws.u, act="swiglu_pair")              # act = silu(gate(h)) * up(h)
+            # (decode regime) the row-owning epilogue that produces h also evaluates the router of the group that consumes h
+            ahead_gu = m._gu.routes_ahead(M)
+            a._o(att, residual=x, out=x, t_buf=ws.t, u_buf=ws.u, post_norm=(layer.post_attention_layernorm.weight, c.rms_norm_eps, h),
+                 route_next=(m._gu, ws.u2) if ahead_gu else None)
+            m._gu(h, out=act, t_buf=ws.t, u_buf=ws.u, act="swiglu_pair", u_ready=ws.u2 if ahead_gu else None)   # silu(gate(h)) * up(h)
             # x += down(act); h = rmsnorm(x) * (next layer's input_layernorm | the final model.norm)
-            nxt = layers[li + 1].input_layernorm.weight if li + 1 < len(layers) else self.model.norm.weight
-            m._down(act, residual=x, out=x, t_buf=ws.t, u_buf=ws.u, post_norm=(nxt, c.rms_norm_eps, h))
+            last = li + 1 == len(layers)
+            nxt = self.model.norm.weight if last else layers[li + 1].input_layernorm.weight
+            nq = None if last else layers[li + 1].self_attn._qkv
+            ahead_q = nq is not None and nq.routes_ahead(M)
+            m._down(act, residual=x, out=x, t_buf=ws.t, u_buf=ws.u, post_norm=(nxt, c.rms_norm_eps, h),
+                    route_next=(nq, ws.u2) if ahead_q else None)
+            u_qkv = ws.u2 if ahead_q else None
         return x, h
 
     # ------------------------------------------------------------------ prefill

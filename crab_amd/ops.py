@@ -114,10 +114,12 @@ def _splitk_workspace(device) -> torch.Tensor:
 def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act: str = "none",
          residual: Optional[torch.Tensor] = None, res_scale: float = 1.0, x2: Optional[torch.Tensor] = None,
          w2: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, out_fp32: bool = False, tune: int = 0,
-         post_norm=None, rope=None) -> torch.Tensor:
+         post_norm=None, rope=None, route=None) -> torch.Tensor:
     """out[M,N] = res_scale*residual + act(x[M,K] @ w[N,K]^T + x2 @ w2^T + bias).  2-D row-strided operands.
     rope = (tab, k_cache, v_cache, H, Hk, d, Tmax, pos0, pos_dev): packed q|k|v projection of ONE row per sequence followed
     by RoPE + KV-cache append (== qkv_rope_split(B=M, S=1) on out), fused into the split-K reduction when there is one.
+    route = (RA, nproj, nl, r, ucols, scaling, u_out) (with post_norm, M <= 256): u_out = hyperlora_route(post-norm rows, RA)
+    for the NEXT projection group, computed inside the row-owning reduction kernel when that path is taken.
     act == "swiglu_pair": w rows are interleaved (gate_i, up_i) and out is [M, N/2] = silu(gate) * up."""
     _chk_bf16(x, w, bias, residual, x2, w2)
     d = _dev(x)
@@ -143,6 +145,11 @@ def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     g.tune = tune
     if post_norm is not None:                      # (weight, eps, out): out = rmsnorm(result) * weight, fused when possible
         g.norm_w, g.norm_eps, g.norm_out, g.ld_norm = post_norm[0].data_ptr(), post_norm[1], post_norm[2].data_ptr(), post_norm[2].stride(0)
+    if route is not None:
+        assert post_norm is not None and M <= 256
+        rRA, rnp, rnl, rr, ruc, rsc, ru = route
+        g.route_RA, g.route_U, g.route_ldra, g.route_ldu = rRA.data_ptr(), ru.data_ptr(), rRA.stride(0), ru.stride(0)
+        g.route_nproj, g.route_nl, g.route_r, g.route_ucols, g.route_scaling = rnp, rnl, rr, ruc, rsc
     if rope is not None:
         tab, kcache, vcache, rH, rHk, rd, rT, rp0, rpd = rope
         g.rope_tab, g.rope_k_cache, g.rope_v_cache = tab.data_ptr(), kcache.data_ptr(), vcache.data_ptr()

@@ -153,19 +153,33 @@ class PackedLinearGroup:
                 lin._attach_lora()
 
     def __call__(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-                 t_buf: Optional[torch.Tensor] = None, u_buf: Optional[torch.Tensor] = None, post_norm=None, act: str = "none", rope=None) -> torch.Tensor:
+                 t_buf: Optional[torch.Tensor] = None, u_buf: Optional[torch.Tensor] = None, post_norm=None, act: str = "none", rope=None, route_next=None, u_ready=None) -> torch.Tensor:
         """y = group(x) (+residual).  post_norm = (rms_weight, eps, h_out): additionally h_out = rmsnorm(y) * rms_weight
         (the LlamaRMSNorm that follows o_proj / down_proj), fused into the GEMM epilogue in the decode regime.
         act = "swiglu_pair" (interleaved groups): returns silu(member0(x)) * member1(x), [M, N/2]."""
         M = x.shape[0]
         if act == "swiglu_pair" and not self.interleave:
             raise ValueError("swiglu_pair needs an interleaved group")
+        # route_next = (group, u_out): this GEMM's fused post-norm also evaluates the router of the NEXT group on the
+        # normalised rows; that group is then called with u_ready=u_out and skips its own router launches
+        route = None
+        if route_next is not None and route_next[0].RA is not None and post_norm is not None and M <= 256:
+            ng, nu = route_next
+            route = (ng.RA, len(ng.names), ng.nl, ng.r, ng.u_cols, ng.scaling, nu[:M, :ng.u_cols])
         if self.RA is None:
-            return ops.gemm(x, self.W, bias=self.bias, residual=residual, out=out, post_norm=post_norm, act=act, rope=rope)
-        u = u_buf[:M, :self.u_cols] if u_buf is not None else torch.empty((M, self.u_cols), device=x.device, dtype=BF16)
-        # route logits | lora_A(x) -> softmax mix, K split over blocks (skinny.hip); t_buf is the partial-sum workspace
-        ops.hyperlora_route(x, self.RA, len(self.names), self.nl, self.r, self.u_cols, self.scaling, out=u, workspace=t_buf)
-        return ops.gemm(x, self.W, bias=self.bias, residual=residual, x2=u, w2=self.B2, out=out, post_norm=post_norm, act=act, rope=rope)
+            return ops.gemm(x, self.W, bias=self.bias, residual=residual, out=out, post_norm=post_norm, act=act, rope=rope, route=route)
+        if u_ready is not None:
+            u = u_ready[:M, :self.u_cols]
+        else:
+            u = u_buf[:M, :self.u_cols] if u_buf is not None else torch.empty((M, self.u_cols), device=x.device, dtype=BF16)
+            # route logits | lora_A(x) -> softmax mix, K split over blocks (skinny.hip); t_buf is the partial-sum workspace
+            ops.hyperlora_route(x, self.RA, len(self.names), self.nl, self.r, self.u_cols, self.scaling, out=u, workspace=t_buf)
+        return ops.gemm(x, self.W, bias=self.bias, residual=residual, x2=u, w2=self.B2, out=out, post_norm=post_norm, act=act, rope=rope,
+                        route=route)
+
+    def routes_ahead(self, M: int) -> bool:
+        """True when a producer GEMM may evaluate this group's router in its fused post-norm epilogue (decode regime)."""
+        return self.RA is not None and M <= 256
 
 
 class PeftModelForCausalLM(nn.Module):

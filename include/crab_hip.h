@@ -74,6 +74,12 @@ typedef struct {
      * N == (rope_H + 2*rope_Hk) * rope_d, bf16 C, no activation / residual / post-norm. */
     const float* rope_tab; void* rope_k_cache; void* rope_v_cache; const int32_t* rope_pos_dev;
     int32_t rope_H, rope_Hk, rope_d, rope_Tmax, rope_pos0;
+    /* optional hyper-LoRA router of the NEXT projection group, evaluated on the post-norm rows (needs norm_w / norm_out):
+     * route_U[M, route_ucols] = crab_hyperlora_route(norm_out, route_RA, ...) - inside the row-owning split-K reduction when
+     * that path is taken (the normalised row is already in registers), by a separate pass otherwise (which then needs
+     * `workspace`).  route_RA == NULL disables it; route_RA is [pad16(nproj*(nl+r)), N] with row stride route_ldra. */
+    const void* route_RA; void* route_U; int64_t route_ldra, route_ldu;
+    int32_t route_nproj, route_nl, route_r, route_ucols; float route_scaling;
 } crab_gemm_desc;
 
 int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc* d);

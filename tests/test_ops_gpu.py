@@ -378,6 +378,30 @@ def test_gemm_fused_post_rmsnorm(M, N):
     _cmp(h, O.rmsnorm(xd.cpu().float(), nw.float(), 1e-5, emulate=BF), 1e-2, "post-norm")
 
 
+@pytest.mark.parametrize("M", [4, 48, 256])
+@pytest.mark.parametrize("nproj", [3, 2])
+def test_gemm_post_norm_routes_next_group(M, nproj):
+    """o_proj / down_proj GEMM with the fused post-RMSNorm that also evaluates the NEXT group's hyper-LoRA router on the
+    normalised rows (row-owning split-K reduction; separate pass on the skinny path) == norm followed by hyperlora_route."""
+    from crab_amd import ops
+    K, N = 1024, 2048
+    tcols, ucols = (nproj * 11 + 15) // 16 * 16, (nproj * 24 + 31) // 32 * 32
+    x, w, r, nw = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=K ** -0.5), _rand(M, N, seed=3), (1 + 0.1 * _rand(N, seed=4).float()).to(BF)
+    ra = _rand(tcols, N, seed=5, scale=N ** -0.5)
+    ra[nproj * 11:] = 0
+    rd = r.cuda().clone()
+    h = torch.empty(M, N, dtype=BF, device="cuda")
+    u = torch.full((M, ucols), 7.0, dtype=BF, device="cuda")
+    ops.gemm(x.cuda(), w.cuda(), residual=rd, out=rd, post_norm=(nw.cuda(), 1e-5, h), route=(ra.cuda(), nproj, 3, 8, ucols, 2.0, u))
+    h2 = torch.empty_like(h)
+    r2 = r.cuda().clone()
+    ops.gemm(x.cuda(), w.cuda(), residual=r2, out=r2, post_norm=(nw.cuda(), 1e-5, h2))
+    assert torch.equal(h, h2) and torch.equal(rd, r2)
+    u_ref = ops.hyperlora_route(h2, ra.cuda(), nproj, 3, 8, ucols, 2.0)
+    _cmp(u, u_ref.float().cpu(), 1e-2, "route ahead")
+    assert (u[:, nproj * 24:] == 0).all()
+
+
 @pytest.mark.parametrize("M", [3, 40, 256])
 @pytest.mark.parametrize("H,Hk,bias", [(4, 4, False), (8, 2, True)])
 def test_gemm_fused_rope_kv_append_equals_unfused_pair(M, H, Hk, bias):
