@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_norm_kernel(const float* 
 }  // namespace
 
 int crab_gemm_skinny_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* d);   // skinny.hip
-int crab_gemm_glds_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* d, int splitk, float* part);     // gemm_glds.hip
+int crab_gemm_glds_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* d, int splitk, float* part, int ring_split);     // gemm_glds.hip
 
 
 // Split-K reduction of the packed q|k|v projection fused with RoPE and the KV-cache append (decode: one row per sequence).
@@ -436,7 +436,7 @@ extern "C" int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc*
     //   M <= 16          : LDS-free skinny kernel (skinny.hip), activations replicated per 16 weight rows
     //   16 < M <= 256    : tiled kernel with split-K over blockIdx.y (needs the caller's workspace) so that
     //                      >= ~2 blocks/CU stream disjoint weight panels; partials reduced in a fixed order
-    int splitk = 1, sk_bm = 0, sk_bn = 0;
+    int splitk = 1, sk_bm = 0, sk_bn = 0, ring_split = 0;
     const int nk_all = (d->K + 63) / 64 + (d->A2 ? (d->K2 + 63) / 64 : 0);
     if (d->batch <= 1 && d->M <= 256 && (d->M <= 128 || d->workspace != nullptr)) {
         bool want_split = d->M > 16 && d->workspace != nullptr && nk_all >= 8;
@@ -471,11 +471,27 @@ extern "C" int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc*
             }
         }
         if (d->tune >= 100) splitk = d->tune % 100;
-        if (splitk > nk_all / 4) splitk = nk_all / 4;
+        if (d->tune >= 400 && d->tune < 500 && sk_bm == 128) ring_split = 1;      // benchmarking: 256x256 ring kernel, S K-slices
+        if (d->tune < 100 && d->M >= 192 && d->N >= 10240) {
+            // wide projections at M ~ 256 (q|k|v: 48 tiles x 5 slices, gate|up: 86 tiles x 2): the 256x256 ring kernel, one
+            // block per CU in a single round, beats the 128x128 kernel by 7 / 11 us (profiles/README.md); the narrow ones
+            // (o, down: 16 tiles) would need 16 slabs and do not gain
+            const long t256 = (long)((d->M + 255) / 256) * ((d->N + 255) / 256);
+            int sr = (int)(256 / t256);
+            if (sr > 5) sr = 5;
+            if (sr >= 2) { ring_split = 1; splitk = sr; }
+        }
+        if (!ring_split && splitk > nk_all / 4) splitk = nk_all / 4;
         if (splitk < 1) splitk = 1;
         if (splitk > 8 && d->tune < 100) splitk = 8;               // partial slabs: S*M*N*4 bytes written and re-read
         if (splitk > 32) splitk = 32;
         while (splitk > 1 && (int64_t)splitk * d->M * d->N * 4 > d->workspace_bytes) --splitk;
+        if (ring_split) {                                              // slices of whole 32-wide K tiles, none empty
+            const int nk32 = (d->K + 31) / 32 + (d->A2 ? (d->K2 + 31) / 32 : 0);
+            const int per = (nk32 + splitk - 1) / splitk;
+            splitk = (nk32 + per - 1) / per;
+            if (splitk < 2) { ring_split = 0; splitk = 1; }
+        }
     }
     GemmP p;
     p.splitk = splitk; p.part = (float*)d->workspace;
@@ -498,7 +514,7 @@ extern "C" int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc*
         else if (sk_bm == 64) hipLaunchKernelGGL((gemm_bt_kernel<64, 64>), grid, dim3(256), 0, s, p);
         else if (d->tune == 300) hipLaunchKernelGGL((gemm_bt_kernel<128, 128>), grid, dim3(256), 0, s, p);
         else {                                                        // 128-row tiles: LDS-DMA staged kernel, K split over blockIdx.y
-            int rc2 = crab_gemm_glds_launch(ctx, s, d, splitk, p.part);
+            int rc2 = crab_gemm_glds_launch(ctx, s, d, splitk, p.part, ring_split);
             if (rc2) return rc2;
         }
         int rc = crab_check_launch(ctx, "gemm_bt_kernel(split-K)");
@@ -534,7 +550,7 @@ extern "C" int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc*
     bool small = (d->M <= 64) || (d->N <= 64) || big_tiles < 192;
     if (!small && d->tune != 300) {
         // 128x128 tiles: LDS-DMA staged kernel (gemm_glds.hip); tune == 300 keeps the register-staged variant for A/B runs
-        int rc = crab_gemm_glds_launch(ctx, s, d, 1, nullptr);
+        int rc = crab_gemm_glds_launch(ctx, s, d, 1, nullptr, 0);
         return rc ? rc : post_norm(ctx, stream, d);
     }
     if (!small) {

@@ -205,7 +205,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bt_ring_kernel(GemmGP p) 
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WGN, wn = wave % WGN;
-    const int z = blockIdx.y;
+    // blockIdx.y = batch index, or (splitk > 1, unbatched) the K slice whose raw fp32 partial tile this block produces
+    const int sk = p.splitk > 1 ? (int)blockIdx.y : 0;
+    const int z = p.splitk > 1 ? 0 : (int)blockIdx.y;
     const int z0 = z % p.nb0, z1 = z / p.nb0;
     const bf16_t* A = p.A + z0 * p.sA0 + z1 * p.sA1;
     const bf16_t* B = p.B + z0 * p.sB0 + z1 * p.sB1;
@@ -215,7 +217,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bt_ring_kernel(GemmGP p) 
     const int m0 = tm * BM, n0 = tn * BN;
     const int nk1 = (p.K + RBK - 1) / RBK;
     const int nk2 = p.A2 ? (p.K2 + RBK - 1) / RBK : 0;
-    const int nk = nk1 + nk2;
+    const int nk_per = (nk1 + nk2 + p.splitk - 1) / p.splitk;
+    const int t_first = sk * nk_per;                                   // first K tile of this slice (both K segments chained)
+    const int nk = min(nk1 + nk2, t_first + nk_per) - t_first;        // K tiles of this slice (>= 1 by construction of splitk)
 
     const bool isA = wave * PPW < PA;
     const int prow = lane >> 2, pc = lane & 3;
@@ -240,8 +244,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bt_ring_kernel(GemmGP p) 
     }
 #define RSTAGE(T_)                                                                                        \
     {                                                                                                     \
-        const int t_ = (T_);                                                                              \
-        const int sb_ = (t_ & (RNS - 1)) * STAGE_ELEMS;                                                   \
+        const int tl_ = (T_);                                                                             \
+        const int t_ = t_first + tl_;                                                                     \
+        const int sb_ = (tl_ & (RNS - 1)) * STAGE_ELEMS;                                                  \
         const bool s2_ = t_ >= nk1;                                                                       \
         const int k0_ = (s2_ ? t_ - nk1 : t_) * RBK;                                                      \
         const int Ks_ = s2_ ? p.K2 : p.K;                                                                 \
@@ -323,6 +328,25 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bt_ring_kernel(GemmGP p) 
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();
 #undef RSTAGE
+    if (p.splitk > 1) {          // raw partial tile; reduced in a fixed slice order by the split-K epilogue kernels (gemm.hip)
+        float* part = p.part + (long)sk * p.M * p.N;
+        const bool v4 = (p.N & 3) == 0;
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+            const int m = m0 + wm * WM + mi * 16 + fr;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+                const int n = n0 + wn * WN + ni * 16 + fg * 4;
+                if (n >= p.N) continue;
+                float* o = part + (long)m * p.N + n;
+                if (v4) *reinterpret_cast<f32x4_t*>(o) = acc[ni][mi];
+                else
+                    for (int r = 0; r < 4 && n + r < p.N; ++r) o[r] = acc[ni][mi][r];
+            }
+        }
+        return;
+    }
     // output stage shared with gemm_bt_kernel (gemm_epilogue.h): unguarded + activation-specialised on interior sub-tiles
     gemm_epilogue<TM, TN>(acc, p.act, m0 + wm * WM, n0 + wn * WN, fr, fg, p.M, p.N, p.bias ? p.bias + z0 * p.sBias0 + z1 * p.sBias1 : nullptr,
                           p.R ? p.R + z0 * p.sR0 + z1 * p.sR1 : nullptr, p.ldr, p.res_scale, p.C, z0 * p.sC0 + z1 * p.sC1, p.ldc, p.c_fp32);
@@ -501,7 +525,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bt_stream_kernel(GemmGP p
 }  // namespace
 
 // called from crab_gemm_bf16 (gemm.hip) for the 128x128 tile regime
-int crab_gemm_glds_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* d, int splitk, float* part) {
+int crab_gemm_glds_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* d, int splitk, float* part, int ring_split) {
     GemmGP p;
     p.splitk = splitk > 1 ? splitk : 1; p.part = part;
     p.A = (const bf16_t*)d->A; p.B = (const bf16_t*)d->B; p.C = d->C; p.bias = (const bf16_t*)d->bias; p.R = (const bf16_t*)d->R;
@@ -520,6 +544,14 @@ int crab_gemm_glds_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* d,
     // rounds, 930 vs 868 TFLOP/s; M = 2056 x N = 4096 x K = 1024: 144 tiles = 56 % of one round, 527 vs 491) and K >= 1024
     const long rounds = (big + 255) / 256;
     bool use_big = big >= 120 && big * 100 >= rounds * 256 * 55 && d->M >= 1024 && d->N >= 1024 && d->K >= 1024 && p.splitk == 1;
+    // decode regime, ring_split (chosen by the cost model in gemm.hip): 256x256 ring kernel with the K slices over blockIdx.y,
+    // one round of <= 256 blocks
+    if (p.splitk > 1 && ring_split) {
+        p.tiles_m = (d->M + 255) / 256; p.tiles_n = (d->N + 255) / 256;
+        dim3 grid(p.tiles_m * p.tiles_n, p.splitk);
+        hipLaunchKernelGGL((gemm_bt_ring_kernel<256, 256, 2, 4>), grid, dim3(512), 0, s, p);
+        return crab_check_launch(ctx, "gemm_bt_ring_kernel(split-K)");
+    }
     if (d->tune == 301) use_big = false;
     if (d->tune == 302 || d->tune == 303) use_big = true;        // 302: one block per tile, 303: persistent stream
     if (use_big && batch == 1 && d->tune == 303) {

@@ -26,9 +26,10 @@ for M in Ms:
         w2 = torch.randn(N, K2, device="cuda", dtype=BF) if K2 else None
         out = torch.empty(M, N, device="cuda", dtype=BF)
         res = []
-        for tune in (0, 1, 2, 4, 102, 104, 108, 116, 204, 208):
+        for tune in (0, 1, 2, 4, 102, 104, 108, 116, 204, 208, 402, 403, 405, 408, 416):
             if M > 64 and tune == 4: continue
             if M <= 16 and tune >= 100: continue
+            if M <= 64 and tune >= 400: continue
             i = [0]
             def fn():
                 i[0] = (i[0] + 1) % ncopy

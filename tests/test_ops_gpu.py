@@ -345,9 +345,10 @@ def test_gemm_skinny_regime(M):
     _cmp(y, z, 3e-3, f"skinny M={M}")
 
 
-@pytest.mark.parametrize("M,tune", [(17, 0), (64, 0), (64, 104), (64, 208), (128, 0), (100, 103), (33, 102)])
+@pytest.mark.parametrize("M,tune", [(17, 0), (64, 0), (64, 104), (64, 208), (128, 0), (100, 103), (33, 102), (256, 403), (200, 407), (256, 0)])
 def test_gemm_splitk_decode_regime(M, tune):
-    """16 < M <= 128 with the caller workspace: split-K tiled kernel + fixed-order reduce epilogue."""
+    """16 < M <= 256 with the caller workspace: split-K tiled kernels (tune 4xx: 256x256 ring kernel with K slices, ragged N / K
+    tails / second segment) + fixed-order reduce epilogue."""
     from crab_amd import ops
     N, K, K2 = 1000 + 9, 1096, 32
     x, w, b, r = _rand(M, K, seed=3), _rand(N, K, seed=4, scale=K ** -0.5), _rand(N, seed=5), _rand(M, N, seed=6)
@@ -376,6 +377,19 @@ def test_gemm_fused_post_rmsnorm(M, N):
     c_ref = (x.float() @ w.float().t() + r.float())
     _cmp(xd, c_ref, 1.2e-2, "C")
     _cmp(h, O.rmsnorm(xd.cpu().float(), nw.float(), 1e-5, emulate=BF), 1e-2, "post-norm")
+
+
+def test_gemm_ring_split_wide_projection_auto():
+    """N >= 10240 at M = 256 takes the 256x256 ring kernel with K slices automatically; result == the 128x128 split path."""
+    from crab_amd import ops
+    M, N, K, K2 = 256, 10240 + 256, 1024, 32
+    x, w = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=K ** -0.5)
+    x2, w2 = _rand(M, K2, seed=3), _rand(N, K2, seed=4, scale=0.1)
+    y0 = ops.gemm(x.cuda(), w.cuda(), x2=x2.cuda(), w2=w2.cuda(), out_fp32=True)                 # automatic: ring, 6 tiles -> 5 slices
+    y1 = ops.gemm(x.cuda(), w.cuda(), x2=x2.cuda(), w2=w2.cuda(), out_fp32=True, tune=104)       # 128x128 kernel, 4 slices
+    z = x.float() @ w.float().t() + x2.float() @ w2.float().t()
+    _cmp(y0, z, 3e-3, "ring split auto")
+    assert (y0 - y1).abs().max().item() < 1e-3 * z.abs().max().item()
 
 
 @pytest.mark.parametrize("M", [4, 48, 256])
