@@ -401,17 +401,39 @@ __global__ void beats_relpos_bias_kernel(const bf16_t* __restrict__ table, float
 }
 
 // gate[b,h,i] from the un-scaled q projection (backbone.py:650-662): grep_linear d->8, view(2,4).sum, sigmoid
-__global__ void beats_gru_gate_kernel(const bf16_t* __restrict__ q, long ldq, const bf16_t* __restrict__ gw, const bf16_t* __restrict__ gb,
-                                      const bf16_t* __restrict__ grep_a, float* __restrict__ gate, int B, int n, int H, int d) {
+__global__ __launch_bounds__(128) void beats_gru_gate_kernel(const bf16_t* __restrict__ q, long ldq, const bf16_t* __restrict__ gw,
+                                                             const bf16_t* __restrict__ gb, const bf16_t* __restrict__ grep_a,
+                                                             float* __restrict__ gate, int B, int n, int H, int d) {
+    // grep_linear weight [8, d] staged once per block in LDS as fp32; each thread reads its q row with 16-byte loads (d % 8 == 0,
+    // rows 16-byte aligned: checked by the launcher; otherwise element loads)
+    __shared__ float wsm[8 * 256];
+    for (int i = threadIdx.x; i < 8 * d; i += blockDim.x) wsm[i] = bf2f(gw[i]);
+    __syncthreads();
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= B * H * n) return;
     int i = idx % n, h = (idx / n) % H, b = idx / (n * H);
     const bf16_t* qr = q + ((long)b * n + i) * ldq + h * d;
     float o[8];
-    for (int k = 0; k < 8; ++k) {
-        float s = bf2f(gb[k]);
-        for (int e = 0; e < d; ++e) s += bf2f(qr[e]) * bf2f(gw[k * d + e]);
-        o[k] = s;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = bf2f(gb[k]);
+    const bool vec = ((d & 7) == 0) && ((ldq & 7) == 0) && ((reinterpret_cast<uintptr_t>(q) & 15) == 0);
+    for (int e0 = 0; e0 < d; e0 += 8) {
+        float x[8];
+        if (vec) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(qr + e0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { x[2 * j] = lo_bf(v[j]); x[2 * j + 1] = hi_bf(v[j]); }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = e0 + j < d ? bf2f(qr[e0 + j]) : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float s = o[k];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += x[j] * (e0 + j < d ? wsm[k * d + e0 + j] : 0.f);   // same e-ascending order as before
+            o[k] = s;
+        }
     }
     float sa = o[0] + o[1] + o[2] + o[3], sb = o[4] + o[5] + o[6] + o[7];
     float ga = 1.f / (1.f + expf(-sa)), gb_ = 1.f / (1.f + expf(-sb));
@@ -625,7 +647,7 @@ int crab_beats_relpos_bias(crab_ctx* ctx, void* stream, const void* table, float
 int crab_beats_gru_gate(crab_ctx* ctx, void* stream, const void* q, int64_t ldq, const void* gw, const void* gb, const void* grep_a,
                         float* gate, int B, int n, int H, int d) {
     if (!ctx) return CRAB_E_INVALID;
-    if (!q || !gw || !gb || !grep_a || !gate) return crab_fail(ctx, CRAB_E_INVALID, "beats_gru_gate: bad argument");
+    if (!q || !gw || !gb || !grep_a || !gate || d <= 0 || d > 256) return crab_fail(ctx, CRAB_E_INVALID, "beats_gru_gate: bad argument (head dim <= 256)");
     hipLaunchKernelGGL(beats_gru_gate_kernel, dim3(cdiv((long)B * H * n, 128)), dim3(128), 0, S_(stream), (const bf16_t*)q, (long)ldq,
                        (const bf16_t*)gw, (const bf16_t*)gb, (const bf16_t*)grep_a, gate, B, n, H, d);
     return crab_check_launch(ctx, "beats_gru_gate");
