@@ -274,3 +274,32 @@ def test_generate_avs_pipeline_vs_oracle():
     ref = O.seg_module(torch.stack([ohid[:, j] for j in picks], 1), feats[:2], ['s4'], Wo)
     if torch.equal(oids, plain):                   # identical contexts -> the masks are comparable
         assert _rel(res['pred_masks'][0], ref[0]) < 1e-1
+
+
+def test_generate_many_clips_vs_oracle():
+    """Six more synthetic clips (3 batches of 2, different prompts / frames / fbank) through the public generate() against
+    the golden-pinned oracle run on the same bf16-rounded weights: greedy ids exact wherever the oracle's top-2 margin
+    exceeds twice the measured logit error."""
+    from crab_amd import synth
+    from oracle import crab_oracle as O
+    meta, A = load_fixture("full_tiny_llama")
+    W = weights_from_table(meta)
+    model = build_tiny_crab(meta)
+    model.load_state_dict(W, strict=False)
+    Wo = _bf(O.strip_peft_prefix(W))
+    from tests.test_oracle_golden import _full_cfg
+    ocfg = _full_cfg(meta)
+    p = meta["prompts"]
+    n = 12
+    worst = 0.0
+    for c0 in (11, 23, 37):
+        ids = [synth.synth_prompt_ids(nt, ocfg.base_vocab, model.SPECIAL_TOKEN_2_IDS, seed=meta["seed"], clip=c)
+               for nt, c in ((p["n0"], c0), (p["n1"], c0 + 1))]                       # ragged: left padding inside the batch
+        mods = [{'<video>': synth.synth_video(p["t_v"], seed=meta["seed"], clip=c), '<audio>': synth.synth_audio(p["t_a"], p["l_a"], seed=meta["seed"], clip=c)}
+                for c in (c0, c0 + 1)]
+        lab = [torch.full_like(i, -100) for i in ids]
+        r = model.generate(batch_input_ids=ids, batch_labels=lab, batch_X_modals=mods, batch_task_names=['avqa'] * 2, use_cache=True,
+                           max_new_tokens=n, pad_token_id=2, eos_token_id=None, output_logits=True, return_dict_in_generate=True)
+        ref_ids, ref_logits = O.generate(ids, mods, Wo, ocfg, n)
+        worst = max(worst, _check_ids(r.sequences, ref_ids, ref_logits, torch.stack(r.logits, 1)))
+    assert worst < REL_F32 * 10.0
