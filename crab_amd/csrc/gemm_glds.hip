@@ -353,175 +353,6 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bt_ring_kernel(GemmGP p) 
 }
 
 
-// ------------------------------------------------------------------------------------------------------------
-// Persistent ("stream") form of the ring kernel: one block per CU walks its tiles L = r*G + xcd_remap(b, G), r = 0,1,..
-// and treats (tile, K tile) as ONE continuous stream of ring positions.  The LDS-DMA for position pos+3 is issued at
-// position pos whichever tile it belongs to, so the first three K tiles of the next output tile are already in flight
-// while the current tile's epilogue runs: the ~20k-cycle prologue of every tile but the first disappears and the
-// epilogue's stores drain under the next tile's loads.  Loop body, swizzles, barrier protocol and counted waits are
-// those of gemm_bt_ring_kernel; stores issued by an epilogue are younger than the two tiles the next counted
-// s_waitcnt vmcnt(8) must retire, so the wait stays correct whether or not stores and loads retire in order.
-template <int BM, int BN, int WGM, int WGN>
-__global__ __launch_bounds__(WGM * WGN * 64) void gemm_bt_stream_kernel(GemmGP p) {
-    constexpr int NW = WGM * WGN;
-    constexpr int WM = BM / WGM, WN = BN / WGN;
-    constexpr int TM = WM / 16, TN = WN / 16;
-    constexpr int PA = BM / 16, PB = BN / 16;
-    constexpr int PPW = (PA + PB) / NW;
-    constexpr int STAGE_ELEMS = (BM + BN) * RBK;
-    __shared__ __attribute__((aligned(16))) bf16_t lds[RNS * STAGE_ELEMS];
-    static_assert(PA == PB && PA % PPW == 0 && PPW == 4, "operand choice uniform per wave; vmcnt(8) = two tiles of 4 DMAs");
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WGN, wn = wave % WGN;
-    const int G = gridDim.x;
-    const int ntiles = p.tiles_m * p.tiles_n;
-    const int lb = xcd_remap(blockIdx.x, G);                  // blocks of one XCD take consecutive tiles of every round
-    const int my_n = (ntiles - lb + G - 1) / G;               // >= 1 (G <= ntiles)
-    const int nk1 = (p.K + RBK - 1) / RBK;
-    const int nk2 = p.A2 ? (p.K2 + RBK - 1) / RBK : 0;
-    const int nk = nk1 + nk2;
-    const int total = my_n * nk;
-
-    const bool isA = wave * PPW < PA;
-    const int prow = lane >> 2, pc = lane & 3;
-    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page);
-    const int ld1 = (int)(isA ? p.lda : p.ldb), ld2 = (int)(isA ? p.lda2 : p.ldb2);
-    int off1[PPW], off2[PPW], kc[PPW], ldso[PPW], prw[PPW];
-#pragma unroll
-    for (int i = 0; i < PPW; ++i) {
-        const int q = wave * PPW + i;
-        const int pr0 = (isA ? q : q - PA) * 16;
-        const int row = pr0 + prow;
-        const int c = pc ^ ((0x78 >> (((row >> 2) & 3) * 2)) & 3);
-        kc[i] = c * 8;
-        prw[i] = row;
-        off1[i] = row * ld1 + c * 8;
-        off2[i] = row * ld2 + c * 8;
-        ldso[i] = (isA ? 0 : BM * RBK) + pr0 * RBK;
-    }
-    // ---- load cursor: output tile and K tile of the next DMA
-    int l_tile = lb, l_k = 0;
-    const bf16_t* lbase1; const bf16_t* lbase2; int llim;
-#define SET_LOAD_TILE()                                                                                   \
-    {                                                                                                     \
-        const int tm_ = l_tile % p.tiles_m, tn_ = l_tile / p.tiles_m;                                     \
-        lbase1 = isA ? p.A + (long)tm_ * BM * p.lda : p.B + (long)tn_ * BN * p.ldb;                       \
-        lbase2 = p.A2 ? (isA ? p.A2 + (long)tm_ * BM * p.lda2 : p.B2 + (long)tn_ * BN * p.ldb2) : zero;  \
-        llim = isA ? p.M - tm_ * BM : p.N - tn_ * BN;                                                     \
-    }
-#define SSTAGE(POS_)                                                                                      \
-    {                                                                                                     \
-        const int sb_ = ((POS_) & (RNS - 1)) * STAGE_ELEMS;                                               \
-        const bool s2_ = l_k >= nk1;                                                                      \
-        const int k0_ = (s2_ ? l_k - nk1 : l_k) * RBK;                                                    \
-        const int Ks_ = s2_ ? p.K2 : p.K;                                                                 \
-        const bf16_t* bs_ = (s2_ ? lbase2 : lbase1) + k0_;                                                \
-        _Pragma("unroll") for (int i = 0; i < PPW; ++i) {                                                 \
-            const bool ok_ = (prw[i] < llim) && (k0_ + kc[i] < Ks_);                                      \
-            const bf16_t* src_ = bs_ + (s2_ ? off2[i] : off1[i]);                                         \
-            src_ = ok_ ? src_ : zero;                                                                     \
-            bf16_t* dst_ = &lds[sb_ + __builtin_amdgcn_readfirstlane(ldso[i])];                           \
-            __builtin_amdgcn_global_load_lds((gbl_vptr)src_, (lds_vptr)dst_, 16, 0, 0);                   \
-        }                                                                                                 \
-        if (++l_k == nk) { l_k = 0; l_tile += G; SET_LOAD_TILE(); }                                       \
-    }
-    SET_LOAD_TILE();
-
-    f32x4_t acc[TN][TM];
-#pragma unroll
-    for (int i = 0; i < TN; ++i)
-#pragma unroll
-        for (int j = 0; j < TM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-    // prologue (once per block): positions 0..2 in flight, position 0 retired
-    SSTAGE(0);
-    if (total > 1) SSTAGE(1);
-    if (total > 2) SSTAGE(2);
-    if (total > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-
-    const int fr = lane & 15, fg = lane >> 4;
-    int wofs[TN], xofs[TM];
-#pragma unroll
-    for (int ni = 0; ni < TN; ++ni) {
-        const int row = wn * WN + ni * 16 + fr;
-        wofs[ni] = BM * RBK + row * RBK + ((fg ^ ((0x78 >> (((row >> 2) & 3) * 2)) & 3)) << 3);
-    }
-#pragma unroll
-    for (int mi = 0; mi < TM; ++mi) {
-        const int row = wm * WM + mi * 16 + fr;
-        xofs[mi] = row * RBK + ((fg ^ ((0x78 >> (((row >> 2) & 3) * 2)) & 3)) << 3);
-    }
-    const bf16_t* bias = p.bias;
-    const bf16_t* R = p.R;
-
-    int c_tile = lb, c_k = 0;                                  // compute cursor
-    int st_pend = 0;                                           // positions after an epilogue whose stores may stay in flight
-    const int grp = wave / (NW / 2);
-    if (grp == 1) __builtin_amdgcn_s_barrier();
-    for (int pos = 0; pos < total; ++pos) {
-        // ---- LOAD segment (see gemm_bt_ring_kernel)
-        const bf16_t* st = &lds[(pos & (RNS - 1)) * STAGE_ELEMS];
-        bf16x8_t wf[TN], xf[TM];
-#pragma unroll
-        for (int ni = 0; ni < TN; ++ni) wf[ni] = *reinterpret_cast<const bf16x8_t*>(st + wofs[ni]);
-#pragma unroll
-        for (int mi = 0; mi < TM; ++mi) xf[mi] = *reinterpret_cast<const bf16x8_t*>(st + xofs[mi]);
-        __builtin_amdgcn_sched_barrier(0);
-        if (pos + 3 < total) SSTAGE(pos + 3);
-        // counted wait: the two youngest K tiles stay in flight.  gfx9 retires vector memory operations IN ORDER on the
-        // single vmcnt counter, loads and stores alike (there is no vscnt; the compiler's own waitcnt insertion relies on
-        // it), so for the two positions after an interior tile's epilogue its TM*TN stores - all younger than the tile
-        // being retired - may stay in flight as well: without this the wait drains the whole store queue and the
-        // persistent form loses the store/prologue overlap that consecutive one-tile blocks get for free.
-        if (pos + 3 >= total) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        else if (st_pend > 0) { asm volatile("s_waitcnt vmcnt(40) lgkmcnt(0)" ::: "memory"); --st_pend; }
-        else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- MFMA segment
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-            for (int mi = 0; mi < TM; ++mi)
-                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        // the trailing group runs its output stage BEFORE this barrier, the leading group AFTER it: both epilogues then
-        // overlap (offset by one MFMA segment).  With the barrier first in both groups the leading group's epilogue
-        // holds the trailing group at the barrier and vice versa: two serialised epilogues per tile (measured -12 %).
-        if (grp == 0) __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- tile boundary: output stage from registers (no LDS, no barrier), accumulators restart
-        if (++c_k == nk) {
-            const int tm = c_tile % p.tiles_m, tn = c_tile / p.tiles_m;
-            gemm_epilogue<TM, TN>(acc, p.act, tm * BM + wm * WM, tn * BN + wn * WN, fr, fg, p.M, p.N, bias, R, p.ldr, p.res_scale, p.C, 0,
-                                  p.ldc, p.c_fp32);
-#pragma unroll
-            for (int i = 0; i < TN; ++i)
-#pragma unroll
-                for (int j = 0; j < TM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-            static_assert(TM * TN + 8 == 40, "vmcnt(40) above = 32 epilogue stores + two K tiles of 4 DMAs");
-            const bool interior = (tm * BM + wm * WM + TM * 16 <= p.M) && (tn * BN + wn * WN + TN * 16 <= p.N) && ((p.ldc & 3) == 0) &&
-                                  (!R || ((p.ldr & 3) == 0));                     // == gemm_epilogue's unguarded form: exactly TM*TN stores
-            st_pend = interior ? 2 : 0;
-            c_k = 0; c_tile += G;
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (grp == 1) __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    if (grp == 0) __builtin_amdgcn_s_barrier();
-#undef SSTAGE
-#undef SET_LOAD_TILE
-}
-
 }  // namespace
 
 // called from crab_gemm_bf16 (gemm.hip) for the 128x128 tile regime
@@ -553,16 +384,7 @@ int crab_gemm_glds_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* d,
         return crab_check_launch(ctx, "gemm_bt_ring_kernel(split-K)");
     }
     if (d->tune == 301) use_big = false;
-    if (d->tune == 302 || d->tune == 303) use_big = true;        // 302: one block per tile, 303: persistent stream
-    if (use_big && batch == 1 && d->tune == 303) {
-        // persistent stream form: one block per CU (256 on MI355X), each walks ceil(tiles / grid) output tiles.  Measured 3-12 %
-        // SLOWER than one block per tile on every decoder / CLIP shape (profiles/README.md), so it is opt-in (tune 303) only
-        p.tiles_m = (d->M + 255) / 256; p.tiles_n = (d->N + 255) / 256;
-        const int nt = p.tiles_m * p.tiles_n;
-        dim3 grid(nt < 256 ? nt : 256, 1);
-        hipLaunchKernelGGL((gemm_bt_stream_kernel<256, 256, 2, 4>), grid, dim3(512), 0, s, p);
-        return crab_check_launch(ctx, "gemm_bt_stream_kernel");
-    }
+    if (d->tune == 302) use_big = true;
     if (use_big) {
         p.tiles_m = (d->M + 255) / 256; p.tiles_n = (d->N + 255) / 256;
         dim3 grid(p.tiles_m * p.tiles_n, batch);

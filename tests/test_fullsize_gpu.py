@@ -28,8 +28,8 @@ def test_prefill_gemm_kernels_agree_at_full_size():
     w = (torch.randn(N, K, device="cuda", generator=g) * 0.02).to(BF)
     x2 = torch.randn(M, K2, device="cuda", generator=g).to(BF)
     w2 = (torch.randn(N, K2, device="cuda", generator=g) * 0.02).to(BF)
-    outs = [ops.gemm(x, w, x2=x2, w2=w2, out_fp32=True, tune=t) for t in (300, 301, 302, 303)]
-    # fp32 outputs of four different schedules / tile shapes: only the accumulation order differs
+    outs = [ops.gemm(x, w, x2=x2, w2=w2, out_fp32=True, tune=t) for t in (300, 301, 302)]
+    # fp32 outputs of three different schedules / tile shapes: only the accumulation order differs
     scale = outs[0].abs().max().item()
     for o in outs[1:]:
         assert (o - outs[0]).abs().max().item() < 2e-4 * scale
