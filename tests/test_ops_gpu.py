@@ -392,6 +392,37 @@ def test_gemm_ring_split_wide_projection_auto():
     assert (y0 - y1).abs().max().item() < 1e-3 * z.abs().max().item()
 
 
+def test_decode_wide_projections_ring_split_with_fused_epilogues():
+    """The two decode GEMMs that take the 256x256 ring kernel with K slices at M = 256, with their fused reductions:
+    q|k|v (N = 12288, 5 slices) + RoPE / KV append == unfused pair bit for bit; gate|up (N = 22016, 2 slices) + SwiGLU."""
+    from crab_amd import ops
+    M, K, K2, H, d, Tmax = 256, 512, 32, 32, 128, 64
+    x, x2 = _rand(M, K, seed=1), _rand(M, K2, seed=3)
+    # q|k|v
+    N = 3 * H * d
+    w, w2 = _rand(N, K, seed=2, scale=K ** -0.5), _rand(N, K2, seed=4, scale=0.1)
+    tab = ops.rope_table(Tmax, d, 10000.0, "cuda")
+    pos = torch.tensor([9], dtype=torch.int32, device="cuda")
+    outs = []
+    for fused in (False, True):
+        kc = torch.zeros(M, H, Tmax, d, dtype=BF, device="cuda")
+        vc = torch.zeros_like(kc)
+        y = ops.gemm(x.cuda(), w.cuda(), x2=x2.cuda(), w2=w2.cuda(), rope=(tab, kc, vc, H, H, d, Tmax, 0, pos) if fused else None)
+        if not fused:
+            ops.qkv_rope_split(y, tab, kc, vc, None, M, 1, H, H, d, Tmax, pos0=0, pos_dev=pos)
+        outs.append((y[:, :H * d].clone(), kc[:, :, 9].clone(), vc[:, :, 9].clone()))
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    z = x.float() @ w.float().t() + x2.float() @ w2.float().t()
+    _cmp(outs[1][2].reshape(M, H * d), z[:, 2 * H * d:], 1.2e-2, "v rows in the cache")
+    # gate|up
+    I = 11008
+    wg, wu = _rand(I, K, seed=5, scale=K ** -0.5), _rand(I, K, seed=6, scale=K ** -0.5)
+    wi = torch.stack([wg, wu], 1).reshape(2 * I, K).contiguous()
+    y = ops.gemm(x.cuda(), wi.cuda(), act="swiglu_pair")
+    _cmp(y, F.silu(x.float() @ wg.float().t()) * (x.float() @ wu.float().t()), 1.2e-2, "gate|up ring split + swiglu")
+
+
 @pytest.mark.parametrize("M", [4, 48, 256])
 @pytest.mark.parametrize("nproj", [3, 2])
 def test_gemm_post_norm_routes_next_group(M, nproj):
