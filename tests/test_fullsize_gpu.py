@@ -73,3 +73,29 @@ def test_generate_deterministic_and_batch_rows_independent_full_size(crab):
     # different M -> different kernels (skinny vs split-K): same math, different rounding; first-step logits must agree closely
     assert _rel(la[0], ls[0]) < 3e-2, _rel(la[0], ls[0])
     assert a.sequences.shape == (3, 6)
+
+
+def test_decode_batch_256_path_agrees_with_small_batch_full_size(crab):
+    """The benchmark's decode regime (M = 256: ring / two-stage split-K GEMMs, RoPE + KV append fused into the q|k|v
+    reduction, SwiGLU epilogue, routers evaluated in the post-norm reductions) against the SAME sequences decoded at batch 4
+    (LDS-free skinny kernels, separate router / RoPE launches): per-step logits of the shared rows agree to bf16 noise and
+    the greedy ids are identical wherever the small-batch top-2 margin exceeds twice the measured difference."""
+    um = crab.base_model.model
+    D = um.config.hidden_size
+    g = torch.Generator(device="cuda").manual_seed(11)
+    emb = (torch.randn(256, 40, D, device="cuda", generator=g) * 0.05).to(BF)
+    kw = dict(max_new_tokens=5, eos_token_id=None, pad_token_id=2, output_logits=True, return_dict_in_generate=True)
+    big = um.generate(inputs_embeds=emb, **kw)
+    big2 = um.generate(inputs_embeds=emb, **kw)
+    assert torch.equal(big.sequences, big2.sequences), "non-deterministic at batch 256"
+    small = um.generate(inputs_embeds=emb[:4], **kw)
+    lb, ls = torch.stack(big.logits, 1)[:4].float(), torch.stack(small.logits, 1).float()
+    for b in range(4):
+        for s in range(5):
+            err = (lb[b, s] - ls[b, s]).abs().max().item()
+            # two different kernel paths through 32 synthetic layers: accumulation-order noise is amplified (DESIGN.md 4)
+            assert err < 8e-2 * ls[b, s].abs().max().item(), (b, s, err)
+            if big.sequences[b, s] != small.sequences[b, s]:
+                top2 = ls[b, s].topk(2).values
+                assert (top2[0] - top2[1]).item() <= 2 * err, (b, s)
+                break
