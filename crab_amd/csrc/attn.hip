@@ -275,16 +275,18 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
 //   C. each 16-lane group takes a V row, reads its 8 probabilities (two broadcast float4 LDS reads) and accumulates
 //      acc[g][8 dims] += p[g] * v: no per-key exponentials or rescales
 // and the 16 groups are merged through LDS at the end.
-constexpr int GQ_CH = 1024;
+constexpr int GQ_CH = 512;
 
 template <int HD, int G>
-__global__ __launch_bounds__(256) void attn_decode_gqa_kernel(const bf16_t* __restrict__ q, long ldq, const bf16_t* __restrict__ kc,
+__global__ __launch_bounds__(256, (G <= 4 ? 3 : 2)) void attn_decode_gqa_kernel(const bf16_t* __restrict__ q, long ldq, const bf16_t* __restrict__ kc,
                                                               const bf16_t* __restrict__ vc, bf16_t* __restrict__ o, long ldo, int Hk,
                                                               int Tmax, int ctx_host, const int* __restrict__ ctx_dev, float scale) {
     static_assert(HD == 128 && G >= 2 && G <= 8, "grouped decode: head_dim 128, 2..8 query heads per kv head");
     constexpr int EPL = 8;
-    // scores [GQ_CH][8] fp32 (32 KB) during the chunks, reused as the merge buffer [16][G][HD] fp32 at the end
-    constexpr int SMEM_F = (16 * G * HD > GQ_CH * 8) ? 16 * G * HD : GQ_CH * 8;
+    // scores [GQ_CH][8] fp32 (16 KB) during the chunks, reused as the merge buffer [4 waves][G][HD] fp32 at the end (the four
+    // 16-lane groups of a wave are merged by shuffles first): ~30 KB per block keeps 5 blocks = 20 waves resident per CU -
+    // this kernel lives on loads in flight (with the 57 KB version only 2 blocks fitted: 2.7 TB/s)
+    constexpr int SMEM_F = (4 * G * HD > GQ_CH * 8) ? 4 * G * HD : GQ_CH * 8;
     __shared__ __attribute__((aligned(16))) float sbuf[SMEM_F];
     __shared__ float red[4][8];
     __shared__ float m_run[8], l_run[8], alpha_s[8];
@@ -312,36 +314,48 @@ __global__ __launch_bounds__(256) void attn_decode_gqa_kernel(const bf16_t* __re
     for (int c0 = 0; c0 < ctx; c0 += GQ_CH) {
         const int cn = min(GQ_CH, ctx - c0);
         __syncthreads();                                  // previous chunk's probabilities consumed, m_run/l_run visible
-        // ---- A: scores
-        for (int j = grp; j < cn; j += 16) {
-            const u32x4 kw = *reinterpret_cast<const u32x4*>(kb + (long)(c0 + j) * HD);
-            float kx[EPL];
+        // ---- A: scores.  Uniform trip count (rows beyond the chunk are clamped and not stored) so the loop can be unrolled
+        // by hand: FOUR K rows are in flight per lane before the first dot product - this kernel is bound by bytes in flight
+        // (one 16-byte load per lane per trip gave 3.0 TB/s)
+        const int rounds = (cn + 15) >> 4;
+        for (int r0 = 0; r0 < rounds; r0 += 4) {
+            u32x4 kw4[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { kx[2 * e] = lo_bf(kw[e]); kx[2 * e + 1] = hi_bf(kw[e]); }
-            float v8[8];
+            for (int u = 0; u < 4; ++u) {
+                const int jc = min((r0 + u) * 16 + grp, cn - 1);
+                kw4[u] = *reinterpret_cast<const u32x4*>(kb + (long)(c0 + jc) * HD);
+            }
 #pragma unroll
-            for (int g = 0; g < 8; ++g) {
-                float d = 0.f;
-                if (g < G) {
+            for (int u = 0; u < 4; ++u) {
+                const int j = (r0 + u) * 16 + grp;
+                float kx[EPL];
 #pragma unroll
-                    for (int e = 0; e < EPL; ++e) d += qv[g < G ? g : 0][e] * kx[e];
+                for (int e = 0; e < 4; ++e) { kx[2 * e] = lo_bf(kw4[u][e]); kx[2 * e + 1] = hi_bf(kw4[u][e]); }
+                float v8[8];
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    float d = 0.f;
+                    if (g < G) {
+#pragma unroll
+                        for (int e = 0; e < EPL; ++e) d += qv[g < G ? g : 0][e] * kx[e];
+                    }
+                    v8[g] = d;
                 }
-                v8[g] = d;
-            }
-            float w4[4], x2[2];
+                float w4[4], x2[2];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float keep = up8 ? v8[4 + i] : v8[i], send = up8 ? v8[i] : v8[4 + i];
-                w4[i] = keep + __shfl_xor(send, 8, 64);
-            }
+                for (int i = 0; i < 4; ++i) {
+                    const float keep = up8 ? v8[4 + i] : v8[i], send = up8 ? v8[i] : v8[4 + i];
+                    w4[i] = keep + __shfl_xor(send, 8, 64);
+                }
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const float keep = up4 ? w4[2 + i] : w4[i], send = up4 ? w4[i] : w4[2 + i];
-                x2[i] = keep + __shfl_xor(send, 4, 64);
+                for (int i = 0; i < 2; ++i) {
+                    const float keep = up4 ? w4[2 + i] : w4[i], send = up4 ? w4[i] : w4[2 + i];
+                    x2[i] = keep + __shfl_xor(send, 4, 64);
+                }
+                float y = (up2 ? x2[1] : x2[0]) + __shfl_xor(up2 ? x2[0] : x2[1], 2, 64);
+                y += __shfl_xor(y, 1, 64);
+                if ((sub & 1) == 0 && j < cn) sbuf[j * 8 + (sub >> 1)] = y;   // head g = sub >> 1 (columns >= G hold zeros)
             }
-            float y = (up2 ? x2[1] : x2[0]) + __shfl_xor(up2 ? x2[0] : x2[1], 2, 64);
-            y += __shfl_xor(y, 1, 64);
-            if ((sub & 1) == 0) sbuf[j * 8 + (sub >> 1)] = y;            // head g = sub >> 1 (columns >= G hold zeros)
         }
         __syncthreads();
         // ---- B: per-head chunk max -> running max, p = exp(s - m) in place, running sum
@@ -379,32 +393,51 @@ __global__ __launch_bounds__(256) void attn_decode_gqa_kernel(const bf16_t* __re
 #pragma unroll
             for (int e = 0; e < EPL; ++e) acc[g][e] *= a;
         }
-        for (int j = grp; j < cn; j += 16) {
-            const u32x4 vw = *reinterpret_cast<const u32x4*>(vb + (long)(c0 + j) * HD);
-            const f32x4_t p0 = *reinterpret_cast<const f32x4_t*>(sbuf + j * 8);
-            const f32x4_t p1 = *reinterpret_cast<const f32x4_t*>(sbuf + j * 8 + 4);
-            float vx[EPL];
+        for (int r0 = 0; r0 < rounds; r0 += 4) {
+            u32x4 vw4[4];
+            f32x4_t p04[4], p14[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { vx[2 * e] = lo_bf(vw[e]); vx[2 * e + 1] = hi_bf(vw[e]); }
+            for (int u = 0; u < 4; ++u) {
+                const int j = (r0 + u) * 16 + grp, jc = min(j, cn - 1);
+                vw4[u] = *reinterpret_cast<const u32x4*>(vb + (long)(c0 + jc) * HD);
+                p04[u] = *reinterpret_cast<const f32x4_t*>(sbuf + jc * 8);
+                p14[u] = *reinterpret_cast<const f32x4_t*>(sbuf + jc * 8 + 4);
+                if (j >= cn) { p04[u] = f32x4_t{0.f, 0.f, 0.f, 0.f}; p14[u] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+            }
 #pragma unroll
-            for (int g = 0; g < G; ++g) {
-                const float pg = g < 4 ? p0[g & 3] : p1[g & 3];
+            for (int u = 0; u < 4; ++u) {
+                float vx[EPL];
 #pragma unroll
-                for (int e = 0; e < EPL; ++e) acc[g][e] += pg * vx[e];
+                for (int e = 0; e < 4; ++e) { vx[2 * e] = lo_bf(vw4[u][e]); vx[2 * e + 1] = hi_bf(vw4[u][e]); }
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const float pg = g < 4 ? p04[u][g & 3] : p14[u][g & 3];
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) acc[g][e] += pg * vx[e];
+                }
             }
         }
     }
     __syncthreads();
-    // ---- merge the 16 key groups (all share the running max): plain sums, then normalise
+    // ---- merge the 16 key groups (all share the running max): the 4 groups of a wave by shuffles, the 4 waves through LDS
 #pragma unroll
     for (int g = 0; g < G; ++g)
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) sbuf[(grp * G + g) * HD + sub * EPL + e] = acc[g][e];
+        for (int e = 0; e < EPL; ++e) {
+            float v = acc[g][e];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            acc[g][e] = v;
+        }
+    if (lane < 16) {
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) sbuf[(wave * G + g) * HD + sub * EPL + e] = acc[g][e];
+    }
     __syncthreads();
     for (int idx = tid; idx < G * HD; idx += 256) {
-        float O = 0.f;
-#pragma unroll
-        for (int gr = 0; gr < 16; ++gr) O += sbuf[gr * G * HD + idx];
+        const float O = (sbuf[idx] + sbuf[G * HD + idx]) + (sbuf[2 * G * HD + idx] + sbuf[3 * G * HD + idx]);
         const int g = idx / HD;
         o[(long)b * ldo + (long)(hk * G) * HD + idx] = f2bf(O / l_run[g]);
     }
