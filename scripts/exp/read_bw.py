@@ -16,3 +16,14 @@ print(f"torch max fp32 4 GiB: {ms:.3f} ms -> {x.numel()*4/ms/1e6:.0f} GB/s")
 y = torch.empty_like(x)
 ms = t(lambda: y.copy_(x))
 print(f"torch copy 4 GiB: {ms:.3f} ms -> {2*x.numel()*4/ms/1e6:.0f} GB/s (read+write)")
+# ---- hand-written streaming read (scripts/exp/read_bw.hip): blocks x loads-in-flight sweep
+import ctypes as C, os
+lib = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "read_bw.so"))
+lib.launch_read.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_int, C.c_int]
+out = torch.zeros(1 << 20, device="cuda", dtype=torch.int32)
+nbytes = x.numel() * 4
+for blocks in (1024, 2048, 4096, 8192, 16384):
+    for un in (1, 4, 8):
+        fn = lambda: lib.launch_read(torch.cuda.current_stream().cuda_stream, x.data_ptr(), nbytes, out.data_ptr(), blocks, un)
+        ms = t(fn)
+        print(f"read kernel blocks={blocks:6d} loads in flight={un}: {nbytes/ms/1e6:.0f} GB/s")
