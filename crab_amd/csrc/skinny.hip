@@ -140,41 +140,54 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(SkinnyP p) {
 }
 
 // ---------------------------------------------------------------------------------------------- hyper-LoRA router
-// grid (nslices, ceil(M/64)); 4 waves, wave w owns rows 16w..16w+15 of the block's 64; all waves share the K slice.
-template <int NT>
+// grid (nslices, ceil(M/(64*MT))); 4 waves, wave w owns MT 16-row tiles (rows 16*(w*MT + i) ..) of the block's 64*MT rows; all
+// waves share the K slice.  MT = 1 in the decode regime; MT = 4 for prefill-sized M: every [R;A] fragment a lane loads is then
+// used for four row tiles, which cuts the dominant (L2) operand traffic of this skinny product by 4.
+template <int NT, int MT>
 __global__ __launch_bounds__(256) void lora_t_partial_kernel(const bf16_t* __restrict__ X, long ldx, const bf16_t* __restrict__ RA, long ldra,
                                                              float* __restrict__ part, int M, int K, int kslice) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int fr = lane & 15, fg = lane >> 4;
     const int sl = blockIdx.x;
-    const int m0 = blockIdx.y * 64 + wave * 16;
+    const int m0 = (blockIdx.y * 4 + wave) * 16 * MT;
     if (m0 >= M) return;
-    const int mrow = min(m0 + fr, M - 1);
-    const int k_begin = sl * kslice, k_end = min(K, k_begin + kslice);
-    f32x4_t acc[NT];
+    int mrow[MT];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < MT; ++i) mrow[i] = min(m0 + i * 16 + fr, M - 1);
+    const int k_begin = sl * kslice, k_end = min(K, k_begin + kslice);
+    f32x4_t acc[NT][MT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const u32x4 z4 = {0u, 0u, 0u, 0u};
     for (int k0 = k_begin; k0 < k_end; k0 += 32) {
         const int k = k0 + fg * 8;
         const bool ok = k < k_end;
         const int kc = ok ? k : 0;
-        union { u32x4 r; bf16x8_t f; } xf;
-        xf.r = *reinterpret_cast<const u32x4*>(X + (long)mrow * ldx + kc);
-        if (!ok) xf.r = z4;
+        union Frag { u32x4 r; bf16x8_t f; };
+        Frag xf[MT], wf[NT];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            union { u32x4 r; bf16x8_t f; } wf;
-            wf.r = *reinterpret_cast<const u32x4*>(RA + (long)(j * 16 + fr) * ldra + kc);
-            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf.f, xf.f, acc[j], 0, 0, 0);
+        for (int i = 0; i < MT; ++i) {
+            xf[i].r = *reinterpret_cast<const u32x4*>(X + (long)mrow[i] * ldx + kc);
+            if (!ok) xf[i].r = z4;
         }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) wf[j].r = *reinterpret_cast<const u32x4*>(RA + (long)(j * 16 + fr) * ldra + kc);
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j].f, xf[i].f, acc[j][i], 0, 0, 0);
     }
     // D[row = t-col 4fg+r][col = m fr]; part layout [slice][m][NT*16]
-    const int m = m0 + fr;
-    if (m < M) {
-        float* o = part + ((long)sl * M + m) * (NT * 16);
 #pragma unroll
-        for (int j = 0; j < NT; ++j) *reinterpret_cast<f32x4_t*>(o + j * 16 + fg * 4) = acc[j];
+    for (int i = 0; i < MT; ++i) {
+        const int m = m0 + i * 16 + fr;
+        if (m < M) {
+            float* o = part + ((long)sl * M + m) * (NT * 16);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) *reinterpret_cast<f32x4_t*>(o + j * 16 + fg * 4) = acc[j][i];
+        }
     }
 }
 
@@ -270,8 +283,16 @@ static int route_slices(int M, int K) {
     return nslices;
 }
 
+// launch shape shared by the workspace query and the launch: row tiles per wave and K slices
+static void route_cfg(int M, int K, int* MT, int* nslices) {
+    *MT = M >= 4096 ? 4 : 1;                                      // prefill-sized M: four row tiles per wave
+    *nslices = route_slices(*MT == 4 ? (M + 3) / 4 : M, K);       // (slice, row block) pairs for ~4 blocks per CU
+}
+
 extern "C" int64_t crab_hyperlora_route_workspace(int M, int K, int tcols) {
-    return (int64_t)route_slices(M, K) * M * tcols * (int64_t)sizeof(float);
+    int MT, ns;
+    route_cfg(M, K, &MT, &ns);
+    return (int64_t)ns * M * tcols * (int64_t)sizeof(float);
 }
 
 extern "C" int crab_hyperlora_route(crab_ctx* ctx, void* stream, const void* X, int64_t ldx, const void* RA, int64_t ldra, int M, int K,
@@ -283,17 +304,20 @@ extern "C" int crab_hyperlora_route(crab_ctx* ctx, void* stream, const void* X, 
     if (nl + r > 16 || nproj < 1 || nproj > 3 || ucols < nproj * nl * r) return crab_fail(ctx, CRAB_E_UNSUPPORTED, "hyperlora_route: nl+r <= 16, nproj <= 3");
     const int tcols = ((nproj * (nl + r) + 15) / 16) * 16;        // RA must hold tcols rows (zero padded)
     if (crab_hyperlora_route_workspace(M, K, tcols) > workspace_bytes) return crab_fail(ctx, CRAB_E_WORKSPACE, "hyperlora_route: workspace too small");
-    int mblocks = (M + 63) / 64;
-    int nslices = route_slices(M, K);
+    int MT, nslices;
+    route_cfg(M, K, &MT, &nslices);
+    int mblocks = (M + 64 * MT - 1) / (64 * MT);
+    hipStream_t s = (hipStream_t)stream;
     int kslice = (((K + nslices - 1) / nslices) + 31) / 32 * 32;
     nslices = (K + kslice - 1) / kslice;
-    hipStream_t s = (hipStream_t)stream;
     dim3 grid(nslices, mblocks), block(256);
     float* part = (float*)workspace;
     const int NT = tcols / 16;
-    if (NT == 1) hipLaunchKernelGGL((lora_t_partial_kernel<1>), grid, block, 0, s, (const bf16_t*)X, (long)ldx, (const bf16_t*)RA, (long)ldra, part, M, K, kslice);
-    else if (NT == 2) hipLaunchKernelGGL((lora_t_partial_kernel<2>), grid, block, 0, s, (const bf16_t*)X, (long)ldx, (const bf16_t*)RA, (long)ldra, part, M, K, kslice);
-    else hipLaunchKernelGGL((lora_t_partial_kernel<3>), grid, block, 0, s, (const bf16_t*)X, (long)ldx, (const bf16_t*)RA, (long)ldra, part, M, K, kslice);
+#define RT_LAUNCH(NT_, MT_) hipLaunchKernelGGL((lora_t_partial_kernel<NT_, MT_>), grid, block, 0, s, (const bf16_t*)X, (long)ldx, (const bf16_t*)RA, \
+                                               (long)ldra, part, M, K, kslice)
+    if (MT == 4) { if (NT == 1) RT_LAUNCH(1, 4); else if (NT == 2) RT_LAUNCH(2, 4); else RT_LAUNCH(3, 4); }
+    else { if (NT == 1) RT_LAUNCH(1, 1); else if (NT == 2) RT_LAUNCH(2, 1); else RT_LAUNCH(3, 1); }
+#undef RT_LAUNCH
     int rc = crab_check_launch(ctx, "lora_t_partial_kernel");
     if (rc) return rc;
     if (tcols > 64) return crab_fail(ctx, CRAB_E_UNSUPPORTED, "hyperlora_route: tcols <= 64");

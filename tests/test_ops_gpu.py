@@ -309,7 +309,7 @@ def test_beats_helpers_match_golden_buckets():
 
 
 @pytest.mark.parametrize("M,K,nproj", [(8, 4096, 3), (64, 11008, 1), (70, 128, 2), (2808, 4096, 3), (1, 256, 1), (256, 4096, 3), (256, 11008, 1),
-                                       (250, 4096, 2), (257, 4096, 3)])
+                                       (250, 4096, 2), (257, 4096, 3), (4500, 4096, 3), (5000, 1056, 1)])
 def test_hyperlora_route_matches_gemm_plus_mix(M, K, nproj):
     """Router (fused single launch for M <= 256, split-K pair above) == (fp32 product -> softmax mix), run-to-run deterministic."""
     from crab_amd import ops
