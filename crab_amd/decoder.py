@@ -147,8 +147,7 @@ class GenerationEngine:
         self._rope = None
         self._ws = {}
         self._kv = {}
-        self._graph = None
-        self._graph_key = None
+        self._dec = {}                 # slot -> persistent decode state (+ captured graph)
 
     # ------------------------------------------------------------------ helpers
     @property
@@ -156,8 +155,7 @@ class GenerationEngine:
         return self.lm_head.weight.device
 
     def invalidate(self):
-        self._graph = None
-        self._graph_key = None
+        self._dec = {}
         self._ws = {}
         self._kv = {}
 
@@ -302,20 +300,33 @@ class GenerationEngine:
         Tmax = _round_up(S + max_new_tokens, 64)
         kc, vc = self.alloc_cache(B, Tmax, slot=slot)
         V = self.lm_head.weight.shape[0]
-        st = _DecodeState()
-        st.B, st.S, st.Tmax, st.kc, st.vc, st.slot = B, S, Tmax, kc, vc, slot
-        st.ws = self._workspace(B, slot)
-        st.logits = torch.empty((B, V), device=dev, dtype=torch.float32)
-        st.hn = torch.empty((B, D), device=dev, dtype=BF16)
-        st.cur_ids = torch.zeros((B,), device=dev, dtype=torch.int64)
-        st.out_ids = torch.full((B, max_new_tokens), pad_token_id if pad_token_id is not None else 0, device=dev, dtype=torch.int64)
-        st.finished = torch.zeros((B,), device=dev, dtype=torch.int32)
-        st.pos_dev = torch.full((1,), S - 1, device=dev, dtype=torch.int32)
-        st.step_dev = torch.zeros((1,), device=dev, dtype=torch.int32)
-        st.eos = -1 if eos_token_id is None else int(eos_token_id)
-        st.pad = int(pad_token_id) if pad_token_id is not None else (st.eos if st.eos >= 0 else 0)
-        st.min_new = int(min_new_tokens)
-        st.want_hidden = bool(return_hidden)
+        eos = -1 if eos_token_id is None else int(eos_token_id)
+        pad = int(pad_token_id) if pad_token_id is not None else (eos if eos >= 0 else 0)
+        ws = self._workspace(B, slot)
+        tab = self._rope_tab(Tmax)
+        # The decode state (and the HIP graph captured over it) is kept per group and reused by every generate() whose shapes,
+        # flags and buffers are the same: the key holds everything the captured launches bake in (pointers included).
+        key = (B, Tmax, max_new_tokens, eos, pad, int(min_new_tokens), bool(return_hidden), kc.data_ptr(), vc.data_ptr(), id(ws),
+               tab.data_ptr(), self.lm_head.weight.data_ptr(), self.model.embed_tokens.weight.data_ptr(),
+               self.model.layers[0].self_attn._qkv.W.data_ptr(),
+               self.model.layers[0].self_attn._qkv.RA is not None)
+        st = self._dec.get(slot)
+        if st is None or st.key != key:
+            st = _DecodeState()
+            st.key, st.graph = key, None
+            st.B, st.Tmax, st.kc, st.vc, st.slot, st.ws = B, Tmax, kc, vc, slot, ws
+            st.logits = torch.empty((B, V), device=dev, dtype=torch.float32)
+            st.hn = torch.empty((B, D), device=dev, dtype=BF16)
+            st.cur_ids = torch.empty((B,), device=dev, dtype=torch.int64)
+            st.out_ids = torch.empty((B, max_new_tokens), device=dev, dtype=torch.int64)
+            st.finished = torch.empty((B,), device=dev, dtype=torch.int32)
+            st.pos_dev = torch.empty((1,), device=dev, dtype=torch.int32)
+            st.step_dev = torch.empty((1,), device=dev, dtype=torch.int32)
+            st.eos, st.pad, st.min_new, st.want_hidden = eos, pad, int(min_new_tokens), bool(return_hidden)
+            self._dec[slot] = st
+        st.S = S
+        st.cur_ids.zero_(); st.out_ids.fill_(pad_token_id if pad_token_id is not None else 0); st.finished.zero_()
+        st.pos_dev.fill_(S - 1); st.step_dev.zero_()
         # ---- prefill in chunks of sequences (bounds activation memory, keeps GEMM M in the MFMA-efficient range)
         for b0 in range(0, B, prefill_chunk):
             b1 = min(B, b0 + prefill_chunk)
@@ -416,7 +427,10 @@ class GenerationEngine:
         return res[0] if len(res) == 1 else tuple(res)
 
     def _capture(self, st: "_DecodeState"):
-        """Capture one decode step into a HIP graph on a side stream (torch.cuda.CUDAGraph = hipGraph on ROCm)."""
+        """Capture one decode step into a HIP graph on a side stream (torch.cuda.CUDAGraph = hipGraph on ROCm); the graph is
+        kept with the state and reused while the state's key holds."""
+        if st.graph is not None:
+            return st.graph
         # warm-up run outside capture is not possible without mutating state; instead snapshot and restore
         snap = (st.cur_ids.clone(), st.out_ids.clone(), st.finished.clone(), st.pos_dev.clone(), st.step_dev.clone())
         s = torch.cuda.Stream()
@@ -432,6 +446,7 @@ class GenerationEngine:
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             self._decode_step(st)
+        st.graph = g
         return g
 
 
