@@ -59,8 +59,10 @@ def randomize_(model: torch.nn.Module, seed: int = 42, std: float = 0.02, condit
 
 
 def build_crab(llm: str = "llama", device="cuda", num_hidden_layers: Optional[int] = None, seed: int = 42,
-               visual: bool = True, audio: bool = True, randomize: bool = True, conditioned: bool = False):
-    """Full-size Crab (Llama-2-7B or Qwen2-7B decoder + CLIP ViT-L/14 + BEATs iter3+ + Q-Former projectors)."""
+               visual: bool = True, audio: bool = True, randomize: bool = True, conditioned: bool = False, segment: bool = False,
+               vqgan: bool = False):
+    """Full-size Crab (Llama-2-7B or Qwen2-7B decoder + CLIP ViT-L/14 + BEATs iter3+ + Q-Former projectors; segment=True adds
+    the SegModule of the AVS tasks, vqgan=True the taming f16/16384 MaskEncoder, as scripts/quick_start.py:505-529 would)."""
     if llm == "llama":
         from .unified_llama import UnifiedConfig, UnifiedForCausalLM
         cfg = UnifiedConfig(hidden_size=4096, intermediate_size=11008, num_hidden_layers=32, num_attention_heads=32,
@@ -77,7 +79,7 @@ def build_crab(llm: str = "llama", device="cuda", num_hidden_layers: Optional[in
     model = get_peft_model(UnifiedForCausalLM(cfg, device=device), LoraConfig())
     model.get_model().pad_token_id = cfg.pad_token_id
     model.get_model().init_multimodal_modules(d_model=cfg.hidden_size, visual_branch=visual, audio_branch=audio,
-                                              select_layer_list=[14, 22, 23])
+                                              select_layer_list=[14, 22, 23], segment_branch=segment, use_vqgan=vqgan)
     model.initialize_MM_tokenizer(CountingTokenizer(base_vocab), mask_token_nums=6)
     model.base_vocab = base_vocab
     if randomize:

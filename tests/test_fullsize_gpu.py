@@ -99,3 +99,29 @@ def test_decode_batch_256_path_agrees_with_small_batch_full_size(crab):
                 top2 = ls[b, s].topk(2).values
                 assert (top2[0] - top2[1]).item() <= 2 * err, (b, s)
                 break
+
+
+def test_generate_avs_full_width_shapes():
+    """SegModule at the reference's full widths (d_model 4096, prompt dim 256, 300 queries, CLIP-L/14 features 1024) on a
+    2-layer decoder: generate_avs runs end to end, returns the reference's dict, is deterministic, and the masks are finite."""
+    from crab_amd import synth
+    from crab_amd.build_model import build_crab
+    model = build_crab("llama", num_hidden_layers=2, segment=True, seed=5)
+    sp = model.SPECIAL_TOKEN_2_IDS
+    ids = synth.synth_prompt_ids(48, model.base_vocab, sp, clip=3)
+    for a_, b_ in (("<video_start>", "<image_start>"), ("<video>", "<image>"), ("<video_end>", "<image_end>")):
+        ids[ids == sp[a_]] = sp[b_]
+    mods = [{'<image>': synth.synth_video(1, clip=3).cuda(), '<audio>': synth.synth_audio(10, 98, clip=3).cuda()}]
+    lab = [torch.full_like(ids, -100)]
+    kw = dict(batch_input_ids=[ids.cuda()], batch_labels=lab, batch_X_modals=mods, batch_task_names=['s4'], max_new_tokens=8, pad_token_id=2,
+              eos_token_id=None)
+    plain = model.generate(**kw).cpu()
+    for i in range(6):                                   # make the six generated ids the <mask_i> tokens, as the tiny test does
+        sp[f'<mask_{i}>'] = int(plain[0, 1 + i])
+    if len({sp[f'<mask_{i}>'] for i in range(6)}) < 6:
+        pytest.skip("synthetic decoder repeated a token; the mask-token picks need six distinct ids")
+    res = model.generate_avs(**kw)
+    res2 = model.generate_avs(**kw)
+    assert torch.equal(res['output_ids'].cpu(), plain)
+    assert len(res['pred_masks']) == 1 and tuple(res['pred_masks'][0].shape) == (1, 224, 224)
+    assert torch.isfinite(res['pred_masks'][0]).all() and torch.equal(res['pred_masks'][0], res2['pred_masks'][0])
