@@ -43,10 +43,19 @@ HBM_PEAK_GBS = 8000.0
 ATTN_DECODE_TRAFFIC_PER_ALGO_BYTE = 1.0002
 
 
-def flops_per_clip(T_v=8, T_a=10, n_a=48, S=702, V=32017):
-    """SURVEY.md 8d parametric form (minimal work)."""
+def flops_per_clip(T_v=8, T_a=10, n_a=48, S=702, V=32017, cfg=None):
+    """SURVEY.md 8d parametric form (minimal work).  Decoder terms default to Llama-2-7B (6.476e9 linear MAC-params,
+    90.3 MFLOP/token of hyper-LoRA, 32 layers x 4096 wide attention); with `cfg` they are derived from the decoder config."""
     f_beats = 12 * 0.687e9 * (n_a / 48) + 0.453e9 + 0.050e9
-    return (T_v * (155.3e9 + 4.0e9) + T_a * (f_beats + 2.57e9) + S * (2 * 6.476e9 + 90.3e6) + 2 * S * S * 131072 + 2 * V * 4096)
+    lin, lora, attn_w, D = 6.476e9, 90.3e6, 131072, 4096
+    if cfg is not None:
+        D, I, L = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers
+        H, Hk, d = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.hidden_size // cfg.num_attention_heads
+        lin = L * (D * (H + 2 * Hk) * d + H * d * D + 3 * D * I)
+        # router + A (3+8 rows) on every projection input and three rank-8 B matrices on every projection output
+        lora = 2.0 * L * (11 * (4 * D + H * d + I) + 24 * ((H + 2 * Hk) * d + D + 2 * I + D))
+        attn_w = L * H * d
+    return (T_v * (155.3e9 + 4.0e9) + T_a * (f_beats + 2.57e9) + S * (2 * lin + lora) + 2 * S * S * attn_w + 2 * V * D)
 
 
 def decode_bytes_per_step(B, ctx, V=32017):
@@ -231,7 +240,7 @@ def main():
         # the north-star target quantity: fused encoder + decoder prefill (prepare_multimodal_inputs + chunked prefill +
         # first-token selection) of all clips, algorithmic FLOPs / HIP-event time of that phase
         pre_ms, dec_ms = prof.phase_ms()
-        pre_flops = flops_per_clip(args.frames, 10, 48, S, V) * B * args.steps
+        pre_flops = flops_per_clip(args.frames, 10, 48, S, V, um.config) * B * args.steps
         prefill_roof = {"bound": "mfma", "phase": "encoders + decoder prefill (whole phase, all kernels)",
                         "achieved": round(pre_flops / (pre_ms * 1e-3) / 1e12, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(pre_flops / (pre_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
@@ -245,7 +254,7 @@ def main():
                                      "AVQA eval, Qwen2-7B + BEATs + CLIP-ViT-L/14, bf16 (BASELINE configs[2] decoder)"), "clips_per_gpu_per_step": B,
                        "frames": args.frames, "audio_segments": 10, "prompt_tokens": 128, "prefill_len": S, "new_tokens": args.new_tokens,
                        "decode": "greedy, EOS suppressed, device-resident HIP-graph loop", "parallelism": f"per-clip x{world}, RCCL gather"},
-            "prefill_tflop_per_clip": round(flops_per_clip(args.frames, 10, 48, S, V) / 1e12, 3),
+            "prefill_tflop_per_clip": round(flops_per_clip(args.frames, 10, 48, S, V, um.config) / 1e12, 3),
             "step_ms": step_ms,
             "prefill_roofline": prefill_roof,
             "roofline": roof,
