@@ -54,6 +54,8 @@ class AttnDesc(C.Structure):
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 SYMBOLS = {
     "crab_abi_version": (_i, []),
+    "crab_sizeof_gemm_desc": (_i, []),
+    "crab_sizeof_attn_desc": (_i, []),
     "crab_ctx_create": (_i, [_i, C.POINTER(_vp)]),
     "crab_ctx_destroy": (None, [_vp]),
     "crab_last_error": (C.c_char_p, [_vp]),

@@ -6,6 +6,9 @@ extern "C" {
 
 int crab_abi_version(void) { return 3; }   // 2: fused RoPE / KV-append fields in crab_gemm_desc; 3: next-group router fields
 
+int crab_sizeof_gemm_desc(void) { return (int)sizeof(crab_gemm_desc); }
+int crab_sizeof_attn_desc(void) { return (int)sizeof(crab_attn_desc); }
+
 int crab_ctx_create(int device, crab_ctx** out) {
     if (!out) return CRAB_E_INVALID;
     *out = nullptr;

@@ -34,6 +34,9 @@ void crab_ctx_destroy(crab_ctx* ctx);
 const char* crab_last_error(crab_ctx* ctx);
 int crab_sync(crab_ctx* ctx, void* stream);
 int crab_abi_version(void);
+/* sizeof(crab_gemm_desc) / sizeof(crab_attn_desc) as compiled into the library: lets a binding verify its struct mirror */
+int crab_sizeof_gemm_desc(void);
+int crab_sizeof_attn_desc(void);
 
 /* activation codes for epilogues */
 enum { CRAB_ACT_NONE = 0, CRAB_ACT_GELU = 1, CRAB_ACT_QUICK_GELU = 2, CRAB_ACT_RELU = 3, CRAB_ACT_SILU = 4 };

@@ -14,7 +14,7 @@ def _declared():
     out = set()
     for f in os.listdir(os.path.join(ROOT, "include")):
         txt = open(os.path.join(ROOT, "include", f)).read()
-        out |= set(re.findall(r"^\s*(?:int|void|const char\*)\s+(crab_[a-z0-9_]+)\s*\(", txt, flags=re.M))
+        out |= set(re.findall(r"^\s*(?:int|int64_t|void|const char\*)\s+(crab_[a-z0-9_]+)\s*\(", txt, flags=re.M))
     return out
 
 
@@ -30,7 +30,7 @@ def test_every_declared_symbol_is_exported_and_bound():
         assert hasattr(lib, name), f"{name} declared in include/ but not exported"
     missing = declared - set(_lib.SYMBOLS)
     assert not missing, f"ctypes bindings missing for {missing}"
-    assert lib.crab_abi_version() >= 1
+    assert lib.crab_abi_version() >= 3
 
 
 def test_ops_fail_loudly_without_gpu_tensors():
@@ -39,3 +39,23 @@ def test_ops_fail_loudly_without_gpu_tensors():
     x = torch.zeros(8, 8, dtype=torch.bfloat16)
     with pytest.raises(_lib.CrabHipError):
         ops.gemm(x, x)
+
+
+def test_struct_mirrors_match_the_compiled_layout():
+    """The ctypes mirrors of crab_gemm_desc / crab_attn_desc must have the size the library was compiled with."""
+    import ctypes as C
+    lib = _lib.load()
+    assert C.sizeof(_lib.GemmDesc) == lib.crab_sizeof_gemm_desc()
+    assert C.sizeof(_lib.AttnDesc) == lib.crab_sizeof_attn_desc()
+
+
+def test_entry_points_reject_null_context_and_operands_without_a_gpu():
+    """Argument validation happens before any HIP call: exercised here without a device."""
+    import ctypes as C
+    lib = _lib.load()
+    g = _lib.GemmDesc()
+    assert lib.crab_gemm_bf16(None, None, C.byref(g)) < 0
+    assert lib.crab_rmsnorm(None, None, None, 0, None, None, 0, 1, 8, C.c_float(1e-5)) < 0
+    assert lib.crab_bicubic_ksize(0, 10) < 0 and lib.crab_bicubic_ksize(480, 224) == 2 * 5 + 1
+    assert lib.crab_kaldi_fbank_frames(16000) == 98
+    assert lib.crab_hyperlora_route_workspace(256, 4096, 48) > 0 and lib.crab_groupnorm_workspace(2, 65536, 32) > 0

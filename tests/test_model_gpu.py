@@ -303,3 +303,44 @@ def test_generate_many_clips_vs_oracle():
         ref_ids, ref_logits = O.generate(ids, mods, Wo, ocfg, n)
         worst = max(worst, _check_ids(r.sequences, ref_ids, ref_logits, torch.stack(r.logits, 1)))
     assert worst < REL_F32 * 10.0
+
+
+def test_generate_edge_cases_vs_oracle():
+    """Prompts the AVQA fixture does not cover: text only, video only, audio only, an <image> block, one- and two-token
+    generations (no HIP graph below three tokens), EOS on the very first token - each against the golden-pinned oracle."""
+    from crab_amd import synth
+    from oracle import crab_oracle as O
+    from tests.test_oracle_golden import _full_cfg
+    meta, A = load_fixture("full_tiny_llama")
+    W = weights_from_table(meta)
+    model = build_tiny_crab(meta)
+    model.load_state_dict(W, strict=False)
+    Wo = _bf(O.strip_peft_prefix(W))
+    ocfg = _full_cfg(meta)
+    sp = model.SPECIAL_TOKEN_2_IDS
+    p = meta["prompts"]
+    g = torch.Generator().manual_seed(123)
+    text = torch.randint(3, ocfg.base_vocab, (19,), generator=g)
+    vid = synth.synth_video(p["t_v"], seed=meta["seed"], clip=41)
+    aud = synth.synth_audio(p["t_a"], p["l_a"], seed=meta["seed"], clip=41)
+    def with_block(kind):
+        ids = text.clone()
+        ids[4:7] = torch.tensor([sp[f"<{kind}_start>"], sp[f"<{kind}>"], sp[f"<{kind}_end>"]])
+        return ids
+    cases = [("text only", text.clone(), {}),
+             ("video only", with_block("video"), {'<video>': vid}),
+             ("audio only", with_block("audio"), {'<audio>': aud}),
+             ("image", with_block("image"), {'<image>': vid[:1]})]
+    for name, ids, mod in cases:
+        for n in (1, 2, 5):
+            r = model.generate(batch_input_ids=[ids], batch_labels=[torch.full_like(ids, -100)], batch_X_modals=[mod], batch_task_names=['avqa'],
+                               use_cache=True, max_new_tokens=n, pad_token_id=2, eos_token_id=None, output_logits=True, return_dict_in_generate=True)
+            ref_ids, ref_logits = O.generate([ids], [mod], Wo, ocfg, n)
+            assert r.sequences.shape == (1, n), name
+            _check_ids(r.sequences, ref_ids, ref_logits, torch.stack(r.logits, 1))
+    # EOS == the first generated token: one column, generation stops immediately (HF semantics)
+    ids, mod = cases[1][1], cases[1][2]
+    first = int(O.generate([ids], [mod], Wo, ocfg, 1)[0][0, 0])
+    out = model.generate(batch_input_ids=[ids], batch_labels=[torch.full_like(ids, -100)], batch_X_modals=[mod], batch_task_names=['avqa'],
+                         max_new_tokens=20, pad_token_id=2, eos_token_id=first)
+    assert out.shape == (1, 1) and int(out[0, 0]) == first
