@@ -514,3 +514,30 @@ def test_gemm_big_ring_kernel(M, N, K, K2, tune):
     y2 = ops.gemm(x.cuda(), w.cuda(), bias=b.cuda(), act="gelu", residual=r.cuda(), x2=x2.cuda() if K2 else None,
                   w2=w2.cuda() if K2 else None, out_fp32=True, tune=301)
     assert (y - y2).abs().max().item() < 1e-3 * z.abs().max().item(), "ring vs 2-stage kernel disagree"
+
+
+def test_invalid_arguments_fail_loudly_with_a_message():
+    """C-ABI error behaviour: bad shapes / alignments / unsupported variants return a negative code with a
+    message in crab_last_error, surfaced as CrabHipError by the Python side; nothing falls back silently."""
+    from crab_amd import ops
+    from crab_amd._lib import CrabHipError
+    x = _rand(8, 20, seed=1).cuda()                     # K = 20 is not a multiple of 8
+    with pytest.raises(CrabHipError, match="multiples of 8"):
+        ops.gemm(x, _rand(16, 20, seed=2).cuda())
+    a, w = _rand(8, 64, seed=1).cuda(), _rand(16, 64, seed=2).cuda()
+    with pytest.raises(CrabHipError, match="A2/B2"):
+        from crab_amd._lib import GemmDesc
+        g = GemmDesc()
+        out = torch.empty(8, 16, dtype=BF, device="cuda")
+        g.A, g.B, g.C, g.A2 = a.data_ptr(), w.data_ptr(), out.data_ptr(), a.data_ptr()
+        g.lda = g.ldb = 64; g.ldc = 16; g.M, g.N, g.K = 8, 16, 64; g.batch = g.nb0 = 1; g.res_scale = 1.0
+        ops.gemm_desc(g)
+    with pytest.raises(CrabHipError, match="swiglu-pair"):
+        ops.gemm(a, _rand(18, 64, seed=3).cuda(), act="swiglu_pair")            # N % 4 != 0
+    q = _rand(2, 4 * 96, seed=4).cuda()
+    kc = torch.zeros(2, 4, 16, 96, dtype=BF, device="cuda")
+    with pytest.raises(CrabHipError, match="head_dim"):
+        ops.attn_decode(q, kc, kc, torch.empty_like(q), 2, 4, 4, 96, 16, 4, 0.1)
+    with pytest.raises(CrabHipError, match="overflow"):
+        ops.qkv_rope_split(_rand(2 * 5, 3 * 4 * 64, seed=5).cuda(), ops.rope_table(16, 64, 1e4, "cuda"), torch.zeros(2, 4, 4, 64, dtype=BF, device="cuda"),
+                           torch.zeros(2, 4, 4, 64, dtype=BF, device="cuda"), None, 2, 5, 4, 4, 64, 4, pos0=0)
