@@ -151,12 +151,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hooks (no effect in a normal launch): CRAB_BENCH_SINGLE_DEVICE=1 maps every rank to cuda:0 and CRAB_BENCH_BACKEND=gloo
+    # swaps RCCL for gloo, so the multi-process path (rendezvous, barriers, max-over-ranks, gather, rank-0 line) can be exercised on
+    # a one-GPU box
+    if os.environ.get("CRAB_BENCH_SINGLE_DEVICE") == "1":
+        local = 0
+    backend = os.environ.get("CRAB_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from crab_amd import ops, synth
     from crab_amd.build_model import build_crab
@@ -203,7 +212,7 @@ def main():
     dt = time.perf_counter() - t0
     ops.PROFILER = None
     if dist is not None:
-        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        tt = torch.tensor([dt], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     psum = prof.summary()

@@ -27,6 +27,9 @@ def gather_results(ids: torch.Tensor, clip0: int, world: int, rank: int, logits:
     if world == 1:
         return cid, ids, logits
     import torch.distributed as dist
+    if dist.get_backend() == "gloo":                      # CPU tests / one-GPU rehearsals: gloo gathers host tensors
+        ids, cid = ids.cpu(), cid.cpu()
+        logits = logits.cpu() if logits is not None else None
     rec = torch.cat([cid[:, None], ids.to(torch.int64)], dim=1).contiguous()
     bufs = [torch.empty_like(rec) for _ in range(world)] if rank == 0 else None
     dist.gather(rec, bufs, dst=0)
