@@ -53,6 +53,20 @@ __device__ __forceinline__ float apply_act(float x, int act) {
     }
 }
 
+// Logical tile id -> (tm, tn) in BANDS of GM tile rows: ids walk the GM rows of a band first, then the band's columns, then the
+// next band.  With xcd_remap an XCD owns a contiguous id range and its ~32 resident blocks cover a GM x (32/GM) patch of
+// output tiles, so they share GM activation panels and 32/GM weight panels through the XCD's L2.  The plain column-major
+// order (32 tiles of ONE column) made every XCD stream every activation panel per column: FETCH_SIZE of the gate|up prefill
+// GEMM was 4.5 GB per launch against 0.27 GB of operands (profiles/README.md).  Bijective for ragged grids.
+__device__ __forceinline__ void tile_coords(int id, int tiles_m, int tiles_n, int GM, int& tm, int& tn) {
+    const int per_band = GM * tiles_n;
+    const int band = id / per_band, r = id - band * per_band;
+    const int first = band * GM;
+    const int rows = min(tiles_m - first, GM);
+    tm = first + r % rows;
+    tn = r / rows;
+}
+
 // RoPE rotation of one (x1, x2) = (x[i], x[i + d/2]) pair, fp32, with the operation order PINNED (one product rounded, then one
 // fma): every kernel that rotates (prefill tile kernel, decode kernel, the fused q|k|v split-K reduction) must produce
 // bit-identical q / k for identical inputs, and the compiler's free choice of which product to contract differs per kernel.

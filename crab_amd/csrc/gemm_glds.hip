@@ -213,7 +213,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bt_ring_kernel(GemmGP p) 
     const bf16_t* B = p.B + z0 * p.sB0 + z1 * p.sB1;
     const int nwg = p.tiles_m * p.tiles_n;
     const int bid = xcd_remap(blockIdx.x, nwg);
-    const int tm = bid % p.tiles_m, tn = bid / p.tiles_m;
+    int tm, tn;
+    tile_coords(bid, p.tiles_m, p.tiles_n, 8, tm, tn);          // 8 x 4 tile patch per XCD (32 CUs, one block each)
     const int m0 = tm * BM, n0 = tn * BN;
     const int nk1 = (p.K + RBK - 1) / RBK;
     const int nk2 = p.A2 ? (p.K2 + RBK - 1) / RBK : 0;
