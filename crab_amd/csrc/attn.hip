@@ -46,9 +46,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
-    const int b = blockIdx.z, h = blockIdx.y;
+    // 1-D grid, XCD-aware: workgroup ids are dealt round-robin to the 8 XCDs, so with a (q block, head, batch) grid the q blocks
+    // of one head landed on 8 different L2s and each re-read the head's K / V through the fabric (FETCH_SIZE 2x the operands).
+    // xcd_remap gives every XCD a contiguous range of logical ids: a head's q blocks share one L2.
+    const int nqb = (p.Sq + 63) >> 6;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int b = lid / (nqb * p.H), h = (lid / nqb) % p.H;
     const int hk = h / (p.H / p.Hk);
-    const int q0 = blockIdx.x * 64;
+    const int q0 = (lid % nqb) * 64;
     const int qrow = q0 + wave * 16 + fr;                       // this lane's query row
     const int qload = qrow < p.Sq ? qrow : p.Sq - 1;
     const int koff = p.Skv - p.Sq;                              // causal offset (0 for prefill)
@@ -465,7 +470,7 @@ extern "C" int crab_attn_fwd(crab_ctx* ctx, void* stream, const crab_attn_desc* 
     p.vt_bs = d->vt_bs; p.vt_hs = d->vt_hs; p.vt_ds = d->vt_ds; p.o_bs = d->o_bs; p.o_ss = d->o_ss;
     p.bias = d->bias; p.gate = d->gate; p.B = d->B; p.H = d->H; p.Hk = d->Hk; p.Sq = d->Sq; p.Skv = d->Skv;
     p.causal = d->causal; p.scale = d->scale;
-    dim3 grid((d->Sq + 63) / 64, d->H, d->B), block(256);
+    dim3 grid(((d->Sq + 63) / 64) * d->H * d->B), block(256);
     hipStream_t s = (hipStream_t)stream;
     const bool hb = d->bias != nullptr;
     if (d->causal && hb) return crab_fail(ctx, CRAB_E_UNSUPPORTED, "attn_fwd: causal + bias not instantiated");
