@@ -87,38 +87,57 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
     const u32x4 z4 = {0u, 0u, 0u, 0u};
     const u32x2 z2 = {0u, 0u};
 
+    // Software pipeline: the global loads of tile t+1 are issued (into registers) right after tile t has been stored to LDS,
+    // so their latency runs under tile t's MFMAs and softmax.  Synchronous staging left the waves parked 70 % of the time
+    // (PMC: SQ_WAIT_ANY / SQ_WAVE_CYCLES, MFMA busy 11 %).
+    constexpr int NKV = (KT * CPR) / 256, NVV = (HD * 8) / 256;
+    u32x4 kreg[NKV], vreg[NVV];
+#define ATT_LOAD_TILE(T_)                                                                                      \
+    {                                                                                                          \
+        const int kvl_ = (T_) * KT;                                                                            \
+        _Pragma("unroll") for (int i = 0; i < NKV; ++i) {                                                      \
+            const int idx = tid + i * 256;                                                                     \
+            const int row = idx / CPR, c = idx % CPR;                                                          \
+            const int kr = kvl_ + row;                                                                         \
+            kreg[i] = kr < p.Skv ? *reinterpret_cast<const u32x4*>(kp + (long)kr * p.k_ss + c * 8) : z4;       \
+        }                                                                                                      \
+        _Pragma("unroll") for (int i = 0; i < NVV; ++i) {                                                      \
+            const int idx = tid + i * 256;                                                                     \
+            const int row = idx >> 3, c = idx & 7;                                                             \
+            const int kc = kvl_ + c * 8;                                                                       \
+            u32x4 v = z4;                                                                                      \
+            if (kc + 8 <= p.Skv) {                                                                             \
+                v = *reinterpret_cast<const u32x4*>(vp + (long)row * p.vt_ds + kc);                            \
+            } else if (kc < p.Skv) {       /* ragged tail: zero beyond Skv so that 0 * pad stays 0 */          \
+                const bf16_t* sp_ = vp + (long)row * p.vt_ds + kc;                                             \
+                uint32_t w[4] = {0u, 0u, 0u, 0u};                                                              \
+                for (int e = 0; e < 8 && kc + e < p.Skv; ++e) w[e >> 1] |= ((uint32_t)sp_[e]) << ((e & 1) * 16); \
+                v = u32x4{w[0], w[1], w[2], w[3]};                                                             \
+            }                                                                                                  \
+            vreg[i] = v;                                                                                       \
+        }                                                                                                      \
+    }
+    ATT_LOAD_TILE(0);
     for (int t = 0; t < ntiles; ++t) {
         const int kv0 = t * KT;
         __syncthreads();                                         // previous tile fully consumed
-        // ---- stage K tile: KT rows x CPR chunks
+        // ---- registers -> LDS: K tile (KT rows x CPR swizzled chunks), V^T tile (HD rows x 8 chunks, padded rows)
 #pragma unroll
-        for (int i = 0; i < (KT * CPR) / 256; ++i) {
-            int idx = tid + i * 256;
-            int row = idx / CPR, c = idx % CPR;
-            int kr = kv0 + row;
-            u32x4 v = kr < p.Skv ? *reinterpret_cast<const u32x4*>(kp + (long)kr * p.k_ss + c * 8) : z4;
-            *reinterpret_cast<u32x4*>(lk + row * HD + (k_swz<HD>(row, c) << 3)) = v;
+        for (int i = 0; i < NKV; ++i) {
+            const int idx = tid + i * 256;
+            const int row = idx / CPR, c = idx % CPR;
+            *reinterpret_cast<u32x4*>(lk + row * HD + (k_swz<HD>(row, c) << 3)) = kreg[i];
         }
-        // ---- stage V^T tile: HD rows x 8 chunks (64 keys); zero beyond Skv so that 0 * pad stays 0
 #pragma unroll
-        for (int i = 0; i < (HD * 8) / 256; ++i) {
-            int idx = tid + i * 256;
-            int row = idx >> 3, c = idx & 7;
-            int kc = kv0 + c * 8;
-            u32x4 v = z4;
-            if (kc + 8 <= p.Skv) {
-                v = *reinterpret_cast<const u32x4*>(vp + (long)row * p.vt_ds + kc);
-            } else if (kc < p.Skv) {
-                const bf16_t* s = vp + (long)row * p.vt_ds + kc;
-                uint32_t w[4] = {0u, 0u, 0u, 0u};
-                for (int e = 0; e < 8 && kc + e < p.Skv; ++e) w[e >> 1] |= ((uint32_t)s[e]) << ((e & 1) * 16);
-                v = u32x4{w[0], w[1], w[2], w[3]};
-            }
+        for (int i = 0; i < NVV; ++i) {
+            const int idx = tid + i * 256;
+            const int row = idx >> 3, c = idx & 7;
             bf16_t* d = lv + row * VT_LD + c * 8;
-            *reinterpret_cast<u32x2*>(d) = u32x2{v[0], v[1]};
-            *reinterpret_cast<u32x2*>(d + 4) = u32x2{v[2], v[3]};
+            *reinterpret_cast<u32x2*>(d) = u32x2{vreg[i][0], vreg[i][1]};
+            *reinterpret_cast<u32x2*>(d + 4) = u32x2{vreg[i][2], vreg[i][3]};
         }
         __syncthreads();
+        if (t + 1 < ntiles) ATT_LOAD_TILE(t + 1);
 
         // ---- S^T = K . Q^T : 4 key sub-tiles of 16
         f32x4_t s[4];
@@ -200,6 +219,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
         }
     }
 }
+
+#undef ATT_LOAD_TILE
 
 // ---------------------------------------------------------------------------------------------- decode
 // block = 256 threads = 16 groups of 16 lanes; group gidx handles keys gidx, gidx+16, ...; each lane owns
