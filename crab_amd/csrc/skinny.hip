@@ -161,24 +161,35 @@ __global__ __launch_bounds__(256) void lora_t_partial_kernel(const bf16_t* __res
 #pragma unroll
         for (int i = 0; i < MT; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const u32x4 z4 = {0u, 0u, 0u, 0u};
-    for (int k0 = k_begin; k0 < k_end; k0 += 32) {
-        const int k = k0 + fg * 8;
-        const bool ok = k < k_end;
-        const int kc = ok ? k : 0;
-        union Frag { u32x4 r; bf16x8_t f; };
-        Frag xf[MT], wf[NT];
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            xf[i].r = *reinterpret_cast<const u32x4*>(X + (long)mrow[i] * ldx + kc);
-            if (!ok) xf[i].r = z4;
-        }
-#pragma unroll
-        for (int j = 0; j < NT; ++j) wf[j].r = *reinterpret_cast<const u32x4*>(RA + (long)(j * 16 + fr) * ldra + kc);
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int i = 0; i < MT; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j].f, xf[i].f, acc[j][i], 0, 0, 0);
+    union Frag { u32x4 r; bf16x8_t f; };
+    // software pipeline: the operands of K step s+1 are loaded before the MFMAs of step s are issued
+    Frag xf[2][MT], wf[2][NT];
+#define RT_LOAD(B_, K0_)                                                                                   \
+    {                                                                                                      \
+        const int k_ = (K0_) + fg * 8;                                                                     \
+        const bool ok_ = k_ < k_end;                                                                       \
+        const int kc_ = ok_ ? k_ : 0;                                                                      \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i) {                                                   \
+            xf[B_][i].r = *reinterpret_cast<const u32x4*>(X + (long)mrow[i] * ldx + kc_);                  \
+            if (!ok_) xf[B_][i].r = z4;                                                                    \
+        }                                                                                                  \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j) wf[B_][j].r = *reinterpret_cast<const u32x4*>(RA + (long)(j * 16 + fr) * ldra + kc_); \
     }
+#define RT_MMA(B_)                                                                                         \
+    _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                         \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                     \
+            acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[B_][j].f, xf[B_][i].f, acc[j][i], 0, 0, 0);
+    if (k_begin < k_end) RT_LOAD(0, k_begin);
+    for (int k0 = k_begin; k0 < k_end; k0 += 64) {
+        if (k0 + 32 < k_end) RT_LOAD(1, k0 + 32);
+        RT_MMA(0);
+        if (k0 + 32 < k_end) {
+            if (k0 + 64 < k_end) RT_LOAD(0, k0 + 64);
+            RT_MMA(1);
+        }
+    }
+#undef RT_LOAD
+#undef RT_MMA
     // D[row = t-col 4fg+r][col = m fr]; part layout [slice][m][NT*16]
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
