@@ -86,7 +86,7 @@ __global__ void embedding_kernel(const int64_t* __restrict__ ids, const bf16_t* 
                                  long ldo, int T, int D, int vocab) {
     const int t = blockIdx.x;
     long id = ids[t];
-    if (id < 0) id = 0;
+    if (id < 0) return;                                  // negative id: row is filled by someone else (modality splice)
     if (id >= vocab) id = vocab - 1;
     const bf16_t* src = table + id * (long)D;
     bf16_t* dst = out + (long)t * ldo;

@@ -162,30 +162,41 @@ __global__ __launch_bounds__(256) void lora_t_partial_kernel(const bf16_t* __res
         for (int i = 0; i < MT; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const u32x4 z4 = {0u, 0u, 0u, 0u};
     union Frag { u32x4 r; bf16x8_t f; };
-    // software pipeline: the operands of K step s+1 are loaded before the MFMAs of step s are issued
-    Frag xf[2][MT], wf[2][NT];
+    // K step = 64: lane (fr, fg) loads the 32 contiguous bytes k = k0 + 16 fg .. +15 of its row (a wave instruction then
+    // covers whole 128-byte lines) and feeds them to two MFMAs; both operands use the same k permutation, so the sum
+    // is the plain dot product.  Three steps are in flight per wave (loads of step s+2 issued before the MFMAs of s).
+    Frag xf[3][MT][2], wf[3][NT][2];
 #define RT_LOAD(B_, K0_)                                                                                   \
-    {                                                                                                      \
-        const int k_ = (K0_) + fg * 8;                                                                     \
-        const bool ok_ = k_ < k_end;                                                                       \
-        const int kc_ = ok_ ? k_ : 0;                                                                      \
-        _Pragma("unroll") for (int i = 0; i < MT; ++i) {                                                   \
-            xf[B_][i].r = *reinterpret_cast<const u32x4*>(X + (long)mrow[i] * ldx + kc_);                  \
-            if (!ok_) xf[B_][i].r = z4;                                                                    \
+    if ((K0_) < k_end) {                                                                                   \
+        _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                    \
+            const int k_ = (K0_) + fg * 16 + h * 8;                                                        \
+            const bool ok_ = k_ < k_end;                                                                   \
+            const int kc_ = ok_ ? k_ : 0;                                                                  \
+            _Pragma("unroll") for (int i = 0; i < MT; ++i) {                                               \
+                xf[B_][i][h].r = *reinterpret_cast<const u32x4*>(X + (long)mrow[i] * ldx + kc_);           \
+                if (!ok_) xf[B_][i][h].r = z4;                                                             \
+            }                                                                                              \
+            _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                 \
+                wf[B_][j][h].r = *reinterpret_cast<const u32x4*>(RA + (long)(j * 16 + fr) * ldra + kc_);   \
         }                                                                                                  \
-        _Pragma("unroll") for (int j = 0; j < NT; ++j) wf[B_][j].r = *reinterpret_cast<const u32x4*>(RA + (long)(j * 16 + fr) * ldra + kc_); \
     }
 #define RT_MMA(B_)                                                                                         \
-    _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                         \
-        _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                     \
-            acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[B_][j].f, xf[B_][i].f, acc[j][i], 0, 0, 0);
-    if (k_begin < k_end) RT_LOAD(0, k_begin);
-    for (int k0 = k_begin; k0 < k_end; k0 += 64) {
-        if (k0 + 32 < k_end) RT_LOAD(1, k0 + 32);
+    _Pragma("unroll") for (int h = 0; h < 2; ++h)                                                          \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                     \
+            _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                 \
+                acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[B_][j][h].f, xf[B_][i][h].f, acc[j][i], 0, 0, 0);
+    RT_LOAD(0, k_begin);
+    RT_LOAD(1, k_begin + 64);
+    for (int k0 = k_begin; k0 < k_end; k0 += 192) {
+        RT_LOAD(2, k0 + 128);
         RT_MMA(0);
-        if (k0 + 32 < k_end) {
-            if (k0 + 64 < k_end) RT_LOAD(0, k0 + 64);
+        if (k0 + 64 < k_end) {
+            RT_LOAD(0, k0 + 192);
             RT_MMA(1);
+        }
+        if (k0 + 128 < k_end) {
+            RT_LOAD(1, k0 + 256);
+            RT_MMA(2);
         }
     }
 #undef RT_LOAD
@@ -319,7 +330,7 @@ extern "C" int crab_hyperlora_route(crab_ctx* ctx, void* stream, const void* X, 
     route_cfg(M, K, &MT, &nslices);
     int mblocks = (M + 64 * MT - 1) / (64 * MT);
     hipStream_t s = (hipStream_t)stream;
-    int kslice = (((K + nslices - 1) / nslices) + 31) / 32 * 32;
+    int kslice = (((K + nslices - 1) / nslices) + 63) / 64 * 64;
     nslices = (K + kslice - 1) / kslice;
     dim3 grid(nslices, mblocks), block(256);
     float* part = (float*)workspace;

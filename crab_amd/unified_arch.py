@@ -14,6 +14,7 @@ from __future__ import annotations
 
 from typing import Dict, List, Optional, Sequence
 
+import numpy as np
 import torch
 
 from . import ops
@@ -176,9 +177,22 @@ class UnifiedMetaForCausalLM:
         # ---- pass 1 (host): segment plan per sample; modality blocks are encoded batched per kind
         plans = []
         vids, auds, msks = [], [], []
+        # one device->host transfer for the ids (and one for the labels) of the whole batch, not one per sample
+        n_ids = [int(x.numel()) for x in batch_input_ids]
+        flat = torch.cat([x.reshape(-1) for x in batch_input_ids]).tolist()
+        ids_ls, o = [], 0
+        for n in n_ids:
+            ids_ls.append(flat[o:o + n])
+            o += n
+        lab_ls = None
+        if batch_labels is not None:
+            flat = torch.cat([x.reshape(-1) for x in batch_labels]).tolist()
+            lab_ls, o = [], 0
+            for n in n_ids:
+                lab_ls.append(flat[o:o + n])
+                o += n
         for i in range(bs):
-            ids = batch_input_ids[i]
-            ids_l = ids.tolist()
+            ids_l = ids_ls[i]
             segs, pre = [], 0
             for pos, tok in enumerate(ids_l):
                 if tok in key_ids:
@@ -202,7 +216,7 @@ class UnifiedMetaForCausalLM:
         img_block = {}                                   # sample -> index of its <image> block (multi-scale features)
         if return_multi_scale_features:
             for i, segs in enumerate(plans):
-                ids_l = batch_input_ids[i].tolist()
+                ids_l = ids_ls[i]
                 k = 0
                 for pos, tok in enumerate(ids_l):
                     if tok in key_ids:
@@ -223,21 +237,20 @@ class UnifiedMetaForCausalLM:
         pad_id = self.get_model().pad_token_id
         attn = torch.zeros((bs, S), dtype=torch.int32)
         labels = torch.full((bs, S), -100, dtype=torch.long)
+        # every text / pad row of the batch is looked up by ONE embedding launch: tok[i, s] = token id, -1 = row is
+        # written by a modality copy (the kernel leaves rows with a negative id untouched)
+        tok = np.full((bs, S), -1, dtype=np.int64)
         for i, segs in enumerate(plans):
             off = S - lens[i]
-            if off:
-                pad_ids = torch.full((off,), pad_id, dtype=torch.long)
-                ops.embedding(pad_ids, emb_w, out=out[i, :off])                         # :344-348
-            ids = batch_input_ids[i]
-            lab = batch_labels[i] if batch_labels is not None else None
+            tok[i, :off] = pad_id                                                        # :344-348
             cur = off
             for sg in segs:
                 if sg[0] == "text":
                     n = sg[2] - sg[1]
                     if n:
-                        ops.embedding(ids[sg[1]:sg[2]], emb_w, out=out[i, cur:cur + n])
-                        if lab is not None:
-                            labels[i, cur:cur + n] = lab[sg[1]:sg[2]].cpu()
+                        tok[i, cur:cur + n] = ids_ls[i][sg[1]:sg[2]]
+                        if lab_ls is not None:
+                            labels[i, cur:cur + n] = torch.tensor(lab_ls[i][sg[1]:sg[2]], dtype=torch.long)
                 elif sg[0] == "mask":
                     n = mids[sg[1]].shape[0]
                     ops.embedding(mids[sg[1]], emb_w, out=out[i, cur:cur + n])          # encode_ids(indices), labels = indices
@@ -248,6 +261,7 @@ class UnifiedMetaForCausalLM:
                     ops.copy_rows(f, out[i, cur:cur + n], n, D)
                 cur += n
             attn[i, off:] = 1
+        ops.embedding(torch.from_numpy(tok).reshape(-1), emb_w, out=out.view(bs * S, D))
         position_ids = torch.cumsum(attn, dim=-1) - 1
         position_ids[position_ids == -1] = 0                                             # :372-373
         dict_data = {
@@ -264,7 +278,7 @@ class UnifiedMetaForCausalLM:
             mask_ids = {special[m] for m in self.MASK}
             for i in range(bs):
                 is_avs = batch_task_names[i] in AVS_TASKS
-                ids_l = batch_input_ids[i].tolist()
+                ids_l = ids_ls[i]
                 if is_avs and i in img_block:
                     for sc in range(scale):
                         ms[sc].append(vvit[img_block[i]][sc])

@@ -111,7 +111,8 @@ int crab_rmsnorm(crab_ctx* ctx, void* stream, const void* x, int64_t ldx, const 
 int crab_layernorm(crab_ctx* ctx, void* stream, const void* x, int64_t ldx, const void* w, const void* b, void* y,
                    int64_t ldy, int M, int D, float eps);
 
-/* out[t,:] = table[ids[t],:]  (embed_tokens; unified_arch.py:213-214, unified_llama.py:125-127) */
+/* out[t,:] = table[ids[t],:]  (embed_tokens; unified_arch.py:213-214, unified_llama.py:125-127).  Rows with ids[t] < 0 are
+ * left untouched (the multimodal splice fills them with projector features, unified_arch.py:283-300); ids >= vocab clamp. */
 int crab_embedding(crab_ctx* ctx, void* stream, const int64_t* ids, const void* table, void* out, int64_t ldo,
                    int T, int D, int vocab);
 
