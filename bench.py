@@ -143,7 +143,7 @@ def main():
     ap.add_argument("--clips", type=int, default=int(os.environ.get("CRAB_BENCH_CLIPS", "256")), help="clips per GPU per step")
     ap.add_argument("--new-tokens", type=int, default=256)
     ap.add_argument("--frames", type=int, default=8)
-    ap.add_argument("--prefill-chunk", type=int, default=16)
+    ap.add_argument("--prefill-chunk", type=int, default=0, help="sequences per prefill chunk; 0 = planned per batch (whole tile rounds)")
     ap.add_argument("--decode-streams", type=int, default=int(os.environ.get("CRAB_DECODE_STREAMS", "1")),
                     help="decode groups replayed on separate HIP streams (KV-cache attention of one overlaps projections of another)")
     ap.add_argument("--llm", default="llama")

@@ -187,6 +187,35 @@ class GenerationEngine:
                 tc, uc = max(tc, g.t_cols), max(uc, g.u_cols)
         return tc, uc
 
+    def plan_prefill_chunks(self, B: int, S: int, max_rows: int = 32768) -> List[int]:
+        """Split B sequences of S rows into prefill chunks whose projection GEMMs fill whole rounds of 256x256 output tiles
+        over the device's CUs.  One block owns a CU, so a GEMM costs ceil(tiles / CUs) rounds of K; a chunk that leaves
+        the last round mostly empty pays for it in every projection of every layer (16 x 702 rows: 8.25 -> 9 rounds for
+        q|k|v, 2.75 -> 3 for o / down = 5.7 % of the decoder GEMM time).  Exact DP over the chunk sizes <= max_rows / S."""
+        cmax = max(1, min(B, max_rows // max(S, 1)))
+        if B * S < 2048:                                   # below the ring-GEMM regime the rounds model does not apply
+            return [B]
+        cus = torch.cuda.get_device_properties(self.device).multi_processor_count
+        shapes = [(g.W.shape[0], g.W.shape[1]) for g in self.model.layers[0].groups()]
+
+        def cost(c):
+            tr = -(-(c * S) // 256)
+            return sum(-(-(tr * -(-n // 256)) // cus) * k for n, k in shapes)
+
+        per_chunk = 0.002 * cost(cmax)                     # weights re-read + launches: prefer fewer chunks on ties
+        best, prev = [0.0] + [float("inf")] * B, [0] * (B + 1)
+        costs = [0.0] + [cost(c) + per_chunk for c in range(1, cmax + 1)]
+        for n in range(1, B + 1):
+            for c in range(1, min(n, cmax) + 1):
+                v = best[n - c] + costs[c]
+                if v < best[n]:
+                    best[n], prev[n] = v, c
+        out, n = [], B
+        while n:
+            out.append(prev[n])
+            n -= prev[n]
+        return sorted(out, reverse=True)
+
     def alloc_cache(self, B: int, Tmax: int, slot: Optional[int] = None):
         """KV cache [L, B, Hk, Tmax, d] x 2.  slot = None: fresh zero-filled tensors (callers that keep the cache, e.g.
         forward(use_cache=True)).  slot = g: the engine's persistent buffers for decode group g, reused by every generate()
@@ -328,9 +357,12 @@ class GenerationEngine:
         st.cur_ids.zero_(); st.out_ids.fill_(pad_token_id if pad_token_id is not None else 0); st.finished.zero_()
         st.pos_dev.fill_(S - 1); st.step_dev.zero_()
         # ---- prefill in chunks of sequences (bounds activation memory, keeps GEMM M in the MFMA-efficient range)
-        for b0 in range(0, B, prefill_chunk):
-            b1 = min(B, b0 + prefill_chunk)
-            self.prefill(embeds[b0:b1], kc, vc, b0=b0, logits_out=st.logits[b0:b1], hn_out=st.hn[b0:b1])
+        chunks = self.plan_prefill_chunks(B, S) if not prefill_chunk else [prefill_chunk] * (B // prefill_chunk) + \
+            ([B % prefill_chunk] if B % prefill_chunk else [])
+        b0 = 0
+        for n in chunks:
+            self.prefill(embeds[b0:b0 + n], kc, vc, b0=b0, logits_out=st.logits[b0:b0 + n], hn_out=st.hn[b0:b0 + n])
+            b0 += n
         if sink is not None:
             sink(st)
         ops.greedy_select(st.logits, st.cur_ids, st.out_ids, st.step_dev, st.finished, st.eos, st.pad, st.min_new)
@@ -339,7 +371,7 @@ class GenerationEngine:
 
     @torch.no_grad()
     def generate(self, embeds: torch.Tensor, max_new_tokens: int, eos_token_id: Optional[int] = None,
-                 pad_token_id: Optional[int] = None, min_new_tokens: int = 0, prefill_chunk: int = 16, use_graph: bool = True,
+                 pad_token_id: Optional[int] = None, min_new_tokens: int = 0, prefill_chunk: int = 0, use_graph: bool = True,
                  return_step_logits: bool = False, return_hidden: bool = False, decode_streams: int = 1):
         """Greedy generation from inputs_embeds only, as UnifiedForCausalLM.generate drives HF generate
         (unified_llama.py:262-267): positions 0..S-1 (left pads attended), returns ONLY new ids.

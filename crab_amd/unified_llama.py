@@ -169,7 +169,7 @@ class UnifiedForCausalLM(nn.Module, UnifiedMetaForCausalLM):
         want_logits = bool(kwargs.get("output_logits")) and bool(kwargs.get("return_dict_in_generate"))
         res = self._engine.generate(embeds, max_new, eos_token_id=eos, pad_token_id=pad,
                                     min_new_tokens=int(kwargs.get("min_new_tokens", 0) or 0),
-                                    prefill_chunk=int(kwargs.get("prefill_chunk", 16)), use_graph=kwargs.get("use_graph", True),
+                                    prefill_chunk=int(kwargs.get("prefill_chunk", 0)), use_graph=kwargs.get("use_graph", True),
                                     return_step_logits=want_logits, decode_streams=int(kwargs.get("decode_streams", 1)))
         if want_logits:
             ids, sl = res

@@ -59,3 +59,25 @@ def test_entry_points_reject_null_context_and_operands_without_a_gpu():
     assert lib.crab_bicubic_ksize(0, 10) < 0 and lib.crab_bicubic_ksize(480, 224) == 2 * 5 + 1
     assert lib.crab_kaldi_fbank_frames(16000) == 98
     assert lib.crab_hyperlora_route_workspace(256, 4096, 48) > 0 and lib.crab_groupnorm_workspace(2, 65536, 32) > 0
+
+
+def test_prefill_chunk_plan_covers_batch():
+    """decoder.GenerationEngine.plan_prefill_chunks: exact partition of the batch, chunks within the row cap, and the
+    whole-rounds choice at the AVQA shape (pure host logic; the device is only asked for its CU count)."""
+    import types
+    from unittest import mock
+    import torch
+    from crab_amd.decoder import GenerationEngine
+    eng = GenerationEngine.__new__(GenerationEngine)
+    mk = lambda n, k: types.SimpleNamespace(W=torch.empty((n, k), dtype=torch.bfloat16, device="meta"))
+    layer = types.SimpleNamespace(groups=lambda: [mk(12288, 4096), mk(4096, 4096), mk(22016, 4096), mk(4096, 11008)])
+    eng.model = types.SimpleNamespace(layers=[layer])
+    with mock.patch.object(GenerationEngine, "device", new="cpu", create=True), \
+            mock.patch("torch.cuda.get_device_properties", return_value=types.SimpleNamespace(multi_processor_count=256)):
+        for B, S in [(1, 5), (3, 100), (16, 702), (256, 702), (255, 559), (7, 4000)]:
+            ch = eng.plan_prefill_chunks(B, S)
+            assert sum(ch) == B and all(c >= 1 for c in ch)
+            assert all(c * S <= 32768 or c == 1 for c in ch)
+        assert eng.plan_prefill_chunks(4, 64) == [4]                        # below the ring regime: one chunk
+        ch = eng.plan_prefill_chunks(256, 702)
+        assert max(ch) > 16 and len(ch) <= 12                                # fuller rounds than the old fixed 16
