@@ -102,6 +102,16 @@ class CLIPImageProcessor:
             x = self._resample(x, oh, False)
         return x, (oh - s) // 2, (ow - s) // 2
 
+    def resize_exact(self, image, height: int, width: int) -> torch.Tensor:
+        """`PIL.Image.resize((width, height))` with Pillow's default BICUBIC filter, aspect ignored: the step the reference's image
+        tasks apply before the processor (dataset/quick_start_dataset.py:456,488,521).  uint8 [H,W,3] -> uint8 [height,width,3]."""
+        x = _as_u8_hwc(image).to(self.device)[None].contiguous()
+        if x.shape[2] != width:
+            x = self._resample(x, width, True)
+        if x.shape[1] != height:
+            x = self._resample(x, height, False)
+        return x[0]
+
     def preprocess(self, images, return_tensors: str = "pt", **_unused) -> _BatchFeature:
         """images: one image or a list of PIL images / uint8 [H,W,3] arrays or tensors -> {'pixel_values': [T,3,224,224]}
         on the device.  Images of equal size are processed in one batch of launches."""

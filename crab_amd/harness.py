@@ -1,0 +1,215 @@
+"""Eval harness around the hot path: what the reference's dataset / collator / inference loop do on
+the host between a media file and `UnifiedForCausalLM.generate`, minus the file decoding (decord / librosa / PIL.open stay
+with the caller, who hands over uint8 frames and a 16 kHz mono waveform).
+
+  reference                                                              here
+  UnifiedTestDataset.add_custome_test_samples  quick_start_dataset.py:149-270   build_instruction
+  UnifiedTestDataset.__getitem__               quick_start_dataset.py:277-620   wrap_prompt, frame_indices, audio_windows, make_instance
+  DataCollatorForUnifiedTestDataset            quick_start_dataset.py:623-707   Collator
+  prepare_sample                               utils/util.py:33-47              to_device
+  inference_ntp / inference_avqa               quick_start.py:30-50, inference_hyper_lora.py:158-212   run_inference
+
+Image and audio preprocessing run on the device through crab_amd.frontend (HIP kernels); prompts and ids are host work.
+The reference loops clip by clip on one GPU; run_inference shards the batches over ranks (crab_amd.parallel) and rank 0
+collects the predictions.  Pinned by tests/golden/harness.npz (made by running the reference's dataset + collator)."""
+from __future__ import annotations
+
+import json
+from typing import Any, Callable, Dict, Iterable, List, Mapping, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+SYSTEM_PROMPT = "You are a helpful assistant."                      # quick_start_dataset.py:286
+_VIDEO_AUDIO = "This is a video:\n<video_start><video><video_end>\nThis is an audio:\n<audio_start><audio><audio_end>\n"
+_IMAGE_AUDIO = "This is an image:\n<image_start><image><image_end>\nThis is an audio:\n<audio_start><audio><audio_end>\n"
+_SEGMENT = "Please segment out the object that makes the sound in the image."
+# task -> (modality header, request); {question} / {exp} are the per-sample fields (quick_start_dataset.py:159-262)
+TASK_PROMPTS: Dict[str, Tuple[str, str]] = {
+    "avqa": (_VIDEO_AUDIO, "Please answer this question: {question}"),
+    "ave": (_VIDEO_AUDIO, "Please describe the events and time range that occurred in the video."),
+    "avvp": (_VIDEO_AUDIO, "Please determine the events that occur based on the visual and audio information, as well as the start and "
+                           "end time of these events."),
+    "arig": (_IMAGE_AUDIO, "Please output the location coordinates of sounding object."),
+    "s4": (_IMAGE_AUDIO, _SEGMENT),
+    "ms3": (_IMAGE_AUDIO, _SEGMENT),
+    "avss": (_IMAGE_AUDIO, _SEGMENT),
+    "ref-avs": (_IMAGE_AUDIO, "Please segment out {exp} in the image."),
+}
+VIDEO_TASKS = ("avqa", "ave", "avvp")
+# task -> (clip seconds the waveform is divided into, windows taken): quick_start_dataset.py:318-336 (avqa), :369-385 (ave),
+# :409-424 (avvp), :446-450 (s4), :478-482 (ms3), :511-516 (avss), :546-555 (arig), :572-588 (ref-avs)
+_AUDIO_PLAN = {"avqa": (60, "two_second"), "ave": (10, "every_second"), "avvp": (10, "every_second"), "ref-avs": (10, "every_second"),
+               "s4": (5, "one"), "ms3": (5, "one"), "avss": (10, "one"), "arig": (5, "one_padded")}
+
+
+def build_instruction(task: str, question: Optional[str] = None, exp: Optional[str] = None) -> str:
+    """The instruction string of one sample; `exp` (ref-avs) is lower-cased like the reference does (:255)."""
+    if task not in TASK_PROMPTS:
+        raise ValueError("invalid task.")
+    head, req = TASK_PROMPTS[task]
+    if task == "avqa":
+        if question is None:
+            raise ValueError("avqa needs a question")
+        req = req.format(question=question)
+    elif task == "ref-avs":
+        if exp is None:
+            raise ValueError("ref-avs needs a referring expression")
+        req = req.format(exp=exp.lower())
+    return head + req
+
+
+def wrap_prompt(tokenizer, instruction: str, output: str = "none") -> Tuple[str, str]:
+    """quick_start_dataset.py:284-290: every tokenizer with `apply_chat_template` gets the system + user conversation rendered
+    with the generation prompt (Llama-2: `<s>[INST] <<SYS>>...`), and the target gains a literal '</s>'."""
+    if tokenizer is not None and hasattr(tokenizer, "apply_chat_template"):
+        messages = [{"role": "system", "content": SYSTEM_PROMPT}, {"role": "user", "content": instruction}]
+        instruction = tokenizer.apply_chat_template(conversation=messages, add_generation_prompt=True, tokenize=False)
+        output = output + "</s>"
+    return instruction, output
+
+
+def encode_text(tokenizer, text: str) -> List[int]:
+    """tokenize + convert_tokens_to_ids (collator :661-662): no BOS / EOS of its own, whatever `<s>` there is comes from the text."""
+    return tokenizer.convert_tokens_to_ids(tokenizer.tokenize(text))
+
+
+def frame_indices(vlen: int, n_frames: int) -> List[int]:
+    """Uniform frame sampling of :305-309: np.arange(0, vlen, vlen / min(n, vlen)) truncated to int."""
+    n = min(int(n_frames), int(vlen))
+    if n <= 0:
+        raise ValueError("empty video")
+    return np.arange(0, vlen, vlen / n).astype(int).tolist()
+
+
+def audio_windows(task: str, audio, idx: Optional[int] = None) -> torch.Tensor:
+    """Waveform [L] (16 kHz mono; numpy or torch) -> the windows the task feeds to the fbank, float32 [T, n].
+    avqa: ten 2 s windows centred at 0.5, 6.5, ..., 54.5 s of a 60 s clip, silence-padded at both ends; ave / avvp / ref-avs:
+    the ten seconds of a 10 s clip (short tail padded); s4 / ms3 / arig: second `idx` of 5; avss: second `idx` of 10.
+    (The reference's padded windows become float64 through np.zeros(dtype=float); everything is float32 here.)"""
+    if task not in _AUDIO_PLAN:
+        raise ValueError("invalid task.")
+    a = torch.as_tensor(np.asarray(audio) if not isinstance(audio, torch.Tensor) else audio).to(torch.float32).reshape(-1)
+    tot, kind = _AUDIO_PLAN[task]
+    nps = int(a.shape[0] / tot)
+    if kind == "two_second":
+        from .frontend import avqa_audio_segments
+        return avqa_audio_segments(a, tot)
+    if kind == "every_second":
+        segs = []
+        for i in range(tot):
+            s = a[int(max(0, i) * nps): int(nps * min(tot, i + 1))]
+            if s.shape[0] < nps:
+                s = torch.cat([s, s.new_zeros(nps - s.shape[0])])
+            segs.append(s)
+        return torch.stack(segs, 0)
+    if idx is None:
+        raise ValueError(f"{task} needs the frame index of the sample")
+    s = a[idx * nps: (idx + 1) * nps]
+    if kind == "one_padded" and s.shape[0] < nps:
+        s = torch.cat([s, s.new_zeros(nps - s.shape[0])])
+    return s[None]
+
+
+def make_instance(task: str, tokenizer, *, question: Optional[str] = None, exp: Optional[str] = None, frames: Optional[Sequence] = None,
+                  image=None, audio=None, idx: Optional[int] = None, mask: Optional[torch.Tensor] = None, n_frames: int = 10,
+                  processor=None, output: str = "none", device="cuda") -> Dict[str, Any]:
+    """One dataset item (`UnifiedTestDataset.__getitem__`): wrapped instruction, target, task name and the preprocessed
+    modalities.  frames: the decoded video as a sequence of uint8 [H,W,3] images (all of them - sampling happens here);
+    image: one uint8 [H,W,3]; audio: waveform [L].  Preprocessing runs on `device` (crab_amd.frontend)."""
+    from . import frontend
+    instruction, output = wrap_prompt(tokenizer, build_instruction(task, question, exp), output)
+    data: Dict[str, Any] = {"instruction": instruction, "output": output, "task_name": task}
+    proc = processor if processor is not None else frontend.CLIPImageProcessor(device=device)
+    if task in VIDEO_TASKS:
+        if frames is None or audio is None:
+            raise ValueError(f"{task} needs frames and audio")
+        pick = frame_indices(len(frames), n_frames)
+        data["video"] = proc.preprocess([frames[i] for i in pick], return_tensors="pt")["pixel_values"]      # [T,3,224,224]
+    else:
+        if image is None or audio is None:
+            raise ValueError(f"{task} needs an image and audio")
+        data["image"] = proc.preprocess([proc.resize_exact(image, 224, 224)], return_tensors="pt")["pixel_values"]   # .resize((224,224)) first (:456)
+        if mask is not None:
+            data["mask"] = mask
+    win = audio_windows(task, audio, idx).to(device)
+    fb = frontend.preprocess(win).to(torch.float32)                                                         # [T, L_a, 128]
+    data["audio"] = fb if _AUDIO_PLAN[task][1] in ("two_second", "every_second") else fb[0]
+    return data
+
+
+class Collator:
+    """DataCollatorForUnifiedTestDataset (:623-707): prompts -> ids (labels all -100), modalities keyed by placeholder."""
+
+    _KEYS = (("image", "<image>"), ("video", "<video>"), ("audio", "<audio>"), ("mask", "<mask>"))
+
+    def __init__(self, tokenizer):
+        self.tokenizer = tokenizer
+
+    def __call__(self, instances: Sequence[Mapping[str, Any]]) -> Dict[str, list]:
+        out = {"batch_input_ids": [], "batch_labels": [], "batch_X_modals": [], "batch_metadata": [], "batch_task_names": []}
+        for inst in instances:
+            ids = encode_text(self.tokenizer, inst["instruction"])
+            out["batch_input_ids"].append(torch.tensor(ids, dtype=torch.long))
+            out["batch_labels"].append(torch.full((len(ids),), -100, dtype=torch.long))
+            meta = {"instruction": inst["instruction"], "output": inst["output"]}
+            mods = {}
+            for key, tag in self._KEYS:
+                if inst.get(key) is not None:
+                    mods[tag] = inst[key]
+                    meta[key + "_path"] = inst.get(key + "_path", "")
+            out["batch_X_modals"].append(mods)
+            out["batch_metadata"].append(meta)
+            out["batch_task_names"].append(inst["task_name"])
+        return out
+
+
+def to_device(data, device="cuda"):
+    """utils/util.py:33-47 `prepare_sample`: tensors inside nested dicts / lists / tuples move to the device."""
+    if isinstance(data, Mapping):
+        return type(data)({k: to_device(v, device) for k, v in data.items()})
+    if isinstance(data, (tuple, list)):
+        return type(data)(to_device(v, device) for v in data)
+    if isinstance(data, torch.Tensor):
+        return data.to(device)
+    return data
+
+
+def run_inference(batches: Iterable[Mapping[str, Any]], model, tokenizer, max_new_tokens: int = 500, out_path: Optional[str] = None,
+                  device="cuda", rank: int = 0, world: int = 1, on_result: Optional[Callable[[dict], None]] = None, **generate_kwargs) -> List[dict]:
+    """inference_ntp / inference_avqa: for every collated batch, generate -> batch_decode(skip_special_tokens=False) ->
+    metadata['predict'], appended to `out_path` as JSON lines when given.  With world > 1 batch i runs on rank i mod world and
+    rank 0 receives every record (returned in batch order; other ranks return their own records)."""
+    mine: List[Tuple[int, dict]] = []
+    for step, sample in enumerate(batches):
+        if step % world != rank:
+            continue
+        sample = dict(sample)
+        metas = sample.pop("batch_metadata")
+        sample = to_device(sample, device)
+        sample.update({"use_cache": True, "max_new_tokens": max_new_tokens})
+        sample.update(generate_kwargs)
+        with torch.no_grad():
+            ids = model.generate(**sample)
+        texts = tokenizer.batch_decode(ids, skip_special_tokens=False)
+        for meta, text in zip(metas, texts):
+            rec = dict(meta)
+            rec["predict"] = text
+            mine.append((step, rec))
+    records = mine
+    if world > 1:
+        import torch.distributed as dist
+        gathered = [None] * world if rank == 0 else None
+        dist.gather_object(mine, gathered, dst=0)
+        if rank == 0:
+            records = sorted((r for part in gathered for r in part), key=lambda t: t[0])
+    out = [r for _, r in records]
+    if rank == 0:
+        for rec in out:
+            if on_result is not None:
+                on_result(rec)
+        if out_path is not None:
+            with open(out_path, "a") as f:
+                for rec in out:
+                    f.write(json.dumps(rec) + "\n")
+    return out

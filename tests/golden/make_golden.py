@@ -14,6 +14,7 @@ tests compare the HIP path with the same numbers.
 """
 from __future__ import annotations
 
+import importlib.machinery
 import json
 import os
 import sys
@@ -396,6 +397,105 @@ def golden_vqgan():
          latents=lat, indices=idx, margin=(top2[:, 1] - top2[:, 0]).reshape(2, -1), decoded=dec)
 
 
+HARNESS_TASKS = ["avqa", "ave", "avvp", "arig", "s4", "ms3", "avss", "ref-avs"]
+
+
+def golden_harness():
+    """The eval harness the hot path is called from: UnifiedTestDataset sample construction
+    (dataset/quick_start_dataset.py:149-270), __getitem__ for the video + audio tasks (:277-436: chat-template wrap, frame
+    sampling, audio windows) and DataCollatorForUnifiedTestDataset (:623-707), driven with an in-memory tokenizer
+    (tests/util.py tiny_tokenizer), a stub decord.VideoReader that records the frame indices it is asked for, a stub
+    librosa.load returning a ramp, and `preprocess` replaced by a recorder of the waveform windows (the fbank itself is
+    pinned separately).  Stored: instruction strings, wrapped prompts, token ids / labels, frame indices, audio windows."""
+    import tempfile
+    import types as _t
+    from tests.util import MM_SPECIAL, tiny_tokenizer
+    rec = dict(frames=[], windows=[])
+
+    class _Batch:
+        def __init__(self, a):
+            self.a = a
+
+        def asnumpy(self):
+            return self.a
+
+    class VideoReader:
+        def __init__(self, uri, height, width):
+            self.n = int(uri.split("_")[-1].split(".")[0])          # "clip_<vlen>.mp4"
+            self.h, self.w = height, width
+
+        def __len__(self):
+            return self.n
+
+        def get_batch(self, indices):
+            rec["frames"].append(list(indices))
+            return _Batch(np.stack([np.full((self.h, self.w, 3), i % 256, np.uint8) for i in indices]))
+
+    def _load(path, sr=16000, mono=True, **k):
+        n = int(path.split("_")[-1].split(".")[0])                   # "wave_<samples>.wav"
+        return (np.arange(n, dtype=np.float32) + 1.0) / n, sr
+
+    for name, attrs in (("decord", dict(VideoReader=VideoReader)), ("librosa", dict(load=_load)), ("cv2", {})):
+        m = _t.ModuleType(name)
+        m.__spec__ = importlib.machinery.ModuleSpec(name, None)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+    import dataset.quick_start_dataset as QD
+    from transformers import CLIPImageProcessor
+
+    def _rec_preprocess(source, *a, **k):
+        rec["windows"].append(source[0].numpy().astype(np.float32).copy())
+        return torch.zeros(1, 2, 128)
+
+    QD.preprocess = _rec_preprocess
+    tok = tiny_tokenizer()
+    tok.add_tokens(MM_SPECIAL, special_tokens=True)
+    q = "How many instruments are playing?"
+    raw = [dict(task="avqa", audio_path="wave_6000.wav", video_path="clip_37.mp4", question=q),
+           dict(task="avqa", audio_path="wave_6031.wav", video_path="clip_5.mp4", question=q),
+           dict(task="ave", audio_path="wave_1000.wav", video_path="clip_100.mp4"),
+           dict(task="avvp", audio_path="wave_1017.wav", video_path="clip_8.mp4"),
+           dict(task="arig", audio_path="a.wav", image_path="x/00003.jpg"),
+           dict(task="s4", audio_path="a.wav", image_path="x/00002.png", mask_path="m.png"),
+           dict(task="ms3", audio_path="a.wav", image_path="x/00001.png", mask_path="m.png"),
+           dict(task="avss", audio_path="a.wav", image_path="x/00004.jpg", mask_path="m.png"),
+           dict(task="ref-avs", audio_path="a.wav", image_path="x/00000.jpg", mask_path="m.png", exp="The Dog")]
+    cwd = os.getcwd()
+    out = dict(instructions={}, prompts=[], frames=[], n_windows=[])
+    arrays = {}
+    with tempfile.TemporaryDirectory() as td:
+        os.makedirs(os.path.join(td, "data"))
+        json.dump(raw, open(os.path.join(td, "data", "example.json"), "w"))
+        os.chdir(td)
+        try:
+            QD.get_v2_pallete = lambda **k: None                  # avss: palette file lives on the authors' cluster
+            for task in HARNESS_TASKS:
+                flag = {"ref-avs": "ref_avs_task"}.get(task, task + "_task")
+                ds = QD.UnifiedTestDataset(mode="test", tokenizer=tok, video_processor=CLIPImageProcessor(), video_frame_nums=8, **{flag: True})
+                out["instructions"][task] = [s["instruction"] for s in ds.samples]
+                if task in ("avqa", "ave", "avvp"):
+                    inst = [ds[i] for i in range(len(ds))]
+                    col = QD.DataCollatorForUnifiedTestDataset(tokenizer=tok)(inst)
+                    for i, it in enumerate(inst):
+                        k = f"{task}{i}"
+                        out["prompts"].append([k, it["instruction"], it["output"]])
+                        arrays[k + "_ids"] = col["batch_input_ids"][i].numpy()
+                        arrays[k + "_labels"] = col["batch_labels"][i].numpy()
+                        arrays[k + "_video_mean"] = col["batch_X_modals"][i]["<video>"].mean(dim=(1, 2, 3)).numpy()
+                        assert col["batch_task_names"][i] == task and sorted(col["batch_X_modals"][i]) == ["<audio>", "<video>"]
+        finally:
+            os.chdir(cwd)
+    out["frames"] = rec["frames"]
+    out["n_windows"] = [len(w) for w in rec["windows"]]
+    for i, w in enumerate(rec["windows"]):
+        arrays[f"win_{i}"] = w
+    out["decode_ids"] = [[5, 6, 7, 1, 2], [66, 65, 67, 3]]
+    out["decoded"] = tok.batch_decode(out["decode_ids"], skip_special_tokens=False)
+    save("harness", out, **arrays)
+    print("harness:", {k: len(v) for k, v in out["instructions"].items()}, "frames", rec["frames"], "windows", len(rec["windows"]))
+
+
 def main():
     ref_shims.install()
     me = ref_shims.patch_bert_config(lambda: ref_shims.tiny_bert_config(**TINY_QF))
@@ -418,6 +518,8 @@ def main():
         golden_frontend()
     if "vqgan" in which:
         golden_vqgan()
+    if "harness" in which:
+        golden_harness()
 
 
 if __name__ == "__main__":

@@ -83,3 +83,43 @@ def seg_inputs(meta):
     pred = torch.randn(2, 6, D, generator=g)
     feats = [torch.randn(2, 256, 128, generator=g) for _ in range(2)]
     return pred, feats
+
+
+# ------------------------------------------------------------------ tiny tokenizer for the harness tests / golden
+HARNESS_WORDS = ("this is a an video audio image please answer question describe the events and time range that occurred in "
+                 "determine occur based on visual information as well start end of these output location coordinates sounding "
+                 "object segment out makes sound how many instruments are playing dog you helpful assistant none . , : ? \n "
+                 "<<SYS>> <</SYS>> [INST] [/INST]").split(" ")
+LLAMA2_CHAT_TEMPLATE = (
+    "{% if messages[0]['role'] == 'system' %}{% set loop_messages = messages[1:] %}{% set system_message = messages[0]['content'] %}"
+    "{% else %}{% set loop_messages = messages %}{% set system_message = false %}{% endif %}"
+    "{% for message in loop_messages %}{% if loop.index0 == 0 and system_message != false %}"
+    "{% set content = '<<SYS>>\\n' + system_message + '\\n<</SYS>>\\n\\n' + message['content'] %}{% else %}{% set content = message['content'] %}{% endif %}"
+    "{% if message['role'] == 'user' %}{{ bos_token + '[INST] ' + content.strip() + ' [/INST]' }}"
+    "{% elif message['role'] == 'assistant' %}{{ ' ' + content.strip() + ' ' + eos_token }}{% endif %}{% endfor %}")
+
+
+def tiny_tokenizer(chat_template: bool = True, pad_to: int = 0):
+    """A word-level PreTrainedTokenizerFast built in memory (no files): lower-cased words split on whitespace (newline kept as
+    a token) and punctuation, <s> / </s> / <unk>, a Llama-2 style chat template, and room for initialize_MM_tokenizer's
+    added tokens.  Used by the harness golden (tests/golden/make_golden.py harness) and by tests/test_harness.py."""
+    from tokenizers import Regex, Tokenizer, models, normalizers, pre_tokenizers
+    from transformers import PreTrainedTokenizerFast
+    vocab = {"<unk>": 0, "<s>": 1, "</s>": 2}
+    for w in HARNESS_WORDS:
+        w = w.lower()
+        if w and w not in vocab:
+            vocab[w] = len(vocab)
+    while len(vocab) < pad_to:                              # filler words: len(tokenizer) == the model's base vocabulary
+        vocab[f"w{len(vocab)}"] = len(vocab)
+    tk = Tokenizer(models.WordLevel(vocab, unk_token="<unk>"))
+    tk.normalizer = normalizers.Lowercase()
+    tk.pre_tokenizer = pre_tokenizers.Split(Regex(r"\n|[^\s\w<>/\[\]]|[<\[][^\s<>\[\]]*[>\]]|[\w]+"), behavior="removed", invert=True)
+    tok = PreTrainedTokenizerFast(tokenizer_object=tk, bos_token="<s>", eos_token="</s>", unk_token="<unk>", pad_token="<unk>")
+    if chat_template:
+        tok.chat_template = LLAMA2_CHAT_TEMPLATE
+    return tok
+
+
+MM_SPECIAL = ['<image>', '<image_start>', '<image_end>', '<video>', '<video_start>', '<video_end>', '<audio>', '<audio_start>',
+              '<audio_end>', '<mask>', '<mask_start>', '<mask_end>'] + [f'<mask_{i}>' for i in range(6)]
