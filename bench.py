@@ -129,7 +129,13 @@ def cpu_baseline(args):
     # encoders: BEATs + projectors are ~8 % of encoder FLOPs; scale the CLIP time by the FLOP ratio
     enc = t["clip_frame"] * 8 * (1.242 + 0.0875 + 0.032 + 0.0257) / 1.242
     per_clip = enc + pre + 256 * dec_tok
-    return {"value": 1.0 / per_clip, "unit": "clips/s", "cores": nth, "kind": "port",
+    cpu = "unknown CPU"
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), cpu)
+    except OSError:
+        pass
+    return {"value": 1.0 / per_clip, "unit": "clips/s", "cores": nth, "kind": "port", "cpu": cpu,
             "sample": ("oracle fp32 eager: 1 CLIP frame x23 layers (x8, +7.5% for BEATs/Q-Formers by FLOPs), 2-layer full-width "
                        "hyper-LoRA decoder prefill S=702 (x16 layers) and 4 decode tokens (x64 tokens, x16 layers); "
                        f"raw s: {json.dumps({k: round(v, 3) for k, v in t.items()})}")}

@@ -221,7 +221,11 @@ class VisualEncoder(nn.Module):
             raise ValueError(f'Unexpected select feature: {select_feature}')
         # model_name_or_path is accepted for signature compatibility; weights arrive through load_state_dict
         self.vision_tower = CLIPVisionModel(config, device=device)
-        self.image_processor = None
+        # multimodal_encoder.py:46 exposes the tower's CLIPImageProcessor to the dataset code (quick_start.py:561); here it is
+        # the device mirror (crab_amd/frontend.py), bit-exact with the Pillow path for uint8 RGB input
+        from .frontend import CLIPImageProcessor
+        size = int(self.vision_tower.config.get("image_size", 224))
+        self.image_processor = CLIPImageProcessor(size=size, crop_size=size, device=device)
 
     def _layers(self):
         n = self.vision_tower.config["num_hidden_layers"] + 1
