@@ -14,7 +14,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
-from typing import Dict, List, Sequence, Tuple
+from typing import Dict, List, Tuple
 
 import numpy as np
 import torch

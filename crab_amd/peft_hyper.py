@@ -21,7 +21,7 @@ eager ops.  The nn.Parameters exposed under the reference's names are VIEWS into
 from __future__ import annotations
 
 from dataclasses import dataclass, field
-from typing import Dict, List, Optional, Sequence
+from typing import List, Optional, Sequence
 
 import torch
 from torch import nn

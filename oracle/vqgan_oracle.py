@@ -9,7 +9,7 @@ the reference classes, make_golden.py vqgan)."""
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import Dict, Sequence, Tuple
+from typing import Dict, Sequence
 
 import torch
 import torch.nn.functional as F

@@ -2,7 +2,7 @@
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from crab_amd import synth, ops
+from crab_amd import synth
 from crab_amd.build_model import build_crab
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8

@@ -171,7 +171,7 @@ def test_make_instance_pipeline_gpu():
     """uint8 frames + waveform -> make_instance (device front-end) -> Collator -> run_inference on the tiny fixture model: the
     video tensor matches what the reference's dataset produced for the same constant frames, and the harness returns
     exactly what a direct generate() call returns."""
-    from tests.util import build_tiny_crab, weights_from_table
+    from tests.util import weights_from_table
     hm, A = load_fixture("harness")
     meta, _ = load_fixture("full_tiny_llama")
     tok = tiny_tokenizer(pad_to=meta["base_vocab"])

@@ -1,8 +1,5 @@
 """VQGAN mask tokenizer: oracle vs the reference-recorded fixture on CPU, HIP kernels and the MaskEncoder
 mirror on the GPU."""
-import os
-
-import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
