@@ -167,18 +167,11 @@ class GenerationEngine:
 
     def _workspace(self, M: int, slot: int = 0) -> _Workspace:
         """Activation buffers for M rows; `slot` separates the groups that decode concurrently on different streams."""
-        if slot:
-            key = (M, slot)
-            if key not in self._ws:
-                self._ws[key] = _Workspace(self.cfg, M, self.device, self._ws_cols()[0], self._ws_cols()[1])
-            return self._ws[key]
-        if M not in self._ws:
-            tc = uc = 0
-            for g in self.model.layers[0].groups():
-                if g.RA is not None:
-                    tc, uc = max(tc, g.t_cols), max(uc, g.u_cols)
-            self._ws[M] = _Workspace(self.cfg, M, self.device, tc, uc)
-        return self._ws[M]
+        key = (M, slot) if slot else M
+        if key not in self._ws:
+            tc, uc = self._ws_cols()
+            self._ws[key] = _Workspace(self.cfg, M, self.device, tc, uc)
+        return self._ws[key]
 
     def _ws_cols(self):
         tc = uc = 0
