@@ -496,6 +496,73 @@ def golden_harness():
     print("harness:", {k: len(v) for k, v in out["instructions"].items()}, "frames", rec["frames"], "windows", len(rec["windows"]))
 
 
+def golden_llama_ops():
+    """The in-tree statement of the decoder arithmetic, models/modeling_llama.py (HF 4.37.2 as vendored by the reference):
+    LlamaRMSNorm (:103-117), LlamaRotaryEmbedding + apply_rotary_pos_emb (:120-236) and one LlamaDecoderLayer with eager
+    attention (:289-455, :765-850) run as prefill (S = 6, causal additive mask) and as a 1-token decode step against the
+    cache it filled.  The config is a plain namespace (transformers 5.x's LlamaConfig no longer carries rope_theta) and
+    the cache a minimal object with the two methods the 4.37 attention calls (update / get_usable_length)."""
+    import types as _t
+    import transformers.utils.import_utils as iu
+    if not hasattr(iu, "is_torch_fx_available"):
+        iu.is_torch_fx_available = lambda: False
+    import models.modeling_llama as ML
+    D, H, I = 128, 2, 256
+    cfg = _t.SimpleNamespace(hidden_size=D, intermediate_size=I, num_attention_heads=H, num_key_value_heads=H, max_position_embeddings=64,
+                             rope_theta=10000.0, rope_scaling=None, attention_bias=False, attention_dropout=0.0, hidden_act="silu",
+                             pretraining_tp=1, rms_norm_eps=1e-5, _attn_implementation="eager")
+
+    class Cache:
+        def __init__(self):
+            self.k, self.v = None, None
+
+        def get_usable_length(self, new_len, layer_idx=0):
+            return 0 if self.k is None else self.k.shape[-2]
+
+        def update(self, k, v, layer_idx, cache_kwargs=None):
+            self.k = k if self.k is None else torch.cat([self.k, k], dim=-2)
+            self.v = v if self.v is None else torch.cat([self.v, v], dim=-2)
+            return self.k, self.v
+
+    g = torch.Generator().manual_seed(SEED + 5)
+    # RMSNorm
+    norm = ML.LlamaRMSNorm(D, eps=1e-5)
+    norm.weight.data = 1.0 + 0.1 * torch.randn(D, generator=g)
+    xn = torch.randn(2, 5, D, generator=g) * 3.0
+    yn = norm(xn)
+    # RoPE
+    rot = ML.LlamaRotaryEmbedding(64, max_position_embeddings=64, base=10000.0)
+    q = torch.randn(1, H, 7, 64, generator=g)
+    k = torch.randn(1, H, 7, 64, generator=g)
+    pos = torch.tensor([[0, 1, 2, 3, 9, 17, 40]])
+    cos, sin = rot(k, seq_len=41)
+    qr, kr = ML.apply_rotary_pos_emb(q, k, cos, sin, pos)
+    # one decoder layer: prefill + one decode step
+    from peft_hyper.tuners.lora import Linear as HyperLinear
+    layer = ML.LlamaDecoderLayer(cfg, 0)
+    # the in-tree attention calls its projections with return_route_weight (:389-391,452): they are hyper-LoRA Linears, wrapped
+    # like get_peft_model does for all seven (quick_start.py:476-493)
+    for mod, names in ((layer.self_attn, ("q_proj", "k_proj", "v_proj", "o_proj")), (layer.mlp, ("gate_proj", "up_proj", "down_proj"))):
+        for n in names:
+            old = getattr(mod, n)
+            setattr(mod, n, HyperLinear(old.in_features, old.out_features, r=8, lora_alpha=16, lora_nums=3, lora_dropout=0.05, bias=False))
+    layer.eval()
+    table = load_synth(layer, "model.layers.0.")
+    S = 6
+    x = torch.randn(1, S, D, generator=g)
+    mask = torch.full((S, S), torch.finfo(torch.float32).min).triu(1)[None, None]
+    cache = Cache()
+    with torch.no_grad():
+        y = layer(x, attention_mask=mask, position_ids=torch.arange(S)[None], past_key_value=cache, use_cache=True)[0][0]   # (outputs, route weights)
+        x1 = torch.randn(1, 1, D, generator=g)
+        y1 = layer(x1, attention_mask=torch.zeros(1, 1, 1, S + 1), position_ids=torch.tensor([[S]]), past_key_value=cache, use_cache=True)[0][0]
+    assert cache.k.shape == (1, H, S + 1, 64)
+    save("llama_ops", dict(seed=SEED, cfg=dict(hidden_size=D, intermediate_size=I, num_attention_heads=H, num_key_value_heads=H,
+                                               rms_norm_eps=1e-5, rope_theta=10000.0), table=table),
+         norm_w=norm.weight.detach(), norm_x=xn, norm_y=yn.detach(), rope_q=q, rope_k=k, rope_pos=pos, rope_q_out=qr, rope_k_out=kr,
+         layer_x=x, layer_y=y, layer_x1=x1, layer_y1=y1, cache_k=cache.k, cache_v=cache.v)
+
+
 def main():
     ref_shims.install()
     me = ref_shims.patch_bert_config(lambda: ref_shims.tiny_bert_config(**TINY_QF))
@@ -520,6 +587,8 @@ def main():
         golden_vqgan()
     if "harness" in which:
         golden_harness()
+    if "llama_ops" in which:
+        golden_llama_ops()
 
 
 if __name__ == "__main__":

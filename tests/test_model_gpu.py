@@ -344,3 +344,52 @@ def test_generate_edge_cases_vs_oracle():
     out = model.generate(batch_input_ids=[ids], batch_labels=[torch.full_like(ids, -100)], batch_X_modals=[mod], batch_task_names=['avqa'],
                          max_new_tokens=20, pad_token_id=2, eos_token_id=first)
     assert out.shape == (1, 1) and int(out[0, 0]) == first
+
+
+def test_llama_ops_fixture_rmsnorm_rope_layer_prefill():
+    """tests/golden/llama_ops.npz (the reference's in-tree modeling_llama.py): RMSNorm and RoPE kernels, and one hyper-LoRA
+    decoder layer run as prefill through the engine (residual stream before the final norm, K / V cache rows)."""
+    from crab_amd import ops
+    from crab_amd.peft_hyper import LoraConfig, get_peft_model
+    from crab_amd.unified_llama import UnifiedConfig, UnifiedForCausalLM
+    meta, A = load_fixture("llama_ops")
+    c = meta["cfg"]
+    # RMSNorm (bf16 in / out against the fp32 reference)
+    x = A["norm_x"].reshape(-1, c["hidden_size"]).to(BF).cuda()
+    y = ops.rmsnorm(x, A["norm_w"].to(BF).cuda(), c["rms_norm_eps"])
+    assert _rel(y, A["norm_y"].reshape(-1, c["hidden_size"])) < 1.2e-2
+    # RoPE: rows at positions 0..3 as one sequence, then the rows at 9, 17, 40 one by one (pos0 = absolute position)
+    H, d = c["num_attention_heads"], 64
+    tab = ops.rope_table(64, d, c["rope_theta"], "cuda")
+    q, k, pos = A["rope_q"], A["rope_k"], A["rope_pos"][0].tolist()
+
+    def run(rows, pos0):
+        S = len(rows)
+        qkv = torch.cat([q[0, :, rows].transpose(0, 1).reshape(S, H * d), k[0, :, rows].transpose(0, 1).reshape(S, H * d),
+                         torch.zeros(S, H * d)], dim=1).to(BF).cuda().contiguous()
+        kc = torch.zeros(1, H, 64, d, device="cuda", dtype=BF)
+        vc = torch.zeros_like(kc)
+        ops.qkv_rope_split(qkv, tab, kc, vc, None, 1, S, H, H, d, 64, pos0=pos0)
+        got_q = qkv[:, :H * d].reshape(S, H, d).transpose(0, 1)
+        got_k = kc[0, :, pos0:pos0 + S]
+        assert _rel(got_q, A["rope_q_out"][0][:, rows]) < 1.2e-2
+        assert _rel(got_k, A["rope_k_out"][0][:, rows]) < 1.2e-2
+
+    run([0, 1, 2, 3], 0)
+    for r in (4, 5, 6):
+        run([r], pos[r])
+    # one decoder layer, prefill
+    cfg = UnifiedConfig(num_hidden_layers=1, vocab_size=320, pad_token_id=2, **c)
+    model = get_peft_model(UnifiedForCausalLM(cfg, device="cuda"), LoraConfig())
+    W = {"base_model.model." + k_: v for k_, v in weights_from_table(meta).items()}
+    r = model.load_state_dict(W, strict=False)
+    assert not r.unexpected_keys, r.unexpected_keys[:5]
+    um = model.base_model.model
+    eng = um._engine
+    S = A["layer_x"].shape[1]
+    kc, vc = eng.alloc_cache(1, 64)
+    eng.prefill(A["layer_x"].to(BF).cuda(), kc, vc, b0=0)
+    ws = eng._workspace(S)
+    assert _rel(ws.x[:S], A["layer_y"][0]) < REL_F32
+    assert _rel(kc[0, 0, :, :S], A["cache_k"][0][:, :S]) < 1.2e-2
+    assert _rel(vc[0, 0, :, :S], A["cache_v"][0][:, :S]) < 1.2e-2

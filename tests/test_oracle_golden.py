@@ -186,3 +186,24 @@ def test_frontend_kaldi_fbank_restatement_self_consistent():
     assert out.shape == (2, 198, 128)
     segs = FO.avqa_audio_segments(synth.synth_waveform(60.0, 6))
     assert len(segs) == 10 and all(len(s) == 32000 for s in segs)
+
+
+def test_llama_ops_rmsnorm_rope_layer_prefill_and_decode():
+    """Fixture from the reference's in-tree models/modeling_llama.py: LlamaRMSNorm, rotary embedding (non-contiguous positions),
+    one hyper-LoRA decoder layer as prefill and as a 1-token decode step against the cache it filled."""
+    meta, A = load_fixture("llama_ops")
+    _close(O.rmsnorm(A["norm_x"], A["norm_w"], meta["cfg"]["rms_norm_eps"]), A["norm_y"], 1e-5)
+    cos, sin = O.rope_cos_sin(A["rope_pos"], 64, meta["cfg"]["rope_theta"])
+    q, k = O.apply_rope(A["rope_q"], A["rope_k"], cos, sin)
+    _close(q, A["rope_q_out"], 1e-5)
+    _close(k, A["rope_k_out"], 1e-5)
+    W = weights_from_table(meta)
+    cfg = O.DecoderConfig(num_hidden_layers=1, vocab_size=320, **meta["cfg"])
+    cache = O.KVCache()
+    S = A["layer_x"].shape[1]
+    y = O.decoder_layer(A["layer_x"], W, 0, cfg, cache, torch.arange(S)[None])
+    _close(y, A["layer_y"], 1e-4)
+    y1 = O.decoder_layer(A["layer_x1"], W, 0, cfg, cache, torch.tensor([[S]]))
+    _close(y1, A["layer_y1"], 1e-4)
+    _close(cache.k[0], A["cache_k"], 1e-5)
+    _close(cache.v[0], A["cache_v"], 1e-5)
