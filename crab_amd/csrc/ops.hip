@@ -301,21 +301,64 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------ im2col (stride == kernel)
+// One block per (image, patch row): the C*P image rows that feed the gw patches of that patch row are read as whole rows
+// (consecutive lanes -> consecutive pixels: coalesced), staged in LDS as bf16, and each patch's K = C*P*P row (+ zero padding up
+// to ldo) is written out contiguously.  out[(n, gy, gx), c*P*P + ky*P + kx] = in[n, c, gy*P + ky, gx*P + kx].
 template <typename TI>
-__global__ void im2col_patch_kernel(const TI* __restrict__ in, bf16_t* __restrict__ out, long ldo, int N, int C, int Hh, int Ww,
-                                    int P, int gh, int gw) {
-    const int tok = blockIdx.x;                     // (n, gy, gx)
-    const int n = tok / (gh * gw), g = tok % (gh * gw), gy = g / gw, gx = g % gw;
+__global__ __launch_bounds__(256) void im2col_patch_kernel(const TI* __restrict__ in, bf16_t* __restrict__ out, long ldo, int N, int C, int Hh,
+                                                           int Ww, int P, int gh, int gw) {
+    extern __shared__ bf16_t smem[];
+    const int n = blockIdx.x / gh, gy = blockIdx.x % gh;
+    const int wu = gw * P;                          // pixels of a row that belong to whole patches
+    const int nrows = C * P;
     const int Kp = C * P * P;
-    bf16_t* o = out + (long)tok * ldo;
-    for (int k = threadIdx.x; k < ldo; k += blockDim.x) {
-        float v = 0.f;
-        if (k < Kp) {
-            int c = k / (P * P), rr = k % (P * P), ky = rr / P, kx = rr % P;
-            TI x = in[(((long)n * C + c) * Hh + gy * P + ky) * Ww + gx * P + kx];
-            v = sizeof(TI) == 4 ? (float)*reinterpret_cast<const float*>(&x) : bf2f(*reinterpret_cast<const bf16_t*>(&x));
+    bf16_t* rows = smem;                            // [C*P][wu]
+    int* koff = reinterpret_cast<int*>(smem + ((nrows * wu + 1) & ~1));          // k -> offset of (c, ky, kx) inside `rows` (gx = 0)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int k = threadIdx.x; k < Kp; k += blockDim.x) {
+        const int c = k / (P * P), rr = k - c * P * P, ky = rr / P;
+        koff[k] = (c * P + ky) * wu + (rr - ky * P);
+    }
+    // one wave per image row, 4 pixels per lane (8- or 16-byte loads) when the row allows it
+    const bool v4 = (wu & 3) == 0 && (Ww & 3) == 0 && ((uintptr_t)in & 15) == 0;
+    for (int r = wave; r < nrows; r += 4) {
+        const int c = r / P, ky = r - c * P;
+        const TI* src = in + (((long)n * C + c) * Hh + gy * P + ky) * Ww;
+        bf16_t* dst = rows + r * wu;
+        if (v4) {
+            for (int x = lane * 4; x < wu; x += 256) {
+                bf16_t h[4];
+                if (sizeof(TI) == 4) {
+                    const float4 f = *reinterpret_cast<const float4*>(src + x);
+                    h[0] = f2bf(f.x); h[1] = f2bf(f.y); h[2] = f2bf(f.z); h[3] = f2bf(f.w);
+                } else {
+                    *reinterpret_cast<uint2*>(h) = *reinterpret_cast<const uint2*>(src + x);
+                }
+                *reinterpret_cast<uint2*>(dst + x) = *reinterpret_cast<const uint2*>(h);
+            }
+        } else {
+            for (int x = lane; x < wu; x += 64) {
+                const TI px = src[x];
+                dst[x] = sizeof(TI) == 4 ? f2bf(*reinterpret_cast<const float*>(&px)) : *reinterpret_cast<const bf16_t*>(&px);
+            }
         }
-        o[k] = f2bf(v);
+    }
+    __syncthreads();
+    bf16_t* o = out + ((long)(n * gh + gy) * gw) * ldo;
+    if ((ldo & 7) == 0 && ((uintptr_t)out & 15) == 0) {            // 16-byte stores: 8 gathered elements per lane
+        const int cpr = (int)(ldo >> 3);
+        for (int i = threadIdx.x; i < gw * cpr; i += blockDim.x) {
+            const int gx = i / cpr, k0 = (i - gx * cpr) * 8;
+            union { u32x4 r; bf16_t h[8]; } v;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v.h[j] = k0 + j < Kp ? rows[koff[k0 + j] + gx * P] : (bf16_t)0;
+            *reinterpret_cast<u32x4*>(o + (long)gx * ldo + k0) = v.r;
+        }
+    } else {
+        for (long i = threadIdx.x; i < (long)gw * ldo; i += blockDim.x) {
+            const int gx = (int)(i / ldo), k = (int)(i - (long)gx * ldo);
+            o[i] = k < Kp ? rows[koff[k] + gx * P] : (bf16_t)0;
+        }
     }
 }
 
@@ -355,6 +398,61 @@ __global__ __launch_bounds__(256) void clip_embed_ln_kernel(const bf16_t* __rest
     for (int i = 0; i < MAXE; ++i) {
         int e = lane + i * 64;
         if (e < D) yr[e] = f2bf((v[i] - mean) * rstd * bf2f(lnw[e]) + bf2f(lnb[e]));
+    }
+}
+
+// D % 8 == 0: each lane owns 16-byte chunks (8 consecutive elements), so every global access of the row is a full-width
+// coalesced dwordx4 (the scalar kernel above moves 2 bytes per lane and reaches 1.6 TB/s; this one is HBM-copy bound)
+__global__ __launch_bounds__(256) void clip_embed_ln_vec_kernel(const bf16_t* __restrict__ patch, const bf16_t* __restrict__ cls,
+                                                                const bf16_t* __restrict__ pos, const bf16_t* __restrict__ lnw,
+                                                                const bf16_t* __restrict__ lnb, bf16_t* __restrict__ y, int N, int P,
+                                                                int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (long)N * (P + 1)) return;
+    const int n = row / (P + 1), tk = row % (P + 1);
+    const bf16_t* src = tk == 0 ? cls : patch + ((long)n * P + (tk - 1)) * D;
+    const bf16_t* pe = pos + (long)tk * D;
+    constexpr int MAXC = 4;                         // D <= 2048: up to 4 chunks of 8 per lane
+    union V8 { u32x4 r; bf16_t h[8]; };
+    float v[MAXC][8];
+    float s1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int e = (lane + i * 64) * 8;
+        if (e < D) {
+            V8 a, b;
+            a.r = *reinterpret_cast<const u32x4*>(src + e);
+            b.r = *reinterpret_cast<const u32x4*>(pe + e);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                v[i][j] = bf2f(f2bf(bf2f(a.h[j]) + bf2f(b.h[j])));      // the bf16 sum of two bf16 tensors, as the reference
+                s1 += v[i][j];
+            }
+        }
+    }
+    const float mean = wave_sum(s1) / (float)D;
+    float sv = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        if ((lane + i * 64) * 8 < D) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float a = v[i][j] - mean; sv += a * a; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(sv) / (float)D + eps);
+    bf16_t* yr = y + row * D;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int e = (lane + i * 64) * 8;
+        if (e < D) {
+            V8 w, b, o;
+            w.r = *reinterpret_cast<const u32x4*>(lnw + e);
+            b.r = *reinterpret_cast<const u32x4*>(lnb + e);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o.h[j] = f2bf((v[i][j] - mean) * rstd * bf2f(w.h[j]) + bf2f(b.h[j]));
+            *reinterpret_cast<u32x4*>(yr + e) = o.r;
+        }
     }
 }
 
@@ -610,11 +708,13 @@ int crab_im2col_patch(crab_ctx* ctx, void* stream, const void* in, int in_fp32, 
     if (!in || !out || N <= 0 || P <= 0 || Hh < P || Ww < P || ldo < (int64_t)C * P * P)
         return crab_fail(ctx, CRAB_E_INVALID, "im2col_patch: bad argument");
     int gh = Hh / P, gw = Ww / P;
+    const size_t lds = (((size_t)C * P * gw * P + 1) & ~(size_t)1) * sizeof(bf16_t) + (size_t)C * P * P * sizeof(int);
+    if (lds > 64 * 1024) return crab_fail(ctx, CRAB_E_UNSUPPORTED, "im2col_patch: a patch row of the image exceeds 64 KiB of LDS");
     if (in_fp32)
-        hipLaunchKernelGGL((im2col_patch_kernel<float>), dim3(N * gh * gw), dim3(256), 0, S_(stream), (const float*)in, (bf16_t*)out,
+        hipLaunchKernelGGL((im2col_patch_kernel<float>), dim3(N * gh), dim3(256), lds, S_(stream), (const float*)in, (bf16_t*)out,
                            (long)ldo, N, C, Hh, Ww, P, gh, gw);
     else
-        hipLaunchKernelGGL((im2col_patch_kernel<bf16_t>), dim3(N * gh * gw), dim3(256), 0, S_(stream), (const bf16_t*)in, (bf16_t*)out,
+        hipLaunchKernelGGL((im2col_patch_kernel<bf16_t>), dim3(N * gh), dim3(256), lds, S_(stream), (const bf16_t*)in, (bf16_t*)out,
                            (long)ldo, N, C, Hh, Ww, P, gh, gw);
     return crab_check_launch(ctx, "im2col_patch");
 }
@@ -623,8 +723,13 @@ int crab_clip_embed_ln(crab_ctx* ctx, void* stream, const void* patch, const voi
                        void* y, int N, int P, int D, float eps) {
     if (!ctx) return CRAB_E_INVALID;
     if (!patch || !cls || !pos || !lnw || !lnb || !y || D > 2048) return crab_fail(ctx, CRAB_E_INVALID, "clip_embed_ln: bad argument");
-    hipLaunchKernelGGL(clip_embed_ln_kernel, dim3(cdiv((long)N * (P + 1), 4)), dim3(256), 0, S_(stream), (const bf16_t*)patch,
-                       (const bf16_t*)cls, (const bf16_t*)pos, (const bf16_t*)lnw, (const bf16_t*)lnb, (bf16_t*)y, N, P, D, eps);
+    const bool vec = (D & 7) == 0 && (((uintptr_t)patch | (uintptr_t)cls | (uintptr_t)pos | (uintptr_t)lnw | (uintptr_t)lnb | (uintptr_t)y) & 15) == 0;
+    if (vec)
+        hipLaunchKernelGGL(clip_embed_ln_vec_kernel, dim3(cdiv((long)N * (P + 1), 4)), dim3(256), 0, S_(stream), (const bf16_t*)patch,
+                           (const bf16_t*)cls, (const bf16_t*)pos, (const bf16_t*)lnw, (const bf16_t*)lnb, (bf16_t*)y, N, P, D, eps);
+    else
+        hipLaunchKernelGGL(clip_embed_ln_kernel, dim3(cdiv((long)N * (P + 1), 4)), dim3(256), 0, S_(stream), (const bf16_t*)patch,
+                           (const bf16_t*)cls, (const bf16_t*)pos, (const bf16_t*)lnw, (const bf16_t*)lnb, (bf16_t*)y, N, P, D, eps);
     return crab_check_launch(ctx, "clip_embed_ln");
 }
 
