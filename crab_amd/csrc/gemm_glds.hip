@@ -37,7 +37,8 @@ typedef const __attribute__((address_space(1))) void* gbl_vptr;
 
 constexpr int GBK = 64;
 
-template <int BM, int BN>
+// NTB: the weight (B) tiles are streamed once - decode regime - and are LDS-DMA'd with the non-temporal hint (aux = 2)
+template <int BM, int BN, bool NTB = false>
 __global__ __launch_bounds__(256) void gemm_bt_glds_kernel(GemmGP p) {
     constexpr int WM = BM / 2, WN = BN / 2;
     constexpr int TM = WM / 16, TN = WN / 16;
@@ -106,7 +107,12 @@ __global__ __launch_bounds__(256) void gemm_bt_glds_kernel(GemmGP p) {
             const bf16_t* src_ = bs_ + (s2_ ? off2[i] : off1[i]);                                         \
             src_ = ok_ ? src_ : zero;                                                                     \
             bf16_t* dst_ = &lds[(BUF_)][__builtin_amdgcn_readfirstlane(ldso[i])];                         \
-            __builtin_amdgcn_global_load_lds((gbl_vptr)src_, (lds_vptr)dst_, 16, 0, 0);                   \
+            if constexpr (NTB) {                                                                          \
+                if (isA) __builtin_amdgcn_global_load_lds((gbl_vptr)src_, (lds_vptr)dst_, 16, 0, 0);      \
+                else __builtin_amdgcn_global_load_lds((gbl_vptr)src_, (lds_vptr)dst_, 16, 0, 2);          \
+            } else {                                                                                      \
+                __builtin_amdgcn_global_load_lds((gbl_vptr)src_, (lds_vptr)dst_, 16, 0, 0);               \
+            }                                                                                             \
         }                                                                                                 \
     }
 
@@ -190,7 +196,7 @@ __global__ __launch_bounds__(256) void gemm_bt_glds_kernel(GemmGP p) {
 // ------------------------------------------------------------------------------------------------------------
 constexpr int RBK = 32, RNS = 4;
 
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM, int WGN, bool NTB = false>
 __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bt_ring_kernel(GemmGP p) {
     constexpr int NW = WGM * WGN;
     constexpr int WM = BM / WGM, WN = BN / WGN;
@@ -257,7 +263,12 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bt_ring_kernel(GemmGP p) 
             const bf16_t* src_ = bs_ + (s2_ ? off2[i] : off1[i]);                                         \
             src_ = ok_ ? src_ : zero;                                                                     \
             bf16_t* dst_ = &lds[sb_ + __builtin_amdgcn_readfirstlane(ldso[i])];                           \
-            __builtin_amdgcn_global_load_lds((gbl_vptr)src_, (lds_vptr)dst_, 16, 0, 0);                   \
+            if constexpr (NTB) {                                                                          \
+                if (isA) __builtin_amdgcn_global_load_lds((gbl_vptr)src_, (lds_vptr)dst_, 16, 0, 0);      \
+                else __builtin_amdgcn_global_load_lds((gbl_vptr)src_, (lds_vptr)dst_, 16, 0, 2);          \
+            } else {                                                                                      \
+                __builtin_amdgcn_global_load_lds((gbl_vptr)src_, (lds_vptr)dst_, 16, 0, 0);               \
+            }                                                                                             \
         }                                                                                                 \
     }
 
@@ -360,6 +371,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bt_ring_kernel(GemmGP p) 
 int crab_gemm_glds_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* d, int splitk, float* part, int ring_split) {
     GemmGP p;
     p.splitk = splitk > 1 ? splitk : 1; p.part = part;
+    const bool ntb = splitk > 1 && d->tune != 601;                 // decode split-K regime: every weight byte is read once per step
     p.A = (const bf16_t*)d->A; p.B = (const bf16_t*)d->B; p.C = d->C; p.bias = (const bf16_t*)d->bias; p.R = (const bf16_t*)d->R;
     p.A2 = (const bf16_t*)d->A2; p.B2 = (const bf16_t*)d->B2;
     p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc; p.ldr = d->ldr; p.lda2 = d->lda2; p.ldb2 = d->ldb2;
@@ -381,7 +393,8 @@ int crab_gemm_glds_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* d,
     if (p.splitk > 1 && ring_split) {
         p.tiles_m = (d->M + 255) / 256; p.tiles_n = (d->N + 255) / 256;
         dim3 grid(p.tiles_m * p.tiles_n, p.splitk);
-        hipLaunchKernelGGL((gemm_bt_ring_kernel<256, 256, 2, 4>), grid, dim3(512), 0, s, p);
+        if (ntb) hipLaunchKernelGGL((gemm_bt_ring_kernel<256, 256, 2, 4, true>), grid, dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((gemm_bt_ring_kernel<256, 256, 2, 4>), grid, dim3(512), 0, s, p);
         return crab_check_launch(ctx, "gemm_bt_ring_kernel(split-K)");
     }
     if (d->tune == 301) use_big = false;
@@ -394,6 +407,7 @@ int crab_gemm_glds_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* d,
     }
     p.tiles_m = (d->M + 127) / 128; p.tiles_n = (d->N + 127) / 128;
     dim3 grid(p.tiles_m * p.tiles_n, p.splitk > 1 ? p.splitk : batch);
-    hipLaunchKernelGGL((gemm_bt_glds_kernel<128, 128>), grid, dim3(256), 0, s, p);
+    if (ntb) hipLaunchKernelGGL((gemm_bt_glds_kernel<128, 128, true>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((gemm_bt_glds_kernel<128, 128>), grid, dim3(256), 0, s, p);
     return crab_check_launch(ctx, "gemm_bt_glds_kernel");
 }

@@ -2,7 +2,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-template <int UN>
+template <int UN, bool NT>
 __global__ __launch_bounds__(256) void read_kernel(const u32x4* __restrict__ x, long n16, uint32_t* __restrict__ out) {
     u32x4 acc = {0u, 0u, 0u, 0u};
     const long stride = (long)gridDim.x * 256;
@@ -10,15 +10,38 @@ __global__ __launch_bounds__(256) void read_kernel(const u32x4* __restrict__ x, 
     for (; i + (UN - 1) * stride < n16; i += UN * stride) {
         u32x4 v[UN];
 #pragma unroll
-        for (int u = 0; u < UN; ++u) v[u] = x[i + u * stride];
+        for (int u = 0; u < UN; ++u) v[u] = NT ? __builtin_nontemporal_load(x + i + u * stride) : x[i + u * stride];
 #pragma unroll
         for (int u = 0; u < UN; ++u) acc ^= v[u];
     }
     if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345678u) out[blockIdx.x] = 1;
 }
-extern "C" void launch_read(void* stream, const void* x, long bytes, void* out, int blocks, int un) {
+extern "C" void launch_read(void* stream, const void* x, long bytes, void* out, int blocks, int un, int nt) {
     long n16 = bytes / 16;
-    if (un == 1) hipLaunchKernelGGL((read_kernel<1>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const u32x4*)x, n16, (uint32_t*)out);
-    else if (un == 4) hipLaunchKernelGGL((read_kernel<4>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const u32x4*)x, n16, (uint32_t*)out);
-    else hipLaunchKernelGGL((read_kernel<8>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const u32x4*)x, n16, (uint32_t*)out);
+#define RL(UN_, NT_) hipLaunchKernelGGL((read_kernel<UN_, NT_>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const u32x4*)x, n16, (uint32_t*)out)
+    if (nt) { if (un == 1) RL(1, true); else if (un == 4) RL(4, true); else RL(8, true); }
+    else { if (un == 1) RL(1, false); else if (un == 4) RL(4, false); else RL(8, false); }
+#undef RL
+}
+
+// copy: 16-byte loads / stores, default policy or non-temporal on either side
+template <bool NTL, bool NTS>
+__global__ __launch_bounds__(256) void copy_kernel(const u32x4* __restrict__ x, u32x4* __restrict__ y, long n16) {
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i + 3 * stride < n16; i += 4 * stride) {
+        u32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = NTL ? __builtin_nontemporal_load(x + i + u * stride) : x[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (NTS) __builtin_nontemporal_store(v[u], y + i + u * stride);
+            else y[i + u * stride] = v[u];
+        }
+    }
+}
+extern "C" void launch_copy(void* stream, const void* x, void* y, long bytes, int blocks, int ntl, int nts) {
+    long n16 = bytes / 16;
+#define CL(A_, B_) hipLaunchKernelGGL((copy_kernel<A_, B_>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const u32x4*)x, (u32x4*)y, n16)
+    if (ntl) { if (nts) CL(true, true); else CL(true, false); } else { if (nts) CL(false, true); else CL(false, false); }
+#undef CL
 }

@@ -19,11 +19,19 @@ print(f"torch copy 4 GiB: {ms:.3f} ms -> {2*x.numel()*4/ms/1e6:.0f} GB/s (read+w
 # ---- hand-written streaming read (scripts/exp/read_bw.hip): blocks x loads-in-flight sweep
 import ctypes as C, os
 lib = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "read_bw.so"))
-lib.launch_read.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_int, C.c_int]
+lib.launch_read.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_int, C.c_int, C.c_int]
 out = torch.zeros(1 << 20, device="cuda", dtype=torch.int32)
 nbytes = x.numel() * 4
-for blocks in (1024, 2048, 4096, 8192, 16384):
-    for un in (1, 4, 8):
-        fn = lambda: lib.launch_read(torch.cuda.current_stream().cuda_stream, x.data_ptr(), nbytes, out.data_ptr(), blocks, un)
-        ms = t(fn)
-        print(f"read kernel blocks={blocks:6d} loads in flight={un}: {nbytes/ms/1e6:.0f} GB/s")
+for nt in (0, 1):
+    for blocks in (2048, 4096, 8192, 16384):
+        for un in (1, 4, 8):
+            fn = lambda: lib.launch_read(torch.cuda.current_stream().cuda_stream, x.data_ptr(), nbytes, out.data_ptr(), blocks, un, nt)
+            ms = t(fn)
+            print(f"read kernel {'nt     ' if nt else 'default'} blocks={blocks:6d} loads in flight={un}: {nbytes/ms/1e6:.0f} GB/s")
+lib.launch_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int]
+for ntl in (0, 1):
+    for nts in (0, 1):
+        for blocks in (2048, 8192):
+            fn = lambda: lib.launch_copy(torch.cuda.current_stream().cuda_stream, x.data_ptr(), y.data_ptr(), nbytes, blocks, ntl, nts)
+            ms = t(fn)
+            print(f"copy kernel nt-load={ntl} nt-store={nts} blocks={blocks:6d}: {2*nbytes/ms/1e6:.0f} GB/s (read+write)")
