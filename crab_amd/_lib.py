@@ -10,7 +10,7 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcrab_hip.so")
+LIB_PATH = os.environ.get("CRAB_HIP_LIB") or os.path.join(_HERE, "libcrab_hip.so")      # override: A/B builds of the same C-ABI
 
 
 class CrabHipError(RuntimeError):
