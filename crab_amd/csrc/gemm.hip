@@ -223,41 +223,45 @@ __global__ __launch_bounds__(256) void splitk_epilogue_norm_kernel(const float* 
     __shared__ float red[4];
     const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long MN = (long)M * N;
-    constexpr int MAXQ = 8;                                   // 8 float4 per thread: N <= 8192
-    float xv[MAXQ][4];
+    constexpr int MAXQ = 4;                                   // 4 chunks of 8 columns per thread: N <= 8192; every access is 16 B wide
+    float xv[MAXQ][8];
     float ss = 0.f;
 #pragma unroll
     for (int q = 0; q < MAXQ; ++q) {
-        const int n = (tid + q * 256) * 4;
+        const int n = (tid + q * 256) * 8;
         if (n < N) {
-            f32x4_t v = {0.f, 0.f, 0.f, 0.f};
+            f32x4_t v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
             const float* pp = part + (long)m * N + n;
             int s = 0;
-            for (; s + 4 <= S; s += 4) {                          // 4 slices in flight, summed in slice order
-                f32x4_t t0 = *reinterpret_cast<const f32x4_t*>(pp + (s + 0) * MN);
-                f32x4_t t1 = *reinterpret_cast<const f32x4_t*>(pp + (s + 1) * MN);
-                f32x4_t t2 = *reinterpret_cast<const f32x4_t*>(pp + (s + 2) * MN);
-                f32x4_t t3 = *reinterpret_cast<const f32x4_t*>(pp + (s + 3) * MN);
-                v += t0; v += t1; v += t2; v += t3;
+            for (; s + 4 <= S; s += 4) {                          // 4 slices (8 loads) in flight, summed in slice order
+                f32x4_t a0 = *reinterpret_cast<const f32x4_t*>(pp + (s + 0) * MN), b0 = *reinterpret_cast<const f32x4_t*>(pp + (s + 0) * MN + 4);
+                f32x4_t a1 = *reinterpret_cast<const f32x4_t*>(pp + (s + 1) * MN), b1 = *reinterpret_cast<const f32x4_t*>(pp + (s + 1) * MN + 4);
+                f32x4_t a2 = *reinterpret_cast<const f32x4_t*>(pp + (s + 2) * MN), b2 = *reinterpret_cast<const f32x4_t*>(pp + (s + 2) * MN + 4);
+                f32x4_t a3 = *reinterpret_cast<const f32x4_t*>(pp + (s + 3) * MN), b3 = *reinterpret_cast<const f32x4_t*>(pp + (s + 3) * MN + 4);
+                v0 += a0; v0 += a1; v0 += a2; v0 += a3;
+                v1 += b0; v1 += b1; v1 += b2; v1 += b3;
             }
-            for (; s < S; ++s) v += *reinterpret_cast<const f32x4_t*>(pp + s * MN);
-            u32x2 rr = {0u, 0u};
-            if (R) rr = *reinterpret_cast<const u32x2*>(R + (long)m * ldr + n);
-            float rv[4] = {lo_bf(rr[0]), hi_bf(rr[0]), lo_bf(rr[1]), hi_bf(rr[1])};
-            u32x2 o;
-            float t[4];
+            for (; s < S; ++s) {
+                v0 += *reinterpret_cast<const f32x4_t*>(pp + s * MN);
+                v1 += *reinterpret_cast<const f32x4_t*>(pp + s * MN + 4);
+            }
+            u32x4 rr = {0u, 0u, 0u, 0u}, bb = {0u, 0u, 0u, 0u};
+            if (R) rr = *reinterpret_cast<const u32x4*>(R + (long)m * ldr + n);
+            if (bias) bb = *reinterpret_cast<const u32x4*>(bias + n);
+            u32x4 o;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float x = v[r];
-                if (bias) x += bf2f(bias[n + r]);
+            for (int r = 0; r < 8; ++r) {
+                float x = r < 4 ? v0[r] : v1[r - 4];
+                const uint32_t bw = bb[r >> 1], rw = rr[r >> 1];
+                if (bias) x += (r & 1) ? hi_bf(bw) : lo_bf(bw);
                 x = apply_act(x, act);
-                if (R) x += res_scale * rv[r];
-                t[r] = bf2f(f2bf(x));                          // the norm sees the stored bf16 value
-                xv[q][r] = t[r];
-                ss += t[r] * t[r];
+                if (R) x += res_scale * ((r & 1) ? hi_bf(rw) : lo_bf(rw));
+                xv[q][r] = bf2f(f2bf(x));                      // the norm sees the stored bf16 value
+                ss += xv[q][r] * xv[q][r];
             }
-            o[0] = pack_bf2(t[0], t[1]); o[1] = pack_bf2(t[2], t[3]);
-            *reinterpret_cast<u32x2*>(C + (long)m * ldc + n) = o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = pack_bf2(xv[q][2 * r], xv[q][2 * r + 1]);
+            *reinterpret_cast<u32x4*>(C + (long)m * ldc + n) = o;
         }
     }
     ss = wave_sum(ss);
@@ -266,18 +270,18 @@ __global__ __launch_bounds__(256) void splitk_epilogue_norm_kernel(const float* 
     const float rstd = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)N + eps);
 #pragma unroll
     for (int q = 0; q < MAXQ; ++q) {
-        const int n = (tid + q * 256) * 4;
+        const int n = (tid + q * 256) * 8;
         if (n < N) {
-            u32x2 wv = *reinterpret_cast<const u32x2*>(nw + n);
-            float w4[4] = {lo_bf(wv[0]), hi_bf(wv[0]), lo_bf(wv[1]), hi_bf(wv[1])};
-            float h4[4];
+            const u32x4 wv = *reinterpret_cast<const u32x4*>(nw + n);
+            float h8[8];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) h4[r] = bf2f(f2bf(xv[q][r] * rstd)) * w4[r];
-            u32x2 o;
-            o[0] = pack_bf2(h4[0], h4[1]); o[1] = pack_bf2(h4[2], h4[3]);
-            *reinterpret_cast<u32x2*>(H + (long)m * ldh + n) = o;
+            for (int r = 0; r < 8; ++r) h8[r] = bf2f(f2bf(xv[q][r] * rstd)) * ((r & 1) ? hi_bf(wv[r >> 1]) : lo_bf(wv[r >> 1]));
+            u32x4 o;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) xv[q][r] = bf2f(f2bf(h4[r]));          // the router sees the stored bf16 row
+            for (int r = 0; r < 4; ++r) o[r] = pack_bf2(h8[2 * r], h8[2 * r + 1]);
+            *reinterpret_cast<u32x4*>(H + (long)m * ldh + n) = o;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) xv[q][r] = bf2f(f2bf(h8[r]));          // the router sees the stored bf16 row
         }
     }
     if (!rt.RA) return;
@@ -293,14 +297,18 @@ __global__ __launch_bounds__(256) void splitk_epilogue_norm_kernel(const float* 
         for (int cc = 0; cc < 16; ++cc) p[cc] = 0.f;
 #pragma unroll
         for (int q = 0; q < MAXQ; ++q) {
-            const int n = (tid + q * 256) * 4;
+            const int n = (tid + q * 256) * 8;
             if (n < N) {
-                u32x2 w[16];
+                u32x4 w[16];
 #pragma unroll
-                for (int cc = 0; cc < 16; ++cc) w[cc] = *reinterpret_cast<const u32x2*>(rt.RA + (long)(c0 + cc) * rt.ldra + n);
+                for (int cc = 0; cc < 16; ++cc) w[cc] = *reinterpret_cast<const u32x4*>(rt.RA + (long)(c0 + cc) * rt.ldra + n);
 #pragma unroll
-                for (int cc = 0; cc < 16; ++cc)
-                    p[cc] += xv[q][0] * lo_bf(w[cc][0]) + xv[q][1] * hi_bf(w[cc][0]) + xv[q][2] * lo_bf(w[cc][1]) + xv[q][3] * hi_bf(w[cc][1]);
+                for (int cc = 0; cc < 16; ++cc) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a += xv[q][2 * e] * lo_bf(w[cc][e]) + xv[q][2 * e + 1] * hi_bf(w[cc][e]);
+                    p[cc] += a;
+                }
             }
         }
 #pragma unroll
@@ -527,8 +535,9 @@ extern "C" int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc*
                                d->rope_pos0, d->rope_H, d->rope_Hk, d->rope_d, d->rope_Tmax);
             return crab_check_launch(ctx, "splitk_epilogue_rope_kernel");
         }
-        if (d->norm_w && !d->c_fp32 && (d->N & 3) == 0 && d->N <= 8192 && (d->ldc & 3) == 0 && (d->ld_norm & 3) == 0 &&
-            (!d->R || (d->ldr & 3) == 0) && (!d->route_RA || ((d->route_ldra & 3) == 0 && d->route_nl <= 8 &&
+        if (d->norm_w && !d->c_fp32 && (d->N & 7) == 0 && d->N <= 8192 && (d->ldc & 7) == 0 && (d->ld_norm & 7) == 0 &&
+            (((uintptr_t)d->C | (uintptr_t)d->norm_out | (uintptr_t)d->norm_w | (uintptr_t)d->R | (uintptr_t)d->bias | (uintptr_t)d->route_RA) & 15) == 0 &&
+            (!d->R || (d->ldr & 7) == 0) && (!d->route_RA || ((d->route_ldra & 7) == 0 && d->route_nl <= 8 &&
                                                              d->route_nproj * (d->route_nl + d->route_r) <= 64))) {
             RouteP rt;
             rt.RA = (const bf16_t*)d->route_RA; rt.U = (bf16_t*)d->route_U; rt.ldra = d->route_ldra; rt.ldu = d->route_ldu;
