@@ -208,6 +208,39 @@ __global__ void splitk_epilogue_kernel(const float* __restrict__ part, int S, in
     }
 }
 
+// SwiGLU-pair fast path of the reduction above (the gate|up projection of the decode step): one thread per 16 interleaved
+// (gate, up) columns = 4 x 16-byte loads per slice and ONE 16-byte store of 8 outputs.  Same summation order per column.
+__global__ __launch_bounds__(256) void splitk_epilogue_swiglu8_kernel(const float* __restrict__ part, int S, int M, int N,
+                                                                       const bf16_t* __restrict__ bias, bf16_t* __restrict__ C, long ldc) {
+    const int nq = N >> 4;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)M * nq) return;
+    const int m = (int)(idx / nq), n = (int)(idx % nq) * 16;
+    const long MN = (long)M * N;
+    const float* q = part + (long)m * N + n;
+    f32x4_t v[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    for (int s = 0; s < S; ++s) {
+        f32x4_t t[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t[i] = *reinterpret_cast<const f32x4_t*>(q + s * MN + 4 * i);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] += t[i];
+    }
+    if (bias) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[i][r] += bf2f(bias[n + 4 * i + r]);
+    }
+    u32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float o0 = v[i][0] / (1.0f + __expf(-v[i][0])) * v[i][1], o1 = v[i][2] / (1.0f + __expf(-v[i][2])) * v[i][3];
+        o[i] = pack_bf2(o0, o1);
+    }
+    *reinterpret_cast<u32x4*>(C + (long)m * ldc + (n >> 1)) = o;
+}
+
 struct RouteP {                                   // router of the next projection group (crab_gemm_desc.route_*)
     const bf16_t* RA; bf16_t* U; long ldra, ldu; int nproj, nl, r, ucols; float scaling;
 };
@@ -350,31 +383,52 @@ int crab_gemm_glds_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* d,
 // One thread per (row, head, 4 dims of the first half): it also owns the matching 4 dims of the second half, i.e. the
 // rotation partners.  Sums are rounded to bf16 before the rotation, exactly like the unfused pair (reduction kernel ->
 // bf16 C -> qkv_rope_split_kernel), so prefill and decode see identical k / q values for identical inputs.
+template <int G>                                                // dims per thread and half: 4 (8-byte stores) or 8 (16-byte stores)
 __global__ __launch_bounds__(256) void splitk_epilogue_rope_kernel(const float* __restrict__ part, int S, int M, int N,
                                                                     const bf16_t* __restrict__ bias, bf16_t* __restrict__ C, long ldc,
                                                                     const float* __restrict__ tab, bf16_t* __restrict__ kc,
                                                                     bf16_t* __restrict__ vc, const int* __restrict__ pos_dev, int pos0,
                                                                     int H, int Hk, int d, int Tmax) {
-    const int half = d >> 1, gpd = half >> 2;                   // 4-dim groups per half head
+    constexpr int V = G / 4;                                    // float4 per half
+    const int half = d >> 1, gpd = half / G;                    // G-dim groups per half head
     const int nh = H + 2 * Hk;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long)M * nh * gpd) return;
     const int j = (int)(idx % gpd);
     const int hh = (int)((idx / gpd) % nh);
     const int m = (int)(idx / ((long)gpd * nh));
-    const int n1 = hh * d + 4 * j, n2 = n1 + half;
+    const int n1 = hh * d + G * j, n2 = n1 + half;
     const long MN = (long)M * N;
     const float* q = part + (long)m * N;
-    f32x4_t a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < S; ++s) {
-        a += *reinterpret_cast<const f32x4_t*>(q + s * MN + n1);
-        b += *reinterpret_cast<const f32x4_t*>(q + s * MN + n2);
-    }
-    float x1[4], x2[4];
+    f32x4_t a[V], b[V];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        x1[r] = bf2f(f2bf(a[r] + (bias ? bf2f(bias[n1 + r]) : 0.f)));
-        x2[r] = bf2f(f2bf(b[r] + (bias ? bf2f(bias[n2 + r]) : 0.f)));
+    for (int i = 0; i < V; ++i) { a[i] = f32x4_t{0.f, 0.f, 0.f, 0.f}; b[i] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+    int s = 0;
+    for (; s + 2 <= S; s += 2) {                                // two slices (4 V loads) in flight, summed in slice order
+        f32x4_t ta[2][V], tb[2][V];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                ta[u][i] = *reinterpret_cast<const f32x4_t*>(q + (s + u) * MN + n1 + 4 * i);
+                tb[u][i] = *reinterpret_cast<const f32x4_t*>(q + (s + u) * MN + n2 + 4 * i);
+            }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int i = 0; i < V; ++i) { a[i] += ta[u][i]; b[i] += tb[u][i]; }
+    }
+    for (; s < S; ++s)
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            a[i] += *reinterpret_cast<const f32x4_t*>(q + s * MN + n1 + 4 * i);
+            b[i] += *reinterpret_cast<const f32x4_t*>(q + s * MN + n2 + 4 * i);
+        }
+    float x1[G], x2[G];
+#pragma unroll
+    for (int r = 0; r < G; ++r) {
+        x1[r] = bf2f(f2bf(a[r >> 2][r & 3] + (bias ? bf2f(bias[n1 + r]) : 0.f)));
+        x2[r] = bf2f(f2bf(b[r >> 2][r & 3] + (bias ? bf2f(bias[n2 + r]) : 0.f)));
     }
     const int pos = (pos_dev ? pos_dev[0] : 0) + pos0;
     bf16_t* dst1; bf16_t* dst2;
@@ -382,27 +436,32 @@ __global__ __launch_bounds__(256) void splitk_epilogue_rope_kernel(const float* 
     else {
         const int hk = (hh - H) % Hk;
         bf16_t* cache = hh < H + Hk ? kc : vc;
-        dst1 = cache + (((long)m * Hk + hk) * Tmax + pos) * d + 4 * j;
+        dst1 = cache + (((long)m * Hk + hk) * Tmax + pos) * d + G * j;
         dst2 = dst1 + half;
     }
-    float o1[4], o2[4];
+    float o1[G], o2[G];
     if (hh < H + Hk) {
-        const float* t = tab + 2 * ((long)pos * half + 4 * j);   // (cos, sin) pairs of dims 4j .. 4j+3
+        const float* t = tab + 2 * ((long)pos * half + G * j);   // (cos, sin) pairs of dims G j .. G j + G - 1
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < G; ++r) {
             const float c = t[2 * r], sn = t[2 * r + 1];
             o1[r] = rope_lo(x1[r], x2[r], c, sn);
             o2[r] = rope_hi(x1[r], x2[r], c, sn);
         }
     } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { o1[r] = x1[r]; o2[r] = x2[r]; }
+        for (int r = 0; r < G; ++r) { o1[r] = x1[r]; o2[r] = x2[r]; }
     }
-    u32x2 w1, w2;
-    w1.x = pack_bf2(o1[0], o1[1]); w1.y = pack_bf2(o1[2], o1[3]);
-    w2.x = pack_bf2(o2[0], o2[1]); w2.y = pack_bf2(o2[2], o2[3]);
-    *reinterpret_cast<u32x2*>(dst1) = w1;
-    *reinterpret_cast<u32x2*>(dst2) = w2;
+    uint32_t w1[G / 2], w2[G / 2];
+#pragma unroll
+    for (int r = 0; r < G / 2; ++r) { w1[r] = pack_bf2(o1[2 * r], o1[2 * r + 1]); w2[r] = pack_bf2(o2[2 * r], o2[2 * r + 1]); }
+    if (G == 8) {
+        *reinterpret_cast<u32x4*>(dst1) = u32x4{w1[0], w1[1], w1[G / 2 - 2], w1[G / 2 - 1]};
+        *reinterpret_cast<u32x4*>(dst2) = u32x4{w2[0], w2[1], w2[G / 2 - 2], w2[G / 2 - 1]};
+    } else {
+        *reinterpret_cast<u32x2*>(dst1) = u32x2{w1[0], w1[1]};
+        *reinterpret_cast<u32x2*>(dst2) = u32x2{w2[0], w2[1]};
+    }
 }
 
 // unfused form of the optional post-RMSNorm (paths whose epilogue does not own whole rows)
@@ -529,10 +588,14 @@ extern "C" int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc*
         if (rc) return rc;
         if (splitk == 1) return post_norm(ctx, stream, d);
         if (d->rope_tab && (d->rope_d & 7) == 0 && (d->ldc & 3) == 0 && (d->N & 3) == 0) {
-            const long nthr = (long)d->M * (d->rope_H + 2 * d->rope_Hk) * (d->rope_d >> 3);
-            hipLaunchKernelGGL(splitk_epilogue_rope_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, p.part, splitk, d->M, d->N, p.bias,
-                               (bf16_t*)d->C, (long)d->ldc, d->rope_tab, (bf16_t*)d->rope_k_cache, (bf16_t*)d->rope_v_cache, d->rope_pos_dev,
-                               d->rope_pos0, d->rope_H, d->rope_Hk, d->rope_d, d->rope_Tmax);
+            const bool g8 = (d->rope_d & 15) == 0 && (d->ldc & 7) == 0 &&
+                            (((uintptr_t)d->C | (uintptr_t)d->rope_k_cache | (uintptr_t)d->rope_v_cache) & 15) == 0;
+            const long nthr = (long)d->M * (d->rope_H + 2 * d->rope_Hk) * (d->rope_d >> (g8 ? 4 : 3));
+#define ROPE_EPI(G_) hipLaunchKernelGGL((splitk_epilogue_rope_kernel<G_>), dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, p.part, splitk, \
+                                        d->M, d->N, p.bias, (bf16_t*)d->C, (long)d->ldc, d->rope_tab, (bf16_t*)d->rope_k_cache,                 \
+                                        (bf16_t*)d->rope_v_cache, d->rope_pos_dev, d->rope_pos0, d->rope_H, d->rope_Hk, d->rope_d, d->rope_Tmax)
+            if (g8) ROPE_EPI(8); else ROPE_EPI(4);
+#undef ROPE_EPI
             return crab_check_launch(ctx, "splitk_epilogue_rope_kernel");
         }
         if (d->norm_w && !d->c_fp32 && (d->N & 7) == 0 && d->N <= 8192 && (d->ldc & 7) == 0 && (d->ld_norm & 7) == 0 &&
@@ -546,6 +609,14 @@ extern "C" int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc*
                                (long)d->ldr, d->res_scale, (bf16_t*)d->C, (long)d->ldc, (const bf16_t*)d->norm_w, d->norm_eps,
                                (bf16_t*)d->norm_out, (long)d->ld_norm, rt);
             return crab_check_launch(ctx, "splitk_epilogue_norm_kernel");
+        }
+        if (d->act == ACT_SWIGLU_PAIR && !d->c_fp32 && (d->N & 15) == 0 && (d->ldc & 7) == 0 && ((uintptr_t)d->C & 15) == 0) {
+            const long nthr8 = (long)d->M * (d->N >> 4);
+            hipLaunchKernelGGL(splitk_epilogue_swiglu8_kernel, dim3((unsigned)((nthr8 + 255) / 256)), dim3(256), 0, s, p.part, splitk, d->M, d->N,
+                               p.bias, (bf16_t*)d->C, (long)d->ldc);
+            rc = crab_check_launch(ctx, "splitk_epilogue_swiglu8_kernel");
+            if (rc) return rc;
+            return post_norm(ctx, stream, d);
         }
         long nthr = (long)d->M * ((d->N + 3) / 4);
         hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, p.part, splitk, d->M, d->N, p.bias, d->act,
