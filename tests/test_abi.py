@@ -81,3 +81,23 @@ def test_prefill_chunk_plan_covers_batch():
         assert eng.plan_prefill_chunks(4, 64) == [4]                        # below the ring regime: one chunk
         ch = eng.plan_prefill_chunks(256, 702)
         assert max(ch) > 16 and len(ch) <= 12                                # fuller rounds than the old fixed 16
+
+
+def test_bench_flop_and_byte_accounting_matches_survey():
+    """bench.py's algorithmic work model: SURVEY.md 8d quotes 10.67 TFLOP per AVQA clip for the prefill phase (8 frames, 10 audio
+    segments, S = 702) and ~13.7 GB per decode token at batch 1; the config-derived form must reproduce the Llama-2-7B constants."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    f = bench.flops_per_clip()
+    assert abs(f - 10.67e12) / 10.67e12 < 0.01
+    from oracle.crab_oracle import DecoderConfig
+    c = DecoderConfig()
+    c.hidden_size, c.intermediate_size, c.num_hidden_layers = 4096, 11008, 32
+    f2 = bench.flops_per_clip(cfg=c)
+    assert abs(f2 - f) / f < 0.01                              # derived linear / LoRA / attention terms == the quoted constants
+    b1 = bench.decode_bytes_per_step(1, 830)
+    assert 13.5e9 < b1 < 14.2e9
+    assert bench.decode_bytes_per_step(256, 830) - bench.decode_bytes_per_step(256, 829) == 256 * 2 * 32 * 4096 * 2
