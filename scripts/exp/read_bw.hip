@@ -45,3 +45,34 @@ extern "C" void launch_copy(void* stream, const void* x, void* y, long bytes, in
     if (ntl) { if (nts) CL(true, true); else CL(true, false); } else { if (nts) CL(false, true); else CL(false, false); }
 #undef CL
 }
+
+// cache-policy bits through inline asm: POL 0 = default, 1 = nt, 2 = sc1, 3 = sc0 sc1, 4 = nt sc1, 5 = nt sc0 sc1, 6 = sc0
+template <int POL>
+__device__ __forceinline__ u32x4 pol_load(const u32x4* p) {
+    u32x4 v;
+    if (POL == 0) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    if (POL == 1) asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(v) : "v"(p) : "memory");
+    if (POL == 2) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+    if (POL == 3) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
+    if (POL == 4) asm volatile("global_load_dwordx4 %0, %1, off sc1 nt" : "=v"(v) : "v"(p) : "memory");
+    if (POL == 5) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1 nt" : "=v"(v) : "v"(p) : "memory");
+    if (POL == 6) asm volatile("global_load_dwordx4 %0, %1, off sc0" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+template <int POL>
+__global__ __launch_bounds__(256) void read_pol_kernel(const u32x4* __restrict__ x, long n16, uint32_t* __restrict__ out) {
+    u32x4 acc = {0u, 0u, 0u, 0u};
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i + stride < n16; i += 2 * stride) {
+        u32x4 a = pol_load<POL>(x + i), b = pol_load<POL>(x + i + stride);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        acc ^= a; acc ^= b;
+    }
+    if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345678u) out[blockIdx.x] = 1;
+}
+extern "C" void launch_read_pol(void* stream, const void* x, long bytes, void* out, int blocks, int pol) {
+    long n16 = bytes / 16;
+#define PL(P_) hipLaunchKernelGGL((read_pol_kernel<P_>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const u32x4*)x, n16, (uint32_t*)out)
+    switch (pol) { case 0: PL(0); break; case 1: PL(1); break; case 2: PL(2); break; case 3: PL(3); break; case 4: PL(4); break; case 5: PL(5); break; default: PL(6); }
+#undef PL
+}

@@ -35,3 +35,10 @@ for ntl in (0, 1):
             fn = lambda: lib.launch_copy(torch.cuda.current_stream().cuda_stream, x.data_ptr(), y.data_ptr(), nbytes, blocks, ntl, nts)
             ms = t(fn)
             print(f"copy kernel nt-load={ntl} nt-store={nts} blocks={blocks:6d}: {2*nbytes/ms/1e6:.0f} GB/s (read+write)")
+lib.launch_read_pol.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_int, C.c_int]
+names = ["default", "nt", "sc1", "sc0 sc1", "sc1 nt", "sc0 sc1 nt", "sc0"]
+for pol in range(7):
+    for blocks in (2048, 8192):
+        fn = lambda: lib.launch_read_pol(torch.cuda.current_stream().cuda_stream, x.data_ptr(), nbytes, out.data_ptr(), blocks, pol)
+        ms = t(fn)
+        print(f"read (asm, 2 loads in flight) policy [{names[pol]:11s}] blocks={blocks:6d}: {nbytes/ms/1e6:.0f} GB/s")
