@@ -272,6 +272,37 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bt_ring_kernel(GemmGP p) 
         }                                                                                                 \
     }
 
+    // Fast staging for the K tiles that lie wholly inside the first K segment (all but the last few): the per-piece source
+    // pointer is carried and advanced by one K tile per call (0 for rows outside the operand: they keep reading the zero
+    // page), so a piece costs the LDS-DMA plus one 64-bit add instead of the segment / tail / row selects of RSTAGE.
+    // FSTAGE must be called for local tiles 0, 1, 2, ... in order (it is: prologue 0..2, then t + 3).
+    const int nfast = max(0, min(nk, p.K / RBK - t_first));
+    const bf16_t* fptr[PPW];
+    int fadv[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        fptr[i] = rok[i] ? base1 + (long)t_first * RBK + off1[i] : zero;
+        fadv[i] = rok[i] ? RBK : 0;
+    }
+#define FSTAGE(T_)                                                                                        \
+    {                                                                                                     \
+        const int sbf_ = ((T_) & (RNS - 1)) * STAGE_ELEMS;                                                \
+        _Pragma("unroll") for (int i = 0; i < PPW; ++i) {                                                 \
+            bf16_t* dst_ = &lds[sbf_ + __builtin_amdgcn_readfirstlane(ldso[i])];                          \
+            if constexpr (NTB) {                                                                          \
+                if (isA) __builtin_amdgcn_global_load_lds((gbl_vptr)fptr[i], (lds_vptr)dst_, 16, 0, 0);   \
+                else __builtin_amdgcn_global_load_lds((gbl_vptr)fptr[i], (lds_vptr)dst_, 16, 0, 2);       \
+            } else {                                                                                      \
+                __builtin_amdgcn_global_load_lds((gbl_vptr)fptr[i], (lds_vptr)dst_, 16, 0, 0);            \
+            }                                                                                             \
+            fptr[i] += fadv[i];                                                                           \
+        }                                                                                                 \
+    }
+#define XSTAGE(T_)                                                                                        \
+    {                                                                                                     \
+        if ((T_) < nfast) FSTAGE(T_) else RSTAGE(T_)                                                      \
+    }
+
     f32x4_t acc[TN][TM];
 #pragma unroll
     for (int i = 0; i < TN; ++i)
@@ -279,9 +310,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bt_ring_kernel(GemmGP p) 
         for (int j = 0; j < TM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     // prologue: tiles 0..2 in flight, tile 0 retired
-    RSTAGE(0);
-    if (nk > 1) RSTAGE(1);
-    if (nk > 2) RSTAGE(2);
+    XSTAGE(0);
+    if (nk > 1) XSTAGE(1);
+    if (nk > 2) XSTAGE(2);
     static_assert(PPW == 4, "vmcnt(8) below = two tiles of 4 LDS-DMA instructions per wave");
     if (nk > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -318,7 +349,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bt_ring_kernel(GemmGP p) 
 #pragma unroll
         for (int mi = 0; mi < TM; ++mi) xf[mi] = *reinterpret_cast<const bf16x8_t*>(st + xofs[mi]);
         __builtin_amdgcn_sched_barrier(0);
-        if (t + 3 < nk) RSTAGE(t + 3);
+        if (t + 3 < nk) XSTAGE(t + 3);
         // retire tile t+1 (the two youngest tiles stay in flight) and drain this tile's LDS reads BEFORE the barrier:
         // after it the partner group may refill the stage these reads came from
         if (t + 3 < nk) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
@@ -340,6 +371,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bt_ring_kernel(GemmGP p) 
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();
 #undef RSTAGE
+#undef FSTAGE
+#undef XSTAGE
     if (p.splitk > 1) {          // raw partial tile; reduced in a fixed slice order by the split-K epilogue kernels (gemm.hip)
         float* part = p.part + (long)sk * p.M * p.N;
         const bool v4 = (p.N & 3) == 0;
