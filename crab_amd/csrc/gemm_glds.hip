@@ -122,14 +122,42 @@ __global__ __launch_bounds__(256) void gemm_bt_glds_kernel(GemmGP p) {
 #pragma unroll
         for (int j = 0; j < TM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    if (t_begin < t_end) STAGE(t_begin, 0);
+    // carried source pointers for the K tiles wholly inside the first K segment (as in the ring kernel below): one 64-bit
+    // add per piece instead of the segment / tail / row selects; tiles are staged in order t_begin, t_begin + 1, ...
+    const int t_fast = min(t_end, p.K / GBK);
+    const bf16_t* fptr[PPW];
+    int fadv[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        fptr[i] = rok[i] ? base1 + (long)t_begin * GBK + off1[i] : zero;
+        fadv[i] = rok[i] ? GBK : 0;
+    }
+#define FSTAGE(BUF_)                                                                                      \
+    {                                                                                                     \
+        _Pragma("unroll") for (int i = 0; i < PPW; ++i) {                                                 \
+            bf16_t* dst_ = &lds[(BUF_)][__builtin_amdgcn_readfirstlane(ldso[i])];                         \
+            if constexpr (NTB) {                                                                          \
+                if (isA) __builtin_amdgcn_global_load_lds((gbl_vptr)fptr[i], (lds_vptr)dst_, 16, 0, 0);   \
+                else __builtin_amdgcn_global_load_lds((gbl_vptr)fptr[i], (lds_vptr)dst_, 16, 0, 2);       \
+            } else {                                                                                      \
+                __builtin_amdgcn_global_load_lds((gbl_vptr)fptr[i], (lds_vptr)dst_, 16, 0, 0);            \
+            }                                                                                             \
+            fptr[i] += fadv[i];                                                                           \
+        }                                                                                                 \
+    }
+#define XSTAGE(T_, BUF_)                                                                                  \
+    {                                                                                                     \
+        if ((T_) < t_fast) FSTAGE(BUF_) else STAGE(T_, BUF_)                                              \
+    }
+
+    if (t_begin < t_end) XSTAGE(t_begin, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     const int fr = lane & 15, fg = lane >> 4;
     for (int t = t_begin; t < t_end; ++t) {
         const int cur = (t - t_begin) & 1;
-        if (t + 1 < t_end) STAGE(t + 1, cur ^ 1);
+        if (t + 1 < t_end) XSTAGE(t + 1, cur ^ 1);
         const bf16_t* la_ = &lds[cur][0];
         const bf16_t* lb_ = &lds[cur][BM * GBK];
 #pragma unroll
@@ -181,6 +209,8 @@ __global__ __launch_bounds__(256) void gemm_bt_glds_kernel(GemmGP p) {
 }
 
 #undef STAGE
+#undef FSTAGE
+#undef XSTAGE
 
 // ------------------------------------------------------------------------------------------------------------
 // Ring variant for large problems: 256x256 tile, 8 waves (2 x 4, 128x64 per wave, two waves per SIMD), BK = 32, four
