@@ -166,18 +166,17 @@ __global__ __launch_bounds__(256) void lora_t_partial_kernel(const bf16_t* __res
     // covers whole 128-byte lines) and feeds them to two MFMAs; both operands use the same k permutation, so the sum
     // is the plain dot product.  Three steps are in flight per wave (loads of step s+2 issued before the MFMAs of s).
     Frag xf[3][MT][2], wf[3][NT][2];
+    // Full 64-wide steps are loaded WITHOUT the K-tail mask: a select on the loaded registers makes the compiler wait for the
+    // loads right after issuing them (s_waitcnt + v_cndmask ahead of the previous step's MFMAs), which serialises the pipeline.
+    // The ragged tail (K slice not a multiple of 64) is one masked, unpipelined step after the loop.
 #define RT_LOAD(B_, K0_)                                                                                   \
-    if ((K0_) < k_end) {                                                                                   \
+    {                                                                                                      \
         _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                    \
             const int k_ = (K0_) + fg * 16 + h * 8;                                                        \
-            const bool ok_ = k_ < k_end;                                                                   \
-            const int kc_ = ok_ ? k_ : 0;                                                                  \
-            _Pragma("unroll") for (int i = 0; i < MT; ++i) {                                               \
-                xf[B_][i][h].r = *reinterpret_cast<const u32x4*>(X + (long)mrow[i] * ldx + kc_);           \
-                if (!ok_) xf[B_][i][h].r = z4;                                                             \
-            }                                                                                              \
+            _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                 \
+                xf[B_][i][h].r = *reinterpret_cast<const u32x4*>(X + (long)mrow[i] * ldx + k_);            \
             _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                 \
-                wf[B_][j][h].r = *reinterpret_cast<const u32x4*>(RA + (long)(j * 16 + fr) * ldra + kc_);   \
+                wf[B_][j][h].r = *reinterpret_cast<const u32x4*>(RA + (long)(j * 16 + fr) * ldra + k_);    \
         }                                                                                                  \
     }
 #define RT_MMA(B_)                                                                                         \
@@ -185,19 +184,44 @@ __global__ __launch_bounds__(256) void lora_t_partial_kernel(const bf16_t* __res
         _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                     \
             _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                 \
                 acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[B_][j][h].f, xf[B_][i][h].f, acc[j][i], 0, 0, 0);
-    RT_LOAD(0, k_begin);
-    RT_LOAD(1, k_begin + 64);
-    for (int k0 = k_begin; k0 < k_end; k0 += 192) {
-        RT_LOAD(2, k0 + 128);
-        RT_MMA(0);
-        if (k0 + 64 < k_end) {
+    const int k_full = k_begin + ((k_end - k_begin) & ~63);       // end of the whole 64-wide steps
+    int k0 = k_begin;
+    if (k0 + 5 * 64 <= k_full) {
+        // steady state: three steps per trip, every load unconditional (a branch around a load makes the wait-count pass
+        // assume the worst at the join and wait for loads that were just issued)
+        RT_LOAD(0, k0);
+        RT_LOAD(1, k0 + 64);
+        for (; k0 + 5 * 64 <= k_full; k0 += 192) {
+            RT_LOAD(2, k0 + 128);
+            RT_MMA(0);
             RT_LOAD(0, k0 + 192);
             RT_MMA(1);
-        }
-        if (k0 + 128 < k_end) {
             RT_LOAD(1, k0 + 256);
             RT_MMA(2);
         }
+        RT_MMA(0);                                                // steps k0 and k0 + 64 are already loaded
+        RT_MMA(1);
+        k0 += 128;
+    }
+    for (; k0 < k_full; k0 += 64) {                               // at most four remaining whole steps
+        RT_LOAD(0, k0);
+        RT_MMA(0);
+    }
+    if (k_full < k_end) {                                         // masked tail step
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int k_ = k_full + fg * 16 + h * 8;
+            const bool ok_ = k_ < k_end;
+            const int kc_ = ok_ ? k_ : 0;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                xf[0][i][h].r = *reinterpret_cast<const u32x4*>(X + (long)mrow[i] * ldx + kc_);
+                if (!ok_) xf[0][i][h].r = z4;
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) wf[0][j][h].r = *reinterpret_cast<const u32x4*>(RA + (long)(j * 16 + fr) * ldra + kc_);
+        }
+        RT_MMA(0);
     }
 #undef RT_LOAD
 #undef RT_MMA
