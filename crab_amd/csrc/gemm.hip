@@ -324,29 +324,38 @@ __global__ __launch_bounds__(256) void splitk_epilogue_norm_kernel(const float* 
     __shared__ float tq[64][4];
     __shared__ float T[64];
     const int tcols = ((rt.nproj * (rt.nl + rt.r) + 15) / 16) * 16;
-    for (int c0 = 0; c0 < tcols; c0 += 16) {                 // 16 router rows per trip: 16 x MAXQ independent loads in flight
-        float p[16];
-#pragma unroll
-        for (int cc = 0; cc < 16; ++cc) p[cc] = 0.f;
-#pragma unroll
-        for (int q = 0; q < MAXQ; ++q) {
-            const int n = (tid + q * 256) * 8;
-            if (n < N) {
-                u32x4 w[16];
-#pragma unroll
-                for (int cc = 0; cc < 16; ++cc) w[cc] = *reinterpret_cast<const u32x4*>(rt.RA + (long)(c0 + cc) * rt.ldra + n);
-#pragma unroll
-                for (int cc = 0; cc < 16; ++cc) {
-                    float a = 0.f;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) a += xv[q][2 * e] * lo_bf(w[cc][e]) + xv[q][2 * e + 1] * hi_bf(w[cc][e]);
-                    p[cc] += a;
-                }
-            }
-        }
-#pragma unroll
-        for (int cc = 0; cc < 16; ++cc) tp[c0 + cc][tid] = p[cc];
+    // RPT router rows per trip, all their loads in flight together.  Every adapter of the model has nl + r = 3 + 8 = 11 rows per
+    // projection: one trip per projection reads exactly the used rows (33 of the 48 padded ones for q|k|v, 22 of 32 for gate|up);
+    // other shapes walk the padded table 16 rows at a time.
+#define ROUTE_TRIPS(RPT_, NTRIPS_)                                                                        \
+    for (int tr = 0; tr < (NTRIPS_); ++tr) {                                                              \
+        const int c0 = tr * (RPT_);                                                                       \
+        float p[RPT_];                                                                                    \
+        _Pragma("unroll") for (int cc = 0; cc < (RPT_); ++cc) p[cc] = 0.f;                                \
+        _Pragma("unroll") for (int q = 0; q < MAXQ; ++q) {                                                \
+            const int n = (tid + q * 256) * 8;                                                            \
+            if (n < N) {                                                                                  \
+                u32x4 w[RPT_];                                                                            \
+                _Pragma("unroll") for (int cc = 0; cc < (RPT_); ++cc)                                     \
+                    w[cc] = *reinterpret_cast<const u32x4*>(rt.RA + (long)(c0 + cc) * rt.ldra + n);       \
+                _Pragma("unroll") for (int cc = 0; cc < (RPT_); ++cc) {                                   \
+                    float a = 0.f;                                                                        \
+                    _Pragma("unroll") for (int e = 0; e < 4; ++e)                                         \
+                        a += xv[q][2 * e] * lo_bf(w[cc][e]) + xv[q][2 * e + 1] * hi_bf(w[cc][e]);         \
+                    p[cc] += a;                                                                           \
+                }                                                                                         \
+            }                                                                                             \
+        }                                                                                                 \
+        _Pragma("unroll") for (int cc = 0; cc < (RPT_); ++cc) tp[c0 + cc][tid] = p[cc];                   \
     }
+    const int used_rows = rt.nproj * (rt.nl + rt.r);
+    if (rt.nl + rt.r == 11) {
+        ROUTE_TRIPS(11, rt.nproj)
+        for (int c = used_rows; c < tcols; ++c) tp[c][tid] = 0.f;
+    } else {
+        ROUTE_TRIPS(16, tcols / 16)
+    }
+#undef ROUTE_TRIPS
     __syncthreads();
     if (tid < tcols * 4) {
         const int c = tid >> 2, qt = tid & 3;
