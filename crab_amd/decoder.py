@@ -165,13 +165,31 @@ class GenerationEngine:
             self._rope = ops.rope_table(n, self.cfg.head_dim, self.cfg.rope_theta, self.device)
         return self._rope
 
-    def _workspace(self, M: int, slot: int = 0) -> _Workspace:
-        """Activation buffers for M rows; `slot` separates the groups that decode concurrently on different streams."""
-        key = (M, slot) if slot else M
-        if key not in self._ws:
+    def _workspace(self, M: int, slot: int = 0, decode: bool = False) -> _Workspace:
+        """Activation buffers for M rows.
+        decode = False: ONE grow-only buffer set shared by every prefill / forward() pass (they are sequential on the stream);
+        callers slice [:M].  The prompt length varies per batch in a real evaluation, so a set per distinct M (1.7 GB at
+        35 x 702 rows) would pin tens of GB next to the KV cache over a long run.
+        decode = True: the buffers a decode state (and its captured HIP graph) keeps; `slot` separates the groups that
+        decode concurrently on different streams.  At most 4 sets are kept here (a live _DecodeState holds its own reference)."""
+        if not decode:
+            ws = self._ws.get("prefill")
+            if ws is None or ws.M < M or ws.x.device != self.device:
+                self._ws.pop("prefill", None)                 # free the smaller set before allocating the bigger one
+                ws = None
+                tc, uc = self._ws_cols()
+                self._ws["prefill"] = ws = _Workspace(self.cfg, M, self.device, tc, uc)
+            return ws
+        key = ("decode", M, slot)
+        ws = self._ws.pop(key, None)
+        if ws is None or ws.x.device != self.device:
             tc, uc = self._ws_cols()
-            self._ws[key] = _Workspace(self.cfg, M, self.device, tc, uc)
-        return self._ws[key]
+            ws = _Workspace(self.cfg, M, self.device, tc, uc)
+        self._ws[key] = ws                                    # most recently used last
+        dec_keys = [k for k in self._ws if k != "prefill"]
+        for k in dec_keys[:-4]:
+            del self._ws[k]
+        return ws
 
     def _ws_cols(self):
         tc = uc = 0
@@ -324,7 +342,7 @@ class GenerationEngine:
         V = self.lm_head.weight.shape[0]
         eos = -1 if eos_token_id is None else int(eos_token_id)
         pad = int(pad_token_id) if pad_token_id is not None else (eos if eos >= 0 else 0)
-        ws = self._workspace(B, slot)
+        ws = self._workspace(B, slot, decode=True)
         tab = self._rope_tab(Tmax)
         # The decode state (and the HIP graph captured over it) is kept per group and reused by every generate() whose shapes,
         # flags and buffers are the same: the key holds everything the captured launches bake in (pointers included).
@@ -444,7 +462,9 @@ class GenerationEngine:
             idx = torch.nonzero(all_fin)
             if idx.numel():
                 out = out_ids[:, : int(idx[0].item()) + 1]
-        res = [out]
+        # st.out_ids is the persistent, graph-baked buffer the next generate() refills: hand the caller its own tensor (HF
+        # generate returns fresh tensors; a caller that collects results over batches must not see them overwritten)
+        res = [out.clone()]
         if return_step_logits:
             res.append(torch.stack(step_logits, 1)[:, : out.shape[1]])
         if return_hidden:

@@ -140,10 +140,18 @@ class PackedLinearGroup:
         for lin in self.linears:
             lin._attach_lora()
 
-    def rebind(self, device):
-        """Move the packed buffers (used by UnifiedForCausalLM.to / .cuda) and re-point the views."""
+    def rebind(self, fn=None):
+        """Re-point the member Parameters at the packed buffers, after applying `fn` (the tensor map of nn.Module._apply:
+        a device move) to the buffers.  nn.Module._apply replaces every view Parameter with an independent tensor, which
+        would leave W / RA / B2 behind; UnifiedForCausalLM._apply calls this for every group afterwards.  A dtype change is
+        refused: the HIP path computes on bf16 storage only."""
         def mv(t):
-            return None if t is None else t.to(device)
+            if t is None or fn is None:
+                return t
+            r = fn(t)
+            if r.dtype != BF16:
+                raise TypeError("crab_amd keeps decoder weights in bfloat16: .float() / .half() / .to(dtype) are not supported")
+            return r
         self.W, self.bias, self.RA, self.B2 = mv(self.W), mv(self.bias), mv(self.RA), mv(self.B2)
         for i, lin in enumerate(self.linears):
             lin.weight = nn.Parameter(self.rows(self.W, i), requires_grad=False)

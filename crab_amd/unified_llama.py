@@ -5,8 +5,11 @@
 Differences a caller can observe, all deliberate:
   * decoding is forced greedy (the reference inherits sampling from the checkpoint's generation_config, A.7);
     `do_sample=True` raises.
-  * like the reference, `attention_mask` / `position_ids` from prepare_multimodal_inputs are NOT forwarded to the
-    decoder (unified_llama.py:261-267): left pads are attended and positions run 0..S-1 (A.1) -- reproduced.
+  * like the reference's generate(), `attention_mask` / `position_ids` from prepare_multimodal_inputs are NOT forwarded
+    to the decoder (unified_llama.py:261-267): left pads are attended and positions run 0..S-1 (A.1) -- reproduced.
+    The reference's forward() DOES pass them on (unified_llama.py:129-160, the training-time batch path); forward() here
+    implements only the unpadded case and raises NotImplementedError for a mask that contains zeros or for position_ids
+    other than 0..S-1, instead of silently attending the pads.
   * the model lives in bf16 on the GPU (the whole-model bf16 conversion of inference_hyper_lora.py:1470, A.8).
 """
 from __future__ import annotations
@@ -65,6 +68,19 @@ class UnifiedForCausalLM(nn.Module, UnifiedMetaForCausalLM):
     def _invalidate_graphs(self):
         self._engine.invalidate()
 
+    def _apply(self, fn, *args, **kwargs):
+        """.to(device) / .cuda() / .cpu(): nn.Module._apply maps every Parameter separately, which would turn the view
+        Parameters of the packed projection groups into independent copies and leave the packed operands the GEMMs read
+        behind.  Map the packed buffers themselves, re-point the views, drop captured graphs / caches.  dtype changes raise."""
+        groups = self.packed_groups()
+        packed = [(g.W, g.bias, g.RA, g.B2) for g in groups]
+        r = super()._apply(fn, *args, **kwargs)
+        for g, (W, b, RA, B2) in zip(groups, packed):
+            g.W, g.bias, g.RA, g.B2 = W, b, RA, B2             # the buffers as they were: rebind maps them once
+            g.rebind(fn)
+        self._invalidate_graphs()
+        return r
+
     def get_input_embeddings(self):
         return self.model.embed_tokens
 
@@ -122,8 +138,18 @@ class UnifiedForCausalLM(nn.Module, UnifiedMetaForCausalLM):
         if labels is not None or self.is_avs_task:
             raise NotImplementedError("training losses / AVS forward are outside the inference hot path")
         eng = self._engine
+        if attention_mask is not None and not bool(attention_mask.to(torch.bool).all()):
+            raise NotImplementedError("forward(): padded batches (attention_mask with zeros) are not implemented on the HIP path; "
+                                      "generate() reproduces the reference's mask-less behaviour (SURVEY appendix A.1)")
         if input_ids is not None and input_ids.shape[1] == 1 and past_key_values is not None:
             kc, vc, n = past_key_values
+            if n >= kc.shape[3]:
+                # the position travels as a device word (graph-friendly), so the kernels cannot check it: an append past
+                # Tmax would write into the next head's rows / past the allocation
+                raise ValueError(f"KV cache is full: position {n} >= capacity {kc.shape[3]} (the prefill call sized it as "
+                                 f"round64(S + 64)); re-run the prefill with a longer cache")
+            if position_ids is not None and not bool((position_ids.reshape(-1) == n).all()):
+                raise NotImplementedError("forward(): position_ids other than the cache length are not implemented")
             B = input_ids.shape[0]
             emb = self.model.embed_tokens(input_ids.reshape(-1))
             ws = eng._workspace(B)
@@ -137,10 +163,15 @@ class UnifiedForCausalLM(nn.Module, UnifiedMetaForCausalLM):
             inputs = self.prepare_multimodal_inputs(batch_input_ids=batch_input_ids, batch_labels=batch_labels,
                                                     batch_X_modals=batch_X_modals, batch_task_names=batch_task_names)
             inputs_embeds = inputs['inputs_embeds']
+            if not bool(inputs['attention_mask'].to(torch.bool).all()):      # ragged batch: the reference masks the left pads here
+                raise NotImplementedError("forward(): ragged batches need the left-pad attention mask, which the HIP prefill does "
+                                          "not implement; call forward() per sample or use generate()")
         elif inputs_embeds is None and input_ids is not None:
             inputs_embeds = self.model.embed_tokens(input_ids)
         inputs_embeds = inputs_embeds.to(device=self.device, dtype=BF16)
         B, S, _ = inputs_embeds.shape
+        if position_ids is not None and not bool((position_ids.reshape(-1, S).cpu() == torch.arange(S)).all()):
+            raise NotImplementedError("forward(): position_ids other than 0..S-1 are not implemented")
         Tmax = (S + 64 + 63) // 64 * 64 if use_cache else (S + 63) // 64 * 64
         kc, vc = eng.alloc_cache(B, Tmax)
         logits, hn = eng.prefill(inputs_embeds, kc, vc, all_logits=True)

@@ -1,0 +1,61 @@
+"""Host-side logic that needs no GPU: packed projection groups stay consistent under nn.Module._apply, forward() refuses
+what the HIP path does not implement, results of generate() do not alias engine state."""
+import pytest
+import torch
+
+from crab_amd.peft_hyper import LoraConfig, PackedLinearGroup, get_peft_model
+from crab_amd.unified_llama import UnifiedConfig, UnifiedForCausalLM
+
+
+def _tiny(device="cpu"):
+    cfg = UnifiedConfig(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4, vocab_size=96, pad_token_id=2)
+    return get_peft_model(UnifiedForCausalLM(cfg, device=device), LoraConfig())
+
+
+def test_packed_group_views_alias_the_packed_buffers():
+    g = PackedLinearGroup(["gate_proj", "up_proj"], 16, [8, 8], False, "cpu", interleave=True)
+    g.attach_lora(8, 16, 3)
+    g.linears[1].weight.data.fill_(3.0)
+    assert float(g.W[1::2].min()) == 3.0 and float(g.W[0::2].abs().max()) == 0.0
+    g.linears[0].lora_B1.weight.data.fill_(2.0)
+    assert float(g.B2[0::2, 8:16].min()) == 2.0 and float(g.B2[1::2].abs().max()) == 0.0
+
+
+def test_module_apply_keeps_views_bound_and_refuses_dtype_changes():
+    model = _tiny()
+    um = model.base_model.model
+    g = um.model.layers[0].self_attn._qkv
+    g.W.normal_()
+    before = g.W.clone()
+    model.to("cpu")                                              # nn.Module._apply with an identity map
+    g2 = um.model.layers[0].self_attn._qkv
+    assert torch.equal(g2.W, before)
+    q = um.model.layers[0].self_attn.q_proj
+    assert q.weight.data_ptr() == g2.W.data_ptr()                # still a view: a later load_state_dict fills the packed operand
+    q.weight.data.zero_()
+    assert float(g2.W[: q.out_features].abs().max()) == 0.0
+    assert q.lora_A.weight.data_ptr() == g2.RA[g2.nl:].data_ptr()
+    with pytest.raises(TypeError):
+        model.float()
+
+
+def test_state_dict_round_trip_through_views():
+    a, b = _tiny(), _tiny()
+    for p in a.parameters():
+        p.data.normal_()
+    r = b.load_state_dict(a.state_dict(), strict=True)
+    assert not r.missing_keys and not r.unexpected_keys
+    ga, gb = a.base_model.model.model.layers[1].mlp._gu, b.base_model.model.model.layers[1].mlp._gu
+    assert torch.equal(ga.W, gb.W) and torch.equal(ga.RA, gb.RA) and torch.equal(ga.B2, gb.B2)
+
+
+def test_forward_refuses_padded_batches_and_full_cache():
+    um = _tiny().base_model.model
+    emb = torch.zeros(2, 5, 64)
+    mask = torch.ones(2, 5, dtype=torch.long)
+    mask[1, :2] = 0
+    with pytest.raises(NotImplementedError):
+        um(inputs_embeds=emb, attention_mask=mask)
+    kc = torch.zeros(2, 1, 4, 64, 16)
+    with pytest.raises(ValueError, match="KV cache is full"):
+        um(input_ids=torch.zeros(1, 1, dtype=torch.long), past_key_values=(kc, kc.clone(), 64))
