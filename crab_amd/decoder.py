@@ -240,7 +240,10 @@ class GenerationEngine:
         key = (slot,)
         hit = self._kv.get(key)
         if hit is None or hit[0].shape != shape or hit[0].device != self.device:
-            self._kv.pop(key, None)                  # drop the old buffers before allocating the new shape
+            self._kv.pop(key, None)                  # drop the old buffers before allocating the new shape ...
+            hit = None
+            if self._dec.pop(slot, None) is not None:    # ... and the decode state (+ graph) that still references them: at
+                torch.cuda.empty_cache()                 # 256 clips the old and new caches (2 x ~65 GB each) do not fit together
             self._kv[key] = (torch.empty(shape, device=self.device, dtype=BF16), torch.empty(shape, device=self.device, dtype=BF16))
         return self._kv[key]
 

@@ -1,0 +1,35 @@
+"""bench.py's launch contract: `--gpus N` must agree with the ranks that exist; without a launcher it starts them itself."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def test_gpus_flag_must_match_world_size():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "--gpus 2" in r.stderr and "WORLD_SIZE=1" in r.stderr
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_self_spawns_two_ranks_on_one_device():
+    """`python bench.py --gpus 2` with no launcher: two ranks (both mapped to cuda:0 by the rehearsal hook, gloo in place of
+    RCCL because one device cannot host two RCCL ranks), per-clip sharding, barrier + max-over-ranks timing, gather to rank 0,
+    one JSON line from rank 0 with n_gpus = 2 and the gathered clip count."""
+    env = dict(os.environ, CRAB_BENCH_SINGLE_DEVICE="1", CRAB_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--clips", "2", "--new-tokens", "4", "--steps", "1", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-operating-points"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["world_size_observed"] == 2 and j["scaling"] == "weak"
+    assert j["config"]["clips_per_gpu_per_step"] == 2 and j["value"] > 0
+    assert abs(j["value"] - 2 * 2 * 1 / (j["ms_per_step"] * 1e-3)) < 1e-2 * j["value"]     # value = clips of ALL ranks / max-over-ranks time
