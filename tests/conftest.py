@@ -20,3 +20,13 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if "gpu" in it.keywords:
             it.add_marker(skip)
+
+
+def pytest_sessionstart(session):
+    import torch
+    if torch.cuda.is_available() and not os.environ.get("PYTEST_XDIST_WORKER"):
+        from tests.util import PARITY_REPORT
+        try:
+            os.remove(PARITY_REPORT)
+        except OSError:
+            pass

@@ -20,11 +20,9 @@ REL_EMU = 2.5e-2
 REL_F32 = 4e-2
 
 
-def _rel(got, ref):
-    got, ref = got.float().cpu(), ref.float().cpu()
-    assert got.shape == ref.shape, (got.shape, ref.shape)
-    assert torch.isfinite(got).all()
-    return (got - ref).abs().max().item() / (ref.abs().max().item() + 1e-9)
+def _rel(got, ref, what=""):
+    from tests.util import rel_err
+    return rel_err(got, ref, what)
 
 
 def _bf(W):
@@ -46,8 +44,8 @@ def test_clip_tower_vs_reference_fixture_and_oracle():
     cfg = O.ClipConfig(**meta["cfg"], select_layers=tuple(meta["select"]))
     emu = O.visual_encoder(video.to(BF).float(), _bf(W), cfg, emulate=BF)
     for i in range(3):
-        assert _rel(feats[i], A[f"f{i}"]) < REL_F32, f"level {i} vs reference"
-        assert _rel(feats[i], emu[i]) < REL_EMU, f"level {i} vs bf16-emulating oracle"
+        assert _rel(feats[i], A[f"f{i}"], f"clip_tiny level {i} vs fp32 reference") < REL_F32, f"level {i} vs reference"
+        assert _rel(feats[i], emu[i], f"clip_tiny level {i} vs bf16-emulating oracle") < REL_EMU, f"level {i} vs bf16-emulating oracle"
 
 
 def test_beats_vs_reference_fixture_and_oracle():
@@ -64,8 +62,8 @@ def test_beats_vs_reference_fixture_and_oracle():
     for L in (98, 198):
         x = A[f"x{L}"]
         y = ae(ops.cast_bf16(x.cuda()))
-        assert _rel(y, A[f"y{L}"]) < REL_F32, f"L={L} vs reference"
-        assert _rel(y, O.beats(x.to(BF).float(), _bf(W), cfg, emulate=BF)) < REL_EMU, f"L={L} vs emulating oracle"
+        assert _rel(y, A[f"y{L}"], f"beats_tiny L={L} vs fp32 reference") < REL_F32, f"L={L} vs reference"
+        assert _rel(y, O.beats(x.to(BF).float(), _bf(W), cfg, emulate=BF), f"beats_tiny L={L} vs bf16-emulating oracle") < REL_EMU, f"L={L} vs emulating oracle"
 
 
 def test_projectors_vs_reference_fixture():
@@ -77,12 +75,12 @@ def test_projectors_vs_reference_fixture():
                      depth=2, bert_config=bc, device="cuda")
     r = vl.load_state_dict({k[len("model.vl_projector."):]: v for k, v in W.items() if k.startswith("model.vl_projector.")}, strict=False)
     assert not r.missing_keys, r.missing_keys
-    assert _rel(vl(A["vfeat"].to(BF).cuda()), A["vout"]) < REL_F32
+    assert _rel(vl(A["vfeat"].to(BF).cuda()), A["vout"], "VLProjector vs fp32 reference") < REL_F32
     al = ALProjector(hidden_size=128, num_query_token=32, num_hidden_layers=2, d_model=meta["d_model"], depth=2, bert_config=bc,
                      device="cuda")
     r = al.load_state_dict({k[len("model.al_projector."):]: v for k, v in W.items() if k.startswith("model.al_projector.")}, strict=False)
     assert not r.missing_keys, r.missing_keys
-    assert _rel(al(A["afeat"].to(BF).cuda()), A["aout"]) < REL_F32
+    assert _rel(al(A["afeat"].to(BF).cuda()), A["aout"], "ALProjector vs fp32 reference") < REL_F32
 
 
 def _inputs(meta):
@@ -112,11 +110,18 @@ def _check_ids(ids, ref_ids, ref_logits, got_logits):
                 break          # legitimately diverged at a sub-noise margin: later steps see different contexts
             checked += 1
     assert checked >= 0.5 * total, f"greedy-id parity covered only {checked}/{total} steps"
+    from tests.util import record_parity
+    record_parity("greedy per-step last-row logits, worst step", worst, ref_logits.abs().max().item(), None, steps_checked=checked, steps_total=total,
+                  min_ref_margin=float(margin.min()))
     return worst
 
 
-def test_full_tiny_llama_generate_matches_reference():
-    meta, A = load_fixture("full_tiny_llama")
+@pytest.mark.parametrize("fixture", ["full_tiny_llama", "full_tiny_qwen"])
+def test_full_tiny_generate_matches_reference(fixture):
+    """encoders -> prepare_multimodal_inputs -> hyper-LoRA decoder -> greedy ids against the reference-recorded fixture:
+    full_tiny_llama = models/unified_llama.py (BASELINE configs[1]); full_tiny_qwen = the class the reference's eval script selects,
+    models/unified_qwen.py over Qwen2 (GQA 4/2, q/k/v bias, projector width 256 != encoder width; BASELINE configs[2])."""
+    meta, A = load_fixture(fixture)
     W = weights_from_table(meta)
     model = build_tiny_crab(meta)
     r = model.load_state_dict(W, strict=False)
@@ -125,15 +130,15 @@ def test_full_tiny_llama_generate_matches_reference():
     mods = _inputs(meta)
     lab = [torch.full_like(A["ids0"], -100), torch.full_like(A["ids1"], -100)]
     inp1 = model.prepare_multimodal_inputs([A["ids0"]], [lab[0]], [mods[0]], ['avqa'])
-    assert _rel(inp1["inputs_embeds"], A["embeds_bs1"]) < REL_F32
+    assert _rel(inp1["inputs_embeds"], A["embeds_bs1"], f"{fixture}: inputs_embeds bs1 (encoders + projectors + splice)") < REL_F32
     inp2 = model.prepare_multimodal_inputs([A["ids0"], A["ids1"]], lab, mods, ['avqa', 'avqa'])
-    assert _rel(inp2["inputs_embeds"], A["embeds_bs2"]) < REL_F32
+    assert _rel(inp2["inputs_embeds"], A["embeds_bs2"], f"{fixture}: inputs_embeds left-padded bs2") < REL_F32
     assert torch.equal(inp2["position_ids"].cpu().long(), A["pos_bs2"].long())
     assert torch.equal(inp2["attention_mask"].cpu().long(), A["mask_bs2"].long())
     # prefill, all rows (LlamaForCausalLM.forward)
     out = model.base_model.model(inputs_embeds=A["embeds_bs1"].to(BF).cuda(), output_hidden_states=True)
-    assert _rel(out.logits, A["prefill_logits_bs1"]) < REL_F32
-    assert _rel(out.hidden_states[-1], A["prefill_hidden_bs1"]) < REL_F32
+    assert _rel(out.logits, A["prefill_logits_bs1"], f"{fixture}: prefill logits, all rows") < REL_F32
+    assert _rel(out.hidden_states[-1], A["prefill_hidden_bs1"], f"{fixture}: post-norm hidden, all rows") < REL_F32
     # generate: public API, bs=1 and left-padded bs=2, graph replay and plain launches must agree bit for bit
     n = meta["new_tokens"]
     kw = dict(use_cache=True, max_new_tokens=n, do_sample=False, pad_token_id=2, eos_token_id=None,
@@ -214,9 +219,9 @@ def test_seg_module_vs_reference_fixture_and_oracle():
     assert tuple(out[0].shape) == (71, 224, 224) and tuple(out[1].shape) == (1, 224, 224)
     ref = O.seg_module(pred.to(BF).float(), [f.to(BF).float() for f in feats], meta["tasks"], _bf(W))
     for i in range(2):
-        assert _rel(out[i], ref[i]) < 6e-2, f"sample {i} vs oracle on bf16-rounded weights"
-    assert _rel(out[0][:, 3::8, 5::8], A["avss_sub"]) < 8e-2
-    assert _rel(out[1][:, 1::2, ::2], A["s4_sub"]) < 8e-2
+        assert _rel(out[i], ref[i], f"SegModule sample {i} vs oracle on bf16-rounded weights") < 6e-2, f"sample {i} vs oracle on bf16-rounded weights"
+    assert _rel(out[0][:, 3::8, 5::8], A["avss_sub"], "SegModule avss vs fp32 reference") < 8e-2
+    assert _rel(out[1][:, 1::2, ::2], A["s4_sub"], "SegModule s4 vs fp32 reference") < 8e-2
 
 
 def test_generate_avs_pipeline_vs_oracle():
@@ -272,8 +277,16 @@ def test_generate_avs_pipeline_vs_oracle():
     assert len(picks) == 6
     feats = O.visual_encoder(image[None].to(BF).float(), Wo, ocfg.clip)
     ref = O.seg_module(torch.stack([ohid[:, j] for j in picks], 1), feats[:2], ['s4'], Wo)
-    if torch.equal(oids, plain):                   # identical contexts -> the masks are comparable
-        assert _rel(res['pred_masks'][0], ref[0]) < 1e-1
+    if not torch.equal(oids, plain):
+        # the ids may only diverge at a step whose oracle top-2 margin is below the bf16 logit noise; a super-margin divergence is a
+        # failure, not a reason to skip the mask comparison
+        _, olog, _ = O.greedy_generate(inp["inputs_embeds"], Wo, ocfg.decoder, n, pad_token_id=2, return_hidden=True)
+        j = int((oids[0] != plain[0]).nonzero()[0])
+        top2 = olog[0, j].topk(2).values
+        assert float(top2[0] - top2[1]) < 0.1 * float(olog.abs().max()), f"generate_avs ids diverge from the oracle at step {j} at a super-margin step"
+        pytest.skip(f"ids diverge at sub-margin step {j}: masks are not comparable")
+    else:
+        assert _rel(res['pred_masks'][0], ref[0], "generate_avs masks vs oracle pipeline") < 1e-1
 
 
 def test_generate_many_clips_vs_oracle():
@@ -357,7 +370,7 @@ def test_llama_ops_fixture_rmsnorm_rope_layer_prefill():
     # RMSNorm (bf16 in / out against the fp32 reference)
     x = A["norm_x"].reshape(-1, c["hidden_size"]).to(BF).cuda()
     y = ops.rmsnorm(x, A["norm_w"].to(BF).cuda(), c["rms_norm_eps"])
-    assert _rel(y, A["norm_y"].reshape(-1, c["hidden_size"])) < 1.2e-2
+    assert _rel(y, A["norm_y"].reshape(-1, c["hidden_size"]), "llama_ops: rmsnorm") < 1.2e-2
     # RoPE: rows at positions 0..3 as one sequence, then the rows at 9, 17, 40 one by one (pos0 = absolute position)
     H, d = c["num_attention_heads"], 64
     tab = ops.rope_table(64, d, c["rope_theta"], "cuda")
@@ -372,24 +385,68 @@ def test_llama_ops_fixture_rmsnorm_rope_layer_prefill():
         ops.qkv_rope_split(qkv, tab, kc, vc, None, 1, S, H, H, d, 64, pos0=pos0)
         got_q = qkv[:, :H * d].reshape(S, H, d).transpose(0, 1)
         got_k = kc[0, :, pos0:pos0 + S]
-        assert _rel(got_q, A["rope_q_out"][0][:, rows]) < 1.2e-2
-        assert _rel(got_k, A["rope_k_out"][0][:, rows]) < 1.2e-2
+        assert _rel(got_q, A["rope_q_out"][0][:, rows], "llama_ops: rope q") < 1.2e-2
+        assert _rel(got_k, A["rope_k_out"][0][:, rows], "llama_ops: rope k") < 1.2e-2
 
     run([0, 1, 2, 3], 0)
     for r in (4, 5, 6):
         run([r], pos[r])
-    # one decoder layer, prefill
-    cfg = UnifiedConfig(num_hidden_layers=1, vocab_size=320, pad_token_id=2, **c)
-    model = get_peft_model(UnifiedForCausalLM(cfg, device="cuda"), LoraConfig())
+    _layer_prefill_and_decode_step("llama_ops", False)
+
+
+def _layer_prefill_and_decode_step(fixture, qwen):
+    """One hyper-LoRA decoder layer of the reference's vendored modeling file, run through the engine as a prefill of S rows and then
+    as a 1-token decode step against the cache the prefill filled (layer output = residual stream before the final norm; K / V rows)."""
+    from crab_amd import ops
+    from crab_amd.peft_hyper import LoraConfig, get_peft_model
+    meta, A = load_fixture(fixture)
+    c = dict(meta["cfg"])
+    if qwen:
+        from crab_amd.unified_qwen import UnifiedConfig, UnifiedForCausalLM
+        c.update(attention_bias=True)
+    else:
+        from crab_amd.unified_llama import UnifiedConfig, UnifiedForCausalLM
+    c.update(num_hidden_layers=1, vocab_size=320, pad_token_id=2)
+    model = get_peft_model(UnifiedForCausalLM(UnifiedConfig(**c), device="cuda"), LoraConfig())
     W = {"base_model.model." + k_: v for k_, v in weights_from_table(meta).items()}
     r = model.load_state_dict(W, strict=False)
     assert not r.unexpected_keys, r.unexpected_keys[:5]
     um = model.base_model.model
     eng = um._engine
-    S = A["layer_x"].shape[1]
+    S, D = A["layer_x"].shape[1], A["layer_x"].shape[2]
     kc, vc = eng.alloc_cache(1, 64)
     eng.prefill(A["layer_x"].to(BF).cuda(), kc, vc, b0=0)
     ws = eng._workspace(S)
-    assert _rel(ws.x[:S], A["layer_y"][0]) < REL_F32
-    assert _rel(kc[0, 0, :, :S], A["cache_k"][0][:, :S]) < 1.2e-2
-    assert _rel(vc[0, 0, :, :S], A["cache_v"][0][:, :S]) < 1.2e-2
+    assert _rel(ws.x[:S], A["layer_y"][0], f"{fixture}: layer output, prefill") < REL_F32
+    assert _rel(kc[0, 0, :, :S], A["cache_k"][0][:, :S], f"{fixture}: K cache rows, prefill") < 1.2e-2
+    assert _rel(vc[0, 0, :, :S], A["cache_v"][0][:, :S], f"{fixture}: V cache rows, prefill") < 1.2e-2
+    # the decode row: position S, device-resident position word, KV append fused behind the q|k|v projection
+    ops.copy_rows(A["layer_x1"][0].to(BF).cuda(), ws.x, 1, D)
+    pos = torch.full((1,), S, device="cuda", dtype=torch.int32)
+    x, _ = eng._layers(ws, 1, 1, kc, vc, 0, 64, 0, pos, None)
+    assert _rel(x[:1], A["layer_y1"][0], f"{fixture}: layer output, 1-token decode step") < REL_F32
+    assert _rel(kc[0, 0, :, S], A["cache_k"][0][:, S], f"{fixture}: K cache row, decode step") < 1.2e-2
+    assert _rel(vc[0, 0, :, S], A["cache_v"][0][:, S], f"{fixture}: V cache row, decode step") < 1.2e-2
+
+
+def test_qwen_ops_fixture_rmsnorm_rope_layer_prefill_and_decode():
+    """tests/golden/qwen_ops.npz (the reference's vendored models/qwen/modeling_qwen2.py): RMSNorm at eps 1e-6, RoPE at theta 1e6 up to
+    position 1400, one hyper-LoRA Qwen2 layer (GQA 4/2, q/k/v bias) as prefill + decode step."""
+    from crab_amd import ops
+    meta, A = load_fixture("qwen_ops")
+    c = meta["cfg"]
+    D, H, Hk = c["hidden_size"], c["num_attention_heads"], c["num_key_value_heads"]
+    d = D // H
+    x = A["norm_x"].reshape(-1, D).to(BF).cuda()
+    y = ops.rmsnorm(x, A["norm_w"].to(BF).cuda(), c["rms_norm_eps"])
+    assert _rel(y, A["norm_y"].reshape(-1, D), "qwen_ops: rmsnorm") < 1.2e-2
+    tab = ops.rope_table(1408, d, c["rope_theta"], "cuda")
+    q, k, pos = A["rope_q"], A["rope_k"], A["rope_pos"][0].tolist()
+    for r_ in range(len(pos)):
+        qkv = torch.cat([q[0, :, r_].reshape(1, H * d), k[0, :, r_].reshape(1, Hk * d), torch.zeros(1, Hk * d)], dim=1).to(BF).cuda().contiguous()
+        kc = torch.zeros(1, Hk, 1408, d, device="cuda", dtype=BF)
+        vc = torch.zeros_like(kc)
+        ops.qkv_rope_split(qkv, tab, kc, vc, None, 1, 1, H, Hk, d, 1408, pos0=pos[r_])
+        assert _rel(qkv[:, :H * d].reshape(H, d), A["rope_q_out"][0][:, r_], f"qwen_ops: rope q @ {pos[r_]}") < 1.2e-2
+        assert _rel(kc[0, :, pos[r_]], A["rope_k_out"][0][:, r_], f"qwen_ops: rope k @ {pos[r_]}") < 1.2e-2
+    _layer_prefill_and_decode_step("qwen_ops", True)

@@ -21,13 +21,9 @@ def _rand(*shape, seed=0, scale=1.0):
 
 
 def _cmp(got, ref, rel=2e-2, what=""):
-    got = got.float().cpu()
-    ref = ref.float()
-    assert got.shape == ref.shape, (got.shape, ref.shape)
-    assert torch.isfinite(got).all(), f"{what}: non-finite output"
-    err = (got - ref).abs().max().item()
-    scale = ref.abs().max().item() + 1e-6
-    assert err <= rel * scale, f"{what}: max err {err:.4g} vs scale {scale:.4g}"
+    from tests.util import rel_err
+    r = rel_err(got, ref, what, rel)
+    assert r <= rel, f"{what}: relative max err {r:.4g} > {rel:.4g}"
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (16, 16, 32), (130, 200, 72), (702, 512, 1024), (257, 136, 592),
@@ -239,6 +235,38 @@ def test_rope_split_and_decode_attention(hd, H, Hk):
     qn = q1d[:, :H * hd].cpu().view(B, 1, H, hd).transpose(1, 2)
     ref = _attn_ref(qn, kc[:, :, :S + 1].cpu(), vc[:, :, :S + 1].cpu(), hd ** -0.5).transpose(1, 2).reshape(B, H * hd)
     _cmp(o, ref, 1.5e-2, "decode attention")
+
+
+@pytest.mark.parametrize("ctx", [702, 830, 958])
+def test_decode_attention_mha_benchmark_regime(ctx):
+    """attn_decode_kernel<128> exactly as bench.py launches it (the dominant kernel of the benchmark): B = 256 clips, H = Hk = 32,
+    head_dim 128, Tmax = 960, live context read from the device position word; EVERY (clip, head) row against fp32 arithmetic on the
+    same bf16 K / V / q.  Cache rows at and beyond the live context are poisoned: reading one would move the result by orders of
+    magnitude."""
+    from crab_amd import ops
+    B, H, hd, Tmax = 256, 32, 128, 960
+    g = torch.Generator(device="cuda").manual_seed(1000 + ctx)
+    kc = torch.empty(B, H, Tmax, hd, device="cuda", dtype=BF)
+    vc = torch.empty_like(kc)
+    for b0 in range(0, B, 32):                              # generated in slices: the fp32 temporaries stay small
+        kc[b0:b0 + 32] = (torch.randn(32, H, Tmax, hd, device="cuda", generator=g) * 0.7).to(BF)
+        vc[b0:b0 + 32] = (torch.randn(32, H, Tmax, hd, device="cuda", generator=g) * 0.7).to(BF)
+    kc[:, :, ctx:] = 3.0e4
+    vc[:, :, ctx:] = -3.0e4
+    q = (torch.randn(B, 3 * H * hd, device="cuda", generator=g) * 1.5).to(BF)      # packed q|k|v row, as the decode step passes it
+    pos = torch.tensor([ctx - 1], dtype=torch.int32, device="cuda")               # position of the newest token: ctx live rows
+    o = torch.zeros(B, H * hd, dtype=BF, device="cuda")
+    ops.attn_decode(q, kc, vc, o, B, H, H, hd, Tmax, 1, hd ** -0.5, ctx_dev=pos)
+    ref = torch.empty(B, H * hd, dtype=torch.float32, device="cuda")
+    for b0 in range(0, B, 32):
+        qf = q[b0:b0 + 32, :H * hd].float().view(32, H, 1, hd)
+        a = torch.matmul(qf, kc[b0:b0 + 32, :, :ctx].float().transpose(2, 3)) * hd ** -0.5
+        ref[b0:b0 + 32] = torch.matmul(torch.softmax(a, -1), vc[b0:b0 + 32, :, :ctx].float()).reshape(32, H * hd)
+    _cmp(o, ref.cpu(), 1.5e-2, f"decode attention MHA, B=256 H=32 ctx={ctx} (bench regime)")
+    # determinism of the launch the benchmark replays from its HIP graph
+    o2 = torch.zeros_like(o)
+    ops.attn_decode(q, kc, vc, o2, B, H, H, hd, Tmax, 1, hd ** -0.5, ctx_dev=pos)
+    assert torch.equal(o, o2)
 
 
 @pytest.mark.parametrize("G,ctx", [(7, 830), (7, 1100), (4, 333), (2, 64), (8, 1025)])

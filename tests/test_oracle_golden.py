@@ -207,3 +207,57 @@ def test_llama_ops_rmsnorm_rope_layer_prefill_and_decode():
     _close(y1, A["layer_y1"], 1e-4)
     _close(cache.k[0], A["cache_k"], 1e-5)
     _close(cache.v[0], A["cache_v"], 1e-5)
+
+
+def test_qwen_ops_rmsnorm_rope_layer_prefill_and_decode():
+    """Fixture from the reference's vendored models/qwen/modeling_qwen2.py: Qwen2RMSNorm, rotary embedding at theta = 1e6 (positions up to
+    1400), one hyper-LoRA Qwen2DecoderLayer (GQA 4/2, q/k/v bias) as prefill and as a 1-token decode step against its cache."""
+    meta, A = load_fixture("qwen_ops")
+    c = meta["cfg"]
+    d = c["hidden_size"] // c["num_attention_heads"]
+    _close(O.rmsnorm(A["norm_x"], A["norm_w"], c["rms_norm_eps"]), A["norm_y"], 1e-5)
+    cos, sin = O.rope_cos_sin(A["rope_pos"], d, c["rope_theta"])
+    q, k = O.apply_rope(A["rope_q"], A["rope_k"], cos, sin)
+    _close(q, A["rope_q_out"], 1e-5)
+    _close(k, A["rope_k_out"], 1e-5)
+    W = weights_from_table(meta)
+    assert "model.layers.0.self_attn.q_proj.bias" in W and "model.layers.0.self_attn.o_proj.bias" not in W
+    cfg = O.DecoderConfig(**{**c, "num_hidden_layers": 1})
+    cache = O.KVCache()
+    S = A["layer_x"].shape[1]
+    y = O.decoder_layer(A["layer_x"], W, 0, cfg, cache, torch.arange(S)[None])
+    _close(y, A["layer_y"], 1e-4)
+    y1 = O.decoder_layer(A["layer_x1"], W, 0, cfg, cache, torch.tensor([[S]]))
+    _close(y1, A["layer_y1"], 1e-4)
+    _close(cache.k[0], A["cache_k"], 1e-5)
+    _close(cache.v[0], A["cache_v"], 1e-5)
+
+
+def test_full_tiny_qwen_prepare_and_generate():
+    """BASELINE configs[2] end to end (encoders -> prepare_multimodal_inputs -> hyper-LoRA Qwen2 decoder at d_model 256) recorded from the
+    reference's models/unified_qwen.py class; the generator also required the in-tree modeling_qwen2.py stack to reproduce the same
+    prefill logits (meta.intree_vs_hf_prefill_max_abs)."""
+    meta, A = load_fixture("full_tiny_qwen")
+    assert meta["intree_vs_hf_prefill_max_abs"] < 2e-4
+    _close(A["prefill_logits_intree_bs1"], A["prefill_logits_bs1"], 2e-4)
+    W = O.strip_peft_prefix(weights_from_table(meta))
+    cfg = _full_cfg(meta)
+    assert cfg.decoder.num_key_value_heads == 2 and cfg.decoder.hidden_size == 256
+    mods = _full_inputs(meta)
+    assert O.special_token_table(meta["base_vocab"]) == meta["special"]
+    inp1 = O.prepare_multimodal_inputs([A["ids0"]], [mods[0]], W, cfg)
+    _close(inp1["inputs_embeds"], A["embeds_bs1"], 5e-4)
+    inp2 = O.prepare_multimodal_inputs([A["ids0"], A["ids1"]], mods, W, cfg)
+    _close(inp2["inputs_embeds"], A["embeds_bs2"], 5e-4)
+    assert torch.equal(inp2["position_ids"].long(), A["pos_bs2"].long())
+    assert torch.equal(inp2["attention_mask"].long(), A["mask_bs2"].long())
+    logits, hn, _ = O.decoder_forward(A["embeds_bs1"], W, cfg.decoder)
+    _close(logits, A["prefill_logits_bs1"], 5e-4)
+    _close(hn, A["prefill_hidden_bs1"], 5e-4)
+    n = meta["new_tokens"]
+    ids, sl = O.generate([A["ids0"]], [mods[0]], W, cfg, n)
+    assert torch.equal(ids, A["ids_bs1"])
+    _close(sl, A["logits_bs1"], 1e-3)
+    ids, sl = O.generate([A["ids0"], A["ids1"]], mods, W, cfg, n)
+    assert torch.equal(ids, A["ids_bs2"])
+    _close(sl, A["logits_bs2"], 1e-3)

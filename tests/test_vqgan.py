@@ -34,8 +34,9 @@ def test_vqgan_oracle_matches_reference_fixture():
     assert torch.equal(VO.decode_mask(shifted, Wv, cfg, 32020), dec)
 
 
-def _rel(a, b):
-    return (a.float().cpu() - b.float().cpu()).abs().max().item() / (b.float().abs().max().item() + 1e-9)
+def _rel(a, b, what=""):
+    from tests.util import rel_err
+    return rel_err(a, b, what)
 
 
 @pytest.mark.gpu

@@ -11,6 +11,40 @@ import torch
 from crab_amd import synth
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# every GPU parity comparison appends {test, what, max_abs, scale, rel, tol} here (gpurun merges gpurun_out/ back; the copy the
+# tolerances were set from is committed as profiles/r02_parity_report.json).  The file is reset at session start (conftest.py).
+PARITY_REPORT = os.environ.get("CRAB_PARITY_REPORT", os.path.join(ROOT, "gpurun_out", "parity_report.json"))
+
+
+def record_parity(what: str, max_abs: float, scale: float, tol=None, **extra):
+    """Append one measured error to the parity report; never raises (a read-only tree must not fail a parity test)."""
+    try:
+        test = os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0]
+        row = {"test": test, "what": what, "max_abs": float(max_abs), "scale": float(scale),
+               "rel": float(max_abs) / (float(scale) + 1e-30), "tol_rel": tol}
+        row.update(extra)
+        os.makedirs(os.path.dirname(PARITY_REPORT), exist_ok=True)
+        rows = []
+        if os.path.exists(PARITY_REPORT):
+            with open(PARITY_REPORT) as f:
+                rows = json.load(f)
+        rows.append(row)
+        with open(PARITY_REPORT, "w") as f:
+            json.dump(rows, f, indent=0)
+    except Exception:
+        pass
+
+
+def rel_err(got: torch.Tensor, ref: torch.Tensor, what: str = "", tol=None) -> float:
+    """max |got - ref| / max |ref| (shapes must match, got must be finite); recorded in the parity report."""
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    assert torch.isfinite(got).all(), f"{what}: non-finite output"
+    err = (got - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    record_parity(what, err, scale, tol)
+    return err / (scale + 1e-9)
 
 
 def load_fixture(name: str) -> Tuple[dict, Dict[str, torch.Tensor]]:
@@ -62,10 +96,15 @@ def bert_cfg(qf: dict) -> dict:
 
 
 def build_tiny_crab(meta: dict, device="cuda"):
-    """The product model at the fixture's tiny configuration, wrapped like scripts/quick_start.py:465-529 does."""
+    """The product model at the fixture's tiny configuration, wrapped like scripts/quick_start.py:465-529 does
+    (models.unified_qwen classes when the fixture says qkv_bias, as inference_hyper_lora.py:1326-1335 selects them)."""
     from crab_amd.peft_hyper import LoraConfig, get_peft_model
-    from crab_amd.unified_llama import UnifiedConfig, UnifiedForCausalLM
-    cfg = UnifiedConfig(**meta["dec"], pad_token_id=meta["pad_token_id"])
+    if meta.get("qkv_bias"):
+        from crab_amd.unified_qwen import UnifiedConfig, UnifiedForCausalLM
+        cfg = UnifiedConfig(**meta["dec"], attention_bias=True, pad_token_id=meta["pad_token_id"])
+    else:
+        from crab_amd.unified_llama import UnifiedConfig, UnifiedForCausalLM
+        cfg = UnifiedConfig(**meta["dec"], pad_token_id=meta["pad_token_id"])
     cfg.vocab_size = meta["base_vocab"]
     model = get_peft_model(UnifiedForCausalLM(cfg, device=device), LoraConfig())
     model.get_model().pad_token_id = meta["pad_token_id"]
