@@ -41,6 +41,16 @@ def _r(x: Tensor, emulate) -> Tensor:
     return x.to(emulate).to(torch.float32)
 
 
+# Measurement knob (scripts/exp/fp32_residual_emulation.py): with emulate=bfloat16, keep the decoder's RESIDUAL
+# STREAM in fp32 (every other storage point still rounds).  Quantifies how close a bf16-storage execution with an fp32
+# residual stream would get to the fp32 reference.
+EMULATE_FP32_RESIDUAL = False
+
+
+def _rres(x: Tensor, emulate) -> Tensor:
+    return x if EMULATE_FP32_RESIDUAL else _r(x, emulate)
+
+
 def strip_peft_prefix(sd: WDict) -> WDict:
     """finetune_weights.bin keys carry PEFT's `base_model.model.` prefix."""
     out = {}
@@ -187,13 +197,13 @@ def decoder_layer(x: Tensor, W: WDict, i: int, cfg: DecoderConfig, cache: KVCach
     pr = torch.softmax(a.float(), dim=-1)                                      # :431 fp32 softmax
     o = torch.matmul(_r(pr, emulate), vv).transpose(1, 2).reshape(b, s, H * d)
     o = _r(o, emulate)
-    x = _r(x + hyperlora_linear(o, W, p + ".self_attn.o_proj", sc, ln, None), emulate)
+    x = _rres(x + hyperlora_linear(o, W, p + ".self_attn.o_proj", sc, ln, None), emulate)
 
     h = rmsnorm(x, W[p + ".post_attention_layernorm.weight"], cfg.rms_norm_eps, emulate)
     g_ = hyperlora_linear(h, W, p + ".mlp.gate_proj", sc, ln, None)
     u_ = hyperlora_linear(h, W, p + ".mlp.up_proj", sc, ln, None)
     m = _r(F.silu(g_) * u_, emulate)                                           # :269
-    x = _r(x + hyperlora_linear(m, W, p + ".mlp.down_proj", sc, ln, None), emulate)
+    x = _rres(x + hyperlora_linear(m, W, p + ".mlp.down_proj", sc, ln, None), emulate)
     return x
 
 

@@ -95,15 +95,19 @@ def test_decode_batch_256_path_agrees_with_small_batch_full_size(crab):
     assert torch.equal(big.sequences, big2.sequences), "non-deterministic at batch 256"
     small = um.generate(inputs_embeds=emb[:4], **kw)
     lb, ls = torch.stack(big.logits, 1)[:4].float(), torch.stack(small.logits, 1).float()
+    worst = 0.0
     for b in range(4):
         for s in range(5):
             err = (lb[b, s] - ls[b, s]).abs().max().item()
+            worst = max(worst, err / ls[b, s].abs().max().item())
             # two different kernel paths through 32 synthetic layers: accumulation-order noise is amplified
             assert err < 8e-2 * ls[b, s].abs().max().item(), (b, s, err)
             if big.sequences[b, s] != small.sequences[b, s]:
                 top2 = ls[b, s].topk(2).values
                 assert (top2[0] - top2[1]).item() <= 2 * err, (b, s)
                 break
+    from tests.util import record_parity
+    record_parity("32-layer: batch-256 decode path vs batch-4 path, per-step logits (HIP vs HIP)", worst, 1.0, 8e-2)
 
 
 def test_generate_avs_full_width_shapes():
@@ -146,7 +150,7 @@ def test_full_width_layer_prefill_and_greedy_vs_cpu_oracle():
     S, n_new = 1100, 4
     g = torch.Generator().manual_seed(11)
     emb = torch.randn(1, S, 4096, generator=g).to(BF)
-    _greedy_vs_oracle(um, W, cfg, emb, n_new, "1-layer Llama-2-7B-wide decoder, S=1100 + 4 greedy tokens vs fp32 CPU oracle", 4e-2)
+    _greedy_vs_oracle(um, W, cfg, emb, n_new, "1-layer Llama-2-7B-wide decoder, S=1100 + 4 greedy tokens vs fp32 CPU oracle", 6e-3, min_same=4)
 
 
 def test_full_size_encoders_vs_cpu_oracle():
@@ -167,37 +171,55 @@ def test_full_size_encoders_vs_cpu_oracle():
     ref_vit, ref_q = O.encode_video(video.to(BF).float(), W, cfg, emulate=BF)
     for lvl in range(3):
         assert _rel(vit[lvl].cpu(), ref_vit[lvl], f"full-size CLIP ViT-L/14 level {lvl} vs bf16-emulating oracle") < 2.5e-2, f"CLIP level {lvl}"
-    assert _rel(qf[-1].cpu(), ref_q[-1], "full-size VLProjector vs bf16-emulating oracle") < 2.5e-2
+    assert _rel(qf[-1].cpu(), ref_q[-1], "full-size VLProjector vs bf16-emulating oracle") < 1.8e-2
     a = um.encode_audio(audio)
     ref_a = O.encode_audio(audio.to(BF).float(), W, cfg, emulate=BF)
     assert a.shape == (1, 64, 4096)
-    assert _rel(a.cpu(), ref_a, "full-size BEATs + ALProjector vs bf16-emulating oracle") < 2.5e-2
+    assert _rel(a.cpu(), ref_a, "full-size BEATs + ALProjector vs bf16-emulating oracle") < 1.6e-2
 
 
-def _greedy_vs_oracle(um, W, cfg, emb, n_new, what, tol):
-    """HIP engine vs oracle.greedy_generate on the same weights / embeddings: per-step last-row logits within `tol` of the logit scale,
-    ids equal wherever the fp32 top-2 margin exceeds twice the measured error.  Returns the relative error."""
+def _greedy_vs_oracle(um, W, cfg, emb, n_new, what, tol, min_same=None):
+    """HIP path vs oracle.greedy_generate on the same weights / embeddings.
+    (1) the public engine.generate(): ids equal to the oracle's up to the first step whose fp32 top-2 margin is below twice the measured
+        logit error (after it the contexts differ);
+    (2) TEACHER-FORCED along the oracle's ids (prefill with the cache kept, then forward() one oracle token at a time), so EVERY step's
+        last-row logits are compared on identical contexts: within `tol` of the logit scale, argmax equal wherever the margin allows."""
     from oracle import crab_oracle as O
     from tests.util import record_parity
     ref_ids, ref_logits = O.greedy_generate(emb.float(), W, cfg, n_new)
+    scale = ref_logits.abs().max().item()
+    top2 = ref_logits[0].topk(2, -1).values
+    margin = top2[:, 0] - top2[:, 1]
+    # (1)
     r = um._engine.generate(emb.cuda(), n_new, eos_token_id=None, pad_token_id=2, return_step_logits=True)
     ids, logits = r[0].cpu(), r[1].float().cpu()
-    scale = ref_logits.abs().max().item()
-    errs = [(logits[0, s] - ref_logits[0, s]).abs().max().item() for s in range(n_new)]
     same = 0
-    for s in range(n_new):                                   # contexts are identical up to the first divergence
+    for s in range(n_new):
+        e = (logits[0, s] - ref_logits[0, s]).abs().max().item()
         if ids[0, s] != ref_ids[0, s]:
-            top2 = ref_logits[0, s].topk(2).values
-            assert (top2[0] - top2[1]).item() <= 2 * errs[s], (what, s, ids[0, s].item(), ref_ids[0, s].item(), errs[s])
+            assert margin[s].item() <= 2 * e, (what, "generate()", s, ids[0, s].item(), ref_ids[0, s].item(), e, margin[s].item())
             break
+        assert e < tol * scale, (what, "generate()", s, e, scale)
         same += 1
-    err = max(errs[:max(same, 1)])
-    top2 = ref_logits[0].topk(2, -1).values
-    record_parity(what, err, scale, tol, first_step_abs=errs[0], steps_with_identical_ids=same, steps=n_new,
-                  min_ref_margin=float((top2[:, 0] - top2[:, 1]).min()))
-    assert err < tol * scale, (what, err, scale)
-    assert same >= (n_new + 1) // 2, (what, same)
-    return err / scale
+    if min_same is not None:
+        assert same >= min_same, (what, same)
+    # (2)
+    out = um(inputs_embeds=emb.cuda(), use_cache=True)
+    errs = [(out.logits[0, -1].float().cpu() - ref_logits[0, 0]).abs().max().item()]
+    agree = [int(out.logits[0, -1].argmax()) == int(ref_ids[0, 0])]
+    past = out.past_key_values
+    for s in range(1, n_new):
+        o = um(input_ids=ref_ids[:, s - 1:s].cuda(), past_key_values=past)
+        past = o.past_key_values
+        lg = o.logits[0, -1].float().cpu()
+        errs.append((lg - ref_logits[0, s]).abs().max().item())
+        agree.append(int(lg.argmax()) == int(ref_ids[0, s]))
+    for s in range(n_new):
+        assert errs[s] < tol * scale, (what, "teacher-forced", s, errs[s], scale)
+        assert agree[s] or margin[s].item() <= 2 * errs[s], (what, "teacher-forced argmax", s, errs[s], margin[s].item())
+    record_parity(what, max(errs), scale, tol, per_step_abs=[round(e, 5) for e in errs], generate_steps_with_identical_ids=same, steps=n_new,
+                  min_ref_margin=float(margin.min()), argmax_agree=sum(agree))
+    return max(errs) / scale
 
 
 def test_full_32_layer_llama_generate_vs_cpu_oracle(crab):
@@ -208,12 +230,12 @@ def test_full_32_layer_llama_generate_vs_cpu_oracle(crab):
     um = crab.base_model.model
     W = {}
     for k, v in O.strip_peft_prefix(crab.state_dict()).items():
-        if v.dtype.is_floating_point and (k.startswith("model.layers.") or k.startswith("model.norm") or k.startswith("lm_head")):
+        if v.dtype.is_floating_point and (k.startswith("model.layers.") or k.startswith("model.norm") or k.startswith("lm_head") or k.startswith("model.embed_tokens")):
             W[k] = v.detach().float().cpu()
     cfg = O.DecoderConfig(vocab_size=um.lm_head.weight.shape[0])
     g = torch.Generator().manual_seed(17)
     emb = torch.randn(1, 702, 4096, generator=g).to(BF)       # conditioned synthetic model: embed_tokens ~ N(0, 1)
-    _greedy_vs_oracle(um, W, cfg, emb, 8, "32-layer Llama-2-7B-size decoder, S=702 + 8 greedy tokens vs fp32 CPU oracle", 4e-2)
+    _greedy_vs_oracle(um, W, cfg, emb, 8, "32-layer Llama-2-7B-size decoder, S=702 + 8 greedy tokens vs fp32 CPU oracle", 3e-2)
 
 
 def test_full_width_qwen2_layer_prefill_and_greedy_vs_cpu_oracle():
@@ -230,4 +252,4 @@ def test_full_width_qwen2_layer_prefill_and_greedy_vs_cpu_oracle():
     cfg = O.DecoderConfig(**{**q.__dict__, "num_hidden_layers": 1, "vocab_size": um.lm_head.weight.shape[0]})
     g = torch.Generator().manual_seed(12)
     emb = torch.randn(1, 1100, cfg.hidden_size, generator=g).to(BF)
-    _greedy_vs_oracle(um, W, cfg, emb, 4, "1-layer Qwen2-7B-wide decoder, S=1100 + 4 greedy tokens vs fp32 CPU oracle", 4e-2)
+    _greedy_vs_oracle(um, W, cfg, emb, 4, "1-layer Qwen2-7B-wide decoder, S=1100 + 4 greedy tokens vs fp32 CPU oracle", 6e-3)

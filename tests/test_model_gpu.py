@@ -2,12 +2,14 @@
   (1) the reference-generated golden fixtures (fp32 reference outputs), and
   (2) the oracle on the same seeded weights, in fp32 and in bf16-storage emulation.
 
-Tolerances (stated per north_star "within 1e-3 bf16"; what bf16 storage can actually deliver is measured and
-written in DESIGN.md):
-  * vs the oracle emulating bf16 storage at the same points: the two paths differ only by accumulation order and
-    rare 1-ulp rounding flips -> REL_EMU of the output scale.
-  * vs the fp32 reference fixture: bf16 storage noise of the whole stack -> REL_F32 of the output scale.
-  * greedy token ids: exact wherever the fp32 reference's top-2 logit margin exceeds the measured logit error.
+Tolerances: north_star asks for "logits within 1e-3 bf16"; what bf16 STORAGE delivers is measured (an exact
+bf16-storage execution of these decoders is already 3.4e-3 .. 5.6e-3 of the logit scale away from fp32).  Every comparison below is
+recorded (tests/util.py:record_parity) and each tolerance is at most twice the worst error measured on MI355X
+(profiles/r02_parity_report.json), relative to max |reference|:
+  * REL_ENC  encoder features / projector outputs / spliced inputs_embeds vs the fp32 reference fixture   (worst 1.40e-2)
+  * REL_DEC  decoder logits / hidden states / layer outputs vs the fp32 reference fixture                 (worst 8.9e-3)
+  * REL_EMU  vs the oracle emulating bf16 storage at the same points (accumulation order, 1-ulp flips)     (worst 1.34e-2)
+  * greedy token ids: exact wherever the fp32 reference's top-2 logit margin exceeds twice the measured logit error.
 """
 import pytest
 import torch
@@ -17,7 +19,8 @@ from tests.util import build_tiny_crab, load_fixture, weights_from_table, bert_c
 pytestmark = pytest.mark.gpu
 BF = torch.bfloat16
 REL_EMU = 2.5e-2
-REL_F32 = 4e-2
+REL_ENC = 2.8e-2
+REL_DEC = 1.8e-2
 
 
 def _rel(got, ref, what=""):
@@ -44,7 +47,7 @@ def test_clip_tower_vs_reference_fixture_and_oracle():
     cfg = O.ClipConfig(**meta["cfg"], select_layers=tuple(meta["select"]))
     emu = O.visual_encoder(video.to(BF).float(), _bf(W), cfg, emulate=BF)
     for i in range(3):
-        assert _rel(feats[i], A[f"f{i}"], f"clip_tiny level {i} vs fp32 reference") < REL_F32, f"level {i} vs reference"
+        assert _rel(feats[i], A[f"f{i}"], f"clip_tiny level {i} vs fp32 reference") < REL_ENC, f"level {i} vs reference"
         assert _rel(feats[i], emu[i], f"clip_tiny level {i} vs bf16-emulating oracle") < REL_EMU, f"level {i} vs bf16-emulating oracle"
 
 
@@ -62,7 +65,7 @@ def test_beats_vs_reference_fixture_and_oracle():
     for L in (98, 198):
         x = A[f"x{L}"]
         y = ae(ops.cast_bf16(x.cuda()))
-        assert _rel(y, A[f"y{L}"], f"beats_tiny L={L} vs fp32 reference") < REL_F32, f"L={L} vs reference"
+        assert _rel(y, A[f"y{L}"], f"beats_tiny L={L} vs fp32 reference") < REL_ENC, f"L={L} vs reference"
         assert _rel(y, O.beats(x.to(BF).float(), _bf(W), cfg, emulate=BF), f"beats_tiny L={L} vs bf16-emulating oracle") < REL_EMU, f"L={L} vs emulating oracle"
 
 
@@ -75,12 +78,12 @@ def test_projectors_vs_reference_fixture():
                      depth=2, bert_config=bc, device="cuda")
     r = vl.load_state_dict({k[len("model.vl_projector."):]: v for k, v in W.items() if k.startswith("model.vl_projector.")}, strict=False)
     assert not r.missing_keys, r.missing_keys
-    assert _rel(vl(A["vfeat"].to(BF).cuda()), A["vout"], "VLProjector vs fp32 reference") < REL_F32
+    assert _rel(vl(A["vfeat"].to(BF).cuda()), A["vout"], "VLProjector vs fp32 reference") < REL_ENC
     al = ALProjector(hidden_size=128, num_query_token=32, num_hidden_layers=2, d_model=meta["d_model"], depth=2, bert_config=bc,
                      device="cuda")
     r = al.load_state_dict({k[len("model.al_projector."):]: v for k, v in W.items() if k.startswith("model.al_projector.")}, strict=False)
     assert not r.missing_keys, r.missing_keys
-    assert _rel(al(A["afeat"].to(BF).cuda()), A["aout"], "ALProjector vs fp32 reference") < REL_F32
+    assert _rel(al(A["afeat"].to(BF).cuda()), A["aout"], "ALProjector vs fp32 reference") < REL_ENC
 
 
 def _inputs(meta):
@@ -130,15 +133,15 @@ def test_full_tiny_generate_matches_reference(fixture):
     mods = _inputs(meta)
     lab = [torch.full_like(A["ids0"], -100), torch.full_like(A["ids1"], -100)]
     inp1 = model.prepare_multimodal_inputs([A["ids0"]], [lab[0]], [mods[0]], ['avqa'])
-    assert _rel(inp1["inputs_embeds"], A["embeds_bs1"], f"{fixture}: inputs_embeds bs1 (encoders + projectors + splice)") < REL_F32
+    assert _rel(inp1["inputs_embeds"], A["embeds_bs1"], f"{fixture}: inputs_embeds bs1 (encoders + projectors + splice)") < REL_ENC
     inp2 = model.prepare_multimodal_inputs([A["ids0"], A["ids1"]], lab, mods, ['avqa', 'avqa'])
-    assert _rel(inp2["inputs_embeds"], A["embeds_bs2"], f"{fixture}: inputs_embeds left-padded bs2") < REL_F32
+    assert _rel(inp2["inputs_embeds"], A["embeds_bs2"], f"{fixture}: inputs_embeds left-padded bs2") < REL_ENC
     assert torch.equal(inp2["position_ids"].cpu().long(), A["pos_bs2"].long())
     assert torch.equal(inp2["attention_mask"].cpu().long(), A["mask_bs2"].long())
     # prefill, all rows (LlamaForCausalLM.forward)
     out = model.base_model.model(inputs_embeds=A["embeds_bs1"].to(BF).cuda(), output_hidden_states=True)
-    assert _rel(out.logits, A["prefill_logits_bs1"], f"{fixture}: prefill logits, all rows") < REL_F32
-    assert _rel(out.hidden_states[-1], A["prefill_hidden_bs1"], f"{fixture}: post-norm hidden, all rows") < REL_F32
+    assert _rel(out.logits, A["prefill_logits_bs1"], f"{fixture}: prefill logits, all rows") < REL_DEC
+    assert _rel(out.hidden_states[-1], A["prefill_hidden_bs1"], f"{fixture}: post-norm hidden, all rows") < REL_DEC
     # generate: public API, bs=1 and left-padded bs=2, graph replay and plain launches must agree bit for bit
     n = meta["new_tokens"]
     kw = dict(use_cache=True, max_new_tokens=n, do_sample=False, pad_token_id=2, eos_token_id=None,
@@ -152,7 +155,7 @@ def test_full_tiny_generate_matches_reference(fixture):
         got = torch.stack(r1.logits, 1)
         assert torch.equal(got, torch.stack(r2.logits, 1))
         err = _check_ids(r1.sequences, A[f"ids_{key}"], A[f"logits_{key}"], got)
-        assert err < REL_F32 * A[f"logits_{key}"].abs().max().item(), err
+        assert err < REL_DEC * A[f"logits_{key}"].abs().max().item(), err
         plain = model.generate(batch_input_ids=bi, batch_labels=lab[:bs], batch_X_modals=mods[:bs], batch_task_names=['avqa'] * bs,
                                use_cache=True, max_new_tokens=n, pad_token_id=2, eos_token_id=None)
         assert torch.equal(plain, r1.sequences) and plain.shape == (bs, n)
@@ -171,7 +174,7 @@ def test_tiny_qwen2_gqa_bias_generate_matches_reference():
                          eos_token_id=None, output_logits=True, return_dict_in_generate=True)
     got = torch.stack(res.logits, 1)
     err = _check_ids(res.sequences, A["ids"], A["logits"], got)
-    assert err < REL_F32 * A["logits"].abs().max().item(), err
+    assert err < REL_DEC * A["logits"].abs().max().item(), err
 
 
 def test_eos_and_min_new_tokens_semantics():
@@ -219,9 +222,9 @@ def test_seg_module_vs_reference_fixture_and_oracle():
     assert tuple(out[0].shape) == (71, 224, 224) and tuple(out[1].shape) == (1, 224, 224)
     ref = O.seg_module(pred.to(BF).float(), [f.to(BF).float() for f in feats], meta["tasks"], _bf(W))
     for i in range(2):
-        assert _rel(out[i], ref[i], f"SegModule sample {i} vs oracle on bf16-rounded weights") < 6e-2, f"sample {i} vs oracle on bf16-rounded weights"
-    assert _rel(out[0][:, 3::8, 5::8], A["avss_sub"], "SegModule avss vs fp32 reference") < 8e-2
-    assert _rel(out[1][:, 1::2, ::2], A["s4_sub"], "SegModule s4 vs fp32 reference") < 8e-2
+        assert _rel(out[i], ref[i], f"SegModule sample {i} vs oracle on bf16-rounded weights") < 1.8e-2, f"sample {i} vs oracle on bf16-rounded weights"
+    assert _rel(out[0][:, 3::8, 5::8], A["avss_sub"], "SegModule avss vs fp32 reference") < 3.2e-2
+    assert _rel(out[1][:, 1::2, ::2], A["s4_sub"], "SegModule s4 vs fp32 reference") < 3.2e-2
 
 
 def test_generate_avs_pipeline_vs_oracle():
@@ -286,7 +289,7 @@ def test_generate_avs_pipeline_vs_oracle():
         assert float(top2[0] - top2[1]) < 0.1 * float(olog.abs().max()), f"generate_avs ids diverge from the oracle at step {j} at a super-margin step"
         pytest.skip(f"ids diverge at sub-margin step {j}: masks are not comparable")
     else:
-        assert _rel(res['pred_masks'][0], ref[0], "generate_avs masks vs oracle pipeline") < 1e-1
+        assert _rel(res['pred_masks'][0], ref[0], "generate_avs masks vs oracle pipeline") < 2e-2
 
 
 def test_generate_many_clips_vs_oracle():
@@ -314,8 +317,8 @@ def test_generate_many_clips_vs_oracle():
         r = model.generate(batch_input_ids=ids, batch_labels=lab, batch_X_modals=mods, batch_task_names=['avqa'] * 2, use_cache=True,
                            max_new_tokens=n, pad_token_id=2, eos_token_id=None, output_logits=True, return_dict_in_generate=True)
         ref_ids, ref_logits = O.generate(ids, mods, Wo, ocfg, n)
-        worst = max(worst, _check_ids(r.sequences, ref_ids, ref_logits, torch.stack(r.logits, 1)))
-    assert worst < REL_F32 * 10.0
+        worst = max(worst, _check_ids(r.sequences, ref_ids, ref_logits, torch.stack(r.logits, 1)) / ref_logits.abs().max().item())
+    assert worst < REL_DEC, worst
 
 
 def test_generate_edge_cases_vs_oracle():
@@ -417,14 +420,14 @@ def _layer_prefill_and_decode_step(fixture, qwen):
     kc, vc = eng.alloc_cache(1, 64)
     eng.prefill(A["layer_x"].to(BF).cuda(), kc, vc, b0=0)
     ws = eng._workspace(S)
-    assert _rel(ws.x[:S], A["layer_y"][0], f"{fixture}: layer output, prefill") < REL_F32
+    assert _rel(ws.x[:S], A["layer_y"][0], f"{fixture}: layer output, prefill") < REL_DEC
     assert _rel(kc[0, 0, :, :S], A["cache_k"][0][:, :S], f"{fixture}: K cache rows, prefill") < 1.2e-2
     assert _rel(vc[0, 0, :, :S], A["cache_v"][0][:, :S], f"{fixture}: V cache rows, prefill") < 1.2e-2
     # the decode row: position S, device-resident position word, KV append fused behind the q|k|v projection
     ops.copy_rows(A["layer_x1"][0].to(BF).cuda(), ws.x, 1, D)
     pos = torch.full((1,), S, device="cuda", dtype=torch.int32)
     x, _ = eng._layers(ws, 1, 1, kc, vc, 0, 64, 0, pos, None)
-    assert _rel(x[:1], A["layer_y1"][0], f"{fixture}: layer output, 1-token decode step") < REL_F32
+    assert _rel(x[:1], A["layer_y1"][0], f"{fixture}: layer output, 1-token decode step") < REL_DEC
     assert _rel(kc[0, 0, :, S], A["cache_k"][0][:, S], f"{fixture}: K cache row, decode step") < 1.2e-2
     assert _rel(vc[0, 0, :, S], A["cache_v"][0][:, S], f"{fixture}: V cache row, decode step") < 1.2e-2
 

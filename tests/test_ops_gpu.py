@@ -1,9 +1,8 @@
 """GPU parity tests of the individual HIP kernels, called through the C-ABI (crab_amd.ops -> ctypes).
 
 Reference for each op: fp32 CPU arithmetic on the SAME bf16-rounded inputs (oracle/crab_oracle.py where a
-restatement exists, otherwise the plain torch fp32 op).  Tolerances: fp32 outputs differ only by
-accumulation order (<= 2e-3 relative to the output scale for K up to 11k); bf16 outputs additionally carry one
-rounding (2^-8 relative)."""
+restatement exists, otherwise the plain torch fp32 op).  Tolerances are set to at most twice the error measured on the
+GPU (every comparison is recorded in the parity report, tests/util.py:record_parity)."""
 import math
 
 import pytest
@@ -13,6 +12,9 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 BF = torch.bfloat16
+# Tolerances = at most 2x the worst error measured on MI355X (profiles/r02_parity_report.json), relative to max |reference|:
+TOL_F32 = 3e-6       # fp32 outputs: accumulation order only (worst 1.15e-6 at K = 6144)
+TOL_BF16 = 6e-3      # bf16 outputs: one storage rounding on top (worst 3.0e-3); attention kernels 2.0-3.0e-3
 
 
 def _rand(*shape, seed=0, scale=1.0):
@@ -32,7 +34,7 @@ def test_gemm_shapes_fp32_out(M, N, K):
     from crab_amd import ops
     x, w = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=1 / math.sqrt(K))
     y = ops.gemm(x.cuda(), w.cuda(), out_fp32=True)
-    _cmp(y, x.float() @ w.float().t(), 2e-3, f"gemm {M}x{N}x{K}")
+    _cmp(y, x.float() @ w.float().t(), TOL_F32, f"gemm {M}x{N}x{K}")
 
 
 @pytest.mark.parametrize("act", ["none", "gelu", "quick_gelu", "relu", "silu"])
@@ -43,7 +45,7 @@ def test_gemm_epilogue(act):
     y = ops.gemm(x.cuda(), w.cuda(), bias=b.cuda(), act=act, residual=r.cuda(), res_scale=2.2133)
     z = x.float() @ w.float().t() + b.float()
     z = {"none": z, "gelu": F.gelu(z), "quick_gelu": z * torch.sigmoid(1.702 * z), "relu": F.relu(z), "silu": F.silu(z)}[act]
-    _cmp(y, z + 2.2133 * r.float(), 1.2e-2, act)
+    _cmp(y, z + 2.2133 * r.float(), TOL_BF16, act)
     assert y.dtype == BF
 
 
@@ -53,7 +55,7 @@ def test_gemm_second_k_segment_and_odd_ldc():
     x, w = _rand(M, K, seed=7), _rand(N, K, seed=8, scale=0.1)
     x2, w2 = _rand(M, K2, seed=9), _rand(N, K2, seed=10, scale=0.1)
     y = ops.gemm(x.cuda(), w.cuda(), x2=x2.cuda(), w2=w2.cuda(), out_fp32=True)
-    _cmp(y, x.float() @ w.float().t() + x2.float() @ w2.float().t(), 2e-3, "2-seg")
+    _cmp(y, x.float() @ w.float().t() + x2.float() @ w2.float().t(), TOL_F32, "2-seg")
 
 
 def test_gemm_batched_sliding_window():
@@ -86,7 +88,7 @@ def test_gemm_batched_sliding_window():
             A = torch.stack([xp[gi, b, t:t + Kc].reshape(-1) for t in range(n)]).float()
             z = F.gelu(A @ w[gi].float().t() + bias[gi * cg:(gi + 1) * cg].float())
             ref[b, :, gi * cg:(gi + 1) * cg] = z + res[b, :, gi * cg:(gi + 1) * cg].float()
-    _cmp(out, ref, 1.2e-2, "sliding-window batched gemm")
+    _cmp(out, ref, TOL_BF16, "sliding-window batched gemm")
 
 
 def test_rmsnorm_layernorm():
@@ -106,7 +108,7 @@ def test_embedding_swiglu_argmax_cast():
     ids = torch.tensor([3, 49, 0, 7, 7])
     assert torch.equal(ops.embedding(ids.cuda(), tab.cuda()).cpu(), tab[ids])
     gu = _rand(33, 2 * 264, seed=2)
-    _cmp(ops.swiglu(gu.cuda()), F.silu(gu[:, :264].float()) * gu[:, 264:].float(), 1e-2, "swiglu")
+    _cmp(ops.swiglu(gu.cuda()), F.silu(gu[:, :264].float()) * gu[:, 264:].float(), TOL_BF16, "swiglu")
     lg = torch.randn(5, 32017)
     lg[2, 100] = lg[2, 5000] = 50.0          # tie -> first index
     assert torch.equal(ops.argmax(lg.cuda()).cpu(), lg.argmax(-1))
@@ -128,7 +130,7 @@ def test_hyperlora_mix_matches_reference_formula():
         pr = torch.softmax(seg[:, :3], -1)
         for i in range(3):
             ref[:, p * 24 + i * 8:p * 24 + (i + 1) * 8] = 2.0 * pr[:, i:i + 1] * seg[:, 3:]
-    _cmp(u, ref, 1e-2, "mix")
+    _cmp(u, ref, TOL_BF16, "mix")
     assert (u[:, 72:] == 0).all()
 
 
@@ -146,7 +148,7 @@ def test_hyperlora_linear_fused_matches_golden():
     t = ops.gemm(x.cuda(), ra.cuda(), out_fp32=True)
     u = ops.hyperlora_mix(t, 1, 3, 8, 32, 2.0)
     y = ops.gemm(x.cuda(), W["lin.weight"].cuda(), bias=W["lin.bias"].cuda(), x2=u, w2=bcat.cuda(), out_fp32=True)
-    _cmp(y, A["y"].reshape(-1, 256), 1.5e-2, "hyper-LoRA linear vs reference")
+    _cmp(y, A["y"].reshape(-1, 256), TOL_BF16, "hyper-LoRA linear vs reference")
 
 
 def _attn_ref(q, k, v, scale, causal=False, bias=None):
@@ -184,7 +186,7 @@ def test_attn_fwd(hd, B, H, Hk, Sq, Skv, causal):
                  vt_strides=(Hk * hd * Sp, hd * Sp, Sp), o_strides=(Sq * H * hd, H * hd), B=B, H=H, Hk=Hk, Sq=Sq, Skv=Skv,
                  head_dim=hd, scale=scale, causal=causal)
     ref = _attn_ref(q, k, v, scale, causal).transpose(1, 2).reshape(B, Sq, H * hd)
-    _cmp(o, ref, 1.5e-2, "attn_fwd")
+    _cmp(o, ref, TOL_BF16, "attn_fwd")
 
 
 def test_attn_fwd_gated_bias():
@@ -199,7 +201,7 @@ def test_attn_fwd_gated_bias():
                  vt_strides=(H * hd * n, hd * n, n), o_strides=(n * H * hd, H * hd), B=B, H=H, Hk=H, Sq=n, Skv=n, head_dim=hd,
                  scale=hd ** -0.5, bias=bias.cuda(), gate=gate.cuda())
     ref = _attn_ref(q, k, v, hd ** -0.5, False, gate[..., None] * bias[None]).transpose(1, 2).reshape(B, n, H * hd)
-    _cmp(o, ref, 1.5e-2, "gated-bias attention")
+    _cmp(o, ref, TOL_BF16, "gated-bias attention")
 
 
 @pytest.mark.parametrize("hd,H,Hk", [(128, 4, 4), (64, 4, 2)])
@@ -221,8 +223,8 @@ def test_rope_split_and_decode_attention(hd, H, Hk):
     v = qkv[:, (H + Hk) * hd:].view(B, S, Hk, hd).transpose(1, 2)
     cos, sin = O.rope_cos_sin(torch.arange(S)[None].expand(B, S), hd, theta)
     qr, kr = O.apply_rope(q, k, cos, sin)
-    _cmp(qd[:, :H * hd].view(B, S, H, hd).transpose(1, 2), qr, 1e-2, "rope q")
-    _cmp(kc[:, :, :S], kr, 1e-2, "rope k -> cache")
+    _cmp(qd[:, :H * hd].view(B, S, H, hd).transpose(1, 2), qr, TOL_BF16, "rope q")
+    _cmp(kc[:, :, :S], kr, TOL_BF16, "rope k -> cache")
     assert torch.equal(vc[:, :, :S].cpu(), v)
     assert torch.equal(vt[..., :S].cpu(), v.transpose(2, 3))
     # decode step at position S (device-resident position word)
@@ -234,7 +236,7 @@ def test_rope_split_and_decode_attention(hd, H, Hk):
     ops.attn_decode(q1d, kc, vc, o, B, H, Hk, hd, Tmax, 1, hd ** -0.5, ctx_dev=pos)
     qn = q1d[:, :H * hd].cpu().view(B, 1, H, hd).transpose(1, 2)
     ref = _attn_ref(qn, kc[:, :, :S + 1].cpu(), vc[:, :, :S + 1].cpu(), hd ** -0.5).transpose(1, 2).reshape(B, H * hd)
-    _cmp(o, ref, 1.5e-2, "decode attention")
+    _cmp(o, ref, TOL_BF16, "decode attention")
 
 
 @pytest.mark.parametrize("ctx", [702, 830, 958])
@@ -262,7 +264,7 @@ def test_decode_attention_mha_benchmark_regime(ctx):
         qf = q[b0:b0 + 32, :H * hd].float().view(32, H, 1, hd)
         a = torch.matmul(qf, kc[b0:b0 + 32, :, :ctx].float().transpose(2, 3)) * hd ** -0.5
         ref[b0:b0 + 32] = torch.matmul(torch.softmax(a, -1), vc[b0:b0 + 32, :, :ctx].float()).reshape(32, H * hd)
-    _cmp(o, ref.cpu(), 1.5e-2, f"decode attention MHA, B=256 H=32 ctx={ctx} (bench regime)")
+    _cmp(o, ref.cpu(), TOL_BF16, f"decode attention MHA, B=256 H=32 ctx={ctx} (bench regime)")
     # determinism of the launch the benchmark replays from its HIP graph
     o2 = torch.zeros_like(o)
     ops.attn_decode(q, kc, vc, o2, B, H, H, hd, Tmax, 1, hd ** -0.5, ctx_dev=pos)
@@ -285,10 +287,10 @@ def test_decode_attention_grouped_query(G, ctx):
     ops.attn_decode(q, kc, vc, o, B, H, Hk, hd, Tmax, 1, hd ** -0.5, ctx_dev=pos)          # B*Hk = 256 -> grouped kernel
     qn = q.cpu().view(B, 1, H, hd).transpose(1, 2)
     ref = _attn_ref(qn, kc[:, :, :ctx].cpu(), vc[:, :, :ctx].cpu(), hd ** -0.5).transpose(1, 2).reshape(B, H * hd)
-    _cmp(o, ref, 1.5e-2, "grouped decode attention")
+    _cmp(o, ref, TOL_BF16, "grouped decode attention")
     o2 = torch.zeros(3, H * hd, dtype=BF, device="cuda")
     ops.attn_decode(q[:3].contiguous(), kc[:3].contiguous(), vc[:3].contiguous(), o2, 3, H, Hk, hd, Tmax, ctx, hd ** -0.5)   # per-head kernel
-    _cmp(o[:3], o2.float().cpu(), 1e-2, "grouped vs per-head decode kernel")
+    _cmp(o[:3], o2.float().cpu(), TOL_BF16, "grouped vs per-head decode kernel")
 
 
 def test_im2col_and_clip_embed():
@@ -307,7 +309,7 @@ def test_im2col_and_clip_embed():
     patch, cls, pos, w, b = _rand(N * P, D, seed=1), _rand(D, seed=2), _rand(P + 1, D, seed=3), _rand(D, seed=4), _rand(D, seed=5)
     y = ops.clip_embed_ln(patch.cuda(), cls.cuda(), pos.cuda(), w.cuda(), b.cuda(), N, P, D, 1e-5)
     xx = torch.cat([cls.float().expand(N, 1, D), patch.float().view(N, P, D)], 1) + pos.float()
-    _cmp(y, F.layer_norm(xx.to(BF).float(), (D,), w.float(), b.float(), 1e-5).reshape(-1, D), 1e-2, "clip embed ln")
+    _cmp(y, F.layer_norm(xx.to(BF).float(), (D,), w.float(), b.float(), 1e-5).reshape(-1, D), TOL_BF16, "clip embed ln")
 
 
 def test_beats_helpers_match_golden_buckets():
@@ -328,7 +330,7 @@ def test_beats_helpers_match_golden_buckets():
     qh = q.float().view(B, n, H, d).transpose(1, 2)
     gl = torch.sigmoid(F.linear(qh, gw.float(), gb.float()).view(B, H, n, 2, 4).sum(-1))
     ref = gl[..., 0] * (gl[..., 1] * ga.float().view(1, H, 1) - 1.0) + 2.0
-    _cmp(gate, ref, 1e-4, "gru gate")
+    _cmp(gate, ref, 1e-6, "gru gate")
     x = _rand(B, n, 128, seed=9)
     xp = ops.beats_posconv_pad(x.cuda(), B, n, 128, 16, 128).cpu()
     ref = torch.zeros(16, B, n + 127, 8, dtype=BF)
@@ -357,7 +359,7 @@ def test_hyperlora_route_matches_gemm_plus_mix(M, K, nproj):
         pr = torch.softmax(seg[:, :3], -1)
         for i in range(3):
             ref[:, p * 24 + i * 8:p * 24 + (i + 1) * 8] = 2.0 * pr[:, i:i + 1] * seg[:, 3:]
-    _cmp(u1, ref, 1.2e-2, "route")
+    _cmp(u1, ref, 7e-3, "route")
     assert (u1[:, nproj * 24:] == 0).all()
 
 
@@ -370,7 +372,7 @@ def test_gemm_skinny_regime(M):
     x2, w2 = _rand(M, K2, seed=7), _rand(N, K2, seed=8, scale=0.1)
     y = ops.gemm(x.cuda(), w.cuda(), bias=b.cuda(), act="silu", residual=r.cuda(), x2=x2.cuda(), w2=w2.cuda(), out_fp32=True)
     z = F.silu(x.float() @ w.float().t() + x2.float() @ w2.float().t() + b.float()) + r.float()
-    _cmp(y, z, 3e-3, f"skinny M={M}")
+    _cmp(y, z, TOL_F32, f"skinny M={M}")
 
 
 @pytest.mark.parametrize("M,tune", [(17, 0), (64, 0), (64, 104), (64, 208), (128, 0), (100, 103), (33, 102), (256, 403), (200, 407), (256, 0)])
@@ -384,11 +386,11 @@ def test_gemm_splitk_decode_regime(M, tune):
     args = dict(bias=b.cuda(), act="gelu", residual=r.cuda(), x2=x2.cuda(), w2=w2.cuda(), tune=tune)
     y = ops.gemm(x.cuda(), w.cuda(), out_fp32=True, **args)
     z = F.gelu(x.float() @ w.float().t() + x2.float() @ w2.float().t() + b.float()) + r.float()
-    _cmp(y, z, 3e-3, f"split-K M={M} tune={tune}")
+    _cmp(y, z, TOL_F32, f"split-K M={M} tune={tune}")
     y2 = ops.gemm(x.cuda(), w.cuda(), out_fp32=True, **args)
     assert torch.equal(y, y2), "split-K reduction must be deterministic"
     yb = ops.gemm(x.cuda(), w.cuda(), **args)
-    _cmp(yb, z, 1.2e-2, "bf16 out")
+    _cmp(yb, z, TOL_BF16, "bf16 out")
 
 
 @pytest.mark.parametrize("M,N", [(64, 4096), (8, 512), (40, 1024), (300, 512)])
@@ -403,8 +405,8 @@ def test_gemm_fused_post_rmsnorm(M, N):
     h = torch.empty(M, N, dtype=BF, device="cuda")
     ops.gemm(x.cuda(), w.cuda(), residual=xd, out=xd, post_norm=(nw.cuda(), 1e-5, h))
     c_ref = (x.float() @ w.float().t() + r.float())
-    _cmp(xd, c_ref, 1.2e-2, "C")
-    _cmp(h, O.rmsnorm(xd.cpu().float(), nw.float(), 1e-5, emulate=BF), 1e-2, "post-norm")
+    _cmp(xd, c_ref, TOL_BF16, "C")
+    _cmp(h, O.rmsnorm(xd.cpu().float(), nw.float(), 2e-3, emulate=BF), 1e-2, "post-norm")
 
 
 def test_gemm_ring_split_wide_projection_auto():
@@ -416,7 +418,7 @@ def test_gemm_ring_split_wide_projection_auto():
     y0 = ops.gemm(x.cuda(), w.cuda(), x2=x2.cuda(), w2=w2.cuda(), out_fp32=True)                 # automatic: ring, 6 tiles -> 5 slices
     y1 = ops.gemm(x.cuda(), w.cuda(), x2=x2.cuda(), w2=w2.cuda(), out_fp32=True, tune=104)       # 128x128 kernel, 4 slices
     z = x.float() @ w.float().t() + x2.float() @ w2.float().t()
-    _cmp(y0, z, 3e-3, "ring split auto")
+    _cmp(y0, z, TOL_F32, "ring split auto")
     assert (y0 - y1).abs().max().item() < 1e-3 * z.abs().max().item()
 
 
@@ -442,13 +444,13 @@ def test_decode_wide_projections_ring_split_with_fused_epilogues():
     for a, b in zip(outs[0], outs[1]):
         assert torch.equal(a, b)
     z = x.float() @ w.float().t() + x2.float() @ w2.float().t()
-    _cmp(outs[1][2].reshape(M, H * d), z[:, 2 * H * d:], 1.2e-2, "v rows in the cache")
+    _cmp(outs[1][2].reshape(M, H * d), z[:, 2 * H * d:], TOL_BF16, "v rows in the cache")
     # gate|up
     I = 11008
     wg, wu = _rand(I, K, seed=5, scale=K ** -0.5), _rand(I, K, seed=6, scale=K ** -0.5)
     wi = torch.stack([wg, wu], 1).reshape(2 * I, K).contiguous()
     y = ops.gemm(x.cuda(), wi.cuda(), act="swiglu_pair")
-    _cmp(y, F.silu(x.float() @ wg.float().t()) * (x.float() @ wu.float().t()), 1.2e-2, "gate|up ring split + swiglu")
+    _cmp(y, F.silu(x.float() @ wg.float().t()) * (x.float() @ wu.float().t()), TOL_BF16, "gate|up ring split + swiglu")
 
 
 @pytest.mark.parametrize("M", [4, 48, 256])
@@ -471,7 +473,7 @@ def test_gemm_post_norm_routes_next_group(M, nproj):
     ops.gemm(x.cuda(), w.cuda(), residual=r2, out=r2, post_norm=(nw.cuda(), 1e-5, h2))
     assert torch.equal(h, h2) and torch.equal(rd, r2)
     u_ref = ops.hyperlora_route(h2, ra.cuda(), nproj, 3, 8, ucols, 2.0)
-    _cmp(u, u_ref.float().cpu(), 1e-2, "route ahead")
+    _cmp(u, u_ref.float().cpu(), 1e-6, "route ahead")
     assert (u[:, nproj * 24:] == 0).all()
 
 
@@ -516,9 +518,9 @@ def test_gemm_swiglu_pair_epilogue(M, tune):
     assert y.shape == (M, I)
     g = x.float() @ wg.float().t() + x2.float() @ bg.float().t()
     u = x.float() @ wu.float().t() + x2.float() @ bu.float().t()
-    _cmp(y, F.silu(g) * u, 1.2e-2, "swiglu pair")
+    _cmp(y, F.silu(g) * u, TOL_BF16, "swiglu pair")
     y32 = ops.gemm(x.cuda(), w.cuda(), x2=x2.cuda(), w2=w2.cuda(), act="swiglu_pair", out_fp32=True, tune=tune)
-    _cmp(y32, F.silu(g) * u, 3e-3, "swiglu pair fp32")
+    _cmp(y32, F.silu(g) * u, TOL_F32, "swiglu pair fp32")
     with pytest.raises(Exception):
         ops.gemm(x.cuda(), w.cuda(), act="swiglu_pair", residual=y)          # no residual with the pair epilogue
 
@@ -538,7 +540,7 @@ def test_gemm_big_ring_kernel(M, N, K, K2, tune):
     z = x.float() @ w.float().t() + b.float()
     if K2:
         z = z + x2.float() @ w2.float().t()
-    _cmp(y, F.gelu(z) + r.float(), 3e-3, "ring 256")
+    _cmp(y, F.gelu(z) + r.float(), TOL_F32, "ring 256")
     y2 = ops.gemm(x.cuda(), w.cuda(), bias=b.cuda(), act="gelu", residual=r.cuda(), x2=x2.cuda() if K2 else None,
                   w2=w2.cuda() if K2 else None, out_fp32=True, tune=301)
     assert (y - y2).abs().max().item() < 1e-3 * z.abs().max().item(), "ring vs 2-stage kernel disagree"
