@@ -11,6 +11,7 @@
 // Global->register->LDS prefetch of tile t+1 overlaps the MFMAs of tile t; one barrier per K tile.
 #include "common.h"
 #include "crab_internal.h"
+#include <stdlib.h>
 #include "gemm_epilogue.h"
 
 namespace {
@@ -386,6 +387,32 @@ __global__ __launch_bounds__(256) void splitk_epilogue_norm_kernel(const float* 
 
 int crab_gemm_skinny_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* d);   // skinny.hip
 int crab_gemm_glds_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* d, int splitk, float* part, int ring_split);     // gemm_glds.hip
+int crab_gemm_dec_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* d, int bn, int splitk, float* part, int nt_weights);  // gemm_decode.hip
+
+// Decode-regime decomposition (128 < M <= 256): column-panel width BN in {96, 64} and K slices for gemm_dec_kernel (one block per
+// CU).  Measured on MI355X (profiles/README.md r02, scripts/bench_dec_gemm.py): a block moves its LDS-DMA bytes - the activation
+// rows of its K slice, re-read from L2 by every block, plus its weight panel - at ~58 GB/s per CU whatever the panel width or the
+// number of active CUs, so the K loop costs bytes_per_block / 58 GB/s; ~7 us (BN 64) / ~9 us (BN 96: 3-slot ring) of prologue +
+// epilogue per round; the reduction kernel
+// ~4 us + the fp32 slabs written and read back at ~4.5 TB/s while they stay MALL / L2 resident (<= 40 MB) and ~2 TB/s beyond.
+static void dec_choose(const crab_gemm_desc* d, int nks /* 64-wide K slots */, int* bn_out, int* split_out) {
+    double best = 1e30;
+    for (int bi = 0; bi < 2; ++bi) {
+        const int bn = bi ? 64 : 96;
+        const long tiles = (d->N + bn - 1) / bn;
+        for (int sp = 1; sp <= 8 && sp * 4 <= nks; ++sp) {
+            const long blocks = tiles * sp;
+            const double rounds = (double)((blocks + 255) / 256);
+            const int per = (nks + sp - 1) / sp;
+            if ((long)(sp - 1) * per >= nks) continue;                   // an empty slice
+            const double slab = (double)sp * d->M * d->N * 4.0;
+            if (sp > 1 && slab > (double)d->workspace_bytes) continue;
+            const double bytes = (256.0 + bn) * per * 64 * 2;
+            const double t = rounds * ((bn == 96 ? 10.0 : 7.0) + bytes / 58.0e3) + (sp > 1 ? 4.0 + 2.0 * slab / (slab <= 40.0e6 ? 4.5e6 : 2.0e6) : 0.0);
+            if (t < best) { best = t; *bn_out = bn; *split_out = sp; }
+        }
+    }
+}
 
 
 // Split-K reduction of the packed q|k|v projection fused with RoPE and the KV-cache append (decode: one row per sequence).
@@ -569,6 +596,23 @@ extern "C" int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc*
             if (splitk < 2) { ring_split = 0; splitk = 1; }
         }
     }
+    // ---- decode regime, 128 < M <= 256: the batch-tall narrow-panel kernel (gemm_decode.hip); tune 70000 + BN * 100 + S forces
+    // a decomposition, any other non-zero tune keeps the older kernels (A/B runs), CRAB_DEC_GEMM=0 disables it process-wide
+    int dec_bn = 0;
+    if (sk_bm == 128 && d->M > 128 && d->workspace) {
+        static const int dec_on = []() { const char* e = getenv("CRAB_DEC_GEMM"); return !(e && e[0] == '0'); }();
+        const int nk32 = (d->K + 63) / 64 + (d->A2 ? (d->K2 + 63) / 64 : 0);      // K slots of the panel kernel (64 wide)
+        if (d->tune >= 70000 && d->tune < 80000) {
+            dec_bn = (d->tune / 100) % 100; splitk = d->tune % 100;
+            if (splitk < 1) splitk = 1;
+            const int per = (nk32 + splitk - 1) / splitk;
+            splitk = (nk32 + per - 1) / per;                              // no empty slice
+            while (splitk > 1 && (int64_t)splitk * d->M * d->N * 4 > d->workspace_bytes) --splitk;
+        } else if (d->tune == 0 && dec_on) {
+            dec_choose(d, nk32, &dec_bn, &splitk);
+        }
+        if (dec_bn) ring_split = 0;
+    }
     GemmP p;
     p.splitk = splitk; p.part = (float*)d->workspace;
     p.A = (const bf16_t*)d->A; p.B = (const bf16_t*)d->B; p.C = d->C;
@@ -589,6 +633,10 @@ extern "C" int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc*
         if (sk_bm == 64 && sk_bn == 128) hipLaunchKernelGGL((gemm_bt_kernel<64, 128>), grid, dim3(256), 0, s, p);
         else if (sk_bm == 64) hipLaunchKernelGGL((gemm_bt_kernel<64, 64>), grid, dim3(256), 0, s, p);
         else if (d->tune == 300) hipLaunchKernelGGL((gemm_bt_kernel<128, 128>), grid, dim3(256), 0, s, p);
+        else if (dec_bn) {
+            int rc2 = crab_gemm_dec_launch(ctx, s, d, dec_bn, splitk, p.part, d->tune != 70001);
+            if (rc2) return rc2;
+        }
         else {                                                        // 128-row tiles: LDS-DMA staged kernel, K split over blockIdx.y
             int rc2 = crab_gemm_glds_launch(ctx, s, d, splitk, p.part, ring_split);
             if (rc2) return rc2;
