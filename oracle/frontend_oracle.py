@@ -17,8 +17,11 @@ Third-party algorithms restated here (absent from /root/reference):
     frontend_clip.npz holds outputs of the reference's own call (CLIPImageProcessor.preprocess) and this restatement is
     bit-exact against them (tests/test_oracle_golden.py).
   * torchaudio 2.0.1 `compliance/kaldi.py` (fbank, get_mel_banks, _get_window, povey window).  PARITY UNPINNED:
-    torchaudio is not installed in the build container, so no reference output could be recorded; the restatement follows
-    the published source and is cross-checked only against an independent float64 DFT formulation in the tests.
+    torchaudio is not installed in the build container, so no output of the reference's own call could be recorded.  The
+    restatement follows the published source; it is checked against known-answer vectors (tests/golden/fbank_kat.npz) produced by
+    a second implementation written independently from Kaldi's compute-fbank-feats definition in float64 (tests/golden/
+    make_fbank_kat.py: per-frame loops, scipy rfft, nine waveforms incl. silence / DC / square wave / one frame / chirp / impulse),
+    which pins the algorithm but not torchaudio's rounding: it stays "unpinned" until a torchaudio-generated fixture exists.
 """
 from __future__ import annotations
 

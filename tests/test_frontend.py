@@ -109,3 +109,54 @@ def test_kaldi_fbank_matches_oracle():
     assert one.shape == (1, 1, 128)
     with pytest.raises(ValueError):
         frontend.kaldi_fbank(torch.zeros(399).cuda())
+
+
+# ------------------------------------------------------------------ kaldi fbank known-answer vectors (tests/golden/make_fbank_kat.py)
+def _kat():
+    import json
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "fbank_kat.npz"))
+    meta = json.loads(bytes(z["meta"]).decode())
+    return meta, z
+
+
+def _fbank_agrees(got, kat, rel=1e-3, abs_of_frame_max=1e-10):
+    """log-mel comparison in the ENERGY domain: |E_got - E_kat| <= rel * E_kat + abs_of_frame_max * max_bin(E_kat) per frame.
+    A plain tolerance on the logarithm is meaningless for bins whose energy is ~1e-13 of the frame's strongest bin (pure tones,
+    chirps): there float32 arithmetic - which the reference's torchaudio call uses - is rounding noise, not signal."""
+    e_k, e_g = np.exp(kat.astype(np.float64)), np.exp(got.astype(np.float64))
+    fmax = e_k.max(axis=1, keepdims=True)
+    excess = np.abs(e_g - e_k) - rel * e_k - abs_of_frame_max * fmax
+    return float((excess / fmax).max())
+
+
+def test_fbank_oracle_matches_independent_kaldi_spec_vectors():
+    """oracle/frontend_oracle.kaldi_fbank (restating torchaudio's float32 port) against the known-answer vectors of the independent
+    float64 implementation written from Kaldi's compute-fbank-feats definition: nine waveforms incl. silence (every bin at the
+    epsilon floor), a DC offset, a full-scale square wave, exactly one frame, a chirp, an impulse."""
+    meta, z = _kat()
+    for name in meta["names"]:
+        w, kat = z["wave_" + name], z["fbank_" + name]
+        fb = FO.kaldi_fbank(w.astype(np.float32) * np.float32(meta["scale"]))
+        assert fb.shape == kat.shape, name
+        assert _fbank_agrees(fb, kat) <= 0.0, (name, _fbank_agrees(fb, kat))
+        floor = kat < -15.9                        # empty mel bins (no FFT bin inside the triangle) and silence: log(eps) exactly
+        assert np.array_equal(fb[floor], kat[floor]), name
+
+
+@pytest.mark.gpu
+def test_fbank_device_matches_independent_kaldi_spec_vectors():
+    """The HIP kernel (fp32 FFT in LDS) against the same known-answer vectors."""
+    from crab_amd import frontend
+    from tests.util import record_parity
+    meta, z = _kat()
+    for name in meta["names"]:
+        w, kat = z["wave_" + name], z["fbank_" + name]
+        fb = frontend.kaldi_fbank(torch.from_numpy(w).cuda(), in_scale=float(meta["scale"]))[0].cpu().numpy()
+        assert fb.shape == kat.shape, name
+        ex = _fbank_agrees(fb, kat, rel=2e-3, abs_of_frame_max=1e-8)
+        strong = kat > kat.max(axis=1, keepdims=True) - 12.0          # bins within e^-12 of the frame's strongest
+        record_parity(f"kaldi fbank vs Kaldi-spec KAT, {name}: max |dlog| over bins within e^-12 of the frame max",
+                      float(np.abs(fb - kat)[strong].max()) if strong.any() else 0.0, 1.0, 2e-3)
+        assert ex <= 0.0, (name, ex)
+        floor = kat < -15.9
+        assert np.abs(fb[floor] - kat[floor]).max() < 1e-5 if floor.any() else True, name
