@@ -1,0 +1,82 @@
+// Experiment: how fast can one CU pull bytes through the LDS-DMA path (global_load_lds_dwordx4), from L2-resident data (every block
+// re-reads the same small buffer, like the activation operand of the decode GEMMs) and from HBM (every block streams its own region)?
+// 512-thread blocks (8 waves), one block per CU; each wave keeps DEPTH batches of P 1-KiB pieces in flight into its own LDS region,
+// no barriers, no compute.  mode 0: all pieces from the shared buffer; 1: all from the private stream; 2: 2 shared : 1 private.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+typedef __attribute__((address_space(3))) void* lds_vptr;
+typedef const __attribute__((address_space(1))) void* gbl_vptr;
+
+template <int P, int DEPTH, int NT>
+__global__ __launch_bounds__(512) void ldsdma_kernel(const char* __restrict__ shared_buf, long shared_bytes, const char* __restrict__ priv, long priv_per_block,
+                                                       int iters, int mode, uint32_t* out) {
+    __shared__ __attribute__((aligned(16))) char lds[8 * DEPTH * P * 1024];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const char* pb = priv + (long)blockIdx.x * priv_per_block;
+    long so = ((long)wave * P * 1024) % shared_bytes, po = (long)wave * P * 1024;
+    int slot = 0;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            const bool usePriv = mode == 1 || (mode == 2 && i == P - 1);
+            const char* src = usePriv ? pb + po : shared_buf + so;
+            char* dst = &lds[((wave * DEPTH + slot) * P + i) * 1024];
+            if (NT && usePriv) __builtin_amdgcn_global_load_lds((gbl_vptr)(src + lane * 16), (lds_vptr)dst, 16, 0, 2);
+            else __builtin_amdgcn_global_load_lds((gbl_vptr)(src + lane * 16), (lds_vptr)dst, 16, 0, 0);
+            if (usePriv) { po += 8 * 1024; if (po + 1024 > priv_per_block) po = (long)wave * 1024; }
+            else { so += 8 * 1024; if (so + 1024 > shared_bytes) so = (long)wave * 1024; }
+        }
+        slot = slot + 1 == DEPTH ? 0 : slot + 1;
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P * (DEPTH - 1)) : "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lds[threadIdx.x] == 123 && iters < 0) out[0] = 1;
+}
+
+extern "C" void launch_ldsdma(void* stream, const void* sh, long shb, const void* pr, long ppb, int blocks, int iters, int mode, int p, int depth, int nt, void* out) {
+#define L(P_, D_) { if (nt) hipLaunchKernelGGL((ldsdma_kernel<P_, D_, 1>), dim3(blocks), dim3(512), 0, (hipStream_t)stream, (const char*)sh, shb, (const char*)pr, ppb, iters, mode, (uint32_t*)out); \
+                    else hipLaunchKernelGGL((ldsdma_kernel<P_, D_, 0>), dim3(blocks), dim3(512), 0, (hipStream_t)stream, (const char*)sh, shb, (const char*)pr, ppb, iters, mode, (uint32_t*)out); }
+    if (p == 3 && depth == 2) L(3, 2) else if (p == 3 && depth == 4) L(3, 4) else if (p == 3 && depth == 6) L(3, 6)
+    else if (p == 6 && depth == 2) L(6, 2) else if (p == 6 && depth == 3) L(6, 3) else L(3, 3)
+#undef L
+}
+
+// ---- vector loads to registers from the L2-resident shared buffer viewed as [256 rows][K] bf16 (ld = K elements):
+// frag = 1: MFMA-fragment shape (a wave instruction = 16 rows x 64 B: lane l reads row r0 + (l & 15), 16 B at chunk (l >> 4));
+// frag = 0: whole lines (a wave instruction = 8 rows x 128 B: lane l reads row r0 + (l >> 3), chunk (l & 7)).
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+template <int FRAG, int UN>
+__global__ __launch_bounds__(512) void vload_kernel(const char* __restrict__ buf, int K, int iters, uint32_t* out) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const long ldb = (long)K * 2;
+    u32x4 acc = {0u, 0u, 0u, 0u};
+    // each wave owns 32 rows (as the decode GEMM); per 64-wide K slot it needs 32 rows x 128 B = 4 instructions either way
+    const int nslots = K / 64;
+    int slot = (blockIdx.x * 7) % nslots;
+    for (int it = 0; it < iters; ++it) {
+        u32x4 v[UN * 4];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const long k0 = (long)slot * 128;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                long off;
+                if (FRAG) off = (long)(wave * 32 + (i >> 1) * 16 + (lane & 15)) * ldb + k0 + (i & 1) * 64 + (lane >> 4) * 16;
+                else off = (long)(wave * 32 + i * 8 + (lane >> 3)) * ldb + k0 + (lane & 7) * 16;
+                v[u * 4 + i] = *reinterpret_cast<const u32x4*>(buf + off);
+            }
+            slot = slot + 1 == nslots ? 0 : slot + 1;
+        }
+#pragma unroll
+        for (int j = 0; j < UN * 4; ++j) acc ^= v[j];
+    }
+    if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345678u) out[blockIdx.x] = 1;
+}
+extern "C" void launch_vload(void* stream, const void* buf, int K, int blocks, int iters, int frag, int un, void* out) {
+#define V(F_, U_) hipLaunchKernelGGL((vload_kernel<F_, U_>), dim3(blocks), dim3(512), 0, (hipStream_t)stream, (const char*)buf, K, iters, (uint32_t*)out)
+    if (frag) { if (un == 1) V(1, 1); else if (un == 2) V(1, 2); else V(1, 4); }
+    else { if (un == 1) V(0, 1); else if (un == 2) V(0, 2); else V(0, 4); }
+#undef V
+}
