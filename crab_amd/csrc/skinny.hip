@@ -285,6 +285,81 @@ __global__ __launch_bounds__(256) void lora_mix_reduce_kernel(const float* __res
         for (int j = 0; j < r; ++j) u[pj * nl * r + i * r + j] = f2bf(scaling * e[i] * inv * t[nl + j]);
 }
 
+
+// Row-owning router for the decode regime (64 < M <= 256, one row per clip): ONE launch instead of the partial-product + mix pair.
+// One block per row keeps the row in registers (8 columns = 16 bytes per lane per chunk), walks the used rows of [R;A] with all
+// of a trip's loads in flight, reduces the per-thread partials through LDS in a fixed order (deterministic), then one thread per
+// projection applies the fp32 softmax over the route logits and writes u = scaling * p_i * (x A^T)_j in bf16
+// (peft_hyper/tuners/lora.py:346-350).  Same arithmetic as the router fused into splitk_epilogue_norm_kernel (gemm.hip).
+template <int MAXQ>                                            // K <= MAXQ * 2048
+__global__ __launch_bounds__(256) void lora_route_row_kernel(const bf16_t* __restrict__ X, long ldx, const bf16_t* __restrict__ RA, long ldra, int K,
+                                                             bf16_t* __restrict__ U, long ldu, int nproj, int nl, int r, int ucols, float scaling) {
+    __shared__ float tp[48][257];
+    __shared__ float tq[48][4];
+    __shared__ float T[48];
+    const int m = blockIdx.x, tid = threadIdx.x;
+    float xv[MAXQ][8];
+#pragma unroll
+    for (int q = 0; q < MAXQ; ++q) {
+        const int n = (tid + q * 256) * 8;
+        u32x4 w = {0u, 0u, 0u, 0u};
+        if (n < K) w = *reinterpret_cast<const u32x4*>(X + (long)m * ldx + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { xv[q][2 * e] = lo_bf(w[e]); xv[q][2 * e + 1] = hi_bf(w[e]); }
+    }
+    const int rows = nproj * (nl + r);                         // <= 48
+#define ROUTE_TRIPS(RPT_, NTRIPS_)                                                                        \
+    for (int tr = 0; tr < (NTRIPS_); ++tr) {                                                              \
+        const int c0 = tr * (RPT_);                                                                       \
+        float p[RPT_];                                                                                    \
+        _Pragma("unroll") for (int cc = 0; cc < (RPT_); ++cc) p[cc] = 0.f;                                \
+        _Pragma("unroll") for (int q = 0; q < MAXQ; ++q) {                                                \
+            const int n = (tid + q * 256) * 8;                                                            \
+            if (n < K) {                                                                                  \
+                u32x4 w[RPT_];                                                                            \
+                _Pragma("unroll") for (int cc = 0; cc < (RPT_); ++cc)                                     \
+                    w[cc] = c0 + cc < rows ? *reinterpret_cast<const u32x4*>(RA + (long)(c0 + cc) * ldra + n) : u32x4{0u, 0u, 0u, 0u};   \
+                _Pragma("unroll") for (int cc = 0; cc < (RPT_); ++cc) {                                   \
+                    float a = 0.f;                                                                        \
+                    _Pragma("unroll") for (int e = 0; e < 4; ++e)                                         \
+                        a += xv[q][2 * e] * lo_bf(w[cc][e]) + xv[q][2 * e + 1] * hi_bf(w[cc][e]);         \
+                    p[cc] += a;                                                                           \
+                }                                                                                         \
+            }                                                                                             \
+        }                                                                                                 \
+        _Pragma("unroll") for (int cc = 0; cc < (RPT_); ++cc)                                             \
+            if (c0 + cc < rows) tp[c0 + cc][tid] = p[cc];                                                 \
+    }
+    if (nl + r == 11) { ROUTE_TRIPS(11, nproj) }
+    else { ROUTE_TRIPS(8, (rows + 7) / 8) }
+#undef ROUTE_TRIPS
+    __syncthreads();
+    if (tid < rows * 4) {
+        const int c = tid >> 2, qt = tid & 3;
+        float a = 0.f;
+        for (int i = qt * 64; i < qt * 64 + 64; ++i) a += tp[c][i];
+        tq[c][qt] = a;
+    }
+    __syncthreads();
+    if (tid < rows) T[tid] = (tq[tid][0] + tq[tid][1]) + (tq[tid][2] + tq[tid][3]);
+    __syncthreads();
+    if (tid > nproj) return;
+    bf16_t* u = U + (long)m * ldu;
+    const int used = nproj * nl * r;
+    if (tid == nproj) {
+        for (int c = used; c < ucols; ++c) u[c] = 0;
+        return;
+    }
+    const float* t = &T[tid * (nl + r)];
+    float e[8], mx = -INFINITY;
+    for (int i = 0; i < nl; ++i) mx = fmaxf(mx, t[i]);
+    float sum = 0.f;
+    for (int i = 0; i < nl; ++i) { e[i] = expf(t[i] - mx); sum += e[i]; }
+    const float inv = 1.0f / sum;
+    for (int i = 0; i < nl; ++i)
+        for (int j = 0; j < r; ++j) u[tid * nl * r + i * r + j] = f2bf(scaling * e[i] * inv * t[nl + j]);
+}
+
 }  // namespace
 
 // called from crab_gemm_bf16 (gemm.hip) for unbatched problems with M <= 128
@@ -350,6 +425,15 @@ extern "C" int crab_hyperlora_route(crab_ctx* ctx, void* stream, const void* X, 
     if (nl + r > 16 || nproj < 1 || nproj > 3 || ucols < nproj * nl * r) return crab_fail(ctx, CRAB_E_UNSUPPORTED, "hyperlora_route: nl+r <= 16, nproj <= 3");
     const int tcols = ((nproj * (nl + r) + 15) / 16) * 16;        // RA must hold tcols rows (zero padded)
     if (crab_hyperlora_route_workspace(M, K, tcols) > workspace_bytes) return crab_fail(ctx, CRAB_E_WORKSPACE, "hyperlora_route: workspace too small");
+    // decode regime (one row per clip, 64 < M <= 256): one row-owning launch (~6 us) instead of the partial-product + mix pair (~11 us)
+    if (M > 64 && M <= 256 && K <= 6 * 2048 && nl <= 8 && ((uintptr_t)X & 15) == 0 && ((uintptr_t)RA & 15) == 0) {
+        hipStream_t s0 = (hipStream_t)stream;
+#define RR_LAUNCH(Q_) hipLaunchKernelGGL((lora_route_row_kernel<Q_>), dim3(M), dim3(256), 0, s0, (const bf16_t*)X, (long)ldx, (const bf16_t*)RA, (long)ldra, K, \
+                                         (bf16_t*)U, (long)ldu, nproj, nl, r, ucols, scaling)
+        if (K <= 2 * 2048) RR_LAUNCH(2); else if (K <= 4 * 2048) RR_LAUNCH(4); else RR_LAUNCH(6);
+#undef RR_LAUNCH
+        return crab_check_launch(ctx, "lora_route_row_kernel");
+    }
     int MT, nslices;
     route_cfg(M, K, &MT, &nslices);
     int mblocks = (M + 64 * MT - 1) / (64 * MT);
