@@ -262,14 +262,40 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
 #pragma unroll
     for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
 
-    for (int j = grp; j < ctx; j += 16) {
-        float kx[EPL], vx[EPL];
-        if (EPL == 8) {
-            u32x4 kw = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kb + (long)j * HD));
-            u32x4 vw = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vb + (long)j * HD));
+    if (EPL == 8) {
+        // software-pipelined: the K / V rows of key j + 16 are requested before key j is consumed, so every lane keeps two 16-byte
+        // K and two 16-byte V loads in flight (the loop-carried online-softmax chain otherwise serialises load -> use -> load)
+        u32x4 kw = {0u, 0u, 0u, 0u}, vw = {0u, 0u, 0u, 0u};
+        if (grp < ctx) {
+            kw = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kb + (long)grp * HD));
+            vw = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vb + (long)grp * HD));
+        }
+        for (int j = grp; j < ctx; j += 16) {
+            u32x4 kn = kw, vn = vw;
+            if (j + 16 < ctx) {
+                kn = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kb + (long)(j + 16) * HD));
+                vn = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vb + (long)(j + 16) * HD));
+            }
+            float kx[EPL], vx[EPL];
 #pragma unroll
             for (int e = 0; e < 4; ++e) { kx[2 * e] = lo_bf(kw[e]); kx[2 * e + 1] = hi_bf(kw[e]); vx[2 * e] = lo_bf(vw[e]); vx[2 * e + 1] = hi_bf(vw[e]); }
-        } else {
+            float sdot = 0.f;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) sdot += qv[e] * kx[e];
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) sdot += __shfl_xor(sdot, off, 64);
+            float mn = fmaxf(m, sdot);
+            float a = __expf(m - mn), pw = __expf(sdot - mn);
+            l = l * a + pw;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) acc[e] = acc[e] * a + pw * vx[e];
+            m = mn;
+            kw = kn; vw = vn;
+        }
+    } else {
+    for (int j = grp; j < ctx; j += 16) {
+        float kx[EPL], vx[EPL];
+        {
             u32x2 kw = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(kb + (long)j * HD));
             u32x2 vw = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(vb + (long)j * HD));
 #pragma unroll
@@ -286,6 +312,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
 #pragma unroll
         for (int e = 0; e < EPL; ++e) acc[e] = acc[e] * a + pw * vx[e];
         m = mn;
+    }
     }
     if (sub == 0) { sm[grp] = m; sl[grp] = l; }
 #pragma unroll
