@@ -205,7 +205,54 @@ __global__ __launch_bounds__(512) void gemm_dec_kernel(GemmDP p) {
     bf16x8_t w0[TN], x0[TM], w1[TN], x1[TM];
     READ_FRAGS(w0, x0, 0, 0)                                    // k step 0 of slot 0
     int sl = 0;                                                 // t % NS, carried
-    for (int t = 0; t < nk; ++t) {
+    int t = 0;
+    // ---- steady state: the refill slot lies wholly inside the first K segment (carried pointers, no conditions).  The LDS-DMA
+    // instructions of the refill are INTERLEAVED with the MFMAs of k step 1 (one piece per output column tile), so that their issue
+    // time - ~50 cycles each, 5-6 per wave per slot - runs under the matrix pipe instead of in front of it (issued as a burst right
+    // after the barrier they left the pipe idle on both waves of a SIMD: the two run in lockstep)
+    const int n_steady = max(0, nfast - NS);
+    for (; t < n_steady; ++t) {
+        const int base = sl * SLOT_ELEMS;
+        MFMA_GROUP(w0, x0, 0, TN / 3)
+        __builtin_amdgcn_sched_barrier(0);
+        READ_FRAGS(w1, x1, base, 1)
+        __builtin_amdgcn_sched_barrier(0);
+        MFMA_GROUP(w0, x0, TN / 3, TN)
+        __builtin_amdgcn_sched_barrier(0);
+        WAIT_KEEP(NS - 2)
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        const int nsl = sl + 1 == NS ? 0 : sl + 1;
+        READ_FRAGS(w0, x0, nsl * SLOT_ELEMS, 0)                 // k step 0 of slot t+1, one MFMA group ahead
+        __builtin_amdgcn_sched_barrier(0);
+        // (literal piece indices: a loop-indexed form put the carried pointers into scratch)
+#define PIECE(I_)                                                                                         \
+    {                                                                                                     \
+        if constexpr ((I_) < PAW) {                                                                       \
+            DMA_A(fptr[I_], &lds[base + ldso[I_]]);                                                       \
+            fptr[I_] += fadv[I_];                                                                         \
+        } else if constexpr ((I_) < NPW) {                                                                \
+            if ((I_) - PAW < nb) {                                                                        \
+                DMA_B(fptr[I_], &lds[base + ldso[I_]]);                                                   \
+                fptr[I_] += fadv[I_];                                                                     \
+            }                                                                                             \
+        }                                                                                                 \
+    }
+#define STEP(NI_) MFMA_GROUP(w1, x1, NI_, (NI_) + 1)
+#define SB __builtin_amdgcn_sched_barrier(0);
+        static_assert((TN == 6 && NPW == 6) || (TN == 4 && NPW == 5), "piece schedule below is written for BN 96 / 64");
+        if constexpr (TN == 6) {
+            STEP(0) PIECE(0) SB STEP(1) PIECE(1) SB STEP(2) PIECE(2) SB STEP(3) PIECE(3) SB STEP(4) PIECE(4) SB STEP(5) PIECE(5) SB
+        } else {
+            STEP(0) PIECE(0) SB STEP(1) PIECE(1) SB STEP(2) PIECE(2) PIECE(3) SB STEP(3) PIECE(4) SB
+        }
+#undef PIECE
+#undef STEP
+#undef SB
+        sl = nsl;
+    }
+    // ---- tail: K tail / second K segment slots (generic staging) and the drain
+    for (; t < nk; ++t) {
         const int base = sl * SLOT_ELEMS;
         // k step 1 of this slot: its reads are issued BEHIND the first MFMAs of k step 0, so that the compiler's wait for w0 / x0
         // (read one group ago, long complete; it emits lgkmcnt(0) at this loop header whatever the order) does not also wait for

@@ -80,3 +80,40 @@ extern "C" void launch_vload(void* stream, const void* buf, int K, int blocks, i
     else { if (un == 1) V(0, 1); else if (un == 2) V(0, 2); else V(0, 4); }
 #undef V
 }
+
+// ---- LDS-DMA from an L2-resident [rows][K] bf16 matrix (ld = K): piece shape HALF = 1: 16 rows x 64 B (the ring kernel's 32-wide K tiles),
+// HALF = 0: 8 rows x 128 B (whole lines, 64-wide K slots).  Each wave walks its own 32 rows along K; P pieces per batch, DEPTH batches in flight.
+template <int HALF, int P, int DEPTH>
+__global__ __launch_bounds__(512) void ldsdma_tile_kernel(const char* __restrict__ buf, int K, int iters, uint32_t* out) {
+    __shared__ __attribute__((aligned(16))) char lds[8 * DEPTH * P * 1024];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long ldb = (long)K * 2;
+    const int row = wave * 32 + (HALF ? (lane >> 2) : (lane >> 3));
+    const int cb = HALF ? (lane & 3) * 16 : (lane & 7) * 16;
+    const int kbytes = HALF ? 64 : 128;
+    const int rows_per_piece = HALF ? 16 : 8;
+    long koff = ((blockIdx.x * 5) % 16) * 256;
+    int slot = 0;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            // pieces of a batch alternate over the wave's 32 rows, then advance along K
+            const int rsub = (i % (32 / rows_per_piece)) * rows_per_piece;
+            const char* src = buf + (long)(row + rsub) * ldb + koff + cb;
+            char* dst = &lds[((wave * DEPTH + slot) * P + i) * 1024];
+            __builtin_amdgcn_global_load_lds((gbl_vptr)src, (lds_vptr)dst, 16, 0, 0);
+            if ((i + 1) % (32 / rows_per_piece) == 0) { koff += kbytes; if (koff + kbytes > ldb) koff = 0; }
+        }
+        slot = slot + 1 == DEPTH ? 0 : slot + 1;
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P * (DEPTH - 1)) : "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lds[threadIdx.x] == 123 && iters < 0) out[0] = 1;
+}
+extern "C" void launch_ldsdma_tile(void* stream, const void* buf, int K, int blocks, int iters, int half, int depth, void* out) {
+    if (half) { if (depth == 2) hipLaunchKernelGGL((ldsdma_tile_kernel<1, 4, 2>), dim3(blocks), dim3(512), 0, (hipStream_t)stream, (const char*)buf, K, iters, (uint32_t*)out);
+                else hipLaunchKernelGGL((ldsdma_tile_kernel<1, 4, 4>), dim3(blocks), dim3(512), 0, (hipStream_t)stream, (const char*)buf, K, iters, (uint32_t*)out); }
+    else { if (depth == 2) hipLaunchKernelGGL((ldsdma_tile_kernel<0, 4, 2>), dim3(blocks), dim3(512), 0, (hipStream_t)stream, (const char*)buf, K, iters, (uint32_t*)out);
+           else hipLaunchKernelGGL((ldsdma_tile_kernel<0, 4, 4>), dim3(blocks), dim3(512), 0, (hipStream_t)stream, (const char*)buf, K, iters, (uint32_t*)out); }
+}
