@@ -25,7 +25,11 @@ __device__ __forceinline__ float act_c(float x) {
     return x;
 }
 
-template <int TM, int TN, int ACT>
+// WIDE (bf16 C, 16-byte aligned rows): the natural store of this fragment layout is 8 bytes per lane (4 bytes with the SwiGLU pair
+// epilogue) - 16 rows x 32 (16) bytes per wave instruction - and the store tail of a 256x256 tile is issue-bound (cdna guide T21).  Lanes
+// 16 / 32 apart hold the neighbouring column groups of the same row, so v_permlane16_swap / v_permlane32_swap regroup them into ONE
+// 16-byte store per lane: a pair of column tiles -> two swaps, the four SwiGLU column tiles of a row -> a 4x4 transpose in four swaps.
+template <int TM, int TN, int ACT, bool WIDE>
 __device__ __forceinline__ void full_impl(const f32x4_t (&acc)[TN][TM], int m_lane, int n_lane, const bf16_t* bias, const bf16_t* R, long ldr,
                                           float rs, void* Cv, long coff, long ldc, int c_fp32) {
     float bv[TN][4];
@@ -35,10 +39,29 @@ __device__ __forceinline__ void full_impl(const f32x4_t (&acc)[TN][TM], int m_la
         if (bias) bw = *reinterpret_cast<const u32x2*>(bias + n_lane + ni * 16);
         bv[ni][0] = lo_bf(bw.x); bv[ni][1] = hi_bf(bw.x); bv[ni][2] = lo_bf(bw.y); bv[ni][3] = hi_bf(bw.y);
     }
+    const int fg = threadIdx.x >> 4 & 3;                    // n_lane = tile column + 4 * fg
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi) {
         const long rowC = coff + (long)(m_lane + mi * 16) * ldc + n_lane;
         const long rowR = (long)(m_lane + mi * 16) * ldr + n_lane;
+        if constexpr (ACT == ACT_SWIGLU_PAIR && WIDE && TN == 4) {
+            uint32_t v[4];
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const float g0 = acc[ni][mi][0] + bv[ni][0], u0 = acc[ni][mi][1] + bv[ni][1];
+                const float g1 = acc[ni][mi][2] + bv[ni][2], u1 = acc[ni][mi][3] + bv[ni][3];
+                v[ni] = pack_bf2(g0 / (1.0f + __expf(-g0)) * u0, g1 / (1.0f + __expf(-g1)) * u1);
+            }
+            // 4x4 transpose over (lane row fg, column tile ni): lane fg ends with tile fg's outputs of the four lane rows = 8 columns
+            auto a02 = __builtin_amdgcn_permlane32_swap(v[0], v[2], false, false);
+            auto a13 = __builtin_amdgcn_permlane32_swap(v[1], v[3], false, false);
+            auto b01 = __builtin_amdgcn_permlane16_swap(a02[0], a13[0], false, false);
+            auto b23 = __builtin_amdgcn_permlane16_swap(a02[1], a13[1], false, false);
+            const long oc = coff + (long)(m_lane + mi * 16) * ldc + ((n_lane - 4 * fg) >> 1) + fg * 8;
+            *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(Cv) + oc) = u32x4{b01[0], b01[1], b23[0], b23[1]};
+            continue;
+        }
+        u32x2 pend = {0u, 0u};
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni) {
             if (ACT == ACT_SWIGLU_PAIR) {              // columns (gate, up, gate, up) -> two outputs at column n/2 (no residual)
@@ -58,6 +81,14 @@ __device__ __forceinline__ void full_impl(const f32x4_t (&acc)[TN][TM], int m_la
             }
             if (c_fp32) {
                 *reinterpret_cast<float4*>(reinterpret_cast<float*>(Cv) + rowC + ni * 16) = make_float4(v0, v1, v2, v3);
+            } else if constexpr (WIDE && TN % 2 == 0) {
+                // column tiles ni (even) and ni + 1 are exchanged between the even and odd lane rows: one 16-byte store per pair
+                u32x2 oa; oa.x = pack_bf2(v0, v1); oa.y = pack_bf2(v2, v3);
+                if ((ni & 1) == 0) { pend.x = oa.x; pend.y = oa.y; continue; }
+                auto rx = __builtin_amdgcn_permlane16_swap(pend.x, oa.x, false, false);
+                auto ry = __builtin_amdgcn_permlane16_swap(pend.y, oa.y, false, false);
+                const long oc = coff + (long)(m_lane + mi * 16) * ldc + (n_lane - 4 * fg) + (ni - 1 + (fg & 1)) * 16 + (fg >> 1) * 8;
+                *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(Cv) + oc) = u32x4{rx[0], ry[0], rx[1], ry[1]};
             } else {
                 u32x2 o; o.x = pack_bf2(v0, v1); o.y = pack_bf2(v2, v3);
                 *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(Cv) + rowC + ni * 16) = o;
@@ -68,18 +99,27 @@ __device__ __forceinline__ void full_impl(const f32x4_t (&acc)[TN][TM], int m_la
 
 }  // namespace crab_epi
 
+template <int TM, int TN, bool WIDE>
+__device__ __forceinline__ void gemm_epilogue_full_w(const f32x4_t (&acc)[TN][TM], int act, int m_lane, int n_lane, const bf16_t* bias,
+                                                     const bf16_t* R, long ldr, float rs, void* C, long coff, long ldc, int c_fp32) {
+    switch (act) {
+        case ACT_NONE: crab_epi::full_impl<TM, TN, ACT_NONE, WIDE>(acc, m_lane, n_lane, bias, R, ldr, rs, C, coff, ldc, c_fp32); break;
+        case ACT_GELU: crab_epi::full_impl<TM, TN, ACT_GELU, WIDE>(acc, m_lane, n_lane, bias, R, ldr, rs, C, coff, ldc, c_fp32); break;
+        case ACT_QUICK_GELU: crab_epi::full_impl<TM, TN, ACT_QUICK_GELU, WIDE>(acc, m_lane, n_lane, bias, R, ldr, rs, C, coff, ldc, c_fp32); break;
+        case ACT_RELU: crab_epi::full_impl<TM, TN, ACT_RELU, WIDE>(acc, m_lane, n_lane, bias, R, ldr, rs, C, coff, ldc, c_fp32); break;
+        case ACT_SWIGLU_PAIR: crab_epi::full_impl<TM, TN, ACT_SWIGLU_PAIR, WIDE>(acc, m_lane, n_lane, bias, R, ldr, rs, C, coff, ldc, c_fp32); break;
+        default: crab_epi::full_impl<TM, TN, ACT_SILU, WIDE>(acc, m_lane, n_lane, bias, R, ldr, rs, C, coff, ldc, c_fp32); break;
+    }
+}
+
 // requires: rows m_lane .. m_lane+16*TM-1 < M, columns n_lane .. +16*TN-1 < N, ldc/coff (and ldr) multiples of 4
 template <int TM, int TN>
 __device__ __forceinline__ void gemm_epilogue_full(const f32x4_t (&acc)[TN][TM], int act, int m_lane, int n_lane, const bf16_t* bias,
                                                    const bf16_t* R, long ldr, float rs, void* C, long coff, long ldc, int c_fp32) {
-    switch (act) {
-        case ACT_NONE: crab_epi::full_impl<TM, TN, ACT_NONE>(acc, m_lane, n_lane, bias, R, ldr, rs, C, coff, ldc, c_fp32); break;
-        case ACT_GELU: crab_epi::full_impl<TM, TN, ACT_GELU>(acc, m_lane, n_lane, bias, R, ldr, rs, C, coff, ldc, c_fp32); break;
-        case ACT_QUICK_GELU: crab_epi::full_impl<TM, TN, ACT_QUICK_GELU>(acc, m_lane, n_lane, bias, R, ldr, rs, C, coff, ldc, c_fp32); break;
-        case ACT_RELU: crab_epi::full_impl<TM, TN, ACT_RELU>(acc, m_lane, n_lane, bias, R, ldr, rs, C, coff, ldc, c_fp32); break;
-        case ACT_SWIGLU_PAIR: crab_epi::full_impl<TM, TN, ACT_SWIGLU_PAIR>(acc, m_lane, n_lane, bias, R, ldr, rs, C, coff, ldc, c_fp32); break;
-        default: crab_epi::full_impl<TM, TN, ACT_SILU>(acc, m_lane, n_lane, bias, R, ldr, rs, C, coff, ldc, c_fp32); break;
-    }
+    // 16-byte stores need bf16 C with 16-byte aligned rows (wave-uniform condition)
+    const bool wide = !c_fp32 && (ldc & 7) == 0 && (coff & 7) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0;
+    if (wide) gemm_epilogue_full_w<TM, TN, true>(acc, act, m_lane, n_lane, bias, R, ldr, rs, C, coff, ldc, c_fp32);
+    else gemm_epilogue_full_w<TM, TN, false>(acc, act, m_lane, n_lane, bias, R, ldr, rs, C, coff, ldc, c_fp32);
 }
 
 namespace crab_epi {
