@@ -9,7 +9,9 @@ namespace {
 
 // ------------------------------------------------------------------------------------------------ norms
 // One wave per row (4 rows per 256-thread block); the row stays in registers between the two passes.
-template <bool RMS>
+// MAXV = vectors of 8 per lane the row may need: 16 (D <= 8192) or 4 (D <= 2048: CLIP / BEATs / Q-Former widths - a quarter of the
+// registers, so twice the resident waves for rows that are only 2-4 KB long)
+template <bool RMS, int MAXV = 16>
 __global__ __launch_bounds__(256) void norm_kernel(const bf16_t* __restrict__ x, long ldx, const bf16_t* __restrict__ w,
                                                    const bf16_t* __restrict__ b, bf16_t* __restrict__ y, long ldy,
                                                    int M, int D, float eps) {
@@ -18,7 +20,6 @@ __global__ __launch_bounds__(256) void norm_kernel(const bf16_t* __restrict__ x,
     if (row >= M) return;
     const bf16_t* xr = x + (long)row * ldx;
     bf16_t* yr = y + (long)row * ldy;
-    constexpr int MAXV = 16;                       // up to 16 vectors of 8 per lane: D <= 8192
     u32x4 v[MAXV];
     const int nvec = D >> 3;                       // D % 8 == 0 (checked on the host)
     float s1 = 0.f, s2 = 0.f;
@@ -622,8 +623,12 @@ int crab_rmsnorm(crab_ctx* ctx, void* stream, const void* x, int64_t ldx, const 
     if (!ctx) return CRAB_E_INVALID;
     if (!x || !w || !y || M <= 0) return crab_fail(ctx, CRAB_E_INVALID, "rmsnorm: bad argument");
     if ((D & 7) || D > 8192 || (ldx & 7) || (ldy & 7)) return crab_fail(ctx, CRAB_E_INVALID, "rmsnorm: D must be a multiple of 8 and <= 8192");
-    hipLaunchKernelGGL((norm_kernel<true>), dim3(cdiv(M, 4)), dim3(256), 0, S_(stream), (const bf16_t*)x, (long)ldx, (const bf16_t*)w,
-                       (const bf16_t*)nullptr, (bf16_t*)y, (long)ldy, M, D, eps);
+    if (D <= 2048)
+        hipLaunchKernelGGL((norm_kernel<true, 4>), dim3(cdiv(M, 4)), dim3(256), 0, S_(stream), (const bf16_t*)x, (long)ldx, (const bf16_t*)w,
+                           (const bf16_t*)nullptr, (bf16_t*)y, (long)ldy, M, D, eps);
+    else
+        hipLaunchKernelGGL((norm_kernel<true>), dim3(cdiv(M, 4)), dim3(256), 0, S_(stream), (const bf16_t*)x, (long)ldx, (const bf16_t*)w,
+                           (const bf16_t*)nullptr, (bf16_t*)y, (long)ldy, M, D, eps);
     return crab_check_launch(ctx, "rmsnorm");
 }
 
@@ -632,8 +637,12 @@ int crab_layernorm(crab_ctx* ctx, void* stream, const void* x, int64_t ldx, cons
     if (!ctx) return CRAB_E_INVALID;
     if (!x || !w || !y || M <= 0) return crab_fail(ctx, CRAB_E_INVALID, "layernorm: bad argument");
     if ((D & 7) || D > 8192 || (ldx & 7) || (ldy & 7)) return crab_fail(ctx, CRAB_E_INVALID, "layernorm: D must be a multiple of 8 and <= 8192");
-    hipLaunchKernelGGL((norm_kernel<false>), dim3(cdiv(M, 4)), dim3(256), 0, S_(stream), (const bf16_t*)x, (long)ldx, (const bf16_t*)w,
-                       (const bf16_t*)b, (bf16_t*)y, (long)ldy, M, D, eps);
+    if (D <= 2048)
+        hipLaunchKernelGGL((norm_kernel<false, 4>), dim3(cdiv(M, 4)), dim3(256), 0, S_(stream), (const bf16_t*)x, (long)ldx, (const bf16_t*)w,
+                           (const bf16_t*)b, (bf16_t*)y, (long)ldy, M, D, eps);
+    else
+        hipLaunchKernelGGL((norm_kernel<false>), dim3(cdiv(M, 4)), dim3(256), 0, S_(stream), (const bf16_t*)x, (long)ldx, (const bf16_t*)w,
+                           (const bf16_t*)b, (bf16_t*)y, (long)ldy, M, D, eps);
     return crab_check_launch(ctx, "layernorm");
 }
 
