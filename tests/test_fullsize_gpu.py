@@ -166,7 +166,7 @@ def test_generate_avs_full_width_vs_cpu_oracle():
     feats = O.visual_encoder(image[None].to(BF).float(), W, ocfg.clip, emulate=BF)
     ref = O.seg_module(torch.stack([ohid[:, j] for j in picks], 1), feats[:2], ['s4'], W)
     r_ = _rel(res['pred_masks'][0].cpu(), ref[0], "full-width generate_avs masks vs CPU oracle pipeline")
-    assert r_ < 4e-2, r_
+    assert r_ < 6.5e-3, r_                 # measured 3.2e-3
 
 
 def test_full_width_layer_prefill_and_greedy_vs_cpu_oracle():
