@@ -263,34 +263,48 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
     for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
 
     if (EPL == 8) {
-        // software-pipelined: the K / V rows of key j + 16 are requested before key j is consumed, so every lane keeps two 16-byte
-        // K and two 16-byte V loads in flight (the loop-carried online-softmax chain otherwise serialises load -> use -> load)
-        u32x4 kw = {0u, 0u, 0u, 0u}, vw = {0u, 0u, 0u, 0u};
+        // TWO keys per trip (j and j + 16) with the next pair requested before the current one is consumed: every lane keeps four
+        // 16-byte K and four 16-byte V loads in flight, and the loop-carried online-softmax chain (max, two exps, rescale of the
+        // accumulators) is paid once per two keys
+        const u32x4 z4 = {0u, 0u, 0u, 0u};
+        u32x4 k0 = z4, v0 = z4, k1 = z4, v1 = z4;
         if (grp < ctx) {
-            kw = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kb + (long)grp * HD));
-            vw = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vb + (long)grp * HD));
+            k0 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kb + (long)grp * HD));
+            v0 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vb + (long)grp * HD));
         }
-        for (int j = grp; j < ctx; j += 16) {
-            u32x4 kn = kw, vn = vw;
-            if (j + 16 < ctx) {
-                kn = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kb + (long)(j + 16) * HD));
-                vn = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vb + (long)(j + 16) * HD));
+        if (grp + 16 < ctx) {
+            k1 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kb + (long)(grp + 16) * HD));
+            v1 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vb + (long)(grp + 16) * HD));
+        }
+        for (int j = grp; j < ctx; j += 32) {
+            u32x4 kn0 = z4, vn0 = z4, kn1 = z4, vn1 = z4;
+            if (j + 32 < ctx) {
+                kn0 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kb + (long)(j + 32) * HD));
+                vn0 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vb + (long)(j + 32) * HD));
             }
-            float kx[EPL], vx[EPL];
+            if (j + 48 < ctx) {
+                kn1 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kb + (long)(j + 48) * HD));
+                vn1 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vb + (long)(j + 48) * HD));
+            }
+            float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { kx[2 * e] = lo_bf(kw[e]); kx[2 * e + 1] = hi_bf(kw[e]); vx[2 * e] = lo_bf(vw[e]); vx[2 * e + 1] = hi_bf(vw[e]); }
-            float sdot = 0.f;
+            for (int e = 0; e < 4; ++e) {
+                s0 += qv[2 * e] * lo_bf(k0[e]) + qv[2 * e + 1] * hi_bf(k0[e]);
+                s1 += qv[2 * e] * lo_bf(k1[e]) + qv[2 * e + 1] * hi_bf(k1[e]);
+            }
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) sdot += qv[e] * kx[e];
+            for (int off = 8; off > 0; off >>= 1) { s0 += __shfl_xor(s0, off, 64); s1 += __shfl_xor(s1, off, 64); }
+            const bool has1 = j + 16 < ctx;                      // group-uniform
+            const float mn = fmaxf(m, has1 ? fmaxf(s0, s1) : s0);
+            const float a = __expf(m - mn), p0 = __expf(s0 - mn), p1 = has1 ? __expf(s1 - mn) : 0.f;
+            l = l * a + (p0 + p1);
 #pragma unroll
-            for (int off = 8; off > 0; off >>= 1) sdot += __shfl_xor(sdot, off, 64);
-            float mn = fmaxf(m, sdot);
-            float a = __expf(m - mn), pw = __expf(sdot - mn);
-            l = l * a + pw;
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) acc[e] = acc[e] * a + pw * vx[e];
+            for (int e = 0; e < 4; ++e) {
+                acc[2 * e] = acc[2 * e] * a + (p0 * lo_bf(v0[e]) + p1 * lo_bf(v1[e]));
+                acc[2 * e + 1] = acc[2 * e + 1] * a + (p0 * hi_bf(v0[e]) + p1 * hi_bf(v1[e]));
+            }
             m = mn;
-            kw = kn; vw = vn;
+            k0 = kn0; v0 = vn0; k1 = kn1; v1 = vn1;
         }
     } else {
     for (int j = grp; j < ctx; j += 16) {
