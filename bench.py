@@ -142,7 +142,7 @@ def cpu_baseline(args):
         for _ in range(4):
             _, _, cache = O.decoder_forward(e1, Wd, dec, cache, last_only=True)
 
-    rec(f"decode4_{NL}l", timed(decode4, 9))            # short sample (< 1 s), the noisiest: 9 repetitions
+    rec(f"decode4_{NL}l", timed(decode4, 15))           # short sample (< 1 s), the noisiest and 88 % of the extrapolated time: 15 repetitions
     h = rnd(1, 4096)
     rec("lm_head", timed(lambda: torch.nn.functional.linear(h, Wd["lm_head.weight"])))
     del Wd
@@ -163,7 +163,7 @@ def cpu_baseline(args):
         pass
     return {"value": 1.0 / per_clip(t), "unit": "clips/s", "cores": nth, "kind": "port", "cpu": cpu,
             "value_range": [round(1.0 / per_clip(hi), 6), round(1.0 / per_clip(lo), 6)],
-            "sample": (f"oracle fp32 eager, one untimed warm-up then median of {NREP} per sample (9 for the decode sample): 1 CLIP frame x23 layers (x8, +7.5% for "
+            "sample": (f"oracle fp32 eager, one untimed warm-up then median of {NREP} per sample (15 for the decode sample): 1 CLIP frame x23 layers (x8, +7.5% for "
                        f"BEATs/Q-Formers by FLOPs), {NL}-layer full-width hyper-LoRA decoder prefill S=702 (x{32 // NL} layers) and 4 decode "
                        f"tokens (x64 tokens, x{32 // NL} layers); median s: {json.dumps({k: round(v, 3) for k, v in t.items()})}; "
                        f"min s: {json.dumps({k: round(v, 3) for k, v in lo.items()})}; max s: {json.dumps({k: round(v, 3) for k, v in hi.items()})}")}
