@@ -50,12 +50,49 @@ class AttnDesc(C.Structure):
     ]
 
 
+class LinearGroup(C.Structure):
+    """crab_linear_group"""
+    _fields_ = [
+        ("W", C.c_void_p), ("bias", C.c_void_p), ("RA", C.c_void_p), ("B2", C.c_void_p),
+        ("ldw", C.c_int64), ("ldra", C.c_int64), ("ldb2", C.c_int64),
+        ("N", C.c_int32), ("K", C.c_int32), ("nproj", C.c_int32), ("nl", C.c_int32), ("r", C.c_int32), ("tcols", C.c_int32),
+        ("ucols", C.c_int32), ("scaling", C.c_float),
+    ]
+
+
+class LlamaLayer(C.Structure):
+    """crab_llama_layer"""
+    _fields_ = [
+        ("qkv", LinearGroup), ("o", LinearGroup), ("gu", LinearGroup), ("down", LinearGroup),
+        ("post_attention_norm_w", C.c_void_p), ("next_norm_w", C.c_void_p), ("next_qkv", C.POINTER(LinearGroup)),
+        ("H", C.c_int32), ("Hk", C.c_int32), ("d", C.c_int32), ("rms_eps", C.c_float),
+    ]
+
+
+class LlamaIO(C.Structure):
+    """crab_llama_io"""
+    _fields_ = [
+        ("x", C.c_void_p), ("h", C.c_void_p), ("qkv", C.c_void_p), ("att", C.c_void_p), ("act", C.c_void_p), ("u", C.c_void_p),
+        ("u2", C.c_void_p),
+        ("ldx", C.c_int64), ("ldh", C.c_int64), ("ldqkv", C.c_int64), ("ldatt", C.c_int64), ("ldact", C.c_int64), ("ldu", C.c_int64),
+        ("route_ws", C.c_void_p), ("route_ws_bytes", C.c_int64), ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_int64),
+        ("rope_tab", C.c_void_p), ("k_cache", C.c_void_p), ("v_cache", C.c_void_p), ("cache_layer_stride", C.c_int64),
+        ("vt", C.c_void_p), ("vt_ld", C.c_int64), ("pos_dev", C.c_void_p),
+        ("B", C.c_int32), ("S", C.c_int32), ("Tmax", C.c_int32), ("pos0", C.c_int32), ("u_qkv_ready", C.c_int32),
+    ]
+
+
 # every symbol include/crab_hip.h declares: name -> (restype, argtypes)
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 SYMBOLS = {
     "crab_abi_version": (_i, []),
     "crab_sizeof_gemm_desc": (_i, []),
     "crab_sizeof_attn_desc": (_i, []),
+    "crab_sizeof_llama_layer": (_i, []),
+    "crab_sizeof_llama_io": (_i, []),
+    "crab_llama_layer_prefill": (_i, [_vp, _vp, C.POINTER(LlamaLayer), C.POINTER(LlamaIO), _i]),
+    "crab_llama_layer_decode": (_i, [_vp, _vp, C.POINTER(LlamaLayer), C.POINTER(LlamaIO), _i]),
+    "crab_llama_layers": (_i, [_vp, _vp, C.POINTER(LlamaLayer), _i, C.POINTER(LlamaIO)]),
     "crab_ctx_create": (_i, [_i, C.POINTER(_vp)]),
     "crab_ctx_destroy": (None, [_vp]),
     "crab_last_error": (C.c_char_p, [_vp]),

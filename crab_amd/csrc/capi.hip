@@ -4,7 +4,7 @@
 
 extern "C" {
 
-int crab_abi_version(void) { return 3; }   // 2: fused RoPE / KV-append fields in crab_gemm_desc; 3: next-group router fields
+int crab_abi_version(void) { return 4; }   // 2: fused RoPE / KV-append fields in crab_gemm_desc; 3: next-group router fields; 4: crab_llama_layer*
 
 int crab_sizeof_gemm_desc(void) { return (int)sizeof(crab_gemm_desc); }
 int crab_sizeof_attn_desc(void) { return (int)sizeof(crab_attn_desc); }

@@ -1,0 +1,201 @@
+// Decoder-layer sequencing behind the C-ABI: crab_llama_layer_prefill / crab_llama_layer_decode / crab_llama_layers
+// (include/crab_hip.h, SURVEY.md 8b "fused blocks").  Host code only: every launch goes through the library's own entry points,
+// in the order crab_amd/decoder.py issued them per layer before this file existed (and still does when a per-launch profiler is
+// attached), so the two sequencers are interchangeable bit for bit (tests/test_model_gpu.py::test_native_layer_sequencer_*).
+//
+// One layer (models/modeling_llama.py:805-827, models/qwen/modeling_qwen2.py:202-317; hyper-LoRA peft_hyper/tuners/lora.py:338-350):
+//     u    = route(h) for q|k|v                     (skipped when the previous layer's epilogue produced it: io->u_qkv_ready)
+//     qkv  = [h | u] . [Wqkv | Bcat]^T (+ bias)      decode: RoPE + KV append ride on this GEMM;  prefill: crab_qkv_rope_split
+//     att  = flash attention (prefill, causal) | KV-streaming attention (decode, ctx read from pos_dev)
+//     x   += [att | u] . [Wo | Bcat]^T ; h = rmsnorm(x) * post_attention_layernorm   (+ the gate|up router ahead, M <= 256)
+//     act  = silu(gate(h)) * up(h)                   one GEMM over the interleaved gate|up rows, SwiGLU in its epilogue
+//     x   += [act | u] . [Wdown | Bcat]^T ; h = rmsnorm(x) * next_norm_w              (+ the next layer's q|k|v router ahead)
+#include "crab_internal.h"
+#include <math.h>
+
+namespace {
+
+struct GroupCall {
+    const void* x; int64_t ldx;              // input rows [M, K]
+    void* out; int64_t ldc;                  // output rows
+    const void* residual; int64_t ldr;       // optional residual (added after the activation)
+    int act;
+    const void* norm_w; void* norm_out; int64_t ld_norm; float eps;   // optional fused post-RMSNorm
+    const crab_linear_group* route_next; void* route_u;                // optional router of the next group on the post-norm rows
+    const void* u_ready;                     // router output of THIS group already computed by a producer epilogue
+    bool rope;                               // decode: RoPE + KV append fused behind this (q|k|v) GEMM
+};
+
+int check_group(crab_ctx* ctx, const crab_linear_group* g, const char* name) {
+    if (!g->W || g->N <= 0 || g->K <= 0 || g->ldw < g->K) {
+        char msg[128];
+        snprintf(msg, sizeof(msg), "llama_layer: group %s needs W, positive N / K and ldw >= K", name);
+        return crab_fail(ctx, CRAB_E_INVALID, msg);
+    }
+    if (g->RA && (!g->B2 || g->nproj < 1 || g->nl < 1 || g->r < 1 || g->tcols < g->nproj * (g->nl + g->r) || (g->tcols & 15) ||
+                  g->ucols < g->nproj * g->nl * g->r || (g->ucols & 7))) {
+        char msg[160];
+        snprintf(msg, sizeof(msg), "llama_layer: adapter of group %s needs B2, tcols = pad16(nproj (nl + r)) and ucols >= nproj nl r, multiple of 8", name);
+        return crab_fail(ctx, CRAB_E_INVALID, msg);
+    }
+    return CRAB_OK;
+}
+
+// PackedLinearGroup.__call__ (crab_amd/peft_hyper.py): router (unless ready) + the K-extended GEMM with its fused epilogues
+int run_group(crab_ctx* ctx, void* stream, const crab_linear_group* g, const crab_llama_io* io, const crab_llama_layer* L, int M,
+              const GroupCall& c, void* k_cache, void* v_cache) {
+    crab_gemm_desc d;
+    memset(&d, 0, sizeof(d));
+    d.A = c.x; d.lda = c.ldx;
+    d.B = g->W; d.ldb = g->ldw;
+    d.C = c.out; d.ldc = c.ldc;
+    d.bias = g->bias;
+    d.R = c.residual; d.ldr = c.ldr;
+    d.M = M; d.N = g->N; d.K = g->K;
+    d.act = c.act;
+    d.res_scale = 1.0f;
+    d.batch = 1; d.nb0 = 1;
+    if (M <= 256) { d.workspace = io->splitk_ws; d.workspace_bytes = io->splitk_ws_bytes; }
+    if (c.norm_w) { d.norm_w = c.norm_w; d.norm_out = c.norm_out; d.ld_norm = c.ld_norm; d.norm_eps = c.eps; }
+    if (c.route_next && c.route_next->RA && c.norm_w && M <= 256) {
+        const crab_linear_group* n = c.route_next;
+        d.route_RA = n->RA; d.route_ldra = n->ldra; d.route_U = c.route_u; d.route_ldu = io->ldu;
+        d.route_nproj = n->nproj; d.route_nl = n->nl; d.route_r = n->r; d.route_ucols = n->ucols; d.route_scaling = n->scaling;
+    }
+    if (c.rope) {
+        d.rope_tab = io->rope_tab; d.rope_k_cache = k_cache; d.rope_v_cache = v_cache; d.rope_pos_dev = io->pos_dev;
+        d.rope_H = L->H; d.rope_Hk = L->Hk; d.rope_d = L->d; d.rope_Tmax = io->Tmax; d.rope_pos0 = io->pos0;
+    }
+    if (g->RA) {
+        const void* u = c.u_ready;
+        if (!u) {
+            int rc = crab_hyperlora_route(ctx, stream, c.x, c.ldx, g->RA, g->ldra, M, g->K, g->nproj, g->nl, g->r, io->u, io->ldu, g->ucols,
+                                          g->scaling, io->route_ws, io->route_ws_bytes);
+            if (rc) return rc;
+            u = io->u;
+        }
+        d.A2 = u; d.lda2 = io->ldu; d.B2 = g->B2; d.ldb2 = g->ldb2; d.K2 = g->ucols;
+    }
+    return crab_gemm_bf16(ctx, stream, &d);
+}
+
+int check_io(crab_ctx* ctx, const crab_llama_layer* L, const crab_llama_io* io, bool prefill) {
+    if (!ctx) return CRAB_E_INVALID;
+    if (!L || !io) return crab_fail(ctx, CRAB_E_INVALID, "llama_layer: null layer / io");
+    if (L->H <= 0 || L->Hk <= 0 || L->d <= 0 || L->H % L->Hk) return crab_fail(ctx, CRAB_E_INVALID, "llama_layer: H, Hk, d must be positive, H % Hk == 0");
+    if (!L->post_attention_norm_w || !L->next_norm_w) return crab_fail(ctx, CRAB_E_INVALID, "llama_layer: post_attention_norm_w / next_norm_w missing");
+    int rc;
+    if ((rc = check_group(ctx, &L->qkv, "qkv")) || (rc = check_group(ctx, &L->o, "o")) || (rc = check_group(ctx, &L->gu, "gate|up")) ||
+        (rc = check_group(ctx, &L->down, "down")))
+        return rc;
+    const int D = L->o.N, I = L->down.K, Nq = (L->H + 2 * L->Hk) * L->d;
+    if (L->qkv.N != Nq || L->qkv.K != D || L->o.K != L->H * L->d || L->gu.K != D || L->gu.N != 2 * I || L->down.N != D)
+        return crab_fail(ctx, CRAB_E_INVALID, "llama_layer: group shapes do not chain (qkv [(H + 2 Hk) d, D], o [D, H d], gate|up [2 I, D], down [D, I])");
+    if (io->B <= 0 || io->S <= 0 || io->Tmax <= 0 || io->pos0 < 0) return crab_fail(ctx, CRAB_E_INVALID, "llama_layer: B, S, Tmax must be positive");
+    if (!io->x || !io->h || !io->qkv || !io->att || !io->act || !io->k_cache || !io->v_cache || !io->rope_tab)
+        return crab_fail(ctx, CRAB_E_INVALID, "llama_layer: x, h, qkv, att, act, k_cache, v_cache and rope_tab are required");
+    if (io->ldx < D || io->ldh < D || io->ldqkv < Nq || io->ldatt < L->H * L->d || io->ldact < I)
+        return crab_fail(ctx, CRAB_E_INVALID, "llama_layer: a leading dimension is smaller than its row");
+    const bool lora = L->qkv.RA || L->o.RA || L->gu.RA || L->down.RA;
+    if (lora && (!io->u || !io->u2 || !io->route_ws)) return crab_fail(ctx, CRAB_E_INVALID, "llama_layer: adapted groups need u, u2 and route_ws");
+    if (prefill) {
+        if (!io->vt || io->vt_ld < io->S) return crab_fail(ctx, CRAB_E_INVALID, "llama_layer_prefill: vt [B, Hk, d, vt_ld >= S] is required");
+        if (io->pos0 + io->S > io->Tmax) return crab_fail(ctx, CRAB_E_INVALID, "llama_layer_prefill: rows do not fit the KV cache");
+    } else {
+        if (io->S != 1) return crab_fail(ctx, CRAB_E_INVALID, "llama_layer_decode: one row per sequence (S == 1)");
+        if (!io->pos_dev && io->pos0 >= io->Tmax) return crab_fail(ctx, CRAB_E_INVALID, "llama_layer_decode: position outside the KV cache");
+    }
+    return CRAB_OK;
+}
+
+int run_layer(crab_ctx* ctx, void* stream, const crab_llama_layer* L, crab_llama_io* io, int layer_index, bool prefill) {
+    const int B = io->B, S = io->S, M = B * S;
+    const int H = L->H, Hk = L->Hk, d = L->d;
+    uint16_t* kc = (uint16_t*)io->k_cache + (int64_t)layer_index * io->cache_layer_stride;
+    uint16_t* vc = (uint16_t*)io->v_cache + (int64_t)layer_index * io->cache_layer_stride;
+    const float scale = (float)(1.0 / sqrt((double)d));   // double, then rounded once: what crab_amd/decoder.py passes
+    int rc;
+    // ---- q|k|v
+    GroupCall q{};
+    q.x = io->h; q.ldx = io->ldh; q.out = io->qkv; q.ldc = io->ldqkv; q.act = CRAB_ACT_NONE;
+    q.u_ready = (io->u_qkv_ready && L->qkv.RA) ? io->u2 : nullptr;
+    q.rope = !prefill;
+    if ((rc = run_group(ctx, stream, &L->qkv, io, L, M, q, kc, vc))) return rc;
+    if (prefill) {
+        if ((rc = crab_qkv_rope_split(ctx, stream, io->qkv, io->ldqkv, io->rope_tab, kc, vc, io->vt, io->vt_ld, B, S, H, Hk, d, io->Tmax, io->pos0,
+                                      io->pos_dev)))
+            return rc;
+        crab_attn_desc a;
+        memset(&a, 0, sizeof(a));
+        a.q = io->qkv; a.k = kc; a.vt = io->vt; a.o = io->att;
+        a.q_bs = (int64_t)S * io->ldqkv; a.q_hs = d; a.q_ss = io->ldqkv;
+        a.k_bs = (int64_t)Hk * io->Tmax * d; a.k_hs = (int64_t)io->Tmax * d; a.k_ss = d;
+        a.vt_bs = (int64_t)Hk * d * io->vt_ld; a.vt_hs = (int64_t)d * io->vt_ld; a.vt_ds = io->vt_ld;
+        a.o_bs = (int64_t)S * io->ldatt; a.o_ss = io->ldatt;
+        a.B = B; a.H = H; a.Hk = Hk; a.Sq = S; a.Skv = io->pos0 + S; a.head_dim = d; a.causal = 1; a.scale = scale;
+        if ((rc = crab_attn_fwd(ctx, stream, &a))) return rc;
+    } else {
+        if ((rc = crab_attn_decode(ctx, stream, io->qkv, io->ldqkv, kc, vc, io->att, io->ldatt, B, H, Hk, d, io->Tmax, io->pos0 + 1,
+                                   io->pos_dev, scale)))
+            return rc;
+    }
+    // ---- o: x += o(att); h = rmsnorm(x) * post_attention_layernorm (+ the gate|up router ahead in the decode regime)
+    const bool ahead_gu = L->gu.RA != nullptr && M <= 256;
+    GroupCall o{};
+    o.x = io->att; o.ldx = io->ldatt; o.out = io->x; o.ldc = io->ldx; o.residual = io->x; o.ldr = io->ldx; o.act = CRAB_ACT_NONE;
+    o.norm_w = L->post_attention_norm_w; o.norm_out = io->h; o.ld_norm = io->ldh; o.eps = L->rms_eps;
+    if (ahead_gu) { o.route_next = &L->gu; o.route_u = io->u2; }
+    if ((rc = run_group(ctx, stream, &L->o, io, L, M, o, nullptr, nullptr))) return rc;
+    // ---- gate|up with SwiGLU in the epilogue
+    GroupCall g{};
+    g.x = io->h; g.ldx = io->ldh; g.out = io->act; g.ldc = io->ldact; g.act = CRAB_ACT_SWIGLU_PAIR;
+    g.u_ready = ahead_gu ? io->u2 : nullptr;
+    if ((rc = run_group(ctx, stream, &L->gu, io, L, M, g, nullptr, nullptr))) return rc;
+    // ---- down: x += down(act); h = rmsnorm(x) * next_norm_w (+ the next layer's q|k|v router ahead)
+    const bool ahead_q = L->next_qkv != nullptr && L->next_qkv->RA != nullptr && M <= 256;
+    GroupCall w{};
+    w.x = io->act; w.ldx = io->ldact; w.out = io->x; w.ldc = io->ldx; w.residual = io->x; w.ldr = io->ldx; w.act = CRAB_ACT_NONE;
+    w.norm_w = L->next_norm_w; w.norm_out = io->h; w.ld_norm = io->ldh; w.eps = L->rms_eps;
+    if (ahead_q) { w.route_next = L->next_qkv; w.route_u = io->u2; }
+    if ((rc = run_group(ctx, stream, &L->down, io, L, M, w, nullptr, nullptr))) return rc;
+    io->u_qkv_ready = ahead_q ? 1 : 0;
+    return CRAB_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int crab_sizeof_llama_layer(void) { return (int)sizeof(crab_llama_layer); }
+int crab_sizeof_llama_io(void) { return (int)sizeof(crab_llama_io); }
+
+int crab_llama_layer_prefill(crab_ctx* ctx, void* stream, const crab_llama_layer* layer, crab_llama_io* io, int layer_index) {
+    int rc = check_io(ctx, layer, io, true);
+    if (rc) return rc;
+    if (layer_index < 0) return crab_fail(ctx, CRAB_E_INVALID, "llama_layer_prefill: negative layer index");
+    return run_layer(ctx, stream, layer, io, layer_index, true);
+}
+
+int crab_llama_layer_decode(crab_ctx* ctx, void* stream, const crab_llama_layer* layer, crab_llama_io* io, int layer_index) {
+    int rc = check_io(ctx, layer, io, false);
+    if (rc) return rc;
+    if (layer_index < 0) return crab_fail(ctx, CRAB_E_INVALID, "llama_layer_decode: negative layer index");
+    return run_layer(ctx, stream, layer, io, layer_index, false);
+}
+
+int crab_llama_layers(crab_ctx* ctx, void* stream, const crab_llama_layer* layers, int n_layers, crab_llama_io* io) {
+    if (!ctx) return CRAB_E_INVALID;
+    if (!layers || n_layers <= 0 || !io) return crab_fail(ctx, CRAB_E_INVALID, "llama_layers: null / empty layer table");
+    const bool prefill = io->vt != nullptr;
+    for (int l = 0; l < n_layers; ++l) {
+        int rc = check_io(ctx, &layers[l], io, prefill);
+        if (rc) return rc;
+    }
+    for (int l = 0; l < n_layers; ++l) {
+        int rc = run_layer(ctx, stream, &layers[l], io, l, prefill);
+        if (rc) return rc;
+    }
+    return CRAB_OK;
+}
+
+}  // extern "C"

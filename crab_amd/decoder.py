@@ -20,10 +20,13 @@ from typing import List, Optional
 import torch
 from torch import nn
 
-from . import ops
+import ctypes as C
+
+from . import _lib, ops
 from .peft_hyper import PackedLinearGroup
 
 BF16 = torch.bfloat16
+NATIVE_LAYERS = True      # False: issue every launch of a layer from Python (A/B runs and the sequencer-equivalence tests)
 
 
 @dataclass
@@ -158,6 +161,7 @@ class GenerationEngine:
         self._dec = {}
         self._ws = {}
         self._kv = {}
+        self._table = None
 
     def _rope_tab(self, need: int) -> torch.Tensor:
         if self._rope is None or self._rope.shape[0] < need or self._rope.device != self.device:
@@ -247,6 +251,55 @@ class GenerationEngine:
             self._kv[key] = (torch.empty(shape, device=self.device, dtype=BF16), torch.empty(shape, device=self.device, dtype=BF16))
         return self._kv[key]
 
+    # ------------------------------------------------------------------ the layer table of the native sequencer
+    def _layer_table(self):
+        """crab_llama_layer[n_layers] (include/crab_hip.h) over the packed groups: borrowed pointers, rebuilt when a buffer moved."""
+        layers = self.model.layers
+        fp = tuple(t.data_ptr() if t is not None else 0 for l in layers for g in l.groups() for t in (g.W, g.RA, g.B2, g.bias)) + \
+            tuple(w.data_ptr() for l in layers for w in (l.input_layernorm.weight, l.post_attention_layernorm.weight)) + \
+            (self.model.norm.weight.data_ptr(),)
+        hit = getattr(self, "_table", None)
+        if hit is not None and hit[0] == fp:
+            return hit[1]
+        c = self.cfg
+        tab = (_lib.LlamaLayer * len(layers))()
+
+        def fill(dst, g: PackedLinearGroup):
+            dst.W, dst.ldw, dst.N, dst.K = g.W.data_ptr(), g.W.stride(0), g.N, g.K
+            dst.bias = g.bias.data_ptr() if g.bias is not None else None
+            if g.RA is not None:
+                dst.RA, dst.ldra, dst.B2, dst.ldb2 = g.RA.data_ptr(), g.RA.stride(0), g.B2.data_ptr(), g.B2.stride(0)
+                dst.nproj, dst.nl, dst.r, dst.tcols, dst.ucols, dst.scaling = len(g.names), g.nl, g.r, g.t_cols, g.u_cols, g.scaling
+        for i, l in enumerate(layers):
+            e = tab[i]
+            fill(e.qkv, l.self_attn._qkv); fill(e.o, l.self_attn._o); fill(e.gu, l.mlp._gu); fill(e.down, l.mlp._down)
+            e.post_attention_norm_w = l.post_attention_layernorm.weight.data_ptr()
+            last = i + 1 == len(layers)
+            e.next_norm_w = (self.model.norm.weight if last else layers[i + 1].input_layernorm.weight).data_ptr()
+            if not last:
+                e.next_qkv = C.pointer(tab[i + 1].qkv)
+            e.H, e.Hk, e.d, e.rms_eps = c.num_attention_heads, c.num_key_value_heads, c.head_dim, c.rms_norm_eps
+        self._table = (fp, tab)
+        return tab
+
+    def _layers_native(self, ws: _Workspace, B: int, S: int, kc: torch.Tensor, vc: torch.Tensor, b0: int, Tmax: int, pos0: int,
+                       pos_dev: Optional[torch.Tensor], vt: Optional[torch.Tensor]):
+        """The whole stack through ONE C call (crab_llama_layers, csrc/llama_layer.hip): the same launches in the same order as the
+        per-launch Python sequence below, which is kept for the runs that time individual kernels (ops.PROFILER)."""
+        io = _lib.LlamaIO()
+        io.x, io.h, io.qkv, io.att, io.act, io.u, io.u2 = (t.data_ptr() for t in (ws.x, ws.h, ws.qkv, ws.att, ws.act, ws.u, ws.u2))
+        io.ldx, io.ldh, io.ldqkv, io.ldatt, io.ldact, io.ldu = (t.stride(0) for t in (ws.x, ws.h, ws.qkv, ws.att, ws.act, ws.u))
+        io.route_ws, io.route_ws_bytes = ws.t.data_ptr(), ws.t.numel()
+        sk = ops._splitk_workspace(self.device)
+        io.splitk_ws, io.splitk_ws_bytes = sk.data_ptr(), sk.numel()
+        io.rope_tab = self._rope_tab(Tmax).data_ptr()
+        io.k_cache, io.v_cache, io.cache_layer_stride = kc[0, b0].data_ptr(), vc[0, b0].data_ptr(), kc.stride(0)
+        if vt is not None:
+            io.vt, io.vt_ld = vt.data_ptr(), vt.stride(-2)
+        io.pos_dev = pos_dev.data_ptr() if pos_dev is not None else None
+        io.B, io.S, io.Tmax, io.pos0, io.u_qkv_ready = B, S, Tmax, pos0, 0
+        ops.llama_layers(self._layer_table(), len(self.model.layers), io, self.device)
+
     # ------------------------------------------------------------------ one pass over the layers
     def _layers(self, ws: _Workspace, B: int, S: int, kc: torch.Tensor, vc: torch.Tensor, b0: int, Tmax: int, pos0: int,
                 pos_dev: Optional[torch.Tensor], vt: Optional[torch.Tensor]):
@@ -261,6 +314,10 @@ class GenerationEngine:
         ldq = qkv.stride(0)
         layers = self.model.layers
         ops.rmsnorm(x, layers[0].input_layernorm.weight, c.rms_norm_eps, out=h)
+        timed = ops.PROFILER is not None and not torch.cuda.is_current_stream_capturing()
+        if NATIVE_LAYERS and not timed and kc.is_contiguous() and vc.is_contiguous() and (vt is not None or S == 1):
+            self._layers_native(ws, B, S, kc, vc, b0, Tmax, pos0, pos_dev, vt)
+            return x, h
         u_qkv = None                                   # router output for the q|k|v group when a producer epilogue made it
         for li, layer in enumerate(layers):
             a, m = layer.self_attn, layer.mlp

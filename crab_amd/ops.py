@@ -292,6 +292,12 @@ def attn_decode(q, k_cache, v_cache, o, B, H, Hk, head_dim, Tmax, ctx_len, scale
     return o
 
 
+def llama_layers(table, n_layers: int, io, device):
+    """crab_llama_layers: every layer of a decoder stack (prefill when io.vt is set, one decode step otherwise) in one call."""
+    d = device.index or 0
+    _lib.check(_lib.load().crab_llama_layers(_lib.ctx(d), _stream(), table, n_layers, C.byref(io)), d)
+
+
 def swiglu(gu: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     d = _dev(gu)
     M, I2 = gu.shape

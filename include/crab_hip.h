@@ -39,7 +39,10 @@ int crab_sizeof_gemm_desc(void);
 int crab_sizeof_attn_desc(void);
 
 /* activation codes for epilogues */
-enum { CRAB_ACT_NONE = 0, CRAB_ACT_GELU = 1, CRAB_ACT_QUICK_GELU = 2, CRAB_ACT_RELU = 3, CRAB_ACT_SILU = 4 };
+enum { CRAB_ACT_NONE = 0, CRAB_ACT_GELU = 1, CRAB_ACT_QUICK_GELU = 2, CRAB_ACT_RELU = 3, CRAB_ACT_SILU = 4,
+       /* crab_gemm_bf16 only: B rows interleaved (gate_i, up_i); C[m, j] = silu(v[m, 2j]) * v[m, 2j+1], C has N/2 columns
+        * (LlamaMLP, modeling_llama.py:269, with gate_proj / up_proj packed into one GEMM) */
+       CRAB_ACT_SWIGLU_PAIR = 5 };
 
 /* ---------------------------------------------------------------------------------------------
  * GEMM:  C[M,N] = res_scale * R[M,N] + act( A[M,K] . B[N,K]^T + A2[M,K2] . B2[N,K2]^T + bias[N] )
@@ -198,6 +201,66 @@ int crab_greedy_select(crab_ctx* ctx, void* stream, const float* logits, int64_t
                        int64_t* out_ids, int64_t ld_out, const int32_t* step_dev, int32_t* finished, int eos_id, int pad_id,
                        int min_new_tokens);
 int crab_advance(crab_ctx* ctx, void* stream, int32_t* pos_dev, int32_t* step_dev);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused decoder blocks: the launch sequence of ONE LlamaDecoderLayer / Qwen2DecoderLayer with hyper-LoRA
+ * adapted projections (models/modeling_llama.py:805-827 = rmsnorm -> self_attn -> residual -> rmsnorm -> mlp -> residual;
+ * models/qwen/modeling_qwen2.py:202-317; peft_hyper/tuners/lora.py:338-350) behind one call, so that a C caller runs a
+ * prefill pass or a decode step without re-implementing the sequencing of crab_amd/decoder.py:
+ *     crab_rmsnorm(x, layer[0] input_layernorm) -> h ; crab_llama_layers(...) ; lm_head = crab_gemm_bf16(h, ...) ;
+ *     crab_greedy_select ; crab_advance.
+ * The functions only issue launches of the entry points above on `stream` (capturable into a HIP graph); they keep no state.
+ *
+ * crab_linear_group: the projections that consume one input, packed (crab_amd/peft_hyper.py PackedLinearGroup):
+ *     W [N, K] (rows of the members stacked: q|k|v; o; gate|up INTERLEAVED (gate_i, up_i); down), optional bias [N],
+ *     RA [tcols, K] = per member nl route rows then r lora_A rows, zero padded to tcols = round_up(nproj*(nl+r), 16),
+ *     B2 [N, ucols] = block-structured lora_B (member p, expert i, rank j at column p*nl*r + i*r + j), ucols = round_up(nproj*nl*r, 32).
+ *     RA == NULL: plain linear.
+ * crab_llama_layer: the four groups of a layer, the RMSNorm weight behind the attention block, and - because the norm that
+ *     FOLLOWS a layer is fused into its down-projection epilogue - the NEXT norm's weight (next layer's input_layernorm, or
+ *     model.norm after the last layer) and the next layer's q|k|v group (its router is evaluated ahead when M <= 256).
+ * crab_llama_io: caller-owned activations for M = B*S rows.  In: x = residual stream, h = rmsnorm(x) * this layer's
+ *     input_layernorm.  Out: x updated, h = rmsnorm(x) * next_norm_w.  qkv / att / act / u / u2 are scratch.
+ *     k_cache / v_cache: rows of these B sequences in layer 0's cache [B, Hk, Tmax, d]; layer l lives cache_layer_stride
+ *     ELEMENTS further.  Prefill (S rows per sequence at positions pos0 .. pos0+S-1): vt [B, Hk, d, vt_ld] receives V^T for
+ *     the flash kernel.  Decode (S == 1): position = pos0 + pos_dev[0] (pos_dev may be NULL), RoPE + KV append are fused
+ *     behind the q|k|v GEMM.  u_qkv_ready (in/out): u2 holds the q|k|v router output of the layer about to run.
+ *     route_ws: crab_hyperlora_route_workspace(M, max K, max tcols) bytes; splitk_ws: the crab_gemm_desc.workspace (M <= 256). */
+typedef struct {
+    const void* W; const void* bias; const void* RA; const void* B2;
+    int64_t ldw, ldra, ldb2;
+    int32_t N, K, nproj, nl, r, tcols, ucols;
+    float scaling;     /* lora_alpha / r */
+} crab_linear_group;
+
+typedef struct {
+    crab_linear_group qkv, o, gu, down;
+    const void* post_attention_norm_w;
+    const void* next_norm_w;
+    const crab_linear_group* next_qkv;   /* NULL after the last layer */
+    int32_t H, Hk, d;
+    float rms_eps;
+} crab_llama_layer;
+
+typedef struct {
+    void* x; void* h; void* qkv; void* att; void* act; void* u; void* u2;
+    int64_t ldx, ldh, ldqkv, ldatt, ldact, ldu;
+    void* route_ws; int64_t route_ws_bytes;
+    void* splitk_ws; int64_t splitk_ws_bytes;
+    const float* rope_tab;               /* crab_rope_table, >= Tmax positions */
+    void* k_cache; void* v_cache; int64_t cache_layer_stride;
+    void* vt; int64_t vt_ld;             /* prefill only; vt == NULL selects the decode sequence in crab_llama_layers */
+    const int32_t* pos_dev;
+    int32_t B, S, Tmax, pos0;
+    int32_t u_qkv_ready;
+} crab_llama_io;
+
+int crab_sizeof_llama_layer(void);
+int crab_sizeof_llama_io(void);
+int crab_llama_layer_prefill(crab_ctx* ctx, void* stream, const crab_llama_layer* layer, crab_llama_io* io, int layer_index);
+int crab_llama_layer_decode(crab_ctx* ctx, void* stream, const crab_llama_layer* layer, crab_llama_io* io, int layer_index);
+/* all layers of a stack in order (layers[l].next_qkv == &layers[l+1].qkv); prefill when io->vt != NULL, decode otherwise */
+int crab_llama_layers(crab_ctx* ctx, void* stream, const crab_llama_layer* layers, int n_layers, crab_llama_io* io);
 
 /* ---------------------------------------------------------------------------------------------
  * SegModule pixel path (models/multimodal_encoder.py:268-543, 891-1444).  Feature maps are token-major [h*w, C] bf16.

@@ -30,7 +30,7 @@ def test_every_declared_symbol_is_exported_and_bound():
         assert hasattr(lib, name), f"{name} declared in include/ but not exported"
     missing = declared - set(_lib.SYMBOLS)
     assert not missing, f"ctypes bindings missing for {missing}"
-    assert lib.crab_abi_version() >= 3
+    assert lib.crab_abi_version() >= 4
 
 
 def test_ops_fail_loudly_without_gpu_tensors():
@@ -47,6 +47,8 @@ def test_struct_mirrors_match_the_compiled_layout():
     lib = _lib.load()
     assert C.sizeof(_lib.GemmDesc) == lib.crab_sizeof_gemm_desc()
     assert C.sizeof(_lib.AttnDesc) == lib.crab_sizeof_attn_desc()
+    assert C.sizeof(_lib.LlamaLayer) == lib.crab_sizeof_llama_layer()
+    assert C.sizeof(_lib.LlamaIO) == lib.crab_sizeof_llama_io()
 
 
 def test_entry_points_reject_null_context_and_operands_without_a_gpu():
@@ -56,6 +58,10 @@ def test_entry_points_reject_null_context_and_operands_without_a_gpu():
     g = _lib.GemmDesc()
     assert lib.crab_gemm_bf16(None, None, C.byref(g)) < 0
     assert lib.crab_rmsnorm(None, None, None, 0, None, None, 0, 1, 8, C.c_float(1e-5)) < 0
+    layer, io = _lib.LlamaLayer(), _lib.LlamaIO()
+    assert lib.crab_llama_layers(None, None, C.byref(layer), 1, C.byref(io)) < 0
+    assert lib.crab_llama_layer_prefill(None, None, C.byref(layer), C.byref(io), 0) < 0
+    assert lib.crab_llama_layer_decode(None, None, C.byref(layer), C.byref(io), 0) < 0
     assert lib.crab_bicubic_ksize(0, 10) < 0 and lib.crab_bicubic_ksize(480, 224) == 2 * 5 + 1
     assert lib.crab_kaldi_fbank_frames(16000) == 98
     assert lib.crab_hyperlora_route_workspace(256, 4096, 48) > 0 and lib.crab_groupnorm_workspace(2, 65536, 32) > 0

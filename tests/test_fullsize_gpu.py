@@ -286,3 +286,25 @@ def test_full_width_qwen2_layer_prefill_and_greedy_vs_cpu_oracle():
     g = torch.Generator().manual_seed(12)
     emb = torch.randn(1, 1100, cfg.hidden_size, generator=g).to(BF)
     _greedy_vs_oracle(um, W, cfg, emb, 4, "1-layer Qwen2-7B-wide decoder, S=1100 + 4 greedy tokens vs fp32 CPU oracle", 6e-3)
+
+
+def test_native_layer_sequencer_equals_python_sequence_full_size(crab):
+    """crab_llama_layers (csrc/llama_layer.hip) vs the per-launch Python sequence on the 32-layer Llama-2-7B-size decoder: prefill chunks
+    at S = 702 (ring GEMMs, flash attention) + decode at batch 3 (skinny kernels) and batch 256 (panel kernels, RoPE / router / norm
+    fused into the reductions): ids and per-step logits bit-identical."""
+    from crab_amd import decoder
+    um = crab.base_model.model
+    D = um.config.hidden_size
+    g = torch.Generator(device="cuda").manual_seed(23)
+    for B, S, n in ((3, 702, 4), (256, 24, 3)):
+        emb = (torch.randn(B, S, D, device="cuda", generator=g) * 0.3).to(BF)
+        outs = []
+        for native in (True, False):
+            decoder.NATIVE_LAYERS = native
+            um._engine._dec.clear()                               # a decode state keeps its captured graph: capture again
+            try:
+                r = um._engine.generate(emb, n, eos_token_id=None, pad_token_id=2, return_step_logits=True)
+                outs.append((r[0].clone(), r[1].clone()))
+            finally:
+                decoder.NATIVE_LAYERS = True
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), (B, S)

@@ -453,3 +453,116 @@ def test_qwen_ops_fixture_rmsnorm_rope_layer_prefill_and_decode():
         assert _rel(qkv[:, :H * d].reshape(H, d), A["rope_q_out"][0][:, r_], f"qwen_ops: rope q @ {pos[r_]}") < 1.2e-2
         assert _rel(kc[0, :, pos[r_]], A["rope_k_out"][0][:, r_], f"qwen_ops: rope k @ {pos[r_]}") < 1.2e-2
     _layer_prefill_and_decode_step("qwen_ops", True)
+
+
+def _gen_both_sequencers(model, embeds, n):
+    """generate() with the layers sequenced by crab_llama_layers (C) and by crab_amd/decoder.py (Python): same launches, same order."""
+    from crab_amd import decoder, ops
+    out = []
+    calls = [0]
+    real = ops.llama_layers
+
+    def counted(*a):
+        calls[0] += 1
+        return real(*a)
+    for native in (True, False):
+        decoder.NATIVE_LAYERS = native
+        ops.llama_layers = counted
+        calls[0] = 0
+        try:
+            for use_graph in (True, False):
+                eng = model.base_model.model._engine
+                eng._dec.clear()                                  # a decode state keeps its captured graph: capture again
+                r = eng.generate(embeds, n, eos_token_id=None, pad_token_id=2, return_step_logits=True, use_graph=use_graph)
+                out.append((r[0].clone(), r[1].clone()))
+        finally:
+            decoder.NATIVE_LAYERS = True
+            ops.llama_layers = real
+        assert (calls[0] > 0) == native, (native, calls[0])      # the C sequencer really is the one that ran (or did not)
+    return out
+
+
+@pytest.mark.parametrize("bs", [1, 3])
+def test_native_layer_sequencer_equals_python_sequence_tiny_qwen(bs):
+    """csrc/llama_layer.hip (crab_llama_layers) against the per-launch Python sequence on the tiny Qwen2 decoder (GQA, q|k|v bias,
+    hyper-LoRA on every projection): bit-identical ids and per-step logits, graph replay and eager."""
+    from crab_amd.peft_hyper import LoraConfig, get_peft_model
+    from crab_amd.unified_qwen import UnifiedConfig, UnifiedForCausalLM
+    meta, A = load_fixture("decoder_tiny_qwen2")
+    W = weights_from_table(meta)
+    cfg = UnifiedConfig(**meta["dec"], attention_bias=True, pad_token_id=2)
+    model = get_peft_model(UnifiedForCausalLM(cfg, device="cuda"), LoraConfig())
+    model.load_state_dict(W, strict=False)
+    emb = A["embeds"].to(BF).cuda()
+    emb = torch.cat([emb] + [emb.flip(1) * (0.5 + 0.25 * i) for i in range(bs - 1)], 0) if bs > 1 else emb
+    outs = _gen_both_sequencers(model, emb, 5)
+    for ids, logits in outs[1:]:
+        assert torch.equal(ids, outs[0][0]) and torch.equal(logits, outs[0][1])
+
+
+def test_single_layer_entry_points_equal_the_stack_call():
+    """crab_llama_layer_prefill / crab_llama_layer_decode called layer by layer == crab_llama_layers over the table (tiny Llama,
+    hyper-LoRA): x and h after the stack bit-identical, prefill (S = 9) and one decode step; argument validation of the io block."""
+    import ctypes as C
+    from crab_amd import _lib, ops
+    from crab_amd.peft_hyper import LoraConfig, get_peft_model
+    from crab_amd.unified_llama import UnifiedConfig, UnifiedForCausalLM
+    torch.manual_seed(5)
+    cfg = UnifiedConfig(hidden_size=128, intermediate_size=352, num_hidden_layers=3, num_attention_heads=2, num_key_value_heads=2,
+                        vocab_size=320, pad_token_id=2)
+    um = UnifiedForCausalLM(cfg, device="cuda")
+    model = get_peft_model(um, LoraConfig())
+    for p in model.parameters():
+        p.data.copy_((torch.randn(p.shape) * (0.05 if p.dim() > 1 else 1.0)).to(BF) if p.dim() > 1 else (1 + 0.1 * torch.randn(p.shape)).to(BF))
+    eng = um._engine
+    B, S, D = 2, 9, cfg.hidden_size
+    emb = (torch.randn(B, S, D) * 0.5).to(BF).cuda()
+    lib, dev = _lib.load(), eng.device
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def run(per_layer: bool, decode: bool, kc, vc):
+        ws = eng._workspace(B * (1 if decode else S))
+        M = B * (1 if decode else S)
+        ops.copy_rows((emb[:, -1] if decode else emb).reshape(M, D).contiguous(), ws.x, M, D)
+        ops.rmsnorm(ws.x[:M], eng.model.layers[0].input_layernorm.weight, cfg.rms_norm_eps, out=ws.h[:M])
+        Tmax = kc.shape[3]
+        vt = None if decode else torch.zeros((B, cfg.num_key_value_heads, cfg.hidden_size // cfg.num_attention_heads, 16), device="cuda", dtype=BF)
+        pos = torch.full((1,), S, device="cuda", dtype=torch.int32) if decode else None
+        if not per_layer:
+            eng._layers_native(ws, B, 1 if decode else S, kc, vc, 0, Tmax, 0, pos, vt)
+        else:
+            io = _lib.LlamaIO()
+            io.x, io.h, io.qkv, io.att, io.act, io.u, io.u2 = (t.data_ptr() for t in (ws.x, ws.h, ws.qkv, ws.att, ws.act, ws.u, ws.u2))
+            io.ldx, io.ldh, io.ldqkv, io.ldatt, io.ldact, io.ldu = (t.stride(0) for t in (ws.x, ws.h, ws.qkv, ws.att, ws.act, ws.u))
+            io.route_ws, io.route_ws_bytes = ws.t.data_ptr(), ws.t.numel()
+            sk = ops._splitk_workspace(dev)
+            io.splitk_ws, io.splitk_ws_bytes = sk.data_ptr(), sk.numel()
+            io.rope_tab = eng._rope_tab(Tmax).data_ptr()
+            io.k_cache, io.v_cache, io.cache_layer_stride = kc.data_ptr(), vc.data_ptr(), kc.stride(0)
+            if vt is not None:
+                io.vt, io.vt_ld = vt.data_ptr(), vt.stride(-2)
+            io.pos_dev = pos.data_ptr() if pos is not None else None
+            io.B, io.S, io.Tmax, io.pos0 = B, 1 if decode else S, Tmax, 0
+            tab = eng._layer_table()
+            fn = lib.crab_llama_layer_decode if decode else lib.crab_llama_layer_prefill
+            for li in range(cfg.num_hidden_layers):
+                _lib.check(fn(_lib.ctx(0), stream, C.byref(tab[li]), C.byref(io), li), 0)
+            assert io.u_qkv_ready == 0                                   # the last layer has no next q|k|v group
+        torch.cuda.synchronize()
+        return ws.x[:M].clone(), ws.h[:M].clone()
+
+    res = {}
+    for per_layer in (False, True):
+        kc = torch.zeros((cfg.num_hidden_layers, B, cfg.num_key_value_heads, 64, cfg.hidden_size // cfg.num_attention_heads), device="cuda", dtype=BF)
+        vc = torch.zeros_like(kc)
+        res[per_layer] = (run(per_layer, False, kc, vc), run(per_layer, True, kc, vc), kc.clone(), vc.clone())
+    for i in range(2):
+        for j in range(2):
+            assert torch.equal(res[False][i][j], res[True][i][j]), (i, j)
+    assert torch.equal(res[False][2], res[True][2]) and torch.equal(res[False][3], res[True][3])     # KV caches incl. the appended row
+    assert res[False][0][0].float().abs().max() > 0
+    # validation: a decode call with S != 1, a prefill call without vt, a group whose shapes do not chain
+    tab = eng._layer_table()
+    io = _lib.LlamaIO()
+    assert lib.crab_llama_layer_decode(_lib.ctx(0), stream, C.byref(tab[0]), C.byref(io), 0) < 0
+    assert b"llama_layer" in lib.crab_last_error(_lib.ctx(0))
