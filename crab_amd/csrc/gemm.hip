@@ -500,6 +500,24 @@ __global__ __launch_bounds__(256) void splitk_epilogue_rope_kernel(const float* 
     }
 }
 
+// The row-owning reduction (splitk_epilogue_norm_kernel): conditions and launch, shared by the split-K paths and the M <= 16 path
+static bool norm_epilogue_ok(const crab_gemm_desc* d) {
+    return d->norm_w && !d->c_fp32 && (d->N & 7) == 0 && d->N <= 8192 && (d->ldc & 7) == 0 && (d->ld_norm & 7) == 0 &&
+           (((uintptr_t)d->C | (uintptr_t)d->norm_out | (uintptr_t)d->norm_w | (uintptr_t)d->R | (uintptr_t)d->bias | (uintptr_t)d->route_RA) & 15) == 0 &&
+           (!d->R || (d->ldr & 7) == 0) && (!d->route_RA || ((d->route_ldra & 7) == 0 && d->route_nl <= 8 &&
+                                                             d->route_nproj * (d->route_nl + d->route_r) <= 64));
+}
+
+static int launch_norm_epilogue(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* d, const float* part, int splitk) {
+    RouteP rt;
+    rt.RA = (const bf16_t*)d->route_RA; rt.U = (bf16_t*)d->route_U; rt.ldra = d->route_ldra; rt.ldu = d->route_ldu;
+    rt.nproj = d->route_nproj; rt.nl = d->route_nl; rt.r = d->route_r; rt.ucols = d->route_ucols; rt.scaling = d->route_scaling;
+    hipLaunchKernelGGL(splitk_epilogue_norm_kernel, dim3(d->M), dim3(256), 0, s, part, splitk, d->M, d->N, (const bf16_t*)d->bias, d->act,
+                       (const bf16_t*)d->R, (long)d->ldr, d->res_scale, (bf16_t*)d->C, (long)d->ldc, (const bf16_t*)d->norm_w, d->norm_eps,
+                       (bf16_t*)d->norm_out, (long)d->ld_norm, rt);
+    return crab_check_launch(ctx, "splitk_epilogue_norm_kernel");
+}
+
 // unfused form of the optional post-RMSNorm (paths whose epilogue does not own whole rows)
 static int post_norm(crab_ctx* ctx, void* stream, const crab_gemm_desc* d) {
     if (d->rope_tab)          // paths whose epilogue did not fuse the RoPE / KV append: the separate pass over C
@@ -546,6 +564,17 @@ extern "C" int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc*
         if (d->tune >= 1 && d->tune <= 4) want_split = false;                      // forced skinny NT
         if (d->tune >= 100) want_split = d->workspace != nullptr;
         if (!want_split && d->M <= 128) {
+            // M <= 16 with a fused post-norm (o / down of a decoder layer at the reference's batch sizes): the skinny kernel leaves raw
+            // fp32 sums in the workspace (one "slice") and the row-owning reduction kernel applies bias / residual, stores C, the
+            // normalised row and the next group's router - one launch instead of rmsnorm + the router's two (CRAB_SKINNY_FUSED=0: off)
+            static const int fused_on = []() { const char* e = getenv("CRAB_SKINNY_FUSED"); return !(e && e[0] == '0'); }();
+            if (fused_on && d->tune == 0 && d->M <= 16 && norm_epilogue_ok(d) && d->workspace &&
+                (int64_t)d->M * d->N * 4 <= d->workspace_bytes && (d->ldb & 7) == 0) {
+                crab_gemm_desc raw = *d;
+                raw.tune = 9;                                               // raw fp32 sums to raw.workspace, no epilogue
+                int rc = crab_gemm_skinny_launch(ctx, (hipStream_t)stream, &raw);
+                return rc ? rc : launch_norm_epilogue(ctx, (hipStream_t)stream, d, (const float*)d->workspace, 1);
+            }
             int rc = crab_gemm_skinny_launch(ctx, (hipStream_t)stream, d);
             return rc ? rc : post_norm(ctx, stream, d);
         }
@@ -655,18 +684,7 @@ extern "C" int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc*
 #undef ROPE_EPI
             return crab_check_launch(ctx, "splitk_epilogue_rope_kernel");
         }
-        if (d->norm_w && !d->c_fp32 && (d->N & 7) == 0 && d->N <= 8192 && (d->ldc & 7) == 0 && (d->ld_norm & 7) == 0 &&
-            (((uintptr_t)d->C | (uintptr_t)d->norm_out | (uintptr_t)d->norm_w | (uintptr_t)d->R | (uintptr_t)d->bias | (uintptr_t)d->route_RA) & 15) == 0 &&
-            (!d->R || (d->ldr & 7) == 0) && (!d->route_RA || ((d->route_ldra & 7) == 0 && d->route_nl <= 8 &&
-                                                             d->route_nproj * (d->route_nl + d->route_r) <= 64))) {
-            RouteP rt;
-            rt.RA = (const bf16_t*)d->route_RA; rt.U = (bf16_t*)d->route_U; rt.ldra = d->route_ldra; rt.ldu = d->route_ldu;
-            rt.nproj = d->route_nproj; rt.nl = d->route_nl; rt.r = d->route_r; rt.ucols = d->route_ucols; rt.scaling = d->route_scaling;
-            hipLaunchKernelGGL(splitk_epilogue_norm_kernel, dim3(d->M), dim3(256), 0, s, p.part, splitk, d->M, d->N, p.bias, d->act, p.R,
-                               (long)d->ldr, d->res_scale, (bf16_t*)d->C, (long)d->ldc, (const bf16_t*)d->norm_w, d->norm_eps,
-                               (bf16_t*)d->norm_out, (long)d->ld_norm, rt);
-            return crab_check_launch(ctx, "splitk_epilogue_norm_kernel");
-        }
+        if (norm_epilogue_ok(d)) return launch_norm_epilogue(ctx, s, d, p.part, splitk);
         if (d->act == ACT_SWIGLU_PAIR && !d->c_fp32 && (d->N & 15) == 0 && (d->ldc & 7) == 0 && ((uintptr_t)d->C & 15) == 0) {
             const long nthr8 = (long)d->M * (d->N >> 4);
             hipLaunchKernelGGL(splitk_epilogue_swiglu8_kernel, dim3((unsigned)((nthr8 + 255) / 256)), dim3(256), 0, s, p.part, splitk, d->M, d->N,

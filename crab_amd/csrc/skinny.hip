@@ -15,6 +15,7 @@
 //   softmax over the route logits and writes U = scaling * p_i * h_j in bf16 (peft_hyper/tuners/lora.py:346-350).
 #include "common.h"
 #include "crab_internal.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -125,6 +126,148 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(SkinnyP p) {
             if (p.c_fp32) { reinterpret_cast<float*>(p.C)[oc] = o0; reinterpret_cast<float*>(p.C)[oc + 1] = o1; }
             else { reinterpret_cast<bf16_t*>(p.C)[oc] = f2bf(o0); reinterpret_cast<bf16_t*>(p.C)[oc + 1] = f2bf(o1); }
             continue;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (n + r >= p.N) break;
+            float x = v[r];
+            if (p.bias) x += bf2f(p.bias[n + r]);
+            x = apply_act(x, p.act);
+            if (p.R) x += p.res_scale * bf2f(p.R[(long)m * p.ldr + n + r]);
+            if (p.c_fp32) reinterpret_cast<float*>(p.C)[(long)m * p.ldc + n + r] = x;
+            else reinterpret_cast<bf16_t*>(p.C)[(long)m * p.ldc + n + r] = f2bf(x);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- M <= 16: weights through LDS
+// gemm_skinny_dma_kernel: the same decomposition as gemm_skinny_kernel<1, 1> (one block per 16 weight rows, 8 waves splitting K,
+// partial tiles reduced through LDS in wave order), but the weight stream goes HBM -> LDS by LDS-DMA in WHOLE cache lines
+// (1-KiB pieces of 8 rows x 128 B, non-temporal) into a wave-private ring of NS 64-wide K slots and is read back as MFMA fragments
+// (ds_read_b128, XOR swizzle, no conflicts).  The register-direct loads of the older kernel are fragment shaped - 16 rows x 64 B,
+// half a line per row per instruction - and only 4 of them are in flight per wave: at M = 8 it streams the decoder projections at
+// 2.3-3.5 TB/s (profiles/README.md).  Here a wave keeps NS x 2 KiB in flight with no register cost, and nothing in the K loop
+// synchronises waves (each wave reads only the ring it fills).  The activation fragments (16 rows x 64 B per k step, L2 / TCP hits)
+// still go straight to registers, issued together with the DMA of their slot so that one counted vmcnt covers both.
+__device__ __attribute__((aligned(16))) uint32_t g_zero_page_sk[64];       // zero-initialised device memory (256 B)
+
+typedef __attribute__((address_space(3))) void* sk_lds_vptr;
+typedef const __attribute__((address_space(1))) void* sk_gbl_vptr;
+
+template <int NT, int NS>
+__global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_dma_kernel(SkinnyP p, float* __restrict__ part) {
+    constexpr int SLOT = NT * 16 * 64;                                  // elements: NT x 16 weight rows x 64 k
+    __shared__ __attribute__((aligned(16))) bf16_t ring[SK_WAVES][NS][SLOT];
+    __shared__ __attribute__((aligned(16))) float red[SK_WAVES][NT][64][4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fg = lane >> 4;
+    const int n0 = blockIdx.x * 16 * NT;
+
+    const int nk1 = (p.K + 63) >> 6;
+    const int nk2 = p.A2 ? (p.K2 + 63) >> 6 : 0;
+    const int ks = nk1 + nk2;
+    const int s_begin = (int)((long)ks * wave / SK_WAVES), s_end = (int)((long)ks * (wave + 1) / SK_WAVES);
+    const int nst = s_end - s_begin;
+
+    // staging coordinates of the 2 NT pieces of a slot: lane l -> row i*8 + (l >> 3), LDS chunk l & 7 (lane-linear, as LDS-DMA writes),
+    // source chunk (l & 7) ^ ((row >> 1) & 7): the inverse of the swizzle the fragment reads apply
+    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page_sk);
+    long off1[2 * NT], off2[2 * NT];
+    int kc[2 * NT];
+#pragma unroll
+    for (int i = 0; i < 2 * NT; ++i) {
+        const int row = i * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        const long wrow = min(n0 + row, p.N - 1);                       // clamped: rows >= N are never stored
+        kc[i] = c * 8;
+        off1[i] = wrow * p.ldb + c * 8;
+        off2[i] = wrow * p.ldb2 + c * 8;
+    }
+    const long xrow1 = (long)min(fr, p.M - 1) * p.lda, xrow2 = (long)min(fr, p.M - 1) * p.lda2;
+    bf16_t* myring = &ring[wave][0][0];
+    // fragment element offsets inside a 16-row tile: row fr, source chunk ks*4 + fg -> LDS chunk (ks*4 + fg) ^ ((fr >> 1) & 7)
+    const int fofs0 = fr * 64 + ((fg ^ ((fr >> 1) & 7)) << 3);
+    const int fofs1 = fofs0 ^ 32;
+
+    u32x4 xv[NS][2];
+#define SKD_STAGE(ST_, U_)                                                                                \
+    {                                                                                                     \
+        const int st_ = (ST_);                                                                            \
+        const bool s2_ = st_ >= nk1;                                                                      \
+        const int k0_ = (s2_ ? st_ - nk1 : st_) << 6;                                                     \
+        const int Ks_ = s2_ ? p.K2 : p.K;                                                                 \
+        _Pragma("unroll") for (int i = 0; i < 2 * NT; ++i) {                                              \
+            const bf16_t* src_ = (s2_ ? p.B2 + off2[i] : p.B + off1[i]) + k0_;                            \
+            src_ = (k0_ + kc[i] < Ks_) ? src_ : zero;                                                     \
+            __builtin_amdgcn_global_load_lds((sk_gbl_vptr)src_, (sk_lds_vptr)(myring + (U_) * SLOT + i * 512), 16, 0, 2);   \
+        }                                                                                                 \
+        _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                   \
+            const int k_ = k0_ + h * 32 + fg * 8;                                                         \
+            const int kk_ = k_ < Ks_ ? k_ : 0;              /* the weight chunk is zero there: any finite activation does */   \
+            xv[U_][h] = *reinterpret_cast<const u32x4*>((s2_ ? p.A2 + xrow2 : p.A + xrow1) + kk_);        \
+        }                                                                                                 \
+    }
+
+    f32x4_t acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < NS; ++u)
+        if (u < nst) SKD_STAGE(s_begin + u, u)
+    for (int s = 0; s < nst; s += NS) {
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            if (s + u < nst) {
+                // slot s+u has landed once at most the NS-1 younger slots (2 NT + 2 vector-memory instructions each) are outstanding
+                if (s + u + NS - 1 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * (2 * NT + 2)) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                union { u32x4 r; bf16x8_t f; } w0[NT], w1[NT], x0, x1;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    w0[j].r = *reinterpret_cast<const u32x4*>(myring + u * SLOT + j * 1024 + fofs0);
+                    w1[j].r = *reinterpret_cast<const u32x4*>(myring + u * SLOT + j * 1024 + fofs1);
+                }
+                x0.r = xv[u][0]; x1.r = xv[u][1];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[j].f, x0.f, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[j].f, x1.f, acc[j], 0, 0, 0);
+                }
+                // the fragments are in registers (the MFMAs consumed them): the ring slot may be refilled
+                asm volatile("" ::: "memory");
+                if (s + u + NS < nst) SKD_STAGE(s_begin + s + u + NS, u)
+            }
+        }
+    }
+#undef SKD_STAGE
+#pragma unroll
+    for (int j = 0; j < NT; ++j) *reinterpret_cast<f32x4_t*>(&red[wave][j][lane][0]) = acc[j];
+    __syncthreads();
+    // reduce over waves in fixed order + epilogue: (tile j, lane l): row m = l & 15, cols n0 + 16 j + 4*(l >> 4) + r
+    if (tid < NT * 64) {
+        const int j = tid >> 6, l = tid & 63;
+        const int m = l & 15, n = n0 + j * 16 + (l >> 4) * 4;
+        if (m >= p.M || n >= p.N) return;
+        f32x4_t v = *reinterpret_cast<const f32x4_t*>(&red[0][j][l][0]);
+#pragma unroll
+        for (int w = 1; w < SK_WAVES; ++w) v += *reinterpret_cast<const f32x4_t*>(&red[w][j][l][0]);
+        if (part) {                                     // raw fp32 sums for a fused reduction epilogue (gemm.hip), slab layout [M][N]
+            float* o = part + (long)m * p.N + n;
+            if (n + 3 < p.N && (p.N & 3) == 0) *reinterpret_cast<f32x4_t*>(o) = v;
+            else
+                for (int r = 0; r < 4 && n + r < p.N; ++r) o[r] = v[r];
+            return;
+        }
+        if (p.act == ACT_SWIGLU_PAIR) {                 // interleaved (gate, up) columns -> two outputs at column n/2
+            float t[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t[r] = v[r] + (p.bias ? bf2f(p.bias[n + r]) : 0.f);
+            const float o0 = t[0] / (1.0f + __expf(-t[0])) * t[1], o1 = t[2] / (1.0f + __expf(-t[2])) * t[3];
+            const long oc = (long)m * p.ldc + (n >> 1);
+            if (p.c_fp32) { reinterpret_cast<float*>(p.C)[oc] = o0; reinterpret_cast<float*>(p.C)[oc + 1] = o1; }
+            else { reinterpret_cast<bf16_t*>(p.C)[oc] = f2bf(o0); reinterpret_cast<bf16_t*>(p.C)[oc + 1] = f2bf(o1); }
+            return;
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -369,6 +512,16 @@ int crab_gemm_skinny_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* 
     p.A2 = (const bf16_t*)d->A2; p.B2 = (const bf16_t*)d->B2;
     p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc; p.ldr = d->ldr; p.lda2 = d->lda2; p.ldb2 = d->ldb2;
     p.M = d->M; p.N = d->N; p.K = d->K; p.K2 = d->A2 ? d->K2 : 0; p.act = d->act; p.c_fp32 = d->c_fp32; p.res_scale = d->res_scale;
+    // M <= 16: the LDS-DMA ring kernel (tune 1 / 2 / 4 keep the register-direct kernel for A/B runs); d->tune == 9: the same with
+    // raw fp32 sums to the workspace (used by crab_gemm_bf16 for its fused reduction epilogues)
+    if (d->M <= 16 && (d->tune == 0 || d->tune == 9) && (d->ldb & 7) == 0 && (!d->A2 || (d->ldb2 & 7) == 0)) {
+        // <NT = 1, NS = 4>: 16 weight rows per block, 4 slots of 2 KiB per wave, two blocks resident per CU.  Measured alternatives
+        // (profiles/README.md): a 6-slot ring changes nothing where a CU holds one block (o, down) and loses where it held two;
+        // 32 rows per block (half the activation re-reads) is 10-25 % slower on every shape at M = 1 .. 16.
+        float* part = d->tune == 9 ? (float*)d->workspace : nullptr;
+        hipLaunchKernelGGL((gemm_skinny_dma_kernel<1, 4>), dim3((d->N + 15) / 16), dim3(SK_WAVES * 64), 0, s, p, part);
+        return crab_check_launch(ctx, "gemm_skinny_dma_kernel");
+    }
     // NT (weight tiles per block): bigger NT = fewer replicated activation reads but a smaller grid.  d->tune forces it.
     int mt = d->M <= 16 ? 1 : (d->M <= 32 ? 2 : (d->M <= 64 ? 4 : 8));
     int nt = d->tune > 0 ? d->tune : 0;
@@ -426,6 +579,7 @@ extern "C" int crab_hyperlora_route(crab_ctx* ctx, void* stream, const void* X, 
     const int tcols = ((nproj * (nl + r) + 15) / 16) * 16;        // RA must hold tcols rows (zero padded)
     if (crab_hyperlora_route_workspace(M, K, tcols) > workspace_bytes) return crab_fail(ctx, CRAB_E_WORKSPACE, "hyperlora_route: workspace too small");
     // decode regime (one row per clip, 64 < M <= 256): one row-owning launch (~6 us) instead of the partial-product + mix pair (~11 us)
+    // (at M <= 16 the row-owning launch has 1-16 blocks and loses to the pair: 6.09 vs 6.22 clips/s at batch 8, profiles/README.md)
     if (M > 64 && M <= 256 && K <= 6 * 2048 && nl <= 8 && ((uintptr_t)X & 15) == 0 && ((uintptr_t)RA & 15) == 0) {
         hipStream_t s0 = (hipStream_t)stream;
 #define RR_LAUNCH(Q_) hipLaunchKernelGGL((lora_route_row_kernel<Q_>), dim3(M), dim3(256), 0, s0, (const bf16_t*)X, (long)ldx, (const bf16_t*)RA, (long)ldra, K, \
