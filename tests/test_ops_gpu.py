@@ -375,6 +375,26 @@ def test_gemm_skinny_regime(M):
     _cmp(y, z, TOL_F32, f"skinny M={M}")
 
 
+@pytest.mark.parametrize("M,N,K,K2", [(16, 48, 64, 0), (13, 4096, 4096, 96), (5, 100, 8, 0), (8, 4096, 11008, 32), (1, 32017, 4096, 0), (16, 1000, 200, 32)])
+def test_gemm_small_batch_lds_dma_kernel(M, N, K, K2):
+    """M <= 16 (the reference's batch sizes): gemm_skinny_dma_kernel (weights through wave-private LDS-DMA rings) against fp32 arithmetic
+    and against the register-direct kernel it replaces (tune 1): K shorter than one slot per wave (most waves idle), ragged K / N,
+    the second K segment, the real projection shapes, bf16 and fp32 outputs, bias + residual."""
+    from crab_amd import ops
+    x, w = _rand(M, K, seed=31).cuda(), _rand(N, K, seed=32, scale=K ** -0.5).cuda()
+    b, r = _rand(N, seed=33).cuda(), _rand(M, N, seed=34).cuda()
+    x2 = _rand(M, K2, seed=35).cuda() if K2 else None
+    w2 = _rand(N, K2, seed=36, scale=0.1).cuda() if K2 else None
+    z = x.float() @ w.float().t() + (x2.float() @ w2.float().t() if K2 else 0) + b.float() + r.float()
+    y = ops.gemm(x, w, bias=b, residual=r, x2=x2, w2=w2, out_fp32=True)
+    _cmp(y, z.cpu(), TOL_F32, f"small-batch LDS-DMA kernel M={M} N={N} K={K}+{K2} (fp32 out)")
+    y_old = ops.gemm(x, w, bias=b, residual=r, x2=x2, w2=w2, out_fp32=True, tune=1)
+    _cmp(y, y_old.cpu(), TOL_F32, "LDS-DMA kernel vs register-direct kernel")
+    yb = ops.gemm(x, w, bias=b, residual=r, x2=x2, w2=w2)
+    assert torch.equal(yb, y.to(BF)), "bf16 output is not the rounded fp32 output"
+    assert torch.equal(ops.gemm(x, w, bias=b, residual=r, x2=x2, w2=w2, out_fp32=True), y), "non-deterministic"
+
+
 @pytest.mark.parametrize("M,tune", [(17, 0), (64, 0), (64, 104), (64, 208), (128, 0), (100, 103), (33, 102), (256, 403), (200, 407), (256, 0)])
 def test_gemm_splitk_decode_regime(M, tune):
     """16 < M <= 256 with the caller workspace: split-K tiled kernels (tune 4xx: 256x256 ring kernel with K slices, ragged N / K
