@@ -1,8 +1,11 @@
 // Weight-streaming kernels for the decode regime (M = clips in flight, <= 128 rows) and for the hyper-LoRA
 // router, where the work is HBM-bound on the weight matrix and a tiled GEMM grid cannot fill 256 CUs.
 //
-// gemm_skinny_kernel<MT>:  C[M,N] = res_scale*R + act(A.B^T + A2.B2^T + bias),  M <= 16*MT.
-//   One block per 16 weight rows (N/16 blocks: 256 for N=4096, i.e. one per CU, 768/1376/2001 for the wider
+// gemm_skinny_dma_kernel (M <= 16, the reference's batch sizes 1 and 8):  C[M,N] = res_scale*R + act(A.B^T + A2.B2^T + bias).
+//   One block per 16 weight rows, 8 waves splitting K; each wave streams its K slice HBM -> LDS by LDS-DMA in whole cache lines
+//   through a private 4-slot ring and reads it back as MFMA fragments (described at the kernel).  5-6.3 TB/s on the wide shapes.
+// gemm_skinny_kernel<MT, NT> (16 < M <= 128 without a split-K workspace; M <= 16 only under tune 1 / 2 / 4 for A/B runs):
+//   One block per 16*NT weight rows (N/16 blocks: 256 for N=4096, i.e. one per CU, 768/1376/2001 for the wider
 //   projections), 8 waves per block splitting K between them.  Each wave streams its K-slice of the 16 weight
 //   rows straight into MFMA A-fragments (global_load_dwordx4, no LDS: every weight byte is used exactly once) and
 //   the matching activation columns into B-fragments (L2-resident, M*K*2 bytes), accumulating 16 x 16*MT fp32.
@@ -13,6 +16,7 @@
 //   T = x.[R;A]^T (N <= 48) is far too skinny for either GEMM grid; it is split over K into `nslices` partial
 //   products (grid nslices x M/64), and the second kernel sums the slices in a fixed order, applies the fp32
 //   softmax over the route logits and writes U = scaling * p_i * h_j in bf16 (peft_hyper/tuners/lora.py:346-350).
+// lora_route_row_kernel: the same router as ONE row-owning launch, used for 64 < M <= 256 (one row per clip at decode).
 #include "common.h"
 #include "crab_internal.h"
 #include <stdlib.h>

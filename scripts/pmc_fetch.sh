@@ -1,6 +1,8 @@
 #!/bin/bash
 # usage (GPU box): scripts/pmc_fetch.sh <tag> <python script + args...> ; separate --pmc passes for FETCH_SIZE and WRITE_SIZE, per kernel+grid means
 tag=$1; shift
+# the passes run from /tmp: make a repo-relative script path absolute
+case "$1" in /*) ;; *) set -- "$GRAFT_REPO_ROOT/$1" "${@:2}" ;; esac
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c -d $GRAFT_REPO_ROOT/gpurun_out/$tag.$c -o r --output-format csv -- python "$@" > $GRAFT_REPO_ROOT/gpurun_out/$tag.$c.log 2>&1

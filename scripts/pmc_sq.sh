@@ -1,6 +1,8 @@
 #!/bin/bash
 # usage (GPU box): scripts/pmc_sq.sh <tag> <absolute python script + args...> ; one --pmc pass of SQ LDS / MFMA / wait counters, per kernel+grid sums
 tag=$1; shift
+# the passes run from /tmp: make a repo-relative script path absolute
+case "$1" in /*) ;; *) set -- "$GRAFT_REPO_ROOT/$1" "${@:2}" ;; esac
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_INSTS_LDS -d $GRAFT_REPO_ROOT/gpurun_out/$tag -o r --output-format csv -- python "$@" > $GRAFT_REPO_ROOT/gpurun_out/$tag.log 2>&1
 python - <<PY > $GRAFT_REPO_ROOT/gpurun_out/$tag.txt
