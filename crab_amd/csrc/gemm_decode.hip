@@ -16,19 +16,21 @@
 // streamed once from HBM with the non-temporal hint.
 //
 // Structure: 8 waves as 8(M) x 1(N), each 32 rows x BN columns (TM = 2, TN = BN / 16 MFMA 16x16x32 tiles = 12 or 8 MFMAs per
-// 32-wide K slot), an NS-slot LDS ring of [256 + BN rows][32 k] images filled by LDS-DMA (16 B per lane, 1-KiB pieces of 16 rows
-// x 64 B, inverse-swizzled source, zero page for rows >= M / N, K tails and slots past the slice) and retired with a counted vmcnt.
-// Each wave stages two pieces of the activation slot; waves 0 .. BN/16 - 1 also one piece of the weight slot.
+// 32-wide k step), an NS-slot LDS ring of [256 + BN rows][64 k] images (128-byte rows: whole cache lines) filled by LDS-DMA
+// (16 B per lane, 1-KiB pieces of 8 rows x 128 B, inverse-swizzled source, zero page for rows >= M / N and K tails) and retired
+// with a counted vmcnt.  Each wave stages four pieces of the activation slot and one or two of the weight slot.
 //
-// The K loop is built around ONE barrier per TWO K slots with the fragment reads running one MFMA group ahead.  A first version
-// with the ring kernel's schedule (per slot: reads -> wait -> barrier -> 12 MFMAs -> barrier) spent ~1000 cycles per slot whatever
-// the ring depth, tile width or even with the LDS-DMA removed (scripts/exp/dec_gemm_anatomy.py): with only 12 MFMAs (~200 cycles)
-// between barriers every wave serialises ds_read latency + two barrier round trips per slot.  Here an iteration is
-//     read slot 2t+1 -> MFMA(slot 2t, fragments read in the previous iteration) -> counted vmcnt + barrier -> DMA for iteration t+NI
-//     -> read slot 2t+2 -> MFMA(slot 2t+1)
-// so no MFMA group ever waits for an LDS read issued in its own interval and the matrix pipe idles only across the one barrier.
-//   RAW: the data of iteration t+1 is read after barrier(t), which every wave reaches after waiting for its own pieces of it.
-//   WAR: after barrier(t) both slots of iteration t are in registers (lgkmcnt(0) before the barrier), so its ring slots are refilled.
+// The K loop has ONE barrier per 64-wide slot (two k steps) with the fragment reads running one MFMA group ahead.  A first version
+// with the ring kernel's schedule (per 32-wide slot: reads -> wait -> barrier -> 12 MFMAs -> barrier) spent ~1000 cycles per slot
+// whatever the ring depth, tile width or even with the LDS-DMA removed (scripts/exp/dec_gemm_anatomy.py): with only 12 MFMAs
+// (~200 cycles) between barriers every wave serialises ds_read latency + two barrier round trips per slot.  Here an iteration is
+//     MFMA(k step 0 of slot t, fragments read in the previous iteration) with the reads of k step 1 issued behind its first MFMAs
+//     -> counted vmcnt + barrier(t) -> reads of k step 0 of slot t+1 -> MFMA(k step 1) interleaved with the LDS-DMA that refills slot t
+// so no MFMA group waits for an LDS read issued in its own interval and the matrix pipe idles only across the one barrier.
+//   RAW: slot t+1 is read after barrier(t), which every wave reaches after waiting for its own pieces of it.
+//   WAR: after barrier(t) both k steps of slot t are in registers (lgkmcnt(0) before the barrier), so its ring slot is refilled.
+// What bounds it (profiles/README.md, r02): the 44 KiB a CU takes in per slot through its vector-memory path, i.e. the arithmetic
+// intensity of the 256 x 96 tile - not LDS reads, not HBM latency (a deeper weight ring was slower), not the matrix pipe (42 % busy).
 #include "common.h"
 #include "crab_internal.h"
 #include <stdlib.h>
