@@ -170,8 +170,8 @@ def cpu_baseline(args):
 
 
 def operating_points(model, um, args, eos):
-    """The reference's own operating points, reported NEXT TO the headline (never as `value`): its eval batch of 8 clips
-    (scripts/finetune/inference_hyper_lora.py:1477), its default 10 sampled frames (dataset/quick_start_dataset.py:83 -> S = 766)
+    """The reference's own operating points, reported NEXT TO the headline (never as `value`): one clip per call (scripts/quick_start.py:43),
+    its eval batch of 8 clips (scripts/finetune/inference_hyper_lora.py:1477), its default 10 sampled frames (dataset/quick_start_dataset.py:83 -> S = 766)
     and the MUSIC-AVQA 2-s audio windows ([10,198,128], dataset/unified_dataset.py:1811-1828).  One warm-up + one timed
     generate() each, inputs resident in HBM, same synthetic weights."""
     from crab_amd import synth
@@ -199,6 +199,7 @@ def operating_points(model, um, args, eos):
         out[name] = {"clips_per_batch": B, "frames": frames, "fbank_frames_per_window": l_a, "prefill_len": 126 + 32 * frames + 320,
                      "clips_per_s": round(B / dt, 3), "ms_per_batch": round(dt * 1e3, 1), "note": note}
 
+    run("single_clip", 1, args.frames, 98, "scripts/quick_start.py: one clip per generate() (BASELINE configs[0] shape on the GPU); latency = ms_per_batch")
     run("eval_batch_8", 8, args.frames, 98, "the reference's eval batch size; per-batch latency = ms_per_batch")
     run("audio_2s_windows", args.clips, args.frames, 198, "MUSIC-AVQA audio shape [10,198,128] (96 BEATs tokens per window)")
     run("frames_10", args.clips, 10, 98, "the reference's default video_frame_nums = 10 (S = 766)")
