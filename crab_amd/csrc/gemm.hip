@@ -256,6 +256,10 @@ __global__ __launch_bounds__(256) void splitk_epilogue_norm_kernel(const float* 
                                                                     RouteP rt) {
     __shared__ float red[4];
     const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // gridDim.y = P > 1 (few rows, launch_norm_epilogue): P blocks share a row; each recomputes the row and its norm (identical
+    // arithmetic), block y == 0 stores C and H, and block y evaluates the router of projection y only.  The inputs must then be
+    // read-only for the launch: no residual operand (the producer folded it into `part`), so that C may alias nothing it reads.
+    const int py = (int)blockIdx.y, P = (int)gridDim.y;
     const long MN = (long)M * N;
     constexpr int MAXQ = 4;                                   // 4 chunks of 8 columns per thread: N <= 8192; every access is 16 B wide
     float xv[MAXQ][8];
@@ -295,7 +299,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_norm_kernel(const float* 
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[r] = pack_bf2(xv[q][2 * r], xv[q][2 * r + 1]);
-            *reinterpret_cast<u32x4*>(C + (long)m * ldc + n) = o;
+            if (py == 0) *reinterpret_cast<u32x4*>(C + (long)m * ldc + n) = o;
         }
     }
     ss = wave_sum(ss);
@@ -313,7 +317,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_norm_kernel(const float* 
             u32x4 o;
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[r] = pack_bf2(h8[2 * r], h8[2 * r + 1]);
-            *reinterpret_cast<u32x4*>(H + (long)m * ldh + n) = o;
+            if (py == 0) *reinterpret_cast<u32x4*>(H + (long)m * ldh + n) = o;
 #pragma unroll
             for (int r = 0; r < 8; ++r) xv[q][r] = bf2f(f2bf(h8[r]));          // the router sees the stored bf16 row
         }
@@ -350,7 +354,32 @@ __global__ __launch_bounds__(256) void splitk_epilogue_norm_kernel(const float* 
         _Pragma("unroll") for (int cc = 0; cc < (RPT_); ++cc) tp[c0 + cc][tid] = p[cc];                   \
     }
     const int used_rows = rt.nproj * (rt.nl + rt.r);
-    if (rt.nl + rt.r == 11) {
+    if (P > 1) {                                             // projection py only (host guarantees nl + r == 11, P == nproj)
+        for (int tr = py; tr == py; ++tr) {
+            const int c0 = tr * 11;
+            float p[11];
+#pragma unroll
+            for (int cc = 0; cc < 11; ++cc) p[cc] = 0.f;
+#pragma unroll
+            for (int q = 0; q < MAXQ; ++q) {
+                const int n = (tid + q * 256) * 8;
+                if (n < N) {
+                    u32x4 w[11];
+#pragma unroll
+                    for (int cc = 0; cc < 11; ++cc) w[cc] = *reinterpret_cast<const u32x4*>(rt.RA + (long)(c0 + cc) * rt.ldra + n);
+#pragma unroll
+                    for (int cc = 0; cc < 11; ++cc) {
+                        float a = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) a += xv[q][2 * e] * lo_bf(w[cc][e]) + xv[q][2 * e + 1] * hi_bf(w[cc][e]);
+                        p[cc] += a;
+                    }
+                }
+            }
+#pragma unroll
+            for (int cc = 0; cc < 11; ++cc) tp[c0 + cc][tid] = p[cc];
+        }
+    } else if (rt.nl + rt.r == 11) {
         ROUTE_TRIPS(11, rt.nproj)
         for (int c = used_rows; c < tcols; ++c) tp[c][tid] = 0.f;
     } else {
@@ -358,7 +387,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_norm_kernel(const float* 
     }
 #undef ROUTE_TRIPS
     __syncthreads();
-    if (tid < tcols * 4) {
+    if (tid < tcols * 4 && (P == 1 || ((tid >> 2) >= py * 11 && (tid >> 2) < py * 11 + 11))) {
         const int c = tid >> 2, qt = tid & 3;
         float a = 0.f;
         for (int i = qt * 64; i < qt * 64 + 64; ++i) a += tp[c][i];
@@ -367,7 +396,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_norm_kernel(const float* 
     __syncthreads();
     if (tid < tcols) T[tid] = (tq[tid][0] + tq[tid][1]) + (tq[tid][2] + tq[tid][3]);
     __syncthreads();
-    if (tid > rt.nproj) return;
+    if (tid > rt.nproj || (P > 1 && tid != py && !(tid == rt.nproj && py == 0))) return;
     bf16_t* u = rt.U + (long)m * rt.ldu;
     const int used = rt.nproj * rt.nl * rt.r;
     if (tid == rt.nproj) {
@@ -508,7 +537,19 @@ static bool norm_epilogue_ok(const crab_gemm_desc* d) {
                                                              d->route_nproj * (d->route_nl + d->route_r) <= 64));
 }
 
-static int launch_norm_epilogue(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* d, const float* part, int splitk) {
+static int launch_norm_epilogue(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* d, const float* part, int splitk, bool folded = false) {
+    // folded: `part` already holds act(sum + bias) + res_scale * R in fp32 (the M <= 16 producer): bias / residual are not read
+    // again, which makes every input read-only and lets nproj blocks share a row (one projection of the next router each)
+    if (folded) {
+        RouteP rf;
+        rf.RA = (const bf16_t*)d->route_RA; rf.U = (bf16_t*)d->route_U; rf.ldra = d->route_ldra; rf.ldu = d->route_ldu;
+        rf.nproj = d->route_nproj; rf.nl = d->route_nl; rf.r = d->route_r; rf.ucols = d->route_ucols; rf.scaling = d->route_scaling;
+        const int P = (rf.RA && rf.nproj > 1 && rf.nl + rf.r == 11) ? rf.nproj : 1;
+        hipLaunchKernelGGL(splitk_epilogue_norm_kernel, dim3(d->M, P), dim3(256), 0, s, part, splitk, d->M, d->N, (const bf16_t*)nullptr, ACT_NONE,
+                           (const bf16_t*)nullptr, 0L, 1.0f, (bf16_t*)d->C, (long)d->ldc, (const bf16_t*)d->norm_w, d->norm_eps,
+                           (bf16_t*)d->norm_out, (long)d->ld_norm, rf);
+        return crab_check_launch(ctx, "splitk_epilogue_norm_kernel");
+    }
     RouteP rt;
     rt.RA = (const bf16_t*)d->route_RA; rt.U = (bf16_t*)d->route_U; rt.ldra = d->route_ldra; rt.ldu = d->route_ldu;
     rt.nproj = d->route_nproj; rt.nl = d->route_nl; rt.r = d->route_r; rt.ucols = d->route_ucols; rt.scaling = d->route_scaling;
@@ -571,9 +612,9 @@ extern "C" int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc*
             if (fused_on && d->tune == 0 && d->M <= 16 && norm_epilogue_ok(d) && d->workspace &&
                 (int64_t)d->M * d->N * 4 <= d->workspace_bytes && (d->ldb & 7) == 0) {
                 crab_gemm_desc raw = *d;
-                raw.tune = 9;                                               // raw fp32 sums to raw.workspace, no epilogue
+                raw.tune = 9;                                               // fp32 act(sum + bias) + residual to raw.workspace, no store of C
                 int rc = crab_gemm_skinny_launch(ctx, (hipStream_t)stream, &raw);
-                return rc ? rc : launch_norm_epilogue(ctx, (hipStream_t)stream, d, (const float*)d->workspace, 1);
+                return rc ? rc : launch_norm_epilogue(ctx, (hipStream_t)stream, d, (const float*)d->workspace, 1, true);
             }
             int rc = crab_gemm_skinny_launch(ctx, (hipStream_t)stream, d);
             return rc ? rc : post_norm(ctx, stream, d);

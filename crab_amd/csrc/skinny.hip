@@ -256,11 +256,17 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_dma_kernel(SkinnyP 
         f32x4_t v = *reinterpret_cast<const f32x4_t*>(&red[0][j][l][0]);
 #pragma unroll
         for (int w = 1; w < SK_WAVES; ++w) v += *reinterpret_cast<const f32x4_t*>(&red[w][j][l][0]);
-        if (part) {                                     // raw fp32 sums for a fused reduction epilogue (gemm.hip), slab layout [M][N]
-            float* o = part + (long)m * p.N + n;
-            if (n + 3 < p.N && (p.N & 3) == 0) *reinterpret_cast<f32x4_t*>(o) = v;
-            else
-                for (int r = 0; r < 4 && n + r < p.N; ++r) o[r] = v[r];
+        if (part) {                                     // fp32 act(sum + bias) + res_scale * R (unrounded) for the row-owning reduction
+            float* o = part + (long)m * p.N + n;        // kernel of gemm.hip, slab layout [M][N]; never with the SwiGLU pair epilogue
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (n + r >= p.N) break;
+                float x = v[r];
+                if (p.bias) x += bf2f(p.bias[n + r]);
+                x = apply_act(x, p.act);
+                if (p.R) x += p.res_scale * bf2f(p.R[(long)m * p.ldr + n + r]);
+                o[r] = x;
+            }
             return;
         }
         if (p.act == ACT_SWIGLU_PAIR) {                 // interleaved (gate, up) columns -> two outputs at column n/2
