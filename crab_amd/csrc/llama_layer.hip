@@ -12,6 +12,8 @@
 //     x   += [act | u] . [Wdown | Bcat]^T ; h = rmsnorm(x) * next_norm_w              (+ the next layer's q|k|v router ahead)
 #include "crab_internal.h"
 #include <math.h>
+#include <algorithm>
+using std::max;
 
 namespace {
 
@@ -98,6 +100,8 @@ int check_io(crab_ctx* ctx, const crab_llama_layer* L, const crab_llama_io* io, 
         return crab_fail(ctx, CRAB_E_INVALID, "llama_layer: a leading dimension is smaller than its row");
     const bool lora = L->qkv.RA || L->o.RA || L->gu.RA || L->down.RA;
     if (lora && (!io->u || !io->u2 || !io->route_ws)) return crab_fail(ctx, CRAB_E_INVALID, "llama_layer: adapted groups need u, u2 and route_ws");
+    const int ucmax = max(max(L->qkv.RA ? L->qkv.ucols : 0, L->o.RA ? L->o.ucols : 0), max(L->gu.RA ? L->gu.ucols : 0, L->down.RA ? L->down.ucols : 0));
+    if (lora && (io->ldu < ucmax || (io->ldu & 7))) return crab_fail(ctx, CRAB_E_INVALID, "llama_layer: ldu must cover the widest group's ucols and be a multiple of 8");
     if (prefill) {
         if (!io->vt || io->vt_ld < io->S) return crab_fail(ctx, CRAB_E_INVALID, "llama_layer_prefill: vt [B, Hk, d, vt_ld >= S] is required");
         if (io->pos0 + io->S > io->Tmax) return crab_fail(ctx, CRAB_E_INVALID, "llama_layer_prefill: rows do not fit the KV cache");
