@@ -308,6 +308,215 @@ __global__ __launch_bounds__(512) void gemm_dec_kernel(GemmDP p) {
     gemm_epilogue<TM, TN>(acc, p.act, m_wave, n0, fr, fg, p.M, p.N, p.bias, p.R, p.ldr, p.res_scale, p.C, 0, p.ldc, p.c_fp32);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Producer / consumer form of the same kernel: 12 waves, 3 per SIMD.  Waves 0-7 are the consumers of gemm_dec_kernel (8(M) x 1(N),
+// 32 rows x BN columns each, same ring, same fragment schedule) and issue NO vector-memory instruction; waves 8-11 - one per SIMD -
+// do nothing but stage: 8 activation pieces + BN/32 weight pieces per slot each.
+//
+// Why (profiles/README.md, "where a slot's cycles go"): in the 8-wave kernel the phase of a slot that carries the refill - 12 MFMAs
+// interleaved with 5-6 LDS-DMA instructions per wave - takes 970 ticks on the younger wave of a SIMD against 305 for the same
+// MFMAs without them: an LDS-DMA instruction waits ~50 ticks for the CU's address path, a wave issues in order, so the MFMAs behind
+// it wait too, and both waves of a SIMD are in that phase together.  The counted vmcnt wait, by contrast, is 5 % of the slot: the
+// data is never late, its ISSUE is what stalls the matrix pipe.  With the staging moved to waves that have no MFMAs the stall lands
+// on a wave with nothing else to do, and the consumers' loop has no vmcnt, no pointer arithmetic and no K-tail branches.
+//
+// Synchronisation: one s_barrier per slot, joined by all 12 waves.  barrier(t) means (consumers) "every fragment of slot t is in
+// registers" and (producers) "my pieces of slot t+1 have landed"; after it the producers refill the ring position of slot t with
+// slot t+NS and the consumers read slot t+1.
+template <int BN, int NS, bool NTB>
+__global__ __launch_bounds__(768) void gemm_dec_ws_kernel(GemmDP p) {
+    constexpr int BM = 256;
+    constexpr int TM = 2, TN = BN / 16;
+    constexpr int PA = BM / 8, PB = BN / 8;                  // 1-KiB pieces (8 rows x 128 B) per slot: activations, weights
+    constexpr int NPROD = 4;
+    constexpr int PAP = PA / NPROD, PBP = PB / NPROD;        // pieces per producer wave per slot: 8 + 3 (BN 96) or 8 + 2 (BN 64)
+    constexpr int NPP = PAP + PBP;
+    constexpr int SLOT_ELEMS = (BM + BN) * DBK;
+    static_assert(BN % 32 == 0 && NS >= 3 && NS * SLOT_ELEMS * 2 <= 160 * 1024, "tile / ring geometry");
+    __shared__ __attribute__((aligned(16))) bf16_t lds[NS * SLOT_ELEMS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int sk = (int)blockIdx.y;
+    const int n0 = (int)blockIdx.x * BN;
+    const int nk1 = (p.K + DBK - 1) / DBK;
+    const int nk2 = p.A2 ? (p.K2 + DBK - 1) / DBK : 0;
+    const int nk_per = (nk1 + nk2 + p.splitk - 1) / p.splitk;
+    const int t_first = sk * nk_per;                                  // first K slot of this slice (both K segments chained)
+    const int nk = min(nk1 + nk2, t_first + nk_per) - t_first;       // >= 1 by construction of splitk (host)
+
+    if (wave >= 8) {
+        // =========================================================== producers
+        const int pw = wave - 8;
+        const int prow = lane >> 3, pc = lane & 7;
+        const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page_dec);
+        // piece i < PAP: activation rows (pw * PAP + i) * 8 ..; piece PAP + j: weight rows (pw + NPROD j) * 8 ..
+        int off1[NPP], off2[NPP], kc[NPP], ldso[NPP];
+        bool rok[NPP];
+#pragma unroll
+        for (int i = 0; i < NPP; ++i) {
+            const bool isA = i < PAP;
+            const int pr0 = isA ? (pw * PAP + i) * 8 : (pw + NPROD * (i - PAP)) * 8;
+            const int row = pr0 + prow;
+            const int c = pc ^ ((row >> 1) & 7);                         // inverse swizzle on the source chunk
+            kc[i] = c * 8;
+            rok[i] = isA ? row < p.M : n0 + row < p.N;
+            off1[i] = row * (int)(isA ? p.lda : p.ldb) + c * 8;
+            off2[i] = row * (int)(isA ? p.lda2 : p.ldb2) + c * 8;
+            ldso[i] = __builtin_amdgcn_readfirstlane((isA ? 0 : BM * DBK) + pr0 * DBK);
+        }
+        const bf16_t* baseA1 = p.A;
+        const bf16_t* baseB1 = p.B + (long)n0 * p.ldb;
+        const bf16_t* baseA2 = p.A2 ? p.A2 : zero;
+        const bf16_t* baseB2 = p.A2 ? p.B2 + (long)n0 * p.ldb2 : zero;
+#define DMA_A(SRC_, DST_) __builtin_amdgcn_global_load_lds((gbl_vptr)(SRC_), (lds_vptr)(DST_), 16, 0, 0)
+#define DMA_B(SRC_, DST_)                                                                                 \
+    {                                                                                                     \
+        if constexpr (NTB) __builtin_amdgcn_global_load_lds((gbl_vptr)(SRC_), (lds_vptr)(DST_), 16, 0, 2);  \
+        else __builtin_amdgcn_global_load_lds((gbl_vptr)(SRC_), (lds_vptr)(DST_), 16, 0, 0);               \
+    }
+        // generic staging (K tails, second K segment, rows outside the operands)
+#define RSTAGE(TL_, SB_)                                                                                  \
+    {                                                                                                     \
+        const int t_ = t_first + (TL_);                                                                   \
+        const int sb_ = (SB_);                                                                            \
+        const bool s2_ = t_ >= nk1;                                                                       \
+        const int k0_ = (s2_ ? t_ - nk1 : t_) * DBK;                                                      \
+        const int Ks_ = s2_ ? p.K2 : p.K;                                                                 \
+        _Pragma("unroll") for (int i = 0; i < NPP; ++i) {                                                 \
+            const bool ok_ = rok[i] && (k0_ + kc[i] < Ks_);                                               \
+            const bf16_t* src_ = (i < PAP ? (s2_ ? baseA2 + off2[i] : baseA1 + off1[i]) : (s2_ ? baseB2 + off2[i] : baseB1 + off1[i])) + k0_;   \
+            src_ = ok_ ? src_ : zero;                                                                     \
+            if (i < PAP) DMA_A(src_, &lds[sb_ + ldso[i]]);                                                \
+            else DMA_B(src_, &lds[sb_ + ldso[i]]);                                                        \
+        }                                                                                                 \
+    }
+        // fast staging for the K slots wholly inside the first K segment: carried per-piece source pointers, slots in order
+        const int nfast = max(0, min(nk, p.K / DBK - t_first));
+        const bf16_t* fptr[NPP];
+        int fadv[NPP];
+#pragma unroll
+        for (int i = 0; i < NPP; ++i) {
+            const bf16_t* b_ = i < PAP ? baseA1 : baseB1;
+            fptr[i] = rok[i] ? b_ + (long)t_first * DBK + off1[i] : zero;
+            fadv[i] = rok[i] ? DBK : 0;
+        }
+#define FSTAGE(SB_)                                                                                       \
+    {                                                                                                     \
+        const int sbf_ = (SB_);                                                                           \
+        _Pragma("unroll") for (int i = 0; i < NPP; ++i) {                                                 \
+            if (i < PAP) DMA_A(fptr[i], &lds[sbf_ + ldso[i]]);                                            \
+            else DMA_B(fptr[i], &lds[sbf_ + ldso[i]]);                                                    \
+            fptr[i] += fadv[i];                                                                           \
+        }                                                                                                 \
+    }
+#define XSTAGE(TL_, SB_)                                                                                  \
+    {                                                                                                     \
+        if ((TL_) < nfast) FSTAGE(SB_) else RSTAGE(TL_, SB_)                                              \
+    }
+#pragma unroll
+        for (int t = 0; t < NS; ++t)
+            if (t < nk) XSTAGE(t, t * SLOT_ELEMS)
+        if (nk >= NS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPP * (NS - 1)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                               // slot 0 is there
+        int sl = 0;
+        for (int t = 0; t < nk; ++t) {
+            // my pieces of slot t+1: at most the NS-2 younger slots may still be in flight
+            if (t + NS - 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPP * (NS - 2)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                           // barrier(t): slot t is in the consumers' registers
+            if (t + NS < nk) XSTAGE(t + NS, sl * SLOT_ELEMS)
+            sl = sl + 1 == NS ? 0 : sl + 1;
+        }
+#undef RSTAGE
+#undef FSTAGE
+#undef XSTAGE
+#undef DMA_A
+#undef DMA_B
+        return;
+    }
+
+    // =============================================================== consumers
+    f32x4_t acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fg = lane >> 4;
+    int wofs[TN], xofs[TM];
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) {
+        const int row = ni * 16 + fr;
+        wofs[ni] = BM * DBK + row * DBK + ((fg ^ ((row >> 1) & 7)) << 3);
+    }
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+        const int row = wave * 32 + mi * 16 + fr;
+        xofs[mi] = row * DBK + ((fg ^ ((row >> 1) & 7)) << 3);
+    }
+#define READ_FRAGS(W_, X_, BASE_, KS_)                                                                    \
+    {                                                                                                     \
+        const bf16_t* st_ = &lds[(BASE_)];                                                                \
+        _Pragma("unroll") for (int ni = 0; ni < TN; ++ni) W_[ni] = *reinterpret_cast<const bf16x8_t*>(st_ + (wofs[ni] ^ ((KS_) * 32)));   \
+        _Pragma("unroll") for (int mi = 0; mi < TM; ++mi) X_[mi] = *reinterpret_cast<const bf16x8_t*>(st_ + (xofs[mi] ^ ((KS_) * 32)));   \
+    }
+#define MFMA_GROUP(W_, X_, NI0_, NI1_)                                                                    \
+    {                                                                                                     \
+        _Pragma("unroll") for (int ni = (NI0_); ni < (NI1_); ++ni)                                        \
+            _Pragma("unroll") for (int mi = 0; mi < TM; ++mi)                                             \
+                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W_[ni], X_[mi], acc[ni][mi], 0, 0, 0);   \
+    }
+    __builtin_amdgcn_s_barrier();                                   // slot 0 is there
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8_t w0[TN], x0[TM], w1[TN], x1[TM];
+    READ_FRAGS(w0, x0, 0, 0)                                        // k step 0 of slot 0
+    int sl = 0;
+    for (int t = 0; t < nk; ++t) {
+        const int base = sl * SLOT_ELEMS;
+        MFMA_GROUP(w0, x0, 0, TN / 3)
+        __builtin_amdgcn_sched_barrier(0);
+        READ_FRAGS(w1, x1, base, 1)                                 // k step 1, behind the first MFMAs of k step 0
+        __builtin_amdgcn_sched_barrier(0);
+        MFMA_GROUP(w0, x0, TN / 3, TN)
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // every fragment of slot t is in registers
+        __builtin_amdgcn_s_barrier();                               // barrier(t): slot t+1 has landed, slot t may be refilled
+        __builtin_amdgcn_sched_barrier(0);
+        const int nsl = sl + 1 == NS ? 0 : sl + 1;
+        if (t + 1 < nk) READ_FRAGS(w0, x0, nsl * SLOT_ELEMS, 0)     // k step 0 of slot t+1, one MFMA group ahead
+        __builtin_amdgcn_sched_barrier(0);
+        MFMA_GROUP(w1, x1, 0, TN)
+        sl = nsl;
+    }
+#undef READ_FRAGS
+#undef MFMA_GROUP
+
+    const int m_wave = wave * 32;
+    if (p.splitk > 1) {          // raw fp32 partial tile; reduced in a fixed slice order by the split-K epilogue kernels (gemm.hip)
+        float* part = p.part + (long)sk * p.M * p.N;
+        const bool v4 = (p.N & 3) == 0;
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+            const int m = m_wave + mi * 16 + fr;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+                const int n = n0 + ni * 16 + fg * 4;
+                if (n >= p.N) continue;
+                float* o = part + (long)m * p.N + n;
+                if (v4) *reinterpret_cast<f32x4_t*>(o) = acc[ni][mi];
+                else
+                    for (int r = 0; r < 4 && n + r < p.N; ++r) o[r] = acc[ni][mi][r];
+            }
+        }
+        return;
+    }
+    gemm_epilogue<TM, TN>(acc, p.act, m_wave, n0, fr, fg, p.M, p.N, p.bias, p.R, p.ldr, p.res_scale, p.C, 0, p.ldc, p.c_fp32);
+}
+
 }  // namespace
 
 // Decode-regime launch (called from crab_gemm_bf16, gemm.hip).  bn in {64, 96}; splitk >= 1 (K slices over blockIdx.y, none empty).
@@ -320,6 +529,13 @@ int crab_gemm_dec_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* d, 
     p.splitk = splitk > 1 ? splitk : 1; p.part = part;
     const int tiles = (d->N + bn - 1) / bn;
     dim3 grid(tiles, p.splitk);
+    static const int ws_on = []() { const char* e = getenv("CRAB_DEC_WS"); return !(e && e[0] == '0'); }();
+    if (ws_on && nt_weights) {                          // producer / consumer form (CRAB_DEC_WS=0: the 8-wave kernel, A/B runs)
+        if (bn == 96) hipLaunchKernelGGL((gemm_dec_ws_kernel<96, 3, true>), grid, dim3(768), 0, s, p);
+        else if (bn == 64) hipLaunchKernelGGL((gemm_dec_ws_kernel<64, 4, true>), grid, dim3(768), 0, s, p);
+        else return crab_fail(ctx, CRAB_E_INVALID, "gemm_dec: bn must be 64 or 96");
+        return crab_check_launch(ctx, "gemm_dec_ws_kernel");
+    }
     if (bn == 96) {
         if (nt_weights) hipLaunchKernelGGL((gemm_dec_kernel<96, 3, true>), grid, dim3(512), 0, s, p);
         else hipLaunchKernelGGL((gemm_dec_kernel<96, 3, false>), grid, dim3(512), 0, s, p);
