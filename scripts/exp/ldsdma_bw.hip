@@ -14,12 +14,14 @@ __global__ __launch_bounds__(512) void ldsdma_kernel(const char* __restrict__ sh
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const char* pb = priv + (long)blockIdx.x * priv_per_block;
-    long so = ((long)wave * P * 1024) % shared_bytes, po = (long)wave * P * 1024;
+    // mode 3: every block walks the shared buffer from its own start (a buffer larger than L2 but smaller than the 256 MiB MALL is then
+    // served by the MALL after the first pass)
+    long so = (mode == 3 ? ((long)blockIdx.x * 977 * 8192 + (long)wave * P * 1024) : ((long)wave * P * 1024)) % shared_bytes, po = (long)wave * P * 1024;
     int slot = 0;
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int i = 0; i < P; ++i) {
-            const bool usePriv = mode == 1 || (mode == 2 && i == P - 1);
+            const bool usePriv = mode == 1 || (mode == 2 && i == P - 1);   // mode 3: shared only
             const char* src = usePriv ? pb + po : shared_buf + so;
             char* dst = &lds[((wave * DEPTH + slot) * P + i) * 1024];
             if (NT && usePriv) __builtin_amdgcn_global_load_lds((gbl_vptr)(src + lane * 16), (lds_vptr)dst, 16, 0, 2);
