@@ -667,12 +667,12 @@ extern "C" int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc*
         }
     }
     // ---- decode regime, 128 < M <= 256: the batch-tall narrow-panel kernel (gemm_decode.hip); tune 70000 + BN * 100 + S forces
-    // a decomposition, any other non-zero tune keeps the older kernels (A/B runs), CRAB_DEC_GEMM=0 disables it process-wide
+    // a decomposition (80000 + ...: on the 8-wave kernel instead of the producer / consumer one), any other non-zero tune keeps the older kernels (A/B runs), CRAB_DEC_GEMM=0 disables it process-wide
     int dec_bn = 0;
     if (sk_bm == 128 && d->M > 128 && d->workspace) {
         static const int dec_on = []() { const char* e = getenv("CRAB_DEC_GEMM"); return !(e && e[0] == '0'); }();
         const int nk32 = (d->K + 63) / 64 + (d->A2 ? (d->K2 + 63) / 64 : 0);      // K slots of the panel kernel (64 wide)
-        if (d->tune >= 70000 && d->tune < 80000) {
+        if (d->tune >= 70000 && d->tune < 90000) {                      // 8xxxx: the same decomposition on the 8-wave kernel (A/B, tests)
             dec_bn = (d->tune / 100) % 100; splitk = d->tune % 100;
             if (splitk < 1) splitk = 1;
             const int per = (nk32 + splitk - 1) / splitk;
@@ -704,7 +704,7 @@ extern "C" int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc*
         else if (sk_bm == 64) hipLaunchKernelGGL((gemm_bt_kernel<64, 64>), grid, dim3(256), 0, s, p);
         else if (d->tune == 300) hipLaunchKernelGGL((gemm_bt_kernel<128, 128>), grid, dim3(256), 0, s, p);
         else if (dec_bn) {
-            int rc2 = crab_gemm_dec_launch(ctx, s, d, dec_bn, splitk, p.part, d->tune != 70001);
+            int rc2 = crab_gemm_dec_launch(ctx, s, d, dec_bn, splitk, p.part, d->tune >= 80000 ? 2 : 1);
             if (rc2) return rc2;
         }
         else {                                                        // 128-row tiles: LDS-DMA staged kernel, K split over blockIdx.y

@@ -530,7 +530,9 @@ int crab_gemm_dec_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* d, 
     const int tiles = (d->N + bn - 1) / bn;
     dim3 grid(tiles, p.splitk);
     static const int ws_on = []() { const char* e = getenv("CRAB_DEC_WS"); return !(e && e[0] == '0'); }();
-    if (ws_on && nt_weights) {                          // producer / consumer form (CRAB_DEC_WS=0: the 8-wave kernel, A/B runs)
+    // nt_weights: 1 = the shipped form (producer / consumer, non-temporal weight loads), 2 = the 8-wave kernel (tune 8xxxx), 0 = the
+    // 8-wave kernel with default-policy weight loads
+    if (ws_on && nt_weights == 1) {                     // CRAB_DEC_WS=0: the 8-wave kernel process-wide (A/B runs)
         if (bn == 96) hipLaunchKernelGGL((gemm_dec_ws_kernel<96, 3, true>), grid, dim3(768), 0, s, p);
         else if (bn == 64) hipLaunchKernelGGL((gemm_dec_ws_kernel<64, 4, true>), grid, dim3(768), 0, s, p);
         else return crab_fail(ctx, CRAB_E_INVALID, "gemm_dec: bn must be 64 or 96");

@@ -414,15 +414,14 @@ def test_gemm_splitk_decode_regime(M, tune):
 
 
 @pytest.mark.parametrize("M", [129, 200, 256])
-@pytest.mark.parametrize("tune", [79601, 79602, 76401, 76404, 79605, 70001, 0])
+@pytest.mark.parametrize("tune", [79601, 79602, 76401, 76404, 79605, 89602, 86404, 0])
 def test_gemm_decode_panel_kernel(M, tune):
-    """gemm_dec_kernel (128 < M <= 256: the whole batch x a 96- or 64-wide weight panel per block, tune = 70000 + BN * 100 + K slices;
-    0 = automatic choice, 70001 = default-policy weight loads): ragged N (last panel partly outside), K not a multiple of the 32-wide
-    K tile, a second K segment, every epilogue input (bias, GELU, residual), fp32 and bf16 outputs; deterministic."""
+    """The decode panel kernels (128 < M <= 256: the whole batch x a 96- or 64-wide weight panel per block; tune = 70000 + BN * 100 + K
+    slices on the producer / consumer kernel, 80000 + ... on the 8-wave kernel, 0 = automatic choice): ragged N (last panel partly outside),
+    K not a multiple of the 64-wide slot, a second K segment, every epilogue input (bias, GELU, residual), fp32 and bf16 outputs;
+    deterministic; the two kernels issue the same MFMAs in the same order: bit-identical."""
     from crab_amd import ops
     N, K, K2 = 1000 + 9, 1096, 32
-    if tune == 70001:
-        tune = 79602
     x, w, b, r = _rand(M, K, seed=3), _rand(N, K, seed=4, scale=K ** -0.5), _rand(N, seed=5), _rand(M, N, seed=6)
     x2, w2 = _rand(M, K2, seed=7), _rand(N, K2, seed=8, scale=0.1)
     args = dict(bias=b.cuda(), act="gelu", residual=r.cuda(), x2=x2.cuda(), w2=w2.cuda(), tune=tune)
@@ -431,6 +430,9 @@ def test_gemm_decode_panel_kernel(M, tune):
     _cmp(y, z, TOL_F32, f"decode panel kernel M={M} tune={tune}")
     assert torch.equal(y, ops.gemm(x.cuda(), w.cuda(), out_fp32=True, **args)), "must be deterministic"
     _cmp(ops.gemm(x.cuda(), w.cuda(), **args), z, TOL_BF16, "decode panel kernel, bf16 out")
+    if 70000 <= tune < 80000:
+        args["tune"] = tune + 10000
+        assert torch.equal(y, ops.gemm(x.cuda(), w.cuda(), out_fp32=True, **args)), "producer / consumer kernel != 8-wave kernel"
 
 
 @pytest.mark.parametrize("name,N,K,K2", [("qkv", 12288, 4096, 96), ("o", 4096, 4096, 32), ("gate|up", 22016, 4096, 64), ("down", 4096, 11008, 32),
