@@ -20,7 +20,7 @@ eager ops.  The nn.Parameters exposed under the reference's names are VIEWS into
 """
 from __future__ import annotations
 
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import List, Optional, Sequence
 
 import torch

@@ -14,7 +14,6 @@ constants 1/3 and 1/2 (A.5); `num_classes` is chosen per sample from the task na
 from __future__ import annotations
 
 import math
-from typing import List
 
 import torch
 from torch import nn

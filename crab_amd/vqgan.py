@@ -14,7 +14,7 @@ against the codebook + a row argmin of |e|^2 - 2 z.e (first minimum wins, as tor
 from __future__ import annotations
 
 import math
-from typing import List, Optional, Tuple
+from typing import Optional, Tuple
 
 import torch
 from torch import nn

@@ -3,8 +3,6 @@ fp32 CPU oracle run on the GPU box's host cores (about a minute); (ii) size-inde
 recompute, batch-row independence, run-to-run determinism, agreement of the three prefill GEMM kernels on the real projection shapes;
 (iii) full-width slices against the oracle: one Llama-2-7B-wide and one Qwen2-7B-wide decoder layer (prefill + 4 greedy steps) and the
 full-size CLIP / BEATs / Q-Former encoders on a 2-frame, 2-segment clip."""
-import math
-
 import pytest
 import torch
 

@@ -5,7 +5,7 @@ Tolerance: fp32 vs fp32, different op order/library versions -> 2e-4 absolute on
 import torch
 
 from oracle import crab_oracle as O
-from tests.util import load_fixture, weights_from_table, strip
+from tests.util import load_fixture, weights_from_table
 
 TOL = 2e-4
 
