@@ -5,7 +5,7 @@ Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 laun
 one rank per GPU over RCCL.  One "step" = one pass of the hot path over one batch of synthetic clips per GPU:
 encoders (CLIP ViT-L/14 on 8 frames, BEATs on ten 1-s fbank windows, both Q-Former projectors) ->
 prepare_multimodal_inputs (S = 702) -> hyper-LoRA Llama-2-7B prefill -> 256 greedy tokens (EOS suppressed) ->
-RCCL gather of {token ids, first-step logits} to rank 0.  Per-clip sharding: every rank holds a full weight
+RCCL gather of {clip id, token ids, fp32 first-step logits} to rank 0 (--no-gather-logits: ids only).  Per-clip sharding: every rank holds a full weight
 replica and its own clips (weak scaling: clips per GPU fixed).
 
 Workload = BASELINE.json configs[1] ("AVQA eval, Llama-2-7B + BEATs + CLIP-ViT-L/14, bf16, 1xMI355X") at the shape the
@@ -219,6 +219,7 @@ def main():
                     help="decode groups replayed on separate HIP streams (KV-cache attention of one overlaps projections of another)")
     ap.add_argument("--llm", default="llama")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather-logits", action="store_true", help="gather token ids only (default: ids + first-step fp32 logits of every clip)")
     ap.add_argument("--no-operating-points", action="store_true",
                     help="skip the extra (untimed-region) runs at the reference's own operating points: eval batch 8, 10 frames, 2-s audio windows")
     args = ap.parse_args()
@@ -281,8 +282,11 @@ def main():
         out = model.generate(batch_input_ids=ids, batch_labels=lab, batch_X_modals=mods, batch_task_names=['avqa'] * B,
                              use_cache=True, max_new_tokens=args.new_tokens, min_new_tokens=args.new_tokens, eos_token_id=eos,
                              pad_token_id=um.model.pad_token_id, prefill_chunk=args.prefill_chunk, output_logits=False,
-                             decode_streams=args.decode_streams)
-        return gather_results(out, clip0, world, rank)
+                             decode_streams=args.decode_streams, output_first_logits=not args.no_gather_logits)
+        if args.no_gather_logits:
+            return gather_results(out, clip0, world, rank)
+        # north_star: "RCCL gather of logits": rank 0 receives {clip id, ids[new_tokens]} and the fp32 first-step logits [V] of every clip
+        return gather_results(out.sequences, clip0, world, rank, logits=out.first_logits)
 
     def sync():
         torch.cuda.synchronize()
@@ -304,8 +308,13 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     ops.PROFILER = None
+    rank_ms = [round(dt / args.steps * 1e3, 2)]
     if dist is not None:
+        # every rank's own wall time of the K steps (a straggler shows up here); `value` uses the MAX over ranks
         tt = torch.tensor([dt], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
+        allt = [torch.empty_like(tt) for _ in range(world)]
+        dist.all_gather(allt, tt)
+        rank_ms = [round(float(t.item()) / args.steps * 1e3, 2) for t in allt]
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     psum = prof.summary()
@@ -313,6 +322,7 @@ def main():
     if rank == 0:
         # the gather really delivered every rank's clips (ordered by clip id) to rank 0
         assert res is not None and res[1].shape[0] == world * B and res[0].tolist() == list(range(world * B)), "gather incomplete"
+        assert args.no_gather_logits or (res[2] is not None and tuple(res[2].shape) == (world * B, V)), "first-step logits not gathered"
         n_clips = world * B * args.steps
         S = 126 + 32 * args.frames + 320
         # per-kernel roofline entries from the live HIP-event samples; the dominant kernel is the one with the largest
@@ -359,7 +369,10 @@ def main():
                        "frames": args.frames, "audio_segments": 10, "prompt_tokens": 128, "prefill_len": S, "new_tokens": args.new_tokens,
                        "decode": "greedy, EOS suppressed, device-resident HIP-graph loop", "parallelism": f"per-clip x{world} (contiguous blocks of clips per rank), RCCL gather",
                        "collective_backend": (backend + (" (RCCL)" if backend == "nccl" else "")) if dist is not None else None,
-                       "world_size_observed": dist.get_world_size() if dist is not None else 1},
+                       "world_size_observed": dist.get_world_size() if dist is not None else 1,
+                       "gathered_per_clip": "clip id + ids" + ("" if args.no_gather_logits else f" + first-step fp32 logits[{V}]"),
+                       "gathered_clips": int(res[1].shape[0])},
+            "rank_ms_per_step": rank_ms,
             "prefill_tflop_per_clip": round(flops_per_clip(args.frames, 10, 48, S, V, um.config) / 1e12, 3),
             "step_ms": step_ms,
             "prefill_roofline": prefill_roof,

@@ -678,6 +678,8 @@ extern "C" int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc*
             const int per = (nk32 + splitk - 1) / splitk;
             splitk = (nk32 + per - 1) / per;                              // no empty slice
             while (splitk > 1 && (int64_t)splitk * d->M * d->N * 4 > d->workspace_bytes) --splitk;
+            const int per2 = (nk32 + splitk - 1) / splitk;                // the clamp may leave a remainder slice empty: normalise again
+            splitk = (nk32 + per2 - 1) / per2;
         } else if (d->tune == 0 && dec_on) {
             dec_choose(d, nk32, &dec_bn, &splitk);
         }

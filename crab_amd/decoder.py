@@ -175,7 +175,7 @@ class GenerationEngine:
         callers slice [:M].  The prompt length varies per batch in a real evaluation, so a set per distinct M (1.7 GB at
         35 x 702 rows) would pin tens of GB next to the KV cache over a long run.
         decode = True: the buffers a decode state (and its captured HIP graph) keeps; `slot` separates the groups that
-        decode concurrently on different streams.  At most 4 sets are kept here (a live _DecodeState holds its own reference)."""
+        decode concurrently on different streams.  max(4, live groups + 1) sets are kept here (a live _DecodeState holds its own reference)."""
         if not decode:
             ws = self._ws.get("prefill")
             if ws is None or ws.M < M or ws.x.device != self.device:
@@ -191,7 +191,8 @@ class GenerationEngine:
             ws = _Workspace(self.cfg, M, self.device, tc, uc)
         self._ws[key] = ws                                    # most recently used last
         dec_keys = [k for k in self._ws if k != "prefill"]
-        for k in dec_keys[:-4]:
+        keep = max(4, len(self._dec) + 1, slot + 1)           # every live decode group keeps its set (decode_streams > 4 included)
+        for k in dec_keys[:-keep]:
             del self._ws[k]
         return ws
 
@@ -334,7 +335,7 @@ class GenerationEngine:
                              vt_strides=(Hk * d * Sp, d * Sp, Sp), o_strides=(S * H * d, H * d), B=B, H=H, Hk=Hk, Sq=S,
                              Skv=pos0 + S, head_dim=d, scale=scale, causal=True)
             else:
-                ops.attn_decode(qkv, kcl, vcl, att, B, H, Hk, d, Tmax, 1, scale, ctx_dev=pos_dev)
+                ops.attn_decode(qkv, kcl, vcl, att, B, H, Hk, d, Tmax, pos0 + 1, scale, ctx_dev=pos_dev)
             # x += o_proj(att); h = rmsnorm(x) * post_attention_layernorm  (norm fused into the GEMM epilogue for small M)
             # (decode regime) the row-owning epilogue that produces h also evaluates the router of the group that consumes h
             ahead_gu = m._gu.routes_ahead(M)
@@ -443,9 +444,13 @@ class GenerationEngine:
     @torch.no_grad()
     def generate(self, embeds: torch.Tensor, max_new_tokens: int, eos_token_id: Optional[int] = None,
                  pad_token_id: Optional[int] = None, min_new_tokens: int = 0, prefill_chunk: int = 0, use_graph: bool = True,
-                 return_step_logits: bool = False, return_hidden: bool = False, decode_streams: int = 1):
+                 return_step_logits: bool = False, return_hidden: bool = False, decode_streams: int = 1,
+                 return_first_logits: bool = False):
         """Greedy generation from inputs_embeds only, as UnifiedForCausalLM.generate drives HF generate
         (unified_llama.py:262-267): positions 0..S-1 (left pads attended), returns ONLY new ids.
+
+        return_first_logits: also return the fp32 last-row logits of the prefill ([B, V], one clone per call: what the multi-GPU
+        eval gathers next to the ids, crab_amd/parallel.py) without keeping every step's logits.
 
         decode_streams > 1 splits the batch into that many groups whose decode steps (one HIP graph each) replay on
         separate HIP streams: the HBM-bound KV-cache attention of one group overlaps the MFMA-bound projections of
@@ -454,9 +459,11 @@ class GenerationEngine:
         graphed = use_graph and max_new_tokens > 2
         G = decode_streams if (decode_streams > 1 and graphed and B >= decode_streams and
                                not return_step_logits and not return_hidden) else 1
-        step_logits, hiddens = [], []
+        step_logits, hiddens, first_logits = [], [], []
 
         def sink(st):
+            if return_first_logits and len(first_logits) < G:
+                first_logits.append(st.logits.clone())
             if return_step_logits:
                 step_logits.append(st.logits.clone())
             if return_hidden:
@@ -529,6 +536,8 @@ class GenerationEngine:
             res.append(torch.stack(step_logits, 1)[:, : out.shape[1]])
         if return_hidden:
             res.append(torch.stack(hiddens, 1)[:, : out.shape[1]])
+        if return_first_logits:
+            res.append(first_logits[0] if G == 1 else torch.cat(first_logits, 0))
         return res[0] if len(res) == 1 else tuple(res)
 
     def _capture(self, st: "_DecodeState"):

@@ -74,7 +74,24 @@ class UnifiedForCausalLM(nn.Module, UnifiedMetaForCausalLM):
         behind.  Map the packed buffers themselves, re-point the views, drop captured graphs / caches.  dtype changes raise."""
         groups = self.packed_groups()
         packed = [(g.W, g.bias, g.RA, g.B2) for g in groups]
-        r = super()._apply(fn, *args, **kwargs)
+        # refuse a dtype change BEFORE anything is converted (rebind would only notice after nn.Module._apply had already mapped every
+        # other parameter, leaving a half-converted model)
+        if fn(torch.empty(1, dtype=BF16, device=self.lm_head.weight.device)).dtype != BF16:
+            raise TypeError("crab_amd keeps decoder weights in bfloat16: .float() / .half() / .to(dtype) are not supported")
+        # detach the view Parameters of the packed groups while nn.Module._apply maps the rest: mapping each view would
+        # materialise a second copy of every projection matrix on the target device before rebind() replaces it
+        views = []
+        for g in groups:
+            for lin in g.linears:
+                for mod in lin.modules():                     # the Linear and its lora_route / lora_A / lora_B{i} holders
+                    for name in list(mod._parameters):
+                        views.append((mod, name, mod._parameters[name]))
+                        mod._parameters[name] = None
+        try:
+            r = super()._apply(fn, *args, **kwargs)
+        finally:
+            for mod, name, prm in views:
+                mod._parameters[name] = prm
         for g, (W, b, RA, B2) in zip(groups, packed):
             g.W, g.bias, g.RA, g.B2 = W, b, RA, B2             # the buffers as they were: rebind maps them once
             g.rebind(fn)
@@ -182,6 +199,7 @@ class UnifiedForCausalLM(nn.Module, UnifiedMetaForCausalLM):
     def generate(self, batch_input_ids=None, batch_labels=None, batch_X_modals=None, batch_task_names=None, **kwargs):
         """unified_llama.py:244-267.  kwargs understood (HF names): max_new_tokens, min_new_tokens, eos_token_id,
         pad_token_id, use_cache, do_sample (must be falsy), output_logits / return_dict_in_generate (parity audits),
+        output_first_logits (ids + the fp32 logits of the first generated position, [B, V]: the record the multi-GPU eval gathers),
         inputs_embeds (skip prepare_multimodal_inputs)."""
         if kwargs.get("do_sample"):
             raise NotImplementedError("sampling is not implemented: the MI355X path is greedy-only")
@@ -198,14 +216,21 @@ class UnifiedForCausalLM(nn.Module, UnifiedMetaForCausalLM):
         eos = kwargs.get("eos_token_id", self.config.eos_token_id)
         pad = kwargs.get("pad_token_id", self.model.pad_token_id if self.model.pad_token_id is not None else eos)
         want_logits = bool(kwargs.get("output_logits")) and bool(kwargs.get("return_dict_in_generate"))
+        want_first = bool(kwargs.get("output_first_logits"))      # not an HF name: ids + the first step's logits only (eval gather)
         res = self._engine.generate(embeds, max_new, eos_token_id=eos, pad_token_id=pad,
                                     min_new_tokens=int(kwargs.get("min_new_tokens", 0) or 0),
                                     prefill_chunk=int(kwargs.get("prefill_chunk", 0)), use_graph=kwargs.get("use_graph", True),
-                                    return_step_logits=want_logits, decode_streams=int(kwargs.get("decode_streams", 1)))
-        if want_logits:
-            ids, sl = res
+                                    return_step_logits=want_logits, decode_streams=int(kwargs.get("decode_streams", 1)),
+                                    return_first_logits=want_first)
+        if want_logits or want_first:
+            res = list(res)
             out = type("GenerateOutput", (), {})()
-            out.sequences, out.logits = ids, tuple(sl[:, i] for i in range(sl.shape[1]))
+            out.sequences = res.pop(0)
+            if want_logits:
+                sl = res.pop(0)
+                out.logits = tuple(sl[:, i] for i in range(sl.shape[1]))
+            if want_first:
+                out.first_logits = res.pop(0)
             return out
         return res
 

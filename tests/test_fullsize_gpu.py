@@ -78,34 +78,94 @@ def test_generate_deterministic_and_batch_rows_independent_full_size(crab):
     assert a.sequences.shape == (3, 6)
 
 
-def test_decode_batch_256_path_agrees_with_small_batch_full_size(crab):
-    """The benchmark's decode regime (M = 256: ring / two-stage split-K GEMMs, RoPE + KV append fused into the q|k|v
-    reduction, SwiGLU epilogue, routers evaluated in the post-norm reductions) against the SAME sequences decoded at batch 4
-    (LDS-free skinny kernels, separate router / RoPE launches): per-step logits of the shared rows agree to bf16 noise and
-    the greedy ids are identical wherever the small-batch top-2 margin exceeds twice the measured difference."""
-    um = crab.base_model.model
-    D = um.config.hidden_size
-    g = torch.Generator(device="cuda").manual_seed(11)
-    emb = (torch.randn(256, 40, D, device="cuda", generator=g) * 0.05).to(BF)
-    kw = dict(max_new_tokens=5, eos_token_id=None, pad_token_id=2, output_logits=True, return_dict_in_generate=True)
-    big = um.generate(inputs_embeds=emb, **kw)
-    big2 = um.generate(inputs_embeds=emb, **kw)
-    assert torch.equal(big.sequences, big2.sequences), "non-deterministic at batch 256"
-    small = um.generate(inputs_embeds=emb[:4], **kw)
-    lb, ls = torch.stack(big.logits, 1)[:4].float(), torch.stack(small.logits, 1).float()
-    worst = 0.0
-    for b in range(4):
-        for s in range(5):
-            err = (lb[b, s] - ls[b, s]).abs().max().item()
-            worst = max(worst, err / ls[b, s].abs().max().item())
-            # two different kernel paths through 32 synthetic layers: accumulation-order noise is amplified (DESIGN.md 4)
-            assert err < 8e-2 * ls[b, s].abs().max().item(), (b, s, err)
-            if big.sequences[b, s] != small.sequences[b, s]:
-                top2 = ls[b, s].topk(2).values
-                assert (top2[0] - top2[1]).item() <= 2 * err, (b, s)
-                break
+def test_decode_batch_256_regime_vs_cpu_oracle_full_size(crab):
+    """The BENCHMARKED regime against the oracle: 32-layer Llama-2-7B-size hyper-LoRA decoder, B = 256 clips, S = 702 embedding rows,
+    8 greedy tokens - chunked ring-kernel prefill, then the M = 256 decode path (gemm_dec_ws_kernel panels, RoPE + KV append fused
+    into the q|k|v reduction, SwiGLU epilogue, routers and norms inside the row-owning reductions, attn_decode_kernel<128> at
+    B = 256), through generate()'s captured HIP graph.  Rows are independent, so the fp32 CPU oracle (O.greedy_generate, ~30 s a row
+    on the GPU box's host cores) is run on three SAMPLED rows and compared
+      (1) with generate()'s per-step logits of those rows up to the first step where the ids part (margin-exact ids), and
+      (2) TEACHER-FORCED: the same decode state driven along the oracle's token path (cur_ids of the sampled rows overwritten
+          before every graph replay), so every step's logits are compared on identical contexts.
+    (3) the same rows decoded at batch 4 (skinny kernels) bound the HIP-vs-HIP path difference at <= 2x what (2) measures.
+    models/modeling_llama.py:394-452, peft_hyper/tuners/lora.py:338-350."""
+    from oracle import crab_oracle as O
     from tests.util import record_parity
-    record_parity("32-layer: batch-256 decode path vs batch-4 path, per-step logits (HIP vs HIP)", worst, 1.0, 8e-2)
+    um = crab.base_model.model
+    eng = um._engine
+    D = um.config.hidden_size
+    B, S, n_new = 256, 702, 8
+    rows = [0, 131, 255]
+    W = {}
+    for k, v in O.strip_peft_prefix(crab.state_dict()).items():
+        if v.dtype.is_floating_point and (k.startswith("model.layers.") or k.startswith("model.norm") or k.startswith("lm_head") or k.startswith("model.embed_tokens")):
+            W[k] = v.detach().float().cpu()
+    cfg = O.DecoderConfig(vocab_size=um.lm_head.weight.shape[0])
+    g = torch.Generator(device="cuda").manual_seed(29)
+    emb = torch.randn(B, S, D, device="cuda", generator=g).to(BF)
+    ref = [O.greedy_generate(emb[r:r + 1].float().cpu(), W, cfg, n_new) for r in rows]
+    scale = max(l.abs().max().item() for _, l in ref)
+    TOL = 3e-2
+    # (1) the public path: graph-replayed decode at M = 256
+    ids, logits = eng.generate(emb, n_new, eos_token_id=None, pad_token_id=2, return_step_logits=True)
+    st = eng._dec[0]
+    assert st.B == B and st.graph is not None, "generate() did not decode 256 rows through a captured graph"
+    ids, logits = ids.cpu(), logits.float().cpu()
+    worst_gen, same_steps = 0.0, []
+    for (rid, rlog), r in zip(ref, rows):
+        top2 = rlog[0].topk(2, -1).values
+        margin = top2[:, 0] - top2[:, 1]
+        same = 0
+        for s in range(n_new):
+            e = (logits[r, s] - rlog[0, s]).abs().max().item()
+            worst_gen = max(worst_gen, e)
+            if ids[r, s] != rid[0, s]:
+                assert margin[s].item() <= 2 * e, ("generate() B=256", r, s, int(ids[r, s]), int(rid[0, s]), e, margin[s].item())
+                break
+            assert e < TOL * scale, ("generate() B=256", r, s, e, scale)
+            same += 1
+        same_steps.append(same)
+    # (2) teacher-forced on the SAME decode state and graph: prefill again (first token selected from the prefill logits), then
+    # overwrite the sampled rows' current ids with the oracle's before every replay
+    eng._start(emb, n_new, None, 2, 0, 0, False, 0)
+    graph = eng._capture(st)
+    errs, agree, total = [], 0, 0
+    rr = torch.tensor(rows, device="cuda")
+    for s in range(n_new):
+        if s > 0:
+            st.cur_ids[rr] = torch.stack([rid[0, s - 1] for rid, _ in ref]).cuda()
+            graph.replay()
+        lg = st.logits[rr].float().cpu()
+        for j, (rid, rlog) in enumerate(ref):
+            e = (lg[j] - rlog[0, s]).abs().max().item()
+            errs.append(e)
+            top2 = rlog[0, s].topk(2).values
+            ok = int(lg[j].argmax()) == int(rid[0, s])
+            assert e < TOL * scale, ("teacher-forced B=256", rows[j], s, e, scale)
+            assert ok or float(top2[0] - top2[1]) <= 2 * e, ("teacher-forced argmax B=256", rows[j], s, e, float(top2[0] - top2[1]))
+            agree += ok
+            total += 1
+    record_parity("32-layer Llama-2-7B-size decoder, B=256 x S=702 + 8 tokens (benchmark decode regime, graph), sampled rows vs fp32 CPU oracle",
+                  max(errs), scale, TOL, rows=rows, generate_worst_abs=worst_gen, generate_steps_with_identical_ids=same_steps,
+                  argmax_agree=agree, comparisons=total)
+    # (3) HIP vs HIP: the sampled rows (+ one) decoded at batch 4 through the skinny kernels
+    small_rows = rows + [7]
+    sids, slog = eng.generate(emb[small_rows], n_new, eos_token_id=None, pad_token_id=2, return_step_logits=True)
+    slog = slog.float().cpu()
+    worst = 0.0
+    for j, r in enumerate(small_rows):
+        for s in range(n_new):
+            e = (logits[r, s] - slog[j, s]).abs().max().item()
+            if ids[r, s] != sids[j, s].cpu():
+                top2 = slog[j, s].topk(2).values
+                assert float(top2[0] - top2[1]) <= 2 * e, (r, s)
+                break
+            worst = max(worst, e)
+    bound = 2 * max(errs)                                   # <= 2x the error of the M = 256 path against the oracle
+    record_parity("32-layer: batch-256 decode path vs batch-4 path on the same rows, per-step logits (HIP vs HIP)", worst, scale, bound / scale)
+    assert worst <= bound, (worst, bound)
+    eng.invalidate()                                        # 2 x 52 GB of KV cache: hand it back before the next test
+    torch.cuda.empty_cache()
 
 
 def test_generate_avs_full_width_vs_cpu_oracle():

@@ -37,6 +37,10 @@ def test_module_apply_keeps_views_bound_and_refuses_dtype_changes():
     assert q.lora_A.weight.data_ptr() == g2.RA[g2.nl:].data_ptr()
     with pytest.raises(TypeError):
         model.float()
+    # the refusal happens BEFORE anything is converted: norms / embeddings still bf16, the views still alias the packed buffers
+    assert all(p.dtype == torch.bfloat16 for p in model.parameters())
+    q = um.model.layers[0].self_attn.q_proj
+    assert q.weight.data_ptr() == um.model.layers[0].self_attn._qkv.W.data_ptr()
 
 
 def test_state_dict_round_trip_through_views():

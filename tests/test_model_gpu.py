@@ -93,9 +93,11 @@ def _inputs(meta):
              '<audio>': synth.synth_audio(p["t_a"], p["l_a"], seed=meta["seed"], clip=c)} for c in (p["clip0"], p["clip1"])]
 
 
-def _check_ids(ids, ref_ids, ref_logits, got_logits):
-    """ids must agree up to (and including) every step whose reference top-2 margin exceeds 4x the measured
-    max logit error; after a sub-margin step the sequences may legitimately diverge."""
+def _check_ids(ids, ref_ids, ref_logits, got_logits, min_frac=1.0):
+    """ids must agree up to (and including) every step whose reference top-2 margin exceeds 2x the measured
+    max logit error; after a sub-margin step the sequences may legitimately diverge.  `min_frac` = the fraction of steps that
+    must be covered before such a divergence: 1.0 (every step of every row, what MI355X measured on every fixture -
+    profiles/r02_parity_report.json: steps_checked == steps_total in all 20 rows) unless a caller states a measured lower value."""
     ids = ids.cpu()
     got_logits = got_logits.float().cpu()
     top2 = ref_logits.topk(2, dim=-1).values
@@ -112,7 +114,7 @@ def _check_ids(ids, ref_ids, ref_logits, got_logits):
                                                  f"{margin[b, s]:.4f} exceeds twice the logit error {err:.4f}")
                 break          # legitimately diverged at a sub-noise margin: later steps see different contexts
             checked += 1
-    assert checked >= 0.5 * total, f"greedy-id parity covered only {checked}/{total} steps"
+    assert checked >= min_frac * total, f"greedy-id parity covered only {checked}/{total} steps (required fraction {min_frac})"
     from tests.util import record_parity
     record_parity("greedy per-step last-row logits, worst step", worst, ref_logits.abs().max().item(), None, steps_checked=checked, steps_total=total,
                   min_ref_margin=float(margin.min()))

@@ -89,6 +89,11 @@ def _build(meta, W, device="cuda"):
     return m
 
 
+# fraction of the fixture's positions whose id may differ from the reference's (each must also sit at a sub-margin position):
+# 2x the fraction measured on MI355X (recorded in the parity report by this test)
+VQ_ID_MISMATCH_CAP = 0.15
+
+
 @pytest.mark.gpu
 def test_mask_encoder_matches_reference_fixture_and_oracle():
     meta, A, cfg, W, x = _setup()
@@ -106,7 +111,10 @@ def test_mask_encoder_matches_reference_fixture_and_oracle():
     zr = A["latents"].permute(0, 2, 3, 1).reshape(-1, e.shape[1])
     derr = 2 * ((zf - zr) @ e.t()).abs().max(1).values.view(2, -1)         # how far the bf16 latents move any distance
     bad = ids != ref
-    assert bad.float().mean() < 0.15, bad.float().mean()
+    from tests.util import record_parity
+    record_parity("vqgan_tiny: fraction of codebook ids that differ from the reference (all at sub-margin positions)", bad.float().mean().item(), 1.0,
+                  VQ_ID_MISMATCH_CAP, positions=int(bad.numel()), mismatches=int(bad.sum()))
+    assert bad.float().mean() <= VQ_ID_MISMATCH_CAP, bad.float().mean()
     assert (A["margin"][bad] <= 2 * derr[bad] + 1e-3).all(), "id mismatch that the latent error cannot explain"
     # decode path from the REFERENCE ids
     img = m.decode_mask(ref.cuda() + 32020).cpu()
