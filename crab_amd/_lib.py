@@ -47,6 +47,7 @@ class AttnDesc(C.Structure):
         ("bias", C.c_void_p), ("gate", C.c_void_p),
         ("B", C.c_int32), ("H", C.c_int32), ("Hk", C.c_int32), ("Sq", C.c_int32), ("Skv", C.c_int32),
         ("head_dim", C.c_int32), ("causal", C.c_int32), ("scale", C.c_float),
+        ("kv_start", C.c_void_p),
     ]
 
 
@@ -106,6 +107,8 @@ SYMBOLS = {
     "crab_embedding": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i]),
     "crab_rope_table": (_i, [_vp, _vp, _vp, _i, _i, _f]),
     "crab_qkv_rope_split": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "crab_qkv_rope_split_ids": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i64]),
+    "crab_attn_decode_masked": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _vp, _f, _vp]),
     "crab_attn_fwd": (_i, [_vp, _vp, C.POINTER(AttnDesc)]),
     "crab_attn_decode": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _vp, _f]),
     "crab_swiglu": (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _i, _i]),

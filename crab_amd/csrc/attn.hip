@@ -22,6 +22,7 @@ struct AttnP {
     const bf16_t* q; const bf16_t* k; const bf16_t* vt; bf16_t* o;
     long q_bs, q_hs, q_ss, k_bs, k_hs, k_ss, vt_bs, vt_hs, vt_ds, o_bs, o_ss;
     const float* bias; const float* gate;
+    const int* kv_start;                    // optional [B]: keys j < kv_start[b] are masked (left-pad attention_mask)
     int B, H, Hk, Sq, Skv, causal;
     float scale;
 };
@@ -84,6 +85,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
         if (last + 1 < kv_end) kv_end = last + 1;
     }
     const int ntiles = (kv_end + KT - 1) / KT;
+    // left-pad mask (forward() with attention_mask, unified_llama.py:149-160): keys below kv_start[b] are invisible; whole tiles
+    // below it are skipped.  A query row that sees no key at all (a pad row) ends with l_run == 0 and stores zeros.
+    const int ks0 = p.kv_start ? p.kv_start[b] : 0;
+    const int t0 = ks0 / KT;
     const u32x4 z4 = {0u, 0u, 0u, 0u};
     const u32x2 z2 = {0u, 0u};
 
@@ -117,8 +122,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
             vreg[i] = v;                                                                                       \
         }                                                                                                      \
     }
-    ATT_LOAD_TILE(0);
-    for (int t = 0; t < ntiles; ++t) {
+    if (t0 < ntiles) ATT_LOAD_TILE(t0);
+    for (int t = t0; t < ntiles; ++t) {
         const int kv0 = t * KT;
         __syncthreads();                                         // previous tile fully consumed
         // ---- registers -> LDS: K tile (KT rows x CPR swizzled chunks), V^T tile (HD rows x 8 chunks, padded rows)
@@ -157,7 +162,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
         // can contain masked keys (the diagonal tile of a causal block, the ragged last tile): after the software
         // pipelining the kernel is VALU-bound (PMC: VALU active 30 % of wave cycles at two waves per SIMD).
         const float sc2 = p.scale * 1.4426950408889634f;
-        const bool need_mask = (kv0 + KT > p.Skv) || (CAUSAL && (kv0 + KT - 1 > q0 + wave * 16 + koff));
+        const bool need_mask = (kv0 + KT > p.Skv) || (CAUSAL && (kv0 + KT - 1 > q0 + wave * 16 + koff)) || (kv0 < ks0);
         float tmax = -1e30f;
         if (BIAS || need_mask) {
 #pragma unroll
@@ -167,7 +172,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
                     int kv = kv0 + j * 16 + fg * 4 + r;
                     float v = s[j][r] * sc2;
                     if (BIAS) { if (kv < p.Skv) v += gate * biasrow[kv] * 1.4426950408889634f; }
-                    bool ok = kv < p.Skv;
+                    bool ok = kv < p.Skv && kv >= ks0;
                     if (CAUSAL) ok = ok && (kv <= qrow + koff);
                     v = ok ? v : -INFINITY;
                     s[j][r] = v;
@@ -183,7 +188,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
         }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float m_new = fmaxf(m_run, tmax);
+        const float m_new = fmaxf(m_run, tmax);                // stays at the finite -1e30 while every key so far is masked
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         m_run = m_new;
         float psum = 0.f;
@@ -220,7 +225,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
     // ---- finish: total row sum over the 4 lane groups, normalise, store 4 consecutive d per lane
     l_run += __shfl_xor(l_run, 16, 64);
     l_run += __shfl_xor(l_run, 32, 64);
-    const float inv = 1.0f / l_run;
+    const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;        // no visible key (left-pad query row): zeros, never read by a valid row
     if (qrow < p.Sq) {
         bf16_t* op = p.o + (long)b * p.o_bs + (long)qrow * p.o_ss + (long)h * HD;
 #pragma unroll
@@ -243,7 +248,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
 template <int HD>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restrict__ q, long ldq, const bf16_t* __restrict__ kc,
                                                           const bf16_t* __restrict__ vc, bf16_t* __restrict__ o, long ldo, int H, int Hk,
-                                                          int Tmax, int ctx_host, const int* __restrict__ ctx_dev, float scale) {
+                                                          int Tmax, int ctx_host, const int* __restrict__ ctx_dev, float scale,
+                                                          const int* __restrict__ kv_start) {
     constexpr int EPL = HD / 16;
     __shared__ float sm[16], sl[16];
     __shared__ float so[16][HD];
@@ -251,13 +257,14 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
     const int grp = tid >> 4, sub = tid & 15;
     const int b = blockIdx.y, h = blockIdx.x;
     const int hk = h / (H / Hk);
-    const int ctx = ctx_host + (ctx_dev ? ctx_dev[0] : 0);
+    const int ks0 = kv_start ? kv_start[b] : 0;                 // left-pad mask: the first ks0 cache rows of this sequence are invisible
+    const int ctx = ctx_host + (ctx_dev ? ctx_dev[0] : 0) - ks0;
     const bf16_t* qp = q + (long)b * ldq + (long)h * HD + sub * EPL;
     float qv[EPL];
 #pragma unroll
     for (int e = 0; e < EPL; ++e) qv[e] = bf2f(qp[e]) * scale;
-    const bf16_t* kb = kc + ((long)b * Hk + hk) * (long)Tmax * HD + sub * EPL;
-    const bf16_t* vb = vc + ((long)b * Hk + hk) * (long)Tmax * HD + sub * EPL;
+    const bf16_t* kb = kc + (((long)b * Hk + hk) * (long)Tmax + ks0) * HD + sub * EPL;
+    const bf16_t* vb = vc + (((long)b * Hk + hk) * (long)Tmax + ks0) * HD + sub * EPL;
     float m = -1e30f, l = 0.f, acc[EPL];
 #pragma unroll
     for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
@@ -362,7 +369,8 @@ constexpr int GQ_CH = 512;
 template <int HD, int G>
 __global__ __launch_bounds__(256, (G <= 4 ? 3 : 2)) void attn_decode_gqa_kernel(const bf16_t* __restrict__ q, long ldq, const bf16_t* __restrict__ kc,
                                                               const bf16_t* __restrict__ vc, bf16_t* __restrict__ o, long ldo, int Hk,
-                                                              int Tmax, int ctx_host, const int* __restrict__ ctx_dev, float scale) {
+                                                              int Tmax, int ctx_host, const int* __restrict__ ctx_dev, float scale,
+                                                              const int* __restrict__ kv_start) {
     static_assert(HD == 128 && G >= 2 && G <= 8, "grouped decode: head_dim 128, 2..8 query heads per kv head");
     constexpr int EPL = 8;
     // scores [GQ_CH][8] fp32 (16 KB) during the chunks, reused as the merge buffer [4 waves][G][HD] fp32 at the end (the four
@@ -375,7 +383,8 @@ __global__ __launch_bounds__(256, (G <= 4 ? 3 : 2)) void attn_decode_gqa_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int grp = tid >> 4, sub = tid & 15;
     const int b = blockIdx.y, hk = blockIdx.x;
-    const int ctx = ctx_host + (ctx_dev ? ctx_dev[0] : 0);
+    const int ks0 = kv_start ? kv_start[b] : 0;
+    const int ctx = ctx_host + (ctx_dev ? ctx_dev[0] : 0) - ks0;
     float qv[G][EPL];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -383,8 +392,8 @@ __global__ __launch_bounds__(256, (G <= 4 ? 3 : 2)) void attn_decode_gqa_kernel(
 #pragma unroll
         for (int e = 0; e < 4; ++e) { qv[g][2 * e] = lo_bf(w[e]) * scale; qv[g][2 * e + 1] = hi_bf(w[e]) * scale; }
     }
-    const bf16_t* kb = kc + ((long)b * Hk + hk) * (long)Tmax * HD + sub * EPL;
-    const bf16_t* vb = vc + ((long)b * Hk + hk) * (long)Tmax * HD + sub * EPL;
+    const bf16_t* kb = kc + (((long)b * Hk + hk) * (long)Tmax + ks0) * HD + sub * EPL;
+    const bf16_t* vb = vc + (((long)b * Hk + hk) * (long)Tmax + ks0) * HD + sub * EPL;
     float acc[G][EPL];
 #pragma unroll
     for (int g = 0; g < G; ++g)
@@ -545,7 +554,7 @@ extern "C" int crab_attn_fwd(crab_ctx* ctx, void* stream, const crab_attn_desc* 
     p.q = (const bf16_t*)d->q; p.k = (const bf16_t*)d->k; p.vt = (const bf16_t*)d->vt; p.o = (bf16_t*)d->o;
     p.q_bs = d->q_bs; p.q_hs = d->q_hs; p.q_ss = d->q_ss; p.k_bs = d->k_bs; p.k_hs = d->k_hs; p.k_ss = d->k_ss;
     p.vt_bs = d->vt_bs; p.vt_hs = d->vt_hs; p.vt_ds = d->vt_ds; p.o_bs = d->o_bs; p.o_ss = d->o_ss;
-    p.bias = d->bias; p.gate = d->gate; p.B = d->B; p.H = d->H; p.Hk = d->Hk; p.Sq = d->Sq; p.Skv = d->Skv;
+    p.bias = d->bias; p.gate = d->gate; p.kv_start = d->kv_start; p.B = d->B; p.H = d->H; p.Hk = d->Hk; p.Sq = d->Sq; p.Skv = d->Skv;
     p.causal = d->causal; p.scale = d->scale;
     dim3 grid(((d->Sq + 63) / 64) * d->H * d->B), block(256);
     hipStream_t s = (hipStream_t)stream;
@@ -565,9 +574,9 @@ extern "C" int crab_attn_fwd(crab_ctx* ctx, void* stream, const crab_attn_desc* 
     return crab_check_launch(ctx, "attn_fwd");
 }
 
-extern "C" int crab_attn_decode(crab_ctx* ctx, void* stream, const void* q, int64_t ldq, const void* k_cache, const void* v_cache,
-                                void* o, int64_t ldo, int B, int H, int Hk, int d, int Tmax, int ctx_len_host, const int32_t* ctx_dev,
-                                float scale) {
+extern "C" int crab_attn_decode_masked(crab_ctx* ctx, void* stream, const void* q, int64_t ldq, const void* k_cache, const void* v_cache,
+                                       void* o, int64_t ldo, int B, int H, int Hk, int d, int Tmax, int ctx_len_host, const int32_t* ctx_dev,
+                                       float scale, const int32_t* kv_start) {
     if (!ctx) return CRAB_E_INVALID;
     if (!q || !k_cache || !v_cache || !o || B <= 0 || H <= 0 || Hk <= 0 || H % Hk) return crab_fail(ctx, CRAB_E_INVALID, "attn_decode: bad argument");
     if (d != 64 && d != 128) return crab_fail(ctx, CRAB_E_UNSUPPORTED, "attn_decode: head_dim must be 64 or 128");
@@ -580,16 +589,22 @@ extern "C" int crab_attn_decode(crab_ctx* ctx, void* stream, const void* q, int6
         dim3 gg(Hk, B);
 #define CRAB_GQA(G_)                                                                                                             \
     hipLaunchKernelGGL((attn_decode_gqa_kernel<128, G_>), gg, block, 0, s, (const bf16_t*)q, (long)ldq, (const bf16_t*)k_cache,   \
-                       (const bf16_t*)v_cache, (bf16_t*)o, (long)ldo, Hk, Tmax, ctx_len_host, ctx_dev, scale)
+                       (const bf16_t*)v_cache, (bf16_t*)o, (long)ldo, Hk, Tmax, ctx_len_host, ctx_dev, scale, kv_start)
         if (G == 2) CRAB_GQA(2); else if (G == 4) CRAB_GQA(4); else if (G == 7) CRAB_GQA(7); else CRAB_GQA(8);
 #undef CRAB_GQA
         return crab_check_launch(ctx, "attn_decode_gqa");
     }
     if (d == 128)
         hipLaunchKernelGGL((attn_decode_kernel<128>), grid, block, 0, s, (const bf16_t*)q, (long)ldq, (const bf16_t*)k_cache,
-                           (const bf16_t*)v_cache, (bf16_t*)o, (long)ldo, H, Hk, Tmax, ctx_len_host, ctx_dev, scale);
+                           (const bf16_t*)v_cache, (bf16_t*)o, (long)ldo, H, Hk, Tmax, ctx_len_host, ctx_dev, scale, kv_start);
     else
         hipLaunchKernelGGL((attn_decode_kernel<64>), grid, block, 0, s, (const bf16_t*)q, (long)ldq, (const bf16_t*)k_cache,
-                           (const bf16_t*)v_cache, (bf16_t*)o, (long)ldo, H, Hk, Tmax, ctx_len_host, ctx_dev, scale);
+                           (const bf16_t*)v_cache, (bf16_t*)o, (long)ldo, H, Hk, Tmax, ctx_len_host, ctx_dev, scale, kv_start);
     return crab_check_launch(ctx, "attn_decode");
+}
+
+extern "C" int crab_attn_decode(crab_ctx* ctx, void* stream, const void* q, int64_t ldq, const void* k_cache, const void* v_cache,
+                                void* o, int64_t ldo, int B, int H, int Hk, int d, int Tmax, int ctx_len_host, const int32_t* ctx_dev,
+                                float scale) {
+    return crab_attn_decode_masked(ctx, stream, q, ldq, k_cache, v_cache, o, ldo, B, H, Hk, d, Tmax, ctx_len_host, ctx_dev, scale, nullptr);
 }

@@ -110,7 +110,8 @@ __global__ void rope_table_kernel(float* tab, int max_pos, int half, float theta
 // grid (T, H + 2*Hk); block d/2 threads... one thread handles the pair (i, i+d/2)
 __global__ void qkv_rope_split_kernel(bf16_t* __restrict__ qkv, long ldqkv, const float* __restrict__ tab,
                                       bf16_t* __restrict__ kc, bf16_t* __restrict__ vc, bf16_t* __restrict__ vt, long vt_ld,
-                                      int S, int H, int Hk, int d, int Tmax, int pos0, const int* __restrict__ pos_dev) {
+                                      int S, int H, int Hk, int d, int Tmax, int pos0, const int* __restrict__ pos_dev,
+                                      const int* __restrict__ pos_ids, long ld_pos) {
     const int t = blockIdx.x;            // token index b*S + s
     const int hh = blockIdx.y;           // 0..H-1 q heads, H..H+Hk-1 k heads, H+Hk.. v heads
     const int b = t / S, s = t % S;
@@ -118,13 +119,14 @@ __global__ void qkv_rope_split_kernel(bf16_t* __restrict__ qkv, long ldqkv, cons
     const int i = threadIdx.x;
     if (i >= half) return;
     if (!tab && (hh < H || (hh < H + Hk && !kc))) return;      // encoder use: only V^T is materialised
-    const int pos = (pos_dev ? pos_dev[0] : 0) + pos0 + s;
+    const int pos = (pos_dev ? pos_dev[0] : 0) + pos0 + s;       // cache slot
+    const int rp = pos_ids ? pos_ids[(long)b * ld_pos + s] : pos;   // rotary position (position_ids of forward())
     bf16_t* src = qkv + (long)t * ldqkv + (long)hh * d;
     if (hh < H + Hk) {
         float x1 = bf2f(src[i]), x2 = bf2f(src[i + half]);
         float o1 = x1, o2 = x2;
         if (tab) {
-            float c = tab[2 * ((long)pos * half + i)], sn = tab[2 * ((long)pos * half + i) + 1];
+            float c = tab[2 * ((long)rp * half + i)], sn = tab[2 * ((long)rp * half + i) + 1];
             // q*cos + rotate_half(q)*sin, each product rounded as in the bf16 reference? fp32 here, one rounding
             o1 = rope_lo(x1, x2, c, sn);
             o2 = rope_hi(x1, x2, c, sn);
@@ -161,7 +163,8 @@ __global__ void qkv_rope_split_kernel(bf16_t* __restrict__ qkv, long ldqkv, cons
 template <int D>
 __global__ __launch_bounds__(256) void qkv_rope_split_tile_kernel(bf16_t* __restrict__ qkv, long ldqkv, const float* __restrict__ tab,
                                                                   bf16_t* __restrict__ kc, bf16_t* __restrict__ vc, bf16_t* __restrict__ vt,
-                                                                  long vt_ld, int S, int H, int Hk, int Tmax, int pos0) {
+                                                                  long vt_ld, int S, int H, int Hk, int Tmax, int pos0,
+                                                                  const int* __restrict__ pos_ids, long ld_pos) {
     constexpr int HALF = D / 2, CH = D / 8;                     // 16-byte chunks per head row
     __shared__ bf16_t tile[64][D + 2];                          // +2: odd word stride for the transposed reads
     const int tid = threadIdx.x;
@@ -178,9 +181,10 @@ __global__ __launch_bounds__(256) void qkv_rope_split_tile_kernel(bf16_t* __rest
             u32x4 lo = *reinterpret_cast<const u32x4*>(src);
             u32x4 hi = *reinterpret_cast<const u32x4*>(src + HALF);
             u32x4 olo = lo, ohi = hi;
-            const int pos = pos0 + s;
+            const int pos = pos0 + s;                                       // cache slot
             if (tab) {
-                const float* cs = tab + 2 * ((long)pos * HALF + c * 8);
+                const int rp = pos_ids ? pos_ids[(long)b * ld_pos + s] : pos;   // rotary position
+                const float* cs = tab + 2 * ((long)rp * HALF + c * 8);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float x1a = lo_bf(lo[e]), x1b = hi_bf(lo[e]), x2a = lo_bf(hi[e]), x2b = hi_bf(hi[e]);
@@ -663,12 +667,19 @@ int crab_rope_table(crab_ctx* ctx, void* stream, float* tab, int max_pos, int he
 
 int crab_qkv_rope_split(crab_ctx* ctx, void* stream, void* qkv, int64_t ldqkv, const float* rope_tab, void* k_cache, void* v_cache,
                         void* vt, int64_t vt_ld, int B, int S, int H, int Hk, int d, int Tmax, int pos0, const int32_t* pos_dev) {
+    return crab_qkv_rope_split_ids(ctx, stream, qkv, ldqkv, rope_tab, k_cache, v_cache, vt, vt_ld, B, S, H, Hk, d, Tmax, pos0, pos_dev, nullptr, 0);
+}
+
+int crab_qkv_rope_split_ids(crab_ctx* ctx, void* stream, void* qkv, int64_t ldqkv, const float* rope_tab, void* k_cache, void* v_cache,
+                            void* vt, int64_t vt_ld, int B, int S, int H, int Hk, int d, int Tmax, int pos0, const int32_t* pos_dev,
+                            const int32_t* pos_ids, int64_t ld_pos) {
     if (!ctx) return CRAB_E_INVALID;
+    if (pos_ids && ld_pos < S) return crab_fail(ctx, CRAB_E_INVALID, "qkv_rope_split: ld_pos < S");
     if (!qkv || B <= 0 || S <= 0 || d > 2048 || (d & 1)) return crab_fail(ctx, CRAB_E_INVALID, "qkv_rope_split: bad argument");
     if ((k_cache || v_cache) && !pos_dev && pos0 + S > Tmax) return crab_fail(ctx, CRAB_E_INVALID, "qkv_rope_split: KV cache overflow");
     if (S >= 16 && !pos_dev && (d == 32 || d == 64 || d == 128) && (ldqkv & 7) == 0 && (vt == nullptr || (vt_ld & 7) == 0)) {
         dim3 grid((S + 63) / 64, H + 2 * Hk, B);
-#define RS_ARGS (bf16_t*)qkv, (long)ldqkv, rope_tab, (bf16_t*)k_cache, (bf16_t*)v_cache, (bf16_t*)vt, (long)vt_ld, S, H, Hk, Tmax, pos0
+#define RS_ARGS (bf16_t*)qkv, (long)ldqkv, rope_tab, (bf16_t*)k_cache, (bf16_t*)v_cache, (bf16_t*)vt, (long)vt_ld, S, H, Hk, Tmax, pos0, pos_ids, (long)ld_pos
         if (d == 128) hipLaunchKernelGGL((qkv_rope_split_tile_kernel<128>), grid, dim3(256), 0, S_(stream), RS_ARGS);
         else if (d == 64) hipLaunchKernelGGL((qkv_rope_split_tile_kernel<64>), grid, dim3(256), 0, S_(stream), RS_ARGS);
         else hipLaunchKernelGGL((qkv_rope_split_tile_kernel<32>), grid, dim3(256), 0, S_(stream), RS_ARGS);
@@ -677,7 +688,7 @@ int crab_qkv_rope_split(crab_ctx* ctx, void* stream, void* qkv, int64_t ldqkv, c
     }
     int threads = ((d / 2 + 63) / 64) * 64;
     hipLaunchKernelGGL(qkv_rope_split_kernel, dim3(B * S, H + 2 * Hk), dim3(threads), 0, S_(stream), (bf16_t*)qkv, (long)ldqkv, rope_tab,
-                       (bf16_t*)k_cache, (bf16_t*)v_cache, (bf16_t*)vt, (long)vt_ld, S, H, Hk, d, Tmax, pos0, pos_dev);
+                       (bf16_t*)k_cache, (bf16_t*)v_cache, (bf16_t*)vt, (long)vt_ld, S, H, Hk, d, Tmax, pos0, pos_dev, pos_ids, (long)ld_pos);
     return crab_check_launch(ctx, "qkv_rope_split");
 }
 

@@ -249,16 +249,21 @@ def rope_table(max_pos: int, head_dim: int, theta: float, device) -> torch.Tenso
 
 def qkv_rope_split(qkv: torch.Tensor, rope_tab: Optional[torch.Tensor], k_cache: Optional[torch.Tensor],
                    v_cache: Optional[torch.Tensor], vt: Optional[torch.Tensor], B: int, S: int, H: int, Hk: int, d_: int,
-                   Tmax: int, pos0: int = 0, pos_dev: Optional[torch.Tensor] = None):
+                   Tmax: int, pos0: int = 0, pos_dev: Optional[torch.Tensor] = None, pos_ids: Optional[torch.Tensor] = None):
+    """pos_ids (int32 [B, S]): explicit rotary positions (forward()'s position_ids); the cache slot stays pos0 + s."""
     d = _dev(qkv)
     vt_ld = vt.stride(-2) if vt is not None else 0
-    _lib.check(_lib.load().crab_qkv_rope_split(_lib.ctx(d), _stream(), _p(qkv), qkv.stride(0), _p(rope_tab), _p(k_cache), _p(v_cache),
-                                               _p(vt), vt_ld, B, S, H, Hk, d_, Tmax, pos0, _p(pos_dev)), d)
+    if pos_ids is not None and (pos_ids.dtype != torch.int32 or pos_ids.dim() != 2 or pos_ids.stride(1) != 1):
+        raise ValueError("pos_ids must be an int32 [B, S] tensor with contiguous rows")
+    _lib.check(_lib.load().crab_qkv_rope_split_ids(_lib.ctx(d), _stream(), _p(qkv), qkv.stride(0), _p(rope_tab), _p(k_cache), _p(v_cache),
+                                                   _p(vt), vt_ld, B, S, H, Hk, d_, Tmax, pos0, _p(pos_dev), _p(pos_ids),
+                                                   pos_ids.stride(0) if pos_ids is not None else 0), d)
 
 
 def attn_fwd(q, k, vt, o, *, q_strides, k_strides, vt_strides, o_strides, B, H, Hk, Sq, Skv, head_dim, scale, causal=False,
-             bias=None, gate=None):
-    """Strided flash attention; *_strides = (batch, head, row) element strides, o_strides = (batch, row)."""
+             bias=None, gate=None, kv_start=None):
+    """Strided flash attention; *_strides = (batch, head, row) element strides, o_strides = (batch, row).
+    kv_start (int32 [B]): keys below kv_start[b] are masked (left-pad attention_mask)."""
     d = _dev(q)
     a = AttnDesc()
     a.q, a.k, a.vt, a.o = q.data_ptr(), k.data_ptr(), vt.data_ptr(), o.data_ptr()
@@ -268,20 +273,21 @@ def attn_fwd(q, k, vt, o, *, q_strides, k_strides, vt_strides, o_strides, B, H, 
     a.o_bs, a.o_ss = o_strides
     a.bias = bias.data_ptr() if bias is not None else None
     a.gate = gate.data_ptr() if gate is not None else None
+    a.kv_start = kv_start.data_ptr() if kv_start is not None else None
     a.B, a.H, a.Hk, a.Sq, a.Skv, a.head_dim, a.causal, a.scale = B, H, Hk, Sq, Skv, head_dim, 1 if causal else 0, scale
     _lib.check(_lib.load().crab_attn_fwd(_lib.ctx(d), _stream(), C.byref(a)), d)
     return o
 
 
-def attn_decode(q, k_cache, v_cache, o, B, H, Hk, head_dim, Tmax, ctx_len, scale, ctx_dev=None):
+def attn_decode(q, k_cache, v_cache, o, B, H, Hk, head_dim, Tmax, ctx_len, scale, ctx_dev=None, kv_start=None):
     d = _dev(q)
     prof = PROFILER
     sample = prof is not None and prof.decode_eager and prof.decode_ctx > 0 and not torch.cuda.is_current_stream_capturing()
     if sample:
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
-    _lib.check(_lib.load().crab_attn_decode(_lib.ctx(d), _stream(), _p(q), q.stride(0), _p(k_cache), _p(v_cache), _p(o), o.stride(0),
-                                            B, H, Hk, head_dim, Tmax, ctx_len, _p(ctx_dev), scale), d)
+    _lib.check(_lib.load().crab_attn_decode_masked(_lib.ctx(d), _stream(), _p(q), q.stride(0), _p(k_cache), _p(v_cache), _p(o), o.stride(0),
+                                                   B, H, Hk, head_dim, Tmax, ctx_len, _p(ctx_dev), scale, _p(kv_start)), d)
     if sample:
         e1.record()
         # algorithmic bytes (DESIGN.md kernel table): every live K and V row once + q in + o out

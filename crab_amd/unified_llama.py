@@ -7,9 +7,11 @@ Differences a caller can observe, all deliberate:
     `do_sample=True` raises.
   * like the reference's generate(), `attention_mask` / `position_ids` from prepare_multimodal_inputs are NOT forwarded
     to the decoder (unified_llama.py:261-267): left pads are attended and positions run 0..S-1 (A.1) -- reproduced.
-    The reference's forward() DOES pass them on (unified_llama.py:129-160, the training-time batch path); forward() here
-    implements only the unpadded case and raises NotImplementedError for a mask that contains zeros or for position_ids
-    other than 0..S-1, instead of silently attending the pads.
+    The reference's forward() DOES pass them on (unified_llama.py:129-160, the training-time batch path) and so does
+    forward() here: a LEFT-padded attention_mask becomes a per-sequence first visible key in the attention kernels and
+    position_ids become explicit rotary positions (golden: forward_masked_tiny_llama.npz).  Masks with interior holes raise
+    NotImplementedError.  The logits of a pad row (a query that sees no key) are undefined in the reference
+    (implementation-dependent softmax over an all-masked row) and finite garbage here; no valid row depends on them.
   * the model lives in bf16 on the GPU (the whole-model bf16 conversion of inference_hyper_lora.py:1470, A.8).
 """
 from __future__ import annotations
@@ -155,9 +157,7 @@ class UnifiedForCausalLM(nn.Module, UnifiedMetaForCausalLM):
         if labels is not None or self.is_avs_task:
             raise NotImplementedError("training losses / AVS forward are outside the inference hot path")
         eng = self._engine
-        if attention_mask is not None and not bool(attention_mask.to(torch.bool).all()):
-            raise NotImplementedError("forward(): padded batches (attention_mask with zeros) are not implemented on the HIP path; "
-                                      "generate() reproduces the reference's mask-less behaviour (SURVEY appendix A.1)")
+        dev = self.device
         if input_ids is not None and input_ids.shape[1] == 1 and past_key_values is not None:
             kc, vc, n = past_key_values
             if n >= kc.shape[3]:
@@ -165,34 +165,65 @@ class UnifiedForCausalLM(nn.Module, UnifiedMetaForCausalLM):
                 # Tmax would write into the next head's rows / past the allocation
                 raise ValueError(f"KV cache is full: position {n} >= capacity {kc.shape[3]} (the prefill call sized it as "
                                  f"round64(S + 64)); re-run the prefill with a longer cache")
-            if position_ids is not None and not bool((position_ids.reshape(-1) == n).all()):
-                raise NotImplementedError("forward(): position_ids other than the cache length are not implemented")
             B = input_ids.shape[0]
+            kv_start = self._left_pad_start(attention_mask, B, n + 1)
+            pos_ids = None
+            if position_ids is not None and not bool((position_ids.reshape(-1) == n).all()):
+                pos_ids = self._rotary_positions(position_ids, B, 1, kc.shape[3])
+                eng._rope_tab(self._rope_need)
             emb = self.model.embed_tokens(input_ids.reshape(-1))
             ws = eng._workspace(B)
             ops.copy_rows(emb, ws.x, B, emb.shape[1])
-            pos = torch.full((1,), n, device=self.device, dtype=torch.int32)
-            x, hfin = eng._layers(ws, B, 1, kc, vc, 0, kc.shape[3], 0, pos, None)
+            pos = torch.full((1,), n, device=dev, dtype=torch.int32)
+            x, hfin = eng._layers(ws, B, 1, kc, vc, 0, kc.shape[3], 0, pos, None, pos_ids=pos_ids, kv_start=kv_start)
             hn = hfin.clone()
             logits = ops.gemm(hn, self.lm_head.weight, out_fp32=True)
             return CausalLMOutput(logits.view(B, 1, -1), (hn.view(B, 1, -1),) if output_hidden_states else None, (kc, vc, n + 1))
         if inputs_embeds is None and batch_input_ids is not None:
+            # the multimodal branch (unified_llama.py:129-146): mask and positions of the padded batch go to the decoder
             inputs = self.prepare_multimodal_inputs(batch_input_ids=batch_input_ids, batch_labels=batch_labels,
                                                     batch_X_modals=batch_X_modals, batch_task_names=batch_task_names)
             inputs_embeds = inputs['inputs_embeds']
-            if not bool(inputs['attention_mask'].to(torch.bool).all()):      # ragged batch: the reference masks the left pads here
-                raise NotImplementedError("forward(): ragged batches need the left-pad attention mask, which the HIP prefill does "
-                                          "not implement; call forward() per sample or use generate()")
+            attention_mask, position_ids = inputs['attention_mask'], inputs['position_ids']
         elif inputs_embeds is None and input_ids is not None:
             inputs_embeds = self.model.embed_tokens(input_ids)
-        inputs_embeds = inputs_embeds.to(device=self.device, dtype=BF16)
+        inputs_embeds = inputs_embeds.to(device=dev, dtype=BF16)
         B, S, _ = inputs_embeds.shape
-        if position_ids is not None and not bool((position_ids.reshape(-1, S).cpu() == torch.arange(S)).all()):
-            raise NotImplementedError("forward(): position_ids other than 0..S-1 are not implemented")
         Tmax = (S + 64 + 63) // 64 * 64 if use_cache else (S + 63) // 64 * 64
+        kv_start = self._left_pad_start(attention_mask, B, S)
+        pos_ids = None
+        if position_ids is not None and not bool((position_ids.reshape(-1, S).cpu() == torch.arange(S)).all()):
+            pos_ids = self._rotary_positions(position_ids, B, S, Tmax)
+            eng._rope_tab(self._rope_need)
         kc, vc = eng.alloc_cache(B, Tmax)
-        logits, hn = eng.prefill(inputs_embeds, kc, vc, all_logits=True)
+        logits, hn = eng.prefill(inputs_embeds, kc, vc, all_logits=True, pos_ids=pos_ids, kv_start=kv_start)
         return CausalLMOutput(logits, (hn,) if output_hidden_states else None, (kc, vc, S) if use_cache else None)
+
+    def _left_pad_start(self, attention_mask, B: int, T: int):
+        """2-D attention_mask [B, T] over ALL keys (cached + new) -> int32 [B] index of the first visible key per sequence, or None
+        when nothing is masked.  Only left padding (zeros, then ones: what prepare_multimodal_inputs builds, unified_arch.py:344-348)."""
+        if attention_mask is None:
+            return None
+        m = attention_mask.to(torch.bool).reshape(B, -1)
+        if m.shape[1] != T:
+            raise ValueError(f"attention_mask covers {m.shape[1]} keys, expected {T} (cached + new tokens)")
+        if bool(m.all()):
+            return None
+        start = (~m).sum(1)
+        if not bool((m == (torch.arange(T, device=m.device)[None] >= start[:, None])).all()):
+            raise NotImplementedError("forward(): only left-padded attention masks (zeros, then ones) are implemented on the HIP path")
+        return start.to(device=self.device, dtype=torch.int32)
+
+    def _rotary_positions(self, position_ids, B: int, S: int, Tmax: int):
+        """position_ids [B | 1, S] -> contiguous int32 [B, S] on the device (the caller grows the RoPE table to cover them)."""
+        p = position_ids.reshape(-1, S)
+        if p.shape[0] not in (1, B):
+            raise ValueError(f"position_ids has {p.shape[0]} rows for a batch of {B}")
+        lo, hi = int(p.min()), int(p.max())
+        if lo < 0:
+            raise ValueError("negative position_ids")
+        self._rope_need = max(hi + 1, Tmax)
+        return p.expand(B, S).to(device=self.device, dtype=torch.int32).contiguous()
 
     # ------------------------------------------------------------------ generate
     @torch.no_grad()

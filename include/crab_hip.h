@@ -134,6 +134,13 @@ int crab_qkv_rope_split(crab_ctx* ctx, void* stream, void* qkv, int64_t ldqkv, c
                         void* k_cache, void* v_cache, void* vt, int64_t vt_ld, int B, int S, int H, int Hk, int d,
                         int Tmax, int pos0, const int32_t* pos_dev);
 
+/* Same with explicit rotary positions: token (b, s) is rotated by pos_ids[b*ld_pos + s] (the position_ids forward() passes on,
+ * models/unified_llama.py:149-160: cumsum(attention_mask) - 1 for a left-padded batch, unified_arch.py:372-373) while its K / V rows
+ * still land in cache slot pos0 + s (+ pos_dev[0]).  pos_ids == NULL is crab_qkv_rope_split. */
+int crab_qkv_rope_split_ids(crab_ctx* ctx, void* stream, void* qkv, int64_t ldqkv, const float* rope_tab,
+                            void* k_cache, void* v_cache, void* vt, int64_t vt_ld, int B, int S, int H, int Hk, int d,
+                            int Tmax, int pos0, const int32_t* pos_dev, const int32_t* pos_ids, int64_t ld_pos);
+
 /* Encoder-side split: qkv[T, 3*H*d] -> kbuf[B,H,S,d], vt[B,H,d,vt_ld]; q stays in place (no RoPE). */
 
 /* Flash attention forward (MFMA, LDS-staged K / V^T tiles, fp32 online softmax).
@@ -150,6 +157,10 @@ typedef struct {
     const float* bias; const float* gate;
     int32_t B, H, Hk, Sq, Skv, head_dim, causal;
     float scale;
+    /* optional [B] int32: keys j < kv_start[b] are masked for sequence b - the left-pad attention_mask that forward() hands to the
+     * decoder (models/unified_llama.py:149-160, prepare_multimodal_inputs' mask :344-373).  A query row left without any visible
+     * key (a pad row) produces zeros.  NULL = no mask. */
+    const int32_t* kv_start;
 } crab_attn_desc;
 int crab_attn_fwd(crab_ctx* ctx, void* stream, const crab_attn_desc* d);
 
@@ -159,6 +170,11 @@ int crab_attn_fwd(crab_ctx* ctx, void* stream, const crab_attn_desc* d);
 int crab_attn_decode(crab_ctx* ctx, void* stream, const void* q, int64_t ldq, const void* k_cache, const void* v_cache,
                      void* o, int64_t ldo, int B, int H, int Hk, int d, int Tmax, int ctx_len_host,
                      const int32_t* ctx_dev, float scale);
+
+/* Same, with the first kv_start[b] cache rows of sequence b invisible (left-pad attention_mask of a padded batch; NULL = none). */
+int crab_attn_decode_masked(crab_ctx* ctx, void* stream, const void* q, int64_t ldq, const void* k_cache, const void* v_cache,
+                            void* o, int64_t ldo, int B, int H, int Hk, int d, int Tmax, int ctx_len_host,
+                            const int32_t* ctx_dev, float scale, const int32_t* kv_start);
 
 /* y[M, I] = silu(gu[:, :I]) * gu[:, I:2I]   (modeling_llama.py:269; gate and up packed side by side) */
 int crab_swiglu(crab_ctx* ctx, void* stream, const void* gu, int64_t ldgu, void* y, int64_t ldy, int M, int I);

@@ -160,9 +160,12 @@ class KVCache:
 
 
 def decoder_layer(x: Tensor, W: WDict, i: int, cfg: DecoderConfig, cache: KVCache, positions: Tensor,
-                  emulate=None) -> Tensor:
+                  emulate=None, key_mask: Optional[Tensor] = None) -> Tensor:
     """One Llama/Qwen2 layer (modeling_llama.py:805-827; attention :394-452; MLP :269).
-    x [b,s,D]; positions [b,s] absolute position ids."""
+    x [b,s,D]; positions [b,s] absolute position ids; key_mask [b,t] (1 = attend) is the 2-D attention_mask over ALL keys
+    (cached + new) that forward() passes on (unified_llama.py:149-160): combined with the causal mask as an additive
+    finfo.min term (modeling_llama.py:420-428).  A query row whose keys are all masked (a left-pad row) gets an undefined
+    (implementation-dependent) output that no valid row ever reads; callers compare valid rows only."""
     p = f"model.layers.{i}"
     b, s, D = x.shape
     H, Hk, d = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
@@ -194,6 +197,8 @@ def decoder_layer(x: Tensor, W: WDict, i: int, cfg: DecoderConfig, cache: KVCach
     qi = torch.arange(t - s, t)[:, None]
     kj = torch.arange(t)[None, :]
     a = a.masked_fill((kj > qi)[None, None], torch.finfo(torch.float32).min)
+    if key_mask is not None:
+        a = a.masked_fill((key_mask[:, None, None, :t] == 0), torch.finfo(torch.float32).min)
     pr = torch.softmax(a.float(), dim=-1)                                      # :431 fp32 softmax
     o = torch.matmul(_r(pr, emulate), vv).transpose(1, 2).reshape(b, s, H * d)
     o = _r(o, emulate)
@@ -208,8 +213,8 @@ def decoder_layer(x: Tensor, W: WDict, i: int, cfg: DecoderConfig, cache: KVCach
 
 
 def decoder_forward(embeds: Tensor, W: WDict, cfg: DecoderConfig, cache: Optional[KVCache] = None,
-                    positions: Optional[Tensor] = None, last_only: bool = False, emulate=None
-                    ) -> Tuple[Tensor, Tensor, KVCache]:
+                    positions: Optional[Tensor] = None, last_only: bool = False, emulate=None,
+                    attention_mask: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, KVCache]:
     """LlamaModel.forward + lm_head (modeling_llama.py:989-1124, 1169-1287).
     Returns (logits fp32, post-final-norm hidden, cache).  `last_only` computes lm_head on the last
     row only (output-identical for generate())."""
@@ -220,7 +225,7 @@ def decoder_forward(embeds: Tensor, W: WDict, cfg: DecoderConfig, cache: Optiona
         positions = torch.arange(past, past + s)[None].expand(b, s)
     x = _r(embeds.float(), emulate)
     for i in range(cfg.num_hidden_layers):
-        x = decoder_layer(x, W, i, cfg, cache, positions, emulate)
+        x = decoder_layer(x, W, i, cfg, cache, positions, emulate, key_mask=attention_mask)
     hn = rmsnorm(x, W["model.norm.weight"], cfg.rms_norm_eps, emulate)
     hh = hn[:, -1:] if last_only else hn
     logits = F.linear(hh, W["lm_head.weight"]).float()

@@ -310,6 +310,28 @@ def golden_full(me):
                 prompts=dict(n0=24, n1=17, t_v=2, t_a=3, l_a=98, clip0=c0, clip1=c0 + 1), min_margin=margin)
     save("full_tiny_llama", meta, ids0=ids0, ids1=ids1, **out)
 
+    # ---- forward() with the left-pad attention_mask / position_ids HONOURED (models/unified_llama.py:129-160: the multimodal branch of
+    # forward() hands prepare_multimodal_inputs' mask and cumsum-1 positions to the decoder, unlike generate()).  Encoders must not run
+    # again after a generate() in this process (transformers-5.15 hidden-state recorder artefact, see golden_full_qwen), so the
+    # decoder is called exactly as unified_llama.py:149-160 does, on the prepared bs-2 inputs: prefill with the cache kept, then the
+    # 1-token decode shortcut (:125-127) with the extended mask and per-row positions.
+    mask2, pos2 = inp2["attention_mask"], inp2["position_ids"]
+    fm = super(type(um), um).forward(inputs_embeds=inp2["inputs_embeds"], attention_mask=mask2, position_ids=pos2, use_cache=True,
+                                     output_hidden_states=True)
+    tok = fm.logits[:, -1].argmax(-1)
+    mask3 = torch.cat([mask2, torch.ones_like(mask2[:, :1])], 1)
+    pos3 = pos2[:, -1:] + 1
+    fs = um.forward(input_ids=tok[:, None], attention_mask=mask3, position_ids=pos3, past_key_values=fm.past_key_values, use_cache=True)
+    # the same batch WITHOUT the mask (what generate() feeds): shows that the mask matters for the padded row and not for the full one
+    fu = super(type(um), um).forward(inputs_embeds=inp2["inputs_embeds"], use_cache=False)
+    d_pad = float((fu.logits[1] - fm.logits[1])[mask2[1].bool()].abs().max())
+    d_full = float((fu.logits[0] - fm.logits[0]).abs().max())
+    print(f"masked forward: padded row differs from the mask-less run by {d_pad:.3e}, full row by {d_full:.3e}")
+    assert d_pad > 1e-3 and d_full < 1e-4
+    save("forward_masked_tiny_llama", dict(meta, pad_row_maskless_diff=d_pad), ids0=ids0, ids1=ids1, embeds_bs2=inp2["inputs_embeds"],
+         mask_bs2=mask2, pos_bs2=pos2, logits_bs2=fm.logits, hidden_bs2=fm.hidden_states[-1], step_tok=tok, step_mask=mask3, step_pos=pos3,
+         step_logits=fs.logits)
+
 
 def golden_qwen(me):
     model, cfg = build_full_model(me, TINY_QWEN, qwen=True)

@@ -53,13 +53,19 @@ def test_state_dict_round_trip_through_views():
     assert torch.equal(ga.W, gb.W) and torch.equal(ga.RA, gb.RA) and torch.equal(ga.B2, gb.B2)
 
 
-def test_forward_refuses_padded_batches_and_full_cache():
+def test_forward_mask_handling_and_full_cache():
     um = _tiny().base_model.model
     emb = torch.zeros(2, 5, 64)
     mask = torch.ones(2, 5, dtype=torch.long)
-    mask[1, :2] = 0
+    mask[1, 2] = 0                                               # an interior hole: only LEFT padding is implemented
     with pytest.raises(NotImplementedError):
         um(inputs_embeds=emb, attention_mask=mask)
+    mask = torch.ones(2, 5, dtype=torch.long)
+    mask[1, :2] = 0
+    assert um._left_pad_start(mask, 2, 5).tolist() == [0, 2] and um._left_pad_start(torch.ones(2, 5), 2, 5) is None
+    with pytest.raises(ValueError, match="covers 5 keys"):
+        um._left_pad_start(mask, 2, 6)
+    assert um._rotary_positions(torch.tensor([[0, 0, 0, 1, 2]]), 2, 5, 64).tolist() == [[0, 0, 0, 1, 2]] * 2
     kc = torch.zeros(2, 1, 4, 64, 16)
     with pytest.raises(ValueError, match="KV cache is full"):
         um(input_ids=torch.zeros(1, 1, dtype=torch.long), past_key_values=(kc, kc.clone(), 64))

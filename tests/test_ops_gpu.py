@@ -239,6 +239,57 @@ def test_rope_split_and_decode_attention(hd, H, Hk):
     _cmp(o, ref, TOL_BF16, "decode attention")
 
 
+@pytest.mark.parametrize("hd,B,H,Hk,S", [(128, 3, 4, 4, 200), (64, 3, 4, 2, 150), (128, 2, 8, 2, 77)])
+def test_attention_left_pad_mask_and_explicit_rotary_positions(hd, B, H, Hk, S):
+    """forward()'s attention_mask / position_ids (models/unified_llama.py:149-160) at the kernel level: kv_start (first visible key
+    per sequence, several 64-key tiles deep) in the causal flash forward and in the decode attention, and per-token rotary positions
+    in the RoPE / KV-split pass, against fp32 arithmetic.  Valid rows only; pad rows must be finite (zeros)."""
+    from crab_amd import ops
+    from oracle import crab_oracle as O
+    Tmax, theta = 256, 10000.0
+    starts = [0, 70, 131][:B] if B == 3 else [5, 0]
+    st = torch.tensor(starts, dtype=torch.int32)
+    pos_ids = (torch.arange(S)[None] - st[:, None].long()).clamp(min=0).to(torch.int32)            # cumsum(mask) - 1, pads -> 0
+    qkv = _rand(B * S, (H + 2 * Hk) * hd, seed=15)
+    tab = ops.rope_table(Tmax, hd, theta, "cuda")
+    kc = torch.zeros(B, Hk, Tmax, hd, dtype=BF, device="cuda")
+    vc = torch.zeros_like(kc)
+    Sp = (S + 7) // 8 * 8
+    vt = torch.zeros(B, Hk, hd, Sp, dtype=BF, device="cuda")
+    qd = qkv.cuda()
+    ops.qkv_rope_split(qd, tab, kc, vc, vt, B, S, H, Hk, hd, Tmax, pos0=0, pos_ids=pos_ids.cuda())
+    q = qkv[:, :H * hd].float().view(B, S, H, hd).transpose(1, 2)
+    k = qkv[:, H * hd:(H + Hk) * hd].float().view(B, S, Hk, hd).transpose(1, 2)
+    v = qkv[:, (H + Hk) * hd:].view(B, S, Hk, hd).transpose(1, 2)
+    cos, sin = O.rope_cos_sin(pos_ids.long(), hd, theta)
+    qr, kr = O.apply_rope(q, k, cos, sin)
+    _cmp(qd[:, :H * hd].view(B, S, H, hd).transpose(1, 2), qr, TOL_BF16, "rope q at explicit positions")
+    _cmp(kc[:, :, :S], kr, TOL_BF16, "rope k at explicit positions -> cache slot s")
+    o = torch.full((B, S, H * hd), float("nan"), dtype=BF, device="cuda")
+    ldq = qd.stride(0)
+    ops.attn_fwd(qd, kc, vt, o, q_strides=(S * ldq, hd, ldq), k_strides=(Hk * Tmax * hd, Tmax * hd, hd), vt_strides=(Hk * hd * Sp, hd * Sp, Sp),
+                 o_strides=(S * H * hd, H * hd), B=B, H=H, Hk=Hk, Sq=S, Skv=S, head_dim=hd, scale=hd ** -0.5, causal=True, kv_start=st.cuda())
+    assert torch.isfinite(o.float()).all()
+    qb = qd[:, :H * hd].cpu().view(B, S, H, hd).transpose(1, 2)
+    for b in range(B):
+        s0 = starts[b]
+        ref = _attn_ref(qb[b:b + 1, :, s0:], kc[b:b + 1, :, s0:S].cpu(), vc[b:b + 1, :, s0:S].cpu(), hd ** -0.5, causal=True)
+        _cmp(o[b, s0:].view(S - s0, H, hd).transpose(0, 1)[None], ref, TOL_BF16, f"left-pad masked causal attention, row {b} (kv_start {s0})")
+        assert float(o[b, :s0].float().abs().max()) == 0.0 if s0 else True          # pad query rows: zeros
+    # decode step at cache slot S, rotary position S - start, keys [start, S]
+    pos = torch.tensor([S], dtype=torch.int32, device="cuda")
+    q1 = _rand(B, (H + 2 * Hk) * hd, seed=16).cuda()
+    p1 = (S - st.long())[:, None].to(torch.int32)
+    ops.qkv_rope_split(q1, tab, kc, vc, None, B, 1, H, Hk, hd, Tmax, pos0=0, pos_dev=pos, pos_ids=p1.cuda())
+    o1 = torch.zeros(B, H * hd, dtype=BF, device="cuda")
+    ops.attn_decode(q1, kc, vc, o1, B, H, Hk, hd, Tmax, 1, hd ** -0.5, ctx_dev=pos, kv_start=st.cuda())
+    for b in range(B):
+        s0 = starts[b]
+        qn = q1[b:b + 1, :H * hd].cpu().view(1, 1, H, hd).transpose(1, 2)
+        ref = _attn_ref(qn, kc[b:b + 1, :, s0:S + 1].cpu(), vc[b:b + 1, :, s0:S + 1].cpu(), hd ** -0.5).transpose(1, 2).reshape(1, H * hd)
+        _cmp(o1[b:b + 1], ref, TOL_BF16, f"left-pad masked decode attention, row {b}")
+
+
 @pytest.mark.parametrize("ctx", [702, 830, 958])
 def test_decode_attention_mha_benchmark_regime(ctx):
     """attn_decode_kernel<128> exactly as bench.py launches it (the dominant kernel of the benchmark): B = 256 clips, H = Hk = 32,

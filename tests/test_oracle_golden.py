@@ -112,6 +112,27 @@ def test_full_tiny_llama_prepare_and_generate():
     _close(sl, A["logits_bs2"], 1e-3)
 
 
+def test_forward_with_left_pad_mask_and_position_ids():
+    """forward() semantics (unified_llama.py:129-160): the left-pad attention_mask and cumsum-1 position_ids ARE honoured (generate()
+    drops them).  Reference logits of the left-padded bs-2 batch, valid rows only (a pad row attends nothing: undefined), then the
+    1-token decode shortcut (:125-127) with the extended mask and per-row positions."""
+    meta, A = load_fixture("forward_masked_tiny_llama")
+    W = O.strip_peft_prefix(weights_from_table(meta))
+    cfg = _full_cfg(meta).decoder
+    mask, pos = A["mask_bs2"], A["pos_bs2"]
+    logits, hn, cache = O.decoder_forward(A["embeds_bs2"], W, cfg, positions=pos, attention_mask=mask)
+    valid = mask.bool()
+    assert int((~valid).sum()) == 7                      # row 1 carries 7 left pads
+    _close(logits[valid], A["logits_bs2"][valid], 5e-4)
+    _close(hn[valid], A["hidden_bs2"][valid], 5e-4)
+    e = W["model.embed_tokens.weight"][A["step_tok"]][:, None]
+    l2, _, _ = O.decoder_forward(e, W, cfg, cache, positions=A["step_pos"], attention_mask=A["step_mask"])
+    _close(l2, A["step_logits"], 5e-4)
+    # and the mask matters: the mask-less run (what generate() feeds) differs on the padded row only
+    lu, _, _ = O.decoder_forward(A["embeds_bs2"], W, cfg)
+    assert float((lu[1] - logits[1])[valid[1]].abs().max()) > 1e-2 and float((lu[0] - logits[0]).abs().max()) < 1e-4
+
+
 def test_decoder_tiny_qwen2_gqa_bias():
     meta, A = load_fixture("decoder_tiny_qwen2")
     W = O.strip_peft_prefix(weights_from_table(meta))
