@@ -151,6 +151,8 @@ class GenerationEngine:
         self._ws = {}
         self._kv = {}
         self._dec = {}                 # slot -> persistent decode state (+ captured graph)
+        self.kv_budget_bytes = None    # None: ask the device (hipMemGetInfo); an int caps what generate() may plan with (tests)
+        self.last_plan = None          # what the last generate() decided: {"B", "groups", "bytes_per_seq", "budget"}
 
     # ------------------------------------------------------------------ helpers
     @property
@@ -231,6 +233,60 @@ class GenerationEngine:
             out.append(prev[n])
             n -= prev[n]
         return sorted(out, reverse=True)
+
+    # ------------------------------------------------------------------ capacity planning
+    def bytes_per_sequence(self, S: int, max_new_tokens: int) -> int:
+        """Device bytes ONE more sequence costs a generate() call: its KV-cache rows (2 x L x Hk x Tmax x d bf16), its row of the
+        decode workspace / logits / output ids, its share of the prefill V^T scratch."""
+        c = self.cfg
+        Tmax = _round_up(S + max_new_tokens, 64)
+        kv = 2 * c.num_hidden_layers * c.num_key_value_heads * Tmax * c.head_dim * 2
+        D, I = c.hidden_size, c.intermediate_size
+        H, Hk, d = c.num_attention_heads, c.num_key_value_heads, c.head_dim
+        dec_row = (2 * D + (H + 2 * Hk) * d + H * d + I + 3 * 128) * 2 + self.lm_head.weight.shape[0] * 4 + D * 2 + max_new_tokens * 8 + 64
+        return kv + dec_row
+
+    def fixed_bytes(self, B: int, S: int) -> int:
+        """Batch-size independent scratch of a generate(): the prefill activation set of the largest chunk (<= 32768 rows) + its V^T."""
+        c = self.cfg
+        D, I = c.hidden_size, c.intermediate_size
+        H, Hk, d = c.num_attention_heads, c.num_key_value_heads, c.head_dim
+        rows = min(B, max(1, 32768 // max(S, 1))) * S
+        per_row = (2 * D + (H + 2 * Hk) * d + H * d + I + 3 * 128) * 2 + Hk * d * 2
+        have = self._ws.get("prefill")
+        have_bytes = have.M * per_row if have is not None else 0
+        return max(rows * per_row - have_bytes, 0) + (256 << 20)                   # + split-K / router workspaces, allocator slack
+
+    def memory_budget(self, B: int, Tmax: int) -> int:
+        """Bytes generate() may still claim on this device: what the driver reports free (hipMemGetInfo) + what torch's caching
+        allocator holds but has not handed out + the engine's own persistent KV buffers of another shape (alloc_cache drops them
+        before allocating the new ones).  `kv_budget_bytes` overrides it."""
+        if self.kv_budget_bytes is not None:
+            return int(self.kv_budget_bytes)
+        free, _total = torch.cuda.mem_get_info(self.device)
+        cached = torch.cuda.memory_reserved(self.device) - torch.cuda.memory_allocated(self.device)
+        own = 0
+        c = self.cfg
+        for (kcb, vcb) in self._kv.values():
+            own += kcb.numel() * 2 + vcb.numel() * 2
+        return int(free + cached + own)
+
+    def plan_batch(self, B: int, S: int, max_new_tokens: int) -> List[int]:
+        """Split B sequences into groups that are generated one after the other when their KV cache + scratch would not fit the device
+        (the reference's max_new_tokens = 500 at S = 766: 0.66 MB of KV per token per clip -> 0.67 GB per clip, B = 384 does not fit
+        288 GB next to the weights; scripts/quick_start.py:36-41).  Returns the group sizes (a single [B] when everything fits)."""
+        per = self.bytes_per_sequence(S, max_new_tokens)
+        budget = self.memory_budget(B, _round_up(S + max_new_tokens, 64))
+        room = int(0.94 * budget) - self.fixed_bytes(B, S)
+        fit = max(1, room // per)
+        if B <= fit:
+            groups = [B]
+        else:
+            n = -(-B // fit)
+            base, extra = divmod(B, n)                        # even groups: the same decode shapes (graphs) repeat
+            groups = [base + (1 if i < extra else 0) for i in range(n)]
+        self.last_plan = {"B": B, "groups": groups, "bytes_per_seq": per, "budget": budget}
+        return groups
 
     def alloc_cache(self, B: int, Tmax: int, slot: Optional[int] = None):
         """KV cache [L, B, Hk, Tmax, d] x 2.  slot = None: fresh zero-filled tensors (callers that keep the cache, e.g.
@@ -462,6 +518,10 @@ class GenerationEngine:
         separate HIP streams: the HBM-bound KV-cache attention of one group overlaps the MFMA-bound projections of
         another.  Rows never interact, so the split only changes which M the projection kernels see."""
         B, S, D = embeds.shape
+        groups = self.plan_batch(B, S, max_new_tokens)
+        if len(groups) > 1:
+            return self._generate_split(groups, embeds, max_new_tokens, eos_token_id, pad_token_id, min_new_tokens, prefill_chunk, use_graph,
+                                        return_step_logits, return_hidden, return_first_logits)
         graphed = use_graph and max_new_tokens > 2
         G = decode_streams if (decode_streams > 1 and graphed and B >= decode_streams and
                                not return_step_logits and not return_hidden) else 1
@@ -544,6 +604,43 @@ class GenerationEngine:
             res.append(torch.stack(hiddens, 1)[:, : out.shape[1]])
         if return_first_logits:
             res.append(first_logits[0] if G == 1 else torch.cat(first_logits, 0))
+        return res[0] if len(res) == 1 else tuple(res)
+
+    def _generate_split(self, groups, embeds, max_new_tokens, eos_token_id, pad_token_id, min_new_tokens, prefill_chunk, use_graph,
+                        return_step_logits, return_hidden, return_first_logits):
+        """The batch does not fit the device's memory in one piece: generate the groups one after the other (rows are independent,
+        so the results are those of the one-piece run up to the kernel choice a different M implies) and join them.  A group
+        that finished early (EOS) is padded to the longest group's length with pad ids, like HF pads finished rows."""
+        import warnings
+        p = self.last_plan
+        warnings.warn(f"generate(): {p['B']} sequences x {p['bytes_per_seq'] / 2**20:.0f} MiB do not fit the {p['budget'] / 2**30:.1f} GiB "
+                      f"available on {self.device}: running {len(groups)} groups of {groups} one after the other", RuntimeWarning)
+        pad = int(pad_token_id) if pad_token_id is not None else (int(eos_token_id) if eos_token_id is not None else 0)
+        parts, b0 = [], 0
+        saved = self.kv_budget_bytes
+        for n in groups:
+            self.kv_budget_bytes = 1 << 62                    # the group sizes are decided: no re-planning inside
+            try:
+                r = self.generate(embeds[b0:b0 + n], max_new_tokens, eos_token_id=eos_token_id, pad_token_id=pad_token_id,
+                                  min_new_tokens=min_new_tokens, prefill_chunk=prefill_chunk, use_graph=use_graph,
+                                  return_step_logits=return_step_logits, return_hidden=return_hidden, return_first_logits=return_first_logits)
+            finally:
+                self.kv_budget_bytes = saved
+            parts.append(r if isinstance(r, tuple) else (r,))
+            b0 += n
+        self.last_plan = p
+        n_max = max(q[0].shape[1] for q in parts)
+        res = []
+        for j in range(len(parts[0])):
+            cols = []
+            for q in parts:
+                t = q[j]
+                per_step = t.dim() >= 2 and not (return_first_logits and j == len(parts[0]) - 1)
+                if per_step and t.shape[1] < n_max:
+                    fill = torch.full((t.shape[0], n_max - t.shape[1]) + tuple(t.shape[2:]), pad if j == 0 else 0, device=t.device, dtype=t.dtype)
+                    t = torch.cat([t, fill], 1)
+                cols.append(t)
+            res.append(torch.cat(cols, 0))
         return res[0] if len(res) == 1 else tuple(res)
 
     def _capture(self, st: "_DecodeState"):

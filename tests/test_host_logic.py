@@ -69,3 +69,26 @@ def test_forward_mask_handling_and_full_cache():
     kc = torch.zeros(2, 1, 4, 64, 16)
     with pytest.raises(ValueError, match="KV cache is full"):
         um(input_ids=torch.zeros(1, 1, dtype=torch.long), past_key_values=(kc, kc.clone(), 64))
+
+
+def test_plan_batch_splits_when_the_kv_cache_would_not_fit():
+    """Capacity planning (scripts/quick_start.py:36-41 runs max_new_tokens = 500): the engine sizes a generate() from the bytes a
+    sequence costs and the memory the device still has, and splits a batch that would not fit into even groups."""
+    um = _tiny().base_model.model
+    eng = um._engine
+    per = eng.bytes_per_sequence(702, 500)
+    c = um.config
+    assert per >= 2 * c.num_hidden_layers * c.num_key_value_heads * 1216 * c.head_dim * 2           # at least the KV rows (Tmax = round64(1202))
+    eng.kv_budget_bytes = int((eng.fixed_bytes(10, 702) + 3.5 * per) / 0.94) + 1
+    assert eng.plan_batch(10, 702, 500) == [3, 3, 2, 2] and eng.last_plan["bytes_per_seq"] == per
+    assert eng.plan_batch(3, 702, 500) == [3]
+    eng.kv_budget_bytes = 1                                       # nothing fits: one sequence at a time, never zero
+    assert eng.plan_batch(4, 702, 500) == [1, 1, 1, 1]
+    # Llama-2-7B geometry: the reference's 500 new tokens at S = 766 cost 0.63 GiB of KV per clip -> 384 clips (240 GiB) cannot share
+    # a 288 GB device with 14 GB of weights, 256 (160 GiB) can
+    from crab_amd.decoder import DecoderConfig, DecoderModel, GenerationEngine
+    big = GenerationEngine.__new__(GenerationEngine)
+    big.cfg, big.lm_head, big._ws, big._kv, big.last_plan = DecoderConfig(), type("H", (), {"weight": torch.empty(32017, 1)})(), {}, {}, None
+    big.kv_budget_bytes = 270 * 2 ** 30 - 15 * 2 ** 30
+    assert big.plan_batch(256, 766, 500) == [256]
+    assert big.plan_batch(384, 766, 500) == [192, 192]

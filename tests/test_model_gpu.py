@@ -601,3 +601,33 @@ def test_single_layer_entry_points_equal_the_stack_call():
     io = _lib.LlamaIO()
     assert lib.crab_llama_layer_decode(_lib.ctx(0), stream, C.byref(tab[0]), C.byref(io), 0) < 0
     assert b"llama_layer" in lib.crab_last_error(_lib.ctx(0))
+
+
+def test_generate_splits_a_batch_that_does_not_fit_the_memory_budget():
+    """Capacity planning: with a (faked) small memory budget generate() runs the batch as several groups one after the other and
+    says so; ids are those of the one-piece run (rows are independent; per-step logits agree to the accumulation-order noise of
+    the different M), first-step logits and per-step logits come back joined in row order."""
+    meta, A = load_fixture("full_tiny_llama")
+    model = build_tiny_crab(meta)
+    model.load_state_dict(weights_from_table(meta), strict=False)
+    um = model.base_model.model
+    eng = um._engine
+    g = torch.Generator(device="cuda").manual_seed(3)
+    emb = A["embeds_bs2"][:1].cuda().to(BF).repeat(7, 1, 1)
+    emb = emb + (torch.randn(emb.shape, device="cuda", generator=g) * 0.05).to(BF)
+    kw = dict(eos_token_id=None, pad_token_id=2, return_step_logits=True, return_first_logits=True)
+    ids, sl, fl = eng.generate(emb, 6, **kw)
+    assert eng.last_plan["groups"] == [7]
+    per = eng.bytes_per_sequence(emb.shape[1], 6)
+    eng.kv_budget_bytes = int((eng.fixed_bytes(7, emb.shape[1]) + 3.5 * per) / 0.94) + 1
+    try:
+        with pytest.warns(RuntimeWarning, match="do not fit"):
+            ids2, sl2, fl2 = eng.generate(emb, 6, **kw)
+    finally:
+        eng.kv_budget_bytes = None
+    assert eng.last_plan["groups"] == [3, 2, 2]
+    assert ids2.shape == ids.shape and sl2.shape == sl.shape and fl2.shape == fl.shape
+    assert _rel(fl2, fl, "generate() split into groups vs one piece: first-step logits (HIP vs HIP)") < 6e-3
+    assert _rel(sl2[:, 0], sl[:, 0], "generate() split into groups vs one piece: step-0 logits (HIP vs HIP)") < 6e-3
+    same = (ids2 == ids).float().mean().item()
+    assert same >= 0.9, same
