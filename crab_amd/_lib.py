@@ -34,6 +34,7 @@ class GemmDesc(C.Structure):
         ("rope_H", C.c_int32), ("rope_Hk", C.c_int32), ("rope_d", C.c_int32), ("rope_Tmax", C.c_int32), ("rope_pos0", C.c_int32),
         ("route_RA", C.c_void_p), ("route_U", C.c_void_p), ("route_ldra", C.c_int64), ("route_ldu", C.c_int64),
         ("route_nproj", C.c_int32), ("route_nl", C.c_int32), ("route_r", C.c_int32), ("route_ucols", C.c_int32), ("route_scaling", C.c_float),
+        ("lora_RA", C.c_void_p), ("lora_ldra", C.c_int64), ("lora_nl", C.c_int32), ("lora_r", C.c_int32), ("lora_scaling", C.c_float),
     ]
 
 
@@ -99,6 +100,7 @@ SYMBOLS = {
     "crab_last_error": (C.c_char_p, [_vp]),
     "crab_sync": (_i, [_vp, _vp]),
     "crab_gemm_bf16": (_i, [_vp, _vp, C.POINTER(GemmDesc)]),
+    "crab_rowfin_workspace": (_i64, [_i, _i]),
     "crab_hyperlora_mix": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _i64, _i, _i, _i, _i, _i, _f]),
     "crab_hyperlora_route_workspace": (_i64, [_i, _i, _i]),
     "crab_hyperlora_route": (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _vp, _i64, _i, _f, _vp, _i64]),

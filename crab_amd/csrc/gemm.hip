@@ -415,6 +415,8 @@ __global__ __launch_bounds__(256) void splitk_epilogue_norm_kernel(const float* 
 }  // namespace
 
 int crab_gemm_skinny_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* d);   // skinny.hip
+bool crab_rowfin_ok(const crab_gemm_desc* d);                                           // rowfin.hip: the M <= 16 layer tail
+int crab_rowfin_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* d);
 int crab_gemm_glds_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* d, int splitk, float* part, int ring_split);     // gemm_glds.hip
 int crab_gemm_dec_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* d, int bn, int splitk, float* part, int nt_weights);  // gemm_decode.hip
 
@@ -587,7 +589,16 @@ extern "C" int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc*
     if (d->M <= 0 || d->N <= 0 || d->K <= 0) return crab_fail(ctx, CRAB_E_INVALID, "gemm: non-positive dimension");
     if ((d->K & 7) || (d->lda & 7) || (d->ldb & 7)) return crab_fail(ctx, CRAB_E_INVALID, "gemm: K/lda/ldb must be multiples of 8");
     if (((uintptr_t)d->A & 15) || ((uintptr_t)d->B & 15)) return crab_fail(ctx, CRAB_E_INVALID, "gemm: A/B must be 16-byte aligned");
-    if ((d->A2 != nullptr) != (d->B2 != nullptr)) return crab_fail(ctx, CRAB_E_INVALID, "gemm: A2/B2 must be given together");
+    if ((d->A2 != nullptr) != (d->B2 != nullptr) && !(d->lora_RA && !d->A2)) return crab_fail(ctx, CRAB_E_INVALID, "gemm: A2/B2 must be given together");
+    if (d->lora_RA) {
+        // in-call hyper-LoRA of a single-projection group: only the M <= 16 tail (rowfin.hip) evaluates it
+        static const int rowfin_on = []() { const char* e = getenv("CRAB_ROWFIN"); return !(e && e[0] == '0'); }();
+        if (d->A2 || !d->B2 || d->lora_nl < 1 || d->lora_r < 1 || (d->lora_ldra & 7) || ((uintptr_t)d->lora_RA & 15))
+            return crab_fail(ctx, CRAB_E_INVALID, "gemm: lora_RA needs B2 = lora_B without A2, positive lora_nl / lora_r, aligned lora_RA");
+        if (!rowfin_on || d->tune != 0 || d->batch > 1 || !crab_rowfin_ok(d) || (d->ldb & 7))
+            return crab_fail(ctx, CRAB_E_UNSUPPORTED, "gemm: the in-call hyper-LoRA (lora_RA) is evaluated by the M <= 16 layer tail only: needs M <= 16, "
+                                                      "the fused post-norm (norm_w / norm_out, bf16 C), a workspace of crab_rowfin_workspace(M, N) bytes");
+    }
     if (d->A2) {
         if (d->K2 <= 0 || (d->K2 & 7) || (d->lda2 & 7) || (d->ldb2 & 7))
             return crab_fail(ctx, CRAB_E_INVALID, "gemm: K2/lda2/ldb2 must be positive multiples of 8");
@@ -609,6 +620,16 @@ extern "C" int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc*
             // fp32 sums in the workspace (one "slice") and the row-owning reduction kernel applies bias / residual, stores C, the
             // normalised row and the next group's router - one launch instead of rmsnorm + the router's two (CRAB_SKINNY_FUSED=0: off)
             static const int fused_on = []() { const char* e = getenv("CRAB_SKINNY_FUSED"); return !(e && e[0] == '0'); }();
+            static const int rowfin_on2 = []() { const char* e = getenv("CRAB_ROWFIN"); return !(e && e[0] == '0'); }();
+            if (fused_on && rowfin_on2 && d->tune == 0 && d->M <= 16 && crab_rowfin_ok(d) && (d->ldb & 7) == 0) {
+                // r03: the wide two-launch tail (rowfin.hip) - the projection's own router rows ride on the GEMM launch (d->lora_RA), the
+                // update, the residual row, its RMSNorm and the NEXT group's router follow in two launches of N / 64 blocks each
+                crab_gemm_desc raw = *d;
+                raw.tune = 9;
+                raw.B2 = d->A2 ? d->B2 : nullptr;                          // a deferred update is not a K segment of the product
+                int rc = crab_gemm_skinny_launch(ctx, (hipStream_t)stream, &raw);
+                return rc ? rc : crab_rowfin_launch(ctx, (hipStream_t)stream, d);
+            }
             if (fused_on && d->tune == 0 && d->M <= 16 && norm_epilogue_ok(d) && d->workspace &&
                 (int64_t)d->M * d->N * 4 <= d->workspace_bytes && (d->ldb & 7) == 0) {
                 crab_gemm_desc raw = *d;

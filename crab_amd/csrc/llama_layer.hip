@@ -12,6 +12,7 @@
 //     x   += [act | u] . [Wdown | Bcat]^T ; h = rmsnorm(x) * next_norm_w              (+ the next layer's q|k|v router ahead)
 #include "crab_internal.h"
 #include <math.h>
+#include <stdlib.h>
 #include <algorithm>
 using std::max;
 
@@ -67,6 +68,14 @@ int run_group(crab_ctx* ctx, void* stream, const crab_linear_group* g, const cra
     if (c.rope) {
         d.rope_tab = io->rope_tab; d.rope_k_cache = k_cache; d.rope_v_cache = v_cache; d.rope_pos_dev = io->pos_dev;
         d.rope_H = L->H; d.rope_Hk = L->Hk; d.rope_d = L->d; d.rope_Tmax = io->Tmax; d.rope_pos0 = io->pos0;
+    }
+    static const int rowfin_on = []() { const char* e = getenv("CRAB_ROWFIN"); return !(e && e[0] == '0'); }();
+    if (g->RA && !c.u_ready && M <= 16 && c.norm_w && g->nproj == 1 && rowfin_on) {
+        // the reference's batch sizes, o_proj / down_proj: the group's [R;A] rows ride on the projection's launch and the update is applied
+        // by the wide layer tail (rowfin.hip) - same choice as PackedLinearGroup.__call__ (crab_amd/peft_hyper.py)
+        d.lora_RA = g->RA; d.lora_ldra = g->ldra; d.lora_nl = g->nl; d.lora_r = g->r; d.lora_scaling = g->scaling;
+        d.B2 = g->B2; d.ldb2 = g->ldb2; d.K2 = g->ucols;
+        return crab_gemm_bf16(ctx, stream, &d);
     }
     if (g->RA) {
         const void* u = c.u_ready;

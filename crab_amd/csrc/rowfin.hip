@@ -1,0 +1,286 @@
+// Small-batch layer tail (M <= 16 rows: the reference's batch sizes 1 and 8, scripts/quick_start.py:43,
+// scripts/finetune/inference_hyper_lora.py:1477): what follows the o_proj / down_proj product of a decoder layer
+// (models/modeling_llama.py:805-827 residual adds + LlamaRMSNorm :112-117; hyper-LoRA peft_hyper/tuners/lora.py:338-350).
+//
+// r02 ran this as FOUR launches per projection - router partial product, router mix, the GEMM, a row-owning reduction with
+// 1-3 blocks per row (8 us: one block walks 90 KB of router rows) - 35 us of every 135 us layer at batch 1.  Kernel boundaries are
+// cheap on this chip (1.2-1.9 us, guide price list "boundary"); a grid barrier is not (4.1+ us, "barrier-xcd"); what costs is a
+// small kernel that is also NARROW.  So the tail is two WIDE launches behind a GEMM that already carries the router product:
+//
+//   gemm_skinny_dma_kernel   S = act(A.W^T + bias) + R in fp32, and - 16 extra weight rows = the group's own [R;A] - T = A.[R;A]^T
+//   rowfin_apply_kernel      column slices of 64: y = S + scaling * sum_i softmax(T_route)_i B_i T_A   (the hyper-LoRA update of THIS
+//                            projection, applied here because T only exists once the GEMM launch is over), x = bf16(y) stored,
+//                            partial sum of squares per (slice, row)
+//   rowfin_route_kernel      column slices of 64: rstd from the partials, h = rmsnorm(x) * w stored, partial router products of the NEXT
+//                            group on its slice (6 KB of [R;A] per block instead of 90 KB per row); the LAST block to arrive (one
+//                            returning atomic, nobody waits) sums the slices in slice order and writes u = scaling * p (x) (h A^T).
+// Nothing spins: the only cross-block step is the last-arriver reduction, so the pair cannot hang.  Deterministic (fixed orders).
+#include "common.h"
+#include "crab_internal.h"
+
+namespace {
+
+constexpr int RF_CW = 64;                        // columns per block
+constexpr int RF_TJ = 64;                        // router rows per (slice, row) record of the partial buffer
+
+constexpr int RF_SKX = 8;                        // K-range partials of the ride-along router product (SKX of skinny.hip)
+constexpr int RF_G = 4;                          // slice groups of the last-arriver reduction
+
+struct RowfinApplyP {
+    const float* S; const float* T;              // S [M][N] fp32; T [RF_SKX][16][16] partial router products: nl route logits then r lora_A
+    const bf16_t* B2; long ldb2; int k2;         // lora_B [N][k2 >= nl * r]                                    (T == NULL: no adapter)
+    bf16_t* X; long ldx;                         // out: the row as stored (residual stream), bf16
+    float* ssq;                                  // out: [slices][16] partial sums of squares of the STORED values
+    unsigned* counter;                           // arrival counter of the route kernel, zeroed here
+    int M, N, nl, r; float scaling;
+};
+
+__global__ __launch_bounds__(256) void rowfin_apply_kernel(RowfinApplyP p) {
+    __shared__ uint32_t b2s[RF_CW][17];          // lora_B rows of this slice, 32 k columns as 16 words + 1 pad word (conflict-free row walk)
+    __shared__ float us[16][32];
+    __shared__ float ts[16][16];
+    const int tid = threadIdx.x, m = tid >> 4, q = tid & 15;
+    const int c0 = blockIdx.x * RF_CW, c = c0 + q * 4;
+    if (blockIdx.x == 0 && tid == 0) *p.counter = 0u;
+    const int nu = p.T ? p.nl * p.r : 0;         // <= 32
+    // every global load of the kernel is issued here, before anything waits: one memory round trip deep
+    const bool live = m < p.M && c < p.N;
+    f32x4_t y = {0.f, 0.f, 0.f, 0.f};
+    if (live) y = *reinterpret_cast<const f32x4_t*>(p.S + (long)m * p.N + c);
+    u32x4 bv = {0u, 0u, 0u, 0u};
+    float tsum = 0.f;
+    if (p.T) {
+        const int row = tid >> 2, ch = tid & 3;  // 64 rows x 4 chunks of 8 columns
+        if (c0 + row < p.N && ch * 8 < p.k2) bv = *reinterpret_cast<const u32x4*>(p.B2 + (long)(c0 + row) * p.ldb2 + ch * 8);
+        if (m < p.M) {
+            float tv[RF_SKX];
+#pragma unroll
+            for (int e = 0; e < RF_SKX; ++e) tv[e] = p.T[((long)e * 16 + m) * 16 + q];
+#pragma unroll
+            for (int e = 0; e < RF_SKX; ++e) tsum += tv[e];               // K ranges in order
+        }
+        b2s[row][ch * 4 + 0] = bv[0]; b2s[row][ch * 4 + 1] = bv[1]; b2s[row][ch * 4 + 2] = bv[2]; b2s[row][ch * 4 + 3] = bv[3];
+        us[m][q] = 0.f; us[m][q + 16] = 0.f;
+        ts[m][q] = tsum;
+    }
+    __syncthreads();
+    if (p.T && q == 0 && m < p.M) {
+        // the routing mix of lora_mix_reduce_kernel (skinny.hip), same expression: u = bf16(scaling * softmax(route)_i * (x A^T)_j)
+        const float* t = &ts[m][0];
+        float e[8], mx = -INFINITY;
+        for (int i = 0; i < p.nl; ++i) mx = fmaxf(mx, t[i]);
+        float sum = 0.f;
+        for (int i = 0; i < p.nl; ++i) { e[i] = expf(t[i] - mx); sum += e[i]; }
+        const float inv = 1.0f / sum;
+        for (int i = 0; i < p.nl; ++i)
+            for (int j = 0; j < p.r; ++j) us[m][i * p.r + j] = bf2f(f2bf(p.scaling * e[i] * inv * t[p.nl + j]));
+    }
+    __syncthreads();
+    float ss = 0.f;
+    if (live) {
+        if (nu) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float a = 0.f;
+                for (int k = 0; k < nu; k += 2) {
+                    const uint32_t w = b2s[q * 4 + j][k >> 1];
+                    a += us[m][k] * lo_bf(w) + us[m][k + 1] * hi_bf(w);      // us[][nu] is zero when nu is odd
+                }
+                y[j] += a;
+            }
+        }
+        const uint32_t w0 = pack_bf2(y[0], y[1]), w1 = pack_bf2(y[2], y[3]);
+        *reinterpret_cast<u32x2*>(p.X + (long)m * p.ldx + c) = u32x2{w0, w1};
+        const float x0 = lo_bf(w0), x1 = hi_bf(w0), x2 = lo_bf(w1), x3 = hi_bf(w1);      // the norm sees the stored bf16 values
+        ss = (x0 * x0 + x1 * x1) + (x2 * x2 + x3 * x3);
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    if (q == 0) p.ssq[blockIdx.x * 16 + m] = m < p.M ? ss : 0.f;
+}
+
+struct RowfinRouteP {
+    const bf16_t* X; long ldx; const float* ssq; int nb;     // nb column slices (== gridDim.x)
+    const bf16_t* nw; float eps; bf16_t* H; long ldh;
+    const bf16_t* RA; long ldra; bf16_t* U; long ldu; int nproj, nl, r, ucols; float scaling;   // the NEXT group's router (RA == NULL: none)
+    float* tpart; unsigned* counter;                          // [nb][16][RF_TJ] fp32 partial router products; arrival count
+    int M, N;
+};
+
+__global__ __launch_bounds__(256) void rowfin_route_kernel(RowfinRouteP p) {
+    __shared__ __attribute__((aligned(16))) bf16_t ras[RF_TJ][RF_CW];       // 8 KB: the slice of [R;A]
+    __shared__ __attribute__((aligned(16))) float Tg[RF_G][16][RF_TJ];     // 16 KB: slice-group sums of the last arriver
+    __shared__ float Tm[16][RF_TJ];
+    __shared__ unsigned s_old;
+    const int tid = threadIdx.x, m = tid >> 4, q = tid & 15;
+    const int c0 = blockIdx.x * RF_CW, c = c0 + q * 4;
+    const int used = p.RA ? p.nproj * (p.nl + p.r) : 0;       // <= RF_TJ (host)
+    const int used16 = (used + 15) & ~15;
+    // ---- every global load first (one round trip): the [R;A] slice (two 16-byte chunks per thread), the partial sums of squares, x, w
+    u32x4 rv[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = tid + i * 256, j = idx >> 3, ch = idx & 7;
+        if (j < used && c0 + ch * 8 < p.N) rv[i] = *reinterpret_cast<const u32x4*>(p.RA + (long)j * p.ldra + c0 + ch * 8);
+    }
+    float sp[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sp[i] = q + i * 16 < p.nb ? p.ssq[(q + i * 16) * 16 + m] : 0.f;       // nb <= 128 (host)
+    const bool live = m < p.M && c < p.N;
+    u32x2 xw = {0u, 0u}, ww = {0u, 0u};
+    if (live) {
+        xw = *reinterpret_cast<const u32x2*>(p.X + (long)m * p.ldx + c);
+        ww = *reinterpret_cast<const u32x2*>(p.nw + c);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = tid + i * 256, j = idx >> 3, ch = idx & 7;
+        if (j < used16) *reinterpret_cast<u32x4*>(&ras[j][ch * 8]) = rv[i];
+    }
+    // ---- rstd of row m: the slices' partial sums of squares in a fixed order (8 strided terms per lane, then a butterfly)
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ss += sp[i];
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    const float rstd = rsqrtf(ss / (float)p.N + p.eps);
+    float hf[4] = {0.f, 0.f, 0.f, 0.f};
+    if (live) {
+        const float h0 = bf2f(f2bf(lo_bf(xw[0]) * rstd)) * lo_bf(ww[0]), h1 = bf2f(f2bf(hi_bf(xw[0]) * rstd)) * hi_bf(ww[0]);
+        const float h2 = bf2f(f2bf(lo_bf(xw[1]) * rstd)) * lo_bf(ww[1]), h3 = bf2f(f2bf(hi_bf(xw[1]) * rstd)) * hi_bf(ww[1]);
+        const uint32_t o0 = pack_bf2(h0, h1), o1 = pack_bf2(h2, h3);
+        *reinterpret_cast<u32x2*>(p.H + (long)m * p.ldh + c) = u32x2{o0, o1};
+        hf[0] = lo_bf(o0); hf[1] = hi_bf(o0); hf[2] = lo_bf(o1); hf[3] = hi_bf(o1);       // the router sees the stored bf16 row
+    }
+    if (!p.RA) return;
+    __syncthreads();
+    // ---- partial router products of this slice: t[m][j] = sum over the slice's columns of h * [R;A][j]; lane q keeps j = 4q .. 4q+3
+    f32x4_t keep = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int jj = 0; jj < RF_TJ / 16; ++jj) {
+        if (jj * 16 < used16) {
+#pragma unroll
+            for (int q2 = 0; q2 < 16; ++q2) {
+                const u32x2 w = *reinterpret_cast<const u32x2*>(&ras[jj * 16 + q2][q * 4]);
+                float a = (hf[0] * lo_bf(w[0]) + hf[1] * hi_bf(w[0])) + (hf[2] * lo_bf(w[1]) + hf[3] * hi_bf(w[1]));
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+                if (q == jj * 4 + (q2 >> 2)) keep[q2 & 3] = a;
+            }
+        }
+    }
+    // one 16-byte write-through (sc1) store per lane, drained by every storing wave before the arrival (guide G16 R1: no release fence)
+    if (4 * q < used16) {
+        float* dst = p.tpart + ((long)blockIdx.x * 16 + m) * RF_TJ + 4 * q;
+        if (m >= p.M) keep = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(keep) : "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) s_old = __hip_atomic_fetch_add(p.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_old != (unsigned)(p.nb - 1)) return;                 // not the last slice to arrive: done, nobody waits
+    // ---- last arriver: every slice's partials are published.  One acquire drops this CU's stale lines, then plain loads:
+    // item = (slice group g, row, 4 router rows): its slices' 16-byte records all in flight, summed in slice order; then the groups in order
+    if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+    const int n4 = used16 >> 2, per = (p.nb + RF_G - 1) / RF_G;
+    for (int idx = tid; idx < RF_G * p.M * n4; idx += 256) {
+        const int j4 = idx % n4, mm = (idx / n4) % p.M, g = idx / (n4 * p.M);
+        const int b0 = g * per, b1 = min(p.nb, b0 + per);
+        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+        const float* src = p.tpart + (long)mm * RF_TJ + 4 * j4;
+        const long st = 16L * RF_TJ;
+        int b = b0;
+        for (; b + 8 <= b1; b += 8) {
+            f32x4_t v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const f32x4_t*>(src + (b + i) * st);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc += v[i];
+        }
+        for (; b < b1; ++b) acc += *reinterpret_cast<const f32x4_t*>(src + b * st);
+        *reinterpret_cast<f32x4_t*>(&Tg[g][mm][4 * j4]) = acc;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < p.M * used16; idx += 256) {
+        const int mm = idx / used16, j = idx % used16;
+        Tm[mm][j] = ((Tg[0][mm][j] + Tg[1][mm][j]) + Tg[2][mm][j]) + Tg[3][mm][j];
+    }
+    __syncthreads();
+    if (tid == 0) *p.counter = 0u;                             // ready for the next call even without the apply kernel in front
+    const int per_row = p.nproj + 1;
+    if (tid >= 16 * per_row) return;
+    const int mm = tid / per_row, pj = tid % per_row;
+    if (mm >= p.M) return;
+    bf16_t* u = p.U + (long)mm * p.ldu;
+    const int usedu = p.nproj * p.nl * p.r;
+    if (pj == p.nproj) {
+        for (int cc = usedu; cc < p.ucols; ++cc) u[cc] = 0;
+        return;
+    }
+    const float* t = &Tm[mm][pj * (p.nl + p.r)];
+    float e[8], mx = -INFINITY;
+    for (int i = 0; i < p.nl; ++i) mx = fmaxf(mx, t[i]);
+    float sum = 0.f;
+    for (int i = 0; i < p.nl; ++i) { e[i] = expf(t[i] - mx); sum += e[i]; }
+    const float inv = 1.0f / sum;
+    for (int i = 0; i < p.nl; ++i)
+        for (int j = 0; j < p.r; ++j) u[pj * p.nl * p.r + i * p.r + j] = f2bf(p.scaling * e[i] * inv * t[p.nl + j]);
+}
+
+}  // namespace
+
+// Workspace carve behind the fp32 sums S [M][N] (all offsets 256-byte aligned): T [RF_SKX][16][16] fp32 | ssq [nb][16] fp32 |
+// tpart [nb][16][RF_TJ] fp32 | counter
+static inline int64_t rf_align(int64_t x) { return (x + 255) & ~(int64_t)255; }
+
+extern "C" int64_t crab_rowfin_workspace(int M, int N) {
+    const int nb = (N + RF_CW - 1) / RF_CW;
+    return rf_align((int64_t)M * N * 4) + rf_align(RF_SKX * 16 * 16 * 4) + rf_align((int64_t)nb * 16 * 4) + rf_align((int64_t)nb * 16 * RF_TJ * 4) + 256;
+}
+
+float* crab_rowfin_T(const crab_gemm_desc* d) { return (float*)((char*)d->workspace + rf_align((int64_t)d->M * d->N * 4)); }
+
+bool crab_rowfin_ok(const crab_gemm_desc* d) {
+    if (!d->norm_w || !d->norm_out || d->c_fp32 || d->M > 16 || !d->workspace) return false;
+    if ((d->N & 7) || (d->ldc & 3) || (d->ld_norm & 3) || (((uintptr_t)d->C | (uintptr_t)d->norm_out | (uintptr_t)d->norm_w) & 7)) return false;
+    if (crab_rowfin_workspace(d->M, d->N) > d->workspace_bytes || d->N > 128 * RF_CW) return false;
+    if (d->route_RA && ((d->route_ldra & 7) || ((uintptr_t)d->route_RA & 15) || d->route_nl > 8 || d->route_nproj * (d->route_nl + d->route_r) > RF_TJ))
+        return false;
+    if (d->lora_RA && (d->lora_nl > 8 || d->lora_nl + d->lora_r > 16 || d->lora_nl * d->lora_r > 32 || !d->B2 || (d->ldb2 & 7) ||
+                       ((uintptr_t)d->B2 & 15) || d->K2 < d->lora_nl * d->lora_r))
+        return false;
+    return true;
+}
+
+// S (and T when d->lora_RA) are in d->workspace, written by the GEMM launch in front (crab_gemm_skinny_launch, tune 9)
+int crab_rowfin_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* d) {
+    const int nb = (d->N + RF_CW - 1) / RF_CW;
+    char* w = (char*)d->workspace;
+    float* S = (float*)w;
+    w += rf_align((int64_t)d->M * d->N * 4);
+    float* T = (float*)w;
+    w += rf_align(RF_SKX * 16 * 16 * 4);
+    float* ssq = (float*)w;
+    w += rf_align((int64_t)nb * 16 * 4);
+    float* tpart = (float*)w;
+    w += rf_align((int64_t)nb * 16 * RF_TJ * 4);
+    unsigned* counter = (unsigned*)w;
+    RowfinApplyP a;
+    a.S = S; a.T = d->lora_RA ? T : nullptr;
+    a.B2 = (const bf16_t*)d->B2; a.ldb2 = d->ldb2; a.k2 = d->K2;
+    a.X = (bf16_t*)d->C; a.ldx = d->ldc; a.ssq = ssq; a.counter = counter;
+    a.M = d->M; a.N = d->N; a.nl = d->lora_nl; a.r = d->lora_r; a.scaling = d->lora_scaling;
+    hipLaunchKernelGGL(rowfin_apply_kernel, dim3(nb), dim3(256), 0, s, a);
+    int rc = crab_check_launch(ctx, "rowfin_apply_kernel");
+    if (rc) return rc;
+    RowfinRouteP r;
+    r.X = (const bf16_t*)d->C; r.ldx = d->ldc; r.ssq = ssq; r.nb = nb;
+    r.nw = (const bf16_t*)d->norm_w; r.eps = d->norm_eps; r.H = (bf16_t*)d->norm_out; r.ldh = d->ld_norm;
+    r.RA = (const bf16_t*)d->route_RA; r.ldra = d->route_ldra; r.U = (bf16_t*)d->route_U; r.ldu = d->route_ldu;
+    r.nproj = d->route_nproj; r.nl = d->route_nl; r.r = d->route_r; r.ucols = d->route_ucols; r.scaling = d->route_scaling;
+    r.tpart = tpart; r.counter = counter; r.M = d->M; r.N = d->N;
+    hipLaunchKernelGGL(rowfin_route_kernel, dim3(nb), dim3(256), 0, s, r);
+    return crab_check_launch(ctx, "rowfin_route_kernel");
+}

@@ -29,9 +29,16 @@ struct SkinnyP {
     long lda, ldb, ldc, ldr, lda2, ldb2;
     int M, N, K, K2, act, c_fp32;
     float res_scale;
+    // gemm_skinny_dma_kernel only: 16 extra weight rows Bx [16][K] behind the N rows of B (the projection's own hyper-LoRA [R;A]):
+    // SKX blocks past the last block of B each take one K range of them and store a partial product Tx[e][m][0..16) = A . Bx^T over
+    // that range (raw fp32 sums; the consumer adds the SKX partials in order) - the router product rides on the projection's launch
+    // instead of two launches of its own.  K is split because a 257th block as long as the others shares a CU with one of them and
+    // both then stream at half rate: o / down measured 13.3 -> 17.5 us with ONE extra full-K block.
+    const bf16_t* Bx; long ldbx; float* Tx;
 };
 
 constexpr int SK_WAVES = 8;
+constexpr int SKX = 8;                           // extra blocks (K ranges) of the ride-along router rows
 
 // MT: 16-row activation tiles (M <= 16*MT).  NT: 16-row weight tiles per block (block covers 16*NT rows of W).
 // Every wave covers all NT weight tiles and all MT activation tiles over its own K slice, so per k-step it issues
@@ -166,12 +173,19 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_dma_kernel(SkinnyP 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fg = lane >> 4;
-    const int n0 = blockIdx.x * 16 * NT;
+    const int nbN = (p.N + 16 * NT - 1) / (16 * NT);
+    const bool extra = (int)blockIdx.x >= nbN;                          // block-uniform: this block owns a K range of Bx, not rows of B
+    const int xe = (int)blockIdx.x - nbN;                               // which K range
+    const bf16_t* Bw = extra ? p.Bx : p.B;
+    const long ldbw = extra ? p.ldbx : p.ldb;
+    const int Nw = extra ? 16 : p.N;
+    const int n0 = extra ? 0 : (int)blockIdx.x * 16 * NT;
 
     const int nk1 = (p.K + 63) >> 6;
-    const int nk2 = p.A2 ? (p.K2 + 63) >> 6 : 0;
-    const int ks = nk1 + nk2;
-    const int s_begin = (int)((long)ks * wave / SK_WAVES), s_end = (int)((long)ks * (wave + 1) / SK_WAVES);
+    const int nk2 = (p.A2 && !extra) ? (p.K2 + 63) >> 6 : 0;
+    const int kx0 = extra ? (int)((long)nk1 * xe / SKX) : 0;            // first K slot of this block
+    const int ks = extra ? (int)((long)nk1 * (xe + 1) / SKX) - kx0 : nk1 + nk2;
+    const int s_begin = kx0 + (int)((long)ks * wave / SK_WAVES), s_end = kx0 + (int)((long)ks * (wave + 1) / SK_WAVES);
     const int nst = s_end - s_begin;
 
     // staging coordinates of the 2 NT pieces of a slot: lane l -> row i*8 + (l >> 3), LDS chunk l & 7 (lane-linear, as LDS-DMA writes),
@@ -183,9 +197,9 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_dma_kernel(SkinnyP 
     for (int i = 0; i < 2 * NT; ++i) {
         const int row = i * 8 + (lane >> 3);
         const int c = (lane & 7) ^ ((row >> 1) & 7);
-        const long wrow = min(n0 + row, p.N - 1);                       // clamped: rows >= N are never stored
+        const long wrow = min(n0 + row, Nw - 1);                        // clamped: rows >= N are never stored
         kc[i] = c * 8;
-        off1[i] = wrow * p.ldb + c * 8;
+        off1[i] = wrow * ldbw + c * 8;
         off2[i] = wrow * p.ldb2 + c * 8;
     }
     const long xrow1 = (long)min(fr, p.M - 1) * p.lda, xrow2 = (long)min(fr, p.M - 1) * p.lda2;
@@ -202,7 +216,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_dma_kernel(SkinnyP 
         const int k0_ = (s2_ ? st_ - nk1 : st_) << 6;                                                     \
         const int Ks_ = s2_ ? p.K2 : p.K;                                                                 \
         _Pragma("unroll") for (int i = 0; i < 2 * NT; ++i) {                                              \
-            const bf16_t* src_ = (s2_ ? p.B2 + off2[i] : p.B + off1[i]) + k0_;                            \
+            const bf16_t* src_ = (s2_ ? p.B2 + off2[i] : Bw + off1[i]) + k0_;                             \
             src_ = (k0_ + kc[i] < Ks_) ? src_ : zero;                                                     \
             __builtin_amdgcn_global_load_lds((sk_gbl_vptr)src_, (sk_lds_vptr)(myring + (U_) * SLOT + i * 512), 16, 0, 2);   \
         }                                                                                                 \
@@ -252,10 +266,14 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_dma_kernel(SkinnyP 
     if (tid < NT * 64) {
         const int j = tid >> 6, l = tid & 63;
         const int m = l & 15, n = n0 + j * 16 + (l >> 4) * 4;
-        if (m >= p.M || n >= p.N) return;
+        if (m >= p.M || n >= Nw) return;
         f32x4_t v = *reinterpret_cast<const f32x4_t*>(&red[0][j][l][0]);
 #pragma unroll
         for (int w = 1; w < SK_WAVES; ++w) v += *reinterpret_cast<const f32x4_t*>(&red[w][j][l][0]);
+        if (extra) {                                    // partial router product x . [R;A]^T over this block's K range, fp32 [SKX][16][16]
+            *reinterpret_cast<f32x4_t*>(p.Tx + ((long)xe * 16 + m) * 16 + n) = v;
+            return;
+        }
         if (part) {                                     // fp32 act(sum + bias) + res_scale * R (unrounded) for the row-owning reduction
             float* o = part + (long)m * p.N + n;        // kernel of gemm.hip, slab layout [M][N]; never with the SwiGLU pair epilogue
 #pragma unroll
@@ -515,6 +533,8 @@ __global__ __launch_bounds__(256) void lora_route_row_kernel(const bf16_t* __res
 
 }  // namespace
 
+float* crab_rowfin_T(const crab_gemm_desc* d);      // rowfin.hip: where the router product of a deferred hyper-LoRA update goes
+
 // called from crab_gemm_bf16 (gemm.hip) for unbatched problems with M <= 128
 int crab_gemm_skinny_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* d) {
     SkinnyP p;
@@ -522,6 +542,7 @@ int crab_gemm_skinny_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* 
     p.A2 = (const bf16_t*)d->A2; p.B2 = (const bf16_t*)d->B2;
     p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc; p.ldr = d->ldr; p.lda2 = d->lda2; p.ldb2 = d->ldb2;
     p.M = d->M; p.N = d->N; p.K = d->K; p.K2 = d->A2 ? d->K2 : 0; p.act = d->act; p.c_fp32 = d->c_fp32; p.res_scale = d->res_scale;
+    p.Bx = nullptr; p.ldbx = 0; p.Tx = nullptr;
     // M <= 16: the LDS-DMA ring kernel (tune 1 / 2 / 4 keep the register-direct kernel for A/B runs); d->tune == 9: the same with
     // raw fp32 sums to the workspace (used by crab_gemm_bf16 for its fused reduction epilogues)
     if (d->M <= 16 && (d->tune == 0 || d->tune == 9) && (d->ldb & 7) == 0 && (!d->A2 || (d->ldb2 & 7) == 0)) {
@@ -529,7 +550,12 @@ int crab_gemm_skinny_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* 
         // (profiles/README.md): a 6-slot ring changes nothing where a CU holds one block (o, down) and loses where it held two;
         // 32 rows per block (half the activation re-reads) is 10-25 % slower on every shape at M = 1 .. 16.
         float* part = d->tune == 9 ? (float*)d->workspace : nullptr;
-        hipLaunchKernelGGL((gemm_skinny_dma_kernel<1, 4>), dim3((d->N + 15) / 16), dim3(SK_WAVES * 64), 0, s, p, part);
+        int extra_blocks = 0;
+        if (d->tune == 9 && d->lora_RA) {               // the projection's own router rows ride on this launch (rowfin.hip applies them)
+            p.Bx = (const bf16_t*)d->lora_RA; p.ldbx = d->lora_ldra; p.Tx = crab_rowfin_T(d);
+            extra_blocks = SKX;
+        }
+        hipLaunchKernelGGL((gemm_skinny_dma_kernel<1, 4>), dim3((d->N + 15) / 16 + extra_blocks), dim3(SK_WAVES * 64), 0, s, p, part);
         return crab_check_launch(ctx, "gemm_skinny_dma_kernel");
     }
     // NT (weight tiles per block): bigger NT = fewer replicated activation reads but a smaller grid.  d->tune forces it.

@@ -6,6 +6,7 @@ caller-visible torch tensors.  No arithmetic happens in PyTorch here.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
 import torch
@@ -98,6 +99,8 @@ def _variant(M: int, N: int, batch: int = 1, K: int = 4096) -> str:
     return "gemm_bt_ring_kernel<256,256>" if ring else "gemm_bt_glds_kernel<128,128>"
 
 
+ROWFIN = os.environ.get("CRAB_ROWFIN", "1") != "0"     # the M <= 16 layer tail of csrc/rowfin.hip (same switch as the library reads)
+
 _SPLITK_WS = {}
 WS_SLOT = 0      # scratch slot of the launches being issued/captured: groups decoding concurrently on different HIP streams
                  # (GenerationEngine.generate, decode_streams > 1) must not share the split-K partial slabs
@@ -114,12 +117,14 @@ def _splitk_workspace(device) -> torch.Tensor:
 def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act: str = "none",
          residual: Optional[torch.Tensor] = None, res_scale: float = 1.0, x2: Optional[torch.Tensor] = None,
          w2: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, out_fp32: bool = False, tune: int = 0,
-         post_norm=None, rope=None, route=None) -> torch.Tensor:
+         post_norm=None, rope=None, route=None, lora_self=None) -> torch.Tensor:
     """out[M,N] = res_scale*residual + act(x[M,K] @ w[N,K]^T + x2 @ w2^T + bias).  2-D row-strided operands.
     rope = (tab, k_cache, v_cache, H, Hk, d, Tmax, pos0, pos_dev): packed q|k|v projection of ONE row per sequence followed
     by RoPE + KV-cache append (== qkv_rope_split(B=M, S=1) on out), fused into the split-K reduction when there is one.
     route = (RA, nproj, nl, r, ucols, scaling, u_out) (with post_norm, M <= 256): u_out = hyperlora_route(post-norm rows, RA)
     for the NEXT projection group, computed inside the row-owning reduction kernel when that path is taken.
+    lora_self = (RA, nl, r, scaling, lora_B) (with post_norm, M <= 16, no x2): the hyper-LoRA update of THIS single-projection group is
+    evaluated inside the call - its router rows ride on the projection's launch, the update is applied by the M <= 16 layer tail.
     act == "swiglu_pair": w rows are interleaved (gate_i, up_i) and out is [M, N/2] = silu(gate) * up."""
     _chk_bf16(x, w, bias, residual, x2, w2)
     d = _dev(x)
@@ -150,6 +155,12 @@ def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
         rRA, rnp, rnl, rr, ruc, rsc, ru = route
         g.route_RA, g.route_U, g.route_ldra, g.route_ldu = rRA.data_ptr(), ru.data_ptr(), rRA.stride(0), ru.stride(0)
         g.route_nproj, g.route_nl, g.route_r, g.route_ucols, g.route_scaling = rnp, rnl, rr, ruc, rsc
+    if lora_self is not None:
+        assert x2 is None and post_norm is not None
+        lRA, lnl, lr, lsc, lB = lora_self
+        _chk_bf16(lRA, lB)
+        g.lora_RA, g.lora_ldra, g.lora_nl, g.lora_r, g.lora_scaling = lRA.data_ptr(), lRA.stride(0), lnl, lr, lsc
+        g.B2, g.ldb2, g.K2 = lB.data_ptr(), lB.stride(0), lB.shape[1]
     if rope is not None:
         tab, kcache, vcache, rH, rHk, rd, rT, rp0, rpd = rope
         g.rope_tab, g.rope_k_cache, g.rope_v_cache = tab.data_ptr(), kcache.data_ptr(), vcache.data_ptr()

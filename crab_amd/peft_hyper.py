@@ -176,6 +176,12 @@ class PackedLinearGroup:
             route = (ng.RA, len(ng.names), ng.nl, ng.r, ng.u_cols, ng.scaling, nu[:M, :ng.u_cols])
         if self.RA is None:
             return ops.gemm(x, self.W, bias=self.bias, residual=residual, out=out, post_norm=post_norm, act=act, rope=rope, route=route)
+        if u_ready is None and M <= 16 and post_norm is not None and len(self.names) == 1 and ops.ROWFIN:
+            # the reference's batch sizes (M <= 16), o_proj / down_proj: no router launches - the [R;A] rows ride on the projection's
+            # launch and the update is applied by the wide layer tail (csrc/rowfin.hip) together with the residual row, its RMSNorm and
+            # the next group's router
+            return ops.gemm(x, self.W, bias=self.bias, residual=residual, out=out, post_norm=post_norm, act=act, route=route,
+                            lora_self=(self.RA, self.nl, self.r, self.scaling, self.B2))
         if u_ready is not None:
             u = u_ready[:M, :self.u_cols]
         else:

@@ -86,9 +86,19 @@ typedef struct {
      * `workspace`).  route_RA == NULL disables it; route_RA is [pad16(nproj*(nl+r)), N] with row stride route_ldra. */
     const void* route_RA; void* route_U; int64_t route_ldra, route_ldu;
     int32_t route_nproj, route_nl, route_r, route_ucols; float route_scaling;
+    /* optional hyper-LoRA of THIS projection evaluated inside the call (single-projection groups: o_proj, down_proj; peft_hyper/tuners/
+     * lora.py:338-350) instead of being handed in as the second K segment:  C = ... + lora_scaling * sum_i softmax(A . R^T)_i * B_i (A . A_lora^T).
+     * lora_RA [pad16(lora_nl + lora_r), K] = lora_nl route rows then lora_r lora_A rows (row stride lora_ldra); B2 / ldb2 / K2 describe
+     * lora_B [N, K2 >= lora_nl * lora_r] (expert i, rank j at column i * lora_r + j) and A2 must be NULL.  The router product rides on the
+     * projection's launch as 16 extra weight rows and the update is applied by the row-owning tail that also stores the residual row, its
+     * RMSNorm and the next group's router (csrc/rowfin.hip): needs M <= 16, norm_w / norm_out, bf16 C and a workspace of
+     * crab_rowfin_workspace(M, N) bytes; CRAB_E_UNSUPPORTED otherwise (use crab_hyperlora_route + A2 there).  lora_RA == NULL disables it. */
+    const void* lora_RA; int64_t lora_ldra; int32_t lora_nl, lora_r; float lora_scaling;
 } crab_gemm_desc;
 
 int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc* d);
+/* bytes of crab_gemm_desc.workspace the M <= 16 layer tail needs (fp32 sums + router product + per-slice partials) */
+int64_t crab_rowfin_workspace(int M, int N);
 
 /* ---------------------------------------------------------------------------------------------
  * hyper-LoRA routing mix (peft_hyper/tuners/lora.py:346-350).

@@ -521,6 +521,76 @@ def test_gemm_fused_post_rmsnorm(M, N):
     _cmp(h, O.rmsnorm(xd.cpu().float(), nw.float(), 1e-5, emulate=BF), 2e-3, "post-norm")
 
 
+@pytest.mark.parametrize("M", [1, 3, 8, 16])
+@pytest.mark.parametrize("N,K,nproj_next", [(4096, 4096, 2), (4096, 11008, 3), (128, 64, 3), (3584, 2048, 0), (200, 72, 1)])
+def test_small_batch_layer_tail_rowfin(M, N, K, nproj_next):
+    """csrc/rowfin.hip, the M <= 16 tail behind o_proj / down_proj (modeling_llama.py:805-827, lora.py:338-350): the projection's own
+    router rows ride on the GEMM launch, then two wide launches apply the hyper-LoRA update, store the residual row, its RMSNorm and the
+    NEXT group's router mix.  Against fp32 arithmetic on the same bf16 inputs, and against the K-extension form (router launches +
+    second K segment) the larger batches use; run twice (the arrival counter must come back to zero)."""
+    from crab_amd import ops
+    from oracle import crab_oracle as O
+    nl, r, sc = 3, 8, 2.0
+    x, w = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=K ** -0.5)
+    res = _rand(M, N, seed=3)
+    bias = _rand(N, seed=4, scale=0.1) if N == 128 else None
+    RA = torch.zeros(16, K, dtype=BF)
+    RA[:nl + r] = _rand(nl + r, K, seed=5, scale=K ** -0.5)
+    B2 = torch.zeros(N, 32, dtype=BF)
+    B2[:, :nl * r] = _rand(N, nl * r, seed=6, scale=0.2)
+    nw = (1 + 0.1 * torch.randn(N, generator=torch.Generator().manual_seed(7))).to(BF)
+    route = None
+    if nproj_next:
+        tc = (nproj_next * (nl + r) + 15) // 16 * 16
+        uc = (nproj_next * nl * r + 31) // 32 * 32
+        RAn = torch.zeros(tc, N, dtype=BF)
+        RAn[:nproj_next * (nl + r)] = _rand(nproj_next * (nl + r), N, seed=8, scale=N ** -0.5)
+        un = torch.full((M, uc), float("nan"), dtype=BF, device="cuda")
+        route = (RAn.cuda(), nproj_next, nl, r, uc, sc, un)
+    xd, wd, RAd, B2d, nwd = x.cuda(), w.cuda(), RA.cuda(), B2.cuda(), nw.cuda()
+    outs = []
+    for rep in range(2):
+        c = res.cuda().clone()
+        h = torch.empty(M, N, dtype=BF, device="cuda")
+        ops.gemm(xd, wd, bias=bias.cuda() if bias is not None else None, residual=c, out=c, post_norm=(nwd, 1e-5, h), route=route,
+                 lora_self=(RAd, nl, r, sc, B2d))
+        outs.append((c.clone(), h.clone(), route[6].clone() if route else None))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and (route is None or torch.equal(outs[0][2], outs[1][2]))
+    c, h, un_got = outs[0]
+    # fp32 reference
+    t = x.float() @ RA[:nl + r].float().t()
+    p = torch.softmax(t[:, :nl], -1)
+    u = (sc * p[:, :, None] * t[:, None, nl:]).reshape(M, nl * r).to(BF).float()
+    y = x.float() @ w.float().t() + (bias.float() if bias is not None else 0) + res.float() + u @ B2[:, :nl * r].float().t()
+    _cmp(c, y, TOL_BF16, f"rowfin: residual row with deferred hyper-LoRA update M={M} N={N} K={K}")
+    _cmp(h, O.rmsnorm(c.cpu().float(), nw.float(), 1e-5, emulate=BF), 2e-3, "rowfin: post-norm row")
+    if route:
+        tn = h.cpu().float() @ route[0].cpu().float().t()
+        refu = torch.zeros(M, route[4])
+        for pj in range(nproj_next):
+            tt = tn[:, pj * (nl + r):(pj + 1) * (nl + r)]
+            pp = torch.softmax(tt[:, :nl], -1)
+            refu[:, pj * nl * r:(pj + 1) * nl * r] = (sc * pp[:, :, None] * tt[:, None, nl:]).reshape(M, nl * r)
+        _cmp(un_got, refu, TOL_BF16, "rowfin: next group's router mix")
+        assert float(un_got[:, nproj_next * nl * r:].float().abs().max()) == 0.0 if route[4] > nproj_next * nl * r else True
+    # the K-extension form (what M > 16 runs): router launches + second K segment
+    ud = ops.hyperlora_route(xd, RAd, 1, nl, r, 32, sc)
+    c2 = res.cuda().clone()
+    h2 = torch.empty(M, N, dtype=BF, device="cuda")
+    ops.gemm(xd, wd, bias=bias.cuda() if bias is not None else None, residual=c2, x2=ud, w2=B2d, out=c2, post_norm=(nwd, 1e-5, h2))
+    _cmp(c, c2.float(), TOL_BF16, "rowfin vs K-extension form: residual row (HIP vs HIP)")
+
+
+def test_rowfin_in_call_lora_is_refused_outside_its_regime():
+    from crab_amd import ops
+    from crab_amd._lib import CrabHipError
+    M, N, K = 32, 128, 64
+    x, w, RA, B2 = _rand(M, K).cuda(), _rand(N, K).cuda(), _rand(16, K).cuda(), _rand(N, 32).cuda()
+    h = torch.empty(M, N, dtype=BF, device="cuda")
+    with pytest.raises(CrabHipError, match="M <= 16"):
+        ops.gemm(x, w, post_norm=(torch.ones(N, dtype=BF, device="cuda"), 1e-5, h), lora_self=(RA, 3, 8, 2.0, B2))
+
+
 def test_gemm_ring_split_wide_projection_auto():
     """N >= 10240 at M = 256 takes the 256x256 ring kernel with K slices automatically; result == the 128x128 split path."""
     from crab_amd import ops
