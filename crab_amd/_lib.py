@@ -81,6 +81,7 @@ class LlamaIO(C.Structure):
         ("rope_tab", C.c_void_p), ("k_cache", C.c_void_p), ("v_cache", C.c_void_p), ("cache_layer_stride", C.c_int64),
         ("vt", C.c_void_p), ("vt_ld", C.c_int64), ("pos_dev", C.c_void_p),
         ("B", C.c_int32), ("S", C.c_int32), ("Tmax", C.c_int32), ("pos0", C.c_int32), ("u_qkv_ready", C.c_int32),
+        ("attn_ws", C.c_void_p), ("attn_ws_bytes", C.c_int64),
     ]
 
 
@@ -101,6 +102,8 @@ SYMBOLS = {
     "crab_sync": (_i, [_vp, _vp]),
     "crab_gemm_bf16": (_i, [_vp, _vp, C.POINTER(GemmDesc)]),
     "crab_rowfin_workspace": (_i64, [_i, _i]),
+    "crab_attn_decode_rope_workspace": (_i64, [_i, _i, _i]),
+    "crab_attn_decode_rope": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _vp, _f, _vp, _i64]),
     "crab_hyperlora_mix": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _i64, _i, _i, _i, _i, _i, _f]),
     "crab_hyperlora_route_workspace": (_i64, [_i, _i, _i]),
     "crab_hyperlora_route": (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _vp, _i64, _i, _f, _vp, _i64]),

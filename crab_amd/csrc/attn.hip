@@ -355,6 +355,214 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
 }
 
 
+// ---------------------------------------------------------------------------------------------- decode, small batch (B * H < 256)
+// attn_decode_rope_kernel: the decode attention of the reference's own batch sizes (1 and 8 clips, scripts/quick_start.py:43,
+// inference_hyper_lora.py:1477) with what surrounded it folded in:
+//   * RoPE of q and of the new k (modeling_llama.py:204-236) and the KV-cache append (:408-412) happen HERE, from the raw packed q|k|v
+//     row: the separate rotate / scatter launch (4.8 us of a 135 us layer) is gone.  Lane `sub` owns EPL consecutive dims of the head, its
+//     rotation partner (dim +- d/2) is lane sub ^ 8 of the same 16-lane group: one shuffle per element.  q and k are rounded to bf16
+//     after the rotation exactly like the stored form (rope_lo / rope_hi, common.h), so the result is bit-identical to the unfused pair.
+//     The new key / value never travel through the cache for THIS step: the split that owns position `pos` takes them from registers,
+//     and the block (h % G == 0, split 0) appends them for the following steps - no inter-block dependency.
+//   * the context is SPLIT over blockIdx.z when (b, h) alone cannot fill the chip (one clip = 32 blocks on 256 CUs: 19 us per layer at
+//     0.7 TB/s): every split writes its (max, sum, weighted V sum) with write-through stores, takes a ticket on a per-(b, h) counter
+//     and the LAST one merges the splits in split order - nobody waits, the order of arrival does not matter (deterministic).
+//     The counters must be zero at entry; the kernel leaves them zero (the caller zero-fills the workspace once).
+template <int HD>
+__global__ __launch_bounds__(256) void attn_decode_rope_kernel(const bf16_t* __restrict__ qkv, long ldq, const float* __restrict__ tab,
+                                                               bf16_t* __restrict__ kc, bf16_t* __restrict__ vc, bf16_t* __restrict__ o, long ldo,
+                                                               int H, int Hk, int Tmax, int pos0, const int* __restrict__ pos_dev, float scale,
+                                                               float* part, unsigned* counters) {
+    constexpr int EPL = HD / 16, WPL = EPL / 2;                 // elements / 32-bit words per lane
+    __shared__ float sm[16], sl[16];
+    __shared__ float so[16][HD];
+    __shared__ unsigned s_old;
+    const int tid = threadIdx.x;
+    const int grp = tid >> 4, sub = tid & 15;
+    const int h = blockIdx.x, b = blockIdx.y, z = blockIdx.z, nsplit = gridDim.z;
+    const int G = H / Hk, hk = h / G;
+    const int pos = pos0 + (pos_dev ? pos_dev[0] : 0);         // the token being decoded: keys 0 .. pos are visible
+    // ---- q, new k (rotated, rounded like the stored form) and new v of this head
+    const bool hi_half = sub >= 8;
+    const float* cs = tab + ((long)pos * (HD / 2) + (sub & 7) * EPL) * 2;
+    const bf16_t* row = qkv + (long)b * ldq;
+    uint32_t qw[WPL], kw[WPL], vw[WPL];
+#pragma unroll
+    for (int i = 0; i < WPL; ++i) {
+        qw[i] = reinterpret_cast<const uint32_t*>(row + (long)h * HD + sub * EPL)[i];
+        kw[i] = reinterpret_cast<const uint32_t*>(row + (long)(H + hk) * HD + sub * EPL)[i];
+        vw[i] = reinterpret_cast<const uint32_t*>(row + (long)(H + Hk + hk) * HD + sub * EPL)[i];
+    }
+    float qv[EPL], kn[EPL], vn[EPL];
+    uint32_t kst[WPL];
+#pragma unroll
+    for (int i = 0; i < WPL; ++i) {
+        float r2[2][2];                                          // [q | k][lo | hi element of the word]
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const float c = cs[2 * (2 * i + e)], sn = cs[2 * (2 * i + e) + 1];
+            const float xq = e ? hi_bf(qw[i]) : lo_bf(qw[i]), xk = e ? hi_bf(kw[i]) : lo_bf(kw[i]);
+            const float pq = __shfl_xor(xq, 8, 64), pk = __shfl_xor(xk, 8, 64);
+            r2[0][e] = hi_half ? rope_hi(pq, xq, c, sn) : rope_lo(xq, pq, c, sn);
+            r2[1][e] = hi_half ? rope_hi(pk, xk, c, sn) : rope_lo(xk, pk, c, sn);
+        }
+        const uint32_t qs = pack_bf2(r2[0][0], r2[0][1]);
+        kst[i] = pack_bf2(r2[1][0], r2[1][1]);
+        qv[2 * i] = lo_bf(qs) * scale; qv[2 * i + 1] = hi_bf(qs) * scale;
+        kn[2 * i] = lo_bf(kst[i]); kn[2 * i + 1] = hi_bf(kst[i]);
+        vn[2 * i] = lo_bf(vw[i]); vn[2 * i + 1] = hi_bf(vw[i]);
+    }
+    const long crow = ((long)b * Hk + hk) * (long)Tmax;
+    if (z == 0 && h % G == 0 && grp == 0) {                     // append for the following steps
+#pragma unroll
+        for (int i = 0; i < WPL; ++i) {
+            reinterpret_cast<uint32_t*>(kc + (crow + pos) * HD + sub * EPL)[i] = kst[i];
+            reinterpret_cast<uint32_t*>(vc + (crow + pos) * HD + sub * EPL)[i] = vw[i];
+        }
+    }
+    // ---- this split's keys: cached rows [kb0, kb0 + nc), and the new key from registers when pos falls in the split
+    const int chunk = (pos + nsplit) / nsplit;                  // ceil((pos + 1) / nsplit)
+    const int kb0 = z * chunk, ke0 = min(pos + 1, kb0 + chunk);
+    const int nc = min(ke0, pos) - kb0;
+    const bool has_new = pos >= kb0 && pos < ke0;
+    const bf16_t* kb = kc + (crow + kb0) * HD + sub * EPL;
+    const bf16_t* vb = vc + (crow + kb0) * HD + sub * EPL;
+    float m = -1e30f, l = 0.f, acc[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
+    if (EPL == 8) {
+        // two keys per trip, the next pair requested before the current one is consumed (the schedule of attn_decode_kernel)
+        const u32x4 z4 = {0u, 0u, 0u, 0u};
+        u32x4 k0 = z4, v0 = z4, k1 = z4, v1 = z4;
+        if (grp < nc) {
+            k0 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kb + (long)grp * HD));
+            v0 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vb + (long)grp * HD));
+        }
+        if (grp + 16 < nc) {
+            k1 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kb + (long)(grp + 16) * HD));
+            v1 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vb + (long)(grp + 16) * HD));
+        }
+        for (int j = grp; j < nc; j += 32) {
+            u32x4 kn0 = z4, vn0 = z4, kn1 = z4, vn1 = z4;
+            if (j + 32 < nc) {
+                kn0 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kb + (long)(j + 32) * HD));
+                vn0 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vb + (long)(j + 32) * HD));
+            }
+            if (j + 48 < nc) {
+                kn1 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kb + (long)(j + 48) * HD));
+                vn1 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vb + (long)(j + 48) * HD));
+            }
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s0 += qv[2 * e] * lo_bf(k0[e]) + qv[2 * e + 1] * hi_bf(k0[e]);
+                s1 += qv[2 * e] * lo_bf(k1[e]) + qv[2 * e + 1] * hi_bf(k1[e]);
+            }
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) { s0 += __shfl_xor(s0, off, 64); s1 += __shfl_xor(s1, off, 64); }
+            const bool has1 = j + 16 < nc;                      // group-uniform
+            const float mn = fmaxf(m, has1 ? fmaxf(s0, s1) : s0);
+            const float a = __expf(m - mn), p0 = __expf(s0 - mn), p1 = has1 ? __expf(s1 - mn) : 0.f;
+            l = l * a + (p0 + p1);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[2 * e] = acc[2 * e] * a + (p0 * lo_bf(v0[e]) + p1 * lo_bf(v1[e]));
+                acc[2 * e + 1] = acc[2 * e + 1] * a + (p0 * hi_bf(v0[e]) + p1 * hi_bf(v1[e]));
+            }
+            m = mn;
+            k0 = kn0; v0 = vn0; k1 = kn1; v1 = vn1;
+        }
+    } else {
+    for (int j = grp; j < nc; j += 16) {
+        uint32_t kk[WPL], vv[WPL];
+#pragma unroll
+        for (int i = 0; i < WPL; ++i) {
+            kk[i] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(kb + (long)j * HD) + i);
+            vv[i] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(vb + (long)j * HD) + i);
+        }
+        float sdot = 0.f;
+#pragma unroll
+        for (int i = 0; i < WPL; ++i) sdot += qv[2 * i] * lo_bf(kk[i]) + qv[2 * i + 1] * hi_bf(kk[i]);
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) sdot += __shfl_xor(sdot, off, 64);
+        const float mn = fmaxf(m, sdot);
+        const float a = __expf(m - mn), pw = __expf(sdot - mn);
+        l = l * a + pw;
+#pragma unroll
+        for (int i = 0; i < WPL; ++i) {
+            acc[2 * i] = acc[2 * i] * a + pw * lo_bf(vv[i]);
+            acc[2 * i + 1] = acc[2 * i + 1] * a + pw * hi_bf(vv[i]);
+        }
+        m = mn;
+    }
+    }
+    {
+        float sdot = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) sdot += qv[e] * kn[e];
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) sdot += __shfl_xor(sdot, off, 64);
+        if (has_new && grp == 0) {
+            const float mn = fmaxf(m, sdot);
+            const float a = __expf(m - mn), pw = __expf(sdot - mn);
+            l = l * a + pw;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) acc[e] = acc[e] * a + pw * vn[e];
+            m = mn;
+        }
+    }
+    if (sub == 0) { sm[grp] = m; sl[grp] = l; }
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) so[grp][sub * EPL + e] = acc[e];
+    __syncthreads();
+    float Mx = -1e30f, L = 0.f, O = 0.f;
+    if (tid < HD) {
+#pragma unroll
+        for (int g = 0; g < 16; ++g) Mx = fmaxf(Mx, sm[g]);
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const float w = __expf(sm[g] - Mx);
+            L += sl[g] * w;
+            O += so[g][tid] * w;
+        }
+    }
+    if (nsplit == 1) {
+        if (tid < HD) o[(long)b * ldo + (long)h * HD + tid] = f2bf(O / L);
+        return;
+    }
+    // ---- publish this split, take a ticket, the last one merges
+    float* mine = part + ((long)(b * H + h) * nsplit + z) * (HD + 2);
+    if (tid < HD) {
+        __hip_atomic_store(mine + tid, O, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) {
+            __hip_atomic_store(mine + HD, Mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(mine + HD + 1, L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) s_old = __hip_atomic_fetch_add(counters + b * H + h, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_old != (unsigned)(nsplit - 1)) return;
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        counters[b * H + h] = 0u;                               // ready for the next step
+    }
+    __syncthreads();
+    if (tid < HD) {
+        const float* base = part + (long)(b * H + h) * nsplit * (HD + 2);
+        float Mt = -1e30f;
+        for (int s2 = 0; s2 < nsplit; ++s2) Mt = fmaxf(Mt, base[s2 * (HD + 2) + HD]);
+        float Lt = 0.f, Ot = 0.f;
+        for (int s2 = 0; s2 < nsplit; ++s2) {                   // split order, whatever the order of arrival
+            const float w = __expf(base[s2 * (HD + 2) + HD] - Mt);
+            Lt += base[s2 * (HD + 2) + HD + 1] * w;
+            Ot += base[s2 * (HD + 2) + tid] * w;
+        }
+        o[(long)b * ldo + (long)h * HD + tid] = f2bf(Ot / Lt);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- decode, grouped-query
 // One block per (b, kv head): every K and V row is read ONCE for the G query heads that share it (the per-(b,h) kernel
 // above re-reads it G times; Qwen2-7B: G = 7).  Keys are processed in chunks of GQ_CH:
@@ -572,6 +780,36 @@ extern "C" int crab_attn_fwd(crab_ctx* ctx, void* stream, const crab_attn_desc* 
         else hipLaunchKernelGGL((attn_fwd_kernel<64, false, false>), grid, block, 0, s, p);
     }
     return crab_check_launch(ctx, "attn_fwd");
+}
+
+extern "C" int64_t crab_attn_decode_rope_workspace(int B, int H, int d) {
+    // up to 8 splits of (d + 2) fp32 per (b, h) + one counter per (b, h); the counters (at the END) must be zero at the first call
+    return ((int64_t)B * H * 8 * (d + 2) * 4 + 255) / 256 * 256 + (int64_t)B * H * 4;
+}
+
+extern "C" int crab_attn_decode_rope(crab_ctx* ctx, void* stream, const void* qkv, int64_t ldqkv, const float* rope_tab, void* k_cache,
+                                     void* v_cache, void* o, int64_t ldo, int B, int H, int Hk, int d, int Tmax, int pos0,
+                                     const int32_t* pos_dev, float scale, void* workspace, int64_t workspace_bytes) {
+    if (!ctx) return CRAB_E_INVALID;
+    if (!qkv || !rope_tab || !k_cache || !v_cache || !o || B <= 0 || H <= 0 || Hk <= 0 || H % Hk) return crab_fail(ctx, CRAB_E_INVALID, "attn_decode_rope: bad argument");
+    if (d != 64 && d != 128) return crab_fail(ctx, CRAB_E_UNSUPPORTED, "attn_decode_rope: head_dim must be 64 or 128");
+    if ((ldqkv & 7) || ((uintptr_t)qkv & 15) || ((uintptr_t)k_cache & 15) || ((uintptr_t)v_cache & 15)) return crab_fail(ctx, CRAB_E_INVALID, "attn_decode_rope: alignment");
+    if (!pos_dev && (pos0 < 0 || pos0 >= Tmax)) return crab_fail(ctx, CRAB_E_INVALID, "attn_decode_rope: position outside the KV cache");
+    int nsplit = 1;
+    if ((long)B * H < 256) { nsplit = (int)(256 / ((long)B * H)); if (nsplit > 8) nsplit = 8; }
+    if (nsplit > 1 && (!workspace || workspace_bytes < crab_attn_decode_rope_workspace(B, H, d)))
+        return crab_fail(ctx, CRAB_E_WORKSPACE, "attn_decode_rope: needs crab_attn_decode_rope_workspace(B, H, d) bytes (counters zeroed once)");
+    float* part = (float*)workspace;
+    unsigned* counters = workspace ? (unsigned*)((char*)workspace + ((int64_t)B * H * 8 * (d + 2) * 4 + 255) / 256 * 256) : nullptr;
+    dim3 grid(H, B, nsplit), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (d == 128)
+        hipLaunchKernelGGL((attn_decode_rope_kernel<128>), grid, block, 0, s, (const bf16_t*)qkv, (long)ldqkv, rope_tab, (bf16_t*)k_cache,
+                           (bf16_t*)v_cache, (bf16_t*)o, (long)ldo, H, Hk, Tmax, pos0, pos_dev, scale, part, counters);
+    else
+        hipLaunchKernelGGL((attn_decode_rope_kernel<64>), grid, block, 0, s, (const bf16_t*)qkv, (long)ldqkv, rope_tab, (bf16_t*)k_cache,
+                           (bf16_t*)v_cache, (bf16_t*)o, (long)ldo, H, Hk, Tmax, pos0, pos_dev, scale, part, counters);
+    return crab_check_launch(ctx, "attn_decode_rope");
 }
 
 extern "C" int crab_attn_decode_masked(crab_ctx* ctx, void* stream, const void* q, int64_t ldq, const void* k_cache, const void* v_cache,

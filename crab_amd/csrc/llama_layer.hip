@@ -129,10 +129,14 @@ int run_layer(crab_ctx* ctx, void* stream, const crab_llama_layer* L, crab_llama
     const float scale = (float)(1.0 / sqrt((double)d));   // double, then rounded once: what crab_amd/decoder.py passes
     int rc;
     // ---- q|k|v
+    // small batch (B * H blocks cannot fill 256 CUs): the projection leaves its raw row and ONE launch does RoPE + KV append + attention with
+    // the context split over several blocks per head (crab_attn_decode_rope) - same choice as crab_amd/decoder.py
+    const bool fuse_attn = !prefill && io->attn_ws && (long)B * H < 256 && (d == 64 || d == 128) && (io->ldqkv & 7) == 0 &&
+                           io->attn_ws_bytes >= crab_attn_decode_rope_workspace(B, H, d);
     GroupCall q{};
     q.x = io->h; q.ldx = io->ldh; q.out = io->qkv; q.ldc = io->ldqkv; q.act = CRAB_ACT_NONE;
     q.u_ready = (io->u_qkv_ready && L->qkv.RA) ? io->u2 : nullptr;
-    q.rope = !prefill;
+    q.rope = !prefill && !fuse_attn;
     if ((rc = run_group(ctx, stream, &L->qkv, io, L, M, q, kc, vc))) return rc;
     if (prefill) {
         if ((rc = crab_qkv_rope_split(ctx, stream, io->qkv, io->ldqkv, io->rope_tab, kc, vc, io->vt, io->vt_ld, B, S, H, Hk, d, io->Tmax, io->pos0,
@@ -147,6 +151,10 @@ int run_layer(crab_ctx* ctx, void* stream, const crab_llama_layer* L, crab_llama
         a.o_bs = (int64_t)S * io->ldatt; a.o_ss = io->ldatt;
         a.B = B; a.H = H; a.Hk = Hk; a.Sq = S; a.Skv = io->pos0 + S; a.head_dim = d; a.causal = 1; a.scale = scale;
         if ((rc = crab_attn_fwd(ctx, stream, &a))) return rc;
+    } else if (fuse_attn) {
+        if ((rc = crab_attn_decode_rope(ctx, stream, io->qkv, io->ldqkv, io->rope_tab, kc, vc, io->att, io->ldatt, B, H, Hk, d, io->Tmax, io->pos0,
+                                        io->pos_dev, scale, io->attn_ws, io->attn_ws_bytes)))
+            return rc;
     } else {
         if ((rc = crab_attn_decode(ctx, stream, io->qkv, io->ldqkv, kc, vc, io->att, io->ldatt, B, H, Hk, d, io->Tmax, io->pos0 + 1,
                                    io->pos_dev, scale)))

@@ -139,6 +139,9 @@ class _Workspace:
         self.t = torch.empty((max(ops.hyperlora_route_workspace(M, max(D, I), max(t_cols, 16)), 16),), device=device, dtype=torch.uint8)
         self.u = e(M, max(u_cols, 32))
         self.u2 = e(M, max(u_cols, 32))       # router output produced ahead by a fused post-norm epilogue
+        # small batches (M * H blocks cannot fill the chip): scratch of the fused RoPE + append + split-context decode attention; its
+        # tickets start at zero and the kernel leaves them zero
+        self.attn_ws = ops.attn_decode_rope_workspace(M, H, d, device) if M * H < 256 and d in (64, 128) else None
 
 
 class GenerationEngine:
@@ -354,6 +357,8 @@ class GenerationEngine:
         if vt is not None:
             io.vt, io.vt_ld = vt.data_ptr(), vt.stride(-2)
         io.pos_dev = pos_dev.data_ptr() if pos_dev is not None else None
+        if ws.attn_ws is not None and vt is None:
+            io.attn_ws, io.attn_ws_bytes = ws.attn_ws.data_ptr(), ws.attn_ws.numel()
         io.B, io.S, io.Tmax, io.pos0, io.u_qkv_ready = B, S, Tmax, pos0, 0
         ops.llama_layers(self._layer_table(), len(self.model.layers), io, self.device)
 
@@ -381,10 +386,15 @@ class GenerationEngine:
             self._layers_native(ws, B, S, kc, vc, b0, Tmax, pos0, pos_dev, vt)
             return x, h
         u_qkv = None                                   # router output for the q|k|v group when a producer epilogue made it
+        # small batch: the projection leaves its raw row, ONE launch does RoPE + KV append + split-context attention (as csrc/llama_layer.hip)
+        fuse_attn = (vt is None and S == 1 and not masked and ws.attn_ws is not None and B * H < 256 and kc.is_contiguous() and
+                     ws.attn_ws.numel() >= ops.attn_decode_rope_bytes(B, H, d))
         for li, layer in enumerate(layers):
             a, m = layer.self_attn, layer.mlp
             kcl, vcl = kc[li, b0:b0 + B], vc[li, b0:b0 + B]
-            if vt is None and S == 1 and kcl.is_contiguous() and not masked:
+            if fuse_attn:
+                a._qkv(h, out=qkv, t_buf=ws.t, u_buf=ws.u, u_ready=u_qkv)
+            elif vt is None and S == 1 and kcl.is_contiguous() and not masked:
                 # decode: RoPE + KV append ride on the q|k|v projection (fused into its split-K reduction when it has one)
                 a._qkv(h, out=qkv, t_buf=ws.t, u_buf=ws.u, u_ready=u_qkv, rope=(tab, kcl, vcl, H, Hk, d, Tmax, pos0, pos_dev))
             else:
@@ -395,6 +405,8 @@ class GenerationEngine:
                 ops.attn_fwd(qkv, kcl, vt, att, q_strides=(S * ldq, d, ldq), k_strides=(Hk * Tmax * d, Tmax * d, d),
                              vt_strides=(Hk * d * Sp, d * Sp, Sp), o_strides=(S * H * d, H * d), B=B, H=H, Hk=Hk, Sq=S,
                              Skv=pos0 + S, head_dim=d, scale=scale, causal=True, kv_start=kv_start)
+            elif fuse_attn:
+                ops.attn_decode_rope(qkv, tab, kcl, vcl, att, B, H, Hk, d, Tmax, pos0, scale, pos_dev=pos_dev, workspace=ws.attn_ws)
             else:
                 ops.attn_decode(qkv, kcl, vcl, att, B, H, Hk, d, Tmax, pos0 + 1, scale, ctx_dev=pos_dev, kv_start=kv_start)
             # x += o_proj(att); h = rmsnorm(x) * post_attention_layernorm  (norm fused into the GEMM epilogue for small M)

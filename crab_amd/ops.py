@@ -309,6 +309,24 @@ def attn_decode(q, k_cache, v_cache, o, B, H, Hk, head_dim, Tmax, ctx_len, scale
     return o
 
 
+def attn_decode_rope_bytes(B: int, H: int, d: int) -> int:
+    return int(_lib.load().crab_attn_decode_rope_workspace(B, H, d))
+
+
+def attn_decode_rope_workspace(B: int, H: int, d: int, device) -> torch.Tensor:
+    """Zero-filled workspace of crab_attn_decode_rope (the tickets at its end must start at zero; the kernel leaves them zero)."""
+    return torch.zeros((int(_lib.load().crab_attn_decode_rope_workspace(B, H, d)),), device=device, dtype=torch.uint8)
+
+
+def attn_decode_rope(qkv, rope_tab, k_cache, v_cache, o, B, H, Hk, head_dim, Tmax, pos0, scale, pos_dev=None, workspace=None):
+    """RoPE of q / new k + KV append + decode attention over keys 0 .. pos from the raw packed q|k|v rows (small batch)."""
+    d = _dev(qkv)
+    _lib.check(_lib.load().crab_attn_decode_rope(_lib.ctx(d), _stream(), _p(qkv), qkv.stride(0), _p(rope_tab), _p(k_cache), _p(v_cache), _p(o),
+                                                 o.stride(0), B, H, Hk, head_dim, Tmax, pos0, _p(pos_dev), scale, _p(workspace),
+                                                 workspace.numel() if workspace is not None else 0), d)
+    return o
+
+
 def llama_layers(table, n_layers: int, io, device):
     """crab_llama_layers: every layer of a decoder stack (prefill when io.vt is set, one decode step otherwise) in one call."""
     d = device.index or 0

@@ -581,6 +581,37 @@ def test_small_batch_layer_tail_rowfin(M, N, K, nproj_next):
     _cmp(c, c2.float(), TOL_BF16, "rowfin vs K-extension form: residual row (HIP vs HIP)")
 
 
+@pytest.mark.parametrize("hd,B,H,Hk,pos", [(128, 1, 32, 32, 702), (128, 1, 32, 32, 5), (128, 8, 32, 32, 830), (128, 2, 28, 4, 333), (64, 3, 4, 2, 0),
+                                           (64, 1, 4, 4, 77), (128, 16, 32, 32, 100)])
+def test_decode_attention_fused_rope_append_split(hd, B, H, Hk, pos):
+    """crab_attn_decode_rope vs crab_qkv_rope_split + crab_attn_decode: the cache rows it appends are BIT-identical (same rotation,
+    same rounding), the attention output agrees to the accumulation order (new key last, splits merged in order), for one block per
+    (b, h) and for the context split over up to 8 blocks (B * H < 256), GQA included; two consecutive calls (tickets back to zero)."""
+    from crab_amd import ops
+    Tmax, theta = 1024, 10000.0
+    tab = ops.rope_table(Tmax, hd, theta, "cuda")
+    g = torch.Generator(device="cuda").manual_seed(pos + B)
+    kc = (torch.randn(B, Hk, Tmax, hd, device="cuda", generator=g) * 0.5).to(BF)
+    vc = (torch.randn(B, Hk, Tmax, hd, device="cuda", generator=g) * 0.5).to(BF)
+    ws = ops.attn_decode_rope_workspace(B, H, hd, "cuda")
+    pd = torch.tensor([pos], dtype=torch.int32, device="cuda")
+    for step in range(2):
+        qkv = (torch.randn(B, (H + 2 * Hk) * hd, device="cuda", generator=g)).to(BF)
+        k1, v1, k2, v2 = kc.clone(), vc.clone(), kc.clone(), vc.clone()
+        q1 = qkv.clone()
+        ops.qkv_rope_split(q1, tab, k1, v1, None, B, 1, H, Hk, hd, Tmax, pos0=0, pos_dev=pd)
+        o1 = torch.zeros(B, H * hd, dtype=BF, device="cuda")
+        ops.attn_decode(q1, k1, v1, o1, B, H, Hk, hd, Tmax, 1, hd ** -0.5, ctx_dev=pd)
+        o2 = torch.zeros(B, H * hd, dtype=BF, device="cuda")
+        ops.attn_decode_rope(qkv, tab, k2, v2, o2, B, H, Hk, hd, Tmax, 0, hd ** -0.5, pos_dev=pd, workspace=ws)
+        assert torch.equal(k1, k2) and torch.equal(v1, v2), "appended cache rows differ from the unfused pair"
+        # q / k take the same roundings as the unfused pair; the softmax accumulation order differs (the new key last, the split merge)
+        _cmp(o2, o1.float(), 6e-3, f"fused rope + append + split-context decode attention vs the unfused pair (HIP vs HIP) B={B} H={H} pos={pos}")
+        kc, vc = k2, v2
+        pd += 1
+    assert int(ws[-B * H * 4:].view(torch.int32).abs().sum()) == 0
+
+
 def test_rowfin_in_call_lora_is_refused_outside_its_regime():
     from crab_amd import ops
     from crab_amd._lib import CrabHipError
