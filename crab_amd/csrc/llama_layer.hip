@@ -131,7 +131,7 @@ int run_layer(crab_ctx* ctx, void* stream, const crab_llama_layer* L, crab_llama
     // ---- q|k|v
     // small batch (B * H blocks cannot fill 256 CUs): the projection leaves its raw row and ONE launch does RoPE + KV append + attention with
     // the context split over several blocks per head (crab_attn_decode_rope) - same choice as crab_amd/decoder.py
-    const bool fuse_attn = !prefill && io->attn_ws && (long)B * H < 256 && (d == 64 || d == 128) && (io->ldqkv & 7) == 0 &&
+    const bool fuse_attn = !prefill && io->attn_ws && (long)B * H < CRAB_ATTN_SPLIT_BELOW && (d == 64 || d == 128) && (io->ldqkv & 7) == 0 &&
                            io->attn_ws_bytes >= crab_attn_decode_rope_workspace(B, H, d);
     GroupCall q{};
     q.x = io->h; q.ldx = io->ldh; q.out = io->qkv; q.ldc = io->ldqkv; q.act = CRAB_ACT_NONE;

@@ -141,7 +141,7 @@ class _Workspace:
         self.u2 = e(M, max(u_cols, 32))       # router output produced ahead by a fused post-norm epilogue
         # small batches (M * H blocks cannot fill the chip): scratch of the fused RoPE + append + split-context decode attention; its
         # tickets start at zero and the kernel leaves them zero
-        self.attn_ws = ops.attn_decode_rope_workspace(M, H, d, device) if M * H < 256 and d in (64, 128) else None
+        self.attn_ws = ops.attn_decode_rope_workspace(M, H, d, device) if M * H < ops.ATTN_SPLIT_BELOW and d in (64, 128) else None
 
 
 class GenerationEngine:
@@ -387,7 +387,7 @@ class GenerationEngine:
             return x, h
         u_qkv = None                                   # router output for the q|k|v group when a producer epilogue made it
         # small batch: the projection leaves its raw row, ONE launch does RoPE + KV append + split-context attention (as csrc/llama_layer.hip)
-        fuse_attn = (vt is None and S == 1 and not masked and ws.attn_ws is not None and B * H < 256 and kc.is_contiguous() and
+        fuse_attn = (vt is None and S == 1 and not masked and ws.attn_ws is not None and B * H < ops.ATTN_SPLIT_BELOW and kc.is_contiguous() and
                      ws.attn_ws.numel() >= ops.attn_decode_rope_bytes(B, H, d))
         for li, layer in enumerate(layers):
             a, m = layer.self_attn, layer.mlp

@@ -309,6 +309,9 @@ def attn_decode(q, k_cache, v_cache, o, B, H, Hk, head_dim, Tmax, ctx_len, scale
     return o
 
 
+ATTN_SPLIT_BELOW = 256           # CRAB_ATTN_SPLIT_BELOW of include/crab_hip.h
+
+
 def attn_decode_rope_bytes(B: int, H: int, d: int) -> int:
     return int(_lib.load().crab_attn_decode_rope_workspace(B, H, d))
 

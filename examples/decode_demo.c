@@ -156,7 +156,7 @@ int main(int argc, char** argv) {
     /* ---- decode: one row per sequence; position and step live in device memory, so the step can be captured once and replayed */
     io.S = 1; io.vt = NULL; io.vt_ld = 0; io.pos_dev = pos_dev;
     head.A = io.h;                                         /* h after the stack = model.norm(x): exactly the B rows lm_head needs */
-    if ((long)B * H < 256) {
+    if ((long)B * H < CRAB_ATTN_SPLIT_BELOW) {
         /* a small batch cannot fill the chip with one attention block per head: hand crab_llama_layers the scratch of the fused
          * RoPE + KV append + split-context attention (crab_attn_decode_rope); its tickets are zeroed ONCE, the kernel leaves them zero */
         io.attn_ws_bytes = crab_attn_decode_rope_workspace(B, H, d);

@@ -191,9 +191,10 @@ int crab_attn_decode_masked(crab_ctx* ctx, void* stream, const void* q, int64_t 
  * (qkv [B, ldqkv]: H query heads, Hk key heads, Hk value heads of d elements, as the projection left them, bias and adapter included).
  * pos = pos0 + pos_dev[0] (pos_dev may be NULL).  q / k are rounded to bf16 after the rotation like crab_qkv_rope_split stores
  * them (the appended cache rows are bit-identical to that pair's; o agrees up to the softmax accumulation order); qkv itself is not modified.  The context is split over up
- * to 8 blocks per (b, h) when B * H < 256, merged by the last split to finish (deterministic).  workspace:
+ * to 8 blocks per (b, h) when B * H < CRAB_ATTN_SPLIT_BELOW, merged by the last split to finish (deterministic).  workspace:
  * crab_attn_decode_rope_workspace(B, H, d) bytes whose LAST B * H * 4 bytes (the tickets) the caller zero-fills once; the call
- * leaves them zero.  May be NULL when B * H >= 256. */
+ * leaves them zero.  May be NULL when B * H >= CRAB_ATTN_SPLIT_BELOW. */
+#define CRAB_ATTN_SPLIT_BELOW 256    /* crab_attn_decode_rope splits the context while B * H is below this many blocks (one per CU) */
 int64_t crab_attn_decode_rope_workspace(int B, int H, int d);
 int crab_attn_decode_rope(crab_ctx* ctx, void* stream, const void* qkv, int64_t ldqkv, const float* rope_tab, void* k_cache,
                           void* v_cache, void* o, int64_t ldo, int B, int H, int Hk, int d, int Tmax, int pos0,
@@ -293,7 +294,7 @@ typedef struct {
     int32_t B, S, Tmax, pos0;
     int32_t u_qkv_ready;
     /* optional, decode only: crab_attn_decode_rope_workspace(B, H, d) bytes whose tickets (the last B * H * 4 bytes) the caller zero-filled
-     * once.  When given and B * H < 256 (a small batch cannot fill the chip with one block per head) the q|k|v projection leaves its raw
+     * once.  When given and B * H < CRAB_ATTN_SPLIT_BELOW (few blocks per head cannot hide the KV stream's latency) the q|k|v projection leaves its raw
      * row and crab_attn_decode_rope does RoPE + KV append + split-context attention in one launch. */
     void* attn_ws; int64_t attn_ws_bytes;
 } crab_llama_io;
