@@ -52,6 +52,38 @@ class AttnDesc(C.Structure):
     ]
 
 
+class Dense(C.Structure):
+    """crab_dense"""
+    _fields_ = [("W", C.c_void_p), ("bias", C.c_void_p), ("ldw", C.c_int64), ("N", C.c_int32), ("K", C.c_int32)]
+
+
+class LN(C.Structure):
+    """crab_ln"""
+    _fields_ = [("w", C.c_void_p), ("b", C.c_void_p), ("eps", C.c_float)]
+
+
+class ClipLayerW(C.Structure):
+    _fields_ = [("ln1", LN), ("ln2", LN), ("qkv", Dense), ("out", Dense), ("fc1", Dense), ("fc2", Dense), ("H", C.c_int32)]
+
+
+class BeatsLayerW(C.Structure):
+    _fields_ = [("qkv", Dense), ("out", Dense), ("fc1", Dense), ("fc2", Dense), ("ln_attn", LN), ("ln_final", LN),
+                ("grep_w", C.c_void_p), ("grep_b", C.c_void_p), ("grep_a", C.c_void_p), ("H", C.c_int32), ("alpha", C.c_float)]
+
+
+class QformerLayerW(C.Structure):
+    _fields_ = [("sq", Dense), ("skv", Dense), ("so", Dense), ("sln", LN), ("cq", Dense), ("ckv", Dense), ("co", Dense), ("cln", LN),
+                ("iq", Dense), ("oq", Dense), ("oln", LN), ("H", C.c_int32)]
+
+
+class EncIO(C.Structure):
+    """crab_enc_io"""
+    _fields_ = [("x", C.c_void_p), ("a", C.c_void_p), ("y", C.c_void_p), ("qkv", C.c_void_p), ("att", C.c_void_p), ("f", C.c_void_p),
+                ("vt", C.c_void_p), ("vt_bytes", C.c_int64), ("enc", C.c_void_p), ("enc_rows", C.c_int32),
+                ("bias", C.c_void_p), ("gate", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
+                ("B", C.c_int32), ("S", C.c_int32)]
+
+
 class LinearGroup(C.Structure):
     """crab_linear_group"""
     _fields_ = [
@@ -93,6 +125,13 @@ SYMBOLS = {
     "crab_sizeof_attn_desc": (_i, []),
     "crab_sizeof_llama_layer": (_i, []),
     "crab_sizeof_llama_io": (_i, []),
+    "crab_clip_layer": (_i, [_vp, _vp, C.POINTER(ClipLayerW), C.POINTER(EncIO)]),
+    "crab_beats_layer": (_i, [_vp, _vp, C.POINTER(BeatsLayerW), C.POINTER(EncIO)]),
+    "crab_qformer_layer": (_i, [_vp, _vp, C.POINTER(QformerLayerW), C.POINTER(EncIO)]),
+    "crab_sizeof_enc_io": (_i, []),
+    "crab_sizeof_clip_layer_w": (_i, []),
+    "crab_sizeof_beats_layer_w": (_i, []),
+    "crab_sizeof_qformer_layer_w": (_i, []),
     "crab_llama_layer_prefill": (_i, [_vp, _vp, C.POINTER(LlamaLayer), C.POINTER(LlamaIO), _i]),
     "crab_llama_layer_decode": (_i, [_vp, _vp, C.POINTER(LlamaLayer), C.POINTER(LlamaIO), _i]),
     "crab_llama_layers": (_i, [_vp, _vp, C.POINTER(LlamaLayer), _i, C.POINTER(LlamaIO)]),

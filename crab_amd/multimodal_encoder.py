@@ -23,11 +23,46 @@ from typing import Dict, List, Optional, Sequence
 import torch
 from torch import nn
 
-from . import ops
+from . import _lib, ops
 from ._lib import GemmDesc
 from .peft_hyper import PackedLinearGroup
 
 BF16 = torch.bfloat16
+NATIVE_ENC_LAYERS = True      # False: issue every launch of an encoder layer from Python (sequencer-equivalence tests, A/B runs)
+
+
+def _dense(lin) -> "_lib.Dense":
+    """crab_dense over an nn.Linear-like holder (LinearP) or a bias-carrying PackedLinearGroup without adapter."""
+    d = _lib.Dense()
+    W = lin.W if isinstance(lin, PackedLinearGroup) else lin.weight
+    d.W, d.ldw, d.N, d.K = W.data_ptr(), W.stride(0), W.shape[0], W.shape[1]
+    d.bias = lin.bias.data_ptr() if lin.bias is not None else None
+    return d
+
+
+def _ln(ln) -> "_lib.LN":
+    r = _lib.LN()
+    r.w, r.b, r.eps = ln.weight.data_ptr(), ln.bias.data_ptr(), ln.eps
+    return r
+
+
+class _EncScratch:
+    """Caller-owned rows of crab_enc_io for M tokens of `width`, an FFN of `ffn`, qkv rows of `qkv_rows` x `qkv_cols`, V^T of `vt_elems`."""
+
+    def __init__(self, M, width, ffn, qkv_rows, qkv_cols, vt_elems, device):
+        e = lambda *s_: torch.empty(s_, device=device, dtype=BF16)
+        self.a, self.y, self.att, self.f = e(M, width), e(M, width), e(M, width), e(M, ffn)
+        self.qkv = e(qkv_rows, qkv_cols)
+        self.vt = torch.zeros((vt_elems,), device=device, dtype=BF16)
+
+    def io(self, x, B, S) -> "_lib.EncIO":
+        io = _lib.EncIO()
+        io.x, io.a, io.y, io.qkv, io.att, io.f = (t.data_ptr() for t in (x, self.a, self.y, self.qkv, self.att, self.f))
+        io.vt, io.vt_bytes = self.vt.data_ptr(), self.vt.numel() * 2
+        ws = ops._splitk_workspace(x.device)
+        io.workspace, io.workspace_bytes = ws.data_ptr(), ws.numel()
+        io.B, io.S = B, S
+        return io
 
 
 def _p(t, device, *shape, fill=0.0):
@@ -174,6 +209,21 @@ class CLIPVisionModel(nn.Module):
         keep = set(range(upto + 1)) if keep is None else set(keep)
         hs = {0: h.view(N, T, D)} if 0 in keep else {}
         M = N * T
+        if NATIVE_ENC_LAYERS:
+            # one C call per layer (crab_clip_layer, csrc/encoder_layers.hip): the launches below, in the same order, x updated in place
+            sc = _EncScratch(M, D, c["intermediate_size"], M, 3 * D, N * D * ((T + 7) // 8 * 8), h.device)
+            if 0 in hs and upto > 0:
+                hs[0] = h.clone().view(N, T, D)                # h is updated in place from here on
+            io = sc.io(h, N, T)
+            for i in range(upto):
+                L = vm.encoder.layers[i]
+                w = _lib.ClipLayerW()
+                w.ln1, w.ln2, w.qkv, w.out = _ln(L.layer_norm1), _ln(L.layer_norm2), _dense(L.self_attn._qkv), _dense(L.self_attn.out_proj)
+                w.fc1, w.fc2, w.H = _dense(L.mlp.fc1), _dense(L.mlp.fc2), Hh
+                ops.enc_layer("clip", w, io, h.device)
+                if i + 1 in keep:
+                    hs[i + 1] = h.clone().view(N, T, D) if i + 1 < upto else h.view(N, T, D)
+            return hs
         a = torch.empty((M, D), device=h.device, dtype=BF16)
         qkv = torch.empty((M, 3 * D), device=h.device, dtype=BF16)
         att = torch.empty((M, D), device=h.device, dtype=BF16)
@@ -337,6 +387,21 @@ class BertModel(nn.Module):
             ops.copy_rows_batched(z0, h, 0, z, h, nq * h, B, nq, h)                  # broadcast the query tokens
         else:
             z = z0
+        if NATIVE_ENC_LAYERS:
+            # one C call per layer (crab_qformer_layer): self-attention, cross-attention to `enc`, query FFN; z updated in place
+            i_ = self.encoder.layer[0].intermediate_query.dense.weight.shape[0]
+            rows = max(B * nq, B * m)
+            sc = _EncScratch(B * nq, h, i_, rows, 2 * h, B * h * ((max(nq, m) + 7) // 8 * 8), dev)
+            io = sc.io(z, B, nq)
+            io.enc, io.enc_rows = enc.data_ptr(), m
+            for L in self.encoder.layer:
+                sa, ca = getattr(L.attention, "self"), getattr(L.crossattention, "self")
+                w = _lib.QformerLayerW()
+                w.sq, w.skv, w.so, w.sln = _dense(sa.query), _dense(sa._kv), _dense(L.attention.output.dense), _ln(L.attention.output.LayerNorm)
+                w.cq, w.ckv, w.co, w.cln = _dense(ca.query), _dense(ca._kv), _dense(L.crossattention.output.dense), _ln(L.crossattention.output.LayerNorm)
+                w.iq, w.oq, w.oln, w.H = _dense(L.intermediate_query.dense), _dense(L.output_query.dense), _ln(L.output_query.LayerNorm), H
+                ops.enc_layer("qformer", w, io, dev)
+            return z
         att = torch.empty((B * nq, h), device=dev, dtype=BF16)
         scale = 1.0 / math.sqrt(d)
         for L in self.encoder.layer:
@@ -561,6 +626,22 @@ class BEATs(nn.Module):
         alpha = math.pow(2 * c.encoder_layers, 0.25) if c.deep_norm else 1.0
         table = enc.layers[0].self_attn.relative_attention_bias.weight
         bias = ops.beats_relpos_bias(table, n, H, c.num_buckets, c.max_distance)        # once per forward (:131-137)
+        if NATIVE_ENC_LAYERS:
+            # one C call per layer (crab_beats_layer): gated relative-position attention + FFN, post-LN deep-norm; x updated in place
+            sc = _EncScratch(B * n, E, c.encoder_ffn_embed_dim, B * n, 3 * E, B * E * ((n + 7) // 8 * 8), dev)
+            io = sc.io(x, B, n)
+            gate = torch.empty((B, H, n), device=dev, dtype=torch.float32)
+            io.bias, io.gate = bias.data_ptr(), gate.data_ptr()
+            for L_ in enc.layers:
+                a = L_.self_attn
+                w = _lib.BeatsLayerW()
+                w.qkv, w.out, w.fc1, w.fc2 = _dense(a._qkv), _dense(a.out_proj), _dense(L_.fc1), _dense(L_.fc2)
+                w.ln_attn, w.ln_final, w.H, w.alpha = _ln(L_.self_attn_layer_norm), _ln(L_.final_layer_norm), H, alpha
+                if c.gru_rel_pos:
+                    ga = a.grep_a.reshape(-1)
+                    w.grep_w, w.grep_b, w.grep_a = a.grep_linear.weight.data_ptr(), a.grep_linear.bias.data_ptr(), ga.data_ptr()
+                ops.enc_layer("beats", w, io, dev)
+            return x.view(B, n, E), padding_mask
         att = torch.empty((B * n, E), device=dev, dtype=BF16)
         for L_ in enc.layers:
             a = L_.self_attn

@@ -330,6 +330,13 @@ def attn_decode_rope(qkv, rope_tab, k_cache, v_cache, o, B, H, Hk, head_dim, Tma
     return o
 
 
+def enc_layer(kind: str, w, io, device):
+    """crab_clip_layer / crab_beats_layer / crab_qformer_layer: one encoder layer's launch sequence in one call."""
+    d = device.index or 0
+    fn = getattr(_lib.load(), f"crab_{kind}_layer")
+    _lib.check(fn(_lib.ctx(d), _stream(), C.byref(w), C.byref(io)), d)
+
+
 def llama_layers(table, n_layers: int, io, device):
     """crab_llama_layers: every layer of a decoder stack (prefill when io.vt is set, one decode step otherwise) in one call."""
     d = device.index or 0

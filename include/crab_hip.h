@@ -307,6 +307,41 @@ int crab_llama_layer_decode(crab_ctx* ctx, void* stream, const crab_llama_layer*
 int crab_llama_layers(crab_ctx* ctx, void* stream, const crab_llama_layer* layers, int n_layers, crab_llama_io* io);
 
 /* ---------------------------------------------------------------------------------------------
+ * Fused encoder blocks: the launch sequence of ONE encoder layer behind one call, so that a C caller runs a whole clip
+ * (examples/clip_demo.c) without re-implementing the sequencing of crab_amd/multimodal_encoder.py.  Like crab_llama_layers they only
+ * issue launches of the entry points above on `stream` and keep no state.
+ *   crab_clip_layer    HF CLIPEncoderLayer as the reference drives it (models/multimodal_encoder.py:52-84; pre-LN, quick-GELU MLP,
+ *                      q|k|v packed as one [3D, D] matrix with bias)
+ *   crab_beats_layer   models/beats/backbone.py:214-275 (post-LN deep-norm: x = LN(alpha x + sublayer)); attention :432-684 with the gated
+ *                      relative position bias: io->bias [H, S, S] fp32 from crab_beats_relpos_bias (once per forward, :131-137),
+ *                      io->gate [B, H, S] fp32 scratch for crab_beats_gru_gate; grep_w == NULL: no gate
+ *   crab_qformer_layer models/Qformer.py:404-476 with cross_attention_freq = 1 and the query FFN (:483-486): x = the B * S query rows,
+ *                      io->enc = the B * enc_rows encoder rows (already layer-normed by the projector, multimodal_encoder.py:119-144, 226-244)
+ * crab_dense = one nn.Linear (W [N, K] row stride ldw, bias [N] or NULL); crab_ln = LayerNorm weight / bias / eps.
+ * crab_enc_io: caller-owned rows for M = B * S tokens.  x [M, width] in / out (dense rows); a [M, width], y [M, width] scratch;
+ *   qkv [max(M, B * enc_rows), 3 * width (2 * width for the Q-Former)]; att [M, width]; f [M, ffn width];
+ *   vt: V^T scratch of vt_bytes >= B * H * d * round8(keys) * 2; workspace: the crab_gemm_desc.workspace handed to every GEMM with <= 256 rows. */
+typedef struct { const void* W; const void* bias; int64_t ldw; int32_t N, K; } crab_dense;
+typedef struct { const void* w; const void* b; float eps; } crab_ln;
+typedef struct { crab_ln ln1, ln2; crab_dense qkv, out, fc1, fc2; int32_t H; } crab_clip_layer_w;
+typedef struct { crab_dense qkv, out, fc1, fc2; crab_ln ln_attn, ln_final; const void* grep_w; const void* grep_b; const void* grep_a; int32_t H; float alpha; } crab_beats_layer_w;
+typedef struct { crab_dense sq, skv, so; crab_ln sln; crab_dense cq, ckv, co; crab_ln cln; crab_dense iq, oq; crab_ln oln; int32_t H; } crab_qformer_layer_w;
+typedef struct {
+    void* x; void* a; void* y; void* qkv; void* att; void* f; void* vt; int64_t vt_bytes;
+    const void* enc; int32_t enc_rows;              /* Q-Former only */
+    const float* bias; float* gate;                 /* BEATs only */
+    void* workspace; int64_t workspace_bytes;
+    int32_t B, S;
+} crab_enc_io;
+int crab_clip_layer(crab_ctx* ctx, void* stream, const crab_clip_layer_w* w, crab_enc_io* io);
+int crab_beats_layer(crab_ctx* ctx, void* stream, const crab_beats_layer_w* w, crab_enc_io* io);
+int crab_qformer_layer(crab_ctx* ctx, void* stream, const crab_qformer_layer_w* w, crab_enc_io* io);
+int crab_sizeof_enc_io(void);
+int crab_sizeof_clip_layer_w(void);
+int crab_sizeof_beats_layer_w(void);
+int crab_sizeof_qformer_layer_w(void);
+
+/* ---------------------------------------------------------------------------------------------
  * SegModule pixel path (models/multimodal_encoder.py:268-543, 891-1444).  Feature maps are token-major [h*w, C] bf16.
  *  im2col3x3       : Conv2d(k=3,pad=1) operand, out[(b,y,x), (ky*3+kx)*C + c]                      (image_feature_neck :316-332)
  *  pixel_shuffle2x : ConvTranspose2d(k=2,s=2) after its GEMM: g[h*w, (dy,dx,co)] -> out[(2h)(2w), Co] + bias  (:937-949)

@@ -49,6 +49,10 @@ def test_struct_mirrors_match_the_compiled_layout():
     assert C.sizeof(_lib.AttnDesc) == lib.crab_sizeof_attn_desc()
     assert C.sizeof(_lib.LlamaLayer) == lib.crab_sizeof_llama_layer()
     assert C.sizeof(_lib.LlamaIO) == lib.crab_sizeof_llama_io()
+    assert C.sizeof(_lib.EncIO) == lib.crab_sizeof_enc_io()
+    assert C.sizeof(_lib.ClipLayerW) == lib.crab_sizeof_clip_layer_w()
+    assert C.sizeof(_lib.BeatsLayerW) == lib.crab_sizeof_beats_layer_w()
+    assert C.sizeof(_lib.QformerLayerW) == lib.crab_sizeof_qformer_layer_w()
 
 
 def test_entry_points_reject_null_context_and_operands_without_a_gpu():
@@ -62,6 +66,10 @@ def test_entry_points_reject_null_context_and_operands_without_a_gpu():
     assert lib.crab_llama_layers(None, None, C.byref(layer), 1, C.byref(io)) < 0
     assert lib.crab_llama_layer_prefill(None, None, C.byref(layer), C.byref(io), 0) < 0
     assert lib.crab_llama_layer_decode(None, None, C.byref(layer), C.byref(io), 0) < 0
+    eio = _lib.EncIO()
+    assert lib.crab_clip_layer(None, None, C.byref(_lib.ClipLayerW()), C.byref(eio)) < 0
+    assert lib.crab_beats_layer(None, None, C.byref(_lib.BeatsLayerW()), C.byref(eio)) < 0
+    assert lib.crab_qformer_layer(None, None, C.byref(_lib.QformerLayerW()), C.byref(eio)) < 0
     assert lib.crab_bicubic_ksize(0, 10) < 0 and lib.crab_bicubic_ksize(480, 224) == 2 * 5 + 1
     assert lib.crab_kaldi_fbank_frames(16000) == 98
     assert lib.crab_hyperlora_route_workspace(256, 4096, 48) > 0 and lib.crab_groupnorm_workspace(2, 65536, 32) > 0

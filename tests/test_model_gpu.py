@@ -86,6 +86,42 @@ def test_projectors_vs_reference_fixture():
     assert _rel(al(A["afeat"].to(BF).cuda()), A["aout"], "ALProjector vs fp32 reference") < REL_ENC
 
 
+def test_native_encoder_layer_sequencers_equal_python_sequences():
+    """crab_clip_layer / crab_beats_layer / crab_qformer_layer (csrc/encoder_layers.hip) against the per-launch Python sequences of
+    crab_amd/multimodal_encoder.py on the tiny fixtures: CLIP hidden states at the three selected levels, BEATs features (L = 98 and
+    198), both projectors - bit-identical (same launches in the same order)."""
+    from crab_amd import multimodal_encoder as ME, ops, synth
+    meta, A = load_fixture("clip_tiny")
+    W = weights_from_table(meta)
+    ve = ME.VisualEncoder(select_layer_list=meta["select"], config=meta["cfg"], device="cuda")
+    ve.load_state_dict({k[len("model.visual_encoder."):]: v for k, v in W.items()}, strict=False)
+    video = ops.cast_bf16(synth.synth_video(meta["t_v"], seed=meta["seed"], clip=meta["clip"])[None].cuda())
+    meta_b, Ab = load_fixture("beats_tiny")
+    ae = ME.AudioEncoder(cfg=meta_b["cfg"], device="cuda")
+    ae.load_state_dict({k[len("model.audio_encoder."):]: v for k, v in weights_from_table(meta_b).items()}, strict=False)
+    meta_p, Ap = load_fixture("projectors_tiny")
+    Wp = weights_from_table(meta_p)
+    bc = bert_cfg(meta_p["qf"])
+    vl = ME.VLProjector(hidden_size=128, image_token_nums=256, num_query_token=32, num_hidden_layers=2, d_model=meta_p["d_model"], depth=2,
+                        bert_config=bc, device="cuda")
+    vl.load_state_dict({k[len("model.vl_projector."):]: v for k, v in Wp.items() if k.startswith("model.vl_projector.")}, strict=False)
+    al = ME.ALProjector(hidden_size=128, num_query_token=32, num_hidden_layers=2, d_model=meta_p["d_model"], depth=2, bert_config=bc, device="cuda")
+    al.load_state_dict({k[len("model.al_projector."):]: v for k, v in Wp.items() if k.startswith("model.al_projector.")}, strict=False)
+    outs = []
+    for native in (True, False):
+        ME.NATIVE_ENC_LAYERS = native
+        try:
+            r = [f.clone() for f in ve(video)]
+            r += [ae(ops.cast_bf16(Ab[f"x{L}"].cuda())).clone() for L in (98, 198)]
+            r += [vl(Ap["vfeat"].to(BF).cuda()).clone(), al(Ap["afeat"].to(BF).cuda()).clone()]
+            outs.append(r)
+        finally:
+            ME.NATIVE_ENC_LAYERS = True
+    assert len(outs[0]) == len(outs[1]) == 7
+    for a_, b_ in zip(*outs):
+        assert torch.equal(a_, b_)
+
+
 def _inputs(meta):
     from crab_amd import synth
     p = meta["prompts"]
