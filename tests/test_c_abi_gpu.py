@@ -66,3 +66,109 @@ def test_c_caller_matches_python_engine(tmp_path, qwen):
         assert np.array_equal(ids, ref_ids), (use_graph, ids, ref_ids)
         assert np.array_equal(logits, ref_logits), (use_graph, np.abs(logits - ref_logits).max())
     assert len(set(ref_ids.reshape(-1).tolist())) > 1                    # not a degenerate constant output
+
+
+def _build(tmp_path, name, extra=()):
+    exe = str(tmp_path / name)
+    cmd = ["gcc", "-O1", "-std=c99", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include",
+           os.path.join(ROOT, "examples", name + ".c"), "-o", exe, "-L" + os.path.join(ROOT, "crab_amd"), "-lcrab_hip", "-L/opt/rocm/lib",
+           "-lamdhip64", "-lm", "-Wl,-rpath," + os.path.join(ROOT, "crab_amd"), "-Wl,-rpath,/opt/rocm/lib"] + list(extra)
+    subprocess.check_call(cmd)
+    return exe
+
+
+def test_c_caller_runs_a_whole_clip(tmp_path):
+    """examples/clip_demo.c: CLIP tower -> VLProjector, BEATs -> ALProjector (crab_clip_layer / crab_beats_layer / crab_qformer_layer), the
+    splice of prepare_multimodal_inputs, decoder prefill + greedy decode (crab_llama_layers), all from C on the weights of the tiny Crab of
+    the reference-recorded fixture: its inputs_embeds, ids and per-step logits equal the Python modules' bit for bit, and its ids equal
+    the ids the REFERENCE generated for this clip (full_tiny_llama.npz)."""
+    from crab_amd import synth
+    from tests.util import build_tiny_crab, load_fixture, weights_from_table
+    meta, A = load_fixture("full_tiny_llama")
+    model = build_tiny_crab(meta)
+    model.load_state_dict(weights_from_table(meta), strict=False)
+    um = model.base_model.model
+    inner = um.model
+    p = meta["prompts"]
+    ids0 = A["ids0"]
+    mods = {'<video>': synth.synth_video(p["t_v"], seed=meta["seed"], clip=p["clip0"]),
+            '<audio>': synth.synth_audio(p["t_a"], p["l_a"], seed=meta["seed"], clip=p["clip0"])}
+    n_new = meta["new_tokens"]
+    inp = model.prepare_multimodal_inputs([ids0], [torch.full_like(ids0, -100)], [mods], ['avqa'])
+    emb_ref = inp["inputs_embeds"]
+    ref_ids, ref_logits = um._engine.generate(emb_ref, n_new, eos_token_id=None, pad_token_id=2, return_step_logits=True, use_graph=False)
+    S = emb_ref.shape[1]
+
+    def dense(m):
+        W = m.W if hasattr(m, "W") else m.weight
+        return [_raw(W), _raw(m.bias)]
+
+    def ln(m):
+        return [_raw(m.weight), _raw(m.bias)]
+
+    def qformer(bert, query, enc_ln, mlp):
+        out = ln(enc_ln) + ln(bert.embeddings.LayerNorm) + [_raw(query[0])]
+        for L in bert.encoder.layer:
+            sa, ca = getattr(L.attention, "self"), getattr(L.crossattention, "self")
+            out += dense(sa.query) + dense(sa._kv) + dense(L.attention.output.dense) + ln(L.attention.output.LayerNorm)
+            out += dense(ca.query) + dense(ca._kv) + dense(L.crossattention.output.dense) + ln(L.crossattention.output.LayerNorm)
+            out += dense(L.intermediate_query.dense) + dense(L.output_query.dense) + ln(L.output_query.LayerNorm)
+        return out + dense(mlp[0]) + dense(mlp[2])
+
+    cc, bc, qc, dc = meta["clip"], meta["beats"], meta["qf"], meta["dec"]
+    Lc = max(meta["select"])
+    sp = model.SPECIAL_TOKEN_2_IDS
+    lc = __import__("crab_amd.peft_hyper", fromlist=["LoraConfig"]).LoraConfig()
+    cfg = [dc["hidden_size"], dc["intermediate_size"], dc["num_hidden_layers"], dc["num_attention_heads"], dc["num_key_value_heads"],
+           um.lm_head.weight.shape[0], lc.lora_nums, lc.r, n_new, 0,
+           cc["hidden_size"], cc["intermediate_size"], Lc, cc["num_attention_heads"], cc["image_size"], cc["patch_size"],
+           bc["embed_dim"], bc["encoder_embed_dim"], bc["encoder_ffn_embed_dim"], bc["encoder_layers"], bc["encoder_attention_heads"],
+           bc["input_patch_size"], bc["conv_pos"], bc["conv_pos_groups"], bc["num_buckets"], bc["max_distance"], 128,
+           qc["hidden"], qc["heads"], qc["inter"], 2, 32,
+           p["t_v"], p["t_a"], p["l_a"], int(ids0.numel()), sp["<video>"], sp["<audio>"]]
+    blob = [np.asarray(cfg, dtype=np.int32).tobytes(), mods['<video>'].float().contiguous().numpy().tobytes(),
+            mods['<audio>'].float().contiguous().numpy().tobytes(), ids0.to(torch.int64).numpy().tobytes()]
+    vt = inner.visual_encoder.vision_tower
+    vm = vt.vision_model
+    blob += [_raw(vt._patch_weight()), _raw(vm.embeddings.class_embedding), _raw(vm.embeddings.position_embedding.weight)] + ln(vm.pre_layrnorm)
+    for L in vm.encoder.layers[:Lc]:
+        blob += ln(L.layer_norm1) + dense(L.self_attn._qkv) + dense(L.self_attn.out_proj) + ln(L.layer_norm2) + dense(L.mlp.fc1) + dense(L.mlp.fc2)
+    vl = inner.vl_projector
+    blob += qformer(vl.visual_Qformer.bert, vl.visual_query_tokens, vl.visual_ln, vl.visual_proj)
+    be = inner.audio_encoder.audio_encoder
+    P_b = bc["input_patch_size"]
+    blob += [_raw(be.patch_embedding.weight.reshape(bc["embed_dim"], P_b * P_b))] + ln(be.layer_norm) + dense(be.post_extract_proj)
+    blob += [_raw(be._posconv_weight()), _raw(be.encoder.pos_conv[0].bias)] + ln(be.encoder.layer_norm)
+    blob += [_raw(be.encoder.layers[0].self_attn.relative_attention_bias.weight)]
+    for L in be.encoder.layers:
+        a = L.self_attn
+        blob += dense(a._qkv) + dense(a.out_proj) + dense(L.fc1) + dense(L.fc2) + ln(L.self_attn_layer_norm) + ln(L.final_layer_norm)
+        blob += [_raw(a.grep_linear.weight), _raw(a.grep_linear.bias), _raw(a.grep_a.reshape(-1))]
+    al = inner.al_projector
+    blob += qformer(al.audio_Qformer.bert, al.audio_query_tokens, al.audio_ln, al.audio_proj)
+    blob += [_raw(um.model.embed_tokens.weight)]
+    for layer in um.model.layers:
+        for g in layer.groups():
+            blob.append(_raw(g.W))
+            if g.bias is not None:
+                blob.append(_raw(g.bias))
+            blob += [_raw(g.RA), _raw(g.B2)]
+        blob += [_raw(layer.input_layernorm.weight), _raw(layer.post_attention_layernorm.weight)]
+    blob += [_raw(um.model.norm.weight), _raw(um.lm_head.weight), _raw(um.model.embed_tokens.weight)]
+    bpath, exe = str(tmp_path / "clip.bin"), _build(tmp_path, "clip_demo")
+    with open(bpath, "wb") as f:
+        f.write(b"".join(blob))
+    V = um.lm_head.weight.shape[0]
+    ref_ids_np, ref_logits_np = ref_ids.cpu().numpy(), ref_logits.float().cpu().numpy()
+    for use_graph in (0, 1):
+        opath, epath = str(tmp_path / f"out{use_graph}.bin"), str(tmp_path / f"emb{use_graph}.bin")
+        r = subprocess.run([exe, bpath, opath, epath, str(use_graph)], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (r.stdout, r.stderr)
+        emb = torch.from_numpy(np.frombuffer(open(epath, "rb").read(), dtype=np.int16).copy()).view(BF).view(S, -1)
+        assert torch.equal(emb, emb_ref[0].cpu()), float((emb.float() - emb_ref[0].cpu().float()).abs().max())
+        raw = open(opath, "rb").read()
+        ids = np.frombuffer(raw[:n_new * 8], dtype=np.int64).reshape(1, n_new)
+        logits = np.frombuffer(raw[n_new * 8:], dtype=np.float32).reshape(n_new, 1, V).transpose(1, 0, 2)
+        assert np.array_equal(ids, ref_ids_np), (use_graph, ids, ref_ids_np)
+        assert np.array_equal(logits, ref_logits_np), (use_graph, np.abs(logits - ref_logits_np).max())
+    assert np.array_equal(ref_ids_np, A["ids_bs1"].numpy()), "the C-run clip does not reproduce the ids the reference recorded"
