@@ -196,8 +196,17 @@ def operating_points(model, um, args, eos):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         assert tuple(r.shape) == (B, args.new_tokens)
-        out[name] = {"clips_per_batch": B, "frames": frames, "fbank_frames_per_window": l_a, "prefill_len": 126 + 32 * frames + 320,
+        S_ = 126 + 32 * frames + 320
+        out[name] = {"clips_per_batch": B, "frames": frames, "fbank_frames_per_window": l_a, "prefill_len": S_,
                      "clips_per_s": round(B / dt, 3), "ms_per_batch": round(dt * 1e3, 1), "note": note}
+        if B <= 16:
+            # small batches are weight-streaming bound: HBM floor of the whole call = every decode step reads the decoder + lm_head + adapter
+            # weights once and the live KV rows of its B clips (SURVEY 8d "algorithmic bytes per clip, decode"); prefill is <2 % of it
+            steps = args.new_tokens - 1
+            algo = sum(decode_bytes_per_step(B, S_ + t + 1, V=um.lm_head.weight.shape[0]) for t in range(steps))
+            out[name]["hbm"] = {"bound": "hbm", "algorithmic_bytes": int(algo), "achieved_GBps": round(algo / dt / 1e9, 1), "peak_GBps": HBM_PEAK_GBS,
+                                "frac": round(algo / dt / 1e9 / HBM_PEAK_GBS, 4), "ms_per_token": round(dt * 1e3 / args.new_tokens, 3),
+                                "note": "whole generate() call (encoders + prefill included in the time, not in the bytes)"}
 
     run("single_clip", 1, args.frames, 98, "scripts/quick_start.py: one clip per generate() (BASELINE configs[0] shape on the GPU); latency = ms_per_batch")
     run("eval_batch_8", 8, args.frames, 98, "the reference's eval batch size; per-batch latency = ms_per_batch")
