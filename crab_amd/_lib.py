@@ -167,6 +167,7 @@ SYMBOLS = {
     "crab_copy_rows_batched": (_i, [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _i64, _i, _i, _i]),
     "crab_greedy_select": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _i64, _vp, _vp, _i, _i, _i]),
     "crab_advance": (_i, [_vp, _vp, _vp, _vp]),
+    "crab_sample_select": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _i64, _vp, _vp, _i, _i, _i, _f, _i, _f, C.c_uint64]),
     "crab_im2col3x3": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i]),
     "crab_pixel_shuffle2x": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i]),
     "crab_bilinear": (_i, [_vp, _vp, _vp, _i, _i64, _i64, _i64, _i, _i, _i, _vp, _i, _i, _f, _f]),

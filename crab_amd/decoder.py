@@ -464,11 +464,20 @@ class GenerationEngine:
         ops.gemm(hfin, self.lm_head.weight, out=st.logits)
         if st.want_hidden:
             ops.copy_rows(hfin, st.hn, B, hfin.shape[1])
-        ops.greedy_select(st.logits, st.cur_ids, st.out_ids, st.step_dev, st.finished, st.eos, st.pad, st.min_new)
+        self._select(st)
         ops.advance(st.pos_dev, st.step_dev)
 
+    def _select(self, st: "_DecodeState"):
+        """Next token of every row from st.logits: greedy (argmax) or, with st.sampling = (temperature, top_k, top_p, seed), HF's sample
+        mode (temperature -> top-k -> top-p -> draw) - both device-resident, so the step stays capturable."""
+        if st.sampling is None:
+            ops.greedy_select(st.logits, st.cur_ids, st.out_ids, st.step_dev, st.finished, st.eos, st.pad, st.min_new)
+        else:
+            t, k, p_, seed = st.sampling
+            ops.sample_select(st.logits, st.cur_ids, st.out_ids, st.step_dev, st.finished, st.eos, st.pad, st.min_new, t, k, p_, seed + 7919 * st.slot)
+
     def _start(self, embeds: torch.Tensor, max_new_tokens: int, eos_token_id, pad_token_id, min_new_tokens: int, prefill_chunk: int,
-               return_hidden: bool, slot: int, sink=None) -> "_DecodeState":
+               return_hidden: bool, slot: int, sink=None, sampling=None) -> "_DecodeState":
         """Allocate the decode state of one group of sequences, prefill it and select its first token."""
         B, S, D = embeds.shape
         dev = self.device
@@ -484,7 +493,7 @@ class GenerationEngine:
         key = (B, Tmax, max_new_tokens, eos, pad, int(min_new_tokens), bool(return_hidden), kc.data_ptr(), vc.data_ptr(), id(ws),
                tab.data_ptr(), self.lm_head.weight.data_ptr(), self.model.embed_tokens.weight.data_ptr(),
                self.model.layers[0].self_attn._qkv.W.data_ptr(),
-               self.model.layers[0].self_attn._qkv.RA is not None)
+               self.model.layers[0].self_attn._qkv.RA is not None, sampling)
         st = self._dec.get(slot)
         if st is None or st.key != key:
             st = _DecodeState()
@@ -498,6 +507,7 @@ class GenerationEngine:
             st.pos_dev = torch.empty((1,), device=dev, dtype=torch.int32)
             st.step_dev = torch.empty((1,), device=dev, dtype=torch.int32)
             st.eos, st.pad, st.min_new, st.want_hidden = eos, pad, int(min_new_tokens), bool(return_hidden)
+            st.sampling = sampling
             self._dec[slot] = st
         st.S = S
         st.cur_ids.zero_(); st.out_ids.fill_(pad_token_id if pad_token_id is not None else 0); st.finished.zero_()
@@ -511,7 +521,7 @@ class GenerationEngine:
             b0 += n
         if sink is not None:
             sink(st)
-        ops.greedy_select(st.logits, st.cur_ids, st.out_ids, st.step_dev, st.finished, st.eos, st.pad, st.min_new)
+        self._select(st)
         ops.advance(st.pos_dev, st.step_dev)           # pos: S-1 -> S (position of the token just selected), step: 0 -> 1
         return st
 
@@ -519,9 +529,12 @@ class GenerationEngine:
     def generate(self, embeds: torch.Tensor, max_new_tokens: int, eos_token_id: Optional[int] = None,
                  pad_token_id: Optional[int] = None, min_new_tokens: int = 0, prefill_chunk: int = 0, use_graph: bool = True,
                  return_step_logits: bool = False, return_hidden: bool = False, decode_streams: int = 1,
-                 return_first_logits: bool = False):
+                 return_first_logits: bool = False, sampling=None):
         """Greedy generation from inputs_embeds only, as UnifiedForCausalLM.generate drives HF generate
         (unified_llama.py:262-267): positions 0..S-1 (left pads attended), returns ONLY new ids.
+
+        sampling = (temperature, top_k, top_p, seed): HF sample mode instead of greedy (what the reference actually runs with a Llama-2-chat
+        checkpoint, whose generation_config sets do_sample); None = greedy.
 
         return_first_logits: also return the fp32 last-row logits of the prefill ([B, V], one clone per call: what the multi-GPU
         eval gathers next to the ids, crab_amd/parallel.py) without keeping every step's logits.
@@ -533,7 +546,7 @@ class GenerationEngine:
         groups = self.plan_batch(B, S, max_new_tokens)
         if len(groups) > 1:
             return self._generate_split(groups, embeds, max_new_tokens, eos_token_id, pad_token_id, min_new_tokens, prefill_chunk, use_graph,
-                                        return_step_logits, return_hidden, return_first_logits)
+                                        return_step_logits, return_hidden, return_first_logits, sampling)
         graphed = use_graph and max_new_tokens > 2
         G = decode_streams if (decode_streams > 1 and graphed and B >= decode_streams and
                                not return_step_logits and not return_hidden) else 1
@@ -553,7 +566,7 @@ class GenerationEngine:
             b0, b1 = B * g // G, B * (g + 1) // G
             ops.WS_SLOT = g
             sts.append(self._start(embeds[b0:b1], max_new_tokens, eos_token_id, pad_token_id, min_new_tokens, prefill_chunk,
-                                   return_hidden, g, sink))
+                                   return_hidden, g, sink, sampling))
         if ops.PROFILER is not None:
             ops.PROFILER.mark("prefill_end")
         # ---- decode loop: HIP graph replay, no host sync inside
@@ -619,7 +632,7 @@ class GenerationEngine:
         return res[0] if len(res) == 1 else tuple(res)
 
     def _generate_split(self, groups, embeds, max_new_tokens, eos_token_id, pad_token_id, min_new_tokens, prefill_chunk, use_graph,
-                        return_step_logits, return_hidden, return_first_logits):
+                        return_step_logits, return_hidden, return_first_logits, sampling=None):
         """The batch does not fit the device's memory in one piece: generate the groups one after the other (rows are independent,
         so the results are those of the one-piece run up to the kernel choice a different M implies) and join them.  A group
         that finished early (EOS) is padded to the longest group's length with pad ids, like HF pads finished rows."""
@@ -635,7 +648,8 @@ class GenerationEngine:
             try:
                 r = self.generate(embeds[b0:b0 + n], max_new_tokens, eos_token_id=eos_token_id, pad_token_id=pad_token_id,
                                   min_new_tokens=min_new_tokens, prefill_chunk=prefill_chunk, use_graph=use_graph,
-                                  return_step_logits=return_step_logits, return_hidden=return_hidden, return_first_logits=return_first_logits)
+                                  return_step_logits=return_step_logits, return_hidden=return_hidden, return_first_logits=return_first_logits,
+                                  sampling=None if sampling is None else (sampling[0], sampling[1], sampling[2], sampling[3] + 104729 * b0))
             finally:
                 self.kv_budget_bytes = saved
             parts.append(r if isinstance(r, tuple) else (r,))

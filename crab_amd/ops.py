@@ -419,6 +419,16 @@ def greedy_select(logits, cur_ids, out_ids, step_dev, finished, eos_id: int, pad
                                               out_ids.stride(0), _p(step_dev), _p(finished), eos_id, pad_id, min_new_tokens), d)
 
 
+def sample_select(logits, cur_ids, out_ids, step_dev, finished, eos_id: int, pad_id: int, min_new_tokens: int, temperature: float, top_k: int,
+                  top_p: float, seed: int):
+    """crab_sample_select: temperature -> top-k -> top-p -> draw (HF sample mode), device-resident like greedy_select."""
+    d = _dev(logits)
+    B, V = logits.shape
+    _lib.check(_lib.load().crab_sample_select(_lib.ctx(d), _stream(), _p(logits), logits.stride(0), B, V, _p(cur_ids), _p(out_ids),
+                                              out_ids.stride(0), _p(step_dev), _p(finished), eos_id, pad_id, min_new_tokens, float(temperature),
+                                              int(top_k), float(top_p), int(seed) & 0xFFFFFFFFFFFFFFFF), d)
+
+
 def advance(pos_dev, step_dev):
     d = _dev(pos_dev)
     _lib.check(_lib.load().crab_advance(_lib.ctx(d), _stream(), _p(pos_dev), _p(step_dev)), d)

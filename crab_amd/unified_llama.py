@@ -3,8 +3,9 @@
 (unified_llama.py:26-391), on the MI355X HIP path.
 
 Differences a caller can observe, all deliberate:
-  * decoding is forced greedy (the reference inherits sampling from the checkpoint's generation_config, A.7);
-    `do_sample=True` raises.
+  * decoding is greedy unless the caller passes `do_sample=True` (the reference inherits sampling from the checkpoint's
+    generation_config, A.7: Llama-2-chat ships temperature 0.6 / top_p 0.9, HF's default top_k 50 - these are the defaults of
+    `do_sample=True` here; draws come from a counter-based generator keyed by `seed`, not from torch's global stream).
   * like the reference's generate(), `attention_mask` / `position_ids` from prepare_multimodal_inputs are NOT forwarded
     to the decoder (unified_llama.py:261-267): left pads are attended and positions run 0..S-1 (A.1) -- reproduced.
     The reference's forward() DOES pass them on (unified_llama.py:129-160, the training-time batch path) and so does
@@ -229,11 +230,10 @@ class UnifiedForCausalLM(nn.Module, UnifiedMetaForCausalLM):
     @torch.no_grad()
     def generate(self, batch_input_ids=None, batch_labels=None, batch_X_modals=None, batch_task_names=None, **kwargs):
         """unified_llama.py:244-267.  kwargs understood (HF names): max_new_tokens, min_new_tokens, eos_token_id,
-        pad_token_id, use_cache, do_sample (must be falsy), output_logits / return_dict_in_generate (parity audits),
+        pad_token_id, use_cache, do_sample (+ temperature, top_k, top_p, seed), output_logits / return_dict_in_generate (parity audits),
         output_first_logits (ids + the fp32 logits of the first generated position, [B, V]: the record the multi-GPU eval gathers),
         inputs_embeds (skip prepare_multimodal_inputs)."""
-        if kwargs.get("do_sample"):
-            raise NotImplementedError("sampling is not implemented: the MI355X path is greedy-only")
+        sampling = self._sampling(kwargs)
         embeds = kwargs.pop("inputs_embeds", None)
         if ops.PROFILER is not None:
             ops.PROFILER.mark("encode_begin")
@@ -252,7 +252,7 @@ class UnifiedForCausalLM(nn.Module, UnifiedMetaForCausalLM):
                                     min_new_tokens=int(kwargs.get("min_new_tokens", 0) or 0),
                                     prefill_chunk=int(kwargs.get("prefill_chunk", 0)), use_graph=kwargs.get("use_graph", True),
                                     return_step_logits=want_logits, decode_streams=int(kwargs.get("decode_streams", 1)),
-                                    return_first_logits=want_first)
+                                    return_first_logits=want_first, sampling=sampling)
         if want_logits or want_first:
             res = list(res)
             out = type("GenerateOutput", (), {})()
@@ -265,14 +265,25 @@ class UnifiedForCausalLM(nn.Module, UnifiedMetaForCausalLM):
             return out
         return res
 
+    @staticmethod
+    def _sampling(kwargs):
+        """HF sample-mode arguments -> (temperature, top_k, top_p, seed) or None (greedy).  Defaults = what a Llama-2-chat checkpoint's
+        generation_config + GenerationConfig's own defaults give the reference's generate() call (temperature 0.6, top_p 0.9, top_k 50)."""
+        if not kwargs.get("do_sample"):
+            return None
+        t, k, p_ = float(kwargs.get("temperature", 0.6)), int(kwargs.get("top_k", 50) or 0), float(kwargs.get("top_p", 0.9))
+        if t <= 0 or not (0 < p_ <= 1) or k < 0:
+            raise ValueError("do_sample: temperature > 0, 0 < top_p <= 1, top_k >= 0")
+        seed = kwargs.get("seed")
+        return (t, k, p_, int(torch.initial_seed() if seed is None else seed) & 0x7FFFFFFFFFFFFFFF)
+
     @torch.no_grad()
     def generate_avs(self, batch_input_ids, batch_labels, batch_X_modals, batch_task_names, **kwargs):
         """unified_llama.py:270-361: greedy generation with the post-final-norm hidden state of every step kept; the states
         of the steps j with output_ids[0, j+1] in {<mask_0..5>} (bs == 1 assumed, :338) become the 6 prompt embeddings
         of the SegModule.  Returns {'output_ids', 'pred_masks'} (only 'output_ids' when != 6 mask tokens were produced).
         One deviation: step 0 contributes its LAST-row state (the reference's step-0 entry holds all S prompt rows)."""
-        if kwargs.get("do_sample"):
-            raise NotImplementedError("sampling is not implemented: the MI355X path is greedy-only")
+        sampling = self._sampling(kwargs)
         inputs = self.prepare_multimodal_inputs(batch_input_ids=batch_input_ids, batch_labels=batch_labels,
                                                 batch_X_modals=batch_X_modals, return_multi_scale_features=True,
                                                 return_gt_mask=True, batch_task_names=batch_task_names)
@@ -281,7 +292,7 @@ class UnifiedForCausalLM(nn.Module, UnifiedMetaForCausalLM):
         pad = kwargs.get("pad_token_id", self.model.pad_token_id if self.model.pad_token_id is not None else eos)
         ids, hidden = self._engine.generate(embeds, int(kwargs.get("max_new_tokens", 20)), eos_token_id=eos, pad_token_id=pad,
                                             min_new_tokens=int(kwargs.get("min_new_tokens", 0) or 0),
-                                            use_graph=kwargs.get("use_graph", True), return_hidden=True)
+                                            use_graph=kwargs.get("use_graph", True), return_hidden=True, sampling=sampling)
         result = {'output_ids': ids}
         seg_ids = {self.SPECIAL_TOKEN_2_IDS[f'<mask_{i}>'] for i in range(6)}
         row0 = ids[0].tolist()

@@ -241,6 +241,14 @@ int crab_greedy_select(crab_ctx* ctx, void* stream, const float* logits, int64_t
                        int64_t* out_ids, int64_t ld_out, const int32_t* step_dev, int32_t* finished, int eos_id, int pad_id,
                        int min_new_tokens);
 int crab_advance(crab_ctx* ctx, void* stream, int32_t* pos_dev, int32_t* step_dev);
+/* The same step with SAMPLING (HF GenerationMixin sample mode: the reference never passes do_sample, so Llama-2-chat's generation_config
+ * applies - temperature 0.6, top_p 0.9, GenerationConfig's default top_k 50; scripts/quick_start.py:36-43): logits / temperature -> keep
+ * the top_k largest (0 = all) -> keep the smallest set of largest tokens whose probability mass reaches top_p (TopPLogitsWarper: token i
+ * stays iff the mass of the strictly larger ones is < top_p) -> draw from the renormalised rest.  The draw uses a counter-based generator
+ * keyed by (seed, step_dev[0], row): deterministic per seed, replayable from a HIP graph; HF's torch.multinomial stream is not reproduced. */
+int crab_sample_select(crab_ctx* ctx, void* stream, const float* logits, int64_t ldl, int B, int V, int64_t* cur_ids,
+                       int64_t* out_ids, int64_t ld_out, const int32_t* step_dev, int32_t* finished, int eos_id, int pad_id,
+                       int min_new_tokens, float temperature, int top_k, float top_p, uint64_t seed);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused decoder blocks: the launch sequence of ONE LlamaDecoderLayer / Qwen2DecoderLayer with hyper-LoRA

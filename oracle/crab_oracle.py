@@ -268,6 +268,25 @@ def greedy_generate(embeds: Tensor, W: WDict, cfg: DecoderConfig, max_new_tokens
     return out, sl
 
 
+def sampling_probs(logits: Tensor, temperature: float = 0.6, top_k: int = 50, top_p: float = 0.9) -> Tensor:
+    """The distribution HF's sample mode draws from (third-party: transformers==4.37.2 generation/logits_process.py, applied in the order
+    of generation/utils.py:_get_logits_warper - TemperatureLogitsWarper, TopKLogitsWarper, TopPLogitsWarper - then softmax; the reference
+    reaches it because scripts/quick_start.py:36-43 never passes do_sample and Llama-2-chat's generation_config sets it).
+    logits [B, V] fp32 -> probabilities [B, V] (zeros outside the kept set).  Pinned against the installed transformers' own warper
+    classes in tests/test_oracle_golden.py."""
+    x = logits.float() / temperature
+    if top_k and top_k < x.shape[-1]:
+        kth = x.topk(top_k, dim=-1).values[..., -1:]
+        x = x.masked_fill(x < kth, -float("inf"))
+    if top_p < 1.0:
+        sl, si = torch.sort(x, descending=False, dim=-1)
+        cum = sl.softmax(-1).cumsum(-1)
+        rem = cum <= (1 - top_p)
+        rem[..., -1:] = False                                            # min_tokens_to_keep = 1
+        x = x.masked_fill(rem.scatter(-1, si, rem), -float("inf"))
+    return x.softmax(-1)
+
+
 # =====================================================================================
 # B.4 CLIP ViT vision tower (HF CLIPVisionModel; Crab use: multimodal_encoder.py:52-84)
 # =====================================================================================

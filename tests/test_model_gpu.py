@@ -667,3 +667,26 @@ def test_generate_splits_a_batch_that_does_not_fit_the_memory_budget():
     assert _rel(sl2[:, 0], sl[:, 0], "generate() split into groups vs one piece: step-0 logits (HIP vs HIP)") < 6e-3
     same = (ids2 == ids).float().mean().item()
     assert same >= 0.9, same
+
+
+def test_generate_with_sampling_like_the_reference_default():
+    """generate(do_sample=True): HF sample mode with the defaults a Llama-2-chat checkpoint hands the reference's generate() call
+    (temperature 0.6, top_k 50, top_p 0.9; scripts/quick_start.py:36-43): ids are valid, reproducible for a seed,
+    different across seeds, identical between graph replay and eager, and top_k = 1 reproduces the greedy ids of the reference fixture."""
+    meta, A = load_fixture("full_tiny_llama")
+    model = build_tiny_crab(meta)
+    model.load_state_dict(weights_from_table(meta), strict=False)
+    mods = _inputs(meta)
+    kw = dict(batch_input_ids=[A["ids0"]], batch_labels=[torch.full_like(A["ids0"], -100)], batch_X_modals=[mods[0]], batch_task_names=['avqa'],
+              use_cache=True, max_new_tokens=meta["new_tokens"], pad_token_id=2, eos_token_id=None)
+    a = model.generate(do_sample=True, seed=5, **kw)
+    b = model.generate(do_sample=True, seed=5, **kw)
+    c = model.generate(do_sample=True, seed=6, **kw)
+    e = model.generate(do_sample=True, seed=5, use_graph=False, **kw)
+    V = model.base_model.model.lm_head.weight.shape[0]
+    assert a.shape == (1, meta["new_tokens"]) and int(a.min()) >= 0 and int(a.max()) < V
+    assert torch.equal(a, b) and torch.equal(a, e) and not torch.equal(a, c)
+    greedy = model.generate(do_sample=True, top_k=1, seed=5, **kw)
+    assert torch.equal(greedy.cpu(), A["ids_bs1"])
+    with pytest.raises(ValueError):
+        model.generate(do_sample=True, temperature=0.0, **kw)

@@ -344,6 +344,46 @@ def test_decode_attention_grouped_query(G, ctx):
     _cmp(o[:3], o2.float().cpu(), TOL_BF16, "grouped vs per-head decode kernel")
 
 
+@pytest.mark.parametrize("V,T,k,p", [(300, 0.6, 50, 0.9), (32017, 0.6, 50, 0.9), (1000, 1.3, 7, 0.5), (64, 0.8, 0, 0.95), (40, 1.0, 5, 1.0)])
+def test_sample_select_draws_from_the_hf_distribution(V, T, k, p):
+    """crab_sample_select (temperature -> top-k -> top-p -> draw, device-resident) against the distribution HF's sample mode draws from
+    (oracle.sampling_probs, pinned to transformers' warpers on CPU): 16384 independent rows with the same logits - no draw outside the
+    kept set, total-variation distance to the reference probabilities < 3 %, every kept token with p >= 2 % is drawn; deterministic per
+    (seed, step); top_k = 1 is the argmax; EOS suppression below min_new_tokens."""
+    from crab_amd import ops
+    from oracle import crab_oracle as O
+    g = torch.Generator().manual_seed(V)
+    lg = torch.randn(1, V, generator=g) * 1.2
+    probs = O.sampling_probs(lg, T, k, p)[0]
+    assert int((probs > 0).sum()) >= 2, "test input too peaked: the kept set must hold several tokens"
+    N = 16384
+    logits = lg.expand(N, V).contiguous().cuda()
+
+    def draw(seed, step, eos=-1, min_new=0, kk=k, pp=p, tt=T):
+        cur = torch.zeros(N, dtype=torch.int64, device="cuda")
+        out = torch.full((N, 4), -1, dtype=torch.int64, device="cuda")
+        fin = torch.zeros(N, dtype=torch.int32, device="cuda")
+        sd = torch.tensor([step], dtype=torch.int32, device="cuda")
+        ops.sample_select(logits, cur, out, sd, fin, eos, 2, min_new, tt, kk, pp, seed)
+        assert torch.equal(out[:, step], cur)
+        return cur.cpu()
+    a = draw(1234, 0)
+    assert torch.equal(a, draw(1234, 0)), "not deterministic for a given (seed, step)"
+    assert not torch.equal(a, draw(1234, 1)) and not torch.equal(a, draw(99, 0))
+    hist = torch.bincount(a, minlength=V).float() / N
+    assert float(hist[probs == 0].sum()) == 0.0, "a token outside HF's kept set was drawn"
+    tv = 0.5 * float((hist - probs).abs().sum())
+    from tests.util import record_parity
+    record_parity(f"sample_select V={V} T={T} top_k={k} top_p={p}: total-variation distance of 16384 draws to the HF distribution", tv, 1.0, 3e-2,
+                  kept_tokens=int((probs > 0).sum()))
+    assert tv < 3e-2, tv
+    assert bool((hist[probs >= 0.02] > 0).all())
+    assert torch.equal(draw(7, 2, kk=1), torch.full((N,), int(lg.argmax()), dtype=torch.int64))
+    top = int(lg.argmax())
+    sup = draw(7, 0, eos=top, min_new=1)                      # the most likely token is EOS and still suppressed at step 0
+    assert not bool((sup == top).any())
+
+
 def test_im2col_and_clip_embed():
     from crab_amd import ops
     x = torch.randn(2, 3, 28, 42)

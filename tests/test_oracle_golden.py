@@ -133,6 +133,25 @@ def test_forward_with_left_pad_mask_and_position_ids():
     assert float((lu[1] - logits[1])[valid[1]].abs().max()) > 1e-2 and float((lu[0] - logits[0]).abs().max()) < 1e-4
 
 
+def test_sampling_distribution_matches_transformers_warpers():
+    """oracle.sampling_probs (the distribution HF's sample mode draws from: temperature -> top-k -> top-p -> softmax) against the
+    installed transformers' own TemperatureLogitsWarper / TopKLogitsWarper / TopPLogitsWarper, incl. the Llama-2-chat defaults the
+    reference's generate() call inherits (0.6 / 50 / 0.9)."""
+    from transformers.generation.logits_process import TemperatureLogitsWarper, TopKLogitsWarper, TopPLogitsWarper
+    g = torch.Generator().manual_seed(0)
+    for V, T, k, p in [(50, 0.6, 50, 0.9), (320, 0.6, 50, 0.9), (1000, 1.3, 7, 0.5), (64, 0.8, 0, 0.95), (40, 1.0, 5, 1.0), (32017, 0.6, 50, 0.9)]:
+        lg = torch.randn(3, V, generator=g) * 3
+        x = TemperatureLogitsWarper(T)(None, lg.clone())
+        if k:
+            x = TopKLogitsWarper(k)(None, x)
+        if p < 1:
+            x = TopPLogitsWarper(p)(None, x)
+        ref = x.softmax(-1)
+        got = O.sampling_probs(lg, T, k, p)
+        assert torch.equal(ref > 0, got > 0), (V, T, k, p)
+        _close(got, ref, 1e-6)
+
+
 def test_decoder_tiny_qwen2_gqa_bias():
     meta, A = load_fixture("decoder_tiny_qwen2")
     W = O.strip_peft_prefix(weights_from_table(meta))
