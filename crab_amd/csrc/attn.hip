@@ -799,7 +799,7 @@ extern "C" int crab_attn_decode_rope(crab_ctx* ctx, void* stream, const void* qk
     // unfused pair 21.6 + 4.9 us - beyond one block per CU the per-block chain (position -> table -> rotate -> stream -> publish -> ticket)
     // costs what the extra parallelism gives; at B = 1 (32 heads) 8 splits take 12.3 us against 19.0 + 4.8
     int nsplit = 1;
-    if ((long)B * H < CRAB_ATTN_SPLIT_BELOW) { nsplit = (int)((CRAB_ATTN_SPLIT_BELOW + (long)B * H - 1) / ((long)B * H)); if (nsplit > 8) nsplit = 8; }
+    if ((long)B * H < 256) { nsplit = (int)(256 / ((long)B * H)); if (nsplit > 8) nsplit = 8; }      // ~one block per CU
     if (nsplit > 1 && (!workspace || workspace_bytes < crab_attn_decode_rope_workspace(B, H, d)))
         return crab_fail(ctx, CRAB_E_WORKSPACE, "attn_decode_rope: needs crab_attn_decode_rope_workspace(B, H, d) bytes (counters zeroed once)");
     float* part = (float*)workspace;
