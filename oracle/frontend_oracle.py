@@ -22,6 +22,11 @@ Third-party algorithms restated here (absent from /root/reference):
     a second implementation written independently from Kaldi's compute-fbank-feats definition in float64 (tests/golden/
     make_fbank_kat.py: per-frame loops, scipy rfft, nine waveforms incl. silence / DC / square wave / one frame / chirp / impulse),
     which pins the algorithm but not torchaudio's rounding: it stays "unpinned" until a torchaudio-generated fixture exists.
+    r03: additionally checked against a THIRD-PARTY implementation of the same call that runs here - Hugging Face transformers'
+    Kaldi-compatible filter bank (transformers.audio_utils: what its feature extractors use instead of torchaudio.compliance.kaldi
+    when torchaudio is absent), recorded with the reference's options on the same waveforms (tests/golden/make_fbank_hf.py ->
+    fbank_hf.npz).  That is not torchaudio's own output either, so the status word stays "parity unpinned"; the evidence is now two
+    independent implementations (one not the builder's) agreeing with this restatement and with the device kernel.
 """
 from __future__ import annotations
 

@@ -160,3 +160,44 @@ def test_fbank_device_matches_independent_kaldi_spec_vectors():
         assert ex <= 0.0, (name, ex)
         floor = kat < -15.9
         assert np.abs(fb[floor] - kat[floor]).max() < 1e-5 if floor.any() else True, name
+
+
+# ------------------------------------------------------------------ kaldi fbank vs a THIRD-PARTY implementation (tests/golden/make_fbank_hf.py)
+def _hf():
+    import json
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "fbank_hf.npz"))
+    return json.loads(bytes(z["meta"]).decode()), z
+
+
+def test_fbank_oracle_matches_transformers_kaldi_compatible_fbank():
+    """oracle/frontend_oracle.kaldi_fbank against Hugging Face transformers' Kaldi-compatible filter bank (audio_utils: povey window,
+    kaldi mel scale, preemphasis, DC removal, log with the epsilon floor - what transformers' feature extractors run instead of
+    torchaudio.compliance.kaldi.fbank when torchaudio is absent), recorded with the reference's options (audio_processor.py:29-41) on the
+    nine edge-case waveforms.  Not torchaudio itself, but an implementation of the same call that this repository's builder did not write."""
+    meta, z = _hf()
+    _, kz = _kat()
+    for name in meta["names"]:
+        w, ref = kz["wave_" + name], z["fbank_" + name]
+        fb = FO.kaldi_fbank(w.astype(np.float32) * np.float32(meta["scale"]))
+        assert fb.shape == ref.shape, name
+        assert _fbank_agrees(fb, ref) <= 0.0, (name, _fbank_agrees(fb, ref))
+        floor = ref < -15.9
+        assert np.array_equal(fb[floor], ref[floor]), name
+
+
+@pytest.mark.gpu
+def test_fbank_device_matches_transformers_kaldi_compatible_fbank():
+    """The HIP kernel against the same third-party vectors."""
+    from crab_amd import frontend
+    from tests.util import record_parity
+    meta, z = _hf()
+    _, kz = _kat()
+    for name in meta["names"]:
+        w, ref = kz["wave_" + name], z["fbank_" + name]
+        fb = frontend.kaldi_fbank(torch.from_numpy(w).cuda(), in_scale=float(meta["scale"]))[0].cpu().numpy()
+        assert fb.shape == ref.shape, name
+        ex = _fbank_agrees(fb, ref, rel=2e-3, abs_of_frame_max=1e-8)
+        strong = ref > ref.max(axis=1, keepdims=True) - 12.0
+        record_parity(f"kaldi fbank vs transformers' Kaldi-compatible fbank, {name}: max |dlog| over bins within e^-12 of the frame max",
+                      float(np.abs(fb - ref)[strong].max()) if strong.any() else 0.0, 1.0, 2e-3)
+        assert ex <= 0.0, (name, ex)
