@@ -353,7 +353,11 @@ def main():
                 total_launches = d["launches"]
                 ach = d["work"] / (d["ms"] * 1e-3) / 1e12
                 e = {"bound": "mfma", "kernel": name, "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None}
+                     "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                     "note": "all launches of this kernel in the timed region: decoder prefill projections AND the encoders' (CLIP K = 1024) shapes",
+                     "by_class": {c: {"launches": v["launches"], "achieved": round(v["work"] / (v["ms"] * 1e-3) / 1e12, 1),
+                                      "frac": round(v["work"] / (v["ms"] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)}
+                                  for c, v in d.get("classes", {}).items() if v["ms"] > 0}}
             e.update({"sampled_launches": d["launches"], "avg_launch_us": round(avg_ms * 1e3, 1),
                       "est_total_ms_in_timed_region": round(avg_ms * total_launches, 1)})
             entries.append(e)

@@ -31,6 +31,12 @@ BF16 = torch.bfloat16
 NATIVE_ENC_LAYERS = True      # False: issue every launch of an encoder layer from Python (sequencer-equivalence tests, A/B runs)
 
 
+def _native_layers() -> bool:
+    """One C call per encoder layer - unless a per-launch profiler is attached (bench.py times individual GEMM launches through
+    ops.gemm; the C sequencers issue the same launches but outside its view), like crab_amd/decoder.py does for the decoder layers."""
+    return NATIVE_ENC_LAYERS and ops.PROFILER is None
+
+
 def _dense(lin) -> "_lib.Dense":
     """crab_dense over an nn.Linear-like holder (LinearP) or a bias-carrying PackedLinearGroup without adapter."""
     d = _lib.Dense()
@@ -209,7 +215,7 @@ class CLIPVisionModel(nn.Module):
         keep = set(range(upto + 1)) if keep is None else set(keep)
         hs = {0: h.view(N, T, D)} if 0 in keep else {}
         M = N * T
-        if NATIVE_ENC_LAYERS:
+        if _native_layers():
             # one C call per layer (crab_clip_layer, csrc/encoder_layers.hip): the launches below, in the same order, x updated in place
             sc = _EncScratch(M, D, c["intermediate_size"], M, 3 * D, N * D * ((T + 7) // 8 * 8), h.device)
             if 0 in hs and upto > 0:
@@ -387,7 +393,7 @@ class BertModel(nn.Module):
             ops.copy_rows_batched(z0, h, 0, z, h, nq * h, B, nq, h)                  # broadcast the query tokens
         else:
             z = z0
-        if NATIVE_ENC_LAYERS:
+        if _native_layers():
             # one C call per layer (crab_qformer_layer): self-attention, cross-attention to `enc`, query FFN; z updated in place
             i_ = self.encoder.layer[0].intermediate_query.dense.weight.shape[0]
             rows = max(B * nq, B * m)
@@ -626,7 +632,7 @@ class BEATs(nn.Module):
         alpha = math.pow(2 * c.encoder_layers, 0.25) if c.deep_norm else 1.0
         table = enc.layers[0].self_attn.relative_attention_bias.weight
         bias = ops.beats_relpos_bias(table, n, H, c.num_buckets, c.max_distance)        # once per forward (:131-137)
-        if NATIVE_ENC_LAYERS:
+        if _native_layers():
             # one C call per layer (crab_beats_layer): gated relative-position attention + FFN, post-LN deep-norm; x updated in place
             sc = _EncScratch(B * n, E, c.encoder_ffn_embed_dim, B * n, 3 * E, B * E * ((n + 7) // 8 * 8), dev)
             io = sc.io(x, B, n)

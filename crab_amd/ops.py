@@ -73,13 +73,19 @@ class KernelProfiler:
         return pre, dec
 
     def summary(self):
+        """{kernel variant: {launches, work, ms, classes: {class: {launches, work, ms}}}}; a record's variant may carry a class after
+        '|' (GEMMs: 'decoder' = hyper-LoRA projections of the decoder, 'encoder' = CLIP / BEATs / Q-Former / head shapes)."""
         torch.cuda.synchronize()
         out = {}
         for variant, work, e0, e1 in self.records:
-            d = out.setdefault(variant, {"launches": 0, "work": 0.0, "ms": 0.0})
-            d["launches"] += 1
-            d["work"] += work
-            d["ms"] += e0.elapsed_time(e1)
+            variant, _, cls = variant.partition("|")
+            ms = e0.elapsed_time(e1)
+            d = out.setdefault(variant, {"launches": 0, "work": 0.0, "ms": 0.0, "classes": {}})
+            for tgt in (d, d["classes"].setdefault(cls, {"launches": 0, "work": 0.0, "ms": 0.0}) if cls else None):
+                if tgt is not None:
+                    tgt["launches"] += 1
+                    tgt["work"] += work
+                    tgt["ms"] += ms
         return out
 
 
@@ -175,7 +181,8 @@ def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
         e0.record()
         _lib.check(_lib.load().crab_gemm_bf16(_lib.ctx(d), _stream(), C.byref(g)), d)
         e1.record()
-        prof.records.append((_variant(M, N, 1, K), 2.0 * M * N * (K + (x2.shape[1] if x2 is not None else 0)), e0, e1))
+        prof.records.append((_variant(M, N, 1, K) + ("|decoder" if x2 is not None else "|encoder"),
+                             2.0 * M * N * (K + (x2.shape[1] if x2 is not None else 0)), e0, e1))
         return out
     _lib.check(_lib.load().crab_gemm_bf16(_lib.ctx(d), _stream(), C.byref(g)), d)
     return out
