@@ -415,6 +415,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_norm_kernel(const float* 
 }  // namespace
 
 int crab_gemm_skinny_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* d);   // skinny.hip
+bool crab_skinny_fuses_rope(const crab_gemm_desc* d);                                   // skinny.hip: RoPE + KV append in the M <= 16 epilogue
 bool crab_rowfin_ok(const crab_gemm_desc* d);                                           // rowfin.hip: the M <= 16 layer tail
 int crab_rowfin_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* d);
 int crab_gemm_glds_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* d, int splitk, float* part, int ring_split);     // gemm_glds.hip
@@ -638,7 +639,8 @@ extern "C" int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc*
                 return rc ? rc : launch_norm_epilogue(ctx, (hipStream_t)stream, d, (const float*)d->workspace, 1, true);
             }
             int rc = crab_gemm_skinny_launch(ctx, (hipStream_t)stream, d);
-            return rc ? rc : post_norm(ctx, stream, d);
+            if (rc || crab_skinny_fuses_rope(d)) return rc;             // M <= 16: the rotation and the cache append ran in the epilogue
+            return post_norm(ctx, stream, d);
         }
         if (want_split) sk_bm = d->M <= 64 ? 64 : 128;
     }

@@ -35,6 +35,12 @@ struct SkinnyP {
     // instead of two launches of its own.  K is split because a 257th block as long as the others shares a CU with one of them and
     // both then stream at half rate: o / down measured 13.3 -> 17.5 us with ONE extra full-K block.
     const bf16_t* Bx; long ldbx; float* Tx;
+    // gemm_skinny_dma_kernel only, packed q|k|v projection of ONE row per sequence (decode): RoPE of q / k and the KV-cache append in the
+    // epilogue (the result of crab_gemm_bf16 followed by crab_qkv_rope_split(B = M, S = 1), bit for bit).  A rotation pair is (dim i,
+    // dim i + d/2) of one head, 64 weight rows apart: a block therefore takes rows [8j, 8j+8) and [d/2 + 8j, d/2 + 8j + 8) of a q / k head
+    // (v heads keep 16 consecutive rows), so both partners of every pair sit in its 16-column tile, two lane groups apart.
+    const float* rope_tab; bf16_t* rope_kc; bf16_t* rope_vc; const int* rope_pos_dev;
+    int rope_H, rope_Hk, rope_d, rope_Tmax, rope_pos0;
 };
 
 constexpr int SK_WAVES = 8;
@@ -180,6 +186,12 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_dma_kernel(SkinnyP 
     const long ldbw = extra ? p.ldbx : p.ldb;
     const int Nw = extra ? 16 : p.N;
     const int n0 = extra ? 0 : (int)blockIdx.x * 16 * NT;
+    // fused RoPE: block -> (head hh, 16-row group j); q / k heads take the two 8-row halves of rotation pairs (see SkinnyP)
+    const bool rope = NT == 1 && p.rope_tab != nullptr && !extra;
+    const int r_bpd = rope ? p.rope_d >> 4 : 1;
+    const int r_hh = (int)blockIdx.x / r_bpd, r_j = (int)blockIdx.x % r_bpd;
+    const bool r_qk = rope && r_hh < p.rope_H + p.rope_Hk;
+    const int r_base = r_hh * p.rope_d, r_half = p.rope_d >> 1;
 
     const int nk1 = (p.K + 63) >> 6;
     const int nk2 = (p.A2 && !extra) ? (p.K2 + 63) >> 6 : 0;
@@ -197,7 +209,8 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_dma_kernel(SkinnyP 
     for (int i = 0; i < 2 * NT; ++i) {
         const int row = i * 8 + (lane >> 3);
         const int c = (lane & 7) ^ ((row >> 1) & 7);
-        const long wrow = min(n0 + row, Nw - 1);                        // clamped: rows >= N are never stored
+        long wrow = min(n0 + row, Nw - 1);                              // clamped: rows >= N are never stored
+        if (r_qk) wrow = r_base + (row >> 3) * r_half + 8 * r_j + (row & 7);
         kc[i] = c * 8;
         off1[i] = wrow * ldbw + c * 8;
         off2[i] = wrow * p.ldb2 + c * 8;
@@ -266,6 +279,49 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_dma_kernel(SkinnyP 
     if (tid < NT * 64) {
         const int j = tid >> 6, l = tid & 63;
         const int m = l & 15, n = n0 + j * 16 + (l >> 4) * 4;
+        if (rope) {
+            // every lane of the wave takes part in the partner exchange, rows >= M included
+            f32x4_t v = *reinterpret_cast<const f32x4_t*>(&red[0][0][l][0]);
+#pragma unroll
+            for (int w = 1; w < SK_WAVES; ++w) v += *reinterpret_cast<const f32x4_t*>(&red[w][0][l][0]);
+            const int cg = l >> 4;
+            const int d = p.rope_d, pos = p.rope_pos0 + (p.rope_pos_dev ? p.rope_pos_dev[0] : 0);
+            // local columns cg*4 .. +3 of this block's tile -> column of the packed projection
+            const int dim = r_qk ? (cg >> 1) * r_half + 8 * r_j + (cg & 1) * 4 : 16 * r_j + cg * 4;
+            const int col = r_base + dim;
+            float x[4], px[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                x[r] = bf2f(f2bf(v[r] + (p.bias ? bf2f(p.bias[col + r]) : 0.f)));      // what the projection stores: the rotation reads bf16
+                px[r] = __shfl_xor(x[r], 32, 64);                                           // the lane two column groups away, same row
+            }
+            if (m >= p.M) return;
+            bf16_t* crow = reinterpret_cast<bf16_t*>(p.C) + (long)m * p.ldc + col;
+            const uint32_t raw0 = pack_bf2(x[0], x[1]), raw1 = pack_bf2(x[2], x[3]);
+            if (!r_qk) {                                                 // value head: cache append, the projection row keeps the value
+                const int hk = r_hh - p.rope_H - p.rope_Hk;
+                *reinterpret_cast<u32x2*>(crow) = u32x2{raw0, raw1};
+                *reinterpret_cast<u32x2*>(p.rope_vc + (((long)m * p.rope_Hk + hk) * p.rope_Tmax + pos) * d + dim) = u32x2{raw0, raw1};
+                return;
+            }
+            const int idim = 8 * r_j + (cg & 1) * 4;                     // index of the rotation pair (first-half dim)
+            const float* cs = p.rope_tab + ((long)pos * r_half + idim) * 2;
+            float o[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float c = cs[2 * r], sn = cs[2 * r + 1];
+                o[r] = cg < 2 ? rope_lo(x[r], px[r], c, sn) : rope_hi(px[r], x[r], c, sn);
+            }
+            const u32x2 ow = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
+            if (r_hh < p.rope_H) {
+                *reinterpret_cast<u32x2*>(crow) = ow;                    // q rotated in place of the projection row
+            } else {
+                const int hk = r_hh - p.rope_H;
+                *reinterpret_cast<u32x2*>(crow) = u32x2{raw0, raw1};     // the row keeps the un-rotated key like the unfused pair
+                *reinterpret_cast<u32x2*>(p.rope_kc + (((long)m * p.rope_Hk + hk) * p.rope_Tmax + pos) * d + dim) = ow;
+            }
+            return;
+        }
         if (m >= p.M || n >= Nw) return;
         f32x4_t v = *reinterpret_cast<const f32x4_t*>(&red[0][j][l][0]);
 #pragma unroll
@@ -535,6 +591,14 @@ __global__ __launch_bounds__(256) void lora_route_row_kernel(const bf16_t* __res
 
 float* crab_rowfin_T(const crab_gemm_desc* d);      // rowfin.hip: where the router product of a deferred hyper-LoRA update goes
 
+// M <= 16 with the fused RoPE + KV append requested: gemm_skinny_dma_kernel does it in its epilogue (CRAB_SKINNY_ROPE=0: separate pass)
+bool crab_skinny_fuses_rope(const crab_gemm_desc* d) {
+    static const int on = []() { const char* e = getenv("CRAB_SKINNY_ROPE"); return !(e && e[0] == '0'); }();
+    return on && d->rope_tab && d->M <= 16 && d->tune == 0 && !d->c_fp32 && (d->rope_d & 15) == 0 && d->rope_d >= 16 && (d->ldc & 3) == 0 &&
+           (d->ldb & 7) == 0 && (!d->A2 || (d->ldb2 & 7) == 0) && d->N == (d->rope_H + 2 * d->rope_Hk) * d->rope_d &&
+           (((uintptr_t)d->C | (uintptr_t)d->rope_k_cache | (uintptr_t)d->rope_v_cache) & 7) == 0;
+}
+
 // called from crab_gemm_bf16 (gemm.hip) for unbatched problems with M <= 128
 int crab_gemm_skinny_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* d) {
     SkinnyP p;
@@ -543,6 +607,11 @@ int crab_gemm_skinny_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* 
     p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc; p.ldr = d->ldr; p.lda2 = d->lda2; p.ldb2 = d->ldb2;
     p.M = d->M; p.N = d->N; p.K = d->K; p.K2 = d->A2 ? d->K2 : 0; p.act = d->act; p.c_fp32 = d->c_fp32; p.res_scale = d->res_scale;
     p.Bx = nullptr; p.ldbx = 0; p.Tx = nullptr;
+    p.rope_tab = nullptr; p.rope_kc = p.rope_vc = nullptr; p.rope_pos_dev = nullptr; p.rope_H = p.rope_Hk = p.rope_d = p.rope_Tmax = p.rope_pos0 = 0;
+    if (crab_skinny_fuses_rope(d)) {
+        p.rope_tab = d->rope_tab; p.rope_kc = (bf16_t*)d->rope_k_cache; p.rope_vc = (bf16_t*)d->rope_v_cache; p.rope_pos_dev = d->rope_pos_dev;
+        p.rope_H = d->rope_H; p.rope_Hk = d->rope_Hk; p.rope_d = d->rope_d; p.rope_Tmax = d->rope_Tmax; p.rope_pos0 = d->rope_pos0;
+    }
     // M <= 16: the LDS-DMA ring kernel (tune 1 / 2 / 4 keep the register-direct kernel for A/B runs); d->tune == 9: the same with
     // raw fp32 sums to the workspace (used by crab_gemm_bf16 for its fused reduction epilogues)
     if (d->M <= 16 && (d->tune == 0 || d->tune == 9) && (d->ldb & 7) == 0 && (!d->A2 || (d->ldb2 & 7) == 0)) {

@@ -730,13 +730,14 @@ def test_gemm_post_norm_routes_next_group(M, nproj):
     assert (u[:, nproj * 24:] == 0).all()
 
 
-@pytest.mark.parametrize("M", [3, 40, 256])
-@pytest.mark.parametrize("H,Hk,bias", [(4, 4, False), (8, 2, True)])
-def test_gemm_fused_rope_kv_append_equals_unfused_pair(M, H, Hk, bias):
+@pytest.mark.parametrize("M", [1, 3, 8, 16, 40, 256])
+@pytest.mark.parametrize("H,Hk,bias,d", [(4, 4, False, 128), (8, 2, True, 128), (4, 2, True, 64)])
+def test_gemm_fused_rope_kv_append_equals_unfused_pair(M, H, Hk, bias, d):
     """q|k|v projection with the fused RoPE + KV-cache append (decode: one row per sequence) must leave exactly what the
-    projection followed by qkv_rope_split(S = 1) leaves: skinny kernel (fallback pass), split-K + fused reduction kernel."""
+    projection followed by qkv_rope_split(S = 1) leaves: M <= 16 in the epilogue of the small-batch kernel (a block owns both halves of
+    its rotation pairs), larger M in the split-K reduction kernel."""
     from crab_amd import ops
-    d, K, Tmax, K2 = 128, 1024, 64, 32
+    K, Tmax, K2 = 1024, 64, 32
     N = (H + 2 * Hk) * d
     x, w = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=K ** -0.5)
     x2, w2 = _rand(M, K2, seed=3), _rand(N, K2, seed=4, scale=0.1)
