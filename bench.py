@@ -208,8 +208,40 @@ def operating_points(model, um, args, eos):
                                 "frac": round(algo / dt / 1e9 / HBM_PEAK_GBS, 4), "ms_per_token": round(dt * 1e3 / args.new_tokens, 3),
                                 "note": "whole generate() call (encoders + prefill included in the time, not in the bytes)"}
 
+    def run_in_flight(name, G, B, note):
+        """G of the reference's eval batches (B clips each, separate prepare_multimodal_inputs / KV caches / HIP graphs) decoding in flight
+        together: UnifiedForCausalLM.generate_batches = what harness.run_inference(in_flight=G) calls; ids per batch = those of G generate() calls."""
+        batches = []
+        for g in range(G):
+            ids = [synth.synth_prompt_ids(128, model.base_vocab, tab, clip=9100 + g * B + i) for i in range(B)]
+            batches.append(dict(batch_input_ids=[i.cuda() for i in ids], batch_labels=[torch.full_like(i, -100) for i in ids],
+                                batch_X_modals=[{'<video>': synth.synth_video(args.frames, clip=9100 + g * B + i).cuda(),
+                                                 '<audio>': synth.synth_audio(10, 98, clip=9100 + g * B + i).cuda()} for i in range(B)],
+                                batch_task_names=['avqa'] * B))
+
+        def go():
+            return model.generate_batches(batches, use_cache=True, max_new_tokens=args.new_tokens, min_new_tokens=args.new_tokens, eos_token_id=eos,
+                                          pad_token_id=um.model.pad_token_id)
+        go()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = go()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        assert len(r) == G and all(tuple(x.shape) == (B, args.new_tokens) for x in r)
+        S_ = 126 + 32 * args.frames + 320
+        steps = args.new_tokens - 1
+        algo = G * sum(decode_bytes_per_step(B, S_ + t + 1, V=um.lm_head.weight.shape[0]) for t in range(steps))
+        out[name] = {"batches_in_flight": G, "clips_per_batch": B, "frames": args.frames, "prefill_len": S_, "clips_per_s": round(G * B / dt, 3),
+                     "ms_per_call": round(dt * 1e3, 1), "note": note,
+                     "hbm": {"bound": "hbm", "algorithmic_bytes": int(algo), "achieved_GBps": round(algo / dt / 1e9, 1), "peak_GBps": HBM_PEAK_GBS,
+                             "frac": round(algo / dt / 1e9 / HBM_PEAK_GBS, 4),
+                             "note": "every batch streams the weights for itself (separate M = 8 launches): bytes = G x one batch's"}}
+
     run("single_clip", 1, args.frames, 98, "scripts/quick_start.py: one clip per generate() (BASELINE configs[0] shape on the GPU); latency = ms_per_batch")
     run("eval_batch_8", 8, args.frames, 98, "the reference's eval batch size; per-batch latency = ms_per_batch")
+    run_in_flight("eval_batch_8_x3_in_flight", 3, 8, "three eval batches of 8 decoding concurrently on separate HIP streams (harness.run_inference in_flight=3)")
+    run_in_flight("eval_batch_8_x4_in_flight", 4, 8, "four eval batches of 8 in flight")
     run("audio_2s_windows", args.clips, args.frames, 198, "MUSIC-AVQA audio shape [10,198,128] (96 BEATs tokens per window)")
     run("frames_10", args.clips, 10, 98, "the reference's default video_frame_nums = 10 (S = 766)")
     return out

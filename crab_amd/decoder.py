@@ -631,6 +631,86 @@ class GenerationEngine:
             res.append(first_logits[0] if G == 1 else torch.cat(first_logits, 0))
         return res[0] if len(res) == 1 else tuple(res)
 
+    @torch.no_grad()
+    def generate_many(self, embeds_list: List[torch.Tensor], max_new_tokens: int, eos_token_id: Optional[int] = None,
+                      pad_token_id: Optional[int] = None, min_new_tokens: int = 0, use_graph: bool = True, sampling=None,
+                      return_first_logits: bool = False):
+        """Several INDEPENDENT batches in flight: each element of `embeds_list` ([B_i, S_i, D], its own prompt length and left padding, i.e.
+        exactly what one generate() call of the reference's eval loop gets) becomes one decode group with its own KV cache, decode state
+        and captured HIP graph; the groups are prefilled one after the other and their decode steps are replayed on separate HIP streams.
+        At the reference's batch of 8 a decode step is latency-bound (a chain of dependent launches that uses a third of the HBM
+        bandwidth), so the chains of 2-4 batches overlap: 8 clips / 4.6 ms alone, 16 / 6.8 ms, 24 / 8.7 ms, 32 / 11.3 ms in flight
+        (profiles/README.md r03) - per-batch RESULTS are those of separate generate() calls (rows never interact, every group runs
+        the kernels its own M selects).  Returns a list of id tensors (each trimmed like generate() trims it; with return_first_logits a list
+        of (ids, first-step logits)).  Sample mode: batch g draws with seed + 7919 g (_select), i.e. what generate(seed = seed + 7919 g) draws for it."""
+        if not embeds_list:
+            return []
+        G = len(embeds_list)
+        if G == 1:
+            r = self.generate(embeds_list[0], max_new_tokens, eos_token_id=eos_token_id, pad_token_id=pad_token_id, min_new_tokens=min_new_tokens,
+                              use_graph=use_graph, sampling=sampling, return_first_logits=return_first_logits)
+            return [r]
+        need = sum(e.shape[0] * self.bytes_per_sequence(e.shape[1], max_new_tokens) for e in embeds_list) + self.fixed_bytes(max(e.shape[0] for e in embeds_list),
+                                                                                                                            max(e.shape[1] for e in embeds_list))
+        budget = self.memory_budget(0, 0)
+        if need > 0.94 * budget:
+            raise MemoryError(f"generate_many: {G} batches need {need / 2**30:.1f} GiB of KV cache and scratch, {budget / 2**30:.1f} GiB available: put fewer in flight")
+        graphed = use_graph and max_new_tokens > 2
+        firsts = []
+
+        def sink(st):
+            if return_first_logits:
+                firsts.append(st.logits.clone())
+
+        main = torch.cuda.current_stream()
+        sts, graphs, streams = [], [], []
+        self._rope_tab(max(_round_up(e.shape[1] + max_new_tokens, 64) for e in embeds_list))    # grown ONCE: every group's launches bake its pointer
+        try:
+            for g, emb in enumerate(embeds_list):
+                ops.WS_SLOT = g
+                sts.append(self._start(emb, max_new_tokens, eos_token_id, pad_token_id, min_new_tokens, 0, False, g, sink, sampling))
+            for g, st in enumerate(sts):
+                ops.WS_SLOT = g
+                graphs.append(self._capture(st) if graphed else None)
+                streams.append(torch.cuda.Stream())
+        finally:
+            ops.WS_SLOT = 0
+        for sg in streams:
+            sg.wait_stream(main)
+        eos_on = sts[0].eos >= 0
+        live = list(range(G))
+        for step in range(1, max_new_tokens):
+            for g in live:
+                with torch.cuda.stream(streams[g]):
+                    ops.WS_SLOT = g
+                    if graphs[g] is not None:
+                        graphs[g].replay()
+                    else:
+                        self._decode_step(sts[g])
+            ops.WS_SLOT = 0
+            if eos_on and step % 16 == 0:
+                still = []
+                for g in live:
+                    with torch.cuda.stream(streams[g]):
+                        if not bool(sts[g].finished.all().item()):
+                            still.append(g)
+                live = still                                   # a batch whose rows have all finished stops stepping (HF stops that call)
+                if not live:
+                    break
+        for sg in streams:
+            main.wait_stream(sg)
+        outs = []
+        for g, st in enumerate(sts):
+            n_done = int(st.step_dev.item())
+            out = st.out_ids[:, :n_done]
+            if eos_on:
+                fin_cols = (out == st.eos).int().cumsum(1) > 0
+                idx = torch.nonzero(fin_cols.all(0))
+                if idx.numel():
+                    out = st.out_ids[:, : int(idx[0].item()) + 1]
+            outs.append((out.clone(), firsts[g]) if return_first_logits else out.clone())
+        return outs
+
     def _generate_split(self, groups, embeds, max_new_tokens, eos_token_id, pad_token_id, min_new_tokens, prefill_chunk, use_graph,
                         return_step_logits, return_hidden, return_first_logits, sampling=None):
         """The batch does not fit the device's memory in one piece: generate the groups one after the other (rows are independent,

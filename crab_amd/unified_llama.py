@@ -265,6 +265,25 @@ class UnifiedForCausalLM(nn.Module, UnifiedMetaForCausalLM):
             return out
         return res
 
+    @torch.no_grad()
+    def generate_batches(self, batches, **kwargs):
+        """Throughput form of the eval loop (scripts/finetune/inference_hyper_lora.py:1466-1479 calls generate() once per collated batch of 8):
+        `batches` = a list of dicts with the four generate() arguments (batch_input_ids, batch_labels, batch_X_modals, batch_task_names).  Every
+        batch goes through prepare_multimodal_inputs on its own (its own left padding, like a separate call), then all of them decode IN
+        FLIGHT together (GenerationEngine.generate_many).  Returns one id tensor per batch, equal to what generate() returns for it."""
+        sampling = self._sampling(kwargs)
+        embeds = []
+        for b in batches:
+            inputs = self.prepare_multimodal_inputs(batch_input_ids=b["batch_input_ids"], batch_labels=b.get("batch_labels"),
+                                                    batch_X_modals=b["batch_X_modals"], return_multi_scale_features=False, return_gt_mask=False,
+                                                    batch_task_names=b.get("batch_task_names"))
+            embeds.append(inputs['inputs_embeds'].to(device=self.device, dtype=BF16))
+        eos = kwargs.get("eos_token_id", self.config.eos_token_id)
+        pad = kwargs.get("pad_token_id", self.model.pad_token_id if self.model.pad_token_id is not None else eos)
+        return self._engine.generate_many(embeds, int(kwargs.get("max_new_tokens", 20)), eos_token_id=eos, pad_token_id=pad,
+                                          min_new_tokens=int(kwargs.get("min_new_tokens", 0) or 0), use_graph=kwargs.get("use_graph", True),
+                                          sampling=sampling)
+
     @staticmethod
     def _sampling(kwargs):
         """HF sample-mode arguments -> (temperature, top_k, top_p, seed) or None (greedy).  Defaults = what a Llama-2-chat checkpoint's

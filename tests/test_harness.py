@@ -102,6 +102,10 @@ class _FakeModel:
         self.calls.append(dict(kw, n=len(batch_input_ids)))
         return torch.stack([i[:3] for i in batch_input_ids])
 
+    def generate_batches(self, batches, **kw):
+        self.calls.append(dict(kw, n=[len(b["batch_input_ids"]) for b in batches], many=True))
+        return [torch.stack([i[:3] for i in b["batch_input_ids"]]) for b in batches]
+
 
 def _batches(tok, n):
     col = harness.Collator(tok)
@@ -123,6 +127,16 @@ def test_run_inference_single_rank(tmp_path):
     lines = [json.loads(l) for l in open(path)]
     assert lines == recs and all(set(r) == {"instruction", "output", "video_path", "audio_path", "predict"} for r in recs)
     assert recs[0]["predict"] == tok.batch_decode([tok.convert_tokens_to_ids(tok.tokenize(recs[0]["instruction"]))[:3]])[0]
+
+
+def test_run_inference_with_batches_in_flight_returns_the_same_records():
+    tok = _tok()
+    one, many = _FakeModel(), _FakeModel()
+    recs1 = harness.run_inference(_batches(tok, 5), one, tok, max_new_tokens=7, device="cpu")
+    recs3 = harness.run_inference(_batches(tok, 5), many, tok, max_new_tokens=7, device="cpu", in_flight=3)
+    assert recs1 == recs3 and len(recs3) == 5
+    assert [c.get("many", False) for c in many.calls] == [True, True] and many.calls[0]["n"] == [1, 1, 1] and many.calls[1]["n"] == [1, 1]
+    assert all(c["max_new_tokens"] == 7 and c["use_cache"] is True for c in many.calls)
 
 
 def _free_port():
@@ -206,6 +220,9 @@ def test_make_instance_pipeline_gpu():
         ids = model.generate(**s, use_cache=True, max_new_tokens=6, do_sample=False, pad_token_id=2, eos_token_id=None)
         assert ids.shape == (1, 6)
         assert rec["predict"] == tok.batch_decode(ids, skip_special_tokens=False)[0]
+    # both batches in flight together (through the Peft wrapper -> UnifiedForCausalLM.generate_batches): the same records
+    recs2 = harness.run_inference(batches, model, tok, max_new_tokens=6, do_sample=False, pad_token_id=2, eos_token_id=None, in_flight=2)
+    assert recs2 == recs
     # image task: .resize((224, 224)) + processor, one audio window
     img = np.random.RandomState(0).randint(0, 256, (120, 300, 3), dtype=np.uint8)
     it = harness.make_instance("s4", tok, image=img, audio=_ramp(16000 * 5), idx=3, mask=torch.zeros(1, 224, 224))

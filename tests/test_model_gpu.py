@@ -690,3 +690,29 @@ def test_generate_with_sampling_like_the_reference_default():
     assert torch.equal(greedy.cpu(), A["ids_bs1"])
     with pytest.raises(ValueError):
         model.generate(do_sample=True, temperature=0.0, **kw)
+
+
+def test_generate_batches_in_flight_equals_separate_generate_calls():
+    """generate_batches (several independent batches decoding on separate HIP streams, each with its own prepare_multimodal_inputs / left
+    padding / KV cache / captured graph) returns for every batch exactly what a separate generate() call returns - greedy and sampled,
+    ragged batch shapes (1 clip, 2 left-padded clips, 1 clip), EOS handling per batch."""
+    meta, A = load_fixture("full_tiny_llama")
+    model = build_tiny_crab(meta)
+    model.load_state_dict(weights_from_table(meta), strict=False)
+    mods = _inputs(meta)
+    lab = [torch.full_like(A["ids0"], -100), torch.full_like(A["ids1"], -100)]
+    batches = [dict(batch_input_ids=[A["ids0"]], batch_labels=[lab[0]], batch_X_modals=[mods[0]], batch_task_names=['avqa']),
+               dict(batch_input_ids=[A["ids0"], A["ids1"]], batch_labels=lab, batch_X_modals=mods, batch_task_names=['avqa', 'avqa']),
+               dict(batch_input_ids=[A["ids1"]], batch_labels=[lab[1]], batch_X_modals=[mods[1]], batch_task_names=['avqa'])]
+    for kw in (dict(max_new_tokens=meta["new_tokens"], pad_token_id=2, eos_token_id=None),
+               dict(max_new_tokens=meta["new_tokens"], pad_token_id=2, eos_token_id=None, do_sample=True, seed=3, top_k=8),
+               dict(max_new_tokens=40, pad_token_id=2, eos_token_id=int(A["ids_bs1"][0, 3]))):
+        many = model.generate_batches(batches, use_cache=True, **kw)
+        assert len(many) == 3
+        for g, b in enumerate(batches):
+            kw1 = dict(kw)
+            if kw1.get("do_sample"):
+                kw1["seed"] = 3 + 7919 * g                        # batch g of generate_batches draws from its own stream
+            solo = model.generate(**b, use_cache=True, **kw1)
+            assert many[g].shape == solo.shape and torch.equal(many[g], solo), (g, kw)
+    assert torch.equal(many[0][:, :4].cpu(), A["ids_bs1"][:, :4]) and many[0].shape[1] == 4     # stopped at the EOS it was given
