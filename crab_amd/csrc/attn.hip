@@ -15,6 +15,7 @@
 #include "common.h"
 #include "crab_internal.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -89,44 +90,53 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
     // below it are skipped.  A query row that sees no key at all (a pad row) ends with l_run == 0 and stores zeros.
     const int ks0 = p.kv_start ? p.kv_start[b] : 0;
     const int t0 = ks0 / KT;
-    const u32x4 z4 = {0u, 0u, 0u, 0u};
-    const u32x2 z2 = {0u, 0u};
 
     // Software pipeline: the global loads of tile t+1 are issued (into registers) right after tile t has been stored to LDS,
     // so their latency runs under tile t's MFMAs and softmax.  Synchronous staging left the waves parked 70 % of the time
     // (PMC: SQ_WAIT_ANY / SQ_WAVE_CYCLES, MFMA busy 11 %).
     constexpr int NKV = (KT * CPR) / 256, NVV = (HD * 8) / 256;
     u32x4 kreg[NKV], vreg[NVV];
+    // Loads are UNCONDITIONAL (addresses clamped into the operands, nothing selected or branched on before the data is used): with
+    // `row < Skv ? load : 0` and a scalar loop for the ragged V^T chunk the compiler could not keep the loads of the next tile in
+    // flight across the MFMAs - every iteration ended in s_waitcnt vmcnt(0) right behind the loads it had just issued, i.e. one full
+    // memory latency per 64-key tile (ISA of r02's kernel; 9500 cycles per tile against ~1000 of MFMA).  Keys >= Skv: the K row is a
+    // copy of the last valid row (its scores are masked), the V^T chunk is masked to zero at the LDS store (0 * stale bits stays 0).
 #define ATT_LOAD_TILE(T_)                                                                                      \
     {                                                                                                          \
         const int kvl_ = (T_) * KT;                                                                            \
         _Pragma("unroll") for (int i = 0; i < NKV; ++i) {                                                      \
             const int idx = tid + i * 256;                                                                     \
             const int row = idx / CPR, c = idx % CPR;                                                          \
-            const int kr = kvl_ + row;                                                                         \
-            kreg[i] = kr < p.Skv ? *reinterpret_cast<const u32x4*>(kp + (long)kr * p.k_ss + c * 8) : z4;       \
+            const int kr = min(kvl_ + row, p.Skv - 1);                                                         \
+            kreg[i] = *reinterpret_cast<const u32x4*>(kp + (long)kr * p.k_ss + c * 8);                         \
         }                                                                                                      \
         _Pragma("unroll") for (int i = 0; i < NVV; ++i) {                                                      \
             const int idx = tid + i * 256;                                                                     \
             const int row = idx >> 3, c = idx & 7;                                                             \
-            const int kc = kvl_ + c * 8;                                                                       \
-            u32x4 v = z4;                                                                                      \
-            if (kc + 8 <= p.Skv) {                                                                             \
-                v = *reinterpret_cast<const u32x4*>(vp + (long)row * p.vt_ds + kc);                            \
-            } else if (kc < p.Skv) {       /* ragged tail: zero beyond Skv so that 0 * pad stays 0 */          \
-                const bf16_t* sp_ = vp + (long)row * p.vt_ds + kc;                                             \
-                uint32_t w[4] = {0u, 0u, 0u, 0u};                                                              \
-                for (int e = 0; e < 8 && kc + e < p.Skv; ++e) w[e >> 1] |= ((uint32_t)sp_[e]) << ((e & 1) * 16); \
-                v = u32x4{w[0], w[1], w[2], w[3]};                                                             \
-            }                                                                                                  \
-            vreg[i] = v;                                                                                       \
+            int kc = kvl_ + c * 8;                         /* vt_ds is a multiple of 8 >= Skv: a chunk that starts below Skv is in the row */ \
+            kc = kc < p.Skv ? kc : 0;                                                                          \
+            vreg[i] = *reinterpret_cast<const u32x4*>(vp + (long)row * p.vt_ds + kc);                          \
         }                                                                                                      \
     }
-    if (t0 < ntiles) ATT_LOAD_TILE(t0);
+    // ragged last tile (wave-uniform test, VALU only): zero the V^T elements of keys >= Skv
+#define ATT_MASK_V(T_)                                                                                         \
+    if ((T_) * KT + KT > p.Skv) {                                                                              \
+        _Pragma("unroll") for (int i = 0; i < NVV; ++i) {                                                      \
+            const int c = (tid + i * 256) & 7;                                                                 \
+            const int rem = p.Skv - ((T_) * KT + c * 8);   /* valid elements of this chunk (<= 0: none) */      \
+            _Pragma("unroll") for (int w = 0; w < 4; ++w) {                                                    \
+                const uint32_t m = (2 * w < rem ? 0x0000ffffu : 0u) | (2 * w + 1 < rem ? 0xffff0000u : 0u);    \
+                vreg[i][w] &= m;                                                                               \
+            }                                                                                                  \
+        }                                                                                                      \
+    }
+    // (a block that sees no key at all - every row a left-pad row - falls through the loop and stores zeros)
+    if (t0 < ntiles) ATT_LOAD_TILE(t0)
     for (int t = t0; t < ntiles; ++t) {
         const int kv0 = t * KT;
         __syncthreads();                                         // previous tile fully consumed
         // ---- registers -> LDS: K tile (KT rows x CPR swizzled chunks), V^T tile (HD rows x 8 chunks, padded rows)
+        ATT_MASK_V(t)
 #pragma unroll
         for (int i = 0; i < NKV; ++i) {
             const int idx = tid + i * 256;
@@ -238,7 +248,210 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------- forward, 128 query rows per block
+// attn_fwd32_kernel: the same flash forward on v_mfma_f32_32x32x16_bf16 with 32 query rows per wave (128 per block) for Sq > 64 (decoder
+// prefill, CLIP).  Why: with 16 rows per wave every 16-cycle MFMA needs a fresh 1-KiB K or V^T fragment from LDS - 64 B/clk per SIMD,
+// 256 B/clk per CU against the 128 the LDS delivers - and every 64-key tile costs two block barriers; the 16-row kernel ran the
+// S = 702 prefill at 0.34 PFLOP/s (13 % of the matrix peak).  Here a 1-KiB fragment feeds a 32-cycle MFMA (half the LDS bytes per
+// flop), the online softmax needs ONE cross-lane exchange (lane ^ 32) because the 32 scores a lane holds per tile all belong to one
+// query row, the K / V^T tiles are double-buffered in LDS (one barrier per tile, next tile's global loads in flight under the
+// MFMAs), the output rescale is skipped while no row of the wave raised its maximum, and a wave whose rows cannot see a causal tile
+// (or lie beyond Sq) skips its arithmetic.  Heavy (late) causal query blocks are scheduled first.
+// Fragment maps (l = lane, c = l & 31, g = l >> 5):
+//   S^T = K.Q^T   A = K rows (key 32 j + c, head-dim 16 ks + 8 g + e)      B = Q (query c, same head-dim)      D[r]: key 8 (r >> 2) + 4 g + (r & 3), query c
+//   O^T += V^T.P^T  contraction index (g, e) <-> key 32 j + 16 kk + 8 (e >> 2) + 4 g + (e & 3): B = the lane's own exp'd scores
+//                 s[j][8 kk + e] (no shuffle, no LDS round trip), A = V^T row d = 32 dt + c gathered with the same map (two ds_read_b64)
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+template <int HD, bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(AttnP p) {
+    constexpr int CPR = HD / 8;             // 16-byte chunks per K row
+    constexpr int KS = HD / 16;             // MFMA k-steps over the head dim
+    constexpr int DT = HD / 32;             // output d tiles
+    constexpr int KBUF = KT * HD, VBUF = HD * VT_LD;
+    __shared__ __attribute__((aligned(16))) bf16_t lk[2 * KBUF];
+    __shared__ __attribute__((aligned(16))) bf16_t lv[2 * VBUF];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fc = lane & 31, fg = lane >> 5;
+    const int nqb = (p.Sq + 127) >> 7;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);           // a head's query blocks share one XCD's L2 (K / V re-reads)
+    const int b = lid / (nqb * p.H), h = (lid / nqb) % p.H;
+    const int hk = h / (p.H / p.Hk);
+    const int q0 = (nqb - 1 - lid % nqb) * 128;                 // longest causal blocks first
+    const int qw0 = q0 + wave * 32;                             // first query row of this wave
+    const int qrow = qw0 + fc;
+    const int qload = qrow < p.Sq ? qrow : p.Sq - 1;
+    const int koff = p.Skv - p.Sq;
+    const bool wave_on = qw0 < p.Sq;
+
+    const bf16_t* qp = p.q + (long)b * p.q_bs + (long)h * p.q_hs + (long)qload * p.q_ss;
+    const bf16_t* kp = p.k + (long)b * p.k_bs + (long)hk * p.k_hs;
+    const bf16_t* vp = p.vt + (long)b * p.vt_bs + (long)hk * p.vt_hs;
+
+    bf16x8_t qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 16 + fg * 8);
+
+    f32x16_t oacc[DT];
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+    float m_run = -1e30f, l_run = 0.f;
+
+    int kv_end = p.Skv;
+    if (CAUSAL) kv_end = min(kv_end, q0 + 128 + koff);
+    const int ntiles = (kv_end + KT - 1) / KT;
+    const int ks0 = p.kv_start ? p.kv_start[b] : 0;             // left-pad mask: keys below it are invisible, whole tiles skipped
+    const int t0 = ks0 / KT;
+    constexpr int NKV = (KT * CPR) / 256, NVV = (HD * 8) / 256;
+    u32x4 kreg[NKV], vreg[NVV];
+#define ATT_STORE_TILE(BUF_, T_)                                                                               \
+    {                                                                                                          \
+        ATT_MASK_V(T_)                                                                                         \
+        bf16_t* lk_ = lk + (BUF_) * KBUF;                                                                      \
+        bf16_t* lv_ = lv + (BUF_) * VBUF;                                                                      \
+        _Pragma("unroll") for (int i = 0; i < NKV; ++i) {                                                      \
+            const int idx = tid + i * 256;                                                                     \
+            const int row = idx / CPR, c = idx % CPR;                                                          \
+            *reinterpret_cast<u32x4*>(lk_ + row * HD + (k_swz<HD>(row, c) << 3)) = kreg[i];                    \
+        }                                                                                                      \
+        _Pragma("unroll") for (int i = 0; i < NVV; ++i) {                                                      \
+            const int idx = tid + i * 256;                                                                     \
+            const int row = idx >> 3, c = idx & 7;                                                             \
+            bf16_t* d_ = lv_ + row * VT_LD + c * 8;                                                            \
+            *reinterpret_cast<u32x2*>(d_) = u32x2{vreg[i][0], vreg[i][1]};                                     \
+            *reinterpret_cast<u32x2*>(d_ + 4) = u32x2{vreg[i][2], vreg[i][3]};                                 \
+        }                                                                                                      \
+    }
+    if (t0 >= ntiles) {                                         // block-uniform: every row is a left-pad row that sees no key -> zeros
+        if (qrow < p.Sq) {
+            bf16_t* op = p.o + (long)b * p.o_bs + (long)qrow * p.o_ss + (long)h * HD;
+#pragma unroll
+            for (int c = 0; c < HD / 4; ++c) *reinterpret_cast<u32x2*>(op + c * 4 + 0) = u32x2{0u, 0u};
+        }
+        return;
+    }
+    // straight-line from here: the wait in front of the first LDS store also covers the (older) Q fragment loads on EVERY path into the
+    // loop, so the loop body carries no vmcnt wait except the one for the tile it is about to store
+    ATT_LOAD_TILE(t0)
+    ATT_STORE_TILE(0, t0)
+    if (t0 + 1 < ntiles) ATT_LOAD_TILE(t0 + 1)
+    __syncthreads();
+    const float sc2 = p.scale * 1.4426950408889634f;            // scores in the log2 domain: one multiply, exp2 instead of exp
+    for (int t = t0; t < ntiles; ++t) {
+        const int cur = (t - t0) & 1;
+        const int kv0 = t * KT;
+        if (t + 1 < ntiles) {
+            // tile t+1 (in registers since the previous iteration) -> the other buffer, whose readers all passed the last barrier;
+            // then the loads of tile t+2 go out and fly under this tile's MFMAs
+            ATT_STORE_TILE(cur ^ 1, t + 1)
+            if (t + 2 < ntiles) ATT_LOAD_TILE(t + 2)
+        }
+        const bool skip = !wave_on || (CAUSAL && kv0 > qw0 + 31 + koff);       // wave-uniform: nothing of this tile is visible to the wave
+        if (!skip) {
+            const bf16_t* lkc = lk + cur * KBUF;
+            const bf16_t* lvc = lv + cur * VBUF;
+            // ---- S^T = K . Q^T : 2 key sub-tiles of 32, the two accumulator chains interleaved (an MFMA never waits for the one issued
+            // right before it)
+            f32x16_t s[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[j][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int row = j * 32 + fc;
+                    const int chunk = ks * 2 + fg;
+                    bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(lkc + row * HD + (k_swz<HD>(row, chunk) << 3));
+                    s[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[j], 0, 0, 0);
+                }
+            }
+            // ---- mask (only on tiles that can hold masked keys: the diagonal of a causal block, the ragged last tile, the tile the
+            // left-pad boundary falls in); lane holds keys kv0 + 32 j + 8 (r >> 2) + 4 g + (r & 3) of its query row.  The scores stay RAW:
+            // the running maximum is kept in the scaled log2 domain and the scale rides in the exponent's fma, exp2(s * sc2 - m).
+            const bool need_mask = (kv0 + KT > p.Skv) || (CAUSAL && (kv0 + KT - 1 > qw0 + koff)) || (kv0 < ks0);
+            if (need_mask) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int kv = kv0 + j * 32 + (r >> 2) * 8 + fg * 4 + (r & 3);
+                        bool ok = kv < p.Skv && kv >= ks0;
+                        if (CAUSAL) ok = ok && (kv <= qrow + koff);
+                        s[j][r] = ok ? s[j][r] : -INFINITY;
+                    }
+            }
+            float tmax = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) tmax = fmaxf(tmax, fmaxf(s[j][r], s[j][r + 1]));
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const float m_new = fmaxf(m_run, tmax * sc2);      // stays at the finite -1e30 while every key so far is masked (sc2 > 0)
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            const bool raised = m_new != m_run;
+            m_run = m_new;
+            float psum = 0.f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[j][r], sc2, -m_new));
+                    s[j][r] = e;
+                    psum += e;
+                }
+            l_run = l_run * alpha + psum;
+            if (__any(raised)) {                                 // alpha == 1 on every lane otherwise
+#pragma unroll
+                for (int i = 0; i < DT; ++i) oacc[i] *= alpha;
+            }
+            // ---- O^T += V^T . P^T : four 16-key contraction chunks
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    union { bf16x8_t v; uint32_t w[4]; } pf;
+                    pf.w[0] = pack_bf2(s[j][8 * kk + 0], s[j][8 * kk + 1]);
+                    pf.w[1] = pack_bf2(s[j][8 * kk + 2], s[j][8 * kk + 3]);
+                    pf.w[2] = pack_bf2(s[j][8 * kk + 4], s[j][8 * kk + 5]);
+                    pf.w[3] = pack_bf2(s[j][8 * kk + 6], s[j][8 * kk + 7]);
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt) {
+                        const bf16_t* vr = lvc + (dt * 32 + fc) * VT_LD + j * 32 + kk * 16 + fg * 4;
+                        union { bf16x8_t v; u32x2 hh[2]; } vf;
+                        vf.hh[0] = *reinterpret_cast<const u32x2*>(vr);
+                        vf.hh[1] = *reinterpret_cast<const u32x2*>(vr + 8);
+                        oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pf.v, oacc[dt], 0, 0, 0);
+                    }
+                }
+        }
+        __syncthreads();                                         // tile t consumed by every wave, tile t+1 visible in the other buffer
+    }
+    // ---- finish: the row sum lives in the two lanes of a query (l, l ^ 32); normalise, store 4 consecutive d per (dt, r >> 2)
+    l_run += __shfl_xor(l_run, 32, 64);
+    const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;        // no visible key (left-pad query row): zeros, never read by a valid row
+    if (qrow < p.Sq) {
+        bf16_t* op = p.o + (long)b * p.o_bs + (long)qrow * p.o_ss + (long)h * HD;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                u32x2 w;
+                w[0] = pack_bf2(oacc[dt][4 * g4 + 0] * inv, oacc[dt][4 * g4 + 1] * inv);
+                w[1] = pack_bf2(oacc[dt][4 * g4 + 2] * inv, oacc[dt][4 * g4 + 3] * inv);
+                *reinterpret_cast<u32x2*>(op + dt * 32 + g4 * 8 + fg * 4) = w;
+            }
+    }
+}
 #undef ATT_LOAD_TILE
+#undef ATT_MASK_V
+#undef ATT_STORE_TILE
 
 // ---------------------------------------------------------------------------------------------- decode
 // block = 256 threads = 16 groups of 16 lanes; group gidx handles keys gidx, gidx+16, ...; each lane owns
@@ -768,6 +981,19 @@ extern "C" int crab_attn_fwd(crab_ctx* ctx, void* stream, const crab_attn_desc* 
     hipStream_t s = (hipStream_t)stream;
     const bool hb = d->bias != nullptr;
     if (d->causal && hb) return crab_fail(ctx, CRAB_E_UNSUPPORTED, "attn_fwd: causal + bias not instantiated");
+    // Sq > 64 without bias (decoder prefill, CLIP): 128 query rows per block on the 32x32x16 MFMA.  CRAB_ATTN_FWD32=0 keeps the 64-row kernel (A/B runs)
+    static const int fwd32 = []() { const char* e = getenv("CRAB_ATTN_FWD32"); return !(e && e[0] == '0'); }();
+    if (fwd32 && !hb && d->Sq > 64 && d->scale > 0.f && (d->head_dim == 128 || d->head_dim == 64)) {
+        dim3 grid32(((d->Sq + 127) / 128) * d->H * d->B);
+        if (d->head_dim == 128) {
+            if (d->causal) hipLaunchKernelGGL((attn_fwd32_kernel<128, true>), grid32, block, 0, s, p);
+            else hipLaunchKernelGGL((attn_fwd32_kernel<128, false>), grid32, block, 0, s, p);
+        } else {
+            if (d->causal) hipLaunchKernelGGL((attn_fwd32_kernel<64, true>), grid32, block, 0, s, p);
+            else hipLaunchKernelGGL((attn_fwd32_kernel<64, false>), grid32, block, 0, s, p);
+        }
+        return crab_check_launch(ctx, "attn_fwd32_kernel");
+    }
     if (d->head_dim == 32) {
         hipLaunchKernelGGL((attn_fwd_kernel<32, false, false>), grid, block, 0, s, p);
     } else if (d->head_dim == 128) {

@@ -170,7 +170,10 @@ def _attn_ref(q, k, v, scale, causal=False, bias=None):
 
 @pytest.mark.parametrize("hd,B,H,Hk,Sq,Skv,causal", [
     (128, 2, 4, 4, 150, 150, True), (128, 1, 4, 2, 702, 702, True), (64, 3, 2, 2, 257, 257, False),
-    (64, 2, 12, 12, 32, 256, False), (64, 2, 2, 2, 32, 48, False), (128, 1, 2, 2, 1, 70, False), (64, 1, 4, 1, 65, 129, True)])
+    (64, 2, 12, 12, 32, 256, False), (64, 2, 2, 2, 32, 48, False), (128, 1, 2, 2, 1, 70, False), (64, 1, 4, 1, 65, 129, True),
+    # the 128-rows-per-block kernel (Sq > 64): exact block / wave boundaries, ragged last key tile, causal offset, grouped kv heads
+    (128, 1, 2, 2, 128, 128, True), (128, 2, 2, 1, 129, 129, True), (128, 1, 2, 2, 300, 300, False), (64, 2, 4, 2, 97, 200, True),
+    (64, 1, 2, 2, 448, 449, False), (128, 1, 1, 1, 66, 66, True)])
 def test_attn_fwd(hd, B, H, Hk, Sq, Skv, causal):
     from crab_amd import ops
     q, k, v = _rand(B, H, Sq, hd, seed=1), _rand(B, Hk, Skv, hd, seed=2), _rand(B, Hk, Skv, hd, seed=3)
