@@ -512,8 +512,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
                 s0 += qv[2 * e] * lo_bf(k0[e]) + qv[2 * e + 1] * hi_bf(k0[e]);
                 s1 += qv[2 * e] * lo_bf(k1[e]) + qv[2 * e + 1] * hi_bf(k1[e]);
             }
-#pragma unroll
-            for (int off = 8; off > 0; off >>= 1) { s0 += __shfl_xor(s0, off, 64); s1 += __shfl_xor(s1, off, 64); }
+            s0 = row16_sum(s0); s1 = row16_sum(s1);
             const bool has1 = j + 16 < ctx;                      // group-uniform
             const float mn = fmaxf(m, has1 ? fmaxf(s0, s1) : s0);
             const float a = __expf(m - mn), p0 = __expf(s0 - mn), p1 = has1 ? __expf(s1 - mn) : 0.f;
@@ -538,8 +537,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
         float sdot = 0.f;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) sdot += qv[e] * kx[e];
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1) sdot += __shfl_xor(sdot, off, 64);
+        sdot = row16_sum(sdot);
         float mn = fmaxf(m, sdot);
         float a = __expf(m - mn), pw = __expf(sdot - mn);
         l = l * a + pw;
@@ -615,7 +613,7 @@ __global__ __launch_bounds__(256) void attn_decode_rope_kernel(const bf16_t* __r
         for (int e = 0; e < 2; ++e) {
             const float c = cs[2 * (2 * i + e)], sn = cs[2 * (2 * i + e) + 1];
             const float xq = e ? hi_bf(qw[i]) : lo_bf(qw[i]), xk = e ? hi_bf(kw[i]) : lo_bf(kw[i]);
-            const float pq = __shfl_xor(xq, 8, 64), pk = __shfl_xor(xk, 8, 64);
+            const float pq = row_xor8(xq), pk = row_xor8(xk);
             r2[0][e] = hi_half ? rope_hi(pq, xq, c, sn) : rope_lo(xq, pq, c, sn);
             r2[1][e] = hi_half ? rope_hi(pk, xk, c, sn) : rope_lo(xk, pk, c, sn);
         }
@@ -671,8 +669,7 @@ __global__ __launch_bounds__(256) void attn_decode_rope_kernel(const bf16_t* __r
                 s0 += qv[2 * e] * lo_bf(k0[e]) + qv[2 * e + 1] * hi_bf(k0[e]);
                 s1 += qv[2 * e] * lo_bf(k1[e]) + qv[2 * e + 1] * hi_bf(k1[e]);
             }
-#pragma unroll
-            for (int off = 8; off > 0; off >>= 1) { s0 += __shfl_xor(s0, off, 64); s1 += __shfl_xor(s1, off, 64); }
+            s0 = row16_sum(s0); s1 = row16_sum(s1);
             const bool has1 = j + 16 < nc;                      // group-uniform
             const float mn = fmaxf(m, has1 ? fmaxf(s0, s1) : s0);
             const float a = __expf(m - mn), p0 = __expf(s0 - mn), p1 = has1 ? __expf(s1 - mn) : 0.f;
@@ -696,8 +693,7 @@ __global__ __launch_bounds__(256) void attn_decode_rope_kernel(const bf16_t* __r
         float sdot = 0.f;
 #pragma unroll
         for (int i = 0; i < WPL; ++i) sdot += qv[2 * i] * lo_bf(kk[i]) + qv[2 * i + 1] * hi_bf(kk[i]);
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1) sdot += __shfl_xor(sdot, off, 64);
+        sdot = row16_sum(sdot);
         const float mn = fmaxf(m, sdot);
         const float a = __expf(m - mn), pw = __expf(sdot - mn);
         l = l * a + pw;
@@ -713,8 +709,7 @@ __global__ __launch_bounds__(256) void attn_decode_rope_kernel(const bf16_t* __r
         float sdot = 0.f;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) sdot += qv[e] * kn[e];
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1) sdot += __shfl_xor(sdot, off, 64);
+        sdot = row16_sum(sdot);
         if (has_new && grp == 0) {
             const float mn = fmaxf(m, sdot);
             const float a = __expf(m - mn), pw = __expf(sdot - mn);
@@ -857,15 +852,15 @@ __global__ __launch_bounds__(256, (G <= 4 ? 3 : 2)) void attn_decode_gqa_kernel(
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const float keep = up8 ? v8[4 + i] : v8[i], send = up8 ? v8[i] : v8[4 + i];
-                    w4[i] = keep + __shfl_xor(send, 8, 64);
+                    w4[i] = keep + row_xor8(send);
                 }
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const float keep = up4 ? w4[2 + i] : w4[i], send = up4 ? w4[i] : w4[2 + i];
-                    x2[i] = keep + __shfl_xor(send, 4, 64);
+                    x2[i] = keep + row_xor4(send);
                 }
-                float y = (up2 ? x2[1] : x2[0]) + __shfl_xor(up2 ? x2[0] : x2[1], 2, 64);
-                y += __shfl_xor(y, 1, 64);
+                float y = (up2 ? x2[1] : x2[0]) + row_xor2(up2 ? x2[0] : x2[1]);
+                y += row_xor1(y);
                 if ((sub & 1) == 0 && j < cn) sbuf[j * 8 + (sub >> 1)] = y;   // head g = sub >> 1 (columns >= G hold zeros)
             }
         }
@@ -875,7 +870,7 @@ __global__ __launch_bounds__(256, (G <= 4 ? 3 : 2)) void attn_decode_gqa_kernel(
             const int g = tid & 7;
             float mx = -1e30f;
             for (int j = tid >> 3; j < cn; j += 32) mx = fmaxf(mx, sbuf[j * 8 + g]);
-            mx = fmaxf(mx, __shfl_xor(mx, 8, 64)); mx = fmaxf(mx, __shfl_xor(mx, 16, 64)); mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = fmaxf(mx, row_xor8(mx)); mx = fmaxf(mx, __shfl_xor(mx, 16, 64)); mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             if (lane < 8) red[wave][lane] = mx;
             __syncthreads();
             const float m_old = m_run[g];
@@ -886,7 +881,7 @@ __global__ __launch_bounds__(256, (G <= 4 ? 3 : 2)) void attn_decode_gqa_kernel(
                 sbuf[j * 8 + g] = pv;
                 sum += pv;
             }
-            sum += __shfl_xor(sum, 8, 64); sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);
+            sum += row_xor8(sum); sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);
             __syncthreads();                                             // red[] max values consumed
             if (lane < 8) red[wave][lane] = sum;
             __syncthreads();

@@ -38,6 +38,27 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// Cross-lane exchange inside a 16-lane row by DPP (data-parallel primitives: the exchange rides on a VALU instruction).  The compiler lowers
+// __shfl_xor(v, 1..8) to ds_bpermute_b32, an LDS-crossbar instruction: the key loop of the decode-attention kernels issued 4-15 of them
+// per key row (ISA, profiles/README.md r03).  lane ^ 1 and ^ 2 are quad permutes, ^ 8 is a rotation of the row by 8, ^ 4 = half-row
+// mirror (i -> 7 - i) followed by a quad reversal (j -> j ^ 3).  Same lanes, same values: results are bit-identical to the shuffles.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row_xor1(float v) { return dpp_f<0xB1>(v); }      // quad_perm [1,0,3,2]
+__device__ __forceinline__ float row_xor2(float v) { return dpp_f<0x4E>(v); }      // quad_perm [2,3,0,1]
+__device__ __forceinline__ float row_xor4(float v) { return dpp_f<0x1B>(dpp_f<0x141>(v)); }   // row_half_mirror, then quad_perm [3,2,1,0]
+__device__ __forceinline__ float row_xor8(float v) { return dpp_f<0x128>(v); }     // row_ror:8
+// butterfly sum over the 16 lanes of a row in the order 8, 4, 2, 1 (what `for (off = 8; off; off >>= 1) v += __shfl_xor(v, off)` computes)
+__device__ __forceinline__ float row16_sum(float v) {
+    v += row_xor8(v);
+    v += row_xor4(v);
+    v += row_xor2(v);
+    v += row_xor1(v);
+    return v;
+}
+
 // activations selectable in GEMM epilogues / elementwise kernels
 // ACT_SWIGLU_PAIR: the weight rows are INTERLEAVED (gate_i, up_i): out[m, j] = silu(v[m, 2j]) * v[m, 2j+1], C has N/2 columns
 // (the SwiGLU of `down(silu(gate(x)) * up(x))`, modeling_llama.py:269, fused into the gate|up projection)
