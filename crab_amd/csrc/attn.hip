@@ -774,8 +774,10 @@ __global__ __launch_bounds__(256) void attn_decode_rope_kernel(const bf16_t* __r
 // ---------------------------------------------------------------------------------------------- decode, grouped-query
 // One block per (b, kv head): every K and V row is read ONCE for the G query heads that share it (the per-(b,h) kernel
 // above re-reads it G times; Qwen2-7B: G = 7).  Keys are processed in chunks of GQ_CH:
-//   A. each 16-lane group takes a key row (16 B per lane), forms the G partial dots and reduces them with an 8-shuffle
-//      transpose-butterfly (8 values x 16 lanes -> lane pair (2g, 2g+1) holds head g's score) -> scores[key][8] in LDS
+//   A. scores on the matrix pipe (r03): a wave takes 16 keys per tile, S[head][key] = Q[16 x 128] . K^T with the G query heads as rows 0..G-1
+//      of the A operand (rows >= G are zero) and the K rows loaded STRAIGHT into B-fragment shape (lane (key = l & 15, g = l >> 4) reads the
+//      16 bytes at d = 32 ks + 8 g of its key row for each of the 4 k-steps) - 4 MFMAs per 16 keys replace 56 fmas + a 15-exchange transpose
+//      butterfly per key row and lane, and the fp32 copy of q (56 VGPRs at G = 7) is gone -> scores[key][8] in LDS
 //   B. per head: chunk max, running max / rescale factor, p = exp(s - m) in place, running sum (once per chunk)
 //   C. each 16-lane group takes a V row, reads its 8 probabilities (two broadcast float4 LDS reads) and accumulates
 //      acc[g][8 dims] += p[g] * v: no per-key exponentials or rescales
@@ -801,14 +803,16 @@ __global__ __launch_bounds__(256, (G <= 4 ? 3 : 2)) void attn_decode_gqa_kernel(
     const int b = blockIdx.y, hk = blockIdx.x;
     const int ks0 = kv_start ? kv_start[b] : 0;
     const int ctx = ctx_host + (ctx_dev ? ctx_dev[0] : 0) - ks0;
-    float qv[G][EPL];
+    // A operand of the score MFMAs: row (l & 15) = query head (zero for rows >= G), k index 8 (l >> 4) + e <-> d = 32 ks + 8 (l >> 4) + e
+    const int fr = lane & 15, fg = lane >> 4;
+    bf16x8_t qf[4];
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-        const u32x4 w = *reinterpret_cast<const u32x4*>(q + (long)b * ldq + (long)(hk * G + g) * HD + sub * EPL);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { qv[g][2 * e] = lo_bf(w[e]) * scale; qv[g][2 * e + 1] = hi_bf(w[e]) * scale; }
+    for (int ks = 0; ks < 4; ++ks) {
+        u32x4 w = {0u, 0u, 0u, 0u};
+        if (fr < G) w = *reinterpret_cast<const u32x4*>(q + (long)b * ldq + (long)(hk * G + fr) * HD + ks * 32 + fg * 8);
+        qf[ks] = __builtin_bit_cast(bf16x8_t, w);
     }
-    const bf16_t* kb = kc + (((long)b * Hk + hk) * (long)Tmax + ks0) * HD + sub * EPL;
+    const bf16_t* kfr = kc + (((long)b * Hk + hk) * (long)Tmax + ks0) * HD + fg * 8;      // + key * HD + 32 ks
     const bf16_t* vb = vc + (((long)b * Hk + hk) * (long)Tmax + ks0) * HD + sub * EPL;
     float acc[G][EPL];
 #pragma unroll
@@ -816,52 +820,35 @@ __global__ __launch_bounds__(256, (G <= 4 ? 3 : 2)) void attn_decode_gqa_kernel(
 #pragma unroll
         for (int e = 0; e < EPL; ++e) acc[g][e] = 0.f;
     if (tid < 8) { m_run[tid] = -1e30f; l_run[tid] = 0.f; }
-    const bool up8 = sub & 8, up4 = sub & 4, up2 = sub & 2;
 
     for (int c0 = 0; c0 < ctx; c0 += GQ_CH) {
         const int cn = min(GQ_CH, ctx - c0);
         __syncthreads();                                  // previous chunk's probabilities consumed, m_run/l_run visible
-        // ---- A: scores.  Uniform trip count (rows beyond the chunk are clamped and not stored) so the loop can be unrolled
-        // by hand: FOUR K rows are in flight per lane before the first dot product - this kernel is bound by bytes in flight
-        // (one 16-byte load per lane per trip gave 3.0 TB/s)
+        // ---- A: scores.  Wave w takes the 16-key tiles w, w + 4, ... of the chunk, two tiles per trip with all eight 16-byte K loads of the
+        // trip issued before the first MFMA (rows beyond the chunk are clamped and not stored)
         const int rounds = (cn + 15) >> 4;
-        for (int r0 = 0; r0 < rounds; r0 += 4) {
-            u32x4 kw4[4];
+        const int ntile = rounds;                               // 16-key tiles in this chunk
+        constexpr int TPT = G <= 4 ? 2 : 4;                     // tiles per trip: 8 or 16 K loads (128 / 256 bytes) in flight per lane
+        for (int t0 = wave; t0 < ntile; t0 += 4 * TPT) {
+            u32x4 kw[TPT][4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int jc = min((r0 + u) * 16 + grp, cn - 1);
-                kw4[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kb + (long)(c0 + jc) * HD));
+            for (int u = 0; u < TPT; ++u) {
+                const int jc = min((t0 + 4 * u) * 16 + fr, cn - 1);
+                const bf16_t* kr = kfr + (long)(c0 + jc) * HD;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) kw[u][ks] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kr + ks * 32));
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int j = (r0 + u) * 16 + grp;
-                float kx[EPL];
+            for (int u = 0; u < TPT; ++u) {
+                if (t0 + 4 * u < ntile) {                       // wave-uniform
+                    f32x4_t sc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { kx[2 * e] = lo_bf(kw4[u][e]); kx[2 * e + 1] = hi_bf(kw4[u][e]); }
-                float v8[8];
-#pragma unroll
-                for (int g = 0; g < 8; ++g) {
-                    float d = 0.f;
-                    if (g < G) {
-#pragma unroll
-                        for (int e = 0; e < EPL; ++e) d += qv[g < G ? g : 0][e] * kx[e];
-                    }
-                    v8[g] = d;
+                    for (int ks = 0; ks < 4; ++ks)
+                        sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[ks], __builtin_bit_cast(bf16x8_t, kw[u][ks]), sc, 0, 0, 0);
+                    // D: lane (key = l & 15, heads 4 (l >> 4) + r): lane groups 0 / 1 hold heads 0-3 / 4-7 of their key
+                    const int j = (t0 + 4 * u) * 16 + fr;
+                    if (fg < 2 && j < cn) *reinterpret_cast<f32x4_t*>(sbuf + j * 8 + fg * 4) = sc * scale;
                 }
-                float w4[4], x2[2];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float keep = up8 ? v8[4 + i] : v8[i], send = up8 ? v8[i] : v8[4 + i];
-                    w4[i] = keep + row_xor8(send);
-                }
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const float keep = up4 ? w4[2 + i] : w4[i], send = up4 ? w4[i] : w4[2 + i];
-                    x2[i] = keep + row_xor4(send);
-                }
-                float y = (up2 ? x2[1] : x2[0]) + row_xor2(up2 ? x2[0] : x2[1]);
-                y += row_xor1(y);
-                if ((sub & 1) == 0 && j < cn) sbuf[j * 8 + (sub >> 1)] = y;   // head g = sub >> 1 (columns >= G hold zeros)
             }
         }
         __syncthreads();
@@ -900,25 +887,27 @@ __global__ __launch_bounds__(256, (G <= 4 ? 3 : 2)) void attn_decode_gqa_kernel(
 #pragma unroll
             for (int e = 0; e < EPL; ++e) acc[g][e] *= a;
         }
-        for (int r0 = 0; r0 < rounds; r0 += 4) {
-            u32x4 vw4[4];
-            f32x4_t p04[4], p14[4];
+        constexpr int RPT = G <= 4 ? 4 : 6;                     // V rows per trip: 64 / 96 bytes in flight per lane (8 rows spill at G >= 7)
+        for (int r0 = 0; r0 < rounds; r0 += RPT) {
+            u32x4 vw[RPT];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int j = (r0 + u) * 16 + grp, jc = min(j, cn - 1);
-                vw4[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vb + (long)(c0 + jc) * HD));
-                p04[u] = *reinterpret_cast<const f32x4_t*>(sbuf + jc * 8);
-                p14[u] = *reinterpret_cast<const f32x4_t*>(sbuf + jc * 8 + 4);
-                if (j >= cn) { p04[u] = f32x4_t{0.f, 0.f, 0.f, 0.f}; p14[u] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+            for (int u = 0; u < RPT; ++u) {
+                const int jc = min((r0 + u) * 16 + grp, cn - 1);
+                vw[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vb + (long)(c0 + jc) * HD));
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < RPT; ++u) {
+                // the row's 8 probabilities are read right before use (two broadcast float4 LDS reads)
+                const int j = (r0 + u) * 16 + grp, jc = min(j, cn - 1);
+                f32x4_t p0 = *reinterpret_cast<const f32x4_t*>(sbuf + jc * 8);
+                f32x4_t p1 = *reinterpret_cast<const f32x4_t*>(sbuf + jc * 8 + 4);
+                if (j >= cn) { p0 = f32x4_t{0.f, 0.f, 0.f, 0.f}; p1 = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
                 float vx[EPL];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { vx[2 * e] = lo_bf(vw4[u][e]); vx[2 * e + 1] = hi_bf(vw4[u][e]); }
+                for (int e = 0; e < 4; ++e) { vx[2 * e] = lo_bf(vw[u][e]); vx[2 * e + 1] = hi_bf(vw[u][e]); }
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
-                    const float pg = g < 4 ? p04[u][g & 3] : p14[u][g & 3];
+                    const float pg = g < 4 ? p0[g & 3] : p1[g & 3];
 #pragma unroll
                     for (int e = 0; e < EPL; ++e) acc[g][e] += pg * vx[e];
                 }
