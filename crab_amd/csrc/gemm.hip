@@ -429,8 +429,12 @@ int crab_gemm_dec_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* d, 
 // ~4 us + the fp32 slabs written and read back at ~4.5 TB/s while they stay MALL / L2 resident (<= 40 MB) and ~2 TB/s beyond.
 static void dec_choose(const crab_gemm_desc* d, int nks /* 64-wide K slots */, int* bn_out, int* split_out) {
     double best = 1e30;
-    for (int bi = 0; bi < 2; ++bi) {
-        const int bn = bi ? 64 : 96;
+    for (int bi = 0; bi < 3; ++bi) {
+        // 160-wide panels (r03), only for projections too wide for ONE round of 96-wide panels: Qwen2-7B gate|up (37888 columns = 395 panels =
+        // 2 rounds, the second 54 % empty) runs as one round of 237 (97.8 -> 71.9 us), the lm_heads in 1 instead of 2 (Llama, 114 -> 88 us) and 4
+        // instead of 7 rounds (Qwen2, 403 -> 357 us); narrower projections lose (activation bytes per block stay, blocks get fewer)
+        const int bn = bi == 0 ? 96 : (bi == 1 ? 64 : 160);
+        if (bn == 160 && (d->N + 95) / 96 <= 256) continue;
         const long tiles = (d->N + bn - 1) / bn;
         for (int sp = 1; sp <= 8 && sp * 4 <= nks; ++sp) {
             const long blocks = tiles * sp;
@@ -440,7 +444,7 @@ static void dec_choose(const crab_gemm_desc* d, int nks /* 64-wide K slots */, i
             const double slab = (double)sp * d->M * d->N * 4.0;
             if (sp > 1 && slab > (double)d->workspace_bytes) continue;
             const double bytes = (256.0 + bn) * per * 64 * 2;
-            const double t = rounds * ((bn == 96 ? 10.0 : 7.0) + bytes / 58.0e3) + (sp > 1 ? 4.0 + 2.0 * slab / (slab <= 40.0e6 ? 4.5e6 : 2.0e6) : 0.0);
+            const double t = rounds * ((bn == 64 ? 7.0 : 10.0) + bytes / 58.0e3) + (sp > 1 ? 4.0 + 2.0 * slab / (slab <= 40.0e6 ? 4.5e6 : 2.0e6) : 0.0);
             if (t < best) { best = t; *bn_out = bn; *split_out = sp; }
         }
     }
@@ -703,6 +707,8 @@ extern "C" int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc*
             while (splitk > 1 && (int64_t)splitk * d->M * d->N * 4 > d->workspace_bytes) --splitk;
             const int per2 = (nk32 + splitk - 1) / splitk;                // the clamp may leave a remainder slice empty: normalise again
             splitk = (nk32 + per2 - 1) / per2;
+        } else if (d->tune == 91601) {                                  // A/B: 160-wide panels, one K slice
+            dec_bn = 160; splitk = 1;
         } else if (d->tune == 0 && dec_on) {
             dec_choose(d, nk32, &dec_bn, &splitk);
         }

@@ -64,7 +64,7 @@ __global__ __launch_bounds__(512) void gemm_dec_kernel(GemmDP p) {
     constexpr int PBW = (PB + 7) / 8;                        // weight pieces per wave per slot, waves < PB - 8 * (PBW - 1) take PBW
     constexpr int NPW = PAW + PBW;
     constexpr int SLOT_ELEMS = (BM + BN) * DBK;
-    static_assert(BN % 16 == 0 && PBW <= 2 && NS >= 3 && NS * SLOT_ELEMS * 2 <= 160 * 1024, "tile / ring geometry");
+    static_assert(BN % 16 == 0 && PBW <= 3 && NS >= 3 && NS * SLOT_ELEMS * 2 <= 160 * 1024, "tile / ring geometry");
     __shared__ __attribute__((aligned(16))) bf16_t lds[NS * SLOT_ELEMS];
 
     const int tid = threadIdx.x;
@@ -242,9 +242,12 @@ __global__ __launch_bounds__(512) void gemm_dec_kernel(GemmDP p) {
     }
 #define STEP(NI_) MFMA_GROUP(w1, x1, NI_, (NI_) + 1)
 #define SB __builtin_amdgcn_sched_barrier(0);
-        static_assert((TN == 6 && NPW == 6) || (TN == 4 && NPW == 5), "piece schedule below is written for BN 96 / 64");
+        static_assert((TN == 6 && NPW == 6) || (TN == 4 && NPW == 5) || (TN == 10 && NPW == 7), "piece schedule below is written for BN 96 / 64 / 160");
         if constexpr (TN == 6) {
             STEP(0) PIECE(0) SB STEP(1) PIECE(1) SB STEP(2) PIECE(2) SB STEP(3) PIECE(3) SB STEP(4) PIECE(4) SB STEP(5) PIECE(5) SB
+        } else if constexpr (TN == 10) {
+            STEP(0) PIECE(0) SB STEP(1) PIECE(1) SB STEP(2) SB STEP(3) PIECE(2) SB STEP(4) PIECE(3) SB STEP(5) SB STEP(6) PIECE(4) SB STEP(7) PIECE(5) SB
+            STEP(8) PIECE(6) SB STEP(9) SB
         } else {
             STEP(0) PIECE(0) SB STEP(1) PIECE(1) SB STEP(2) PIECE(2) PIECE(3) SB STEP(3) PIECE(4) SB
         }
@@ -532,10 +535,16 @@ int crab_gemm_dec_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* d, 
     static const int ws_on = []() { const char* e = getenv("CRAB_DEC_WS"); return !(e && e[0] == '0'); }();
     // nt_weights: 1 = the shipped form (producer / consumer, non-temporal weight loads), 2 = the 8-wave kernel (tune 8xxxx), 0 = the
     // 8-wave kernel with default-policy weight loads
+    if (bn == 160) {
+        // 160-wide panels (a projection too wide for one round of 96-wide panels): 80 accumulator + 96 fragment VGPRs per consumer wave do
+        // not fit three waves per SIMD (108 spills in the producer / consumer form): the 8-wave form, non-temporal weight loads
+        hipLaunchKernelGGL((gemm_dec_kernel<160, 3, true>), grid, dim3(512), 0, s, p);
+        return crab_check_launch(ctx, "gemm_dec_kernel<160>");
+    }
     if (ws_on && nt_weights == 1) {                     // CRAB_DEC_WS=0: the 8-wave kernel process-wide (A/B runs)
         if (bn == 96) hipLaunchKernelGGL((gemm_dec_ws_kernel<96, 3, true>), grid, dim3(768), 0, s, p);
         else if (bn == 64) hipLaunchKernelGGL((gemm_dec_ws_kernel<64, 4, true>), grid, dim3(768), 0, s, p);
-        else return crab_fail(ctx, CRAB_E_INVALID, "gemm_dec: bn must be 64 or 96");
+        else return crab_fail(ctx, CRAB_E_INVALID, "gemm_dec: bn must be 64, 96 or 160");
         return crab_check_launch(ctx, "gemm_dec_ws_kernel");
     }
     if (bn == 96) {

@@ -43,6 +43,7 @@ for name, N, K, K2, act in shapes:
     for bn in (96, 64):
         for sp in (1, 2, 3, 4, 6, 8):
             tunes.append((f"bn{bn}x{sp}", 70000 + bn * 100 + sp))
+    tunes.append(("bn160x1", 91601))
     for label, tune in tunes:
         i = [0]
 

@@ -508,10 +508,11 @@ def test_gemm_splitk_decode_regime(M, tune):
 
 
 @pytest.mark.parametrize("M", [129, 200, 256])
-@pytest.mark.parametrize("tune", [79601, 79602, 76401, 76404, 79605, 89602, 86404, 0])
+@pytest.mark.parametrize("tune", [79601, 79602, 76401, 76404, 79605, 89602, 86404, 91601, 0])
 def test_gemm_decode_panel_kernel(M, tune):
     """The decode panel kernels (128 < M <= 256: the whole batch x a 96- or 64-wide weight panel per block; tune = 70000 + BN * 100 + K
-    slices on the producer / consumer kernel, 80000 + ... on the 8-wave kernel, 0 = automatic choice): ragged N (last panel partly outside),
+    slices on the producer / consumer kernel, 80000 + ... on the 8-wave kernel, 91601 = 160-wide panels (projections wider than one round of
+    96-wide panels), 0 = automatic choice): ragged N (last panel partly outside),
     K not a multiple of the 64-wide slot, a second K segment, every epilogue input (bias, GELU, residual), fp32 and bf16 outputs;
     deterministic; the two kernels issue the same MFMAs in the same order: bit-identical."""
     from crab_amd import ops
@@ -527,6 +528,9 @@ def test_gemm_decode_panel_kernel(M, tune):
     if 70000 <= tune < 80000:
         args["tune"] = tune + 10000
         assert torch.equal(y, ops.gemm(x.cuda(), w.cuda(), out_fp32=True, **args)), "producer / consumer kernel != 8-wave kernel"
+    if tune == 91601:                           # same K order, same MFMAs per output element as the 96-wide panels with one K slice
+        args["tune"] = 79601
+        assert torch.equal(y, ops.gemm(x.cuda(), w.cuda(), out_fp32=True, **args)), "160-wide panels != 96-wide panels"
 
 
 @pytest.mark.parametrize("name,N,K,K2", [("qkv", 12288, 4096, 96), ("o", 4096, 4096, 32), ("gate|up", 22016, 4096, 64), ("down", 4096, 11008, 32),
