@@ -27,17 +27,6 @@ __device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf2(f, 0.
 __device__ __forceinline__ float lo_bf(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float hi_bf(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
-}
-
 // Cross-lane exchange inside a 16-lane row by DPP (data-parallel primitives: the exchange rides on a VALU instruction).  The compiler lowers
 // __shfl_xor(v, 1..8) to ds_bpermute_b32, an LDS-crossbar instruction: the key loop of the decode-attention kernels issued 4-15 of them
 // per key row (ISA, profiles/README.md r03).  lane ^ 1 and ^ 2 are quad permutes, ^ 8 is a rotation of the row by 8, ^ 4 = half-row
@@ -56,6 +45,23 @@ __device__ __forceinline__ float row16_sum(float v) {
     v += row_xor4(v);
     v += row_xor2(v);
     v += row_xor1(v);
+    return v;
+}
+
+// wave-wide butterflies in the order 32, 16, 8, 4, 2, 1: the two cross-row steps by shuffle, the four in-row steps by DPP (same pairs,
+// same order: bit-identical to the all-shuffle form)
+__device__ __forceinline__ float wave_sum(float v) {
+    v += __shfl_xor(v, 32, 64);
+    v += __shfl_xor(v, 16, 64);
+    return row16_sum(v);
+}
+__device__ __forceinline__ float wave_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 32, 64));
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    v = fmaxf(v, row_xor8(v));
+    v = fmaxf(v, row_xor4(v));
+    v = fmaxf(v, row_xor2(v));
+    v = fmaxf(v, row_xor1(v));
     return v;
 }
 

@@ -94,8 +94,7 @@ __global__ __launch_bounds__(256) void rowfin_apply_kernel(RowfinApplyP p) {
         const float x0 = lo_bf(w0), x1 = hi_bf(w0), x2 = lo_bf(w1), x3 = hi_bf(w1);      // the norm sees the stored bf16 values
         ss = (x0 * x0 + x1 * x1) + (x2 * x2 + x3 * x3);
     }
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    ss = row16_sum(ss);
     if (q == 0) p.ssq[blockIdx.x * 16 + m] = m < p.M ? ss : 0.f;
 }
 
@@ -141,8 +140,7 @@ __global__ __launch_bounds__(256) void rowfin_route_kernel(RowfinRouteP p) {
     float ss = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) ss += sp[i];
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    ss = row16_sum(ss);
     const float rstd = rsqrtf(ss / (float)p.N + p.eps);
     float hf[4] = {0.f, 0.f, 0.f, 0.f};
     if (live) {
@@ -163,8 +161,7 @@ __global__ __launch_bounds__(256) void rowfin_route_kernel(RowfinRouteP p) {
             for (int q2 = 0; q2 < 16; ++q2) {
                 const u32x2 w = *reinterpret_cast<const u32x2*>(&ras[jj * 16 + q2][q * 4]);
                 float a = (hf[0] * lo_bf(w[0]) + hf[1] * hi_bf(w[0])) + (hf[2] * lo_bf(w[1]) + hf[3] * hi_bf(w[1]));
-#pragma unroll
-                for (int o = 8; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+                a = row16_sum(a);
                 if (q == jj * 4 + (q2 >> 2)) keep[q2 & 3] = a;
             }
         }
