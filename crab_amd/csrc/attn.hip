@@ -604,6 +604,28 @@ __global__ __launch_bounds__(256) void attn_decode_rope_kernel(const bf16_t* __r
         kw[i] = reinterpret_cast<const uint32_t*>(row + (long)(H + hk) * HD + sub * EPL)[i];
         vw[i] = reinterpret_cast<const uint32_t*>(row + (long)(H + Hk + hk) * HD + sub * EPL)[i];
     }
+    // ---- this split's keys: cached rows [kb0, kb0 + nc), and the new key from registers when pos falls in the split
+    const long crow = ((long)b * Hk + hk) * (long)Tmax;
+    const int chunk = (pos + nsplit) / nsplit;                  // ceil((pos + 1) / nsplit)
+    const int kb0 = z * chunk, ke0 = min(pos + 1, kb0 + chunk);
+    const int nc = min(ke0, pos) - kb0;
+    const bool has_new = pos >= kb0 && pos < ke0;
+    const bf16_t* kb = kc + (crow + kb0) * HD + sub * EPL;
+    const bf16_t* vb = vc + (crow + kb0) * HD + sub * EPL;
+    // HD = 128: the first NB cached keys of every 16-lane group (8 x 16 = 128 keys per block: a whole split at the context lengths of the
+    // benchmark) are requested HERE, unconditionally (clamped rows, masked later), in the same memory round trip as the q|k|v row and the
+    // rotation table: r02's two-keys-per-trip loop with conditional loads cost one round trip per 32 keys plus one for the prologue (ISA: the
+    // compiler waited for the prefetched pair at the bottom of every trip) - ~5 of this kernel's 12 us at one clip
+    constexpr int NB = 8;
+    u32x4 kk[EPL == 8 ? NB : 1], vv[EPL == 8 ? NB : 1];
+    if (EPL == 8) {
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int jc = max(min(grp + 16 * u, nc - 1), 0);   // nc == 0: row kb0 <= pos is inside the cache, its value is never used
+            kk[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kb + (long)jc * HD));
+            vv[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vb + (long)jc * HD));
+        }
+    }
     float qv[EPL], kn[EPL], vn[EPL];
     uint32_t kst[WPL];
 #pragma unroll
@@ -623,7 +645,6 @@ __global__ __launch_bounds__(256) void attn_decode_rope_kernel(const bf16_t* __r
         kn[2 * i] = lo_bf(kst[i]); kn[2 * i + 1] = hi_bf(kst[i]);
         vn[2 * i] = lo_bf(vw[i]); vn[2 * i + 1] = hi_bf(vw[i]);
     }
-    const long crow = ((long)b * Hk + hk) * (long)Tmax;
     if (z == 0 && h % G == 0 && grp == 0) {                     // append for the following steps
 #pragma unroll
         for (int i = 0; i < WPL; ++i) {
@@ -631,76 +652,72 @@ __global__ __launch_bounds__(256) void attn_decode_rope_kernel(const bf16_t* __r
             reinterpret_cast<uint32_t*>(vc + (crow + pos) * HD + sub * EPL)[i] = vw[i];
         }
     }
-    // ---- this split's keys: cached rows [kb0, kb0 + nc), and the new key from registers when pos falls in the split
-    const int chunk = (pos + nsplit) / nsplit;                  // ceil((pos + 1) / nsplit)
-    const int kb0 = z * chunk, ke0 = min(pos + 1, kb0 + chunk);
-    const int nc = min(ke0, pos) - kb0;
-    const bool has_new = pos >= kb0 && pos < ke0;
-    const bf16_t* kb = kc + (crow + kb0) * HD + sub * EPL;
-    const bf16_t* vb = vc + (crow + kb0) * HD + sub * EPL;
     float m = -1e30f, l = 0.f, acc[EPL];
 #pragma unroll
     for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
     if (EPL == 8) {
-        // two keys per trip, the next pair requested before the current one is consumed (the schedule of attn_decode_kernel)
-        const u32x4 z4 = {0u, 0u, 0u, 0u};
-        u32x4 k0 = z4, v0 = z4, k1 = z4, v1 = z4;
-        if (grp < nc) {
-            k0 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kb + (long)grp * HD));
-            v0 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vb + (long)grp * HD));
-        }
-        if (grp + 16 < nc) {
-            k1 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kb + (long)(grp + 16) * HD));
-            v1 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vb + (long)(grp + 16) * HD));
-        }
-        for (int j = grp; j < nc; j += 32) {
-            u32x4 kn0 = z4, vn0 = z4, kn1 = z4, vn1 = z4;
-            if (j + 32 < nc) {
-                kn0 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kb + (long)(j + 32) * HD));
-                vn0 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vb + (long)(j + 32) * HD));
-            }
-            if (j + 48 < nc) {
-                kn1 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kb + (long)(j + 48) * HD));
-                vn1 = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vb + (long)(j + 48) * HD));
-            }
-            float s0 = 0.f, s1 = 0.f;
+        // NB keys per group and trip: NB scores, ONE running-max update and rescale, then the weighted V rows; keys beyond the split are
+        // masked (probability 0, V row replaced by zeros: the clamped row may hold anything)
+        for (int j0 = 0; j0 < nc; j0 += 16 * NB) {
+            if (j0 > 0) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                s0 += qv[2 * e] * lo_bf(k0[e]) + qv[2 * e + 1] * hi_bf(k0[e]);
-                s1 += qv[2 * e] * lo_bf(k1[e]) + qv[2 * e + 1] * hi_bf(k1[e]);
+                for (int u = 0; u < NB; ++u) {
+                    const int jc = min(j0 + grp + 16 * u, nc - 1);
+                    kk[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kb + (long)jc * HD));
+                    vv[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vb + (long)jc * HD));
+                }
             }
-            s0 = row16_sum(s0); s1 = row16_sum(s1);
-            const bool has1 = j + 16 < nc;                      // group-uniform
-            const float mn = fmaxf(m, has1 ? fmaxf(s0, s1) : s0);
-            const float a = __expf(m - mn), p0 = __expf(s0 - mn), p1 = has1 ? __expf(s1 - mn) : 0.f;
-            l = l * a + (p0 + p1);
+            float sc[NB], mx = -1e30f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                acc[2 * e] = acc[2 * e] * a + (p0 * lo_bf(v0[e]) + p1 * lo_bf(v1[e]));
-                acc[2 * e + 1] = acc[2 * e + 1] * a + (p0 * hi_bf(v0[e]) + p1 * hi_bf(v1[e]));
+            for (int u = 0; u < NB; ++u) {
+                float d = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) d += qv[2 * e] * lo_bf(kk[u][e]) + qv[2 * e + 1] * hi_bf(kk[u][e]);
+                d = row16_sum(d);
+                sc[u] = j0 + grp + 16 * u < nc ? d : -INFINITY;  // group-uniform
+                mx = fmaxf(mx, sc[u]);
             }
+            const float mn = fmaxf(m, mx);
+            const float a = __expf(m - mn);
+            float ps = 0.f, t[EPL];
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) t[e] = 0.f;
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const bool ok = j0 + grp + 16 * u < nc;
+                const float pw = __expf(sc[u] - mn);            // exp(-inf) = 0 for the masked keys
+                ps += pw;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t w = ok ? vv[u][e] : 0u;
+                    t[2 * e] += pw * lo_bf(w);
+                    t[2 * e + 1] += pw * hi_bf(w);
+                }
+            }
+            l = l * a + ps;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) acc[e] = acc[e] * a + t[e];
             m = mn;
-            k0 = kn0; v0 = vn0; k1 = kn1; v1 = vn1;
         }
     } else {
     for (int j = grp; j < nc; j += 16) {
-        uint32_t kk[WPL], vv[WPL];
+        uint32_t kk2[WPL], vv2[WPL];
 #pragma unroll
         for (int i = 0; i < WPL; ++i) {
-            kk[i] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(kb + (long)j * HD) + i);
-            vv[i] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(vb + (long)j * HD) + i);
+            kk2[i] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(kb + (long)j * HD) + i);
+            vv2[i] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(vb + (long)j * HD) + i);
         }
         float sdot = 0.f;
 #pragma unroll
-        for (int i = 0; i < WPL; ++i) sdot += qv[2 * i] * lo_bf(kk[i]) + qv[2 * i + 1] * hi_bf(kk[i]);
+        for (int i = 0; i < WPL; ++i) sdot += qv[2 * i] * lo_bf(kk2[i]) + qv[2 * i + 1] * hi_bf(kk2[i]);
         sdot = row16_sum(sdot);
         const float mn = fmaxf(m, sdot);
         const float a = __expf(m - mn), pw = __expf(sdot - mn);
         l = l * a + pw;
 #pragma unroll
         for (int i = 0; i < WPL; ++i) {
-            acc[2 * i] = acc[2 * i] * a + pw * lo_bf(vv[i]);
-            acc[2 * i + 1] = acc[2 * i + 1] * a + pw * hi_bf(vv[i]);
+            acc[2 * i] = acc[2 * i] * a + pw * lo_bf(vv2[i]);
+            acc[2 * i + 1] = acc[2 * i + 1] * a + pw * hi_bf(vv2[i]);
         }
         m = mn;
     }
@@ -758,14 +775,28 @@ __global__ __launch_bounds__(256) void attn_decode_rope_kernel(const bf16_t* __r
     }
     __syncthreads();
     if (tid < HD) {
+        // every partial of every split is requested before the first is used (<= 8 splits: the workspace is sized for 8): the two loops over
+        // a runtime split count compiled to one dependent load after the other - up to 16 serial trips to memory on the critical path
         const float* base = part + (long)(b * H + h) * nsplit * (HD + 2);
+        constexpr int MAXS = 8;
+        float mv[MAXS], lv[MAXS], ov[MAXS];
+#pragma unroll
+        for (int s2 = 0; s2 < MAXS; ++s2) {
+            const float* bs = base + min(s2, nsplit - 1) * (HD + 2);
+            mv[s2] = bs[HD]; lv[s2] = bs[HD + 1]; ov[s2] = bs[tid];
+        }
         float Mt = -1e30f;
-        for (int s2 = 0; s2 < nsplit; ++s2) Mt = fmaxf(Mt, base[s2 * (HD + 2) + HD]);
+#pragma unroll
+        for (int s2 = 0; s2 < MAXS; ++s2)
+            if (s2 < nsplit) Mt = fmaxf(Mt, mv[s2]);
         float Lt = 0.f, Ot = 0.f;
-        for (int s2 = 0; s2 < nsplit; ++s2) {                   // split order, whatever the order of arrival
-            const float w = __expf(base[s2 * (HD + 2) + HD] - Mt);
-            Lt += base[s2 * (HD + 2) + HD + 1] * w;
-            Ot += base[s2 * (HD + 2) + tid] * w;
+#pragma unroll
+        for (int s2 = 0; s2 < MAXS; ++s2) {                     // split order, whatever the order of arrival
+            if (s2 < nsplit) {
+                const float w = __expf(mv[s2] - Mt);
+                Lt += lv[s2] * w;
+                Ot += ov[s2] * w;
+            }
         }
         o[(long)b * ldo + (long)h * HD + tid] = f2bf(Ot / Lt);
     }

@@ -115,22 +115,31 @@ __global__ __launch_bounds__(256) void rowfin_route_kernel(RowfinRouteP p) {
     const int c0 = blockIdx.x * RF_CW, c = c0 + q * 4;
     const int used = p.RA ? p.nproj * (p.nl + p.r) : 0;       // <= RF_TJ (host)
     const int used16 = (used + 15) & ~15;
-    // ---- every global load first (one round trip): the [R;A] slice (two 16-byte chunks per thread), the partial sums of squares, x, w
-    u32x4 rv[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+    // ---- every global load first (one round trip): the [R;A] slice (two 16-byte chunks per thread), the partial sums of squares, x, w.
+    // The loads are UNCONDITIONAL (clamped addresses, values masked afterwards): with `cond ? load : 0` the compiler sank the first use into
+    // the first conditional block and waited there (vmcnt(0) behind the first 4-byte load: a second, serialised memory round trip; ISA, r03)
+    u32x4 rv[2];
+    const bf16_t* ra = p.RA ? p.RA : p.X;                     // no adapter: any readable row (the values are masked), so that no branch
+    const long ldra = p.RA ? p.ldra : p.ldx;                  // separates these loads from the ones below
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int idx = tid + i * 256, j = idx >> 3, ch = idx & 7;
-        if (j < used && c0 + ch * 8 < p.N) rv[i] = *reinterpret_cast<const u32x4*>(p.RA + (long)j * p.ldra + c0 + ch * 8);
+        const int jc = p.RA ? min(j, used - 1) : 0, cc = min(c0 + ch * 8, p.N - 8);
+        rv[i] = *reinterpret_cast<const u32x4*>(ra + (long)jc * ldra + cc);
     }
     float sp[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) sp[i] = q + i * 16 < p.nb ? p.ssq[(q + i * 16) * 16 + m] : 0.f;       // nb <= 128 (host)
+    for (int i = 0; i < 8; ++i) sp[i] = p.ssq[min(q + i * 16, p.nb - 1) * 16 + m];       // nb <= 128 (host)
     const bool live = m < p.M && c < p.N;
-    u32x2 xw = {0u, 0u}, ww = {0u, 0u};
-    if (live) {
-        xw = *reinterpret_cast<const u32x2*>(p.X + (long)m * p.ldx + c);
-        ww = *reinterpret_cast<const u32x2*>(p.nw + c);
+    u32x2 xw = *reinterpret_cast<const u32x2*>(p.X + (long)min(m, p.M - 1) * p.ldx + min(c, p.N - 4));
+    u32x2 ww = *reinterpret_cast<const u32x2*>(p.nw + min(c, p.N - 4));
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = tid + i * 256, j = idx >> 3, ch = idx & 7;
+        if (!(j < used && c0 + ch * 8 < p.N)) rv[i] = u32x4{0u, 0u, 0u, 0u};
     }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sp[i] = q + i * 16 < p.nb ? sp[i] : 0.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int idx = tid + i * 256, j = idx >> 3, ch = idx & 7;
