@@ -621,9 +621,11 @@ __global__ __launch_bounds__(256) void attn_decode_rope_kernel(const bf16_t* __r
     if (EPL == 8) {
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
-            const int jc = max(min(grp + 16 * u, nc - 1), 0);   // nc == 0: row kb0 <= pos is inside the cache, its value is never used
-            kk[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kb + (long)jc * HD));
-            vv[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vb + (long)jc * HD));
+            // clamped in ABSOLUTE rows: an empty split (kb0 beyond pos; nc <= 0) must not read past this head's cache rows - it reads row
+            // max(pos - 1, 0) or an earlier one, whose value is never used
+            const int ja = max(min(kb0 + grp + 16 * u, kb0 + nc - 1), 0) - kb0;
+            kk[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kb + (long)ja * HD));
+            vv[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vb + (long)ja * HD));
         }
     }
     float qv[EPL], kn[EPL], vn[EPL];

@@ -629,7 +629,9 @@ def test_small_batch_layer_tail_rowfin(M, N, K, nproj_next):
 
 
 @pytest.mark.parametrize("hd,B,H,Hk,pos", [(128, 1, 32, 32, 702), (128, 1, 32, 32, 5), (128, 8, 32, 32, 830), (128, 2, 28, 4, 333), (64, 3, 4, 2, 0),
-                                           (64, 1, 4, 4, 77), (128, 16, 32, 32, 100)])
+                                           (64, 1, 4, 4, 77), (128, 16, 32, 32, 100),
+                                           # empty splits (8 splits, fewer keys), the first token, more than 128 keys per split, the last cache row
+                                           (128, 1, 4, 4, 0), (128, 1, 4, 4, 3), (128, 4, 32, 32, 1000), (128, 2, 8, 8, 1022)])
 def test_decode_attention_fused_rope_append_split(hd, B, H, Hk, pos):
     """crab_attn_decode_rope vs crab_qkv_rope_split + crab_attn_decode: the cache rows it appends are BIT-identical (same rotation,
     same rounding), the attention output agrees to the accumulation order (new key last, splits merged in order), for one block per
