@@ -566,7 +566,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
 }
 
 
-// ---------------------------------------------------------------------------------------------- decode, small batch (B * H < 256)
+// ---------------------------------------------------------------------------------------------- decode, small batch (B * H <= 256)
 // attn_decode_rope_kernel: the decode attention of the reference's own batch sizes (1 and 8 clips, scripts/quick_start.py:43,
 // inference_hyper_lora.py:1477) with what surrounded it folded in:
 //   * RoPE of q and of the new k (modeling_llama.py:204-236) and the KV-cache append (:408-412) happen HERE, from the raw packed q|k|v
@@ -1038,11 +1038,13 @@ extern "C" int crab_attn_decode_rope(crab_ctx* ctx, void* stream, const void* qk
     if (d != 64 && d != 128) return crab_fail(ctx, CRAB_E_UNSUPPORTED, "attn_decode_rope: head_dim must be 64 or 128");
     if ((ldqkv & 7) || ((uintptr_t)qkv & 15) || ((uintptr_t)k_cache & 15) || ((uintptr_t)v_cache & 15)) return crab_fail(ctx, CRAB_E_INVALID, "attn_decode_rope: alignment");
     if (!pos_dev && (pos0 < 0 || pos0 >= Tmax)) return crab_fail(ctx, CRAB_E_INVALID, "attn_decode_rope: position outside the KV cache");
-    // split while (b, h) alone leaves CUs idle.  Measured at B = 8 (256 heads, 830 keys): fused 1 split 28.9 us, fused 8 splits 27.7 us,
-    // unfused pair 21.6 + 4.9 us - beyond one block per CU the per-block chain (position -> table -> rotate -> stream -> publish -> ticket)
-    // costs what the extra parallelism gives; at B = 1 (32 heads) 8 splits take 12.3 us against 19.0 + 4.8
+    // split while (b, h) alone leaves CUs idle: up to 8 splits, ~two blocks per CU (r03, after every load of the kernel moved into its first
+    // memory round trip: a block keeps 64 KB of K / V in flight, two of them saturate a CU's queue).  Decode step at 2 / 3 / 4 / 8 clips with a
+    // 256- vs 512-block target: 3.865 / 4.015 / 4.092 / 4.514 vs 3.820 / 3.948 / 3.994 / 4.482 ms (768: slower again); one clip has 8 splits
+    // either way.  CRAB_ATTN_BLOCKS overrides the target (A/B runs).
     int nsplit = 1;
-    if ((long)B * H < 256) { nsplit = (int)(256 / ((long)B * H)); if (nsplit > 8) nsplit = 8; }      // ~one block per CU
+    static const int tgt = []() { const char* e = getenv("CRAB_ATTN_BLOCKS"); return e ? atoi(e) : 512; }();
+    if ((long)B * H < tgt) { nsplit = (int)(tgt / ((long)B * H)); if (nsplit > 8) nsplit = 8; }
     if (nsplit > 1 && (!workspace || workspace_bytes < crab_attn_decode_rope_workspace(B, H, d)))
         return crab_fail(ctx, CRAB_E_WORKSPACE, "attn_decode_rope: needs crab_attn_decode_rope_workspace(B, H, d) bytes (counters zeroed once)");
     float* part = (float*)workspace;

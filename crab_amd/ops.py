@@ -316,7 +316,7 @@ def attn_decode(q, k_cache, v_cache, o, B, H, Hk, head_dim, Tmax, ctx_len, scale
     return o
 
 
-ATTN_SPLIT_BELOW = 129           # CRAB_ATTN_SPLIT_BELOW of include/crab_hip.h
+ATTN_SPLIT_BELOW = 257           # CRAB_ATTN_SPLIT_BELOW of include/crab_hip.h
 
 
 def attn_decode_rope_bytes(B: int, H: int, d: int) -> int:

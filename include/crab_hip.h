@@ -194,8 +194,8 @@ int crab_attn_decode_masked(crab_ctx* ctx, void* stream, const void* q, int64_t 
  * to 8 blocks per (b, h) while B * H < 256 (about one block per CU), merged by the last split to finish (deterministic).  workspace:
  * crab_attn_decode_rope_workspace(B, H, d) bytes whose LAST B * H * 4 bytes (the tickets) the caller zero-fills once; the call
  * leaves them zero.  May be NULL when B * H >= 256.  crab_llama_layers / crab_amd/decoder.py pick this entry point while
- * B * H < CRAB_ATTN_SPLIT_BELOW (at least two splits per head; with one block per head the unfused pair measured faster). */
-#define CRAB_ATTN_SPLIT_BELOW 129    /* the fused small-batch attention is used while B * H is below this: at least two context splits per head */
+ * B * H < CRAB_ATTN_SPLIT_BELOW (at least two context splits per head: the reference's batch sizes 1 .. 8 with 32 heads). */
+#define CRAB_ATTN_SPLIT_BELOW 257    /* the fused small-batch attention is used while B * H is below this (512-block target: >= 2 context splits per head) */
 int64_t crab_attn_decode_rope_workspace(int B, int H, int d);
 int crab_attn_decode_rope(crab_ctx* ctx, void* stream, const void* qkv, int64_t ldqkv, const float* rope_tab, void* k_cache,
                           void* v_cache, void* o, int64_t ldo, int B, int H, int Hk, int d, int Tmax, int pos0,

@@ -635,7 +635,7 @@ def test_small_batch_layer_tail_rowfin(M, N, K, nproj_next):
 def test_decode_attention_fused_rope_append_split(hd, B, H, Hk, pos):
     """crab_attn_decode_rope vs crab_qkv_rope_split + crab_attn_decode: the cache rows it appends are BIT-identical (same rotation,
     same rounding), the attention output agrees to the accumulation order (new key last, splits merged in order), for one block per
-    (b, h) and for the context split over up to 8 blocks (B * H < 256), GQA included; two consecutive calls (tickets back to zero)."""
+    (b, h) and for the context split over up to 8 blocks (B * H < 512), GQA included; two consecutive calls (tickets back to zero)."""
     from crab_amd import ops
     Tmax, theta = 1024, 10000.0
     tab = ops.rope_table(Tmax, hd, theta, "cuda")
