@@ -716,3 +716,28 @@ def test_generate_batches_in_flight_equals_separate_generate_calls():
             solo = model.generate(**b, use_cache=True, **kw1)
             assert many[g].shape == solo.shape and torch.equal(many[g], solo), (g, kw)
     assert torch.equal(many[0][:, :4].cpu(), A["ids_bs1"][:, :4]) and many[0].shape[1] == 4     # stopped at the EOS it was given
+
+
+def test_generate_many_refuses_batches_that_do_not_fit_together_and_returns_first_logits():
+    """Engine level: generate_many with return_first_logits gives (ids, first-step logits) per batch, equal to generate()'s; with a (faked)
+    small memory budget it raises MemoryError instead of failing in the allocator (the caller puts fewer batches in flight)."""
+    meta, A = load_fixture("full_tiny_llama")
+    model = build_tiny_crab(meta)
+    model.load_state_dict(weights_from_table(meta), strict=False)
+    eng = model.base_model.model._engine
+    e1 = A["embeds_bs2"][:1].cuda().to(BF)
+    e2 = A["embeds_bs2"].cuda().to(BF)
+    kw = dict(eos_token_id=None, pad_token_id=2)
+    outs = eng.generate_many([e1, e2, e1], 5, return_first_logits=True, **kw)
+    assert len(outs) == 3
+    for emb, (ids, fl) in zip([e1, e2, e1], outs):
+        ids1, fl1 = eng.generate(emb, 5, return_first_logits=True, **kw)
+        assert torch.equal(ids, ids1) and torch.equal(fl, fl1)
+    per = eng.bytes_per_sequence(e2.shape[1], 5)
+    eng.kv_budget_bytes = int(per * 1.5)
+    try:
+        with pytest.raises(MemoryError, match="fewer in flight"):
+            eng.generate_many([e1, e2, e1], 5, **kw)
+    finally:
+        eng.kv_budget_bytes = None
+    assert eng.generate_many([], 5) == []
