@@ -35,6 +35,7 @@ class GemmDesc(C.Structure):
         ("route_RA", C.c_void_p), ("route_U", C.c_void_p), ("route_ldra", C.c_int64), ("route_ldu", C.c_int64),
         ("route_nproj", C.c_int32), ("route_nl", C.c_int32), ("route_r", C.c_int32), ("route_ucols", C.c_int32), ("route_scaling", C.c_float),
         ("lora_RA", C.c_void_p), ("lora_ldra", C.c_int64), ("lora_nl", C.c_int32), ("lora_r", C.c_int32), ("lora_scaling", C.c_float),
+        ("rope_S", C.c_int32), ("rope_ld_pos", C.c_int64), ("rope_pos_ids", C.c_void_p),
     ]
 
 
@@ -122,6 +123,7 @@ _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 SYMBOLS = {
     "crab_abi_version": (_i, []),
     "crab_sizeof_gemm_desc": (_i, []),
+    "crab_gemm_fuses_prefill_rope": (_i, [_vp]),
     "crab_sizeof_attn_desc": (_i, []),
     "crab_sizeof_llama_layer": (_i, []),
     "crab_sizeof_llama_io": (_i, []),

@@ -568,6 +568,7 @@ static int launch_norm_epilogue(crab_ctx* ctx, hipStream_t s, const crab_gemm_de
 
 // unfused form of the optional post-RMSNorm (paths whose epilogue does not own whole rows)
 static int post_norm(crab_ctx* ctx, void* stream, const crab_gemm_desc* d) {
+    if (d->rope_tab && d->rope_S > 1) return CRAB_OK;   // prefill form: fused in the large-M epilogue or left to the caller (crab_gemm_fuses_prefill_rope)
     if (d->rope_tab)          // paths whose epilogue did not fuse the RoPE / KV append: the separate pass over C
         return crab_qkv_rope_split(ctx, stream, d->C, d->ldc, d->rope_tab, d->rope_k_cache, d->rope_v_cache, nullptr, 0, d->M, 1, d->rope_H,
                                    d->rope_Hk, d->rope_d, d->rope_Tmax, d->rope_pos0, d->rope_pos_dev);
@@ -589,6 +590,11 @@ extern "C" int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc*
             d->rope_H <= 0 || d->rope_Hk <= 0 || d->rope_d <= 0 || d->N != (d->rope_H + 2 * d->rope_Hk) * d->rope_d)
             return crab_fail(ctx, CRAB_E_INVALID, "gemm: fused rope needs bf16 C, N == (H + 2 Hk) d, caches, no act / residual / post-norm / batch");
     }
+    // prefill form of the fused RoPE (rope_S > 1 rows per sequence): only the large-M kernel implements it; when it will not (shape, alignment,
+    // kernel choice - crab_gemm_fuses_prefill_rope, the caller asks the same question and then runs crab_qkv_rope_split itself) the rope
+    // fields are dropped here so that no decode-form path (one row per sequence) ever sees them
+    crab_gemm_desc plain;
+    if (d->rope_tab && d->rope_S > 1 && !crab_gemm_fuses_prefill_rope(d)) { plain = *d; plain.rope_tab = nullptr; d = &plain; }
     if (d->act == ACT_SWIGLU_PAIR && ((d->N & 3) || d->R || d->norm_w || d->batch > 1 || (d->ldc & 1)))
         return crab_fail(ctx, CRAB_E_INVALID, "gemm: swiglu-pair epilogue needs N % 4 == 0, even ldc, no residual / post-norm / batch");
     if (d->M <= 0 || d->N <= 0 || d->K <= 0) return crab_fail(ctx, CRAB_E_INVALID, "gemm: non-positive dimension");

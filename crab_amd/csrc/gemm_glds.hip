@@ -14,6 +14,7 @@
 #include "common.h"
 #include "crab_internal.h"
 #include "gemm_epilogue.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -28,6 +29,9 @@ struct GemmGP {
     int tiles_m, tiles_n;
     int splitk;          // > 1: blockIdx.y = K slice (unbatched), raw fp32 partial tiles to `part` [slice][M][N]
     float* part;
+    // prefill q|k|v projection (ring kernel, head_dim 128): q and k column tiles rotate and scatter in the epilogue (crab_gemm_desc.rope_S > 1)
+    const float* rope_tab; bf16_t* rope_kc; const int* rope_pos_ids; long rope_ld_pos;
+    int rope_S, rope_H, rope_Hk, rope_Tmax, rope_pos0;
 };
 
 __device__ __attribute__((aligned(16))) uint32_t g_zero_page[64];      // zero-initialised device memory (256 B)
@@ -422,6 +426,61 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bt_ring_kernel(GemmGP p) 
         }
         return;
     }
+    if constexpr (BM == 256 && BN == 256) {
+        if (p.rope_tab && n0 / 128 < p.rope_H + p.rope_Hk) {
+            // ---- q / k column tile of the prefill q|k|v projection: RoPE (modeling_llama.py:204-236) and the K-cache append (:408-412) HERE
+            // instead of a pass over C (qkv_rope_split_tile_kernel read and re-wrote these columns: 2/3 of its 1.4 GB per 35-clip chunk).
+            // The tile is two heads of 128; the rotation partner of dim i (< 64) is dim i + 64, held by the wave one column block over,
+            // so the tile goes through LDS once: bf16(acc + bias) - the value the unfused pair stores and re-reads - in a [256][256] image
+            // (exactly the 128 KB of the ring, idle now) with the 16-byte chunk index XOR-ed with (row & 31), then every thread takes
+            // (row, head, 8 dims + their partners), rotates with the pinned rope_lo / rope_hi order and stores q in place / k into the cache.
+            // Same arithmetic, same roundings as GEMM -> qkv_rope_split: bit-identical.
+            __syncthreads();                                    // every wave is past its last fragment read
+            uint32_t* T32 = reinterpret_cast<uint32_t*>(lds);
+            const bf16_t* bias = p.bias;
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+                const int col = wn * WN + ni * 16 + fg * 4;
+                u32x2 bw = {0u, 0u};
+                if (bias) bw = *reinterpret_cast<const u32x2*>(bias + n0 + col);
+                const float b0 = lo_bf(bw.x), b1 = hi_bf(bw.x), b2 = lo_bf(bw.y), b3 = hi_bf(bw.y);
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi) {
+                    const int row = wm * WM + mi * 16 + fr;
+                    const uint32_t w0 = pack_bf2(acc[ni][mi][0] + b0, acc[ni][mi][1] + b1), w1 = pack_bf2(acc[ni][mi][2] + b2, acc[ni][mi][3] + b3);
+                    const int ch = (col >> 3) ^ (row & 31);
+                    *reinterpret_cast<u32x2*>(T32 + row * 128 + ch * 4 + ((col >> 2) & 1) * 2) = u32x2{w0, w1};
+                }
+            }
+            __syncthreads();
+            const int hh0 = n0 / 128;
+            for (int it = tid; it < 256 * 2 * 8; it += NW * 64) {
+                const int c = it & 7, hl = (it >> 3) & 1, r = it >> 4;
+                const int m = m0 + r;
+                if (m >= p.M) continue;
+                const int b = m / p.rope_S, sq = m - b * p.rope_S;
+                const int pos = p.rope_pos0 + sq;
+                const int rp = p.rope_pos_ids ? p.rope_pos_ids[(long)b * p.rope_ld_pos + sq] : pos;
+                const u32x4 lo = *reinterpret_cast<const u32x4*>(T32 + r * 128 + (((hl * 16 + c) ^ (r & 31)) << 2));
+                const u32x4 hi = *reinterpret_cast<const u32x4*>(T32 + r * 128 + (((hl * 16 + 8 + c) ^ (r & 31)) << 2));
+                const float* cs = p.rope_tab + 2 * ((long)rp * 64 + c * 8);
+                u32x4 olo, ohi;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float x1a = lo_bf(lo[e]), x1b = hi_bf(lo[e]), x2a = lo_bf(hi[e]), x2b = hi_bf(hi[e]);
+                    const float ca = cs[4 * e], sa = cs[4 * e + 1], cb = cs[4 * e + 2], sb = cs[4 * e + 3];
+                    olo[e] = pack_bf2(rope_lo(x1a, x2a, ca, sa), rope_lo(x1b, x2b, cb, sb));
+                    ohi[e] = pack_bf2(rope_hi(x1a, x2a, ca, sa), rope_hi(x1b, x2b, cb, sb));
+                }
+                const int hh = hh0 + hl;
+                bf16_t* dst = hh < p.rope_H ? reinterpret_cast<bf16_t*>(p.C) + (long)m * p.ldc + (long)hh * 128 + c * 8
+                                            : p.rope_kc + (((long)b * p.rope_Hk + (hh - p.rope_H)) * p.rope_Tmax + pos) * 128 + c * 8;
+                *reinterpret_cast<u32x4*>(dst) = olo;
+                *reinterpret_cast<u32x4*>(dst + 64) = ohi;
+            }
+            return;
+        }
+    }
     // output stage shared with gemm_bt_kernel (gemm_epilogue.h): unguarded + activation-specialised on interior sub-tiles
     gemm_epilogue<TM, TN>(acc, p.act, m0 + wm * WM, n0 + wn * WN, fr, fg, p.M, p.N, p.bias ? p.bias + z0 * p.sBias0 + z1 * p.sBias1 : nullptr,
                           p.R ? p.R + z0 * p.sR0 + z1 * p.sR1 : nullptr, p.ldr, p.res_scale, p.C, z0 * p.sC0 + z1 * p.sC1, p.ldc, p.c_fp32);
@@ -430,10 +489,29 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bt_ring_kernel(GemmGP p) 
 
 }  // namespace
 
+// 256x256 ring kernel chosen for an unbatched, unsplit problem (the rule of crab_gemm_glds_launch below)
+static bool ring_chosen(const crab_gemm_desc* d) {
+    if (d->batch > 1 || d->tune == 301 || d->tune == 300) return false;
+    const long big = (long)((d->M + 255) / 256) * ((d->N + 255) / 256);
+    const long rounds = (big + 255) / 256;
+    return d->tune == 302 || (big >= 120 && big * 100 >= rounds * 256 * 55 && d->M >= 1024 && d->N >= 1024 && d->K >= 1024);
+}
+
+// include/crab_hip.h: will crab_gemm_bf16(d) rotate q / k and append k in its epilogue (prefill q|k|v projection)?  A pure function of the descriptor.
+extern "C" int crab_gemm_fuses_prefill_rope(const crab_gemm_desc* d) {
+    static const int on = []() { const char* e = getenv("CRAB_PREFILL_ROPE_FUSED"); return !(e && e[0] == '0'); }();
+    if (!on || !d || !d->rope_tab || d->rope_S <= 1 || d->rope_pos_dev || !d->rope_k_cache) return 0;
+    if (d->rope_d != 128 || (d->rope_H & 1) || (d->rope_Hk & 1) || d->N != (d->rope_H + 2 * d->rope_Hk) * 128) return 0;
+    if (d->M <= 256 || d->act != 0 || d->R || d->c_fp32 || d->norm_w || d->lora_RA || (d->ldc & 7)) return 0;
+    if ((((uintptr_t)d->C | (uintptr_t)d->rope_k_cache | (uintptr_t)d->rope_tab) & 15) || (d->bias && ((uintptr_t)d->bias & 7))) return 0;
+    if (d->rope_pos_ids && d->rope_ld_pos < d->rope_S) return 0;
+    return ring_chosen(d) ? 1 : 0;
+}
+
 // called from crab_gemm_bf16 (gemm.hip) for the 128x128 tile regime
 int crab_gemm_glds_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* d, int splitk, float* part, int ring_split) {
     GemmGP p;
-    p.splitk = splitk > 1 ? splitk : 1; p.part = part;
+    p.splitk = splitk > 1 ? splitk : 1; p.part = part; p.rope_tab = nullptr;
     const bool ntb = splitk > 1 && d->tune != 601;                 // decode split-K regime: every weight byte is read once per step
     p.A = (const bf16_t*)d->A; p.B = (const bf16_t*)d->B; p.C = d->C; p.bias = (const bf16_t*)d->bias; p.R = (const bf16_t*)d->R;
     p.A2 = (const bf16_t*)d->A2; p.B2 = (const bf16_t*)d->B2;
@@ -465,6 +543,10 @@ int crab_gemm_glds_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* d,
     if (use_big) {
         p.tiles_m = (d->M + 255) / 256; p.tiles_n = (d->N + 255) / 256;
         dim3 grid(p.tiles_m * p.tiles_n, batch);
+        if (crab_gemm_fuses_prefill_rope(d)) {
+            p.rope_tab = d->rope_tab; p.rope_kc = (bf16_t*)d->rope_k_cache; p.rope_pos_ids = d->rope_pos_ids; p.rope_ld_pos = d->rope_ld_pos;
+            p.rope_S = d->rope_S; p.rope_H = d->rope_H; p.rope_Hk = d->rope_Hk; p.rope_Tmax = d->rope_Tmax; p.rope_pos0 = d->rope_pos0;
+        }
         hipLaunchKernelGGL((gemm_bt_ring_kernel<256, 256, 2, 4>), grid, dim3(512), 0, s, p);
         return crab_check_launch(ctx, "gemm_bt_ring_kernel");
     }

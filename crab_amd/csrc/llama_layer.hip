@@ -27,6 +27,8 @@ struct GroupCall {
     const crab_linear_group* route_next; void* route_u;                // optional router of the next group on the post-norm rows
     const void* u_ready;                     // router output of THIS group already computed by a producer epilogue
     bool rope;                               // decode: RoPE + KV append fused behind this (q|k|v) GEMM
+    int rope_prefill_S;                      // prefill: rows per sequence; q / k rotate in the projection's epilogue when the library can (crab_gemm_fuses_prefill_rope)
+    int* fused_prefill_rope;                 // out: whether it did
 };
 
 int check_group(crab_ctx* ctx, const crab_linear_group* g, const char* name) {
@@ -68,6 +70,11 @@ int run_group(crab_ctx* ctx, void* stream, const crab_linear_group* g, const cra
     if (c.rope) {
         d.rope_tab = io->rope_tab; d.rope_k_cache = k_cache; d.rope_v_cache = v_cache; d.rope_pos_dev = io->pos_dev;
         d.rope_H = L->H; d.rope_Hk = L->Hk; d.rope_d = L->d; d.rope_Tmax = io->Tmax; d.rope_pos0 = io->pos0;
+    }
+    if (c.rope_prefill_S > 1 && !io->pos_dev) {
+        d.rope_tab = io->rope_tab; d.rope_k_cache = k_cache; d.rope_v_cache = v_cache; d.rope_pos_dev = nullptr;
+        d.rope_H = L->H; d.rope_Hk = L->Hk; d.rope_d = L->d; d.rope_Tmax = io->Tmax; d.rope_pos0 = io->pos0; d.rope_S = c.rope_prefill_S;
+        if (c.fused_prefill_rope) *c.fused_prefill_rope = crab_gemm_fuses_prefill_rope(&d);      // a function of shapes / pointers set above only
     }
     static const int rowfin_on = []() { const char* e = getenv("CRAB_ROWFIN"); return !(e && e[0] == '0'); }();
     if (g->RA && !c.u_ready && M <= 16 && c.norm_w && g->nproj == 1 && rowfin_on) {
@@ -137,10 +144,13 @@ int run_layer(crab_ctx* ctx, void* stream, const crab_llama_layer* L, crab_llama
     q.x = io->h; q.ldx = io->ldh; q.out = io->qkv; q.ldc = io->ldqkv; q.act = CRAB_ACT_NONE;
     q.u_ready = (io->u_qkv_ready && L->qkv.RA) ? io->u2 : nullptr;
     q.rope = !prefill && !fuse_attn;
+    int fused_rope = 0;
+    if (prefill) { q.rope_prefill_S = S; q.fused_prefill_rope = &fused_rope; }
     if ((rc = run_group(ctx, stream, &L->qkv, io, L, M, q, kc, vc))) return rc;
     if (prefill) {
-        if ((rc = crab_qkv_rope_split(ctx, stream, io->qkv, io->ldqkv, io->rope_tab, kc, vc, io->vt, io->vt_ld, B, S, H, Hk, d, io->Tmax, io->pos0,
-                                      io->pos_dev)))
+        // q and k already rotated (k in the cache) by the projection's epilogue: only the v columns are left (cache append + V^T)
+        if ((rc = crab_qkv_rope_split(ctx, stream, io->qkv, io->ldqkv, fused_rope ? nullptr : io->rope_tab, fused_rope ? nullptr : kc, vc, io->vt,
+                                      io->vt_ld, B, S, H, Hk, d, io->Tmax, io->pos0, io->pos_dev)))
             return rc;
         crab_attn_desc a;
         memset(&a, 0, sizeof(a));

@@ -397,6 +397,15 @@ class GenerationEngine:
             elif vt is None and S == 1 and kcl.is_contiguous() and not masked:
                 # decode: RoPE + KV append ride on the q|k|v projection (fused into its split-K reduction when it has one)
                 a._qkv(h, out=qkv, t_buf=ws.t, u_buf=ws.u, u_ready=u_qkv, rope=(tab, kcl, vcl, H, Hk, d, Tmax, pos0, pos_dev))
+            elif vt is not None and pos_dev is None and kcl.is_contiguous():
+                # prefill: q and k rotate (and k lands in the cache) in the projection's epilogue when the library says so; the v columns
+                # (cache append + V^T) are then all that is left for the split pass
+                gi = {}
+                a._qkv(h, out=qkv, t_buf=ws.t, u_buf=ws.u, u_ready=u_qkv, rope=(tab, kcl, vcl, H, Hk, d, Tmax, pos0, None, S, pos_ids), info=gi)
+                if gi.get("fused_prefill_rope"):
+                    ops.qkv_rope_split(qkv, None, None, vcl, vt, B, S, H, Hk, d, Tmax, pos0=pos0)
+                else:
+                    ops.qkv_rope_split(qkv, tab, kcl, vcl, vt, B, S, H, Hk, d, Tmax, pos0=pos0, pos_dev=pos_dev, pos_ids=pos_ids)
             else:
                 a._qkv(h, out=qkv, t_buf=ws.t, u_buf=ws.u, u_ready=u_qkv)
                 ops.qkv_rope_split(qkv, tab, kcl, vcl, vt, B, S, H, Hk, d, Tmax, pos0=pos0, pos_dev=pos_dev, pos_ids=pos_ids)

@@ -123,10 +123,13 @@ def _splitk_workspace(device) -> torch.Tensor:
 def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act: str = "none",
          residual: Optional[torch.Tensor] = None, res_scale: float = 1.0, x2: Optional[torch.Tensor] = None,
          w2: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, out_fp32: bool = False, tune: int = 0,
-         post_norm=None, rope=None, route=None, lora_self=None) -> torch.Tensor:
+         post_norm=None, rope=None, route=None, lora_self=None, info: Optional[dict] = None) -> torch.Tensor:
     """out[M,N] = res_scale*residual + act(x[M,K] @ w[N,K]^T + x2 @ w2^T + bias).  2-D row-strided operands.
     rope = (tab, k_cache, v_cache, H, Hk, d, Tmax, pos0, pos_dev): packed q|k|v projection of ONE row per sequence followed
     by RoPE + KV-cache append (== qkv_rope_split(B=M, S=1) on out), fused into the split-K reduction when there is one.
+    rope = (..., pos_dev = None, S, pos_ids): the PREFILL form, S rows per sequence - when the library says so (info["fused_prefill_rope"],
+    crab_gemm_fuses_prefill_rope) q is rotated in place and k rotated into the cache by the projection's epilogue and the caller finishes with
+    qkv_rope_split(rope_tab=None, k_cache=None) for the v columns; otherwise the caller runs the full qkv_rope_split as before.
     route = (RA, nproj, nl, r, ucols, scaling, u_out) (with post_norm, M <= 256): u_out = hyperlora_route(post-norm rows, RA)
     for the NEXT projection group, computed inside the row-owning reduction kernel when that path is taken.
     lora_self = (RA, nl, r, scaling, lora_B) (with post_norm, M <= 16, no x2): the hyper-LoRA update of THIS single-projection group is
@@ -168,10 +171,18 @@ def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
         g.lora_RA, g.lora_ldra, g.lora_nl, g.lora_r, g.lora_scaling = lRA.data_ptr(), lRA.stride(0), lnl, lr, lsc
         g.B2, g.ldb2, g.K2 = lB.data_ptr(), lB.stride(0), lB.shape[1]
     if rope is not None:
-        tab, kcache, vcache, rH, rHk, rd, rT, rp0, rpd = rope
+        tab, kcache, vcache, rH, rHk, rd, rT, rp0, rpd = rope[:9]
         g.rope_tab, g.rope_k_cache, g.rope_v_cache = tab.data_ptr(), kcache.data_ptr(), vcache.data_ptr()
         g.rope_pos_dev = rpd.data_ptr() if rpd is not None else None
         g.rope_H, g.rope_Hk, g.rope_d, g.rope_Tmax, g.rope_pos0 = rH, rHk, rd, rT, rp0
+        if len(rope) > 9:                          # prefill form: S rows per sequence (+ optional rotary positions [B, S] int32)
+            g.rope_S = int(rope[9])
+            pid = rope[10] if len(rope) > 10 else None
+            if pid is not None:
+                assert pid.dtype == torch.int32 and pid.stride(-1) == 1
+                g.rope_pos_ids, g.rope_ld_pos = pid.data_ptr(), pid.stride(0)
+            if info is not None:
+                info["fused_prefill_rope"] = bool(_lib.load().crab_gemm_fuses_prefill_rope(C.byref(g)))
     if M <= 256:
         ws = _splitk_workspace(x.device)
         g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel()

@@ -94,9 +94,17 @@ typedef struct {
      * RMSNorm and the next group's router (csrc/rowfin.hip): needs M <= 16, norm_w / norm_out, bf16 C and a workspace of
      * crab_rowfin_workspace(M, N) bytes; CRAB_E_UNSUPPORTED otherwise (use crab_hyperlora_route + A2 there).  lora_RA == NULL disables it. */
     const void* lora_RA; int64_t lora_ldra; int32_t lora_nl, lora_r; float lora_scaling;
+    /* PREFILL form of the fused RoPE (rope_S > 1 rows per sequence, M = B * rope_S; head_dim 128, rope_pos_dev == NULL): the q and k column
+     * tiles of the large-M kernel rotate in their epilogue - q in place in C, k straight into rope_k_cache[b, hk, rope_pos0 + s, :] - with
+     * the rotary position rope_pos_ids[b * rope_ld_pos + s] when given (forward()'s position_ids) and rope_pos0 + s otherwise.  The v
+     * columns are written to C as usual: the caller finishes with crab_qkv_rope_split(rope_tab = NULL, k_cache = NULL) (v-cache append + V^T).
+     * Whether a given call will do this is a pure function of the descriptor: crab_gemm_fuses_prefill_rope(d); when it returns 0 the rope_*
+     * fields are ignored at M > 256 and the caller runs the full crab_qkv_rope_split as before.  Bit-identical to that pair. */
+    int32_t rope_S; int64_t rope_ld_pos; const int32_t* rope_pos_ids;
 } crab_gemm_desc;
 
 int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc* d);
+int crab_gemm_fuses_prefill_rope(const crab_gemm_desc* d);   /* 1: this call rotates q / k and appends k in its epilogue (see rope_S) */
 /* bytes of crab_gemm_desc.workspace the M <= 16 layer tail needs (fp32 sums + router product + per-slice partials) */
 int64_t crab_rowfin_workspace(int M, int N);
 

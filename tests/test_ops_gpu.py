@@ -834,3 +834,38 @@ def test_invalid_arguments_fail_loudly_with_a_message():
     with pytest.raises(CrabHipError, match="overflow"):
         ops.qkv_rope_split(_rand(2 * 5, 3 * 4 * 64, seed=5).cuda(), ops.rope_table(16, 64, 1e4, "cuda"), torch.zeros(2, 4, 4, 64, dtype=BF, device="cuda"),
                            torch.zeros(2, 4, 4, 64, dtype=BF, device="cuda"), None, 2, 5, 4, 4, 64, 4, pos0=0)
+
+
+@pytest.mark.parametrize("B,S,H,Hk,bias,ids", [(5, 300, 32, 32, False, False), (3, 702, 28, 4, True, False), (4, 333, 16, 16, False, True)])
+def test_prefill_qkv_projection_rotates_in_its_epilogue(B, S, H, Hk, bias, ids):
+    """Prefill q|k|v projection with the RoPE of q / k and the K-cache append in the GEMM epilogue (crab_gemm_desc.rope_S) followed by the
+    v-only split == projection followed by the full qkv_rope_split, bit for bit: q columns of C, K cache, V cache, V^T; ragged last row tile,
+    rows of several sequences in one tile, grouped kv heads + bias (Qwen2), explicit rotary positions (forward()'s position_ids)."""
+    from crab_amd import ops
+    d, K, Tmax, pos0 = 128, 1024, 1024, 5
+    M, N = B * S, (H + 2 * Hk) * d
+    g = torch.Generator(device="cuda").manual_seed(B * S)
+    x = torch.randn(M, K, device="cuda", generator=g).to(BF)
+    w = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).to(BF)
+    bv = torch.randn(N, device="cuda", generator=g).to(BF) if bias else None
+    tab = ops.rope_table(2048, d, 10000.0, "cuda")
+    pid = (torch.randint(0, 2000, (B, S), device="cuda", generator=g).to(torch.int32)) if ids else None
+    Sp = (S + 7) // 8 * 8
+    outs = []
+    for fused in (True, False):
+        kc = torch.zeros(B, Hk, Tmax, d, dtype=BF, device="cuda")
+        vc = torch.zeros_like(kc)
+        vt = torch.zeros(B, Hk, d, Sp, dtype=BF, device="cuda")
+        qkv = torch.empty(M, N, dtype=BF, device="cuda")
+        if fused:
+            info = {}
+            ops.gemm(x, w, bias=bv, out=qkv, rope=(tab, kc, vc, H, Hk, d, Tmax, pos0, None, S, pid), info=info)
+            assert info["fused_prefill_rope"], "the library declined the fused prefill RoPE at a shape it is built for"
+            ops.qkv_rope_split(qkv, None, None, vc, vt, B, S, H, Hk, d, Tmax, pos0=pos0)
+        else:
+            ops.gemm(x, w, bias=bv, out=qkv)
+            ops.qkv_rope_split(qkv, tab, kc, vc, vt, B, S, H, Hk, d, Tmax, pos0=pos0, pos_ids=pid)
+        outs.append((qkv[:, :H * d].clone(), kc, vc, vt))
+    for name, a, b in zip(("q", "k cache", "v cache", "v^T"), outs[0], outs[1]):
+        assert torch.equal(a, b), f"fused prefill RoPE: {name} differs from the unfused pair"
+    assert float(outs[0][1][:, :, pos0:pos0 + S].float().abs().sum()) > 0
