@@ -36,6 +36,7 @@ class GemmDesc(C.Structure):
         ("route_nproj", C.c_int32), ("route_nl", C.c_int32), ("route_r", C.c_int32), ("route_ucols", C.c_int32), ("route_scaling", C.c_float),
         ("lora_RA", C.c_void_p), ("lora_ldra", C.c_int64), ("lora_nl", C.c_int32), ("lora_r", C.c_int32), ("lora_scaling", C.c_float),
         ("rope_S", C.c_int32), ("rope_ld_pos", C.c_int64), ("rope_pos_ids", C.c_void_p),
+        ("rope_vt", C.c_void_p), ("rope_vt_ld", C.c_int64),
     ]
 
 

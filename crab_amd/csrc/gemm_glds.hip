@@ -32,6 +32,7 @@ struct GemmGP {
     // prefill q|k|v projection (ring kernel, head_dim 128): q and k column tiles rotate and scatter in the epilogue (crab_gemm_desc.rope_S > 1)
     const float* rope_tab; bf16_t* rope_kc; const int* rope_pos_ids; long rope_ld_pos;
     int rope_S, rope_H, rope_Hk, rope_Tmax, rope_pos0;
+    bf16_t* rope_vc; bf16_t* rope_vt; long rope_vt_ld;      // v column tiles: cache append + V^T in the epilogue too (rope_vt != NULL)
 };
 
 __device__ __attribute__((aligned(16))) uint32_t g_zero_page[64];      // zero-initialised device memory (256 B)
@@ -427,7 +428,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bt_ring_kernel(GemmGP p) 
         return;
     }
     if constexpr (BM == 256 && BN == 256) {
-        if (p.rope_tab && n0 / 128 < p.rope_H + p.rope_Hk) {
+        if (p.rope_tab && (n0 / 128 < p.rope_H + p.rope_Hk || p.rope_vt)) {
             // ---- q / k column tile of the prefill q|k|v projection: RoPE (modeling_llama.py:204-236) and the K-cache append (:408-412) HERE
             // instead of a pass over C (qkv_rope_split_tile_kernel read and re-wrote these columns: 2/3 of its 1.4 GB per 35-clip chunk).
             // The tile is two heads of 128; the rotation partner of dim i (< 64) is dim i + 64, held by the wave one column block over,
@@ -454,6 +455,51 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bt_ring_kernel(GemmGP p) 
             }
             __syncthreads();
             const int hh0 = n0 / 128;
+            if (hh0 >= p.rope_H + p.rope_Hk) {
+                // ---- v column tile (two kv heads): the rows go to the V cache as they are, and transposed to V^T [b, hk, d, vt_ld] for the
+                // prefill attention.  V^T is written in octets of 8 consecutive tokens of ONE sequence starting at s % 8 == 0 (16-byte
+                // stores); a tile's rows start anywhere in a sequence, so the octets cut by the tile's first / middle / last row or begun
+                // before it are written element by element by whichever tile holds each element (the neighbouring row tile writes the rest).
+                const int hk0 = hh0 - p.rope_H - p.rope_Hk;
+                for (int it = tid; it < 256 * 32; it += NW * 64) {
+                    const int ch = it & 31, r = it >> 5;
+                    const int m = m0 + r;
+                    if (m >= p.M) continue;
+                    const int b = m / p.rope_S, sq = m - b * p.rope_S;
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(T32 + r * 128 + ((ch ^ (r & 31)) << 2));
+                    bf16_t* dst = p.rope_vc + (((long)b * p.rope_Hk + hk0 + (ch >> 4)) * p.rope_Tmax + p.rope_pos0 + sq) * 128 + (ch & 15) * 8;
+                    *reinterpret_cast<u32x4*>(dst) = v;
+                }
+                {
+                    const int col = tid & 255, ra = (tid >> 8) * 128, rb = ra + 128;      // one column (head, dim) and half of the rows per thread
+                    const int hl = col >> 7, dd = col & 127;
+                    const bf16_t* T16 = reinterpret_cast<const bf16_t*>(T32);
+                    int m = m0 + ra;
+                    if (m < p.M) {
+                        int b = m / p.rope_S, sq = m - b * p.rope_S;
+                        uint32_t w[4] = {0u, 0u, 0u, 0u};
+                        int k0 = sq & 7;                                   // first element of the octet being collected
+                        for (int r = ra; r < rb && m < p.M; ++r, ++m) {
+                            const int k = sq & 7;
+                            const uint32_t e = T16[r * 256 + ((((col >> 3) ^ (r & 31)) << 3) | (col & 7))];
+                            w[k >> 1] |= e << ((k & 1) * 16);
+                            const bool seq_end = sq == p.rope_S - 1;
+                            if (k == 7 || seq_end || r == rb - 1 || m == p.M - 1) {
+                                bf16_t* vrow = p.rope_vt + (((long)b * p.rope_Hk + hk0 + hl) * 128 + dd) * p.rope_vt_ld + (sq & ~7);
+                                if (k0 == 0 && (k == 7 || seq_end)) {
+                                    *reinterpret_cast<u32x4*>(vrow) = u32x4{w[0], w[1], w[2], w[3]};    // whole octet (zeros behind a sequence's last token)
+                                } else {
+                                    for (int kk = k0; kk <= k; ++kk) vrow[kk] = (bf16_t)(w[kk >> 1] >> ((kk & 1) * 16));
+                                }
+                                w[0] = w[1] = w[2] = w[3] = 0u;
+                                k0 = seq_end ? 0 : ((k + 1) & 7);
+                            }
+                            if (seq_end) { sq = 0; ++b; } else ++sq;
+                        }
+                    }
+                }
+                return;
+            }
             for (int it = tid; it < 256 * 2 * 8; it += NW * 64) {
                 const int c = it & 7, hl = (it >> 3) & 1, r = it >> 4;
                 const int m = m0 + r;
@@ -505,7 +551,12 @@ extern "C" int crab_gemm_fuses_prefill_rope(const crab_gemm_desc* d) {
     if (d->M <= 256 || d->act != 0 || d->R || d->c_fp32 || d->norm_w || d->lora_RA || (d->ldc & 7)) return 0;
     if ((((uintptr_t)d->C | (uintptr_t)d->rope_k_cache | (uintptr_t)d->rope_tab) & 15) || (d->bias && ((uintptr_t)d->bias & 7))) return 0;
     if (d->rope_pos_ids && d->rope_ld_pos < d->rope_S) return 0;
-    return ring_chosen(d) ? 1 : 0;
+    if (!ring_chosen(d)) return 0;
+    // 2: the v columns too (V-cache append + V^T): needs the V^T scratch, 16-byte rows, whole octets inside a sequence
+    if (d->rope_vt && d->rope_v_cache && (d->rope_vt_ld & 7) == 0 && d->rope_vt_ld >= d->rope_S && d->rope_S >= 8 &&
+        (((uintptr_t)d->rope_vt | (uintptr_t)d->rope_v_cache) & 15) == 0)
+        return 2;
+    return 1;
 }
 
 // called from crab_gemm_bf16 (gemm.hip) for the 128x128 tile regime
@@ -546,6 +597,7 @@ int crab_gemm_glds_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* d,
         if (crab_gemm_fuses_prefill_rope(d)) {
             p.rope_tab = d->rope_tab; p.rope_kc = (bf16_t*)d->rope_k_cache; p.rope_pos_ids = d->rope_pos_ids; p.rope_ld_pos = d->rope_ld_pos;
             p.rope_S = d->rope_S; p.rope_H = d->rope_H; p.rope_Hk = d->rope_Hk; p.rope_Tmax = d->rope_Tmax; p.rope_pos0 = d->rope_pos0;
+            p.rope_vc = (bf16_t*)d->rope_v_cache; p.rope_vt = crab_gemm_fuses_prefill_rope(d) == 2 ? (bf16_t*)d->rope_vt : nullptr; p.rope_vt_ld = d->rope_vt_ld;
         }
         hipLaunchKernelGGL((gemm_bt_ring_kernel<256, 256, 2, 4>), grid, dim3(512), 0, s, p);
         return crab_check_launch(ctx, "gemm_bt_ring_kernel");

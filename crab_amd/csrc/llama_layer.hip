@@ -74,6 +74,7 @@ int run_group(crab_ctx* ctx, void* stream, const crab_linear_group* g, const cra
     if (c.rope_prefill_S > 1 && !io->pos_dev) {
         d.rope_tab = io->rope_tab; d.rope_k_cache = k_cache; d.rope_v_cache = v_cache; d.rope_pos_dev = nullptr;
         d.rope_H = L->H; d.rope_Hk = L->Hk; d.rope_d = L->d; d.rope_Tmax = io->Tmax; d.rope_pos0 = io->pos0; d.rope_S = c.rope_prefill_S;
+        d.rope_vt = io->vt; d.rope_vt_ld = io->vt_ld;
         if (c.fused_prefill_rope) *c.fused_prefill_rope = crab_gemm_fuses_prefill_rope(&d);      // a function of shapes / pointers set above only
     }
     static const int rowfin_on = []() { const char* e = getenv("CRAB_ROWFIN"); return !(e && e[0] == '0'); }();
@@ -148,8 +149,10 @@ int run_layer(crab_ctx* ctx, void* stream, const crab_llama_layer* L, crab_llama
     if (prefill) { q.rope_prefill_S = S; q.fused_prefill_rope = &fused_rope; }
     if ((rc = run_group(ctx, stream, &L->qkv, io, L, M, q, kc, vc))) return rc;
     if (prefill) {
-        // q and k already rotated (k in the cache) by the projection's epilogue: only the v columns are left (cache append + V^T)
-        if ((rc = crab_qkv_rope_split(ctx, stream, io->qkv, io->ldqkv, fused_rope ? nullptr : io->rope_tab, fused_rope ? nullptr : kc, vc, io->vt,
+        // fused_rope 1: q and k already rotated (k in the cache) by the projection's epilogue, only the v columns are left (cache append + V^T);
+        // 2: those too
+        if (fused_rope != 2 &&
+            (rc = crab_qkv_rope_split(ctx, stream, io->qkv, io->ldqkv, fused_rope ? nullptr : io->rope_tab, fused_rope ? nullptr : kc, vc, io->vt,
                                       io->vt_ld, B, S, H, Hk, d, io->Tmax, io->pos0, io->pos_dev)))
             return rc;
         crab_attn_desc a;

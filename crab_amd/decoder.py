@@ -401,8 +401,10 @@ class GenerationEngine:
                 # prefill: q and k rotate (and k lands in the cache) in the projection's epilogue when the library says so; the v columns
                 # (cache append + V^T) are then all that is left for the split pass
                 gi = {}
-                a._qkv(h, out=qkv, t_buf=ws.t, u_buf=ws.u, u_ready=u_qkv, rope=(tab, kcl, vcl, H, Hk, d, Tmax, pos0, None, S, pos_ids), info=gi)
-                if gi.get("fused_prefill_rope"):
+                a._qkv(h, out=qkv, t_buf=ws.t, u_buf=ws.u, u_ready=u_qkv, rope=(tab, kcl, vcl, H, Hk, d, Tmax, pos0, None, S, pos_ids, vt), info=gi)
+                if gi.get("fused_prefill_rope") == 2:
+                    pass                                          # v-cache append and V^T written by the projection's epilogue as well
+                elif gi.get("fused_prefill_rope") == 1:
                     ops.qkv_rope_split(qkv, None, None, vcl, vt, B, S, H, Hk, d, Tmax, pos0=pos0)
                 else:
                     ops.qkv_rope_split(qkv, tab, kcl, vcl, vt, B, S, H, Hk, d, Tmax, pos0=pos0, pos_dev=pos_dev, pos_ids=pos_ids)

@@ -127,9 +127,10 @@ def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     """out[M,N] = res_scale*residual + act(x[M,K] @ w[N,K]^T + x2 @ w2^T + bias).  2-D row-strided operands.
     rope = (tab, k_cache, v_cache, H, Hk, d, Tmax, pos0, pos_dev): packed q|k|v projection of ONE row per sequence followed
     by RoPE + KV-cache append (== qkv_rope_split(B=M, S=1) on out), fused into the split-K reduction when there is one.
-    rope = (..., pos_dev = None, S, pos_ids): the PREFILL form, S rows per sequence - when the library says so (info["fused_prefill_rope"],
-    crab_gemm_fuses_prefill_rope) q is rotated in place and k rotated into the cache by the projection's epilogue and the caller finishes with
-    qkv_rope_split(rope_tab=None, k_cache=None) for the v columns; otherwise the caller runs the full qkv_rope_split as before.
+    rope = (..., pos_dev = None, S, pos_ids[, vt]): the PREFILL form, S rows per sequence - when the library says so (info["fused_prefill_rope"]
+    = crab_gemm_fuses_prefill_rope: 1 or 2) q is rotated in place and k rotated into the cache by the projection's epilogue; at 1 the caller
+    finishes with qkv_rope_split(rope_tab=None, k_cache=None) for the v columns, at 2 (vt given) the epilogue did those too; at 0 the caller
+    runs the full qkv_rope_split as before.
     route = (RA, nproj, nl, r, ucols, scaling, u_out) (with post_norm, M <= 256): u_out = hyperlora_route(post-norm rows, RA)
     for the NEXT projection group, computed inside the row-owning reduction kernel when that path is taken.
     lora_self = (RA, nl, r, scaling, lora_B) (with post_norm, M <= 16, no x2): the hyper-LoRA update of THIS single-projection group is
@@ -181,8 +182,10 @@ def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
             if pid is not None:
                 assert pid.dtype == torch.int32 and pid.stride(-1) == 1
                 g.rope_pos_ids, g.rope_ld_pos = pid.data_ptr(), pid.stride(0)
-            if info is not None:
-                info["fused_prefill_rope"] = bool(_lib.load().crab_gemm_fuses_prefill_rope(C.byref(g)))
+            if len(rope) > 11 and rope[11] is not None:           # V^T scratch [B, Hk, d, vt_ld]: the v columns in the epilogue too
+                g.rope_vt, g.rope_vt_ld = rope[11].data_ptr(), rope[11].stride(-2)
+            if info is not None:                                   # 0: not fused; 1: q / k; 2: q / k / v (no split pass left)
+                info["fused_prefill_rope"] = int(_lib.load().crab_gemm_fuses_prefill_rope(C.byref(g)))
     if M <= 256:
         ws = _splitk_workspace(x.device)
         g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel()

@@ -101,10 +101,13 @@ typedef struct {
      * Whether a given call will do this is a pure function of the descriptor: crab_gemm_fuses_prefill_rope(d); when it returns 0 the rope_*
      * fields are ignored at M > 256 and the caller runs the full crab_qkv_rope_split as before.  Bit-identical to that pair. */
     int32_t rope_S; int64_t rope_ld_pos; const int32_t* rope_pos_ids;
+    /* optional with rope_S > 1: V^T scratch [B, Hk, 128, rope_vt_ld] (what crab_qkv_rope_split's `vt` is).  When given - and the call fuses at all -
+     * the v column tiles append to rope_v_cache and write V^T in the epilogue as well: crab_gemm_fuses_prefill_rope(d) == 2, no split pass left. */
+    void* rope_vt; int64_t rope_vt_ld;
 } crab_gemm_desc;
 
 int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc* d);
-int crab_gemm_fuses_prefill_rope(const crab_gemm_desc* d);   /* 1: this call rotates q / k and appends k in its epilogue (see rope_S) */
+int crab_gemm_fuses_prefill_rope(const crab_gemm_desc* d);   /* 0: no; 1: this call rotates q / k and appends k in its epilogue (see rope_S); 2: and handles the v columns (rope_vt) */
 /* bytes of crab_gemm_desc.workspace the M <= 16 layer tail needs (fp32 sums + router product + per-slice partials) */
 int64_t crab_rowfin_workspace(int M, int N);
 

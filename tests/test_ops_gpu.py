@@ -836,8 +836,9 @@ def test_invalid_arguments_fail_loudly_with_a_message():
                            torch.zeros(2, 4, 4, 64, dtype=BF, device="cuda"), None, 2, 5, 4, 4, 64, 4, pos0=0)
 
 
-@pytest.mark.parametrize("B,S,H,Hk,bias,ids", [(5, 300, 32, 32, False, False), (3, 702, 28, 4, True, False), (4, 333, 16, 16, False, True)])
-def test_prefill_qkv_projection_rotates_in_its_epilogue(B, S, H, Hk, bias, ids):
+@pytest.mark.parametrize("with_vt", [True, False])
+@pytest.mark.parametrize("B,S,H,Hk,bias,ids", [(5, 300, 32, 32, False, False), (3, 702, 28, 4, True, False), (4, 333, 16, 16, False, True), (2, 1000, 32, 32, False, False)])
+def test_prefill_qkv_projection_rotates_in_its_epilogue(B, S, H, Hk, bias, ids, with_vt):
     """Prefill q|k|v projection with the RoPE of q / k and the K-cache append in the GEMM epilogue (crab_gemm_desc.rope_S) followed by the
     v-only split == projection followed by the full qkv_rope_split, bit for bit: q columns of C, K cache, V cache, V^T; ragged last row tile,
     rows of several sequences in one tile, grouped kv heads + bias (Qwen2), explicit rotary positions (forward()'s position_ids)."""
@@ -859,13 +860,15 @@ def test_prefill_qkv_projection_rotates_in_its_epilogue(B, S, H, Hk, bias, ids):
         qkv = torch.empty(M, N, dtype=BF, device="cuda")
         if fused:
             info = {}
-            ops.gemm(x, w, bias=bv, out=qkv, rope=(tab, kc, vc, H, Hk, d, Tmax, pos0, None, S, pid), info=info)
-            assert info["fused_prefill_rope"], "the library declined the fused prefill RoPE at a shape it is built for"
-            ops.qkv_rope_split(qkv, None, None, vc, vt, B, S, H, Hk, d, Tmax, pos0=pos0)
+            ops.gemm(x, w, bias=bv, out=qkv, rope=(tab, kc, vc, H, Hk, d, Tmax, pos0, None, S, pid, vt if with_vt else None), info=info)
+            assert info["fused_prefill_rope"] == (2 if with_vt else 1), "the library declined the fused prefill RoPE at a shape it is built for"
+            if not with_vt:
+                ops.qkv_rope_split(qkv, None, None, vc, vt, B, S, H, Hk, d, Tmax, pos0=pos0)
         else:
             ops.gemm(x, w, bias=bv, out=qkv)
             ops.qkv_rope_split(qkv, tab, kc, vc, vt, B, S, H, Hk, d, Tmax, pos0=pos0, pos_ids=pid)
         outs.append((qkv[:, :H * d].clone(), kc, vc, vt))
+    # V^T beyond a sequence's last token (the pad of the last octet) is zero in both forms (the unfused pass writes zeros, the fused one packs them)
     for name, a, b in zip(("q", "k cache", "v cache", "v^T"), outs[0], outs[1]):
         assert torch.equal(a, b), f"fused prefill RoPE: {name} differs from the unfused pair"
     assert float(outs[0][1][:, :, pos0:pos0 + S].float().abs().sum()) > 0
