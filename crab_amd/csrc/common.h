@@ -48,16 +48,37 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
-// wave-wide butterflies in the order 32, 16, 8, 4, 2, 1: the two cross-row steps by shuffle, the four in-row steps by DPP (same pairs,
-// same order: bit-identical to the all-shuffle form)
+// lane ^ 32 and lane ^ 16 partners without the LDS crossbar: v_permlane32_swap / v_permlane16_swap (gfx950) exchange the upper half (the odd
+// 16-lane rows) of one register with the lower half (the even rows) of another; with the same value in both, the two results hold, per lane,
+// {own, partner} or {partner, own} - their sum / max is the butterfly step, whichever order (commutative: bit-identical to the shuffle form).
+// (the two operands must live in DIFFERENT registers - the instruction swaps in place, and with one register for both the halves are merely
+// exchanged within it: the empty asm pins a copy)
+__device__ __forceinline__ void xor32_pair(float v, float& a, float& b) {
+    unsigned u0 = __builtin_bit_cast(unsigned, v), u1 = u0;
+    asm volatile("" : "+v"(u1));
+    auto r = __builtin_amdgcn_permlane32_swap(u0, u1, false, false);
+    const unsigned ra = r[0], rb = r[1];                    // (element reads BEFORE the casts: bit_cast(float, r[1]) compiled to element 0)
+    a = __uint_as_float(ra); b = __uint_as_float(rb);
+}
+__device__ __forceinline__ void xor16_pair(float v, float& a, float& b) {
+    unsigned u0 = __builtin_bit_cast(unsigned, v), u1 = u0;
+    asm volatile("" : "+v"(u1));
+    auto r = __builtin_amdgcn_permlane16_swap(u0, u1, false, false);
+    const unsigned ra = r[0], rb = r[1];
+    a = __uint_as_float(ra); b = __uint_as_float(rb);
+}
+// wave-wide butterflies in the order 32, 16, 8, 4, 2, 1: the two cross-row steps by permlane swaps, the four in-row steps by DPP - no LDS
+// instruction at all (same pairs, same order: bit-identical to the all-shuffle form)
 __device__ __forceinline__ float wave_sum(float v) {
-    v += __shfl_xor(v, 32, 64);
-    v += __shfl_xor(v, 16, 64);
+    float a, b;
+    xor32_pair(v, a, b); v = a + b;
+    xor16_pair(v, a, b); v = a + b;
     return row16_sum(v);
 }
 __device__ __forceinline__ float wave_max(float v) {
-    v = fmaxf(v, __shfl_xor(v, 32, 64));
-    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    float a, b;
+    xor32_pair(v, a, b); v = fmaxf(a, b);
+    xor16_pair(v, a, b); v = fmaxf(a, b);
     v = fmaxf(v, row_xor8(v));
     v = fmaxf(v, row_xor4(v));
     v = fmaxf(v, row_xor2(v));
