@@ -885,6 +885,14 @@ __global__ __launch_bounds__(256, (G <= 4 ? 3 : 2)) void attn_decode_gqa_kernel(
             }
         }
         __syncthreads();
+        // the first trip of V rows of phase C is requested HERE: it flies under phase B (four barriers, the exponentials, no memory traffic)
+        constexpr int RPT = G <= 4 ? 4 : 6;                     // V rows per trip: 64 / 96 bytes in flight per lane (8 rows spill at G >= 7)
+        u32x4 vw[RPT];
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) {
+            const int jc = min(u * 16 + grp, cn - 1);
+            vw[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vb + (long)(c0 + jc) * HD));
+        }
         // ---- B: per-head chunk max -> running max, p = exp(s - m) in place, running sum
         {
             const int g = tid & 7;
@@ -920,13 +928,13 @@ __global__ __launch_bounds__(256, (G <= 4 ? 3 : 2)) void attn_decode_gqa_kernel(
 #pragma unroll
             for (int e = 0; e < EPL; ++e) acc[g][e] *= a;
         }
-        constexpr int RPT = G <= 4 ? 4 : 6;                     // V rows per trip: 64 / 96 bytes in flight per lane (8 rows spill at G >= 7)
         for (int r0 = 0; r0 < rounds; r0 += RPT) {
-            u32x4 vw[RPT];
+            if (r0 > 0) {
 #pragma unroll
-            for (int u = 0; u < RPT; ++u) {
-                const int jc = min((r0 + u) * 16 + grp, cn - 1);
-                vw[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vb + (long)(c0 + jc) * HD));
+                for (int u = 0; u < RPT; ++u) {
+                    const int jc = min((r0 + u) * 16 + grp, cn - 1);
+                    vw[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vb + (long)(c0 + jc) * HD));
+                }
             }
 #pragma unroll
             for (int u = 0; u < RPT; ++u) {
