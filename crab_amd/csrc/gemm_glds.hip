@@ -536,11 +536,17 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_bt_ring_kernel(GemmGP p) 
 }  // namespace
 
 // 256x256 ring kernel chosen for an unbatched, unsplit problem (the rule of crab_gemm_glds_launch below)
+// measured (profiles/README.md, after the epilogue rewrite): the one-block-per-CU ring kernel beats the 128x128 kernel whenever its grid fills
+// at least ~55 % of whole rounds of 256 blocks (M = 5616 x N = 4096: 352 tiles = 69 % of 2 rounds, 930 vs 868 TFLOP/s; M = 2056 x N = 4096 x
+// K = 1024: 144 tiles = 56 % of one round, 527 vs 491); r03: also at width 768 (BEATs at 256 clips, M = 122880: q-k-v 458 vs 671 us, o 164 vs 225,
+// fc1 888 vs 1236, fc2 (N = 768, K = 3072) 513 vs 795), so N and K only have to reach 768
 static bool ring_chosen(const crab_gemm_desc* d) {
-    if (d->batch > 1 || d->tune == 301 || d->tune == 300) return false;
-    const long big = (long)((d->M + 255) / 256) * ((d->N + 255) / 256);
+    const int batch = d->batch > 1 ? d->batch : 1;
+    if (d->tune == 301 || d->tune == 300) return false;
+    if (d->tune == 302) return true;
+    const long big = (long)((d->M + 255) / 256) * ((d->N + 255) / 256) * batch;
     const long rounds = (big + 255) / 256;
-    return d->tune == 302 || (big >= 120 && big * 100 >= rounds * 256 * 55 && d->M >= 1024 && d->N >= 1024 && d->K >= 1024);
+    return big >= 120 && big * 100 >= rounds * 256 * 55 && d->M >= 1024 && d->N >= 768 && d->K >= 768;
 }
 
 // include/crab_hip.h: will crab_gemm_bf16(d) rotate q / k and append k in its epilogue (prefill q|k|v projection)?  A pure function of the descriptor.
@@ -551,7 +557,7 @@ extern "C" int crab_gemm_fuses_prefill_rope(const crab_gemm_desc* d) {
     if (d->M <= 256 || d->act != 0 || d->R || d->c_fp32 || d->norm_w || d->lora_RA || (d->ldc & 7)) return 0;
     if ((((uintptr_t)d->C | (uintptr_t)d->rope_k_cache | (uintptr_t)d->rope_tab) & 15) || (d->bias && ((uintptr_t)d->bias & 7))) return 0;
     if (d->rope_pos_ids && d->rope_ld_pos < d->rope_S) return 0;
-    if (!ring_chosen(d)) return 0;
+    if (d->batch > 1 || !ring_chosen(d)) return 0;
     // 2: the v columns too (V-cache append + V^T): needs the V^T scratch, 16-byte rows, whole octets inside a sequence
     if (d->rope_vt && d->rope_v_cache && (d->rope_vt_ld & 7) == 0 && d->rope_vt_ld >= d->rope_S && d->rope_S >= 8 &&
         (((uintptr_t)d->rope_vt | (uintptr_t)d->rope_v_cache) & 15) == 0)
@@ -573,13 +579,8 @@ int crab_gemm_glds_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* d,
     p.sA0 = d->sA0; p.sA1 = d->sA1; p.sB0 = d->sB0; p.sB1 = d->sB1; p.sC0 = d->sC0; p.sC1 = d->sC1;
     p.sR0 = d->sR0; p.sR1 = d->sR1; p.sBias0 = d->sBias0; p.sBias1 = d->sBias1;
     if (batch == 1) { p.sA0 = p.sA1 = p.sB0 = p.sB1 = p.sC0 = p.sC1 = p.sR0 = p.sR1 = p.sBias0 = p.sBias1 = 0; }
-    // 256x256 ring kernel when the problem fills the chip with big tiles; 128x128 two-stage kernel otherwise
-    const long big = (long)((d->M + 255) / 256) * ((d->N + 255) / 256) * batch;
-    // measured (profiles/README.md, after the epilogue rewrite): the one-block-per-CU ring kernel beats the 128x128 kernel
-    // whenever its grid fills at least ~55 % of whole rounds of 256 blocks (M = 5616 x N = 4096: 352 tiles = 69 % of 2
-    // rounds, 930 vs 868 TFLOP/s; M = 2056 x N = 4096 x K = 1024: 144 tiles = 56 % of one round, 527 vs 491) and K >= 1024
-    const long rounds = (big + 255) / 256;
-    bool use_big = big >= 120 && big * 100 >= rounds * 256 * 55 && d->M >= 1024 && d->N >= 1024 && d->K >= 1024 && p.splitk == 1;
+    // 256x256 ring kernel when the problem fills the chip with big tiles (ring_chosen above); 128x128 two-stage kernel otherwise
+    bool use_big = p.splitk == 1 && ring_chosen(d);
     // decode regime, ring_split (chosen by the cost model in gemm.hip): 256x256 ring kernel with the K slices over blockIdx.y,
     // one round of <= 256 blocks
     if (p.splitk > 1 && ring_split) {
@@ -589,8 +590,6 @@ int crab_gemm_glds_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* d,
         else hipLaunchKernelGGL((gemm_bt_ring_kernel<256, 256, 2, 4>), grid, dim3(512), 0, s, p);
         return crab_check_launch(ctx, "gemm_bt_ring_kernel(split-K)");
     }
-    if (d->tune == 301) use_big = false;
-    if (d->tune == 302) use_big = true;
     if (use_big) {
         p.tiles_m = (d->M + 255) / 256; p.tiles_n = (d->N + 255) / 256;
         dim3 grid(p.tiles_m * p.tiles_n, batch);
