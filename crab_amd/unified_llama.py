@@ -271,6 +271,9 @@ class UnifiedForCausalLM(nn.Module, UnifiedMetaForCausalLM):
         `batches` = a list of dicts with the four generate() arguments (batch_input_ids, batch_labels, batch_X_modals, batch_task_names).  Every
         batch goes through prepare_multimodal_inputs on its own (its own left padding, like a separate call), then all of them decode IN
         FLIGHT together (GenerationEngine.generate_many).  Returns one id tensor per batch, equal to what generate() returns for it."""
+        for k in ("output_logits", "output_first_logits", "return_dict_in_generate", "inputs_embeds"):
+            if kwargs.get(k) is not None and kwargs.get(k) is not False:
+                raise NotImplementedError(f"generate_batches returns token ids only: {k} is a generate() argument")
         sampling = self._sampling(kwargs)
         embeds = []
         for b in batches:

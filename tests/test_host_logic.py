@@ -92,3 +92,13 @@ def test_plan_batch_splits_when_the_kv_cache_would_not_fit():
     big.kv_budget_bytes = 270 * 2 ** 30 - 15 * 2 ** 30
     assert big.plan_batch(256, 766, 500) == [256]
     assert big.plan_batch(384, 766, 500) == [192, 192]
+
+
+def test_generate_batches_refuses_generate_only_arguments():
+    """generate_batches returns ids only; the per-call extras of generate() are refused loudly instead of being dropped."""
+    from crab_amd.unified_llama import UnifiedForCausalLM
+    class _Stub:
+        _sampling = staticmethod(UnifiedForCausalLM._sampling)
+    for k in ("output_logits", "output_first_logits", "return_dict_in_generate"):
+        with pytest.raises(NotImplementedError, match=k):
+            UnifiedForCausalLM.generate_batches.__wrapped__(_Stub(), [], **{k: True})
