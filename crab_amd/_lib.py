@@ -37,6 +37,7 @@ class GemmDesc(C.Structure):
         ("lora_RA", C.c_void_p), ("lora_ldra", C.c_int64), ("lora_nl", C.c_int32), ("lora_r", C.c_int32), ("lora_scaling", C.c_float),
         ("rope_S", C.c_int32), ("rope_ld_pos", C.c_int64), ("rope_pos_ids", C.c_void_p),
         ("rope_vt", C.c_void_p), ("rope_vt_ld", C.c_int64),
+        ("r_fp32", C.c_int32),
     ]
 
 
@@ -83,7 +84,7 @@ class EncIO(C.Structure):
     _fields_ = [("x", C.c_void_p), ("a", C.c_void_p), ("y", C.c_void_p), ("qkv", C.c_void_p), ("att", C.c_void_p), ("f", C.c_void_p),
                 ("vt", C.c_void_p), ("vt_bytes", C.c_int64), ("enc", C.c_void_p), ("enc_rows", C.c_int32),
                 ("bias", C.c_void_p), ("gate", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
-                ("B", C.c_int32), ("S", C.c_int32)]
+                ("B", C.c_int32), ("S", C.c_int32), ("x_fp32", C.c_int32)]
 
 
 class LinearGroup(C.Structure):
@@ -116,6 +117,7 @@ class LlamaIO(C.Structure):
         ("vt", C.c_void_p), ("vt_ld", C.c_int64), ("pos_dev", C.c_void_p),
         ("B", C.c_int32), ("S", C.c_int32), ("Tmax", C.c_int32), ("pos0", C.c_int32), ("u_qkv_ready", C.c_int32),
         ("attn_ws", C.c_void_p), ("attn_ws_bytes", C.c_int64),
+        ("x_fp32", C.c_int32),
     ]
 
 
@@ -152,6 +154,11 @@ SYMBOLS = {
     "crab_rmsnorm": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _i, _i, _f]),
     "crab_layernorm": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _f]),
     "crab_embedding": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i]),
+    "crab_embedding_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i]),
+    "crab_rmsnorm_f32": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _i, _i, _f]),
+    "crab_layernorm_f32": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _f]),
+    "crab_cast_rows_bf16_f32": (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _i, _i]),
+    "crab_cast_rows_f32_bf16": (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _i, _i]),
     "crab_rope_table": (_i, [_vp, _vp, _vp, _i, _i, _f]),
     "crab_qkv_rope_split": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "crab_qkv_rope_split_ids": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i64]),

@@ -86,6 +86,13 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// Storage flags carried in the GEMM kernels' `c_fp32` parameter word: bit 0 = C is fp32, bit 1 = R is fp32 (crab_gemm_desc.c_fp32 / r_fp32;
+// both with R == C = the fp32 residual stream)
+enum { CF_C32 = 1, CF_R32 = 2 };
+__device__ __forceinline__ float ld_res(const bf16_t* R, long idx, int flags) {
+    return (flags & CF_R32) ? reinterpret_cast<const float*>(R)[idx] : bf2f(R[idx]);
+}
+
 // activations selectable in GEMM epilogues / elementwise kernels
 // ACT_SWIGLU_PAIR: the weight rows are INTERLEAVED (gate_i, up_i): out[m, j] = silu(v[m, 2j]) * v[m, 2j+1], C has N/2 columns
 // (the SwiGLU of `down(silu(gate(x)) * up(x))`, modeling_llama.py:269, fused into the gate|up projection)

@@ -34,3 +34,6 @@ static inline int crab_check_launch(crab_ctx* ctx, const char* what) {
             return CRAB_E_HIP;                                                                   \
         }                                                                                        \
     } while (0)
+
+// the kernels' storage-flags word (common.h CF_C32 | CF_R32) of a GEMM descriptor
+static inline int crab_cflags(const crab_gemm_desc* d) { return (d->c_fp32 ? 1 : 0) | ((d->r_fp32 && d->R) ? 2 : 0); }

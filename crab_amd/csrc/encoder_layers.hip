@@ -6,9 +6,12 @@
 //   CLIP ViT layer   (HF CLIPEncoderLayer as used by models/multimodal_encoder.py:52-84; pre-LN, quick-GELU):
 //       a = LN1(x); qkv = a.Wqkv^T + b; att = softmax(q k^T / sqrt(d)) v; x2 = att.Wo^T + b + x; a = LN2(x2); f = quick_gelu(a.W1^T + b);
 //       x = f.W2^T + b + x2
+//       io->x_fp32: x and x2 (= io->y) are fp32 - the residual stream of the 23-layer pre-LN tower is never rounded to bf16
 //   BEATs layer      (models/beats/backbone.py:214-275 post-LN deep-norm; attention :432-684 with the gated relative position bias):
 //       qkv = x.Wqkv^T + b; gate = gru_gate(q); att = softmax(q k^T / sqrt(d) + gate * bias) v; x = LN(att.Wo^T + b + alpha x);
 //       x = LN(gelu(x.W1^T + b).W2^T + b + alpha x)
+//       io->x_fp32 (BEATs and Q-Former, post-LN): the pre-LN sums (io->y) are fp32 and the LayerNorm reads them unrounded; x itself stays bf16
+//       (it is the next GEMM's operand anyway)
 //   Q-Former layer   (models/Qformer.py:404-476 BertLayer with cross_attention_freq = 1, query branch :483-486):
 //       self-attention over the nq query rows, post-LN; cross-attention to the m encoder rows (K / V from `enc`), post-LN; query FFN
 //       (intermediate_query / output_query), post-LN
@@ -18,11 +21,11 @@
 namespace {
 
 int dense(crab_ctx* ctx, void* stream, const crab_enc_io* io, const crab_dense* w, const void* a, int64_t lda, void* c, int64_t ldc, int M, int act,
-          const void* residual, int64_t ldr, float res_scale) {
+          const void* residual, int64_t ldr, float res_scale, int c_fp32 = 0, int r_fp32 = 0) {
     crab_gemm_desc d;
     memset(&d, 0, sizeof(d));
     d.A = a; d.lda = lda; d.B = w->W; d.ldb = w->ldw; d.C = c; d.ldc = ldc; d.bias = w->bias;
-    d.R = residual; d.ldr = ldr; d.res_scale = res_scale;
+    d.R = residual; d.ldr = ldr; d.res_scale = res_scale; d.c_fp32 = c_fp32; d.r_fp32 = residual ? r_fp32 : 0;
     d.M = M; d.N = w->N; d.K = w->K; d.act = act; d.batch = 1; d.nb0 = 1;
     if (M <= 256) { d.workspace = io->workspace; d.workspace_bytes = io->workspace_bytes; }     // the rule of crab_amd/ops.py: gemm()
     return crab_gemm_bf16(ctx, stream, &d);
@@ -49,6 +52,12 @@ int attention(crab_ctx* ctx, void* stream, const crab_enc_io* io, const uint16_t
     return crab_attn_fwd(ctx, stream, &a);
 }
 
+// LayerNorm of bf16 rows, or of fp32 rows (the fp32 residual stream / fp32 pre-LN sums)
+int ln(crab_ctx* ctx, void* stream, int x_fp32, const void* x, int64_t ldx, const crab_ln* w, void* y, int64_t ldy, int M, int D) {
+    return x_fp32 ? crab_layernorm_f32(ctx, stream, (const float*)x, ldx, w->w, w->b, y, ldy, M, D, w->eps)
+                  : crab_layernorm(ctx, stream, x, ldx, w->w, w->b, y, ldy, M, D, w->eps);
+}
+
 int check_io(crab_ctx* ctx, const crab_enc_io* io, bool need_f, const char* who) {
     char msg[160];
     if (!io || !io->x || !io->a || !io->qkv || !io->att || !io->vt || !io->y || (need_f && !io->f) || io->B <= 0 || io->S <= 0) {
@@ -72,13 +81,14 @@ int crab_clip_layer(crab_ctx* ctx, void* stream, const crab_clip_layer_w* w, cra
         return crab_fail(ctx, CRAB_E_INVALID, "clip_layer: shapes do not chain (qkv [3D, D], out [D, D], fc1 [I, D], fc2 [D, I])");
     const int d = D / H;
     uint16_t* qkv = (uint16_t*)io->qkv;
-    if ((rc = crab_layernorm(ctx, stream, io->x, D, w->ln1.w, w->ln1.b, io->a, D, M, D, w->ln1.eps))) return rc;
+    const int xf = io->x_fp32 ? 1 : 0;
+    if ((rc = ln(ctx, stream, xf, io->x, D, &w->ln1, io->a, D, M, D))) return rc;
     if ((rc = dense(ctx, stream, io, &w->qkv, io->a, D, qkv, 3 * D, M, CRAB_ACT_NONE, nullptr, 0, 1.0f))) return rc;
     if ((rc = attention(ctx, stream, io, qkv, 3 * D, qkv + D, 3 * D, qkv, 3 * D, H, io->B, H, io->S, io->S, d, nullptr, nullptr))) return rc;
-    if ((rc = dense(ctx, stream, io, &w->out, io->att, D, io->y, D, M, CRAB_ACT_NONE, io->x, D, 1.0f))) return rc;          // y = x + attn
-    if ((rc = crab_layernorm(ctx, stream, io->y, D, w->ln2.w, w->ln2.b, io->a, D, M, D, w->ln2.eps))) return rc;
+    if ((rc = dense(ctx, stream, io, &w->out, io->att, D, io->y, D, M, CRAB_ACT_NONE, io->x, D, 1.0f, xf, xf))) return rc;  // y = x + attn
+    if ((rc = ln(ctx, stream, xf, io->y, D, &w->ln2, io->a, D, M, D))) return rc;
     if ((rc = dense(ctx, stream, io, &w->fc1, io->a, D, io->f, w->fc1.N, M, CRAB_ACT_QUICK_GELU, nullptr, 0, 1.0f))) return rc;
-    return dense(ctx, stream, io, &w->fc2, io->f, w->fc1.N, io->x, D, M, CRAB_ACT_NONE, io->y, D, 1.0f);                    // x = y + mlp
+    return dense(ctx, stream, io, &w->fc2, io->f, w->fc1.N, io->x, D, M, CRAB_ACT_NONE, io->y, D, 1.0f, xf, xf);            // x = y + mlp
 }
 
 int crab_beats_layer(crab_ctx* ctx, void* stream, const crab_beats_layer_w* w, crab_enc_io* io) {
@@ -99,11 +109,12 @@ int crab_beats_layer(crab_ctx* ctx, void* stream, const crab_beats_layer_w* w, c
         gate = io->gate;
     }
     if ((rc = attention(ctx, stream, io, qkv, 3 * E, qkv + E, 3 * E, qkv, 3 * E, H, io->B, H, io->S, io->S, d, io->bias, gate))) return rc;
-    if ((rc = dense(ctx, stream, io, &w->out, io->att, E, io->y, E, M, CRAB_ACT_NONE, io->x, E, w->alpha))) return rc;       // y = alpha x + attn
-    if ((rc = crab_layernorm(ctx, stream, io->y, E, w->ln_attn.w, w->ln_attn.b, io->x, E, M, E, w->ln_attn.eps))) return rc;
+    const int yf = io->x_fp32 ? 1 : 0;
+    if ((rc = dense(ctx, stream, io, &w->out, io->att, E, io->y, E, M, CRAB_ACT_NONE, io->x, E, w->alpha, yf, 0))) return rc;       // y = alpha x + attn
+    if ((rc = ln(ctx, stream, yf, io->y, E, &w->ln_attn, io->x, E, M, E))) return rc;
     if ((rc = dense(ctx, stream, io, &w->fc1, io->x, E, io->f, w->fc1.N, M, CRAB_ACT_GELU, nullptr, 0, 1.0f))) return rc;
-    if ((rc = dense(ctx, stream, io, &w->fc2, io->f, w->fc1.N, io->y, E, M, CRAB_ACT_NONE, io->x, E, w->alpha))) return rc;
-    return crab_layernorm(ctx, stream, io->y, E, w->ln_final.w, w->ln_final.b, io->x, E, M, E, w->ln_final.eps);
+    if ((rc = dense(ctx, stream, io, &w->fc2, io->f, w->fc1.N, io->y, E, M, CRAB_ACT_NONE, io->x, E, w->alpha, yf, 0))) return rc;
+    return ln(ctx, stream, yf, io->y, E, &w->ln_final, io->x, E, M, E);
 }
 
 int crab_qformer_layer(crab_ctx* ctx, void* stream, const crab_qformer_layer_w* w, crab_enc_io* io) {
@@ -122,18 +133,19 @@ int crab_qformer_layer(crab_ctx* ctx, void* stream, const crab_qformer_layer_w* 
     if ((rc = dense(ctx, stream, io, &w->sq, io->x, h, io->a, h, M, CRAB_ACT_NONE, nullptr, 0, 1.0f))) return rc;
     if ((rc = dense(ctx, stream, io, &w->skv, io->x, h, kv, 2 * h, M, CRAB_ACT_NONE, nullptr, 0, 1.0f))) return rc;
     if ((rc = attention(ctx, stream, io, (const uint16_t*)io->a, h, kv, 2 * h, kv, 2 * h, 0, B, H, nq, nq, d, nullptr, nullptr))) return rc;
-    if ((rc = dense(ctx, stream, io, &w->so, io->att, h, io->y, h, M, CRAB_ACT_NONE, io->x, h, 1.0f))) return rc;
-    if ((rc = crab_layernorm(ctx, stream, io->y, h, w->sln.w, w->sln.b, io->x, h, M, h, w->sln.eps))) return rc;
+    const int yf = io->x_fp32 ? 1 : 0;
+    if ((rc = dense(ctx, stream, io, &w->so, io->att, h, io->y, h, M, CRAB_ACT_NONE, io->x, h, 1.0f, yf, 0))) return rc;
+    if ((rc = ln(ctx, stream, yf, io->y, h, &w->sln, io->x, h, M, h))) return rc;
     // ---- cross-attention to the encoder rows
     if ((rc = dense(ctx, stream, io, &w->cq, io->x, h, io->a, h, M, CRAB_ACT_NONE, nullptr, 0, 1.0f))) return rc;
     if ((rc = dense(ctx, stream, io, &w->ckv, io->enc, w->ckv.K, kv, 2 * h, B * m, CRAB_ACT_NONE, nullptr, 0, 1.0f))) return rc;
     if ((rc = attention(ctx, stream, io, (const uint16_t*)io->a, h, kv, 2 * h, kv, 2 * h, 0, B, H, nq, m, d, nullptr, nullptr))) return rc;
-    if ((rc = dense(ctx, stream, io, &w->co, io->att, h, io->y, h, M, CRAB_ACT_NONE, io->x, h, 1.0f))) return rc;
-    if ((rc = crab_layernorm(ctx, stream, io->y, h, w->cln.w, w->cln.b, io->x, h, M, h, w->cln.eps))) return rc;
+    if ((rc = dense(ctx, stream, io, &w->co, io->att, h, io->y, h, M, CRAB_ACT_NONE, io->x, h, 1.0f, yf, 0))) return rc;
+    if ((rc = ln(ctx, stream, yf, io->y, h, &w->cln, io->x, h, M, h))) return rc;
     // ---- query FFN
     if ((rc = dense(ctx, stream, io, &w->iq, io->x, h, io->f, w->iq.N, M, CRAB_ACT_GELU, nullptr, 0, 1.0f))) return rc;
-    if ((rc = dense(ctx, stream, io, &w->oq, io->f, w->iq.N, io->y, h, M, CRAB_ACT_NONE, io->x, h, 1.0f))) return rc;
-    return crab_layernorm(ctx, stream, io->y, h, w->oln.w, w->oln.b, io->x, h, M, h, w->oln.eps);
+    if ((rc = dense(ctx, stream, io, &w->oq, io->f, w->iq.N, io->y, h, M, CRAB_ACT_NONE, io->x, h, 1.0f, yf, 0))) return rc;
+    return ln(ctx, stream, yf, io->y, h, &w->oln, io->x, h, M, h);
 }
 
 int crab_sizeof_enc_io(void) { return (int)sizeof(crab_enc_io); }

@@ -195,7 +195,7 @@ __global__ void splitk_epilogue_kernel(const float* __restrict__ part, int S, in
         if (bias) { for (int r = 0; r < 4; ++r) v[r] += bf2f(bias[n + r]); }
         const float o0 = v[0] / (1.0f + __expf(-v[0])) * v[1], o1 = v[2] / (1.0f + __expf(-v[2])) * v[3];
         const long oc = (long)m * ldc + (n >> 1);
-        if (c_fp32) { reinterpret_cast<float*>(C)[oc] = o0; reinterpret_cast<float*>(C)[oc + 1] = o1; }
+        if (c_fp32 & CF_C32) { reinterpret_cast<float*>(C)[oc] = o0; reinterpret_cast<float*>(C)[oc + 1] = o1; }
         else { reinterpret_cast<bf16_t*>(C)[oc] = f2bf(o0); reinterpret_cast<bf16_t*>(C)[oc + 1] = f2bf(o1); }
         return;
     }
@@ -203,8 +203,8 @@ __global__ void splitk_epilogue_kernel(const float* __restrict__ part, int S, in
         float x = v[r];
         if (bias) x += bf2f(bias[n + r]);
         x = apply_act(x, act);
-        if (R) x += res_scale * bf2f(R[(long)m * ldr + n + r]);
-        if (c_fp32) reinterpret_cast<float*>(C)[(long)m * ldc + n + r] = x;
+        if (R) x += res_scale * ld_res(R, (long)m * ldr + n + r, c_fp32);
+        if (c_fp32 & CF_C32) reinterpret_cast<float*>(C)[(long)m * ldc + n + r] = x;
         else reinterpret_cast<bf16_t*>(C)[(long)m * ldc + n + r] = f2bf(x);
     }
 }
@@ -249,6 +249,9 @@ struct RouteP {                                   // router of the next projecti
 // Row-owning variant of the split-K epilogue: one block per output row sums the K-slice partials (fixed order), applies
 // bias / activation / residual, writes C (bf16) AND the RMS-normalised row rmsnorm(C)*w for the next projection
 // (LlamaRMSNorm, modeling_llama.py:112-117, fused behind o_proj / down_proj in the decode regime).  N <= 8192.
+// XF: R and C are the FP32 residual stream (ldr / ldc in fp32 elements): the row is stored unrounded, the norm sees that fp32 row and the
+// normalised row is bf16(x * rstd * w) without the intermediate rounding of x_hat.
+template <bool XF>
 __global__ __launch_bounds__(256) void splitk_epilogue_norm_kernel(const float* __restrict__ part, int S, int M, int N,
                                                                     const bf16_t* __restrict__ bias, int act, const bf16_t* __restrict__ R,
                                                                     long ldr, float res_scale, bf16_t* __restrict__ C, long ldc,
@@ -284,7 +287,13 @@ __global__ __launch_bounds__(256) void splitk_epilogue_norm_kernel(const float* 
                 v1 += *reinterpret_cast<const f32x4_t*>(pp + s * MN + 4);
             }
             u32x4 rr = {0u, 0u, 0u, 0u}, bb = {0u, 0u, 0u, 0u};
-            if (R) rr = *reinterpret_cast<const u32x4*>(R + (long)m * ldr + n);
+            f32x4_t rf0 = {0.f, 0.f, 0.f, 0.f}, rf1 = {0.f, 0.f, 0.f, 0.f};
+            if (XF) {
+                if (R) {
+                    rf0 = *reinterpret_cast<const f32x4_t*>(reinterpret_cast<const float*>(R) + (long)m * ldr + n);
+                    rf1 = *reinterpret_cast<const f32x4_t*>(reinterpret_cast<const float*>(R) + (long)m * ldr + n + 4);
+                }
+            } else if (R) rr = *reinterpret_cast<const u32x4*>(R + (long)m * ldr + n);
             if (bias) bb = *reinterpret_cast<const u32x4*>(bias + n);
             u32x4 o;
 #pragma unroll
@@ -293,13 +302,26 @@ __global__ __launch_bounds__(256) void splitk_epilogue_norm_kernel(const float* 
                 const uint32_t bw = bb[r >> 1], rw = rr[r >> 1];
                 if (bias) x += (r & 1) ? hi_bf(bw) : lo_bf(bw);
                 x = apply_act(x, act);
-                if (R) x += res_scale * ((r & 1) ? hi_bf(rw) : lo_bf(rw));
-                xv[q][r] = bf2f(f2bf(x));                      // the norm sees the stored bf16 value
+                if (XF) {
+                    if (R) x += res_scale * (r < 4 ? rf0[r & 3] : rf1[r & 3]);
+                    xv[q][r] = x;                              // fp32 residual stream: stored and normalised unrounded
+                } else {
+                    if (R) x += res_scale * ((r & 1) ? hi_bf(rw) : lo_bf(rw));
+                    xv[q][r] = bf2f(f2bf(x));                  // the norm sees the stored bf16 value
+                }
                 ss += xv[q][r] * xv[q][r];
             }
+            if (XF) {
+                if (py == 0) {
+                    float* cx = reinterpret_cast<float*>(C) + (long)m * ldc + n;
+                    *reinterpret_cast<f32x4_t*>(cx) = f32x4_t{xv[q][0], xv[q][1], xv[q][2], xv[q][3]};
+                    *reinterpret_cast<f32x4_t*>(cx + 4) = f32x4_t{xv[q][4], xv[q][5], xv[q][6], xv[q][7]};
+                }
+            } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = pack_bf2(xv[q][2 * r], xv[q][2 * r + 1]);
-            if (py == 0) *reinterpret_cast<u32x4*>(C + (long)m * ldc + n) = o;
+                for (int r = 0; r < 4; ++r) o[r] = pack_bf2(xv[q][2 * r], xv[q][2 * r + 1]);
+                if (py == 0) *reinterpret_cast<u32x4*>(C + (long)m * ldc + n) = o;
+            }
         }
     }
     ss = wave_sum(ss);
@@ -313,7 +335,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_norm_kernel(const float* 
             const u32x4 wv = *reinterpret_cast<const u32x4*>(nw + n);
             float h8[8];
 #pragma unroll
-            for (int r = 0; r < 8; ++r) h8[r] = bf2f(f2bf(xv[q][r] * rstd)) * ((r & 1) ? hi_bf(wv[r >> 1]) : lo_bf(wv[r >> 1]));
+            for (int r = 0; r < 8; ++r) h8[r] = (XF ? xv[q][r] * rstd : bf2f(f2bf(xv[q][r] * rstd))) * ((r & 1) ? hi_bf(wv[r >> 1]) : lo_bf(wv[r >> 1]));
             u32x4 o;
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[r] = pack_bf2(h8[2 * r], h8[2 * r + 1]);
@@ -538,7 +560,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_rope_kernel(const float* 
 
 // The row-owning reduction (splitk_epilogue_norm_kernel): conditions and launch, shared by the split-K paths and the M <= 16 path
 static bool norm_epilogue_ok(const crab_gemm_desc* d) {
-    return d->norm_w && !d->c_fp32 && (d->N & 7) == 0 && d->N <= 8192 && (d->ldc & 7) == 0 && (d->ld_norm & 7) == 0 &&
+    return d->norm_w && (d->N & 7) == 0 && d->N <= 8192 && (d->ldc & 7) == 0 && (d->ld_norm & 7) == 0 &&
            (((uintptr_t)d->C | (uintptr_t)d->norm_out | (uintptr_t)d->norm_w | (uintptr_t)d->R | (uintptr_t)d->bias | (uintptr_t)d->route_RA) & 15) == 0 &&
            (!d->R || (d->ldr & 7) == 0) && (!d->route_RA || ((d->route_ldra & 7) == 0 && d->route_nl <= 8 &&
                                                              d->route_nproj * (d->route_nl + d->route_r) <= 64));
@@ -552,17 +574,21 @@ static int launch_norm_epilogue(crab_ctx* ctx, hipStream_t s, const crab_gemm_de
         rf.RA = (const bf16_t*)d->route_RA; rf.U = (bf16_t*)d->route_U; rf.ldra = d->route_ldra; rf.ldu = d->route_ldu;
         rf.nproj = d->route_nproj; rf.nl = d->route_nl; rf.r = d->route_r; rf.ucols = d->route_ucols; rf.scaling = d->route_scaling;
         const int P = (rf.RA && rf.nproj > 1 && rf.nl + rf.r == 11) ? rf.nproj : 1;
-        hipLaunchKernelGGL(splitk_epilogue_norm_kernel, dim3(d->M, P), dim3(256), 0, s, part, splitk, d->M, d->N, (const bf16_t*)nullptr, ACT_NONE,
-                           (const bf16_t*)nullptr, 0L, 1.0f, (bf16_t*)d->C, (long)d->ldc, (const bf16_t*)d->norm_w, d->norm_eps,
-                           (bf16_t*)d->norm_out, (long)d->ld_norm, rf);
+#define NE_LAUNCH(XF_) hipLaunchKernelGGL((splitk_epilogue_norm_kernel<XF_>), dim3(d->M, P), dim3(256), 0, s, part, splitk, d->M, d->N, (const bf16_t*)nullptr, ACT_NONE, \
+                           (const bf16_t*)nullptr, 0L, 1.0f, (bf16_t*)d->C, (long)d->ldc, (const bf16_t*)d->norm_w, d->norm_eps,                      \
+                           (bf16_t*)d->norm_out, (long)d->ld_norm, rf)
+        if (d->c_fp32) NE_LAUNCH(true); else NE_LAUNCH(false);
+#undef NE_LAUNCH
         return crab_check_launch(ctx, "splitk_epilogue_norm_kernel");
     }
     RouteP rt;
     rt.RA = (const bf16_t*)d->route_RA; rt.U = (bf16_t*)d->route_U; rt.ldra = d->route_ldra; rt.ldu = d->route_ldu;
     rt.nproj = d->route_nproj; rt.nl = d->route_nl; rt.r = d->route_r; rt.ucols = d->route_ucols; rt.scaling = d->route_scaling;
-    hipLaunchKernelGGL(splitk_epilogue_norm_kernel, dim3(d->M), dim3(256), 0, s, part, splitk, d->M, d->N, (const bf16_t*)d->bias, d->act,
-                       (const bf16_t*)d->R, (long)d->ldr, d->res_scale, (bf16_t*)d->C, (long)d->ldc, (const bf16_t*)d->norm_w, d->norm_eps,
-                       (bf16_t*)d->norm_out, (long)d->ld_norm, rt);
+#define NE_LAUNCH(XF_) hipLaunchKernelGGL((splitk_epilogue_norm_kernel<XF_>), dim3(d->M), dim3(256), 0, s, part, splitk, d->M, d->N, (const bf16_t*)d->bias, d->act, \
+                       (const bf16_t*)d->R, (long)d->ldr, d->res_scale, (bf16_t*)d->C, (long)d->ldc, (const bf16_t*)d->norm_w, d->norm_eps,             \
+                       (bf16_t*)d->norm_out, (long)d->ld_norm, rt)
+    if (d->c_fp32) NE_LAUNCH(true); else NE_LAUNCH(false);
+#undef NE_LAUNCH
     return crab_check_launch(ctx, "splitk_epilogue_norm_kernel");
 }
 
@@ -573,7 +599,8 @@ static int post_norm(crab_ctx* ctx, void* stream, const crab_gemm_desc* d) {
         return crab_qkv_rope_split(ctx, stream, d->C, d->ldc, d->rope_tab, d->rope_k_cache, d->rope_v_cache, nullptr, 0, d->M, 1, d->rope_H,
                                    d->rope_Hk, d->rope_d, d->rope_Tmax, d->rope_pos0, d->rope_pos_dev);
     if (!d->norm_w) return CRAB_OK;
-    int rc = crab_rmsnorm(ctx, stream, d->C, d->ldc, d->norm_w, d->norm_out, d->ld_norm, d->M, d->N, d->norm_eps);
+    int rc = d->c_fp32 ? crab_rmsnorm_f32(ctx, stream, (const float*)d->C, d->ldc, d->norm_w, d->norm_out, d->ld_norm, d->M, d->N, d->norm_eps)
+                       : crab_rmsnorm(ctx, stream, d->C, d->ldc, d->norm_w, d->norm_out, d->ld_norm, d->M, d->N, d->norm_eps);
     if (rc || !d->route_RA) return rc;
     return crab_hyperlora_route(ctx, stream, d->norm_out, d->ld_norm, d->route_RA, d->route_ldra, d->M, d->N, d->route_nproj, d->route_nl,
                                 d->route_r, d->route_U, d->route_ldu, d->route_ucols, d->route_scaling, d->workspace, d->workspace_bytes);
@@ -581,7 +608,15 @@ static int post_norm(crab_ctx* ctx, void* stream, const crab_gemm_desc* d) {
 
 extern "C" int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc* d) {
     if (!ctx) return CRAB_E_INVALID;
-    if (d && d->norm_w && (!d->norm_out || d->c_fp32 || d->batch > 1)) return crab_fail(ctx, CRAB_E_INVALID, "gemm: post-norm needs norm_out, bf16 C, no batch");
+    if (d && d->norm_w && (!d->norm_out || d->batch > 1)) return crab_fail(ctx, CRAB_E_INVALID, "gemm: post-norm needs norm_out, no batch");
+    // storage of the residual stream: R and C are bf16 (r01-r03) or, with c_fp32 = r_fp32 = 1, the fp32 residual stream.  The post-norm reads
+    // C, so an fp32 C with a bf16 R (or the reverse) under a post-norm is refused rather than guessed at
+    if (d && d->r_fp32 && (!d->R || d->batch > 1 || (d->ldr & 3) || ((uintptr_t)d->R & 15)))
+        return crab_fail(ctx, CRAB_E_INVALID, "gemm: r_fp32 needs R (16-byte aligned, ldr % 4 == 0), no batch");
+    if (d && d->norm_w && d->R && (!!d->c_fp32 != !!d->r_fp32))
+        return crab_fail(ctx, CRAB_E_INVALID, "gemm: with a post-norm R and C must have the same storage (both bf16, or c_fp32 = r_fp32 = 1)");
+    if (d && d->norm_w && d->c_fp32 && ((d->ldc & 3) || ((uintptr_t)d->C & 15)))
+        return crab_fail(ctx, CRAB_E_INVALID, "gemm: an fp32 C under a post-norm needs 16-byte aligned rows");
     if (!d || !d->A || !d->B || !d->C) return crab_fail(ctx, CRAB_E_INVALID, "gemm: null operand");
     if (d->route_RA && (!d->norm_w || !d->route_U || d->route_nproj < 1 || d->route_nl < 1 || d->route_r < 1))
         return crab_fail(ctx, CRAB_E_INVALID, "gemm: the next-group router needs the fused post-norm, route_U and positive nproj / nl / r");
@@ -726,7 +761,7 @@ extern "C" int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc*
     p.bias = (const bf16_t*)d->bias; p.R = (const bf16_t*)d->R;
     p.A2 = (const bf16_t*)d->A2; p.B2 = (const bf16_t*)d->B2;
     p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc; p.ldr = d->ldr; p.lda2 = d->lda2; p.ldb2 = d->ldb2;
-    p.M = d->M; p.N = d->N; p.K = d->K; p.K2 = d->A2 ? d->K2 : 0; p.act = d->act; p.c_fp32 = d->c_fp32;
+    p.M = d->M; p.N = d->N; p.K = d->K; p.K2 = d->A2 ? d->K2 : 0; p.act = d->act; p.c_fp32 = crab_cflags(d);
     p.res_scale = d->res_scale;
     int batch = d->batch > 1 ? d->batch : 1;
     p.nb0 = (batch > 1 && d->nb0 > 0) ? d->nb0 : 1;
@@ -773,7 +808,7 @@ extern "C" int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc*
         }
         long nthr = (long)d->M * ((d->N + 3) / 4);
         hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, p.part, splitk, d->M, d->N, p.bias, d->act,
-                           p.R, (long)d->ldr, d->res_scale, d->C, (long)d->ldc, d->c_fp32);
+                           p.R, (long)d->ldr, d->res_scale, d->C, (long)d->ldc, crab_cflags(d));
         rc = crab_check_launch(ctx, "splitk_epilogue_kernel");
         if (rc) return rc;
         return post_norm(ctx, stream, d);

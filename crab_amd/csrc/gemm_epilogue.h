@@ -69,17 +69,22 @@ __device__ __forceinline__ void full_impl(const f32x4_t (&acc)[TN][TM], int m_la
                 const float g1 = acc[ni][mi][2] + bv[ni][2], u1 = acc[ni][mi][3] + bv[ni][3];
                 const float o0 = g0 / (1.0f + __expf(-g0)) * u0, o1 = g1 / (1.0f + __expf(-g1)) * u1;
                 const long oc = coff + (long)(m_lane + mi * 16) * ldc + ((n_lane + ni * 16) >> 1);
-                if (c_fp32) *reinterpret_cast<float2*>(reinterpret_cast<float*>(Cv) + oc) = make_float2(o0, o1);
+                if (c_fp32 & CF_C32) *reinterpret_cast<float2*>(reinterpret_cast<float*>(Cv) + oc) = make_float2(o0, o1);
                 else *reinterpret_cast<uint32_t*>(reinterpret_cast<bf16_t*>(Cv) + oc) = pack_bf2(o0, o1);
                 continue;
             }
             float v0 = act_c<ACT>(acc[ni][mi][0] + bv[ni][0]), v1 = act_c<ACT>(acc[ni][mi][1] + bv[ni][1]);
             float v2 = act_c<ACT>(acc[ni][mi][2] + bv[ni][2]), v3 = act_c<ACT>(acc[ni][mi][3] + bv[ni][3]);
             if (R) {
-                u32x2 rr = *reinterpret_cast<const u32x2*>(R + rowR + ni * 16);
-                v0 += rs * lo_bf(rr.x); v1 += rs * hi_bf(rr.x); v2 += rs * lo_bf(rr.y); v3 += rs * hi_bf(rr.y);
+                if (c_fp32 & CF_R32) {              // fp32 residual stream
+                    const float4 rr = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(R) + rowR + ni * 16);
+                    v0 += rs * rr.x; v1 += rs * rr.y; v2 += rs * rr.z; v3 += rs * rr.w;
+                } else {
+                    u32x2 rr = *reinterpret_cast<const u32x2*>(R + rowR + ni * 16);
+                    v0 += rs * lo_bf(rr.x); v1 += rs * hi_bf(rr.x); v2 += rs * lo_bf(rr.y); v3 += rs * hi_bf(rr.y);
+                }
             }
-            if (c_fp32) {
+            if (c_fp32 & CF_C32) {
                 *reinterpret_cast<float4*>(reinterpret_cast<float*>(Cv) + rowC + ni * 16) = make_float4(v0, v1, v2, v3);
             } else if constexpr (WIDE && TN % 2 == 0) {
                 // column tiles ni (even) and ni + 1 are exchanged between the even and odd lane rows: one 16-byte store per pair
@@ -117,7 +122,7 @@ template <int TM, int TN>
 __device__ __forceinline__ void gemm_epilogue_full(const f32x4_t (&acc)[TN][TM], int act, int m_lane, int n_lane, const bf16_t* bias,
                                                    const bf16_t* R, long ldr, float rs, void* C, long coff, long ldc, int c_fp32) {
     // 16-byte stores need bf16 C with 16-byte aligned rows (wave-uniform condition)
-    const bool wide = !c_fp32 && (ldc & 7) == 0 && (coff & 7) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0;
+    const bool wide = !(c_fp32 & CF_C32) && (ldc & 7) == 0 && (coff & 7) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0;
     if (wide) gemm_epilogue_full_w<TM, TN, true>(acc, act, m_lane, n_lane, bias, R, ldr, rs, C, coff, ldc, c_fp32);
     else gemm_epilogue_full_w<TM, TN, false>(acc, act, m_lane, n_lane, bias, R, ldr, rs, C, coff, ldc, c_fp32);
 }
@@ -142,7 +147,7 @@ __device__ __forceinline__ void guarded_impl(const f32x4_t (&acc)[TN][TM], int m
                 for (int r = 0; r < 4; ++r) t[r] = acc[ni][mi][r] + (bias ? bf2f(bias[n + r]) : 0.f);
                 const float o0 = t[0] / (1.0f + __expf(-t[0])) * t[1], o1 = t[2] / (1.0f + __expf(-t[2])) * t[3];
                 const long oc = coff + (long)m * ldc + (n >> 1);
-                if (c_fp32) { reinterpret_cast<float*>(Cv)[oc] = o0; reinterpret_cast<float*>(Cv)[oc + 1] = o1; }
+                if (c_fp32 & CF_C32) { reinterpret_cast<float*>(Cv)[oc] = o0; reinterpret_cast<float*>(Cv)[oc + 1] = o1; }
                 else { reinterpret_cast<bf16_t*>(Cv)[oc] = f2bf(o0); reinterpret_cast<bf16_t*>(Cv)[oc + 1] = f2bf(o1); }
                 continue;
             }
@@ -154,11 +159,14 @@ __device__ __forceinline__ void guarded_impl(const f32x4_t (&acc)[TN][TM], int m
                 v[r] = act_c<ACT>(x);
             }
             if (n + 3 < N && vec_ok) {
-                if (R) {
+                if (R && (c_fp32 & CF_R32)) {
+                    const float4 rr = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(R) + (long)m * ldr + n);
+                    v[0] += rs * rr.x; v[1] += rs * rr.y; v[2] += rs * rr.z; v[3] += rs * rr.w;
+                } else if (R) {
                     u32x2 rr = *reinterpret_cast<const u32x2*>(R + (long)m * ldr + n);
                     v[0] += rs * lo_bf(rr.x); v[1] += rs * hi_bf(rr.x); v[2] += rs * lo_bf(rr.y); v[3] += rs * hi_bf(rr.y);
                 }
-                if (c_fp32) {
+                if (c_fp32 & CF_C32) {
                     *reinterpret_cast<float4*>(reinterpret_cast<float*>(Cv) + coff + (long)m * ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
                 } else {
                     u32x2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
@@ -169,8 +177,8 @@ __device__ __forceinline__ void guarded_impl(const f32x4_t (&acc)[TN][TM], int m
                 for (int r = 0; r < 4; ++r) {
                     if (n + r >= N) break;
                     float x = v[r];
-                    if (R) x += rs * bf2f(R[(long)m * ldr + n + r]);
-                    if (c_fp32) reinterpret_cast<float*>(Cv)[coff + (long)m * ldc + n + r] = x;
+                    if (R) x += rs * ld_res(R, (long)m * ldr + n + r, c_fp32);
+                    if (c_fp32 & CF_C32) reinterpret_cast<float*>(Cv)[coff + (long)m * ldc + n + r] = x;
                     else reinterpret_cast<bf16_t*>(Cv)[coff + (long)m * ldc + n + r] = f2bf(x);
                 }
             }

@@ -10,6 +10,7 @@
 //     x   += [att | u] . [Wo | Bcat]^T ; h = rmsnorm(x) * post_attention_layernorm   (+ the gate|up router ahead, M <= 256)
 //     act  = silu(gate(h)) * up(h)                   one GEMM over the interleaved gate|up rows, SwiGLU in its epilogue
 //     x   += [act | u] . [Wdown | Bcat]^T ; h = rmsnorm(x) * next_norm_w              (+ the next layer's q|k|v router ahead)
+// io->x_fp32: x is fp32 (the residual adds of modeling_llama.py:805-827 are never rounded to bf16); h and every GEMM operand stay bf16.
 #include "crab_internal.h"
 #include <math.h>
 #include <stdlib.h>
@@ -56,6 +57,7 @@ int run_group(crab_ctx* ctx, void* stream, const crab_linear_group* g, const cra
     d.C = c.out; d.ldc = c.ldc;
     d.bias = g->bias;
     d.R = c.residual; d.ldr = c.ldr;
+    if (c.residual && io->x_fp32) d.c_fp32 = d.r_fp32 = 1;        // the fp32 residual stream: x is read and written unrounded (o_proj, down_proj)
     d.M = M; d.N = g->N; d.K = g->K;
     d.act = c.act;
     d.res_scale = 1.0f;
@@ -113,6 +115,7 @@ int check_io(crab_ctx* ctx, const crab_llama_layer* L, const crab_llama_io* io, 
     if (io->B <= 0 || io->S <= 0 || io->Tmax <= 0 || io->pos0 < 0) return crab_fail(ctx, CRAB_E_INVALID, "llama_layer: B, S, Tmax must be positive");
     if (!io->x || !io->h || !io->qkv || !io->att || !io->act || !io->k_cache || !io->v_cache || !io->rope_tab)
         return crab_fail(ctx, CRAB_E_INVALID, "llama_layer: x, h, qkv, att, act, k_cache, v_cache and rope_tab are required");
+    if (io->x_fp32 && (((uintptr_t)io->x & 15) || (io->ldx & 3))) return crab_fail(ctx, CRAB_E_INVALID, "llama_layer: the fp32 residual stream needs 16-byte aligned rows");
     if (io->ldx < D || io->ldh < D || io->ldqkv < Nq || io->ldatt < L->H * L->d || io->ldact < I)
         return crab_fail(ctx, CRAB_E_INVALID, "llama_layer: a leading dimension is smaller than its row");
     const bool lora = L->qkv.RA || L->o.RA || L->gu.RA || L->down.RA;

@@ -82,6 +82,77 @@ __global__ __launch_bounds__(256) void norm_kernel(const bf16_t* __restrict__ x,
     }
 }
 
+// The same for an fp32 input row (the fp32 residual stream of the decoder / CLIP tower: x stays fp32 between the projection epilogues,
+// only the normalised row that feeds the next MFMA GEMM is bf16).  No intermediate rounding of x_hat: the reference runs this norm in fp32
+// (scripts/quick_start.sh:42-44 --bf16 False; modeling_llama.py:112-117 with an fp32 input is exact), so y = bf16(x_hat * w [+ b]).
+template <bool RMS, int MAXV = 16>
+__global__ __launch_bounds__(256) void norm_f32in_kernel(const float* __restrict__ x, long ldx, const bf16_t* __restrict__ w,
+                                                         const bf16_t* __restrict__ b, bf16_t* __restrict__ y, long ldy,
+                                                         int M, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + (long)row * ldx;
+    bf16_t* yr = y + (long)row * ldy;
+    f32x4_t v[MAXV][2];
+    const int nvec = D >> 3;                       // D % 8 == 0 (checked on the host)
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        int vi = lane + i * 64;
+        if (vi < nvec) {
+            v[i][0] = *reinterpret_cast<const f32x4_t*>(xr + vi * 8);
+            v[i][1] = *reinterpret_cast<const f32x4_t*>(xr + vi * 8 + 4);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float a = v[i][j >> 2][j & 3];
+                s1 += a;
+                s2 += a * a;
+            }
+        }
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    float mean = 0.f, rstd;
+    if (RMS) {
+        rstd = rsqrtf(s2 / (float)D + eps);
+    } else {
+        mean = s1 / (float)D;
+        float sv = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            int vi = lane + i * 64;
+            if (vi < nvec) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float a = v[i][j >> 2][j & 3] - mean;
+                    sv += a * a;
+                }
+            }
+        }
+        sv = wave_sum(sv);
+        rstd = rsqrtf(sv / (float)D + eps);
+    }
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        int vi = lane + i * 64;
+        if (vi < nvec) {
+            u32x4 wv = *reinterpret_cast<const u32x4*>(w + vi * 8);
+            u32x4 bv = {0u, 0u, 0u, 0u};
+            if (!RMS && b) bv = *reinterpret_cast<const u32x4*>(b + vi * 8);
+            u32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float a = (v[i][j >> 1][(2 * j) & 3] - mean) * rstd, c = (v[i][j >> 1][(2 * j + 1) & 3] - mean) * rstd;
+                a = a * lo_bf(wv[j]) + lo_bf(bv[j]);
+                c = c * hi_bf(wv[j]) + hi_bf(bv[j]);
+                o[j] = pack_bf2(a, c);
+            }
+            *reinterpret_cast<u32x4*>(yr + vi * 8) = o;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ embedding
 __global__ void embedding_kernel(const int64_t* __restrict__ ids, const bf16_t* __restrict__ table, bf16_t* __restrict__ out,
                                  long ldo, int T, int D, int vocab) {
@@ -93,6 +164,43 @@ __global__ void embedding_kernel(const int64_t* __restrict__ ids, const bf16_t* 
     bf16_t* dst = out + (long)t * ldo;
     for (int i = threadIdx.x; i < (D >> 3); i += blockDim.x)
         *reinterpret_cast<u32x4*>(dst + i * 8) = *reinterpret_cast<const u32x4*>(src + i * 8);
+}
+
+// fp32 output rows (the decoder's fp32 residual stream starts here in the decode step)
+__global__ void embedding_f32_kernel(const int64_t* __restrict__ ids, const bf16_t* __restrict__ table, float* __restrict__ out,
+                                     long ldo, int T, int D, int vocab) {
+    const int t = blockIdx.x;
+    long id = ids[t];
+    if (id < 0) return;
+    if (id >= vocab) id = vocab - 1;
+    const bf16_t* src = table + id * (long)D;
+    float* dst = out + (long)t * ldo;
+    for (int i = threadIdx.x; i < (D >> 3); i += blockDim.x) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(src + i * 8);
+        *reinterpret_cast<f32x4_t*>(dst + i * 8) = f32x4_t{lo_bf(v[0]), hi_bf(v[0]), lo_bf(v[1]), hi_bf(v[1])};
+        *reinterpret_cast<f32x4_t*>(dst + i * 8 + 4) = f32x4_t{lo_bf(v[2]), hi_bf(v[2]), lo_bf(v[3]), hi_bf(v[3])};
+    }
+}
+
+// strided row casts between the bf16 activations and the fp32 residual stream (8 columns per thread)
+__global__ void cast_rows_bf16_f32_kernel(const bf16_t* __restrict__ src, long lds_, float* __restrict__ dst, long ldd, int rows, int cols) {
+    const int nv = cols >> 3;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)rows * nv) return;
+    const int r = idx / nv, c = idx % nv;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(src + (long)r * lds_ + c * 8);
+    float* d_ = dst + (long)r * ldd + c * 8;
+    *reinterpret_cast<f32x4_t*>(d_) = f32x4_t{lo_bf(v[0]), hi_bf(v[0]), lo_bf(v[1]), hi_bf(v[1])};
+    *reinterpret_cast<f32x4_t*>(d_ + 4) = f32x4_t{lo_bf(v[2]), hi_bf(v[2]), lo_bf(v[3]), hi_bf(v[3])};
+}
+__global__ void cast_rows_f32_bf16_kernel(const float* __restrict__ src, long lds_, bf16_t* __restrict__ dst, long ldd, int rows, int cols) {
+    const int nv = cols >> 3;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)rows * nv) return;
+    const int r = idx / nv, c = idx % nv;
+    const float* s_ = src + (long)r * lds_ + c * 8;
+    const f32x4_t a = *reinterpret_cast<const f32x4_t*>(s_), b = *reinterpret_cast<const f32x4_t*>(s_ + 4);
+    *reinterpret_cast<u32x4*>(dst + (long)r * ldd + c * 8) = u32x4{pack_bf2(a[0], a[1]), pack_bf2(a[2], a[3]), pack_bf2(b[0], b[1]), pack_bf2(b[2], b[3])};
 }
 
 // ------------------------------------------------------------------------------------------------ RoPE
@@ -648,6 +756,58 @@ int crab_layernorm(crab_ctx* ctx, void* stream, const void* x, int64_t ldx, cons
         hipLaunchKernelGGL((norm_kernel<false>), dim3(cdiv(M, 4)), dim3(256), 0, S_(stream), (const bf16_t*)x, (long)ldx, (const bf16_t*)w,
                            (const bf16_t*)b, (bf16_t*)y, (long)ldy, M, D, eps);
     return crab_check_launch(ctx, "layernorm");
+}
+
+int crab_rmsnorm_f32(crab_ctx* ctx, void* stream, const float* x, int64_t ldx, const void* w, void* y, int64_t ldy, int M, int D, float eps) {
+    if (!ctx) return CRAB_E_INVALID;
+    if (!x || !w || !y || M <= 0) return crab_fail(ctx, CRAB_E_INVALID, "rmsnorm_f32: bad argument");
+    if ((D & 7) || D > 8192 || (ldx & 3) || (ldy & 7) || ((uintptr_t)x & 15)) return crab_fail(ctx, CRAB_E_INVALID, "rmsnorm_f32: D must be a multiple of 8 and <= 8192, 16-byte aligned rows");
+    if (D <= 2048)
+        hipLaunchKernelGGL((norm_f32in_kernel<true, 4>), dim3(cdiv(M, 4)), dim3(256), 0, S_(stream), x, (long)ldx, (const bf16_t*)w,
+                           (const bf16_t*)nullptr, (bf16_t*)y, (long)ldy, M, D, eps);
+    else
+        hipLaunchKernelGGL((norm_f32in_kernel<true>), dim3(cdiv(M, 4)), dim3(256), 0, S_(stream), x, (long)ldx, (const bf16_t*)w,
+                           (const bf16_t*)nullptr, (bf16_t*)y, (long)ldy, M, D, eps);
+    return crab_check_launch(ctx, "rmsnorm_f32");
+}
+
+int crab_layernorm_f32(crab_ctx* ctx, void* stream, const float* x, int64_t ldx, const void* w, const void* b, void* y, int64_t ldy, int M,
+                       int D, float eps) {
+    if (!ctx) return CRAB_E_INVALID;
+    if (!x || !w || !y || M <= 0) return crab_fail(ctx, CRAB_E_INVALID, "layernorm_f32: bad argument");
+    if ((D & 7) || D > 8192 || (ldx & 3) || (ldy & 7) || ((uintptr_t)x & 15)) return crab_fail(ctx, CRAB_E_INVALID, "layernorm_f32: D must be a multiple of 8 and <= 8192, 16-byte aligned rows");
+    if (D <= 2048)
+        hipLaunchKernelGGL((norm_f32in_kernel<false, 4>), dim3(cdiv(M, 4)), dim3(256), 0, S_(stream), x, (long)ldx, (const bf16_t*)w,
+                           (const bf16_t*)b, (bf16_t*)y, (long)ldy, M, D, eps);
+    else
+        hipLaunchKernelGGL((norm_f32in_kernel<false>), dim3(cdiv(M, 4)), dim3(256), 0, S_(stream), x, (long)ldx, (const bf16_t*)w,
+                           (const bf16_t*)b, (bf16_t*)y, (long)ldy, M, D, eps);
+    return crab_check_launch(ctx, "layernorm_f32");
+}
+
+int crab_embedding_f32(crab_ctx* ctx, void* stream, const int64_t* ids, const void* table, float* out, int64_t ldo, int T, int D, int vocab) {
+    if (!ctx) return CRAB_E_INVALID;
+    if (!ids || !table || !out || T <= 0 || (D & 7) || (ldo & 3) || ((uintptr_t)out & 15)) return crab_fail(ctx, CRAB_E_INVALID, "embedding_f32: bad argument");
+    hipLaunchKernelGGL(embedding_f32_kernel, dim3(T), dim3(128), 0, S_(stream), ids, (const bf16_t*)table, out, (long)ldo, T, D, vocab);
+    return crab_check_launch(ctx, "embedding_f32");
+}
+
+int crab_cast_rows_bf16_f32(crab_ctx* ctx, void* stream, const void* src, int64_t lds_, float* dst, int64_t ldd, int rows, int cols) {
+    if (!ctx) return CRAB_E_INVALID;
+    if (!src || !dst || rows <= 0 || cols <= 0 || (cols & 7) || (lds_ & 7) || (ldd & 3) || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15))
+        return crab_fail(ctx, CRAB_E_INVALID, "cast_rows_bf16_f32: cols / lds multiples of 8, ldd multiple of 4, 16-byte aligned");
+    hipLaunchKernelGGL(cast_rows_bf16_f32_kernel, dim3(cdiv((long)rows * (cols >> 3), 256)), dim3(256), 0, S_(stream), (const bf16_t*)src, (long)lds_,
+                       dst, (long)ldd, rows, cols);
+    return crab_check_launch(ctx, "cast_rows_bf16_f32");
+}
+
+int crab_cast_rows_f32_bf16(crab_ctx* ctx, void* stream, const float* src, int64_t lds_, void* dst, int64_t ldd, int rows, int cols) {
+    if (!ctx) return CRAB_E_INVALID;
+    if (!src || !dst || rows <= 0 || cols <= 0 || (cols & 7) || (lds_ & 3) || (ldd & 7) || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15))
+        return crab_fail(ctx, CRAB_E_INVALID, "cast_rows_f32_bf16: cols / ldd multiples of 8, lds multiple of 4, 16-byte aligned");
+    hipLaunchKernelGGL(cast_rows_f32_bf16_kernel, dim3(cdiv((long)rows * (cols >> 3), 256)), dim3(256), 0, S_(stream), src, (long)lds_,
+                       (bf16_t*)dst, (long)ldd, rows, cols);
+    return crab_check_launch(ctx, "cast_rows_f32_bf16");
 }
 
 int crab_embedding(crab_ctx* ctx, void* stream, const int64_t* ids, const void* table, void* out, int64_t ldo, int T, int D, int vocab) {

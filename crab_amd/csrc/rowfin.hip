@@ -29,12 +29,13 @@ constexpr int RF_G = 4;                          // slice groups of the last-arr
 struct RowfinApplyP {
     const float* S; const float* T;              // S [M][N] fp32; T [RF_SKX][16][16] partial router products: nl route logits then r lora_A
     const bf16_t* B2; long ldb2; int k2;         // lora_B [N][k2 >= nl * r]                                    (T == NULL: no adapter)
-    bf16_t* X; long ldx;                         // out: the row as stored (residual stream), bf16
+    bf16_t* X; long ldx;                         // out: the row as stored (residual stream): bf16, or fp32 in the XF instantiation (ldx in fp32 elements)
     float* ssq;                                  // out: [slices][16] partial sums of squares of the STORED values
     unsigned* counter;                           // arrival counter of the route kernel, zeroed here
     int M, N, nl, r; float scaling;
 };
 
+template <bool XF>
 __global__ __launch_bounds__(256) void rowfin_apply_kernel(RowfinApplyP p) {
     __shared__ uint32_t b2s[RF_CW][17];          // lora_B rows of this slice, 32 k columns as 16 words + 1 pad word (conflict-free row walk)
     __shared__ float us[16][32];
@@ -89,10 +90,15 @@ __global__ __launch_bounds__(256) void rowfin_apply_kernel(RowfinApplyP p) {
                 y[j] += a;
             }
         }
-        const uint32_t w0 = pack_bf2(y[0], y[1]), w1 = pack_bf2(y[2], y[3]);
-        *reinterpret_cast<u32x2*>(p.X + (long)m * p.ldx + c) = u32x2{w0, w1};
-        const float x0 = lo_bf(w0), x1 = hi_bf(w0), x2 = lo_bf(w1), x3 = hi_bf(w1);      // the norm sees the stored bf16 values
-        ss = (x0 * x0 + x1 * x1) + (x2 * x2 + x3 * x3);
+        if (XF) {                                 // fp32 residual stream: stored and normalised unrounded
+            *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(p.X) + (long)m * p.ldx + c) = y;
+            ss = (y[0] * y[0] + y[1] * y[1]) + (y[2] * y[2] + y[3] * y[3]);
+        } else {
+            const uint32_t w0 = pack_bf2(y[0], y[1]), w1 = pack_bf2(y[2], y[3]);
+            *reinterpret_cast<u32x2*>(p.X + (long)m * p.ldx + c) = u32x2{w0, w1};
+            const float x0 = lo_bf(w0), x1 = hi_bf(w0), x2 = lo_bf(w1), x3 = hi_bf(w1);      // the norm sees the stored bf16 values
+            ss = (x0 * x0 + x1 * x1) + (x2 * x2 + x3 * x3);
+        }
     }
     ss = row16_sum(ss);
     if (q == 0) p.ssq[blockIdx.x * 16 + m] = m < p.M ? ss : 0.f;
@@ -106,6 +112,7 @@ struct RowfinRouteP {
     int M, N;
 };
 
+template <bool XF>
 __global__ __launch_bounds__(256) void rowfin_route_kernel(RowfinRouteP p) {
     __shared__ __attribute__((aligned(16))) bf16_t ras[RF_TJ][RF_CW];       // 8 KB: the slice of [R;A]
     __shared__ __attribute__((aligned(16))) float Tg[RF_G][16][RF_TJ];     // 16 KB: slice-group sums of the last arriver
@@ -119,8 +126,8 @@ __global__ __launch_bounds__(256) void rowfin_route_kernel(RowfinRouteP p) {
     // The loads are UNCONDITIONAL (clamped addresses, values masked afterwards): with `cond ? load : 0` the compiler sank the first use into
     // the first conditional block and waited there (vmcnt(0) behind the first 4-byte load: a second, serialised memory round trip; ISA, r03)
     u32x4 rv[2];
-    const bf16_t* ra = p.RA ? p.RA : p.X;                     // no adapter: any readable row (the values are masked), so that no branch
-    const long ldra = p.RA ? p.ldra : p.ldx;                  // separates these loads from the ones below
+    const bf16_t* ra = p.RA ? p.RA : p.nw;                    // no adapter: any readable row (the values are masked), so that no branch
+    const long ldra = p.RA ? p.ldra : 0;                      // separates these loads from the ones below
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int idx = tid + i * 256, j = idx >> 3, ch = idx & 7;
@@ -131,7 +138,10 @@ __global__ __launch_bounds__(256) void rowfin_route_kernel(RowfinRouteP p) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) sp[i] = p.ssq[min(q + i * 16, p.nb - 1) * 16 + m];       // nb <= 128 (host)
     const bool live = m < p.M && c < p.N;
-    u32x2 xw = *reinterpret_cast<const u32x2*>(p.X + (long)min(m, p.M - 1) * p.ldx + min(c, p.N - 4));
+    u32x2 xw = {0u, 0u};
+    f32x4_t xf = {0.f, 0.f, 0.f, 0.f};
+    if (XF) xf = *reinterpret_cast<const f32x4_t*>(reinterpret_cast<const float*>(p.X) + (long)min(m, p.M - 1) * p.ldx + min(c, p.N - 4));
+    else xw = *reinterpret_cast<const u32x2*>(p.X + (long)min(m, p.M - 1) * p.ldx + min(c, p.N - 4));
     u32x2 ww = *reinterpret_cast<const u32x2*>(p.nw + min(c, p.N - 4));
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -153,8 +163,14 @@ __global__ __launch_bounds__(256) void rowfin_route_kernel(RowfinRouteP p) {
     const float rstd = rsqrtf(ss / (float)p.N + p.eps);
     float hf[4] = {0.f, 0.f, 0.f, 0.f};
     if (live) {
-        const float h0 = bf2f(f2bf(lo_bf(xw[0]) * rstd)) * lo_bf(ww[0]), h1 = bf2f(f2bf(hi_bf(xw[0]) * rstd)) * hi_bf(ww[0]);
-        const float h2 = bf2f(f2bf(lo_bf(xw[1]) * rstd)) * lo_bf(ww[1]), h3 = bf2f(f2bf(hi_bf(xw[1]) * rstd)) * hi_bf(ww[1]);
+        float h0, h1, h2, h3;
+        if (XF) {
+            h0 = xf[0] * rstd * lo_bf(ww[0]); h1 = xf[1] * rstd * hi_bf(ww[0]);
+            h2 = xf[2] * rstd * lo_bf(ww[1]); h3 = xf[3] * rstd * hi_bf(ww[1]);
+        } else {
+            h0 = bf2f(f2bf(lo_bf(xw[0]) * rstd)) * lo_bf(ww[0]); h1 = bf2f(f2bf(hi_bf(xw[0]) * rstd)) * hi_bf(ww[0]);
+            h2 = bf2f(f2bf(lo_bf(xw[1]) * rstd)) * lo_bf(ww[1]); h3 = bf2f(f2bf(hi_bf(xw[1]) * rstd)) * hi_bf(ww[1]);
+        }
         const uint32_t o0 = pack_bf2(h0, h1), o1 = pack_bf2(h2, h3);
         *reinterpret_cast<u32x2*>(p.H + (long)m * p.ldh + c) = u32x2{o0, o1};
         hf[0] = lo_bf(o0); hf[1] = hi_bf(o0); hf[2] = lo_bf(o1); hf[3] = hi_bf(o1);       // the router sees the stored bf16 row
@@ -249,7 +265,8 @@ extern "C" int64_t crab_rowfin_workspace(int M, int N) {
 float* crab_rowfin_T(const crab_gemm_desc* d) { return (float*)((char*)d->workspace + rf_align((int64_t)d->M * d->N * 4)); }
 
 bool crab_rowfin_ok(const crab_gemm_desc* d) {
-    if (!d->norm_w || !d->norm_out || d->c_fp32 || d->M > 16 || !d->workspace) return false;
+    if (!d->norm_w || !d->norm_out || d->M > 16 || !d->workspace) return false;
+    if (d->c_fp32 && (((uintptr_t)d->C & 15) || (d->R && !d->r_fp32))) return false;      // the fp32 residual stream: R and C both fp32
     if ((d->N & 7) || (d->ldc & 3) || (d->ld_norm & 3) || (((uintptr_t)d->C | (uintptr_t)d->norm_out | (uintptr_t)d->norm_w) & 7)) return false;
     if (crab_rowfin_workspace(d->M, d->N) > d->workspace_bytes || d->N > 128 * RF_CW) return false;
     if (d->route_RA && ((d->route_ldra & 7) || ((uintptr_t)d->route_RA & 15) || d->route_nl > 8 || d->route_nproj * (d->route_nl + d->route_r) > RF_TJ))
@@ -278,7 +295,8 @@ int crab_rowfin_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* d) {
     a.B2 = (const bf16_t*)d->B2; a.ldb2 = d->ldb2; a.k2 = d->K2;
     a.X = (bf16_t*)d->C; a.ldx = d->ldc; a.ssq = ssq; a.counter = counter;
     a.M = d->M; a.N = d->N; a.nl = d->lora_nl; a.r = d->lora_r; a.scaling = d->lora_scaling;
-    hipLaunchKernelGGL(rowfin_apply_kernel, dim3(nb), dim3(256), 0, s, a);
+    if (d->c_fp32) hipLaunchKernelGGL(rowfin_apply_kernel<true>, dim3(nb), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(rowfin_apply_kernel<false>, dim3(nb), dim3(256), 0, s, a);
     int rc = crab_check_launch(ctx, "rowfin_apply_kernel");
     if (rc) return rc;
     RowfinRouteP r;
@@ -287,6 +305,7 @@ int crab_rowfin_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* d) {
     r.RA = (const bf16_t*)d->route_RA; r.ldra = d->route_ldra; r.U = (bf16_t*)d->route_U; r.ldu = d->route_ldu;
     r.nproj = d->route_nproj; r.nl = d->route_nl; r.r = d->route_r; r.ucols = d->route_ucols; r.scaling = d->route_scaling;
     r.tpart = tpart; r.counter = counter; r.M = d->M; r.N = d->N;
-    hipLaunchKernelGGL(rowfin_route_kernel, dim3(nb), dim3(256), 0, s, r);
+    if (d->c_fp32) hipLaunchKernelGGL(rowfin_route_kernel<true>, dim3(nb), dim3(256), 0, s, r);
+    else hipLaunchKernelGGL(rowfin_route_kernel<false>, dim3(nb), dim3(256), 0, s, r);
     return crab_check_launch(ctx, "rowfin_route_kernel");
 }

@@ -140,7 +140,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(SkinnyP p) {
             for (int r = 0; r < 4; ++r) t[r] = v[r] + (p.bias ? bf2f(p.bias[n + r]) : 0.f);
             const float o0 = t[0] / (1.0f + __expf(-t[0])) * t[1], o1 = t[2] / (1.0f + __expf(-t[2])) * t[3];
             const long oc = (long)m * p.ldc + (n >> 1);
-            if (p.c_fp32) { reinterpret_cast<float*>(p.C)[oc] = o0; reinterpret_cast<float*>(p.C)[oc + 1] = o1; }
+            if (p.c_fp32 & CF_C32) { reinterpret_cast<float*>(p.C)[oc] = o0; reinterpret_cast<float*>(p.C)[oc + 1] = o1; }
             else { reinterpret_cast<bf16_t*>(p.C)[oc] = f2bf(o0); reinterpret_cast<bf16_t*>(p.C)[oc + 1] = f2bf(o1); }
             continue;
         }
@@ -150,8 +150,8 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(SkinnyP p) {
             float x = v[r];
             if (p.bias) x += bf2f(p.bias[n + r]);
             x = apply_act(x, p.act);
-            if (p.R) x += p.res_scale * bf2f(p.R[(long)m * p.ldr + n + r]);
-            if (p.c_fp32) reinterpret_cast<float*>(p.C)[(long)m * p.ldc + n + r] = x;
+            if (p.R) x += p.res_scale * ld_res(p.R, (long)m * p.ldr + n + r, p.c_fp32);
+            if (p.c_fp32 & CF_C32) reinterpret_cast<float*>(p.C)[(long)m * p.ldc + n + r] = x;
             else reinterpret_cast<bf16_t*>(p.C)[(long)m * p.ldc + n + r] = f2bf(x);
         }
     }
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_dma_kernel(SkinnyP 
                 float x = v[r];
                 if (p.bias) x += bf2f(p.bias[n + r]);
                 x = apply_act(x, p.act);
-                if (p.R) x += p.res_scale * bf2f(p.R[(long)m * p.ldr + n + r]);
+                if (p.R) x += p.res_scale * ld_res(p.R, (long)m * p.ldr + n + r, p.c_fp32);
                 o[r] = x;
             }
             return;
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_dma_kernel(SkinnyP 
             for (int r = 0; r < 4; ++r) t[r] = v[r] + (p.bias ? bf2f(p.bias[n + r]) : 0.f);
             const float o0 = t[0] / (1.0f + __expf(-t[0])) * t[1], o1 = t[2] / (1.0f + __expf(-t[2])) * t[3];
             const long oc = (long)m * p.ldc + (n >> 1);
-            if (p.c_fp32) { reinterpret_cast<float*>(p.C)[oc] = o0; reinterpret_cast<float*>(p.C)[oc + 1] = o1; }
+            if (p.c_fp32 & CF_C32) { reinterpret_cast<float*>(p.C)[oc] = o0; reinterpret_cast<float*>(p.C)[oc + 1] = o1; }
             else { reinterpret_cast<bf16_t*>(p.C)[oc] = f2bf(o0); reinterpret_cast<bf16_t*>(p.C)[oc + 1] = f2bf(o1); }
             return;
         }
@@ -359,8 +359,8 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_dma_kernel(SkinnyP 
             float x = v[r];
             if (p.bias) x += bf2f(p.bias[n + r]);
             x = apply_act(x, p.act);
-            if (p.R) x += p.res_scale * bf2f(p.R[(long)m * p.ldr + n + r]);
-            if (p.c_fp32) reinterpret_cast<float*>(p.C)[(long)m * p.ldc + n + r] = x;
+            if (p.R) x += p.res_scale * ld_res(p.R, (long)m * p.ldr + n + r, p.c_fp32);
+            if (p.c_fp32 & CF_C32) reinterpret_cast<float*>(p.C)[(long)m * p.ldc + n + r] = x;
             else reinterpret_cast<bf16_t*>(p.C)[(long)m * p.ldc + n + r] = f2bf(x);
         }
     }
@@ -605,7 +605,7 @@ int crab_gemm_skinny_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* 
     p.A = (const bf16_t*)d->A; p.B = (const bf16_t*)d->B; p.C = d->C; p.bias = (const bf16_t*)d->bias; p.R = (const bf16_t*)d->R;
     p.A2 = (const bf16_t*)d->A2; p.B2 = (const bf16_t*)d->B2;
     p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc; p.ldr = d->ldr; p.lda2 = d->lda2; p.ldb2 = d->ldb2;
-    p.M = d->M; p.N = d->N; p.K = d->K; p.K2 = d->A2 ? d->K2 : 0; p.act = d->act; p.c_fp32 = d->c_fp32; p.res_scale = d->res_scale;
+    p.M = d->M; p.N = d->N; p.K = d->K; p.K2 = d->A2 ? d->K2 : 0; p.act = d->act; p.c_fp32 = crab_cflags(d); p.res_scale = d->res_scale;
     p.Bx = nullptr; p.ldbx = 0; p.Tx = nullptr;
     p.rope_tab = nullptr; p.rope_kc = p.rope_vc = nullptr; p.rope_pos_dev = nullptr; p.rope_H = p.rope_Hk = p.rope_d = p.rope_Tmax = p.rope_pos0 = 0;
     if (crab_skinny_fuses_rope(d)) {

@@ -131,7 +131,7 @@ class _Workspace:
         H, Hk, d = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
         e = lambda *s, dt=BF16: torch.empty(s, device=device, dtype=dt)
         self.M = M
-        self.x = e(M, D)
+        self.x = e(M, D, dt=ops.RES_DTYPE)       # the residual stream: fp32 (ops.RESIDUAL_FP32), read / written by the o_proj / down_proj epilogues
         self.h = e(M, D)
         self.qkv = e(M, (H + 2 * Hk) * d)
         self.att = e(M, H * d)
@@ -246,7 +246,8 @@ class GenerationEngine:
         kv = 2 * c.num_hidden_layers * c.num_key_value_heads * Tmax * c.head_dim * 2
         D, I = c.hidden_size, c.intermediate_size
         H, Hk, d = c.num_attention_heads, c.num_key_value_heads, c.head_dim
-        dec_row = (2 * D + (H + 2 * Hk) * d + H * d + I + 3 * 128) * 2 + self.lm_head.weight.shape[0] * 4 + D * 2 + max_new_tokens * 8 + 64
+        xb = 2 if ops.RESIDUAL_FP32 else 0                    # the fp32 residual row costs 2 more bytes per element
+        dec_row = (2 * D + (H + 2 * Hk) * d + H * d + I + 3 * 128) * 2 + D * xb + self.lm_head.weight.shape[0] * 4 + D * 2 + max_new_tokens * 8 + 64
         return kv + dec_row
 
     def fixed_bytes(self, B: int, S: int) -> int:
@@ -255,7 +256,7 @@ class GenerationEngine:
         D, I = c.hidden_size, c.intermediate_size
         H, Hk, d = c.num_attention_heads, c.num_key_value_heads, c.head_dim
         rows = min(B, max(1, 32768 // max(S, 1))) * S
-        per_row = (2 * D + (H + 2 * Hk) * d + H * d + I + 3 * 128) * 2 + Hk * d * 2
+        per_row = (2 * D + (H + 2 * Hk) * d + H * d + I + 3 * 128) * 2 + Hk * d * 2 + (D * 2 if ops.RESIDUAL_FP32 else 0)
         have = self._ws.get("prefill")
         have_bytes = have.M * per_row if have is not None else 0
         return max(rows * per_row - have_bytes, 0) + (256 << 20)                   # + split-K / router workspaces, allocator slack
@@ -360,6 +361,7 @@ class GenerationEngine:
         if ws.attn_ws is not None and vt is None:
             io.attn_ws, io.attn_ws_bytes = ws.attn_ws.data_ptr(), ws.attn_ws.numel()
         io.B, io.S, io.Tmax, io.pos0, io.u_qkv_ready = B, S, Tmax, pos0, 0
+        io.x_fp32 = 1 if ws.x.dtype == torch.float32 else 0
         ops.llama_layers(self._layer_table(), len(self.model.layers), io, self.device)
 
     # ------------------------------------------------------------------ one pass over the layers
@@ -451,7 +453,7 @@ class GenerationEngine:
             raise ValueError("prompt longer than the KV cache")
         M = B * S
         ws = self._workspace(M)
-        ops.copy_rows(embeds.reshape(M, D), ws.x, M, D)
+        ops.cast_rows(embeds.reshape(M, D), ws.x, M, D)          # bf16 inputs_embeds -> the (fp32) residual stream
         Sp = (S + 7) // 8 * 8
         vt = torch.empty((B, c.num_key_value_heads, c.head_dim, Sp), device=self.device, dtype=BF16)
         x, hfin = self._layers(ws, B, S, kc, vc, b0, Tmax, 0, None, vt, pos_ids=pos_ids, kv_start=kv_start)   # hfin = model.norm(x), all rows

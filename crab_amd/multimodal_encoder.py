@@ -56,8 +56,9 @@ class _EncScratch:
     """Caller-owned rows of crab_enc_io for M tokens of `width`, an FFN of `ffn`, qkv rows of `qkv_rows` x `qkv_cols`, V^T of `vt_elems`."""
 
     def __init__(self, M, width, ffn, qkv_rows, qkv_cols, vt_elems, device):
-        e = lambda *s_: torch.empty(s_, device=device, dtype=BF16)
-        self.a, self.y, self.att, self.f = e(M, width), e(M, width), e(M, width), e(M, ffn)
+        e = lambda *s_, dt=BF16: torch.empty(s_, device=device, dtype=dt)
+        # y: CLIP's mid-layer residual row x + attn / the pre-LN sums of the post-LN encoders - fp32 with ops.RESIDUAL_FP32 (crab_enc_io.x_fp32)
+        self.a, self.y, self.att, self.f = e(M, width), e(M, width, dt=ops.RES_DTYPE), e(M, width), e(M, ffn)
         self.qkv = e(qkv_rows, qkv_cols)
         self.vt = torch.zeros((vt_elems,), device=device, dtype=BF16)
 
@@ -68,6 +69,7 @@ class _EncScratch:
         ws = ops._splitk_workspace(x.device)
         io.workspace, io.workspace_bytes = ws.data_ptr(), ws.numel()
         io.B, io.S = B, S
+        io.x_fp32 = 1 if self.y.dtype == torch.float32 else 0
         return io
 
 
@@ -87,8 +89,8 @@ class LinearP(nn.Module):
         else:
             self.register_parameter("bias", None)
 
-    def forward(self, x, act="none", residual=None, res_scale=1.0, out=None):
-        return ops.gemm(x, self.weight, bias=self.bias, act=act, residual=residual, res_scale=res_scale, out=out)
+    def forward(self, x, act="none", residual=None, res_scale=1.0, out=None, out_fp32=False):
+        return ops.gemm(x, self.weight, bias=self.bias, act=act, residual=residual, res_scale=res_scale, out=out, out_fp32=out_fp32)
 
 
 class LayerNormP(nn.Module):
@@ -215,10 +217,25 @@ class CLIPVisionModel(nn.Module):
         keep = set(range(upto + 1)) if keep is None else set(keep)
         hs = {0: h.view(N, T, D)} if 0 in keep else {}
         M = N * T
+        f32 = ops.RESIDUAL_FP32
+        if f32 and upto > 0:
+            # the residual stream of the pre-LN tower is fp32 from here on; the kept hidden states go back to bf16 (what the projectors read)
+            h16, h = h, torch.empty((M, D), device=h.device, dtype=torch.float32)
+            ops.cast_rows(h16, h, M, D)
+            if 0 in hs:
+                hs[0] = h16.view(N, T, D)
+
+        def keep_state(x):
+            if not f32:
+                return x
+            o = torch.empty((M, D), device=x.device, dtype=BF16)
+            ops.cast_rows(x, o, M, D)
+            return o
+
         if _native_layers():
             # one C call per layer (crab_clip_layer, csrc/encoder_layers.hip): the launches below, in the same order, x updated in place
             sc = _EncScratch(M, D, c["intermediate_size"], M, 3 * D, N * D * ((T + 7) // 8 * 8), h.device)
-            if 0 in hs and upto > 0:
+            if 0 in hs and upto > 0 and not f32:
                 hs[0] = h.clone().view(N, T, D)                # h is updated in place from here on
             io = sc.io(h, N, T)
             for i in range(upto):
@@ -228,7 +245,7 @@ class CLIPVisionModel(nn.Module):
                 w.fc1, w.fc2, w.H = _dense(L.mlp.fc1), _dense(L.mlp.fc2), Hh
                 ops.enc_layer("clip", w, io, h.device)
                 if i + 1 in keep:
-                    hs[i + 1] = h.clone().view(N, T, D) if i + 1 < upto else h.view(N, T, D)
+                    hs[i + 1] = keep_state(h).view(N, T, D) if f32 else (h.clone().view(N, T, D) if i + 1 < upto else h.view(N, T, D))
             return hs
         a = torch.empty((M, D), device=h.device, dtype=BF16)
         qkv = torch.empty((M, 3 * D), device=h.device, dtype=BF16)
@@ -240,12 +257,12 @@ class CLIPVisionModel(nn.Module):
             L.self_attn._qkv(a, out=qkv)
             _attention(qkv, qkv, None, att, B=N, H=Hh, Sq=T, Skv=T, d=d, ldq=3 * D, ldk=3 * D, k_off=D, scale=d ** -0.5,
                        split_src=qkv, split_H=Hh)
-            hn = L.self_attn.out_proj(att, residual=h)
+            hn = L.self_attn.out_proj(att, residual=h, out_fp32=f32)
             L.layer_norm2(hn, out=a)
             L.mlp.fc1(a, act="quick_gelu", out=f1)
-            h = L.mlp.fc2(f1, residual=hn)
+            h = L.mlp.fc2(f1, residual=hn, out_fp32=f32)
             if i + 1 in keep:
-                hs[i + 1] = h.view(N, T, D)
+                hs[i + 1] = keep_state(h).view(N, T, D)
         return hs
 
 
@@ -415,14 +432,15 @@ class BertModel(nn.Module):
             q = sa.query(z)
             kv = sa._kv(z)                                                           # [B*nq, 2h]
             _attention(q, kv, None, att, B=B, H=H, Sq=nq, Skv=nq, d=d, ldq=h, ldk=2 * h, scale=scale, split_src=kv, split_H=0)
-            z = L.attention.output.LayerNorm(L.attention.output.dense(att, residual=z))          # :287-291
+            f32 = ops.RESIDUAL_FP32                                                  # fp32 pre-LN sums (crab_enc_io.x_fp32)
+            z = L.attention.output.LayerNorm(L.attention.output.dense(att, residual=z, out_fp32=f32))          # :287-291
             ca = getattr(L.crossattention, "self")
             q = ca.query(z)
             kv = ca._kv(enc)                                                         # [B*m, 2h]
             _attention(q, kv, None, att, B=B, H=H, Sq=nq, Skv=m, d=d, ldq=h, ldk=2 * h, scale=scale, split_src=kv, split_H=0)
-            z = L.crossattention.output.LayerNorm(L.crossattention.output.dense(att, residual=z))
+            z = L.crossattention.output.LayerNorm(L.crossattention.output.dense(att, residual=z, out_fp32=f32))
             f = L.intermediate_query.dense(z, act="gelu")                            # :483-486
-            z = L.output_query.LayerNorm(L.output_query.dense(f, residual=z))
+            z = L.output_query.LayerNorm(L.output_query.dense(f, residual=z, out_fp32=f32))
         return z
 
 
@@ -614,13 +632,13 @@ class BEATs(nn.Module):
         cg = E // G
         xp = ops.beats_posconv_pad(x, B, n, E, G, Kc)                                   # [G][B][n+Kc-1][cg]
         w = self._posconv_weight()
-        y = torch.empty((B * n, E), device=dev, dtype=BF16)
+        y = torch.empty((B * n, E), device=dev, dtype=ops.RES_DTYPE)                    # the pre-LN sum x + gelu(pos_conv(x)): fp32 (ops.RESIDUAL_FP32)
         g = GemmDesc()
         npad = n + Kc - 1
         g.A, g.B, g.C, g.bias, g.R = xp.data_ptr(), w.data_ptr(), y.data_ptr(), enc.pos_conv[0].bias.data_ptr(), x.data_ptr()
         g.lda, g.ldb, g.ldc, g.ldr = cg, Kc * cg, E, E
         g.M, g.N, g.K = n, cg, Kc * cg
-        g.act, g.c_fp32, g.res_scale = 1, 0, 1.0                                        # x + gelu(conv + bias)
+        g.act, g.c_fp32, g.res_scale = 1, 1 if y.dtype == torch.float32 else 0, 1.0     # x + gelu(conv + bias)
         g.batch, g.nb0 = G * B, B
         g.sA0, g.sA1 = npad * cg, B * npad * cg
         g.sB0, g.sB1 = 0, cg * Kc * cg
@@ -656,9 +674,10 @@ class BEATs(nn.Module):
                 if c.gru_rel_pos else None
             _attention(qkv, qkv, None, att, B=B, H=H, Sq=n, Skv=n, d=d, ldq=3 * E, ldk=3 * E, k_off=E, scale=d ** -0.5,
                        bias=bias, gate=gate, split_src=qkv, split_H=H)
-            x = L_.self_attn_layer_norm(a.out_proj(att, residual=x, res_scale=alpha))
+            f32 = ops.RESIDUAL_FP32                                                     # fp32 pre-LN sums (crab_enc_io.x_fp32)
+            x = L_.self_attn_layer_norm(a.out_proj(att, residual=x, res_scale=alpha, out_fp32=f32))
             f = L_.fc1(x, act="gelu")
-            x = L_.final_layer_norm(L_.fc2(f, residual=x, res_scale=alpha))
+            x = L_.final_layer_norm(L_.fc2(f, residual=x, res_scale=alpha, out_fp32=f32))
         return x.view(B, n, E), padding_mask
 
 

@@ -105,6 +105,12 @@ def _variant(M: int, N: int, batch: int = 1, K: int = 4096) -> str:
     return "gemm_bt_ring_kernel<256,256>" if ring else "gemm_bt_glds_kernel<128,128>"
 
 
+# The residual stream (decoder x, CLIP tower x, the pre-LN sums of the post-LN encoders) is kept in fp32: the reference adds its residuals in
+# fp32 (models/modeling_llama.py:805-827 run with --bf16 False, scripts/quick_start.sh:42-44) and a bf16 rounding of x per sub-layer is what put
+# the 32-layer logits 1.7e-2 away from it.  CRAB_RESIDUAL_FP32=0 restores the all-bf16 storage of r01-r03 (A/B runs only).
+RESIDUAL_FP32 = os.environ.get("CRAB_RESIDUAL_FP32", "1") != "0"
+RES_DTYPE = torch.float32 if RESIDUAL_FP32 else torch.bfloat16
+
 ROWFIN = os.environ.get("CRAB_ROWFIN", "1") != "0"     # the M <= 16 layer tail of csrc/rowfin.hip (same switch as the library reads)
 
 _SPLITK_WS = {}
@@ -136,7 +142,9 @@ def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     lora_self = (RA, nl, r, scaling, lora_B) (with post_norm, M <= 16, no x2): the hyper-LoRA update of THIS single-projection group is
     evaluated inside the call - its router rows ride on the projection's launch, the update is applied by the M <= 16 layer tail.
     act == "swiglu_pair": w rows are interleaved (gate_i, up_i) and out is [M, N/2] = silu(gate) * up."""
-    _chk_bf16(x, w, bias, residual, x2, w2)
+    _chk_bf16(x, w, bias, x2, w2)
+    if residual is not None and residual.dtype not in (BF16, torch.float32):
+        raise _lib.CrabHipError(f"residual must be bfloat16 or float32, got {residual.dtype}")
     d = _dev(x)
     M, K = x.shape
     N = w.shape[0]
@@ -149,6 +157,7 @@ def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     g.R = residual.data_ptr() if residual is not None else None
     g.lda, g.ldb, g.ldc = x.stride(0), w.stride(0), out.stride(0)
     g.ldr = residual.stride(0) if residual is not None else 0
+    g.r_fp32 = 1 if (residual is not None and residual.dtype == torch.float32) else 0
     if x2 is not None:
         assert w2 is not None and x2.shape[1] == w2.shape[1] and x2.shape[0] == M and w2.shape[0] == N
         g.A2, g.B2, g.lda2, g.ldb2, g.K2 = x2.data_ptr(), w2.data_ptr(), x2.stride(0), w2.stride(0), x2.shape[1]
@@ -240,22 +249,31 @@ def hyperlora_route(x: torch.Tensor, ra: torch.Tensor, nproj: int, nl: int, r: i
 
 
 def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    _chk_bf16(x, w)
+    """x bf16, or fp32 (a row of the fp32 residual stream: no intermediate rounding of x_hat); out bf16."""
+    _chk_bf16(w)
     d = _dev(x)
     M, D = x.shape
     if out is None:
         out = torch.empty((M, D), device=x.device, dtype=BF16)
+    if x.dtype == torch.float32:
+        _lib.check(_lib.load().crab_rmsnorm_f32(_lib.ctx(d), _stream(), _p(x), x.stride(0), _p(w), _p(out), out.stride(0), M, D, eps), d)
+        return out
+    _chk_bf16(x)
     _lib.check(_lib.load().crab_rmsnorm(_lib.ctx(d), _stream(), _p(x), x.stride(0), _p(w), _p(out), out.stride(0), M, D, eps), d)
     return out
 
 
 def layernorm(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], eps: float,
               out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    _chk_bf16(x, w, b)
+    _chk_bf16(w, b)
     d = _dev(x)
     M, D = x.shape
     if out is None:
         out = torch.empty((M, D), device=x.device, dtype=BF16)
+    if x.dtype == torch.float32:             # fp32 rows (residual stream / pre-LN sums)
+        _lib.check(_lib.load().crab_layernorm_f32(_lib.ctx(d), _stream(), _p(x), x.stride(0), _p(w), _p(b), _p(out), out.stride(0), M, D, eps), d)
+        return out
+    _chk_bf16(x)
     _lib.check(_lib.load().crab_layernorm(_lib.ctx(d), _stream(), _p(x), x.stride(0), _p(w), _p(b), _p(out), out.stride(0), M, D, eps), d)
     return out
 
@@ -268,8 +286,24 @@ def embedding(ids: torch.Tensor, table: torch.Tensor, out: Optional[torch.Tensor
     if out is None:
         out = torch.empty((T, D), device=table.device, dtype=BF16)
     if T:
-        _lib.check(_lib.load().crab_embedding(_lib.ctx(d), _stream(), _p(ids), _p(table), _p(out), out.stride(0), T, D, table.shape[0]), d)
+        fn = _lib.load().crab_embedding_f32 if out.dtype == torch.float32 else _lib.load().crab_embedding      # fp32: the residual stream's first row
+        _lib.check(fn(_lib.ctx(d), _stream(), _p(ids), _p(table), _p(out), out.stride(0), T, D, table.shape[0]), d)
     return out
+
+
+def cast_rows(src: torch.Tensor, dst: torch.Tensor, rows: int, cols: int, lds: Optional[int] = None):
+    """dst[r, :cols] = src[r, :cols] across bf16 <-> fp32 (or a plain copy when the dtypes agree); row-strided 2-D views."""
+    d = _dev(src)
+    lds = src.stride(0) if lds is None else lds
+    if src.dtype == dst.dtype:
+        return copy_rows(src, dst, rows, cols, lds=lds)
+    if src.dtype == BF16 and dst.dtype == torch.float32:
+        _lib.check(_lib.load().crab_cast_rows_bf16_f32(_lib.ctx(d), _stream(), _p(src), lds, _p(dst), dst.stride(0), rows, cols), d)
+    elif src.dtype == torch.float32 and dst.dtype == BF16:
+        _lib.check(_lib.load().crab_cast_rows_f32_bf16(_lib.ctx(d), _stream(), _p(src), lds, _p(dst), dst.stride(0), rows, cols), d)
+    else:
+        raise _lib.CrabHipError(f"cast_rows: {src.dtype} -> {dst.dtype} is not supported")
+    return dst
 
 
 def rope_table(max_pos: int, head_dim: int, theta: float, device) -> torch.Tensor:

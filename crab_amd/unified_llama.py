@@ -174,7 +174,7 @@ class UnifiedForCausalLM(nn.Module, UnifiedMetaForCausalLM):
                 eng._rope_tab(self._rope_need)
             emb = self.model.embed_tokens(input_ids.reshape(-1))
             ws = eng._workspace(B)
-            ops.copy_rows(emb, ws.x, B, emb.shape[1])
+            ops.cast_rows(emb, ws.x, B, emb.shape[1])
             pos = torch.full((1,), n, device=dev, dtype=torch.int32)
             x, hfin = eng._layers(ws, B, 1, kc, vc, 0, kc.shape[3], 0, pos, None, pos_ids=pos_ids, kv_start=kv_start)
             hn = hfin.clone()

@@ -104,7 +104,8 @@ static void* run_projector(hipStream_t s, const projector* p, const void* feat, 
     crab_enc_io io;
     memset(&io, 0, sizeof(io));
     const int keys = nq > m ? nq : m;
-    io.x = z; io.a = dev_alloc((size_t)M * hq * 2); io.y = dev_alloc((size_t)M * hq * 2); io.att = dev_alloc((size_t)M * hq * 2);
+    /* x_fp32: the pre-LN sums (io.y) of the post-LN Q-Former are fp32, as crab_amd/multimodal_encoder.py keeps them */
+    io.x = z; io.a = dev_alloc((size_t)M * hq * 2); io.y = dev_alloc((size_t)M * hq * 4); io.att = dev_alloc((size_t)M * hq * 2); io.x_fp32 = 1;
     io.f = dev_alloc((size_t)M * iq * 2); io.qkv = dev_alloc((size_t)rows * 2 * hq * 2);
     io.vt_bytes = (int64_t)B * hq * pad_to(keys, 8) * 2; io.vt = dev_alloc((size_t)io.vt_bytes);
     io.enc = enc; io.enc_rows = m; io.workspace = gws; io.workspace_bytes = gws_bytes; io.B = B; io.S = nq;
@@ -167,11 +168,15 @@ int main(int argc, char** argv) {
     {
         crab_enc_io io;
         memset(&io, 0, sizeof(io));
-        io.x = hc; io.a = dev_alloc((size_t)Mv * Dc * 2); io.y = dev_alloc((size_t)Mv * Dc * 2); io.att = dev_alloc((size_t)Mv * Dc * 2);
+        /* the residual stream of the pre-LN tower is fp32 (crab_enc_io.x_fp32): x and the mid-layer row y; the kept state goes back to bf16 */
+        float* hx = (float*)dev_alloc((size_t)Mv * Dc * 4);
+        CRAB_OK_(crab_cast_rows_bf16_f32(ctx, s, hc, Dc, hx, Dc, Mv, Dc));
+        io.x = hx; io.a = dev_alloc((size_t)Mv * Dc * 2); io.y = dev_alloc((size_t)Mv * Dc * 4); io.att = dev_alloc((size_t)Mv * Dc * 2); io.x_fp32 = 1;
         io.qkv = dev_alloc((size_t)Mv * 3 * Dc * 2); io.f = dev_alloc((size_t)Mv * Ic * 2);
         io.vt_bytes = (int64_t)Tv * Dc * pad_to(T, 8) * 2; io.vt = dev_alloc((size_t)io.vt_bytes);
         io.workspace = gws; io.workspace_bytes = gws_bytes; io.B = Tv; io.S = T;
         for (int l = 0; l < Lc; ++l) CRAB_OK_(crab_clip_layer(ctx, s, &cl[l], &io));
+        if (Lc > 0) CRAB_OK_(crab_cast_rows_f32_bf16(ctx, s, hx, Dc, hc, Dc, Mv, Dc));
     }
     void* vfeat = dev_alloc((size_t)Tv * Pn * Dc * 2);                                               /* drop CLS (select_feature 'patch') */
     CRAB_OK_(crab_copy_rows_batched(ctx, s, (const uint16_t*)hc + Dc, Dc, (int64_t)T * Dc, vfeat, Dc, (int64_t)Pn * Dc, Tv, Pn, Dc));
@@ -212,11 +217,11 @@ int main(int argc, char** argv) {
     gemm(s, ax0, emb, &post, ax, E, Ma, CRAB_ACT_NONE);
     void* xp = dev_alloc((size_t)G * Ta * npad * cg * 2);                                            /* x + gelu(pos_conv(x)): sliding-window GEMM */
     CRAB_OK_(crab_beats_posconv_pad(ctx, s, ax, xp, Ta, n, E, G, Kc));
-    void* ay = dev_alloc((size_t)Ma * E * 2);
+    void* ay = dev_alloc((size_t)Ma * E * 4);                                                        /* the pre-LN sum, fp32 */
     {
         crab_gemm_desc g;
         memset(&g, 0, sizeof(g));
-        g.A = xp; g.B = pcw; g.C = ay; g.bias = pcb; g.R = ax;
+        g.A = xp; g.B = pcw; g.C = ay; g.bias = pcb; g.R = ax; g.c_fp32 = 1;
         g.lda = cg; g.ldb = (int64_t)Kc * cg; g.ldc = E; g.ldr = E;
         g.M = n; g.N = cg; g.K = Kc * cg; g.act = CRAB_ACT_GELU; g.res_scale = 1.0f;
         g.batch = G * Ta; g.nb0 = Ta;
@@ -225,13 +230,13 @@ int main(int argc, char** argv) {
         CRAB_OK_(crab_gemm_bf16(ctx, s, &g));
     }
     void* bx = dev_alloc((size_t)Ma * E * 2);
-    CRAB_OK_(crab_layernorm(ctx, s, ay, E, enc_ln.w, enc_ln.b, bx, E, Ma, E, enc_ln.eps));
+    CRAB_OK_(crab_layernorm_f32(ctx, s, (const float*)ay, E, enc_ln.w, enc_ln.b, bx, E, Ma, E, enc_ln.eps));
     float* relb = (float*)dev_alloc((size_t)Hb * n * n * 4);
     CRAB_OK_(crab_beats_relpos_bias(ctx, s, table, relb, n, Hb, c[C_BUCKETS], c[C_MAXDIST]));
     {
         crab_enc_io io;
         memset(&io, 0, sizeof(io));
-        io.x = bx; io.a = dev_alloc((size_t)Ma * E * 2); io.y = dev_alloc((size_t)Ma * E * 2); io.att = dev_alloc((size_t)Ma * E * 2);
+        io.x = bx; io.a = dev_alloc((size_t)Ma * E * 2); io.y = dev_alloc((size_t)Ma * E * 4); io.att = dev_alloc((size_t)Ma * E * 2); io.x_fp32 = 1;
         io.qkv = dev_alloc((size_t)Ma * 3 * E * 2); io.f = dev_alloc((size_t)Ma * F * 2);
         io.vt_bytes = (int64_t)Ta * E * pad_to(n, 8) * 2; io.vt = dev_alloc((size_t)io.vt_bytes);
         io.bias = relb; io.gate = (float*)dev_alloc((size_t)Ta * Hb * n * 4);

@@ -93,7 +93,7 @@ static int run_decoder(void* embeds, const char* outpath, int D, int I, int L, i
     const int Kmax = D > I ? D : I;
     crab_llama_io io;
     memset(&io, 0, sizeof(io));
-    io.x = dev_alloc((size_t)Mp * D * 2); io.ldx = D;
+    io.x = dev_alloc((size_t)Mp * D * 4); io.ldx = D; io.x_fp32 = 1;      /* the residual stream is fp32 (crab_llama_io.x_fp32), like crab_amd/decoder.py keeps it */
     io.h = dev_alloc((size_t)Mp * D * 2); io.ldh = D;
     io.qkv = dev_alloc((size_t)Mp * Nq * 2); io.ldqkv = Nq;
     io.att = dev_alloc((size_t)Mp * H * d * 2); io.ldatt = H * d;
@@ -127,8 +127,8 @@ static int run_decoder(void* embeds, const char* outpath, int D, int I, int L, i
     head.workspace = io.splitk_ws; head.workspace_bytes = io.splitk_ws_bytes;
 
     /* ---- prefill: x = embeds; h = rmsnorm(x) * layer 0 input_layernorm; all layers; logits of the last row of each sequence */
-    CRAB_OK_(crab_copy_rows(ctx, stream, embeds, D, io.x, D, Mp, D));
-    CRAB_OK_(crab_rmsnorm(ctx, stream, io.x, D, ln_in[0], io.h, D, Mp, D, eps));
+    CRAB_OK_(crab_cast_rows_bf16_f32(ctx, stream, embeds, D, (float*)io.x, D, Mp, D));
+    CRAB_OK_(crab_rmsnorm_f32(ctx, stream, (const float*)io.x, D, ln_in[0], io.h, D, Mp, D, eps));
     io.B = B; io.S = S; io.vt = vt; io.vt_ld = Sp; io.pos_dev = NULL; io.u_qkv_ready = 0;
     CRAB_OK_(crab_llama_layers(ctx, stream, layers, L, &io));
     CRAB_OK_(crab_copy_rows(ctx, stream, (const uint16_t*)io.h + (size_t)(S - 1) * D, (int64_t)S * D, hn, D, B, D));
@@ -159,8 +159,8 @@ static int run_decoder(void* embeds, const char* outpath, int D, int I, int L, i
         const int capture = use_graph && step == 2;
         if (!exec) {
             if (capture) HIP_OK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-            CRAB_OK_(crab_embedding(ctx, stream, cur_ids, embed_tokens, io.x, D, B, D, V));
-            CRAB_OK_(crab_rmsnorm(ctx, stream, io.x, D, ln_in[0], io.h, D, B, D, eps));
+            CRAB_OK_(crab_embedding_f32(ctx, stream, cur_ids, embed_tokens, (float*)io.x, D, B, D, V));
+            CRAB_OK_(crab_rmsnorm_f32(ctx, stream, (const float*)io.x, D, ln_in[0], io.h, D, B, D, eps));
             io.u_qkv_ready = 0;
             CRAB_OK_(crab_llama_layers(ctx, stream, layers, L, &io));
             CRAB_OK_(crab_gemm_bf16(ctx, stream, &head));

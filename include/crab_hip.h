@@ -47,7 +47,10 @@ enum { CRAB_ACT_NONE = 0, CRAB_ACT_GELU = 1, CRAB_ACT_QUICK_GELU = 2, CRAB_ACT_R
 /* ---------------------------------------------------------------------------------------------
  * GEMM:  C[M,N] = res_scale * R[M,N] + act( A[M,K] . B[N,K]^T + A2[M,K2] . B2[N,K2]^T + bias[N] )
  * A, B (and A2, B2) are K-contiguous bf16 ("x @ W^T" with W stored [out,in] exactly as
- * torch.nn.Linear.weight).  fp32 MFMA accumulation.  C is bf16, or fp32 when c_fp32 != 0.
+ * torch.nn.Linear.weight).  fp32 MFMA accumulation.  C is bf16, or fp32 when c_fp32 != 0; R is bf16, or fp32 when r_fp32 != 0
+ * (ldr then counts fp32 elements).  c_fp32 = r_fp32 = 1 with R == C is the FP32 RESIDUAL STREAM of the decoder / CLIP tower
+ * (x += proj(...) without a bf16 rounding of x per layer; the reference adds its residuals in fp32, models/modeling_llama.py:805-827
+ * run with --bf16 False, scripts/quick_start.sh:42-44).
  * The optional second K segment carries the hyper-LoRA update (A2 = routed rank-24 activations,
  * B2 = concatenated lora_B), see crab_hyperlora_mix.
  * Replaces: every nn.Linear / F.linear on the path -- peft_hyper/tuners/lora.py:341 (base linear),
@@ -104,6 +107,9 @@ typedef struct {
     /* optional with rope_S > 1: V^T scratch [B, Hk, 128, rope_vt_ld] (what crab_qkv_rope_split's `vt` is).  When given - and the call fuses at all -
      * the v column tiles append to rope_v_cache and write V^T in the epilogue as well: crab_gemm_fuses_prefill_rope(d) == 2, no split pass left. */
     void* rope_vt; int64_t rope_vt_ld;
+    /* R is fp32 [M, ldr] (see the top of this comment).  With norm_w the fused post-norm then reads the fp32 row (c_fp32 must be set too, and
+     * the normalised row is bf16(x_hat * w) without the intermediate bf16 rounding of x_hat that the all-bf16 form reproduces).  Unbatched only. */
+    int32_t r_fp32;
 } crab_gemm_desc;
 
 int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc* d);
@@ -135,10 +141,19 @@ int crab_rmsnorm(crab_ctx* ctx, void* stream, const void* x, int64_t ldx, const 
 int crab_layernorm(crab_ctx* ctx, void* stream, const void* x, int64_t ldx, const void* w, const void* b, void* y,
                    int64_t ldy, int M, int D, float eps);
 
+/* The same over an fp32 input row (the fp32 residual stream): y = bf16(x_hat * w [+ b]), no intermediate rounding. */
+int crab_rmsnorm_f32(crab_ctx* ctx, void* stream, const float* x, int64_t ldx, const void* w, void* y, int64_t ldy,
+                     int M, int D, float eps);
+int crab_layernorm_f32(crab_ctx* ctx, void* stream, const float* x, int64_t ldx, const void* w, const void* b, void* y,
+                       int64_t ldy, int M, int D, float eps);
+
 /* out[t,:] = table[ids[t],:]  (embed_tokens; unified_arch.py:213-214, unified_llama.py:125-127).  Rows with ids[t] < 0 are
  * left untouched (the multimodal splice fills them with projector features, unified_arch.py:283-300); ids >= vocab clamp. */
 int crab_embedding(crab_ctx* ctx, void* stream, const int64_t* ids, const void* table, void* out, int64_t ldo,
                    int T, int D, int vocab);
+/* fp32 output rows: where the fp32 residual stream of a decode step starts */
+int crab_embedding_f32(crab_ctx* ctx, void* stream, const int64_t* ids, const void* table, float* out, int64_t ldo,
+                       int T, int D, int vocab);
 
 /* rope table: tab[pos][i] = (cos, sin)(pos * theta^(-2i/d)), fp32 pairs, i < d/2  (modeling_llama.py:130-156) */
 int crab_rope_table(crab_ctx* ctx, void* stream, float* tab, int max_pos, int head_dim, float theta);
@@ -243,6 +258,9 @@ int crab_copy_rows(crab_ctx* ctx, void* stream, const void* src, int64_t lds, vo
 int crab_copy_rows_batched(crab_ctx* ctx, void* stream, const void* src, int64_t lds, int64_t src_bs, void* dst, int64_t ldd,
                            int64_t dst_bs, int batch, int rows, int cols);
 int crab_cast_f32_bf16(crab_ctx* ctx, void* stream, const float* src, void* dst, int64_t n);
+/* strided row casts between bf16 activations and the fp32 residual stream: dst[r, 0:cols] = (T)src[r, 0:cols]; cols % 8 == 0 */
+int crab_cast_rows_bf16_f32(crab_ctx* ctx, void* stream, const void* src, int64_t lds, float* dst, int64_t ldd, int rows, int cols);
+int crab_cast_rows_f32_bf16(crab_ctx* ctx, void* stream, const float* src, int64_t lds, void* dst, int64_t ldd, int rows, int cols);
 
 /* Device-resident greedy decoding step (HF GenerationMixin greedy search as driven by unified_llama.py:262-267,
  * SURVEY.md B.3): tok = argmax(logits[b]) on fp32 logits (first maximum wins); eos is suppressed while
@@ -317,6 +335,9 @@ typedef struct {
      * once.  When given and B * H < CRAB_ATTN_SPLIT_BELOW (few blocks per head cannot hide the KV stream's latency) the q|k|v projection leaves its raw
      * row and crab_attn_decode_rope does RoPE + KV append + split-context attention in one launch. */
     void* attn_ws; int64_t attn_ws_bytes;
+    /* x is the FP32 residual stream: fp32 [M, ldx] (ldx in fp32 elements), read and written by the o_proj / down_proj epilogues and read by
+     * the norms; h and everything else stay bf16.  0: x is bf16 (the r01-r03 storage). */
+    int32_t x_fp32;
 } crab_llama_io;
 
 int crab_sizeof_llama_layer(void);
@@ -352,6 +373,8 @@ typedef struct {
     const float* bias; float* gate;                 /* BEATs only */
     void* workspace; int64_t workspace_bytes;
     int32_t B, S;
+    /* crab_clip_layer only (pre-LN residual tower): x is fp32 [M, width]; 0: bf16 */
+    int32_t x_fp32;
 } crab_enc_io;
 int crab_clip_layer(crab_ctx* ctx, void* stream, const crab_clip_layer_w* w, crab_enc_io* io);
 int crab_beats_layer(crab_ctx* ctx, void* stream, const crab_beats_layer_w* w, crab_enc_io* io);

@@ -41,10 +41,25 @@ def _r(x: Tensor, emulate) -> Tensor:
     return x.to(emulate).to(torch.float32)
 
 
-# Measurement knob (scripts/exp/fp32_residual_emulation.py): with emulate=bfloat16, keep the decoder's RESIDUAL
-# STREAM in fp32 (every other storage point still rounds).  Quantifies how close a bf16-storage execution with an fp32
-# residual stream would get to the fp32 reference.
-EMULATE_FP32_RESIDUAL = False
+# With emulate=bfloat16: the RESIDUAL STREAM (decoder x, CLIP tower x) stays fp32 and RMSNorm's x_hat is not rounded before the
+# weight multiply, every other storage point still rounds - the storage points of the HIP path since r04 (crab_amd.ops.RESIDUAL_FP32).
+# False = the all-bf16 storage of r01-r03 (scripts/exp/fp32_residual_emulation.py compares the two).
+EMULATE_FP32_RESIDUAL = True
+
+
+class residual_storage:
+    """`with residual_storage(fp32=False):` emulate the all-bf16 storage of r01-r03 inside the block (tests of the bf16-residual form of the kernels)."""
+
+    def __init__(self, fp32: bool):
+        self.fp32 = bool(fp32)
+
+    def __enter__(self):
+        global EMULATE_FP32_RESIDUAL
+        self.prev, EMULATE_FP32_RESIDUAL = EMULATE_FP32_RESIDUAL, self.fp32
+
+    def __exit__(self, *a):
+        global EMULATE_FP32_RESIDUAL
+        EMULATE_FP32_RESIDUAL = self.prev
 
 
 def _rres(x: Tensor, emulate) -> Tensor:
@@ -127,6 +142,8 @@ def rmsnorm(x: Tensor, w: Tensor, eps: float, emulate=None) -> Tensor:
     """modeling_llama.py:112-117: fp32 variance, x_hat cast to input dtype, then * weight."""
     x32 = x.float()
     xh = x32 * torch.rsqrt(x32.pow(2).mean(-1, keepdim=True) + eps)
+    if EMULATE_FP32_RESIDUAL:                 # fp32 row in: bf16(w * x_hat), one rounding (crab_rmsnorm_f32)
+        return _r(w.float() * xh, emulate)
     return _r(w.float() * _r(xh, emulate), emulate)
 
 
@@ -354,12 +371,12 @@ def clip_vision(pixels: Tensor, W: WDict, cfg: ClipConfig, prefix: str = "model.
         k = linear(a, W, p + ".self_attn.k_proj", emulate)
         v = linear(a, W, p + ".self_attn.v_proj", emulate)
         o = _mha(q, k, v, H, d ** -0.5, None, emulate)
-        h = _r(h + linear(o, W, p + ".self_attn.out_proj", None), emulate)
+        h = _rres(h + linear(o, W, p + ".self_attn.out_proj", None), emulate)
         a = layernorm(h, W, p + ".layer_norm2", cfg.layer_norm_eps, emulate)
         f1 = linear(a, W, p + ".mlp.fc1", None)
         f1 = _r(f1 * torch.sigmoid(1.702 * f1), emulate)                 # quick_gelu
-        h = _r(h + linear(f1, W, p + ".mlp.fc2", None), emulate)
-        hs.append(h)
+        h = _rres(h + linear(f1, W, p + ".mlp.fc2", None), emulate)
+        hs.append(_r(h, emulate))                                        # the kept states are bf16 (what the projectors read)
     return hs
 
 

@@ -30,7 +30,7 @@ def test_every_declared_symbol_is_exported_and_bound():
         assert hasattr(lib, name), f"{name} declared in include/ but not exported"
     missing = declared - set(_lib.SYMBOLS)
     assert not missing, f"ctypes bindings missing for {missing}"
-    assert lib.crab_abi_version() >= 6
+    assert lib.crab_abi_version() >= 7
 
 
 def test_ops_fail_loudly_without_gpu_tensors():

@@ -52,12 +52,12 @@ def test_incremental_decode_equals_full_recompute_full_size(crab):
     kc, vc, n = out.past_key_values
     ws = eng._workspace(1)
     from crab_amd import ops
-    ops.copy_rows(emb[0, S:S + 1], ws.x, 1, D)
+    ops.cast_rows(emb[0, S:S + 1], ws.x, 1, D)
     pos = torch.full((1,), n, device="cuda", dtype=torch.int32)
     x, hfin = eng._layers(ws, 1, 1, kc, vc, 0, kc.shape[3], 0, pos, None)
     inc = ops.gemm(hfin, um.lm_head.weight, out_fp32=True)
     r_ = _rel(inc, full, "32-layer: incremental decode step vs recompute by prefill (HIP vs HIP)")
-    assert r_ < 3e-2, r_
+    assert r_ < 1.1e-2, r_                     # r04 (fp32 residual stream): 5.6e-3; r03: 1.84e-2 under 3e-2
     assert int(inc.argmax()) == int(full.argmax()) or (full.topk(2).values[0, 0] - full.topk(2).values[0, 1]) < 0.05 * full.abs().max()
 
 
@@ -74,7 +74,7 @@ def test_generate_deterministic_and_batch_rows_independent_full_size(crab):
     la, ls = torch.stack(a.logits, 1)[1], torch.stack(solo.logits, 1)[0]
     # different M -> different kernels (skinny vs split-K): same math, different rounding; first-step logits must agree closely
     r_ = _rel(la[0], ls[0], "32-layer: batch-3 row vs solo run, first-step logits (HIP vs HIP)")
-    assert r_ < 3e-2, r_
+    assert r_ < 1.1e-2, r_
     assert a.sequences.shape == (3, 6)
 
 
@@ -105,7 +105,7 @@ def test_decode_batch_256_regime_vs_cpu_oracle_full_size(crab):
     emb = torch.randn(B, S, D, device="cuda", generator=g).to(BF)
     ref = [O.greedy_generate(emb[r:r + 1].float().cpu(), W, cfg, n_new) for r in rows]
     scale = max(l.abs().max().item() for _, l in ref)
-    TOL = 3e-2
+    TOL = 6e-3            # r04, fp32 residual stream: measured 3.9e-3 (r03: 1.59e-2 under 3e-2)
     # (1) the public path: graph-replayed decode at M = 256
     ids, logits = eng.generate(emb, n_new, eos_token_id=None, pad_token_id=2, return_step_logits=True)
     st = eng._dec[0]
@@ -266,12 +266,12 @@ def test_full_size_encoders_vs_cpu_oracle():
     vit, qf = um.encode_video(video)
     ref_vit, ref_q = O.encode_video(video.to(BF).float(), W, cfg, emulate=BF)
     for lvl in range(3):
-        assert _rel(vit[lvl].cpu(), ref_vit[lvl], f"full-size CLIP ViT-L/14 level {lvl} vs bf16-emulating oracle") < 2.5e-2, f"CLIP level {lvl}"
-    assert _rel(qf[-1].cpu(), ref_q[-1], "full-size VLProjector vs bf16-emulating oracle") < 1.8e-2
+        assert _rel(vit[lvl].cpu(), ref_vit[lvl], f"full-size CLIP ViT-L/14 level {lvl} vs bf16-emulating oracle") < 1e-2, f"CLIP level {lvl}"     # r04: 4.7e-3 .. 6.0e-3 (r03: 1.9e-2)
+    assert _rel(qf[-1].cpu(), ref_q[-1], "full-size VLProjector vs bf16-emulating oracle") < 1.4e-2
     a = um.encode_audio(audio)
     ref_a = O.encode_audio(audio.to(BF).float(), W, cfg, emulate=BF)
     assert a.shape == (1, 64, 4096)
-    assert _rel(a.cpu(), ref_a, "full-size BEATs + ALProjector vs bf16-emulating oracle") < 1.6e-2
+    assert _rel(a.cpu(), ref_a, "full-size BEATs + ALProjector vs bf16-emulating oracle") < 8e-3      # r04: 3.8e-3 (r03: 7.5e-3)
 
 
 def _oracle_teacher_forced(W, cfg, emb, ids, emulate=None):
@@ -354,8 +354,8 @@ def test_full_32_layer_llama_generate_vs_cpu_oracle(crab):
     cfg = O.DecoderConfig(vocab_size=um.lm_head.weight.shape[0])
     g = torch.Generator().manual_seed(17)
     emb = torch.randn(1, 702, 4096, generator=g).to(BF)       # conditioned synthetic model: embed_tokens ~ N(0, 1)
-    # tolerance 3e-2 of the logit scale AND (non-circular) at most 1.5 x the error of the exact bf16-storage execution of the oracle
-    _greedy_vs_oracle(um, W, cfg, emb, 8, "32-layer Llama-2-7B-size decoder, S=702 + 8 greedy tokens vs fp32 CPU oracle", 3e-2, emu_factor=1.5)
+    # tolerance 6e-3 of the logit scale (r04, fp32 residual stream: measured 3.9e-3; r03 1.66e-2 under 3e-2) AND (non-circular) at most 1.5 x the error of the exact bf16-storage execution of the oracle
+    _greedy_vs_oracle(um, W, cfg, emb, 8, "32-layer Llama-2-7B-size decoder, S=702 + 8 greedy tokens vs fp32 CPU oracle", 6e-3, emu_factor=1.5)
 
 
 def test_full_width_qwen2_layer_prefill_and_greedy_vs_cpu_oracle():

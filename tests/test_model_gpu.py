@@ -6,9 +6,9 @@ Tolerances: north_star asks for "logits within 1e-3 bf16"; what bf16 STORAGE del
 bf16-storage execution of these decoders is already 3.4e-3 .. 5.6e-3 of the logit scale away from fp32).  Every comparison below is
 recorded (tests/util.py:record_parity) and each tolerance is at most twice the worst error measured on MI355X
 (profiles/r02_parity_report.json), relative to max |reference|:
-  * REL_ENC  encoder features / projector outputs / spliced inputs_embeds vs the fp32 reference fixture   (worst 1.40e-2)
-  * REL_DEC  decoder logits / hidden states / layer outputs vs the fp32 reference fixture                 (worst 8.9e-3)
-  * REL_EMU  vs the oracle emulating bf16 storage at the same points (accumulation order, 1-ulp flips)     (worst 1.34e-2)
+  * REL_ENC  encoder features / projector outputs / spliced inputs_embeds vs the fp32 reference fixture   (r04, fp32 residual stream / fp32 pre-LN sums: worst 1.29e-2; r03: 1.40e-2, tolerance 2.8e-2)
+  * REL_DEC  decoder logits / hidden states / layer outputs vs the fp32 reference fixture                 (r04: worst 6.7e-3 = a standalone bf16 rmsnorm, stacks 5.8e-3; r03: 8.9e-3, tolerance 1.8e-2)
+  * REL_EMU  vs the oracle emulating bf16 storage at the same points (accumulation order, 1-ulp flips)     (r04: worst 1.01e-2; r03: 1.34e-2, tolerance 2.5e-2)
   * greedy token ids: exact wherever the fp32 reference's top-2 logit margin exceeds twice the measured logit error.
 """
 import pytest
@@ -18,9 +18,9 @@ from tests.util import build_tiny_crab, load_fixture, weights_from_table, bert_c
 
 pytestmark = pytest.mark.gpu
 BF = torch.bfloat16
-REL_EMU = 2.5e-2
-REL_ENC = 2.8e-2
-REL_DEC = 1.8e-2
+REL_EMU = 1.5e-2
+REL_ENC = 1.4e-2
+REL_DEC = 9e-3
 
 
 def _rel(got, ref, what=""):
@@ -388,7 +388,9 @@ def test_generate_many_clips_vs_oracle():
         r = model.generate(batch_input_ids=ids, batch_labels=lab, batch_X_modals=mods, batch_task_names=['avqa'] * 2, use_cache=True,
                            max_new_tokens=n, pad_token_id=2, eos_token_id=None, output_logits=True, return_dict_in_generate=True)
         ref_ids, ref_logits = O.generate(ids, mods, Wo, ocfg, n)
-        worst = max(worst, _check_ids(r.sequences, ref_ids, ref_logits, torch.stack(r.logits, 1)) / ref_logits.abs().max().item())
+        # these clips are NOT searched for wide margins (unlike the fixtures): with the fp32 residual stream (r04) clip 11 flips one step whose
+        # reference top-2 margin is below twice the logit error (asserted inside) - 20 of 21 steps covered there, all steps elsewhere
+        worst = max(worst, _check_ids(r.sequences, ref_ids, ref_logits, torch.stack(r.logits, 1), min_frac=0.9) / ref_logits.abs().max().item())
     assert worst < REL_DEC, worst
 
 
@@ -495,7 +497,7 @@ def _layer_prefill_and_decode_step(fixture, qwen):
     assert _rel(kc[0, 0, :, :S], A["cache_k"][0][:, :S], f"{fixture}: K cache rows, prefill") < 1.2e-2
     assert _rel(vc[0, 0, :, :S], A["cache_v"][0][:, :S], f"{fixture}: V cache rows, prefill") < 1.2e-2
     # the decode row: position S, device-resident position word, KV append fused behind the q|k|v projection
-    ops.copy_rows(A["layer_x1"][0].to(BF).cuda(), ws.x, 1, D)
+    ops.cast_rows(A["layer_x1"][0].to(BF).cuda(), ws.x, 1, D)
     pos = torch.full((1,), S, device="cuda", dtype=torch.int32)
     x, _ = eng._layers(ws, 1, 1, kc, vc, 0, 64, 0, pos, None)
     assert _rel(x[:1], A["layer_y1"][0], f"{fixture}: layer output, 1-token decode step") < REL_DEC
@@ -594,7 +596,7 @@ def test_single_layer_entry_points_equal_the_stack_call():
     def run(per_layer: bool, decode: bool, kc, vc):
         ws = eng._workspace(B * (1 if decode else S))
         M = B * (1 if decode else S)
-        ops.copy_rows((emb[:, -1] if decode else emb).reshape(M, D).contiguous(), ws.x, M, D)
+        ops.cast_rows((emb[:, -1] if decode else emb).reshape(M, D).contiguous(), ws.x, M, D)
         ops.rmsnorm(ws.x[:M], eng.model.layers[0].input_layernorm.weight, cfg.rms_norm_eps, out=ws.h[:M])
         Tmax = kc.shape[3]
         vt = None if decode else torch.zeros((B, cfg.num_key_value_heads, cfg.hidden_size // cfg.num_attention_heads, 16), device="cuda", dtype=BF)
@@ -614,6 +616,7 @@ def test_single_layer_entry_points_equal_the_stack_call():
                 io.vt, io.vt_ld = vt.data_ptr(), vt.stride(-2)
             io.pos_dev = pos.data_ptr() if pos is not None else None
             io.B, io.S, io.Tmax, io.pos0 = B, 1 if decode else S, Tmax, 0
+            io.x_fp32 = 1 if ws.x.dtype == torch.float32 else 0
             tab = eng._layer_table()
             fn = lib.crab_llama_layer_decode if decode else lib.crab_llama_layer_prefill
             for li in range(cfg.num_hidden_layers):
