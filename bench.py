@@ -263,6 +263,9 @@ def main():
     ap.add_argument("--llm", default="llama")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather-logits", action="store_true", help="gather token ids only (default: ids + first-step fp32 logits of every clip)")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: --clips is the TOTAL over all ranks (contiguous blocks, the first total %% N ranks hold one more clip); "
+                         "default is weak scaling (--clips per GPU)")
     ap.add_argument("--no-operating-points", action="store_true",
                     help="skip the extra (untimed-region) runs at the reference's own operating points: eval batch 8, 10 frames, 2-s audio windows")
     args = ap.parse_args()
@@ -306,13 +309,26 @@ def main():
 
     from crab_amd import ops, synth
     from crab_amd.build_model import build_crab
-    from crab_amd.parallel import gather_results
+    from crab_amd.parallel import block_of, gather_results
 
+    t_setup = time.perf_counter()
+    # every rank holds a full replica (13.8 GB of weights in bf16) + its own KV cache: say so BEFORE the allocator does when a device is
+    # already occupied (a stale process on one GPU of the node would otherwise surface as an OOM traceback on one rank and a hang on the others)
+    free0, total0 = torch.cuda.mem_get_info(local)
+    if free0 < 20 * 2 ** 30:
+        sys.exit(f"bench.py: rank {rank}: cuda:{local} has {free0 / 2**30:.1f} GiB free of {total0 / 2**30:.1f}: a weight replica (13.8 GB) + the KV cache "
+                 f"of even one clip do not fit; is another process holding this GPU?")
     model = build_crab(args.llm, device=torch.device("cuda", local), seed=42)
     um = model.base_model.model
     tab = um.SPECIAL_TOKEN_2_IDS
-    B = args.clips
-    clip0 = rank * B
+    if args.strong:
+        clip0, B = block_of(args.clips, world, rank)          # fixed TOTAL work: rank r owns a contiguous block of the args.clips clips
+        if B == 0:
+            sys.exit(f"bench.py --strong: {args.clips} clips over {world} ranks leave rank {rank} without work")
+    else:
+        B = args.clips                                        # weak scaling: args.clips per GPU
+        clip0 = rank * B
+    n_total = args.clips if args.strong else world * B
     ids = [synth.synth_prompt_ids(128, model.base_vocab, tab, clip=clip0 + i) for i in range(B)]
     mods = [{'<video>': synth.synth_video(args.frames, clip=clip0 + i).cuda(), '<audio>': synth.synth_audio(10, 98, clip=clip0 + i).cuda()}
             for i in range(B)]
@@ -337,8 +353,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    t_build = time.perf_counter() - t_setup
+    t_w = time.perf_counter()
     for _ in range(args.warmup):
         step()
+    torch.cuda.synchronize()
+    t_warm = time.perf_counter() - t_w
+    # capacity: generate() splits a batch whose KV cache + scratch do not fit the device into groups that run one after the other (with a
+    # warning); the line says so (decode_groups), and a rank that cannot hold ONE clip has already raised inside generate()
+    plan = um._engine.last_plan or {}
+    free1, _ = torch.cuda.mem_get_info(local)
+    rank_info = {"rank": rank, "build_s": round(t_build, 1), "warmup_s": round(t_warm, 1), "clips": B, "decode_groups": len(plan.get("groups", [B])),
+                 "kv_bytes_per_clip": int(plan.get("bytes_per_seq", 0)), "free_gib_before": round(free0 / 2 ** 30, 1), "free_gib_after_warmup": round(free1 / 2 ** 30, 1)}
     # ---- the timed region: the SHIPPED path (native layer sequencers, every decode step a HIP-graph replay, no profiler attached)
     assert ops.PROFILER is None
     sync()
@@ -362,7 +388,10 @@ def main():
     instrumented_ms = (time.perf_counter() - ti) * 1e3
     ops.PROFILER = None
     rank_ms = [round(dt / args.steps * 1e3, 2)]
+    rank_infos = [rank_info]
     if dist is not None:
+        rank_infos = [None] * world
+        dist.all_gather_object(rank_infos, rank_info)
         # every rank's own wall time of the K steps (a straggler shows up here); `value` uses the MAX over ranks
         tt = torch.tensor([dt], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
         allt = [torch.empty_like(tt) for _ in range(world)]
@@ -374,9 +403,9 @@ def main():
 
     if rank == 0:
         # the gather really delivered every rank's clips (ordered by clip id) to rank 0
-        assert res is not None and res[1].shape[0] == world * B and res[0].tolist() == list(range(world * B)), "gather incomplete"
-        assert args.no_gather_logits or (res[2] is not None and tuple(res[2].shape) == (world * B, V)), "first-step logits not gathered"
-        n_clips = world * B * args.steps
+        assert res is not None and res[1].shape[0] == n_total and res[0].tolist() == list(range(n_total)), "gather incomplete"
+        assert args.no_gather_logits or (res[2] is not None and tuple(res[2].shape) == (n_total, V)), "first-step logits not gathered"
+        n_clips = n_total * args.steps
         S = 126 + 32 * args.frames + 320
         # per-kernel roofline entries from the live HIP-event samples; the dominant kernel is the one with the largest
         # (estimated) total time in the timed region: GEMM buckets are timed on every launch, the decode-attention
@@ -419,10 +448,11 @@ def main():
         line = {
             "metric": "clips/sec prefill+decode (AVQA 10s clip, 8 frames, 256 out tok)",
             "value": round(n_clips / dt, 4), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic (seeded N(0,0.02) weights, synthetic 8x224x224 frames, 10x98x128 fbank, 128-token prompt)",
             "config": {"workload": ("AVQA eval, Llama-2-7B + BEATs + CLIP-ViT-L/14, bf16 (BASELINE configs[1])" if args.llm == "llama" else
-                                     "AVQA eval, Qwen2-7B + BEATs + CLIP-ViT-L/14, bf16 (BASELINE configs[2] decoder)"), "clips_per_gpu_per_step": B,
+                                     "AVQA eval, Qwen2-7B + BEATs + CLIP-ViT-L/14, bf16 (BASELINE configs[2] decoder)"), "clips_per_gpu_per_step": B if not args.strong else [ri["clips"] for ri in rank_infos],
+                       "total_clips_per_step": n_total,
                        "frames": args.frames, "audio_segments": 10, "prompt_tokens": 128, "prefill_len": S, "new_tokens": args.new_tokens,
                        "decode": "greedy, EOS suppressed, device-resident HIP-graph loop", "parallelism": f"per-clip x{world} (contiguous blocks of clips per rank), RCCL gather",
                        "collective_backend": (backend + (" (RCCL)" if backend == "nccl" else "")) if dist is not None else None,
@@ -430,6 +460,7 @@ def main():
                        "gathered_per_clip": "clip id + ids" + ("" if args.no_gather_logits else f" + first-step fp32 logits[{V}]"),
                        "gathered_clips": int(res[1].shape[0])},
             "rank_ms_per_step": rank_ms,
+            "ranks": rank_infos,
             "prefill_tflop_per_clip": round(flops_per_clip(args.frames, 10, 48, S, V, um.config) / 1e12, 3),
             "step_ms": step_ms,
             "timed_region": "the shipped path: native layer sequencers + HIP-graph replay of every decode step, no profiler attached",

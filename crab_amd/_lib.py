@@ -146,6 +146,7 @@ SYMBOLS = {
     "crab_sync": (_i, [_vp, _vp]),
     "crab_gemm_bf16": (_i, [_vp, _vp, C.POINTER(GemmDesc)]),
     "crab_rowfin_workspace": (_i64, [_i, _i]),
+    "crab_rowfin_lora_ok": (_i, [_i, _i, _i]),
     "crab_attn_decode_rope_workspace": (_i64, [_i, _i, _i]),
     "crab_attn_decode_rope": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _vp, _f, _vp, _i64]),
     "crab_hyperlora_mix": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _i64, _i, _i, _i, _i, _i, _f]),

@@ -37,3 +37,7 @@ static inline int crab_check_launch(crab_ctx* ctx, const char* what) {
 
 // the kernels' storage-flags word (common.h CF_C32 | CF_R32) of a GEMM descriptor
 static inline int crab_cflags(const crab_gemm_desc* d) { return (d->c_fp32 ? 1 : 0) | ((d->r_fp32 && d->R) ? 2 : 0); }
+
+// rowfin.hip: the M <= 16 layer tail
+bool crab_rowfin_enabled();                                     // CRAB_ROWFIN != "0"
+extern "C" int crab_rowfin_lora_ok(int nl, int r, int N);       // declared in include/crab_hip.h as well

@@ -638,12 +638,13 @@ extern "C" int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc*
     if ((d->A2 != nullptr) != (d->B2 != nullptr) && !(d->lora_RA && !d->A2)) return crab_fail(ctx, CRAB_E_INVALID, "gemm: A2/B2 must be given together");
     if (d->lora_RA) {
         // in-call hyper-LoRA of a single-projection group: only the M <= 16 tail (rowfin.hip) evaluates it
-        static const int rowfin_on = []() { const char* e = getenv("CRAB_ROWFIN"); return !(e && e[0] == '0'); }();
+        const bool rowfin_on = crab_rowfin_enabled();
         if (d->A2 || !d->B2 || d->lora_nl < 1 || d->lora_r < 1 || (d->lora_ldra & 7) || ((uintptr_t)d->lora_RA & 15))
             return crab_fail(ctx, CRAB_E_INVALID, "gemm: lora_RA needs B2 = lora_B without A2, positive lora_nl / lora_r, aligned lora_RA");
+        if (d->K2 & 7) return crab_fail(ctx, CRAB_E_INVALID, "gemm: lora_RA needs K2 % 8 == 0 (lora_B is read in 16-byte chunks) and lora_RA padded to 16 rows (rows beyond lora_nl + lora_r zero)");
         if (!rowfin_on || d->tune != 0 || d->batch > 1 || !crab_rowfin_ok(d) || (d->ldb & 7))
             return crab_fail(ctx, CRAB_E_UNSUPPORTED, "gemm: the in-call hyper-LoRA (lora_RA) is evaluated by the M <= 16 layer tail only: needs M <= 16, "
-                                                      "the fused post-norm (norm_w / norm_out, bf16 C), a workspace of crab_rowfin_workspace(M, N) bytes");
+                                                      "the fused post-norm (norm_w / norm_out), crab_rowfin_lora_ok(lora_nl, lora_r, N), a workspace of crab_rowfin_workspace(M, N) bytes");
     }
     if (d->A2) {
         if (d->K2 <= 0 || (d->K2 & 7) || (d->lda2 & 7) || (d->ldb2 & 7))
@@ -666,8 +667,7 @@ extern "C" int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc*
             // fp32 sums in the workspace (one "slice") and the row-owning reduction kernel applies bias / residual, stores C, the
             // normalised row and the next group's router - one launch instead of rmsnorm + the router's two (CRAB_SKINNY_FUSED=0: off)
             static const int fused_on = []() { const char* e = getenv("CRAB_SKINNY_FUSED"); return !(e && e[0] == '0'); }();
-            static const int rowfin_on2 = []() { const char* e = getenv("CRAB_ROWFIN"); return !(e && e[0] == '0'); }();
-            if (fused_on && rowfin_on2 && d->tune == 0 && d->M <= 16 && crab_rowfin_ok(d) && (d->ldb & 7) == 0) {
+            if (fused_on && crab_rowfin_enabled() && d->tune == 0 && d->M <= 16 && crab_rowfin_ok(d) && (d->ldb & 7) == 0) {
                 // r03: the wide two-launch tail (rowfin.hip) - the projection's own router rows ride on the GEMM launch (d->lora_RA), the
                 // update, the residual row, its RMSNorm and the NEXT group's router follow in two launches of N / 64 blocks each
                 crab_gemm_desc raw = *d;

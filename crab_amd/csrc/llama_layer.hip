@@ -79,8 +79,7 @@ int run_group(crab_ctx* ctx, void* stream, const crab_linear_group* g, const cra
         d.rope_vt = io->vt; d.rope_vt_ld = io->vt_ld;
         if (c.fused_prefill_rope) *c.fused_prefill_rope = crab_gemm_fuses_prefill_rope(&d);      // a function of shapes / pointers set above only
     }
-    static const int rowfin_on = []() { const char* e = getenv("CRAB_ROWFIN"); return !(e && e[0] == '0'); }();
-    if (g->RA && !c.u_ready && M <= 16 && c.norm_w && g->nproj == 1 && rowfin_on) {
+    if (g->RA && !c.u_ready && M <= 16 && c.norm_w && g->nproj == 1 && crab_rowfin_enabled() && crab_rowfin_lora_ok(g->nl, g->r, g->N)) {
         // the reference's batch sizes, o_proj / down_proj: the group's [R;A] rows ride on the projection's launch and the update is applied
         // by the wide layer tail (rowfin.hip) - same choice as PackedLinearGroup.__call__ (crab_amd/peft_hyper.py)
         d.lora_RA = g->RA; d.lora_ldra = g->ldra; d.lora_nl = g->nl; d.lora_r = g->r; d.lora_scaling = g->scaling;

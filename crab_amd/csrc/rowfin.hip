@@ -17,6 +17,7 @@
 // Nothing spins: the only cross-block step is the last-arriver reduction, so the pair cannot hang.  Deterministic (fixed orders).
 #include "common.h"
 #include "crab_internal.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -264,6 +265,19 @@ extern "C" int64_t crab_rowfin_workspace(int M, int N) {
 
 float* crab_rowfin_T(const crab_gemm_desc* d) { return (float*)((char*)d->workspace + rf_align((int64_t)d->M * d->N * 4)); }
 
+// ONE predicate for "the in-call hyper-LoRA (crab_gemm_desc.lora_RA) can be evaluated by this tail": shared by crab_rowfin_ok, the layer
+// sequencer (llama_layer.hip: run_group) and - through the C-ABI - crab_amd/peft_hyper.py, so that an adapter outside these limits
+// (e.g. lora_r = 16: r is a CLI argument of the reference, 8 is only its default) takes the router + K-extension path instead of failing.
+extern "C" int crab_rowfin_lora_ok(int nl, int r, int N) {
+    return nl >= 1 && r >= 1 && nl <= 8 && nl + r <= 16 && nl * r <= 32 && N <= 128 * RF_CW && (N & 7) == 0;
+}
+
+// CRAB_ROWFIN=0 disables the tail process-wide (one parse for the library; crab_amd/ops.py reads the same variable the same way)
+bool crab_rowfin_enabled() {
+    static const int on = []() { const char* e = getenv("CRAB_ROWFIN"); return !(e && e[0] == '0' && e[1] == 0); }();
+    return on != 0;
+}
+
 bool crab_rowfin_ok(const crab_gemm_desc* d) {
     if (!d->norm_w || !d->norm_out || d->M > 16 || !d->workspace) return false;
     if (d->c_fp32 && (((uintptr_t)d->C & 15) || (d->R && !d->r_fp32))) return false;      // the fp32 residual stream: R and C both fp32
@@ -271,7 +285,8 @@ bool crab_rowfin_ok(const crab_gemm_desc* d) {
     if (crab_rowfin_workspace(d->M, d->N) > d->workspace_bytes || d->N > 128 * RF_CW) return false;
     if (d->route_RA && ((d->route_ldra & 7) || ((uintptr_t)d->route_RA & 15) || d->route_nl > 8 || d->route_nproj * (d->route_nl + d->route_r) > RF_TJ))
         return false;
-    if (d->lora_RA && (d->lora_nl > 8 || d->lora_nl + d->lora_r > 16 || d->lora_nl * d->lora_r > 32 || !d->B2 || (d->ldb2 & 7) ||
+    // K2 % 8: rowfin_apply loads lora_B in 16-byte chunks while ch * 8 < K2 - a K2 that is not a multiple of 8 would read past the row
+    if (d->lora_RA && (!crab_rowfin_lora_ok(d->lora_nl, d->lora_r, d->N) || !d->B2 || (d->ldb2 & 7) || (d->K2 & 7) ||
                        ((uintptr_t)d->B2 & 15) || d->K2 < d->lora_nl * d->lora_r))
         return false;
     return true;

@@ -680,9 +680,19 @@ extern "C" int crab_hyperlora_route(crab_ctx* ctx, void* stream, const void* X, 
     if (!ctx) return CRAB_E_INVALID;
     if (!X || !RA || !U || !workspace || M <= 0 || K <= 0 || (K & 7) || (ldx & 7) || (ldra & 7))
         return crab_fail(ctx, CRAB_E_INVALID, "hyperlora_route: bad argument");
-    if (nl + r > 16 || nproj < 1 || nproj > 3 || ucols < nproj * nl * r) return crab_fail(ctx, CRAB_E_UNSUPPORTED, "hyperlora_route: nl+r <= 16, nproj <= 3");
+    if (nproj < 1 || nl < 1 || nl > 8 || r < 1 || ucols < nproj * nl * r) return crab_fail(ctx, CRAB_E_INVALID, "hyperlora_route: nproj, r >= 1, 1 <= nl <= 8, ucols >= nproj nl r");
     const int tcols = ((nproj * (nl + r) + 15) / 16) * 16;        // RA must hold tcols rows (zero padded)
     if (crab_hyperlora_route_workspace(M, K, tcols) > workspace_bytes) return crab_fail(ctx, CRAB_E_WORKSPACE, "hyperlora_route: workspace too small");
+    if (nl + r > 16 || nproj > 3 || tcols > 64) {
+        // outside the fused kernels' shapes (e.g. lora_r = 16: r is a free argument of the reference's LoraConfig, peft_hyper/tuners/lora.py:42-83):
+        // the same arithmetic as two general launches - T = X . [R;A]^T in fp32 (the library GEMM, into the workspace) and the routing mix
+        crab_gemm_desc g;
+        memset(&g, 0, sizeof(g));
+        g.A = X; g.lda = ldx; g.B = RA; g.ldb = ldra; g.C = workspace; g.ldc = tcols; g.M = M; g.N = tcols; g.K = K;
+        g.c_fp32 = 1; g.res_scale = 1.0f; g.batch = 1; g.nb0 = 1;
+        int rc = crab_gemm_bf16(ctx, stream, &g);
+        return rc ? rc : crab_hyperlora_mix(ctx, stream, workspace, tcols, 1, U, ldu, M, nproj, nl, r, ucols, scaling);
+    }
     // decode regime (one row per clip, 64 < M <= 256): one row-owning launch (~6 us) instead of the partial-product + mix pair (~11 us)
     // (at M <= 16 the row-owning launch has 1-16 blocks and loses to the pair: 6.09 vs 6.22 clips/s at batch 8, profiles/README.md)
     if (M > 64 && M <= 256 && K <= 6 * 2048 && nl <= 8 && ((uintptr_t)X & 15) == 0 && ((uintptr_t)RA & 15) == 0) {

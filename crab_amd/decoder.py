@@ -68,6 +68,7 @@ class Attention(nn.Module):
         D, H, Hk, d = cfg.hidden_size, cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
         self._qkv = PackedLinearGroup(["q_proj", "k_proj", "v_proj"], D, [H * d, Hk * d, Hk * d], cfg.attention_bias, device)
         self._o = PackedLinearGroup(["o_proj"], H * d, [D], False, device)
+        self._qkv.prof_class = self._o.prof_class = "decoder"
         self.q_proj, self.k_proj, self.v_proj = self._qkv.linears
         self.o_proj = self._o.linears[0]
 
@@ -79,6 +80,7 @@ class MLP(nn.Module):
         # gate / up rows interleaved: the gate|up GEMM epilogue applies SwiGLU itself (no [M, 2I] round trip, one launch less)
         self._gu = PackedLinearGroup(["gate_proj", "up_proj"], D, [I, I], False, device, interleave=True)
         self._down = PackedLinearGroup(["down_proj"], I, [D], False, device)
+        self._gu.prof_class = self._down.prof_class = "decoder"
         self.gate_proj, self.up_proj = self._gu.linears
         self.down_proj = self._down.linears[0]
 
@@ -261,26 +263,43 @@ class GenerationEngine:
         have_bytes = have.M * per_row if have is not None else 0
         return max(rows * per_row - have_bytes, 0) + (256 << 20)                   # + split-K / router workspaces, allocator slack
 
-    def memory_budget(self, B: int, Tmax: int) -> int:
+    def _drop_stale_slots(self, keep_slots: int):
+        """Free the persistent KV buffers, decode states (+ graphs) and decode workspaces of the slots >= keep_slots: what an earlier
+        generate_many / decode_streams > 1 call left behind and the upcoming call (which uses slots 0 .. keep_slots-1) will not reuse.
+        alloc_cache(slot=g) only ever replaces the buffer of the slot it is asked for, so without this those tens of GB would neither be
+        reclaimable by the new call nor counted correctly by memory_budget()."""
+        stale = [k for k in self._kv if k[0] >= keep_slots]
+        for k in stale:
+            del self._kv[k]
+        for g in [g for g in self._dec if g >= keep_slots]:
+            del self._dec[g]
+        for k in [k for k in self._ws if k != "prefill" and k[2] >= keep_slots]:
+            del self._ws[k]
+        if stale:
+            torch.cuda.empty_cache()
+
+    def memory_budget(self, B: int, Tmax: int, slots: int = 1) -> int:
         """Bytes generate() may still claim on this device: what the driver reports free (hipMemGetInfo) + what torch's caching
-        allocator holds but has not handed out + the engine's own persistent KV buffers of another shape (alloc_cache drops them
-        before allocating the new ones).  `kv_budget_bytes` overrides it."""
+        allocator holds but has not handed out + the engine's own persistent KV buffers of the slots the upcoming call will re-allocate
+        (slots 0 .. slots-1: alloc_cache drops a slot's old buffers before allocating the new shape; buffers of OTHER slots are released by
+        _drop_stale_slots before planning, so they show up as free memory, not here).  `kv_budget_bytes` overrides it."""
         if self.kv_budget_bytes is not None:
             return int(self.kv_budget_bytes)
+        self._drop_stale_slots(slots)
         free, _total = torch.cuda.mem_get_info(self.device)
         cached = torch.cuda.memory_reserved(self.device) - torch.cuda.memory_allocated(self.device)
         own = 0
-        c = self.cfg
-        for (kcb, vcb) in self._kv.values():
-            own += kcb.numel() * 2 + vcb.numel() * 2
+        for key, (kcb, vcb) in self._kv.items():
+            if key[0] < slots:
+                own += kcb.numel() * 2 + vcb.numel() * 2
         return int(free + cached + own)
 
-    def plan_batch(self, B: int, S: int, max_new_tokens: int) -> List[int]:
+    def plan_batch(self, B: int, S: int, max_new_tokens: int, slots: int = 1) -> List[int]:
         """Split B sequences into groups that are generated one after the other when their KV cache + scratch would not fit the device
         (the reference's max_new_tokens = 500 at S = 766: 0.66 MB of KV per token per clip -> 0.67 GB per clip, B = 384 does not fit
         288 GB next to the weights; scripts/quick_start.py:36-41).  Returns the group sizes (a single [B] when everything fits)."""
         per = self.bytes_per_sequence(S, max_new_tokens)
-        budget = self.memory_budget(B, _round_up(S + max_new_tokens, 64))
+        budget = self.memory_budget(B, _round_up(S + max_new_tokens, 64), slots)
         room = int(0.94 * budget) - self.fixed_bytes(B, S)
         fit = max(1, room // per)
         if B <= fit:
@@ -459,7 +478,7 @@ class GenerationEngine:
         x, hfin = self._layers(ws, B, S, kc, vc, b0, Tmax, 0, None, vt, pos_ids=pos_ids, kv_start=kv_start)   # hfin = model.norm(x), all rows
         if all_logits:
             hn = hfin.clone()
-            logits = ops.gemm(hn, self.lm_head.weight, out_fp32=True)
+            logits = ops.gemm(hn, self.lm_head.weight, out_fp32=True, prof_class="head")
             return logits.view(B, S, -1), hn.view(B, S, D)
         hn = hn_out if hn_out is not None else torch.empty((B, D), device=self.device, dtype=BF16)
         ops.copy_rows(hfin[S - 1:], hn, B, D, lds=S * D)                  # hn[b] = hfin[b*S + S-1]
@@ -556,7 +575,7 @@ class GenerationEngine:
         separate HIP streams: the HBM-bound KV-cache attention of one group overlaps the MFMA-bound projections of
         another.  Rows never interact, so the split only changes which M the projection kernels see."""
         B, S, D = embeds.shape
-        groups = self.plan_batch(B, S, max_new_tokens)
+        groups = self.plan_batch(B, S, max_new_tokens, slots=max(1, decode_streams))
         if len(groups) > 1:
             return self._generate_split(groups, embeds, max_new_tokens, eos_token_id, pad_token_id, min_new_tokens, prefill_chunk, use_graph,
                                         return_step_logits, return_hidden, return_first_logits, sampling)
@@ -665,7 +684,7 @@ class GenerationEngine:
             return [r]
         need = sum(e.shape[0] * self.bytes_per_sequence(e.shape[1], max_new_tokens) for e in embeds_list) + self.fixed_bytes(max(e.shape[0] for e in embeds_list),
                                                                                                                             max(e.shape[1] for e in embeds_list))
-        budget = self.memory_budget(0, 0)
+        budget = self.memory_budget(0, 0, slots=G)
         if need > 0.94 * budget:
             raise MemoryError(f"generate_many: {G} batches need {need / 2**30:.1f} GiB of KV cache and scratch, {budget / 2**30:.1f} GiB available: put fewer in flight")
         graphed = use_graph and max_new_tokens > 2

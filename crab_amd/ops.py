@@ -111,7 +111,12 @@ def _variant(M: int, N: int, batch: int = 1, K: int = 4096) -> str:
 RESIDUAL_FP32 = os.environ.get("CRAB_RESIDUAL_FP32", "1") != "0"
 RES_DTYPE = torch.float32 if RESIDUAL_FP32 else torch.bfloat16
 
-ROWFIN = os.environ.get("CRAB_ROWFIN", "1") != "0"     # the M <= 16 layer tail of csrc/rowfin.hip (same switch as the library reads)
+ROWFIN = os.environ.get("CRAB_ROWFIN", "1") != "0"     # the M <= 16 layer tail of csrc/rowfin.hip (same switch, same parse as the library: off iff the value is exactly "0")
+
+
+def rowfin_lora_ok(nl: int, r: int, N: int) -> bool:
+    """crab_rowfin_lora_ok: the library's own predicate for the in-call hyper-LoRA form (lora_self) - the one run_group (csrc/llama_layer.hip) uses."""
+    return bool(_lib.load().crab_rowfin_lora_ok(int(nl), int(r), int(N)))
 
 _SPLITK_WS = {}
 WS_SLOT = 0      # scratch slot of the launches being issued/captured: groups decoding concurrently on different HIP streams
@@ -129,7 +134,7 @@ def _splitk_workspace(device) -> torch.Tensor:
 def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act: str = "none",
          residual: Optional[torch.Tensor] = None, res_scale: float = 1.0, x2: Optional[torch.Tensor] = None,
          w2: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, out_fp32: bool = False, tune: int = 0,
-         post_norm=None, rope=None, route=None, lora_self=None, info: Optional[dict] = None) -> torch.Tensor:
+         post_norm=None, rope=None, route=None, lora_self=None, info: Optional[dict] = None, prof_class: Optional[str] = None) -> torch.Tensor:
     """out[M,N] = res_scale*residual + act(x[M,K] @ w[N,K]^T + x2 @ w2^T + bias).  2-D row-strided operands.
     rope = (tab, k_cache, v_cache, H, Hk, d, Tmax, pos0, pos_dev): packed q|k|v projection of ONE row per sequence followed
     by RoPE + KV-cache append (== qkv_rope_split(B=M, S=1) on out), fused into the split-K reduction when there is one.
@@ -204,8 +209,10 @@ def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
         e0.record()
         _lib.check(_lib.load().crab_gemm_bf16(_lib.ctx(d), _stream(), C.byref(g)), d)
         e1.record()
-        prof.records.append((_variant(M, N, 1, K) + ("|decoder" if x2 is not None else "|encoder"),
-                             2.0 * M * N * (K + (x2.shape[1] if x2 is not None else 0)), e0, e1))
+        # class of the launch for bench.py's by_class split: stated by the caller (PackedLinearGroup.prof_class: "decoder" for every projection
+        # of the decoder stack, adapted or not; "head" for lm_head); un-tagged launches are the encoders' / projectors'
+        k2 = x2.shape[1] if x2 is not None else (lora_self[4].shape[1] if lora_self is not None else 0)
+        prof.records.append((_variant(M, N, 1, K) + "|" + (prof_class or "encoder"), 2.0 * M * N * (K + k2), e0, e1))
         return out
     _lib.check(_lib.load().crab_gemm_bf16(_lib.ctx(d), _stream(), C.byref(g)), d)
     return out

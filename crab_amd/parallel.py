@@ -18,10 +18,21 @@ def shard_clips(n_clips: int, world: int, rank: int) -> List[int]:
     return list(range(rank, n_clips, world))
 
 
+def block_of(n_clips: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous block [first, first + count) of rank `rank` when n_clips are spread over `world` ranks as evenly as possible (the first
+    n_clips % world ranks hold one more): the strong-scaling partition of bench.py --strong and of an eval set whose size the world does not divide."""
+    base, extra = divmod(n_clips, world)
+    first = rank * base + min(rank, extra)
+    return first, base + (1 if rank < extra else 0)
+
+
 def gather_results(ids: torch.Tensor, clip0: int, world: int, rank: int, logits: Optional[torch.Tensor] = None
                    ) -> Optional[Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]]:
-    """ids [B, n_new] int64 of clips clip0..clip0+B-1 on this rank -> on rank 0: (clip_ids [W*B], ids [W*B, n_new],
-    logits [W*B, V] or None) ordered by clip id; other ranks return None.  Equal B on every rank (weak scaling)."""
+    """ids [B, n_new] int64 of clips clip0..clip0+B-1 on this rank -> on rank 0: (clip_ids [sum B], ids [sum B, n_new],
+    logits [sum B, V] or None) ordered by clip id; other ranks return None.  B may DIFFER between ranks (a clip count the world size does
+    not divide; a rank may even hold zero clips): every rank pads its records to the largest B (one all_reduce(MAX) of a single word) with
+    clip id -1 and rank 0 drops the padding, so the gather itself stays a fixed-size `dist.gather` per payload (RCCL: one peer->root
+    transfer per rank over its own xGMI link)."""
     B = ids.shape[0]
     cid = torch.arange(clip0, clip0 + B, device=ids.device, dtype=torch.int64)
     if world == 1:
@@ -30,7 +41,15 @@ def gather_results(ids: torch.Tensor, clip0: int, world: int, rank: int, logits:
     if dist.get_backend() == "gloo":                      # CPU tests / one-GPU rehearsals: gloo gathers host tensors
         ids, cid = ids.cpu(), cid.cpu()
         logits = logits.cpu() if logits is not None else None
-    rec = torch.cat([cid[:, None], ids.to(torch.int64)], dim=1).contiguous()
+    bmax = torch.tensor([B], device=ids.device, dtype=torch.int64)
+    dist.all_reduce(bmax, op=dist.ReduceOp.MAX)
+    Bm = int(bmax.item())
+    rec = torch.cat([cid[:, None], ids.to(torch.int64)], dim=1)
+    if B < Bm:                                            # uneven shard: pad with clip id -1 (dropped on rank 0)
+        rec = torch.cat([rec, torch.full((Bm - B, rec.shape[1]), -1, device=rec.device, dtype=torch.int64)], 0)
+        if logits is not None:
+            logits = torch.cat([logits, torch.zeros((Bm - B, logits.shape[1]), device=logits.device, dtype=logits.dtype)], 0)
+    rec = rec.contiguous()
     bufs = [torch.empty_like(rec) for _ in range(world)] if rank == 0 else None
     dist.gather(rec, bufs, dst=0)
     lbufs = None
@@ -41,7 +60,10 @@ def gather_results(ids: torch.Tensor, clip0: int, world: int, rank: int, logits:
     if rank != 0:
         return None
     allrec = torch.cat(bufs, dim=0)
+    live = allrec[:, 0] >= 0
+    lg = torch.cat(lbufs, dim=0)[live] if lbufs is not None else None
+    allrec = allrec[live]
     order = torch.argsort(allrec[:, 0])
     allrec = allrec[order]
-    lg = torch.cat(lbufs, dim=0)[order] if lbufs is not None else None
+    lg = lg[order] if lg is not None else None
     return allrec[:, 0], allrec[:, 1:], lg

@@ -107,6 +107,7 @@ class PackedLinearGroup:
         if interleave and (len(names) != 2 or out_features[0] != out_features[1]):
             raise ValueError("interleave needs two members of equal width")
         self.interleave = interleave
+        self.prof_class = None            # ops.KernelProfiler class tag of this group's launches (decoder.py sets "decoder")
         self.names = list(names)
         self.K = in_features
         self.outs = list(out_features)
@@ -175,13 +176,14 @@ class PackedLinearGroup:
             ng, nu = route_next
             route = (ng.RA, len(ng.names), ng.nl, ng.r, ng.u_cols, ng.scaling, nu[:M, :ng.u_cols])
         if self.RA is None:
-            return ops.gemm(x, self.W, bias=self.bias, residual=residual, out=out, post_norm=post_norm, act=act, rope=rope, route=route, info=info)
-        if u_ready is None and M <= 16 and post_norm is not None and len(self.names) == 1 and ops.ROWFIN:
+            return ops.gemm(x, self.W, bias=self.bias, residual=residual, out=out, post_norm=post_norm, act=act, rope=rope, route=route, info=info,
+                            prof_class=self.prof_class)
+        if u_ready is None and M <= 16 and post_norm is not None and len(self.names) == 1 and ops.ROWFIN and ops.rowfin_lora_ok(self.nl, self.r, self.N):
             # the reference's batch sizes (M <= 16), o_proj / down_proj: no router launches - the [R;A] rows ride on the projection's
             # launch and the update is applied by the wide layer tail (csrc/rowfin.hip) together with the residual row, its RMSNorm and
             # the next group's router
             return ops.gemm(x, self.W, bias=self.bias, residual=residual, out=out, post_norm=post_norm, act=act, route=route,
-                            lora_self=(self.RA, self.nl, self.r, self.scaling, self.B2))
+                            lora_self=(self.RA, self.nl, self.r, self.scaling, self.B2), prof_class=self.prof_class)
         if u_ready is not None:
             u = u_ready[:M, :self.u_cols]
         else:
@@ -189,7 +191,7 @@ class PackedLinearGroup:
             # route logits | lora_A(x) -> softmax mix, K split over blocks (skinny.hip); t_buf is the partial-sum workspace
             ops.hyperlora_route(x, self.RA, len(self.names), self.nl, self.r, self.u_cols, self.scaling, out=u, workspace=t_buf)
         return ops.gemm(x, self.W, bias=self.bias, residual=residual, x2=u, w2=self.B2, out=out, post_norm=post_norm, act=act, rope=rope,
-                        route=route, info=info)
+                        route=route, info=info, prof_class=self.prof_class)
 
     def routes_ahead(self, M: int) -> bool:
         """True when a producer GEMM may evaluate this group's router in its fused post-norm epilogue (decode regime)."""

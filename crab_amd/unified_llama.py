@@ -297,7 +297,13 @@ class UnifiedForCausalLM(nn.Module, UnifiedMetaForCausalLM):
         if t <= 0 or not (0 < p_ <= 1) or k < 0:
             raise ValueError("do_sample: temperature > 0, 0 < top_p <= 1, top_k >= 0")
         seed = kwargs.get("seed")
-        return (t, k, p_, int(torch.initial_seed() if seed is None else seed) & 0x7FFFFFFFFFFFFFFF)
+        if seed is None:
+            # no explicit seed: like HF (whose torch.multinomial advances the global generator) every call draws a fresh stream - the seed is
+            # taken from torch's default CPU generator, so torch.manual_seed(n) still reproduces a whole run while two calls on the same prompt
+            # no longer return the same sample.  seed=<int> stays fully deterministic per call.  (The seed is baked into the captured decode
+            # graph: an unseeded sampling call re-captures it.)
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        return (t, k, p_, int(seed) & 0x7FFFFFFFFFFFFFFF)
 
     @torch.no_grad()
     def generate_avs(self, batch_input_ids, batch_labels, batch_X_modals, batch_task_names, **kwargs):

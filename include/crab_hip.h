@@ -94,7 +94,8 @@ typedef struct {
      * lora_RA [pad16(lora_nl + lora_r), K] = lora_nl route rows then lora_r lora_A rows (row stride lora_ldra); B2 / ldb2 / K2 describe
      * lora_B [N, K2 >= lora_nl * lora_r] (expert i, rank j at column i * lora_r + j) and A2 must be NULL.  The router product rides on the
      * projection's launch as 16 extra weight rows and the update is applied by the row-owning tail that also stores the residual row, its
-     * RMSNorm and the next group's router (csrc/rowfin.hip): needs M <= 16, norm_w / norm_out, bf16 C and a workspace of
+     * RMSNorm and the next group's router (csrc/rowfin.hip): needs M <= 16, norm_w / norm_out, crab_rowfin_lora_ok(lora_nl, lora_r, N), K2 % 8 == 0, lora_RA
+     * padded to 16 rows (the ride-along blocks read 16), and a workspace of
      * crab_rowfin_workspace(M, N) bytes; CRAB_E_UNSUPPORTED otherwise (use crab_hyperlora_route + A2 there).  lora_RA == NULL disables it. */
     const void* lora_RA; int64_t lora_ldra; int32_t lora_nl, lora_r; float lora_scaling;
     /* PREFILL form of the fused RoPE (rope_S > 1 rows per sequence, M = B * rope_S; head_dim 128, rope_pos_dev == NULL): the q and k column
@@ -116,6 +117,10 @@ int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc* d);
 int crab_gemm_fuses_prefill_rope(const crab_gemm_desc* d);   /* 0: no; 1: this call rotates q / k and appends k in its epilogue (see rope_S); 2: and handles the v columns (rope_vt) */
 /* bytes of crab_gemm_desc.workspace the M <= 16 layer tail needs (fp32 sums + router product + per-slice partials) */
 int64_t crab_rowfin_workspace(int M, int N);
+/* 1 when the in-call hyper-LoRA form (crab_gemm_desc.lora_RA, M <= 16) can serve an adapter with nl experts of rank r on a projection of N
+ * outputs (nl <= 8, nl + r <= 16, nl * r <= 32, N <= 8192, N % 8 == 0); callers pick crab_hyperlora_route + the A2 / B2 segment otherwise
+ * (e.g. lora_r = 16: peft_hyper/tuners/lora.py:42-83 makes r a free argument, 8 is only the reference's default) */
+int crab_rowfin_lora_ok(int nl, int r, int N);
 
 /* ---------------------------------------------------------------------------------------------
  * hyper-LoRA routing mix (peft_hyper/tuners/lora.py:346-350).

@@ -38,6 +38,25 @@ def test_bench_gpus_2_self_spawns_two_ranks_on_one_device():
 
 
 @pytest.mark.gpu
+def test_bench_strong_scaling_with_a_clip_count_the_world_does_not_divide():
+    """`--strong`: --clips is the total; 3 clips over 2 ranks = 2 + 1 (uneven shards through the padded gather), every clip reaches rank 0
+    exactly once, value = total clips / max-over-ranks time, and the line carries every rank's build / warm-up seconds and memory."""
+    env = dict(os.environ, CRAB_BENCH_SINGLE_DEVICE="1", CRAB_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--clips", "3", "--strong", "--new-tokens", "4", "--steps", "1", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-operating-points"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["config"]["total_clips_per_step"] == 3 and j["config"]["gathered_clips"] == 3
+    assert j["config"]["clips_per_gpu_per_step"] == [2, 1]
+    assert [ri["rank"] for ri in j["ranks"]] == [0, 1] and all(ri["build_s"] > 0 and ri["warmup_s"] > 0 and ri["decode_groups"] == 1 for ri in j["ranks"])
+    assert abs(j["value"] - 3 / (j["ms_per_step"] * 1e-3)) < 1e-2 * j["value"]
+
+
+@pytest.mark.gpu
 def test_bench_gpus_2_on_rccl_when_two_gpus_are_visible():
     """The real N > 1 path: two ranks, one per GPU, `nccl` (= RCCL) process group with device_id, barrier + max-over-ranks timing,
     RCCL gather of {clip id, ids, first-step logits} to rank 0.  Needs two visible MI355X; the builder's and the driver's test

@@ -180,6 +180,42 @@ def test_run_inference_world2_gloo():
     assert got[1] == (2, [want[1], want[3]])
 
 
+def _worker3(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    tok = _tok()
+    model = _FakeModel()
+    recs = harness.run_inference(_batches(tok, 7), model, tok, max_new_tokens=4, device="cpu", rank=rank, world=world, in_flight=2)
+    q.put((rank, [c["n"] if c.get("many") else [1] for c in model.calls], [r["instruction"] for r in recs]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_run_inference_uneven_shards_world3_gloo_in_flight():
+    """7 eval batches over 3 ranks (3 + 2 + 2: the batch count is not a multiple of the world size), two batches in flight per rank:
+    rank 0 ends up with all seven records in batch order, the other ranks with their own (scripts/finetune/inference_hyper_lora.py:1466-1479
+    is the single-process loop this shards)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker3, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(3):
+        r, calls, ins = q.get(timeout=180)
+        got[r] = (calls, ins)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    tok = _tok()
+    want = [b["batch_metadata"][0]["instruction"] for b in _batches(tok, 7)]
+    assert got[0][1] == want and got[0][0] == [[1, 1], [1]]           # batches 0, 3 in flight together, then 6 alone
+    assert got[1][1] == [want[1], want[4]] and got[2][1] == [want[2], want[5]]
+
+
 @pytest.mark.gpu
 def test_make_instance_pipeline_gpu():
     """uint8 frames + waveform -> make_instance (device front-end) -> Collator -> run_inference on the tiny fixture model: the

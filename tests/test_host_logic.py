@@ -94,6 +94,32 @@ def test_plan_batch_splits_when_the_kv_cache_would_not_fit():
     assert big.plan_batch(384, 766, 500) == [192, 192]
 
 
+def test_memory_budget_counts_only_the_slots_the_call_will_replace(monkeypatch):
+    """After generate_many (slots 0 .. G-1) a single-group generate() must neither count the other slots' KV buffers as reclaimable
+    while they stay allocated (r03 over-estimated the budget by tens of GB and ran into an OOM instead of splitting) nor leave them
+    allocated: the stale slots' caches, decode states and decode workspaces are dropped before planning."""
+    from crab_amd.decoder import DecoderConfig, GenerationEngine
+    eng = GenerationEngine.__new__(GenerationEngine)
+    eng.cfg, eng.lm_head, eng.last_plan, eng.kv_budget_bytes = DecoderConfig(), type("H", (), {"weight": torch.empty(8, 1)})(), None, None
+    kv = lambda n: (torch.empty(n, dtype=torch.bfloat16), torch.empty(n, dtype=torch.bfloat16))
+    eng._kv = {(0,): kv(1000), (1,): kv(3000), (2,): kv(5000)}
+    eng._dec = {0: object(), 1: object(), 2: object()}
+    eng._ws = {"prefill": object(), ("decode", 8, 0): object(), ("decode", 8, 1): object(), ("decode", 8, 2): object()}
+    emptied = []
+    monkeypatch.setattr(torch.cuda, "mem_get_info", lambda dev=None: (10_000, 100_000))
+    monkeypatch.setattr(torch.cuda, "memory_reserved", lambda dev=None: 700)
+    monkeypatch.setattr(torch.cuda, "memory_allocated", lambda dev=None: 200)
+    monkeypatch.setattr(torch.cuda, "empty_cache", lambda: emptied.append(1))
+    # a call that will use slots 0 and 1: slot 2 is released (and shows up as free memory on a real device), slots 0 / 1 count as reclaimable
+    assert eng.memory_budget(0, 0, slots=2) == 10_000 + 500 + 2 * 2 * (1000 + 3000)
+    assert sorted(eng._kv) == [(0,), (1,)] and sorted(eng._dec) == [0, 1] and ("decode", 8, 2) not in eng._ws and "prefill" in eng._ws and emptied
+    # a single-group generate(): only slot 0 is its own
+    assert eng.memory_budget(0, 0) == 10_000 + 500 + 2 * 2 * 1000
+    assert sorted(eng._kv) == [(0,)] and sorted(eng._dec) == [0] and [k for k in eng._ws if k != "prefill"] == [("decode", 8, 0)]
+    eng.kv_budget_bytes = 123                                     # the override never touches the device or the slots
+    assert eng.memory_budget(0, 0) == 123
+
+
 def test_generate_batches_refuses_generate_only_arguments():
     """generate_batches returns ids only; the per-call extras of generate() are refused loudly instead of being dropped."""
     from crab_amd.unified_llama import UnifiedForCausalLM

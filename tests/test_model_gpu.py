@@ -573,6 +573,37 @@ def test_native_layer_sequencer_equals_python_sequence_tiny_qwen(bs):
         assert torch.equal(ids, outs[0][0]) and torch.equal(logits, outs[0][1])
 
 
+@pytest.mark.parametrize("r,nl", [(16, 3), (4, 8)])
+def test_adapter_rank_outside_the_small_batch_tail_limits_still_generates(r, nl):
+    """lora_r is a CLI argument of the reference (peft_hyper/tuners/lora.py:42-83; 8 is only the default).  r = 16 (nl + r > 16) and nl * r = 32 at
+    the edge: batches <= 16 must take the router + K-extension path when crab_rowfin_lora_ok says no (r03 hard-failed with CRAB_E_UNSUPPORTED),
+    in BOTH sequencers (csrc/llama_layer.hip run_group and crab_amd/peft_hyper.py), and agree with the oracle at batch 1, 3 and 20."""
+    from crab_amd import ops
+    from crab_amd.peft_hyper import LoraConfig, get_peft_model
+    from crab_amd.unified_llama import UnifiedConfig, UnifiedForCausalLM
+    from oracle import crab_oracle as O
+    torch.manual_seed(11)
+    cfg = UnifiedConfig(hidden_size=128, intermediate_size=352, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=2,
+                        vocab_size=320, pad_token_id=2)
+    um = UnifiedForCausalLM(cfg, device="cuda")
+    model = get_peft_model(um, LoraConfig(r=r, lora_alpha=2 * r, lora_nums=nl))
+    assert bool(ops.rowfin_lora_ok(nl, r, 128)) == (nl + r <= 16 and nl * r <= 32)
+    for n_, p in model.named_parameters():
+        small = 0.2 if ("o_proj" in n_ or "down_proj" in n_ or "lora_B" in n_) else 1.0
+        p.data.copy_((torch.randn(p.shape) * 0.08 * small).to(BF) if p.dim() > 1 else (1 + 0.1 * torch.randn(p.shape)).to(BF))
+    W = {k: v.detach().float().cpu() for k, v in O.strip_peft_prefix(model.state_dict()).items() if v.dtype.is_floating_point}
+    ocfg = O.DecoderConfig(hidden_size=128, intermediate_size=352, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=2, vocab_size=320,
+                           lora_r=r, lora_alpha=2 * r, lora_nums=nl)
+    for B in (1, 3, 20):
+        emb = (torch.randn(B, 7, 128) * 0.5).to(BF).cuda()
+        outs = _gen_both_sequencers(model, emb, 4)
+        for ids, logits in outs[1:]:
+            assert torch.equal(ids, outs[0][0]) and torch.equal(logits, outs[0][1])
+        ref_ids, ref_logits = O.greedy_generate(emb.float().cpu(), W, ocfg, 4)
+        err = _check_ids(outs[0][0], ref_ids, ref_logits, outs[0][1], min_frac=0.5)
+        assert err < REL_DEC * ref_logits.abs().max().item(), (B, err)
+
+
 def test_single_layer_entry_points_equal_the_stack_call():
     """crab_llama_layer_prefill / crab_llama_layer_decode called layer by layer == crab_llama_layers over the table (tiny Llama,
     hyper-LoRA): x and h after the stack bit-identical, prefill (S = 9) and one decode step; argument validation of the io block."""
@@ -691,6 +722,12 @@ def test_generate_with_sampling_like_the_reference_default():
     assert torch.equal(a, b) and torch.equal(a, e) and not torch.equal(a, c)
     greedy = model.generate(do_sample=True, top_k=1, seed=5, **kw)
     assert torch.equal(greedy.cpu(), A["ids_bs1"])
+    # without seed=: like HF, consecutive calls on the same prompt draw different streams; torch.manual_seed reproduces the pair
+    torch.manual_seed(77)
+    u1, u2 = model.generate(do_sample=True, **kw), model.generate(do_sample=True, **kw)
+    torch.manual_seed(77)
+    v1, v2 = model.generate(do_sample=True, **kw), model.generate(do_sample=True, **kw)
+    assert not torch.equal(u1, u2) and torch.equal(u1, v1) and torch.equal(u2, v2)
     with pytest.raises(ValueError):
         model.generate(do_sample=True, temperature=0.0, **kw)
 

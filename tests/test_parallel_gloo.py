@@ -52,6 +52,52 @@ def test_gather_results_world2_gloo():
     assert shard == [1, 3, 5]
 
 
+def _worker_uneven(rank, world, port, q):
+    import torch.distributed as dist
+    from crab_amd.parallel import block_of, gather_results
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out = []
+    for n_total in (7, 2):                          # 7 clips over 3 ranks: 3 + 2 + 2; 2 clips over 3 ranks: the last rank holds none
+        clip0, B = block_of(n_total, world, rank)
+        n_new, V = 4, 5
+        ids = torch.stack([torch.arange(n_new) + 100 * (clip0 + i) for i in range(B)]) if B else torch.empty((0, n_new), dtype=torch.int64)
+        logits = torch.stack([torch.full((V,), float(clip0 + i)) for i in range(B)]) if B else torch.empty((0, V))
+        res = gather_results(ids, clip0, world, rank, logits)
+        if rank == 0:
+            out.append((res[0].tolist(), res[1].tolist(), res[2][:, 0].tolist()))
+        else:
+            assert res is None
+    if rank == 0:
+        q.put(out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_results_uneven_shards_world3_gloo():
+    """A clip count the world size does not divide (bench.py --strong, an eval set of any size): every clip arrives exactly once, in order,
+    the padding rows never reach the caller, and a rank without clips takes part in the collective."""
+    from crab_amd.parallel import block_of
+    assert [block_of(7, 3, r) for r in range(3)] == [(0, 3), (3, 2), (5, 2)] and [block_of(2, 3, r) for r in range(3)] == [(0, 1), (1, 1), (2, 0)]
+    assert sum(block_of(1000, 8, r)[1] for r in range(8)) == 1000
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_uneven, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for n_total, (cid, ids, lg0) in zip((7, 2), out):
+        assert cid == list(range(n_total))
+        assert ids == [[100 * c + j for j in range(4)] for c in range(n_total)]
+        assert lg0 == [float(c) for c in range(n_total)]
+
+
 def test_single_rank_passthrough():
     from crab_amd.parallel import gather_results
     ids = torch.arange(6).view(2, 3)
