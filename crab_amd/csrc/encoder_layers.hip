@@ -27,7 +27,7 @@ int dense(crab_ctx* ctx, void* stream, const crab_enc_io* io, const crab_dense* 
     d.A = a; d.lda = lda; d.B = w->W; d.ldb = w->ldw; d.C = c; d.ldc = ldc; d.bias = w->bias;
     d.R = residual; d.ldr = ldr; d.res_scale = res_scale; d.c_fp32 = c_fp32; d.r_fp32 = residual ? r_fp32 : 0;
     d.M = M; d.N = w->N; d.K = w->K; d.act = act; d.batch = 1; d.nb0 = 1;
-    if (M <= 256) { d.workspace = io->workspace; d.workspace_bytes = io->workspace_bytes; }     // the rule of crab_amd/ops.py: gemm()
+    if (M <= CRAB_DECODE_MAX_ROWS) { d.workspace = io->workspace; d.workspace_bytes = io->workspace_bytes; }     // the rule of crab_amd/ops.py: gemm()
     return crab_gemm_bf16(ctx, stream, &d);
 }
 

@@ -473,6 +473,35 @@ static void dec_choose(const crab_gemm_desc* d, int nks /* 64-wide K slots */, i
 }
 
 
+// The same choice for the two-row-group kernel (gemm_dec2_kernel, 256 < M <= 512), calibrated on scripts/bench_dec2_cfg.py (profiles/README.md
+// r04): a K slot costs 0.7 + 0.8 f us with 96-wide panels and 0.45 + 0.55 f us with 64-wide ones, f = the fraction of the 256 CUs streaming in
+// the round (the weight stream slows every CU down as more of them pull on HBM), ~12 us of prologue + epilogue per round; the reduction
+// ~4 us + one pass over the slabs at ~4 TB/s; a q|k|v projection without slices pays a separate RoPE / KV-append pass (~12 us), an o / down projection without
+// slices a separate norm + router pass (~25 us).  Picks q|k|v 96 x 2, o / down 64 x 4, gate|up 96 x 1, lm_head 64 x 1 at Llama-2-7B widths.
+static void dec2_choose(const crab_gemm_desc* d, int nks, int* bn_out, int* split_out) {
+    double best = 1e30;
+    for (int bi = 0; bi < 2; ++bi) {
+        const int bn = bi == 0 ? 96 : 64;
+        const long tiles = (d->N + bn - 1) / bn;
+        for (int sp = 1; sp <= 8 && sp * 4 <= nks; ++sp) {
+            const long blocks = tiles * sp;
+            const int per = (nks + sp - 1) / sp;
+            if ((long)(sp - 1) * per >= nks) continue;                   // an empty slice
+            const double slab = (double)sp * d->M * d->N * 4.0;
+            if (sp > 1 && slab > (double)d->workspace_bytes) continue;
+            double t = 0.0;
+            for (long left = blocks; left > 0; left -= 256) {
+                const double f = (double)(left < 256 ? left : 256) / 256.0;
+                t += 12.0 + per * (bn == 96 ? 0.7 + 0.8 * f : 0.45 + 0.55 * f);
+            }
+            if (sp > 1) t += 4.0 + slab / 4.0e6;
+            else t += d->rope_tab ? 12.0 : (d->norm_w ? 25.0 : 0.0);
+            if (t < best) { best = t; *bn_out = bn; *split_out = sp; }
+        }
+    }
+}
+
+
 // Split-K reduction of the packed q|k|v projection fused with RoPE and the KV-cache append (decode: one row per sequence).
 // One thread per (row, head, 4 dims of the first half): it also owns the matching 4 dims of the second half, i.e. the
 // rotation partners.  Sums are rounded to bf16 before the rotation, exactly like the unfused pair (reduction kernel ->
@@ -658,7 +687,14 @@ extern "C" int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc*
     //                      >= ~2 blocks/CU stream disjoint weight panels; partials reduced in a fixed order
     int splitk = 1, sk_bm = 0, sk_bn = 0, ring_split = 0;
     const int nk_all = (d->K + 63) / 64 + (d->A2 ? (d->K2 + 63) / 64 : 0);
-    if (d->batch <= 1 && d->M <= 256 && (d->M <= 128 || d->workspace != nullptr)) {
+    //   256 < M <= 512   : (r04) the same panel kernel over TWO 256-row groups in one launch (gemm_decode.hip: the two blocks of a weight
+    //                      panel run side by side on one XCD and share the panel through its L2) - a decode step of up to 512 clips streams
+    //                      the weights once.  Only with a workspace, automatic tuning and never for the prefill form of the fused RoPE.
+    static const int dec_on_ = []() { const char* e = getenv("CRAB_DEC_GEMM"); return !(e && e[0] == '0'); }();
+    const bool dec512 = d->M > 256 && d->M <= CRAB_DECODE_MAX_ROWS && d->batch <= 1 && d->workspace != nullptr && dec_on_ &&
+                        (d->tune == 0 || (d->tune >= 70000 && d->tune < 80000)) &&          // 7BBSS: a forced (panel width, K slices), benchmarking
+                        nk_all >= 8 && !(d->rope_tab && d->rope_S > 1) && (int64_t)d->M * d->N * 4 <= d->workspace_bytes;
+    if (d->batch <= 1 && (d->M <= 256 || dec512) && (d->M <= 128 || d->workspace != nullptr)) {
         bool want_split = d->M > 16 && d->workspace != nullptr && nk_all >= 8;
         if (d->tune >= 1 && d->tune <= 4) want_split = false;                      // forced skinny NT
         if (d->tune >= 100) want_split = d->workspace != nullptr;
@@ -713,7 +749,7 @@ extern "C" int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc*
         }
         if (d->tune >= 100) splitk = d->tune % 100;
         if (d->tune >= 400 && d->tune < 500 && sk_bm == 128) ring_split = 1;      // benchmarking: 256x256 ring kernel, S K-slices
-        if (d->tune < 100 && d->M >= 192 && d->N >= 10240) {
+        if (d->tune < 100 && d->M >= 192 && d->M <= 256 && d->N >= 10240) {
             // wide projections at M ~ 256 (q|k|v: 48 tiles x 5 slices, gate|up: 86 tiles x 2): the 256x256 ring kernel, one
             // block per CU in a single round, beats the 128x128 kernel by 7 / 11 us (profiles/README.md); the narrow ones
             // (o, down: 16 tiles) would need 16 slabs and do not gain
@@ -751,7 +787,8 @@ extern "C" int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc*
         } else if (d->tune == 91601) {                                  // A/B: 160-wide panels, one K slice
             dec_bn = 160; splitk = 1;
         } else if (d->tune == 0 && dec_on) {
-            dec_choose(d, nk32, &dec_bn, &splitk);
+            if (d->M > 256) dec2_choose(d, nk32, &dec_bn, &splitk);      // two row groups per block: its own calibration, 96- / 64-wide panels only
+            else dec_choose(d, nk32, &dec_bn, &splitk);
         }
         if (dec_bn) ring_split = 0;
     }

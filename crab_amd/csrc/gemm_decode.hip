@@ -44,9 +44,36 @@ struct GemmDP {
     long lda, ldb, ldc, ldr, lda2, ldb2;
     int M, N, K, K2, act, c_fp32;
     float res_scale;
-    int splitk;          // > 1: blockIdx.y = K slice, raw fp32 partial tiles to `part` [slice][M][N]
+    int splitk;          // > 1: blockIdx.y = K slice, raw fp32 partial tiles to `part` [slice][Mtot][N]
     float* part;
+    // ROW GROUPS (256 < M <= 512): groups == 2 runs the kernel once per 256-row group INSIDE one launch.  The 1-D block index is decoded so that
+    // the two blocks of a weight panel (group 0 / group 1) are 8 apart in dispatch order: the same XCD (workgroups go round-robin over the 8
+    // XCDs), resident at the same time on two of its CUs, streaming the SAME weight addresses in step - the second reader of a line finds it
+    // in that XCD's L2 (or merges with the miss in flight), so a panel costs one HBM pass for 512 rows.  Mtot = rows of the whole problem.
+    int groups, Mtot;
 };
+
+// block index -> (panel, row group) for GemmDP.groups == 2 (grid.x = 2 * round_up(panels, 8)); identity otherwise
+__device__ __forceinline__ void dec_block_coords(const GemmDP& p, int& panel, int& group) {
+    const int L = (int)blockIdx.x;
+    if (p.groups > 1) { group = (L >> 3) & 1; panel = ((L >> 4) << 3) | (L & 7); }
+    else { group = 0; panel = L; }
+}
+
+// the kernel's view of ONE row group: operands, outputs and the slab rows moved to the group's first row (wave-uniform scalar arithmetic)
+__device__ __forceinline__ GemmDP dec_group_view(const GemmDP& q, int group) {
+    GemmDP p = q;
+    const int m0 = group * 256;
+    p.M = min(256, q.Mtot - m0);
+    if (group) {
+        p.A = q.A + (long)m0 * q.lda;
+        if (q.A2) p.A2 = q.A2 + (long)m0 * q.lda2;
+        p.C = (q.c_fp32 & CF_C32) ? (void*)((float*)q.C + (long)m0 * q.ldc) : (void*)((bf16_t*)q.C + (long)m0 * q.ldc);
+        if (q.R) p.R = (q.c_fp32 & CF_R32) ? (const bf16_t*)((const float*)q.R + (long)m0 * q.ldr) : q.R + (long)m0 * q.ldr;
+        if (q.part) p.part = q.part + (long)m0 * q.N;
+    }
+    return p;
+}
 
 __device__ __attribute__((aligned(16))) uint32_t g_zero_page_dec[64];      // zero-initialised device memory (256 B)
 
@@ -56,7 +83,11 @@ typedef const __attribute__((address_space(1))) void* gbl_vptr;
 constexpr int DBK = 64;      // K extent of a ring slot: 128-byte rows, so every LDS-DMA piece (8 rows x 128 B) moves whole cache lines
 
 template <int BN, int NS, bool NTB>
-__global__ __launch_bounds__(512) void gemm_dec_kernel(GemmDP p) {
+__global__ __launch_bounds__(512) void gemm_dec_kernel(GemmDP pin) {
+    int panel_, group_;
+    dec_block_coords(pin, panel_, group_);
+    if (panel_ * BN >= pin.N) return;                          // padding block of the row-group grid (whole block, before any barrier)
+    const GemmDP p = dec_group_view(pin, group_);
     constexpr int BM = 256;
     constexpr int TM = 2, TN = BN / 16;
     constexpr int PA = BM / 8, PB = BN / 8;                  // 1-KiB pieces (8 rows x 128 B) per slot: activations, weights
@@ -71,7 +102,7 @@ __global__ __launch_bounds__(512) void gemm_dec_kernel(GemmDP p) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int sk = (int)blockIdx.y;
-    const int n0 = (int)blockIdx.x * BN;
+    const int n0 = panel_ * BN;
     const int nk1 = (p.K + DBK - 1) / DBK;
     const int nk2 = p.A2 ? (p.K2 + DBK - 1) / DBK : 0;
     const int nk_per = (nk1 + nk2 + p.splitk - 1) / p.splitk;
@@ -290,7 +321,7 @@ __global__ __launch_bounds__(512) void gemm_dec_kernel(GemmDP p) {
 
     const int m_wave = wave * 32;
     if (p.splitk > 1) {          // raw fp32 partial tile; reduced in a fixed slice order by the split-K epilogue kernels (gemm.hip)
-        float* part = p.part + (long)sk * p.M * p.N;
+        float* part = p.part + (long)sk * p.Mtot * p.N;
         const bool v4 = (p.N & 3) == 0;
 #pragma unroll
         for (int mi = 0; mi < TM; ++mi) {
@@ -328,7 +359,11 @@ __global__ __launch_bounds__(512) void gemm_dec_kernel(GemmDP p) {
 // registers" and (producers) "my pieces of slot t+1 have landed"; after it the producers refill the ring position of slot t with
 // slot t+NS and the consumers read slot t+1.
 template <int BN, int NS, bool NTB>
-__global__ __launch_bounds__(768) void gemm_dec_ws_kernel(GemmDP p) {
+__global__ __launch_bounds__(768) void gemm_dec_ws_kernel(GemmDP pin) {
+    int panel_, group_;
+    dec_block_coords(pin, panel_, group_);
+    if (panel_ * BN >= pin.N) return;                          // padding block of the row-group grid (whole block, before any barrier)
+    const GemmDP p = dec_group_view(pin, group_);
     constexpr int BM = 256;
     constexpr int TM = 2, TN = BN / 16;
     constexpr int PA = BM / 8, PB = BN / 8;                  // 1-KiB pieces (8 rows x 128 B) per slot: activations, weights
@@ -343,7 +378,7 @@ __global__ __launch_bounds__(768) void gemm_dec_ws_kernel(GemmDP p) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int sk = (int)blockIdx.y;
-    const int n0 = (int)blockIdx.x * BN;
+    const int n0 = panel_ * BN;
     const int nk1 = (p.K + DBK - 1) / DBK;
     const int nk2 = p.A2 ? (p.K2 + DBK - 1) / DBK : 0;
     const int nk_per = (nk1 + nk2 + p.splitk - 1) / p.splitk;
@@ -499,7 +534,7 @@ __global__ __launch_bounds__(768) void gemm_dec_ws_kernel(GemmDP p) {
 
     const int m_wave = wave * 32;
     if (p.splitk > 1) {          // raw fp32 partial tile; reduced in a fixed slice order by the split-K epilogue kernels (gemm.hip)
-        float* part = p.part + (long)sk * p.M * p.N;
+        float* part = p.part + (long)sk * p.Mtot * p.N;
         const bool v4 = (p.N & 3) == 0;
 #pragma unroll
         for (int mi = 0; mi < TM; ++mi) {
@@ -520,6 +555,349 @@ __global__ __launch_bounds__(768) void gemm_dec_ws_kernel(GemmDP p) {
     gemm_epilogue<TM, TN>(acc, p.act, m_wave, n0, fr, fg, p.M, p.N, p.bias, p.R, p.ldr, p.res_scale, p.C, 0, p.ldc, p.c_fp32);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// TWO ROW GROUPS PER BLOCK (256 < M <= 512, r04): one block = one weight panel x BOTH 256-row groups, so a panel is staged ONCE per CU for
+// 512 rows.  Why a new kernel and not the pair-of-blocks launch above (GemmDP.groups, kept for A/B): with the two blocks of a panel side by
+// side on one XCD the second reader merges with the first reader's miss instead of hitting - every CU still waits one HBM latency per weight
+// piece, and a CU's throughput is its bytes in flight / latency (DESIGN.md 3 machine model), so halving the HBM traffic bought 6 %
+// (scripts/bench_dec_gemm_groups.py, profiles/README.md r04).  Here the weight bytes a CU takes in per MFMA are halved.
+//
+// LDS: an ACTIVATION ring of 3 entries of [256 rows][64 k] (32 KiB each) that the sub-slots u = 2 t + g (K slot t, row group g) walk in
+// order, and a WEIGHT ring of NW = 4 entries of [BN][64 k]: the weights of slot t stay put for both sub-slots and are prefetched NW slots
+// (6+ sub-slot times, several HBM latencies) ahead, the activations (L2 resident, ~0.5 us) 3 sub-slots ahead.  144 KiB at BN = 96.
+// 8 waves as 8(M) x 1(N): wave w owns rows [32 w, 32 w + 32) of EACH group - 2 x (2 x TN) accumulator tiles - and stages 4 activation
+// pieces per sub-slot plus 1-2 weight pieces per slot; the inner schedule of a sub-slot is gemm_dec_kernel's slot schedule (fragments read
+// one MFMA group ahead, ONE barrier per sub-slot, the LDS-DMA issue interleaved with the MFMAs of k step 1), with the weight fragments of
+// k step 0 / 1 kept in registers across the two groups.
+//
+// Order of this wave's LDS-DMA instructions (vmcnt retires them in order):  G(v) = what is issued after barrier(v) = [weights of slot
+// t + NW, only when g(v) == 1] then [activations of sub-slot v + 3].  barrier(u) needs sub-slot u + 1 - issued in G(u - 2) - so the wait
+// before it keeps |G(u - 1)| instructions in flight: 4 + nb before an even barrier, 4 before an odd one; the weights it may need (slot
+// t + 1 at an odd barrier) were issued 2 NW - 2 groups earlier.
+//   RAW: sub-slot u + 1 (and slot t + 1's weights) are read after barrier(u), which every wave reaches after waiting for its own pieces.
+//   WAR: after barrier(u) every fragment of sub-slot u is in registers (lgkmcnt(0) before it): its activation entry is refilled; after an
+//   odd barrier both groups are done with slot t's weights: that entry is refilled.
+template <int BN, bool NTB>
+__global__ __launch_bounds__(512) void gemm_dec2_kernel(GemmDP p) {
+    constexpr int BM = 256, NA = 3, NW = 4;
+    constexpr int TM = 2, TN = BN / 16;
+    constexpr int PB = BN / 8;                               // 1-KiB weight pieces (8 rows x 128 B) per slot
+    constexpr int PAW = 4;                                   // activation pieces per wave per sub-slot (32 pieces / 8 waves)
+    constexpr int PBW = (PB + 7) / 8;                        // weight pieces per wave per slot: waves < PB - 8 (PBW - 1) take PBW
+    constexpr int A_ELEMS = BM * DBK, W_ELEMS = BN * DBK;
+    constexpr int W_BASE = NA * A_ELEMS;
+    static_assert(BN % 16 == 0 && PBW <= 2 && (NA * A_ELEMS + NW * W_ELEMS) * 2 <= 160 * 1024, "tile / ring geometry");
+    __shared__ __attribute__((aligned(16))) bf16_t lds[NA * A_ELEMS + NW * W_ELEMS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int sk = (int)blockIdx.y;
+    const int n0 = (int)blockIdx.x * BN;
+    const int M1 = p.Mtot - BM;                                       // rows of group 1 (1 .. 256)
+    const int nk1 = (p.K + DBK - 1) / DBK;
+    const int nk2 = p.A2 ? (p.K2 + DBK - 1) / DBK : 0;
+    const int nk_per = (nk1 + nk2 + p.splitk - 1) / p.splitk;
+    const int t_first = sk * nk_per;
+    const int nk = min(nk1 + nk2, t_first + nk_per) - t_first;       // >= 1 by construction of splitk (host)
+    const int nu = 2 * nk;                                            // sub-slots
+
+    // ---- staging coordinates: activation piece i: rows (wave * 4 + i) * 8 .. of a group; weight piece j: rows (wave + 8 j) * 8 ..
+    const int nb = (wave < PB - 8 * (PBW - 1)) ? PBW : PBW - 1;      // weight pieces of this wave (wave-uniform, 0 .. 2)
+    const int prow = lane >> 3, pc = lane & 7;
+    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page_dec);
+    int aoff1[PAW], aoff2[PAW], akc[PAW], aldso[PAW];
+    bool arok[2][PAW];
+#pragma unroll
+    for (int i = 0; i < PAW; ++i) {
+        const int pr0 = (wave * PAW + i) * 8, row = pr0 + prow;
+        const int c = pc ^ ((row >> 1) & 7);                         // inverse swizzle on the source chunk
+        akc[i] = c * 8;
+        arok[0][i] = true; arok[1][i] = row < M1;                     // group 0 has all 256 rows (M > 256)
+        aoff1[i] = row * (int)p.lda + c * 8;
+        aoff2[i] = row * (int)p.lda2 + c * 8;
+        aldso[i] = __builtin_amdgcn_readfirstlane(pr0 * DBK);
+    }
+    int boff1[PBW], boff2[PBW], bkc[PBW], bldso[PBW];
+    bool brok[PBW];
+#pragma unroll
+    for (int j = 0; j < PBW; ++j) {
+        const int pr0 = (wave + 8 * j) * 8, row = pr0 + prow;
+        const int c = pc ^ ((row >> 1) & 7);
+        bkc[j] = c * 8;
+        brok[j] = j < nb && n0 + row < p.N;
+        boff1[j] = row * (int)p.ldb + c * 8;
+        boff2[j] = row * (int)p.ldb2 + c * 8;
+        bldso[j] = __builtin_amdgcn_readfirstlane(pr0 * DBK);
+    }
+    const bf16_t* baseA1[2] = {p.A, p.A + (long)BM * p.lda};
+    const bf16_t* baseA2[2] = {p.A2 ? p.A2 : zero, p.A2 ? p.A2 + (long)BM * p.lda2 : zero};
+    const bf16_t* baseB1 = p.B + (long)n0 * p.ldb;
+    const bf16_t* baseB2 = p.A2 ? p.B2 + (long)n0 * p.ldb2 : zero;
+
+#define DMA_A(SRC_, DST_) __builtin_amdgcn_global_load_lds((gbl_vptr)(SRC_), (lds_vptr)(DST_), 16, 0, 0)
+#define DMA_B(SRC_, DST_)                                                                                 \
+    {                                                                                                     \
+        if constexpr (NTB) __builtin_amdgcn_global_load_lds((gbl_vptr)(SRC_), (lds_vptr)(DST_), 16, 0, 2);  \
+        else __builtin_amdgcn_global_load_lds((gbl_vptr)(SRC_), (lds_vptr)(DST_), 16, 0, 0);               \
+    }
+    // generic staging (K tails, second K segment, rows outside the operands): activations of (local slot TL_, group G_) into entry EA_
+#define RSTAGE_A(TL_, G_, EA_)                                                                            \
+    {                                                                                                     \
+        const int t_ = t_first + (TL_);                                                                   \
+        const bool s2_ = t_ >= nk1;                                                                       \
+        const int k0_ = (s2_ ? t_ - nk1 : t_) * DBK;                                                      \
+        const int Ks_ = s2_ ? p.K2 : p.K;                                                                 \
+        _Pragma("unroll") for (int i = 0; i < PAW; ++i) {                                                 \
+            const bool ok_ = arok[G_][i] && (k0_ + akc[i] < Ks_);                                         \
+            const bf16_t* src_ = (s2_ ? baseA2[G_] + aoff2[i] : baseA1[G_] + aoff1[i]) + k0_;             \
+            src_ = ok_ ? src_ : zero;                                                                     \
+            DMA_A(src_, &lds[(EA_) * A_ELEMS + aldso[i]]);                                                \
+        }                                                                                                 \
+    }
+#define RSTAGE_B(TL_, EW_)                                                                                \
+    {                                                                                                     \
+        const int t_ = t_first + (TL_);                                                                   \
+        const bool s2_ = t_ >= nk1;                                                                       \
+        const int k0_ = (s2_ ? t_ - nk1 : t_) * DBK;                                                      \
+        const int Ks_ = s2_ ? p.K2 : p.K;                                                                 \
+        _Pragma("unroll") for (int j = 0; j < PBW; ++j) {                                                 \
+            if (j < nb) {                                                                                 \
+                const bool ok_ = brok[j] && (k0_ + bkc[j] < Ks_);                                         \
+                const bf16_t* src_ = (s2_ ? baseB2 + boff2[j] : baseB1 + boff1[j]) + k0_;                 \
+                src_ = ok_ ? src_ : zero;                                                                 \
+                DMA_B(src_, &lds[W_BASE + (EW_) * W_ELEMS + bldso[j]]);                                   \
+            }                                                                                             \
+        }                                                                                                 \
+    }
+    // fast staging for the K slots wholly inside the first K segment: carried source pointers, one 64-bit add per piece; every (slot, group)
+    // and every slot must be staged in order through these
+    const int nfast = max(0, min(nk, p.K / DBK - t_first));
+    const bf16_t* fa[2][PAW];
+    int fadv_a[2][PAW];
+    const bf16_t* fb[PBW];
+    int fadv_b[PBW];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int i = 0; i < PAW; ++i) {
+            fa[g][i] = arok[g][i] ? baseA1[g] + (long)t_first * DBK + aoff1[i] : zero;
+            fadv_a[g][i] = arok[g][i] ? DBK : 0;
+        }
+#pragma unroll
+    for (int j = 0; j < PBW; ++j) {
+        fb[j] = brok[j] ? baseB1 + (long)t_first * DBK + boff1[j] : zero;
+        fadv_b[j] = brok[j] ? DBK : 0;
+    }
+#define FSTAGE_A(G_, EA_)                                                                                 \
+    {                                                                                                     \
+        _Pragma("unroll") for (int i = 0; i < PAW; ++i) {                                                 \
+            DMA_A(fa[G_][i], &lds[(EA_) * A_ELEMS + aldso[i]]);                                           \
+            fa[G_][i] += fadv_a[G_][i];                                                                   \
+        }                                                                                                 \
+    }
+#define FSTAGE_B(EW_)                                                                                     \
+    {                                                                                                     \
+        _Pragma("unroll") for (int j = 0; j < PBW; ++j) {                                                 \
+            if (j < nb) {                                                                                 \
+                DMA_B(fb[j], &lds[W_BASE + (EW_) * W_ELEMS + bldso[j]]);                                  \
+                fb[j] += fadv_b[j];                                                                       \
+            }                                                                                             \
+        }                                                                                                 \
+    }
+#define XSTAGE_A(TL_, G_, EA_) { if ((TL_) < nfast) FSTAGE_A(G_, EA_) else RSTAGE_A(TL_, G_, EA_) }
+#define XSTAGE_B(TL_, EW_) { if ((TL_) < nfast) FSTAGE_B(EW_) else RSTAGE_B(TL_, EW_) }
+    // counted wait (+ every LDS read drained): leave the youngest KEEP_ LDS-DMA instructions of THIS wave in flight
+#define WAITK(KEEP_) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(KEEP_) : "memory");
+#define WAIT_EVEN() { if (nb == 2) WAITK(PAW + 2) else if (nb == 1) WAITK(PAW + 1) else WAITK(PAW) }
+#define WAIT_RT(K_)                                                                                       \
+    {                                                                                                     \
+        switch (K_) {                                                                                     \
+            case 0: WAITK(0) break;                                                                       \
+            case 1: WAITK(1) break;                                                                       \
+            case 2: WAITK(2) break;                                                                       \
+            case 4: WAITK(4) break;                                                                       \
+            case 5: WAITK(5) break;                                                                       \
+            default: WAITK(6) break;                                                                      \
+        }                                                                                                 \
+    }
+
+    f32x4_t acc0[TN][TM], acc1[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) { acc0[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc1[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+
+    // ---- prologue, in the steady-state order ... A(1), W(NW-1), A(2):  W(0 .. NW-2), A(0), A(1), W(NW-1), A(2); then sub-slot 0 retired
+#pragma unroll
+    for (int t = 0; t < NW - 1; ++t)
+        if (t < nk) XSTAGE_B(t, t)
+    XSTAGE_A(0, 0, 0)
+    XSTAGE_A(0, 1, 1)
+    if (NW - 1 < nk) XSTAGE_B(NW - 1, NW - 1)
+    if (1 < nk) XSTAGE_A(1, 0, 2)
+    {
+        const int keep = PAW + ((NW - 1 < nk) ? nb : 0) + ((1 < nk) ? PAW : 0);      // A(1) + W(NW-1) + A(2) may still fly
+        if (keep == 2 * PAW + 2) WAITK(2 * PAW + 2) else if (keep == 2 * PAW + 1) WAITK(2 * PAW + 1) else if (keep == 2 * PAW) WAITK(2 * PAW)
+        else WAITK(0)
+    }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+
+    const int fr = lane & 15, fg = lane >> 4;
+    int wofs[TN], xofs[TM];
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) {
+        const int row = ni * 16 + fr;
+        wofs[ni] = W_BASE + row * DBK + ((fg ^ ((row >> 1) & 7)) << 3);
+    }
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+        const int row = wave * 32 + mi * 16 + fr;
+        xofs[mi] = row * DBK + ((fg ^ ((row >> 1) & 7)) << 3);
+    }
+#define READ_W(W_, EW_, KS_) { _Pragma("unroll") for (int ni = 0; ni < TN; ++ni) W_[ni] = *reinterpret_cast<const bf16x8_t*>(&lds[((EW_) * W_ELEMS + wofs[ni]) ^ ((KS_) * 32)]); }
+#define READ_X(X_, EA_, KS_) { _Pragma("unroll") for (int mi = 0; mi < TM; ++mi) X_[mi] = *reinterpret_cast<const bf16x8_t*>(&lds[((EA_) * A_ELEMS + xofs[mi]) ^ ((KS_) * 32)]); }
+#define MFMA_GROUP(ACC_, W_, X_, NI0_, NI1_)                                                              \
+    {                                                                                                     \
+        _Pragma("unroll") for (int ni = (NI0_); ni < (NI1_); ++ni)                                        \
+            _Pragma("unroll") for (int mi = 0; mi < TM; ++mi)                                             \
+                ACC_[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W_[ni], X_[mi], ACC_[ni][mi], 0, 0, 0);   \
+    }
+#define SB __builtin_amdgcn_sched_barrier(0);
+
+    bf16x8_t w0[TN], w1[TN], x0[TM], x1[TM];
+    READ_W(w0, 0, 0)
+    READ_X(x0, 0, 0)                                            // k step 0 of sub-slot 0
+    int ea = 0, ew = 0;                                         // activation entry of sub-slot 2 t, weight entry of slot t
+    int t = 0;
+    // ---- steady state: every refill of the iteration lies wholly inside the first K segment (carried pointers, no conditions)
+    const int n_steady = max(0, nfast - NW);
+    for (; t < n_steady; ++t) {
+        const int ea1 = ea + 1 == NA ? 0 : ea + 1, ea2 = ea1 + 1 == NA ? 0 : ea1 + 1;
+        // ===== sub-slot 2 t (group 0)
+        MFMA_GROUP(acc0, w0, x0, 0, TN / 3) SB
+        READ_W(w1, ew, 1)
+        READ_X(x1, ea, 1) SB
+        MFMA_GROUP(acc0, w0, x0, TN / 3, TN) SB
+        WAIT_EVEN()
+        __builtin_amdgcn_s_barrier(); SB
+        READ_X(x0, ea1, 0) SB                                   // k step 0 of sub-slot 2 t + 1 (w0 stays: same slot)
+        // G(2 t): activations of sub-slot 2 t + 3 = (slot t + 1, group 1) into the entry sub-slot 2 t leaves, interleaved with the MFMAs
+#define PIECE_A(G_, I_, EA_) { DMA_A(fa[G_][I_], &lds[(EA_) * A_ELEMS + aldso[I_]]); fa[G_][I_] += fadv_a[G_][I_]; }
+#define PIECE_B(J_, EW_) { if ((J_) < nb) { DMA_B(fb[J_], &lds[W_BASE + (EW_) * W_ELEMS + bldso[J_]]); fb[J_] += fadv_b[J_]; } }
+#define STEP(ACC_, NI_) MFMA_GROUP(ACC_, w1, x1, NI_, (NI_) + 1)
+        static_assert(TN == 6 || TN == 4, "piece schedule below is written for BN 96 / 64");
+        if constexpr (TN == 6) {
+            STEP(acc0, 0) PIECE_A(1, 0, ea) SB STEP(acc0, 1) PIECE_A(1, 1, ea) SB STEP(acc0, 2) PIECE_A(1, 2, ea) SB STEP(acc0, 3) PIECE_A(1, 3, ea) SB
+            STEP(acc0, 4) SB STEP(acc0, 5) SB
+        } else {
+            STEP(acc0, 0) PIECE_A(1, 0, ea) SB STEP(acc0, 1) PIECE_A(1, 1, ea) SB STEP(acc0, 2) PIECE_A(1, 2, ea) SB STEP(acc0, 3) PIECE_A(1, 3, ea) SB
+        }
+        // ===== sub-slot 2 t + 1 (group 1)
+        MFMA_GROUP(acc1, w0, x0, 0, TN / 3) SB
+        READ_X(x1, ea1, 1) SB                                   // (w1 stays)
+        MFMA_GROUP(acc1, w0, x0, TN / 3, TN) SB
+        WAITK(PAW)
+        __builtin_amdgcn_s_barrier(); SB
+        const int ew1 = ew + 1 == NW ? 0 : ew + 1;
+        READ_W(w0, ew1, 0)
+        READ_X(x0, ea2, 0) SB                                   // k step 0 of sub-slot 2 t + 2
+        // G(2 t + 1): weights of slot t + NW into the entry slot t leaves, THEN activations of sub-slot 2 t + 4 = (slot t + 2, group 0)
+        if constexpr (TN == 6) {
+            STEP(acc1, 0) PIECE_B(0, ew) SB STEP(acc1, 1) PIECE_B(1, ew) SB STEP(acc1, 2) PIECE_A(0, 0, ea1) SB STEP(acc1, 3) PIECE_A(0, 1, ea1) SB
+            STEP(acc1, 4) PIECE_A(0, 2, ea1) SB STEP(acc1, 5) PIECE_A(0, 3, ea1) SB
+        } else {
+            STEP(acc1, 0) PIECE_B(0, ew) SB STEP(acc1, 1) PIECE_A(0, 0, ea1) PIECE_A(0, 1, ea1) SB STEP(acc1, 2) PIECE_A(0, 2, ea1) SB STEP(acc1, 3) PIECE_A(0, 3, ea1) SB
+        }
+        ea = ea2; ew = ew1;
+    }
+    // ---- tail: K tail / second K segment slots (generic staging, run-time wait counts) and the drain
+    for (; t < nk; ++t) {
+        const int ea1 = ea + 1 == NA ? 0 : ea + 1, ea2 = ea1 + 1 == NA ? 0 : ea1 + 1;
+        const int u = 2 * t;
+        // ===== sub-slot u (group 0).  G(u - 1) = [W(t - 1 + NW)] + [A(u + 2)]
+        MFMA_GROUP(acc0, w0, x0, 0, TN / 3) SB
+        READ_W(w1, ew, 1)
+        READ_X(x1, ea, 1) SB
+        MFMA_GROUP(acc0, w0, x0, TN / 3, TN) SB
+        {
+            const int keep = ((t >= 1 && t - 1 + NW < nk) ? nb : 0) + ((u + 2 < nu && u >= 1) ? PAW : 0);
+            WAIT_RT(keep)
+        }
+        __builtin_amdgcn_s_barrier(); SB
+        READ_X(x0, ea1, 0) SB
+        if (u + 3 < nu) XSTAGE_A(t + 1, 1, ea)                  // G(u): A(u + 3) = (slot t + 1, group 1)
+        MFMA_GROUP(acc0, w1, x1, 0, TN) SB
+        // ===== sub-slot u + 1 (group 1).  G(u) = [A(u + 3)]
+        MFMA_GROUP(acc1, w0, x0, 0, TN / 3) SB
+        READ_X(x1, ea1, 1) SB
+        MFMA_GROUP(acc1, w0, x0, TN / 3, TN) SB
+        {
+            const int keep = (u + 3 < nu) ? PAW : 0;
+            WAIT_RT(keep)
+        }
+        __builtin_amdgcn_s_barrier(); SB
+        const int ew1 = ew + 1 == NW ? 0 : ew + 1;
+        if (t + 1 < nk) {
+            READ_W(w0, ew1, 0)
+            READ_X(x0, ea2, 0)
+        }
+        SB
+        if (t + NW < nk) XSTAGE_B(t + NW, ew)                   // G(u + 1): W(t + NW), then A(u + 4) = (slot t + 2, group 0)
+        if (u + 4 < nu) XSTAGE_A(t + 2, 0, ea1)
+        MFMA_GROUP(acc1, w1, x1, 0, TN) SB
+        ea = ea2; ew = ew1;
+    }
+#undef PIECE_A
+#undef PIECE_B
+#undef STEP
+#undef SB
+#undef READ_W
+#undef READ_X
+#undef MFMA_GROUP
+#undef WAITK
+#undef WAIT_EVEN
+#undef WAIT_RT
+#undef XSTAGE_A
+#undef XSTAGE_B
+#undef FSTAGE_A
+#undef FSTAGE_B
+#undef RSTAGE_A
+#undef RSTAGE_B
+#undef DMA_A
+#undef DMA_B
+
+    // ---- epilogue, one row group at a time (the group's view of the operands: dec_group_view)
+    const int m_wave = wave * 32;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const GemmDP q = dec_group_view(p, g);
+        const f32x4_t (&acc)[TN][TM] = g ? acc1 : acc0;
+        if (p.splitk > 1) {      // raw fp32 partial tile; reduced in a fixed slice order by the split-K epilogue kernels (gemm.hip)
+            float* part = q.part + (long)sk * p.Mtot * p.N;
+            const bool v4 = (p.N & 3) == 0;
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi) {
+                const int m = m_wave + mi * 16 + fr;
+                if (m >= q.M) continue;
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni) {
+                    const int n = n0 + ni * 16 + fg * 4;
+                    if (n >= p.N) continue;
+                    float* o = part + (long)m * p.N + n;
+                    if (v4) *reinterpret_cast<f32x4_t*>(o) = acc[ni][mi];
+                    else
+                        for (int r = 0; r < 4 && n + r < p.N; ++r) o[r] = acc[ni][mi][r];
+                }
+            }
+        } else {
+            gemm_epilogue<TM, TN>(acc, q.act, m_wave, n0, fr, fg, q.M, q.N, q.bias, q.R, q.ldr, q.res_scale, q.C, 0, q.ldc, q.c_fp32);
+        }
+    }
+}
+
 }  // namespace
 
 // Decode-regime launch (called from crab_gemm_bf16, gemm.hip).  bn in {64, 96}; splitk >= 1 (K slices over blockIdx.y, none empty).
@@ -530,8 +908,34 @@ int crab_gemm_dec_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* d, 
     p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc; p.ldr = d->ldr; p.lda2 = d->lda2; p.ldb2 = d->ldb2;
     p.M = d->M; p.N = d->N; p.K = d->K; p.K2 = d->A2 ? d->K2 : 0; p.act = d->act; p.c_fp32 = crab_cflags(d); p.res_scale = d->res_scale;
     p.splitk = splitk > 1 ? splitk : 1; p.part = part;
+    p.Mtot = d->M; p.groups = d->M > 256 ? 2 : 1;
+    if (d->M > 512) return crab_fail(ctx, CRAB_E_INVALID, "gemm_dec: at most 512 rows (two row groups)");
     const int tiles = (d->N + bn - 1) / bn;
-    dim3 grid(tiles, p.splitk);
+    // two row groups: grid.x = 2 x panels rounded up to 8, see GemmDP.groups; the weights then use the DEFAULT cache policy (the
+    // non-temporal hint would keep the first reader's lines out of the L2 the second reader is meant to hit)
+    dim3 grid(p.groups > 1 ? 2 * ((tiles + 7) / 8 * 8) : tiles, p.splitk);
+    static const int pair_form = []() { const char* e = getenv("CRAB_DEC_GROUPS"); return (e && e[0] == 'p') ? 1 : 0; }();     // "pair": the A/B form
+    if (p.groups > 1 && !pair_form) {
+        // the shipped form for 256 < M <= 512: one block per panel (x K slice) holds BOTH row groups (gemm_dec2_kernel)
+        if (bn != 96 && bn != 64) return crab_fail(ctx, CRAB_E_UNSUPPORTED, "gemm_dec: the two-row-group kernel has 96- and 64-wide panels");
+        dim3 grid2(tiles, p.splitk);
+        p.groups = 1;                                       // (plain block index; dec_group_view is applied per group in the epilogue)
+        if (bn == 96) hipLaunchKernelGGL((gemm_dec2_kernel<96, true>), grid2, dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((gemm_dec2_kernel<64, true>), grid2, dim3(512), 0, s, p);
+        return crab_check_launch(ctx, "gemm_dec2_kernel");
+    }
+    if (p.groups > 1) {
+        static const int nt2 = []() { const char* e = getenv("CRAB_DEC_GROUPS_NT"); return (e && e[0] == '1') ? 1 : 0; }();
+        if (bn == 160) return crab_fail(ctx, CRAB_E_UNSUPPORTED, "gemm_dec: 160-wide panels have no row-group form");
+        if (nt2) {
+            if (bn == 96) hipLaunchKernelGGL((gemm_dec_ws_kernel<96, 3, true>), grid, dim3(768), 0, s, p);
+            else hipLaunchKernelGGL((gemm_dec_ws_kernel<64, 4, true>), grid, dim3(768), 0, s, p);
+        } else {
+            if (bn == 96) hipLaunchKernelGGL((gemm_dec_ws_kernel<96, 3, false>), grid, dim3(768), 0, s, p);
+            else hipLaunchKernelGGL((gemm_dec_ws_kernel<64, 4, false>), grid, dim3(768), 0, s, p);
+        }
+        return crab_check_launch(ctx, "gemm_dec_ws_kernel(row groups)");
+    }
     static const int ws_on = []() { const char* e = getenv("CRAB_DEC_WS"); return !(e && e[0] == '0'); }();
     // nt_weights: 1 = the shipped form (producer / consumer, non-temporal weight loads), 2 = the 8-wave kernel (tune 8xxxx), 0 = the
     // 8-wave kernel with default-policy weight loads

@@ -7,7 +7,7 @@
 //     u    = route(h) for q|k|v                     (skipped when the previous layer's epilogue produced it: io->u_qkv_ready)
 //     qkv  = [h | u] . [Wqkv | Bcat]^T (+ bias)      decode: RoPE + KV append ride on this GEMM;  prefill: crab_qkv_rope_split
 //     att  = flash attention (prefill, causal) | KV-streaming attention (decode, ctx read from pos_dev)
-//     x   += [att | u] . [Wo | Bcat]^T ; h = rmsnorm(x) * post_attention_layernorm   (+ the gate|up router ahead, M <= 256)
+//     x   += [att | u] . [Wo | Bcat]^T ; h = rmsnorm(x) * post_attention_layernorm   (+ the gate|up router ahead, M <= CRAB_DECODE_MAX_ROWS)
 //     act  = silu(gate(h)) * up(h)                   one GEMM over the interleaved gate|up rows, SwiGLU in its epilogue
 //     x   += [act | u] . [Wdown | Bcat]^T ; h = rmsnorm(x) * next_norm_w              (+ the next layer's q|k|v router ahead)
 // io->x_fp32: x is fp32 (the residual adds of modeling_llama.py:805-827 are never rounded to bf16); h and every GEMM operand stay bf16.
@@ -62,9 +62,9 @@ int run_group(crab_ctx* ctx, void* stream, const crab_linear_group* g, const cra
     d.act = c.act;
     d.res_scale = 1.0f;
     d.batch = 1; d.nb0 = 1;
-    if (M <= 256) { d.workspace = io->splitk_ws; d.workspace_bytes = io->splitk_ws_bytes; }
+    if (M <= CRAB_DECODE_MAX_ROWS) { d.workspace = io->splitk_ws; d.workspace_bytes = io->splitk_ws_bytes; }
     if (c.norm_w) { d.norm_w = c.norm_w; d.norm_out = c.norm_out; d.ld_norm = c.ld_norm; d.norm_eps = c.eps; }
-    if (c.route_next && c.route_next->RA && c.norm_w && M <= 256) {
+    if (c.route_next && c.route_next->RA && c.norm_w && M <= CRAB_DECODE_MAX_ROWS) {
         const crab_linear_group* n = c.route_next;
         d.route_RA = n->RA; d.route_ldra = n->ldra; d.route_U = c.route_u; d.route_ldu = io->ldu;
         d.route_nproj = n->nproj; d.route_nl = n->nl; d.route_r = n->r; d.route_ucols = n->ucols; d.route_scaling = n->scaling;
@@ -176,7 +176,7 @@ int run_layer(crab_ctx* ctx, void* stream, const crab_llama_layer* L, crab_llama
             return rc;
     }
     // ---- o: x += o(att); h = rmsnorm(x) * post_attention_layernorm (+ the gate|up router ahead in the decode regime)
-    const bool ahead_gu = L->gu.RA != nullptr && M <= 256;
+    const bool ahead_gu = L->gu.RA != nullptr && M <= CRAB_DECODE_MAX_ROWS;
     GroupCall o{};
     o.x = io->att; o.ldx = io->ldatt; o.out = io->x; o.ldc = io->ldx; o.residual = io->x; o.ldr = io->ldx; o.act = CRAB_ACT_NONE;
     o.norm_w = L->post_attention_norm_w; o.norm_out = io->h; o.ld_norm = io->ldh; o.eps = L->rms_eps;
@@ -188,7 +188,7 @@ int run_layer(crab_ctx* ctx, void* stream, const crab_llama_layer* L, crab_llama
     g.u_ready = ahead_gu ? io->u2 : nullptr;
     if ((rc = run_group(ctx, stream, &L->gu, io, L, M, g, nullptr, nullptr))) return rc;
     // ---- down: x += down(act); h = rmsnorm(x) * next_norm_w (+ the next layer's q|k|v router ahead)
-    const bool ahead_q = L->next_qkv != nullptr && L->next_qkv->RA != nullptr && M <= 256;
+    const bool ahead_q = L->next_qkv != nullptr && L->next_qkv->RA != nullptr && M <= CRAB_DECODE_MAX_ROWS;
     GroupCall w{};
     w.x = io->act; w.ldx = io->ldact; w.out = io->x; w.ldc = io->ldx; w.residual = io->x; w.ldr = io->ldx; w.act = CRAB_ACT_NONE;
     w.norm_w = L->next_norm_w; w.norm_out = io->h; w.ld_norm = io->ldh; w.eps = L->rms_eps;

@@ -693,9 +693,9 @@ extern "C" int crab_hyperlora_route(crab_ctx* ctx, void* stream, const void* X, 
         int rc = crab_gemm_bf16(ctx, stream, &g);
         return rc ? rc : crab_hyperlora_mix(ctx, stream, workspace, tcols, 1, U, ldu, M, nproj, nl, r, ucols, scaling);
     }
-    // decode regime (one row per clip, 64 < M <= 256): one row-owning launch (~6 us) instead of the partial-product + mix pair (~11 us)
+    // decode regime (one row per clip, 64 < M <= CRAB_DECODE_MAX_ROWS): one row-owning launch (~6 us) instead of the partial-product + mix pair (~11 us)
     // (at M <= 16 the row-owning launch has 1-16 blocks and loses to the pair: 6.09 vs 6.22 clips/s at batch 8, profiles/README.md)
-    if (M > 64 && M <= 256 && K <= 6 * 2048 && nl <= 8 && ((uintptr_t)X & 15) == 0 && ((uintptr_t)RA & 15) == 0) {
+    if (M > 64 && M <= CRAB_DECODE_MAX_ROWS && K <= 6 * 2048 && nl <= 8 && ((uintptr_t)X & 15) == 0 && ((uintptr_t)RA & 15) == 0) {
         hipStream_t s0 = (hipStream_t)stream;
 #define RR_LAUNCH(Q_) hipLaunchKernelGGL((lora_route_row_kernel<Q_>), dim3(M), dim3(256), 0, s0, (const bf16_t*)X, (long)ldx, (const bf16_t*)RA, (long)ldra, K, \
                                          (bf16_t*)U, (long)ldu, nproj, nl, r, ucols, scaling)

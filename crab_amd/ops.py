@@ -111,6 +111,8 @@ def _variant(M: int, N: int, batch: int = 1, K: int = 4096) -> str:
 RESIDUAL_FP32 = os.environ.get("CRAB_RESIDUAL_FP32", "1") != "0"
 RES_DTYPE = torch.float32 if RESIDUAL_FP32 else torch.bfloat16
 
+DECODE_MAX_ROWS = 512      # CRAB_DECODE_MAX_ROWS (include/crab_hip.h): up to this many rows a GEMM with a workspace streams the weights once
+
 ROWFIN = os.environ.get("CRAB_ROWFIN", "1") != "0"     # the M <= 16 layer tail of csrc/rowfin.hip (same switch, same parse as the library: off iff the value is exactly "0")
 
 
@@ -142,7 +144,7 @@ def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     = crab_gemm_fuses_prefill_rope: 1 or 2) q is rotated in place and k rotated into the cache by the projection's epilogue; at 1 the caller
     finishes with qkv_rope_split(rope_tab=None, k_cache=None) for the v columns, at 2 (vt given) the epilogue did those too; at 0 the caller
     runs the full qkv_rope_split as before.
-    route = (RA, nproj, nl, r, ucols, scaling, u_out) (with post_norm, M <= 256): u_out = hyperlora_route(post-norm rows, RA)
+    route = (RA, nproj, nl, r, ucols, scaling, u_out) (with post_norm, M <= DECODE_MAX_ROWS): u_out = hyperlora_route(post-norm rows, RA)
     for the NEXT projection group, computed inside the row-owning reduction kernel when that path is taken.
     lora_self = (RA, nl, r, scaling, lora_B) (with post_norm, M <= 16, no x2): the hyper-LoRA update of THIS single-projection group is
     evaluated inside the call - its router rows ride on the projection's launch, the update is applied by the M <= 16 layer tail.
@@ -175,7 +177,7 @@ def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     if post_norm is not None:                      # (weight, eps, out): out = rmsnorm(result) * weight, fused when possible
         g.norm_w, g.norm_eps, g.norm_out, g.ld_norm = post_norm[0].data_ptr(), post_norm[1], post_norm[2].data_ptr(), post_norm[2].stride(0)
     if route is not None:
-        assert post_norm is not None and M <= 256
+        assert post_norm is not None and M <= DECODE_MAX_ROWS
         rRA, rnp, rnl, rr, ruc, rsc, ru = route
         g.route_RA, g.route_U, g.route_ldra, g.route_ldu = rRA.data_ptr(), ru.data_ptr(), rRA.stride(0), ru.stride(0)
         g.route_nproj, g.route_nl, g.route_r, g.route_ucols, g.route_scaling = rnp, rnl, rr, ruc, rsc
@@ -200,7 +202,7 @@ def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
                 g.rope_vt, g.rope_vt_ld = rope[11].data_ptr(), rope[11].stride(-2)
             if info is not None:                                   # 0: not fused; 1: q / k; 2: q / k / v (no split pass left)
                 info["fused_prefill_rope"] = int(_lib.load().crab_gemm_fuses_prefill_rope(C.byref(g)))
-    if M <= 256:
+    if M <= DECODE_MAX_ROWS:
         ws = _splitk_workspace(x.device)
         g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel()
     prof = PROFILER

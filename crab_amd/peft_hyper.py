@@ -172,7 +172,7 @@ class PackedLinearGroup:
         # route_next = (group, u_out): this GEMM's fused post-norm also evaluates the router of the NEXT group on the
         # normalised rows; that group is then called with u_ready=u_out and skips its own router launches
         route = None
-        if route_next is not None and route_next[0].RA is not None and post_norm is not None and M <= 256:
+        if route_next is not None and route_next[0].RA is not None and post_norm is not None and M <= ops.DECODE_MAX_ROWS:
             ng, nu = route_next
             route = (ng.RA, len(ng.names), ng.nl, ng.r, ng.u_cols, ng.scaling, nu[:M, :ng.u_cols])
         if self.RA is None:
@@ -195,7 +195,7 @@ class PackedLinearGroup:
 
     def routes_ahead(self, M: int) -> bool:
         """True when a producer GEMM may evaluate this group's router in its fused post-norm epilogue (decode regime)."""
-        return self.RA is not None and M <= 256
+        return self.RA is not None and M <= ops.DECODE_MAX_ROWS
 
 
 class PeftModelForCausalLM(nn.Module):

@@ -113,6 +113,10 @@ typedef struct {
     int32_t r_fp32;
 } crab_gemm_desc;
 
+/* Rows up to which crab_gemm_bf16 treats a problem as WEIGHT-STREAMING (the decode regime: one row per clip) when a workspace is given:
+ * the weights are read once per call whatever M; crab_llama_layers / crab_amd/decoder.py fuse the routers and norms into the reductions up
+ * to the same bound.  256 until r03; 512 since r04 (two 256-row groups per launch sharing each weight panel through an XCD's L2). */
+#define CRAB_DECODE_MAX_ROWS 512
 int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc* d);
 int crab_gemm_fuses_prefill_rope(const crab_gemm_desc* d);   /* 0: no; 1: this call rotates q / k and appends k in its epilogue (see rope_S); 2: and handles the v columns (rope_vt) */
 /* bytes of crab_gemm_desc.workspace the M <= 16 layer tail needs (fp32 sums + router product + per-slice partials) */
@@ -301,14 +305,14 @@ int crab_sample_select(crab_ctx* ctx, void* stream, const float* logits, int64_t
  *     RA == NULL: plain linear.
  * crab_llama_layer: the four groups of a layer, the RMSNorm weight behind the attention block, and - because the norm that
  *     FOLLOWS a layer is fused into its down-projection epilogue - the NEXT norm's weight (next layer's input_layernorm, or
- *     model.norm after the last layer) and the next layer's q|k|v group (its router is evaluated ahead when M <= 256).
+ *     model.norm after the last layer) and the next layer's q|k|v group (its router is evaluated ahead when M <= CRAB_DECODE_MAX_ROWS).
  * crab_llama_io: caller-owned activations for M = B*S rows.  In: x = residual stream, h = rmsnorm(x) * this layer's
  *     input_layernorm.  Out: x updated, h = rmsnorm(x) * next_norm_w.  qkv / att / act / u / u2 are scratch.
  *     k_cache / v_cache: rows of these B sequences in layer 0's cache [B, Hk, Tmax, d]; layer l lives cache_layer_stride
  *     ELEMENTS further.  Prefill (S rows per sequence at positions pos0 .. pos0+S-1): vt [B, Hk, d, vt_ld] receives V^T for
  *     the flash kernel.  Decode (S == 1): position = pos0 + pos_dev[0] (pos_dev may be NULL), RoPE + KV append are fused
  *     behind the q|k|v GEMM.  u_qkv_ready (in/out): u2 holds the q|k|v router output of the layer about to run.
- *     route_ws: crab_hyperlora_route_workspace(M, max K, max tcols) bytes; splitk_ws: the crab_gemm_desc.workspace (M <= 256). */
+ *     route_ws: crab_hyperlora_route_workspace(M, max K, max tcols) bytes; splitk_ws: the crab_gemm_desc.workspace (M <= CRAB_DECODE_MAX_ROWS). */
 typedef struct {
     const void* W; const void* bias; const void* RA; const void* B2;
     int64_t ldw, ldra, ldb2;
@@ -366,7 +370,7 @@ int crab_llama_layers(crab_ctx* ctx, void* stream, const crab_llama_layer* layer
  * crab_dense = one nn.Linear (W [N, K] row stride ldw, bias [N] or NULL); crab_ln = LayerNorm weight / bias / eps.
  * crab_enc_io: caller-owned rows for M = B * S tokens.  x [M, width] in / out (dense rows); a [M, width], y [M, width] scratch;
  *   qkv [max(M, B * enc_rows), 3 * width (2 * width for the Q-Former)]; att [M, width]; f [M, ffn width];
- *   vt: V^T scratch of vt_bytes >= B * H * d * round8(keys) * 2; workspace: the crab_gemm_desc.workspace handed to every GEMM with <= 256 rows. */
+ *   vt: V^T scratch of vt_bytes >= B * H * d * round8(keys) * 2; workspace: the crab_gemm_desc.workspace handed to every GEMM with <= CRAB_DECODE_MAX_ROWS rows. */
 typedef struct { const void* W; const void* bias; int64_t ldw; int32_t N, K; } crab_dense;
 typedef struct { const void* w; const void* b; float eps; } crab_ln;
 typedef struct { crab_ln ln1, ln2; crab_dense qkv, out, fc1, fc2; int32_t H; } crab_clip_layer_w;

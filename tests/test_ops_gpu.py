@@ -507,6 +507,27 @@ def test_gemm_splitk_decode_regime(M, tune):
     _cmp(yb, z, TOL_BF16, "bf16 out")
 
 
+@pytest.mark.parametrize("M", [257, 300, 384, 511, 512])
+def test_gemm_decode_panel_kernel_two_row_groups(M):
+    """256 < M <= 512 (r04): the panel kernel over two 256-row groups in ONE launch (the two blocks of a weight panel side by side on one
+    XCD).  Ragged N / K, second K segment, every epilogue input, fp32 and bf16 outputs, against fp32 arithmetic; and - the row groups run
+    the very same block program - rows [0, 256) and [256, M) bit-identical to separate calls on those rows alone."""
+    from crab_amd import ops
+    N, K, K2 = 1000 + 9, 1096, 32
+    x, w, b, r = _rand(M, K, seed=3), _rand(N, K, seed=4, scale=K ** -0.5), _rand(N, seed=5), _rand(M, N, seed=6)
+    x2, w2 = _rand(M, K2, seed=7), _rand(N, K2, seed=8, scale=0.1)
+    xd, wd, bd, rd, x2d, w2d = x.cuda(), w.cuda(), b.cuda(), r.cuda(), x2.cuda(), w2.cuda()
+    y = ops.gemm(xd, wd, out_fp32=True, bias=bd, act="gelu", residual=rd, x2=x2d, w2=w2d)
+    z = F.gelu(x.float() @ w.float().t() + x2.float() @ w2.float().t() + b.float()) + r.float()
+    _cmp(y, z, TOL_F32, f"decode panel kernel, two row groups, M={M}")
+    assert torch.equal(y, ops.gemm(xd, wd, out_fp32=True, bias=bd, act="gelu", residual=rd, x2=x2d, w2=w2d)), "must be deterministic"
+    _cmp(ops.gemm(xd, wd, bias=bd, act="gelu", residual=rd, x2=x2d, w2=w2d), z, TOL_BF16, "two row groups, bf16 out")
+    if M - 256 > 128:                      # the second group alone takes the panel kernel too (128 < rows <= 256): same program, same bits
+        for lo, hi in ((0, 256), (256, M)):
+            part = ops.gemm(xd[lo:hi], wd, out_fp32=True, bias=bd, act="gelu", residual=rd[lo:hi], x2=x2d[lo:hi], w2=w2d)
+            assert torch.equal(y[lo:hi], part), f"rows {lo}:{hi} of the two-group launch differ from a launch on those rows alone"
+
+
 @pytest.mark.parametrize("M", [129, 200, 256])
 @pytest.mark.parametrize("tune", [79601, 79602, 76401, 76404, 79605, 89602, 86404, 91601, 0])
 def test_gemm_decode_panel_kernel(M, tune):
@@ -535,11 +556,11 @@ def test_gemm_decode_panel_kernel(M, tune):
 
 @pytest.mark.parametrize("name,N,K,K2", [("qkv", 12288, 4096, 96), ("o", 4096, 4096, 32), ("gate|up", 22016, 4096, 64), ("down", 4096, 11008, 32),
                                           ("qwen qkv", 4608, 3584, 96), ("qwen gate|up", 37888, 3584, 64), ("qwen down", 3584, 18944, 32)])
-def test_gemm_decode_panel_kernel_projection_shapes(name, N, K, K2):
-    """The automatic decomposition on the real decoder projections at M = 256 (Llama-2-7B and Qwen2-7B widths) against fp32
-    arithmetic, and against the older split-K kernels (tune 104: 128x128 tiles, 4 slices) on the same operands."""
+@pytest.mark.parametrize("M", [256, 448])
+def test_gemm_decode_panel_kernel_projection_shapes(name, N, K, K2, M):
+    """The automatic decomposition on the real decoder projections at M = 256 and M = 448 (two row groups) (Llama-2-7B and Qwen2-7B widths)
+    against fp32 arithmetic, and against the older split-K kernels (tune 104: 128x128 tiles, 4 slices) on the same operands."""
     from crab_amd import ops
-    M = 256
     g = torch.Generator(device="cuda").manual_seed(N + K)
     x = torch.randn(M, K, device="cuda", generator=g).to(BF)
     w = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).to(BF)
@@ -547,9 +568,9 @@ def test_gemm_decode_panel_kernel_projection_shapes(name, N, K, K2):
     w2 = (torch.randn(N, K2, device="cuda", generator=g) * 0.1).to(BF)
     y = ops.gemm(x, w, x2=x2, w2=w2, out_fp32=True)
     z = x.float() @ w.float().t() + x2.float() @ w2.float().t()
-    _cmp(y, z.cpu(), TOL_F32 * 4, f"decode panel kernel, {name} at M=256 (vs torch fp32 matmul on the GPU)")
-    y1 = ops.gemm(x, w, x2=x2, w2=w2, out_fp32=True, tune=104)
-    _cmp(y, y1.cpu(), TOL_F32, f"decode panel kernel vs 128x128 split-K kernel, {name}")
+    _cmp(y, z.cpu(), TOL_F32 * 4, f"decode panel kernel, {name} at M={M} (vs torch fp32 matmul on the GPU)")
+    y1 = ops.gemm(x[:256], w, x2=x2[:256], w2=w2, out_fp32=True, tune=104)
+    _cmp(y[:256], y1.cpu(), TOL_F32, f"decode panel kernel vs 128x128 split-K kernel, {name}")
 
 
 @pytest.mark.parametrize("res_fp32", [True, False])
