@@ -188,6 +188,15 @@ class CLIPVisionModel(nn.Module):
         self.vision_model = _ClipVisionTransformer(self.config, device)
         self._pw = None
 
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        """Accept both serialisations of the HF tower: `vision_model.<...>` (transformers 4.37.2, the reference's pin, and the checkpoint
+        files on the hub) and the flattened `<...>` a transformers 5.x CLIPVisionModel.state_dict() gives (tests/golden/ckpt_manifest.npz);
+        `embeddings.position_ids` (a persistent buffer in checkpoints written before transformers 4.31) is not a parameter here."""
+        for k in [k for k in state_dict if k.startswith(prefix) and not k.startswith(prefix + "vision_model.")]:
+            state_dict[prefix + "vision_model." + k[len(prefix):]] = state_dict.pop(k)
+        state_dict.pop(prefix + "vision_model.embeddings.position_ids", None)
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
     def _patch_weight(self):
         w = self.vision_model.embeddings.patch_embedding.weight
         key = (w.data_ptr(), w._version)
@@ -451,6 +460,16 @@ class _BertLMHeadModel(nn.Module):
         super().__init__()
         self.bert = BertModel(cfg, n_layers, enc_width, device)
 
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        """The reference's BertLMHeadModel also owns `cls.predictions.*` (the 30522-way LM head: trainable, so finetune_weights.bin carries it,
+        utils/deepspeed_utils.py:56-59) and the `bert.embeddings.position_ids` buffer; neither is ever read on the path (only `.bert` with
+        query_embeds runs, models/multimodal_encoder.py:119-144).  They are consumed here instead of being reported as unexpected, so that a
+        reference checkpoint loads with strict=True; they are not kept (24 M dead parameters per projector)."""
+        for k in [k for k in state_dict if k.startswith(prefix + "cls.")]:
+            state_dict.pop(k)
+        state_dict.pop(prefix + "bert.embeddings.position_ids", None)
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
 
 class VLProjector(nn.Module):
     """multimodal_encoder.py:87-144."""
@@ -595,6 +614,10 @@ class BEATs(nn.Module):
         # layers 1.. alias layer 0's relative_attention_bias (backbone.py:78-81): drop the duplicate keys
         for k in [k for k in state_dict if k.startswith(prefix + "encoder.layers.") and k.endswith("relative_attention_bias.weight")
                   and not k.startswith(prefix + "encoder.layers.0.")]:
+            state_dict.pop(k)
+        # the AudioSet classifier head of the fine-tuned checkpoint (BEATs.py: `predictor`, cfg.finetuned_model): never evaluated by
+        # extract_features(feature_only=True), the only call on the path (models/multimodal_encoder.py:167-171)
+        for k in [k for k in state_dict if k.startswith(prefix + "predictor.")]:
             state_dict.pop(k)
         super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 

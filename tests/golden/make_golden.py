@@ -333,6 +333,56 @@ def golden_full(me):
          step_logits=fs.logits)
 
 
+def golden_id_stats(me, n_clips=24, new=12):
+    """UNSEARCHED clips for the id-parity statistic: the tiny full model of `full_tiny_llama` (same seeded weights) on
+    clip indices 200 .. 200 + n_clips - 1, one clip per generate() call, no selection of any kind - the reference's greedy ids, per-step
+    last-row logits and top-2 margins.  The GPU test reports (does not gate on) the fraction of steps whose id equals the reference's and the
+    reference margin at each first divergence."""
+    model, cfg = build_full_model(me, TINY_DEC)
+    inner = model.get_model()
+    inner.pad_token_id = 2
+    inner.visual_encoder = build_visual_encoder(me)
+    inner.vl_projector = me.VLProjector(hidden_size=128, image_token_nums=256, num_query_token=32, num_hidden_layers=2, d_model=D_MODEL, depth=2)
+
+    class AE(me.AudioEncoder):
+        def __init__(self, beats):
+            torch.nn.Module.__init__(self)
+            self.audio_encoder = beats
+    beats = build_beats(TINY_BEATS)
+    inner.audio_encoder = AE(beats)
+    inner.al_projector = me.ALProjector(hidden_size=128, num_query_token=32, num_hidden_layers=2, d_model=D_MODEL, depth=2)
+    tok = _Tok(TINY_DEC["vocab_size"] - 17)
+    base_vocab = len(tok)
+    model.base_model.model.initialize_MM_tokenizer(tok, mask_token_nums=6, use_vqgan=False)
+    model.eval()
+    alias = [("base_model.model.model.audio_encoder.audio_encoder." + c, ["base_model.model.model.audio_encoder.audio_encoder." + o for o in os_])
+             for c, os_ in beats_alias(beats)]
+    table = load_synth(model, "", alias_groups=alias)
+    um = model.base_model.model
+    tab = dict(um.SPECIAL_TOKEN_2_IDS)
+    gen_kw = dict(use_cache=True, max_new_tokens=new, do_sample=False, output_logits=True, return_dict_in_generate=True, pad_token_id=2, eos_token_id=None)
+    clips = list(range(200, 200 + n_clips))
+    nts = [16 + (c * 7) % 17 for c in clips]                       # prompt lengths 16 .. 32, fixed by the clip index
+    preps = []
+    for c, nt in zip(clips, nts):                                  # every encoder pass BEFORE the first generate() (transformers-5.15 artefact)
+        ids = synth.synth_prompt_ids(nt, base_vocab, tab, seed=SEED, clip=c)
+        mods = {'<video>': synth.synth_video(2, seed=SEED, clip=c), '<audio>': synth.synth_audio(3, 98, seed=SEED, clip=c)}
+        preps.append(um.prepare_multimodal_inputs([ids], [torch.full_like(ids, -100)], [mods], ['avqa'])["inputs_embeds"])
+    ids_out, logits_out = [], []
+    for e in preps:
+        r = super(type(um), um).generate(inputs_embeds=e, **gen_kw)
+        ids_out.append(r.sequences[0])
+        logits_out.append(torch.stack(r.logits, dim=1)[0])
+    ids_out, logits_out = torch.stack(ids_out), torch.stack(logits_out)
+    t2 = logits_out.topk(2, dim=-1).values
+    margin = t2[..., 0] - t2[..., 1]
+    print("id_stats: margins min / median", float(margin.min()), float(margin.median()), "scale", float(logits_out.abs().max()))
+    meta = dict(seed=SEED, dec=TINY_DEC, clip=TINY_CLIP, select=TINY_CLIP_SELECT, beats=TINY_BEATS, qf=TINY_QF, d_model=D_MODEL, base_vocab=base_vocab,
+                pad_token_id=2, special=tab, table=table, new_tokens=new, clips=clips, prompt_tokens=nts, t_v=2, t_a=3, l_a=98,
+                note="unsearched clip indices: no margin selection")
+    save("id_stats_tiny_llama", meta, ids=ids_out, logits=logits_out, margin=margin)
+
+
 def golden_qwen(me):
     model, cfg = build_full_model(me, TINY_QWEN, qwen=True)
     model.eval()
@@ -817,6 +867,8 @@ def main():
         golden_qwen_ops()
     if "full_qwen" in which:
         golden_full_qwen(me)
+    if "id_stats" in which:
+        golden_id_stats(me)
 
 
 if __name__ == "__main__":

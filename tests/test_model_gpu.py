@@ -394,6 +394,47 @@ def test_generate_many_clips_vs_oracle():
     assert worst < REL_DEC, worst
 
 
+def test_unfiltered_id_parity_statistic_on_unsearched_clips():
+    """A denominator nobody selected: the 24 clips of tests/golden/id_stats_tiny_llama.npz (indices 200..223, recorded from the
+    reference's generate() without any margin search), one clip per generate() call.  REPORTED in the parity report: the fraction of greedy
+    steps identical to the reference's, how many clips agree on all 12 steps, and at each first divergence the reference's top-2 margin next to
+    the logit error there.  Gated only on what must hold physically: a divergence happens where margin <= 2 x the logit error, and the logit error
+    stays under REL_DEC."""
+    from crab_amd import synth
+    from tests.util import record_parity
+    meta, A = load_fixture("id_stats_tiny_llama")
+    model = build_tiny_crab(meta)
+    model.load_state_dict(weights_from_table(meta), strict=False)
+    n = meta["new_tokens"]
+    scale = A["logits"].abs().max().item()
+    steps_same = clips_same = 0
+    divergences, worst = [], 0.0
+    for i, (c, nt) in enumerate(zip(meta["clips"], meta["prompt_tokens"])):
+        ids = synth.synth_prompt_ids(nt, meta["base_vocab"], meta["special"], seed=meta["seed"], clip=c)
+        mods = [{'<video>': synth.synth_video(meta["t_v"], seed=meta["seed"], clip=c), '<audio>': synth.synth_audio(meta["t_a"], meta["l_a"], seed=meta["seed"], clip=c)}]
+        r = model.generate(batch_input_ids=[ids], batch_labels=[torch.full_like(ids, -100)], batch_X_modals=mods, batch_task_names=['avqa'], use_cache=True,
+                           max_new_tokens=n, pad_token_id=2, eos_token_id=None, output_logits=True, return_dict_in_generate=True)
+        got_ids, got_logits = r.sequences[0].cpu(), torch.stack(r.logits, 1)[0].float().cpu()
+        k = n
+        for s in range(n):
+            e = (got_logits[s] - A["logits"][i, s]).abs().max().item()      # contexts identical up to the first divergence
+            worst = max(worst, e)
+            if got_ids[s] != A["ids"][i, s]:
+                m_ = A["margin"][i, s].item()
+                divergences.append({"clip": c, "step": s, "ref_margin": round(m_, 5), "logit_err": round(e, 5)})
+                assert m_ <= 2 * e, (c, s, m_, e)
+                k = s
+                break
+        steps_same += k
+        clips_same += k == n
+    total = n * len(meta["clips"])
+    record_parity("UNSEARCHED clips 200..223 (tiny Llama, bs 1): greedy steps identical to the reference's before the first divergence / all steps",
+                  worst, scale, None, steps_identical=steps_same, steps_total=total, fraction=round(steps_same / total, 4), clips_fully_identical=clips_same,
+                  clips=len(meta["clips"]), first_divergences=divergences, min_ref_margin=float(A["margin"].min()), median_ref_margin=float(A["margin"].median()))
+    assert worst < REL_DEC * scale, worst
+    assert steps_same >= 0.5 * total, (steps_same, total, divergences)            # sanity only: the statistic itself is the report row
+
+
 def test_generate_edge_cases_vs_oracle():
     """Prompts the AVQA fixture does not cover: text only, video only, audio only, an <image> block, one- and two-token
     generations (no HIP graph below three tokens), EOS on the very first token - each against the golden-pinned oracle."""

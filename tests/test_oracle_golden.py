@@ -301,3 +301,26 @@ def test_full_tiny_qwen_prepare_and_generate():
     ids, sl = O.generate([A["ids0"], A["ids1"]], mods, W, cfg, n)
     assert torch.equal(ids, A["ids_bs2"])
     _close(sl, A["logits_bs2"], 1e-3)
+
+
+def test_id_stats_unsearched_clips_oracle_reproduces_the_reference():
+    """tests/golden/id_stats_tiny_llama.npz: 24 UNSEARCHED clips (indices 200..223, no margin selection) through the reference's generate().
+    The fp32 oracle reproduces every per-step logit row to 1e-3 and every id whose reference top-2 margin exceeds 2e-3."""
+    from crab_amd import synth
+    meta, A = load_fixture("id_stats_tiny_llama")
+    W = O.strip_peft_prefix(weights_from_table(meta))
+    cfg = _full_cfg(meta)
+    n = meta["new_tokens"]
+    same = total = 0
+    for i, (c, nt) in enumerate(zip(meta["clips"][:6], meta["prompt_tokens"][:6])):          # 6 of the 24 here (CPU time); the GPU test runs all
+        ids = synth.synth_prompt_ids(nt, meta["base_vocab"], meta["special"], seed=meta["seed"], clip=c)
+        mods = [{'<video>': synth.synth_video(meta["t_v"], seed=meta["seed"], clip=c), '<audio>': synth.synth_audio(meta["t_a"], meta["l_a"], seed=meta["seed"], clip=c)}]
+        got_ids, got_logits = O.generate([ids], mods, W, cfg, n)
+        for s in range(n):
+            assert (got_logits[0, s] - A["logits"][i, s]).abs().max() < 1e-3
+            if got_ids[0, s] != A["ids"][i, s]:
+                assert A["margin"][i, s] < 2e-3
+                break
+            same += 1
+        total += n
+    assert same >= total - 2
