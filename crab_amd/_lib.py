@@ -186,6 +186,13 @@ SYMBOLS = {
     "crab_add_rows": (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _i, _vp, _i64, _i, _i]),
     "crab_mask_gate": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _i64, _i, _i]),
     "crab_act_inplace": (_i, [_vp, _vp, _vp, _i64, _i]),
+    "crab_dist_unique_id": (_i, [_vp, _vp]),
+    "crab_dist_init": (_i, [_vp, _vp, _i, _i, C.POINTER(_vp)]),
+    "crab_gather_results": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _i]),
+    "crab_dist_world": (_i, [_vp]),
+    "crab_dist_rank": (_i, [_vp]),
+    "crab_dist_destroy": (None, [_vp]),
+    "crab_mask_labels": (_i, [_vp, _vp, _vp, _i, _i64, _vp]),
     "crab_group_mean": (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _i, _i, _i, _f]),
     "crab_bicubic_ksize": (_i, [_i, _i]),
     "crab_bicubic_coeffs": (_i, [_i, _i, _vp, _vp, _i]),

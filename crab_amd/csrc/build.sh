@@ -20,5 +20,5 @@ for f in *.hip; do
   fi
 done
 for p in "${pids[@]}"; do wait "$p"; done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC build/*.o -o "$OUT"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC build/*.o -o "$OUT" -ldl
 echo "built $(realpath $OUT)"

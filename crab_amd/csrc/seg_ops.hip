@@ -108,6 +108,22 @@ __global__ void group_mean_kernel(const bf16_t* __restrict__ in, long ldi, bf16_
     out[(long)g * ldo + e] = f2bf(scale * s);
 }
 
+// What the reference's eval loops make of a predicted mask before writing the PNG (scripts/quick_start.py:313-318: binary tasks
+// `(sigmoid(pred) > 0.5) * 255`; utils/avss_utils.py:291-292: `argmax(softmax(pred, dim=classes))`): C == 1 -> 255 where pred > 0 (sigmoid is
+// monotone, sigmoid(0) = 0.5), else 0; C > 1 -> the index of the first maximum over the C class planes (softmax is monotone).
+__global__ void mask_labels_kernel(const float* __restrict__ pred, int C, long hw, uint8_t* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= hw) return;
+    if (C == 1) { out[i] = pred[i] > 0.0f ? 255 : 0; return; }
+    float best = pred[i];
+    int bi = 0;
+    for (int c = 1; c < C; ++c) {
+        const float v = pred[(long)c * hw + i];
+        if (v > best) { best = v; bi = c; }
+    }
+    out[i] = (uint8_t)bi;
+}
+
 __global__ void act_kernel(bf16_t* __restrict__ x, long n, int act) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) x[i] = f2bf(apply_act(bf2f(x[i]), act));
@@ -172,6 +188,13 @@ int crab_group_mean(crab_ctx* ctx, void* stream, const void* in, int64_t ldi, vo
     if (!in || !out || G <= 0 || T <= 0 || D <= 0) return crab_fail(ctx, CRAB_E_INVALID, "group_mean: bad argument");
     hipLaunchKernelGGL(group_mean_kernel, dim3(cdiv_((long)G * D, 256)), dim3(256), 0, S_(stream), (const bf16_t*)in, (long)ldi, (bf16_t*)out, (long)ldo, G, T, D, scale);
     return crab_check_launch(ctx, "group_mean");
+}
+
+int crab_mask_labels(crab_ctx* ctx, void* stream, const float* pred, int C, int64_t hw, uint8_t* out) {
+    if (!ctx) return CRAB_E_INVALID;
+    if (!pred || !out || C <= 0 || C > 255 || hw <= 0) return crab_fail(ctx, CRAB_E_INVALID, "mask_labels: pred [C, hw] fp32, 1 <= C <= 255, out [hw] uint8");
+    hipLaunchKernelGGL(mask_labels_kernel, dim3(cdiv_(hw, 256)), dim3(256), 0, S_(stream), pred, C, (long)hw, out);
+    return crab_check_launch(ctx, "mask_labels");
 }
 
 int crab_act_inplace(crab_ctx* ctx, void* stream, void* x, int64_t n, int act) {

@@ -8,6 +8,7 @@ with the caller, who hands over uint8 frames and a 16 kHz mono waveform).
   DataCollatorForUnifiedTestDataset            quick_start_dataset.py:623-707   Collator
   prepare_sample                               utils/util.py:33-47              to_device
   inference_ntp / inference_avqa               quick_start.py:30-50, inference_hyper_lora.py:158-212   run_inference
+  inference_ms3 / _s4 / _avss / _ref_avs       quick_start.py:270-450 (generate_avs -> mask -> PNG + record)   run_inference_avs
 
 Image and audio preprocessing run on the device through crab_amd.frontend (HIP kernels); prompts and ids are host work.
 The reference loops clip by clip on one GPU; run_inference shards the batches over ranks (crab_amd.parallel) and rank 0
@@ -214,6 +215,88 @@ def run_inference(batches: Iterable[Mapping[str, Any]], model, tokenizer, max_ne
         if len(pending) >= max(1, in_flight):
             flush()
     flush()
+    records = mine
+    if world > 1:
+        import torch.distributed as dist
+        gathered = [None] * world if rank == 0 else None
+        dist.gather_object(mine, gathered, dst=0)
+        if rank == 0:
+            records = sorted((r for part in gathered for r in part), key=lambda t: t[0])
+    out = [r for _, r in records]
+    if rank == 0:
+        for rec in out:
+            if on_result is not None:
+                on_result(rec)
+        if out_path is not None:
+            with open(out_path, "a") as f:
+                for rec in out:
+                    f.write(json.dumps(rec) + "\n")
+    return out
+
+
+def default_palette(n: int = 71) -> np.ndarray:
+    """A deterministic [n, 3] uint8 colour table for the AVSS class map (the PASCAL-VOC bit-shuffle palette; background = class 0 = black).
+    The reference builds its table from a dataset file on its cluster (utils/avss_utils.py get_v2_pallete over label2idx.json), which is
+    data, not code: hand that table in as `palette=` to reproduce its colours."""
+    pal = np.zeros((n, 3), np.uint8)
+    for i in range(n):
+        c, r, g, b = i, 0, 0, 0
+        for j in range(8):
+            r |= ((c >> 0) & 1) << (7 - j)
+            g |= ((c >> 1) & 1) << (7 - j)
+            b |= ((c >> 2) & 1) << (7 - j)
+            c >>= 3
+        pal[i] = (r, g, b)
+    return pal
+
+
+def run_inference_avs(batches: Iterable[Mapping[str, Any]], model, tokenizer, out_dir: str, max_new_tokens: int = 100, device="cuda",
+                      rank: int = 0, world: int = 1, palette: Optional[np.ndarray] = None, out_path: Optional[str] = None,
+                      on_result: Optional[Callable[[dict], None]] = None, **generate_kwargs) -> List[dict]:
+    """The pixel-task loops of the reference (scripts/quick_start.py:270-359 inference_ms3 / _s4 / _ref_avs, :361-450 inference_avss): for every
+    collated batch (one sample per batch, like the reference, which reads batch_metadata[0]) generate_avs -> text + masks -> files:
+      binary tasks (one class plane):  `<out_dir>/mask_img_dir/<video>/<frame>_pred.png`, mode 'P', 255 where sigmoid(pred) > 0.5 (:313-319)
+      avss (71 class planes):          `<out_dir>/avss_result/<video>/<frame>_pred.png`, RGB, palette[argmax over classes] (avss_utils.py:281-312)
+    <video> / <frame> come from metadata['mask_path'] (`.../<video>/<fid>/<frame>.png`, :308-311) when present, else from the batch index.
+    The thresholding / argmax runs on the device (crab_mask_labels); PNG encoding is host work (Pillow).  A sample whose generation did not
+    produce the six <mask_i> tokens has no masks: its record carries pred_path None, as the reference skips it (:303-306).  Metrics (mIoU,
+    F-score, S) are outside the path.  Batch i runs on rank i mod world; rank 0 returns every record in batch order and
+    appends them to `out_path` as JSON lines when given."""
+    import os
+    from PIL import Image
+    from . import ops
+    pal = default_palette() if palette is None else np.asarray(palette, np.uint8)
+    mine: List[Tuple[int, dict]] = []
+    for step, sample in enumerate(batches):
+        if step % world != rank:
+            continue
+        sample = dict(sample)
+        meta = dict(sample.pop("batch_metadata")[0])
+        task = sample["batch_task_names"][0]
+        kw = {"use_cache": True, "max_new_tokens": max_new_tokens}
+        kw.update(generate_kwargs)
+        with torch.no_grad():
+            result = model.generate_avs(**to_device(sample, device), **kw)
+        rec = {"instruction": meta.get("instruction"), "label": meta.get("output"), "image_path": meta.get("image_path"),
+               "predict": tokenizer.decode(result["output_ids"][0], skip_special_tokens=False), "pred_path": None}
+        masks = result.get("pred_masks")
+        if masks is not None:
+            pred = masks[0].float()                                     # [num_classes, 224, 224]
+            parts = (meta.get("mask_path") or "").split("/")
+            video = parts[-3] if len(parts) >= 3 else f"sample_{step:06d}"
+            frame = os.path.splitext(parts[-1])[0] if parts[-1:] and parts[-1] else "0"
+            lab = ops.mask_labels(pred).cpu().numpy()                   # uint8 [224, 224]: 0 / 255, or the class index
+            if pred.shape[0] == 1:
+                d = os.path.join(out_dir, "mask_img_dir", video)
+                img = Image.fromarray(lab).convert("P")
+            else:
+                d = os.path.join(out_dir, "avss_result", video)
+                img = Image.fromarray(pal[np.minimum(lab, len(pal) - 1)])
+            os.makedirs(d, exist_ok=True)
+            rec["pred_path"] = os.path.join(d, frame + "_pred.png")
+            img.save(rec["pred_path"], format="PNG")
+            rec["task"], rec["num_classes"] = task, int(pred.shape[0])
+        mine.append((step, rec))
     records = mine
     if world > 1:
         import torch.distributed as dist

@@ -637,3 +637,16 @@ def vq_argmin(dots: torch.Tensor, e2: torch.Tensor, offset: int = 0) -> torch.Te
     out = torch.empty((M,), device=dots.device, dtype=torch.int64)
     _lib.check(_lib.load().crab_vq_argmin(_lib.ctx(d), _stream(), _p(dots), dots.stride(0), _p(e2), M, N, _p(out), offset), d)
     return out
+
+
+def mask_labels(pred: torch.Tensor) -> torch.Tensor:
+    """pred [C, H, W] fp32 (a SegModule mask) -> uint8 [H, W]: 0 / 255 by sigmoid > 0.5 for C == 1, the argmax class index otherwise
+    (what the reference's eval loops write to the PNG)."""
+    d = _dev(pred)
+    if pred.dtype != torch.float32 or pred.dim() != 3:
+        raise _lib.CrabHipError("mask_labels: fp32 [C, H, W] expected")
+    pred = pred.contiguous()
+    C_, H, W = pred.shape
+    out = torch.empty((H, W), device=pred.device, dtype=torch.uint8)
+    _lib.check(_lib.load().crab_mask_labels(_lib.ctx(d), _stream(), _p(pred), C_, H * W, _p(out)), d)
+    return out

@@ -414,6 +414,10 @@ int crab_add_rows(crab_ctx* ctx, void* stream, const void* a, int64_t lda, const
 int crab_mask_gate(crab_ctx* ctx, void* stream, const void* prev, int64_t ldp, int ncls, void* src, int64_t lds, int M, int D);
 int crab_group_mean(crab_ctx* ctx, void* stream, const void* in, int64_t ldi, void* out, int64_t ldo, int G, int T, int D, float scale);
 int crab_act_inplace(crab_ctx* ctx, void* stream, void* x, int64_t n, int act);
+/* mask_labels: what the eval loops write to the PNG from a predicted mask pred [C, hw] fp32 (SegModule output): C == 1 -> 255 where
+ * sigmoid(pred) > 0.5 else 0 (scripts/quick_start.py:313-318); C > 1 -> argmax over the class planes, first maximum
+ * (utils/avss_utils.py:291-292 softmax + argmax); out [hw] uint8 */
+int crab_mask_labels(crab_ctx* ctx, void* stream, const float* pred, int C, int64_t hw, uint8_t* out);
 
 /* ---------------------------------------------------------------------------------------------
  * Input front-end: what the reference's dataset code does on the CPU right before generate().
@@ -460,6 +464,27 @@ int crab_upsample_nearest2x(crab_ctx* ctx, void* stream, const void* in, void* o
 int crab_softmax_rows(crab_ctx* ctx, void* stream, const float* in, int64_t ldi, void* out, int64_t ldo, int M, int N, float scale);
 int crab_row_sqnorm(crab_ctx* ctx, void* stream, const void* e, int64_t lde, int N, int D, float* out);
 int crab_vq_argmin(crab_ctx* ctx, void* stream, const float* dots, int64_t ldd, const float* e2, int M, int N, int64_t* idx, int64_t offset);
+
+/* ---------------------------------------------------------------------------------------------
+ * Multi-GPU: per-clip sharding, one process per GPU, full weight replica; the ONLY exchange is a gather of fixed-size result
+ * records to a root rank.  crab_gather_results is that gather over RCCL (ncclGather: every peer sends over its own xGMI link to the root);
+ * RCCL is dlopen()ed at the first crab_dist_* call (CRAB_RCCL_LIB overrides the name), so a single-GPU caller never loads it.
+ * The reference has no collective on this path (scripts/finetune/inference_hyper_lora.py:1466-1479 is a single-process loop);
+ * crab_amd/parallel.py:gather_results is the torch.distributed form of the same exchange.
+ *   crab_dist_unique_id : rank 0 makes the 128-byte rendezvous id; the CALLER ships it to the other ranks (file, socket, environment)
+ *   crab_dist_init      : collective over all ranks: the communicator on ctx's device
+ *   crab_gather_results : send [bytes_per_rank] (device) from every rank -> recv [world * bytes_per_rank] (device) on `root`, rank order; a
+ *                         record is whatever the caller packs, e.g. {int64 clip_id, int64 ids[n_new]} per clip (+ fp32 first-step logits);
+ *                         asynchronous on `stream`; recv may be NULL on the other ranks
+ */
+#define CRAB_DIST_ID_BYTES 128
+typedef struct crab_comm crab_comm;
+int crab_dist_unique_id(crab_ctx* ctx, void* id_out /* host, CRAB_DIST_ID_BYTES */);
+int crab_dist_init(crab_ctx* ctx, const void* id /* host */, int world, int rank, crab_comm** out);
+int crab_gather_results(crab_ctx* ctx, void* stream, crab_comm* comm, const void* send, int64_t bytes_per_rank, void* recv, int root);
+int crab_dist_world(const crab_comm* comm);
+int crab_dist_rank(const crab_comm* comm);
+void crab_dist_destroy(crab_comm* comm);
 
 #ifdef __cplusplus
 }

@@ -172,3 +172,78 @@ def test_c_caller_runs_a_whole_clip(tmp_path):
         assert np.array_equal(ids, ref_ids_np), (use_graph, ids, ref_ids_np)
         assert np.array_equal(logits, ref_logits_np), (use_graph, np.abs(logits - ref_logits_np).max())
     assert np.array_equal(ref_ids_np, A["ids_bs1"].numpy()), "the C-run clip does not reproduce the ids the reference recorded"
+
+
+def test_crab_gather_results_over_rccl_single_rank():
+    """crab_dist_unique_id / crab_dist_init / crab_gather_results / crab_dist_destroy (csrc/dist.hip): the C-ABI form of the per-clip result
+    gather, RCCL dlopen()ed on first use.  One GPU box: a world of one rank (the communicator, the stream-ordered ncclGather and
+    the record layout are the real ones; the 2-rank form needs two devices and is exercised by the test below when they exist)."""
+    import ctypes as C
+    import torch
+    from crab_amd import _lib
+    lib = _lib.load()
+    ctx = _lib.ctx(0)
+    uid = (C.c_char * 128)()
+    _lib.check(lib.crab_dist_unique_id(ctx, uid), 0)
+    assert any(bytes(uid))
+    comm = C.c_void_p()
+    _lib.check(lib.crab_dist_init(ctx, uid, 1, 0, C.byref(comm)), 0)
+    assert lib.crab_dist_world(comm) == 1 and lib.crab_dist_rank(comm) == 0
+    n_new = 6
+    rec = torch.stack([torch.cat([torch.tensor([cid]), torch.arange(n_new) + 100 * cid]) for cid in (4, 5, 6)]).to("cuda")      # {clip id, ids[n_new]} x 3 clips
+    out = torch.zeros_like(rec)
+    stream = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.crab_gather_results(ctx, stream, comm, rec.data_ptr(), rec.numel() * 8, out.data_ptr(), 0), 0)
+    torch.cuda.synchronize()
+    assert torch.equal(out, rec)
+    assert lib.crab_gather_results(ctx, stream, comm, rec.data_ptr(), 0, out.data_ptr(), 0) < 0 and b"gather_results" in lib.crab_last_error(ctx)
+    lib.crab_dist_destroy(comm)
+
+
+def _gather_worker(rank, world, idfile, q):
+    import ctypes as C
+    import os
+    import time
+    import torch
+    torch.cuda.set_device(rank)
+    from crab_amd import _lib
+    lib = _lib.load()
+    ctx = _lib.ctx(rank)
+    uid = (C.c_char * 128)()
+    if rank == 0:
+        _lib.check(lib.crab_dist_unique_id(ctx, uid), rank)
+        with open(idfile + ".tmp", "wb") as f:
+            f.write(bytes(uid))
+        os.replace(idfile + ".tmp", idfile)                       # the caller ships the id: here through a file
+    else:
+        for _ in range(600):
+            if os.path.exists(idfile):
+                break
+            time.sleep(0.1)
+        C.memmove(uid, open(idfile, "rb").read(), 128)
+    comm = C.c_void_p()
+    _lib.check(lib.crab_dist_init(ctx, uid, world, rank, C.byref(comm)), rank)
+    rec = (torch.arange(5, dtype=torch.int64) + 1000 * rank).to(f"cuda:{rank}")
+    out = torch.zeros(world * 5, dtype=torch.int64, device=f"cuda:{rank}") if rank == 0 else None
+    _lib.check(lib.crab_gather_results(ctx, torch.cuda.current_stream().cuda_stream, comm, rec.data_ptr(), 40, out.data_ptr() if out is not None else None, 0), rank)
+    torch.cuda.synchronize()
+    if rank == 0:
+        q.put(out.cpu().tolist())
+    lib.crab_dist_destroy(comm)
+
+
+def test_crab_gather_results_two_ranks_when_two_gpus_are_visible(tmp_path):
+    import torch
+    import torch.multiprocessing as mp
+    if torch.cuda.device_count() < 2:
+        pytest.skip(f"{torch.cuda.device_count()} GPU visible: the 2-rank RCCL gather needs two devices (the single-rank form runs above)")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, str(tmp_path / "uid"), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert got == list(range(5)) + [1000 + i for i in range(5)]

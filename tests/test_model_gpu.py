@@ -298,10 +298,8 @@ def test_seg_module_vs_reference_fixture_and_oracle():
     assert _rel(out[1][:, 1::2, ::2], A["s4_sub"], "SegModule s4 vs fp32 reference") < 3.2e-2
 
 
-def test_generate_avs_pipeline_vs_oracle():
-    """generate_avs (unified_llama.py:270-361): <image> prompt -> greedy ids + per-step hidden states -> the states of the
-    steps followed by a <mask_i> token -> SegModule masks.  The tiny random decoder never emits real mask tokens, so the six
-    <mask_i> ids are re-pointed at the tokens it does emit at steps 1..6 (the selection logic is what is under test)."""
+def _avs_setup():
+    """Tiny Crab with the SegModule; the six <mask_i> ids re-pointed at the tokens the random decoder emits at steps 1..6."""
     from crab_amd import synth
     from oracle import crab_oracle as O
     from tests.test_oracle_golden import _full_cfg
@@ -336,6 +334,16 @@ def test_generate_avs_pipeline_vs_oracle():
                            pad_token_id=2, eos_token_id=None).cpu()
     for i in range(6):
         sp[f'<mask_{i}>'] = int(plain[0, 1 + i])
+    return model, meta, A, W, sp, ids, image, mods, lab, n, plain
+
+
+def test_generate_avs_pipeline_vs_oracle():
+    """generate_avs (unified_llama.py:270-361): <image> prompt -> greedy ids + per-step hidden states -> the states of the
+    steps followed by a <mask_i> token -> SegModule masks.  The tiny random decoder never emits real mask tokens, so the six
+    <mask_i> ids are re-pointed at the tokens it does emit at steps 1..6 (the selection logic is what is under test)."""
+    from oracle import crab_oracle as O
+    from tests.test_oracle_golden import _full_cfg
+    model, meta, A, W, sp, ids, image, mods, lab, n, plain = _avs_setup()
     res = model.generate_avs(batch_input_ids=[ids], batch_labels=lab, batch_X_modals=mods, batch_task_names=['s4'], max_new_tokens=n,
                              pad_token_id=2, eos_token_id=None)
     assert torch.equal(res['output_ids'].cpu(), plain)
@@ -361,6 +369,44 @@ def test_generate_avs_pipeline_vs_oracle():
         pytest.skip(f"ids diverge at sub-margin step {j}: masks are not comparable")
     else:
         assert _rel(res['pred_masks'][0], ref[0], "generate_avs masks vs oracle pipeline") < 2e-2
+
+
+def test_harness_pixel_task_loop_writes_the_masks(tmp_path):
+    """harness.run_inference_avs = scripts/quick_start.py:270-450: generate_avs -> text + mask files.  Binary task: a mode-'P' PNG with 255 where
+    sigmoid(pred) > 0.5; avss: an RGB PNG of palette[argmax over the 71 class planes]; a sample without the six mask tokens: no file."""
+    import numpy as np
+    from PIL import Image
+    from crab_amd import harness, ops
+    from tests.util import DuckTokenizer
+    model, meta, A, W, sp, ids, image, mods, lab, n, plain = _avs_setup()
+
+    class Tok(DuckTokenizer):
+        def decode(self, ids_, skip_special_tokens=False):
+            return " ".join(str(int(i)) for i in ids_)
+    tok = Tok(meta["base_vocab"])
+    mk = lambda task, path: {"batch_input_ids": [ids], "batch_labels": lab, "batch_X_modals": mods, "batch_task_names": [task],
+                             "batch_metadata": [{"instruction": "seg", "output": "x", "image_path": "/d/v1/frames/3.jpg", "mask_path": path}]}
+    batches = [mk("s4", "/data/avs/vidA/0/3.png"), mk("avss", "/data/avs/vidB/0/7.png")]
+    recs = harness.run_inference_avs(batches, model, tok, str(tmp_path), max_new_tokens=n, pad_token_id=2, eos_token_id=None,
+                                     out_path=str(tmp_path / "res.jsonl"))
+    assert [r["num_classes"] for r in recs] == [1, 71] and recs[0]["predict"] == " ".join(str(int(i)) for i in plain[0])
+    direct = [model.generate_avs(batch_input_ids=[ids], batch_labels=lab, batch_X_modals=mods, batch_task_names=[t], max_new_tokens=n, pad_token_id=2,
+                                 eos_token_id=None)["pred_masks"][0].float() for t in ("s4", "avss")]
+    p0 = np.array(Image.open(recs[0]["pred_path"]))
+    assert recs[0]["pred_path"].endswith("mask_img_dir/vidA/3_pred.png") and Image.open(recs[0]["pred_path"]).mode == "P"
+    assert np.array_equal(p0, ((torch.sigmoid(direct[0][0]) > 0.5).cpu().numpy() * 255).astype(np.uint8))
+    rnd = torch.randn(1, 224, 224, device="cuda")                              # (the tiny random model's mask is one-signed: both signs here)
+    assert np.array_equal(ops.mask_labels(rnd).cpu().numpy(), ((rnd[0] > 0).cpu().numpy() * 255).astype(np.uint8))
+    p1 = np.array(Image.open(recs[1]["pred_path"]))
+    cls = torch.argmax(torch.softmax(direct[1], 0), 0).cpu().numpy()
+    assert recs[1]["pred_path"].endswith("avss_result/vidB/7_pred.png") and np.array_equal(p1, harness.default_palette()[cls]) and len(np.unique(cls)) > 1
+    assert np.array_equal(ops.mask_labels(direct[1]).cpu().numpy(), cls.astype(np.uint8))
+    assert len(open(tmp_path / "res.jsonl").read().strip().splitlines()) == 2
+    # no mask tokens in the output -> no masks, no file, the record says so (quick_start.py:303-306)
+    for i in range(6):
+        sp[f'<mask_{i}>'] = meta["base_vocab"] + 11 + i
+    r = harness.run_inference_avs([mk("s4", "/data/avs/vidC/0/1.png")], model, tok, str(tmp_path), max_new_tokens=n, pad_token_id=2, eos_token_id=None)
+    assert r[0]["pred_path"] is None and not (tmp_path / "mask_img_dir" / "vidC").exists()
 
 
 def test_generate_many_clips_vs_oracle():
