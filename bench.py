@@ -301,9 +301,13 @@ def main():
         sys.exit(f"bench.py: {world} ranks need {world} visible GPUs, found {torch.cuda.device_count()} (one process per GPU)")
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    # CRAB_BENCH_FORCE_DIST=1 (test hook): make the process group even for ONE rank, so that the RCCL code path - communicator init with
+    # device_id, barrier, all_reduce, all_gather, the result gather - really executes on a one-GPU box (tests/test_bench_launch.py)
+    force_dist = os.environ.get("CRAB_BENCH_FORCE_DIST") == "1"
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:

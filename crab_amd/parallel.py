@@ -8,6 +8,7 @@ the CPU tests.  No collective sits on the data path between clips.
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Tuple
 
 import torch
@@ -35,9 +36,9 @@ def gather_results(ids: torch.Tensor, clip0: int, world: int, rank: int, logits:
     transfer per rank over its own xGMI link)."""
     B = ids.shape[0]
     cid = torch.arange(clip0, clip0 + B, device=ids.device, dtype=torch.int64)
-    if world == 1:
-        return cid, ids, logits
     import torch.distributed as dist
+    if world == 1 and not (dist.is_available() and dist.is_initialized() and os.environ.get("CRAB_BENCH_FORCE_DIST") == "1"):
+        return cid, ids, logits                            # (the hook runs the collective with one rank: a one-GPU rehearsal of the RCCL path)
     if dist.get_backend() == "gloo":                      # CPU tests / one-GPU rehearsals: gloo gathers host tensors
         ids, cid = ids.cpu(), cid.cpu()
         logits = logits.cpu() if logits is not None else None

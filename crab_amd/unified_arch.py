@@ -12,6 +12,8 @@ row copies into one preallocated [bs, S, D] buffer (the reference builds it with
 """
 from __future__ import annotations
 
+import os
+
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np
@@ -23,6 +25,8 @@ from .multimodal_encoder import ALProjector, AudioEncoder, VLProjector, VisualEn
 BF16 = torch.bfloat16
 AVS_TASKS = ('ms3', 's4', 'avss', 'ref-avs')
 
+
+ENC_CHUNK = int(os.environ.get("CRAB_ENC_CHUNK", "64"))      # clips (modality blocks) per encoder call in prepare_multimodal_inputs
 
 class UnifiedMetaModel:
 
@@ -317,18 +321,23 @@ class UnifiedMetaForCausalLM:
         groups: Dict[tuple, List[int]] = {}
         for i, b in enumerate(blocks):
             groups.setdefault(tuple(b.shape), []).append(i)
-        for shape, idxs in groups.items():
-            x = torch.stack([blocks[i] for i in idxs], dim=0)
-            if video:
-                vit, qf = self.encode_video(x, batch_first=True)
-                f = qf[-1]
-                if want_vit:
-                    for j, i in enumerate(idxs):
-                        vit_out[i] = [v[j] for v in vit]
-            else:
-                f = self.encode_audio(x, batch_first=True)
-            for j, i in enumerate(idxs):
-                out[i] = f[j]
+        # at most ENC_CHUNK blocks per encoder call: the towers' scratch is ~60 MB per clip (CLIP: 8 frames x 257 tokens x 29 KB of rows), which at
+        # several hundred clips per generate() would take tens of GB away from the KV cache; rows are independent and every chunk is far inside
+        # the large-M regime of the kernels, so the features do not depend on the chunking
+        for shape, all_idxs in groups.items():
+            for c0 in range(0, len(all_idxs), ENC_CHUNK):
+                idxs = all_idxs[c0:c0 + ENC_CHUNK]
+                x = torch.stack([blocks[i] for i in idxs], dim=0)
+                if video:
+                    vit, qf = self.encode_video(x, batch_first=True)
+                    f = qf[-1]
+                    if want_vit:
+                        for j, i in enumerate(idxs):
+                            vit_out[i] = [v[j] for v in vit]
+                else:
+                    f = self.encode_audio(x, batch_first=True)
+                for j, i in enumerate(idxs):
+                    out[i] = f[j]
         return out, vit_out
 
     def initialize_MM_tokenizer(self, tokenizer, mask_token_nums=6, output_embeddings_require_grad=False, use_vqgan=False):

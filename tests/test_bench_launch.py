@@ -57,6 +57,24 @@ def test_bench_strong_scaling_with_a_clip_count_the_world_does_not_divide():
 
 
 @pytest.mark.gpu
+def test_bench_runs_its_collectives_on_rccl_with_one_rank():
+    """CRAB_BENCH_FORCE_DIST=1: `python bench.py --gpus 1` makes the `nccl` (= RCCL) process group for its single rank and takes every
+    distributed branch of the line's path on it - init_process_group(device_id=...), barrier, the all_reduce(MIN) of the batch choice, the padded
+    result gather on device tensors, all_gather / all_reduce(MAX) of the timings, all_gather_object of the per-rank records.  One rank is all a
+    one-GPU box can host; what this pins is that the RCCL branch EXECUTES (it never had before r04), not that ranks exchange data."""
+    env = dict(os.environ, CRAB_BENCH_FORCE_DIST="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    env.pop("CRAB_BENCH_BACKEND", None)
+    env.pop("CRAB_BENCH_SINGLE_DEVICE", None)
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--clips", "3", "--new-tokens", "4", "--steps", "1", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-operating-points"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    c = j["config"]
+    assert c["collective_backend"] == "nccl (RCCL)" and c["world_size_observed"] == 1 and c["gathered_clips"] == 3 and "logits" in c["gathered_per_clip"]
+    assert len(j["ranks"]) == 1 and j["rank_ms_per_step"][0] == pytest.approx(j["ms_per_step"], rel=1e-3)
+
+
+@pytest.mark.gpu
 def test_bench_gpus_2_on_rccl_when_two_gpus_are_visible():
     """The real N > 1 path: two ranks, one per GPU, `nccl` (= RCCL) process group with device_id, barrier + max-over-ranks timing,
     RCCL gather of {clip id, ids, first-step logits} to rank 0.  Needs two visible MI355X; the builder's and the driver's test

@@ -409,6 +409,32 @@ def test_harness_pixel_task_loop_writes_the_masks(tmp_path):
     assert r[0]["pred_path"] is None and not (tmp_path / "mask_img_dir" / "vidC").exists()
 
 
+def test_encoder_chunking_does_not_change_the_features():
+    """prepare_multimodal_inputs encodes the modality blocks in chunks of ENC_CHUNK clips (bounded scratch at hundreds of clips per call): the
+    rows are independent, so the spliced inputs_embeds of 5 clips agree for chunks of 2 and for one call over all of them - to the last bit wherever
+    both runs take the same kernels (every realistic chunk is deep inside the large-M regime; at this tiny size the 2-clip chunk crosses a tile-choice
+    boundary of the GEMM dispatcher, which changes the summation order: agreement to bf16 accumulation noise is what is asserted)."""
+    from crab_amd import synth, unified_arch
+    meta, A = load_fixture("full_tiny_llama")
+    model = build_tiny_crab(meta)
+    model.load_state_dict(weights_from_table(meta), strict=False)
+    um = model.base_model.model
+    p = meta["prompts"]
+    ids = [synth.synth_prompt_ids(20 + i, meta["base_vocab"], um.SPECIAL_TOKEN_2_IDS, seed=meta["seed"], clip=50 + i) for i in range(5)]
+    mods = [{'<video>': synth.synth_video(p["t_v"], seed=meta["seed"], clip=50 + i), '<audio>': synth.synth_audio(p["t_a"], p["l_a"], seed=meta["seed"], clip=50 + i)}
+            for i in range(5)]
+    lab = [torch.full_like(i, -100) for i in ids]
+    outs = []
+    saved = unified_arch.ENC_CHUNK
+    try:
+        for chunk in (64, 2):
+            unified_arch.ENC_CHUNK = chunk
+            outs.append(um.prepare_multimodal_inputs(ids, lab, mods, ['avqa'] * 5)["inputs_embeds"].clone())
+    finally:
+        unified_arch.ENC_CHUNK = saved
+    assert _rel(outs[1], outs[0].float().cpu(), "inputs_embeds: encoder chunks of 2 clips vs one call over 5 (HIP vs HIP)") < 6e-3
+
+
 def test_generate_many_clips_vs_oracle():
     """Six more synthetic clips (3 batches of 2, different prompts / frames / fbank) through the public generate() against
     the golden-pinned oracle run on the same bf16-rounded weights: greedy ids exact wherever the oracle's top-2 margin
