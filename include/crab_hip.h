@@ -10,7 +10,9 @@
  * module whose arithmetic it replaces, i.e. what a maintainer would bind instead of the eager
  * PyTorch op sequence (see INTEGRATION.md for the ctypes stubs).
  *
- * Storage dtype is bf16 (uint16 raw bits == torch.bfloat16); accumulation and softmax/norm math are fp32.
+ * Storage dtype is bf16 (uint16 raw bits == torch.bfloat16); accumulation and softmax/norm math are fp32.  One exception since ABI 7:
+ * the RESIDUAL STREAM (decoder x, CLIP tower x, the pre-LayerNorm sums of the post-LN encoders) may be - and in crab_amd is - fp32
+ * (crab_gemm_desc.c_fp32 / r_fp32, crab_llama_io.x_fp32, crab_enc_io.x_fp32).
  */
 #ifndef CRAB_HIP_H
 #define CRAB_HIP_H
@@ -74,7 +76,9 @@ typedef struct {
     int32_t tune;      /* 0 = automatic kernel choice; >0 forces a variant (benchmarking only) */
     void* workspace;   /* optional caller-owned scratch for split-K partials (decode regime, 16 < M <= 128); NULL = none */
     int64_t workspace_bytes;
-    /* optional fused post-RMSNorm: norm_out[M,N] = rmsnorm(C) * norm_w (LlamaRMSNorm behind o_proj / down_proj); bf16 C only */
+    /* optional fused post-RMSNorm: norm_out[M,N] (bf16) = rmsnorm(C) * norm_w (LlamaRMSNorm behind o_proj / down_proj).  C bf16: the norm sees the
+     * stored bf16 row and rounds x_hat before the weight multiply (modeling_llama.py:116-117 in bf16).  C fp32 (then R, if given, must be fp32 too:
+     * r_fp32): the norm sees the unrounded row, one rounding of x_hat * w. */
     const void* norm_w; void* norm_out; int64_t ld_norm; float norm_eps;
     /* optional fused RoPE + KV-cache append behind the packed q|k|v projection, ONE ROW PER SEQUENCE (decode): the result
      * is what crab_gemm_bf16 followed by crab_qkv_rope_split(B = M, S = 1) on C would leave - C[:, :H*d] = RoPE(q), the

@@ -62,7 +62,11 @@ def test_bench_runs_its_collectives_on_rccl_with_one_rank():
     distributed branch of the line's path on it - init_process_group(device_id=...), barrier, the all_reduce(MIN) of the batch choice, the padded
     result gather on device tensors, all_gather / all_reduce(MAX) of the timings, all_gather_object of the per-rank records.  One rank is all a
     one-GPU box can host; what this pins is that the RCCL branch EXECUTES (it never had before r04), not that ranks exchange data."""
-    env = dict(os.environ, CRAB_BENCH_FORCE_DIST="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, CRAB_BENCH_FORCE_DIST="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     env.pop("CRAB_BENCH_BACKEND", None)
     env.pop("CRAB_BENCH_SINGLE_DEVICE", None)
     r = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--clips", "3", "--new-tokens", "4", "--steps", "1", "--warmup", "1",
