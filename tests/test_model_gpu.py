@@ -717,6 +717,38 @@ def test_adapter_rank_outside_the_small_batch_tail_limits_still_generates(r, nl)
         assert err < REL_DEC * ref_logits.abs().max().item(), (B, err)
 
 
+def test_decode_batch_between_256_and_512_rows_two_row_groups_tiny():
+    """A decode batch of 300 rows (two row groups, the second one ragged: 44 rows) on the tiny hyper-LoRA Llama through generate()'s captured graph:
+    the C sequencer and the Python sequence agree bit for bit, rows are independent of the batch they decode in (rows 0, 255, 256, 299 vs the same
+    prompts decoded as a batch of 4: the skinny kernels - same ids wherever the margin allows, logits within the decoder tolerance), and the oracle
+    agrees on those rows."""
+    from crab_amd.peft_hyper import LoraConfig, get_peft_model
+    from crab_amd.unified_llama import UnifiedConfig, UnifiedForCausalLM
+    from oracle import crab_oracle as O
+    meta, A = load_fixture("full_tiny_llama")
+    W = weights_from_table(meta)
+    cfg = UnifiedConfig(**meta["dec"], pad_token_id=meta["pad_token_id"])
+    model = get_peft_model(UnifiedForCausalLM(cfg, device="cuda"), LoraConfig())
+    model.load_state_dict({k: v for k, v in W.items() if ".layers." in k or "embed_tokens" in k or "lm_head" in k or k.endswith("model.norm.weight")}, strict=False)
+    g = torch.Generator().manual_seed(17)
+    B, S, n = 300, 9, 5
+    emb = (torch.randn(B, S, cfg.hidden_size, generator=g) * 0.5).to(BF).cuda()
+    outs = _gen_both_sequencers(model, emb, n)
+    for ids, logits in outs[1:]:
+        assert torch.equal(ids, outs[0][0]) and torch.equal(logits, outs[0][1])
+    ids, logits = outs[0][0].cpu(), outs[0][1].float().cpu()
+    rows = [0, 255, 256, 299]
+    eng = model.base_model.model._engine
+    sids, slog = eng.generate(emb[rows], n, eos_token_id=None, pad_token_id=2, return_step_logits=True)
+    Wo = {k: v.to(BF).float() for k, v in O.strip_peft_prefix(W).items() if v.dtype.is_floating_point}
+    ocfg = O.DecoderConfig(**meta["dec"])
+    ref_ids, ref_logits = O.greedy_generate(emb[rows].float().cpu(), Wo, ocfg, n)
+    worst = _check_ids(ids[rows], ref_ids, ref_logits, logits[rows], min_frac=0.75)
+    assert worst < REL_DEC * ref_logits.abs().max().item(), worst
+    _check_ids(sids.cpu(), ref_ids, ref_logits, slog.float().cpu(), min_frac=0.75)
+    assert _rel(logits[rows][:, 0], slog.float().cpu()[:, 0], "tiny Llama: rows of a 300-row decode batch vs the same rows as a batch of 4, first step (HIP vs HIP)") < REL_DEC
+
+
 def test_single_layer_entry_points_equal_the_stack_call():
     """crab_llama_layer_prefill / crab_llama_layer_decode called layer by layer == crab_llama_layers over the table (tiny Llama,
     hyper-LoRA): x and h after the stack bit-identical, prefill (S = 9) and one decode step; argument validation of the io block."""
