@@ -401,7 +401,7 @@ class GenerationEngine:
         ldq = qkv.stride(0)
         layers = self.model.layers
         ops.rmsnorm(x, layers[0].input_layernorm.weight, c.rms_norm_eps, out=h)
-        timed = ops.PROFILER is not None and not torch.cuda.is_current_stream_capturing()
+        timed = ops.per_launch_profiling() and not torch.cuda.is_current_stream_capturing()
         masked = pos_ids is not None or kv_start is not None
         if NATIVE_LAYERS and not timed and not masked and kc.is_contiguous() and vc.is_contiguous() and (vt is not None or S == 1):
             self._layers_native(ws, B, S, kc, vc, b0, Tmax, pos0, pos_dev, vt)

@@ -34,7 +34,7 @@ NATIVE_ENC_LAYERS = True      # False: issue every launch of an encoder layer fr
 def _native_layers() -> bool:
     """One C call per encoder layer - unless a per-launch profiler is attached (bench.py times individual GEMM launches through
     ops.gemm; the C sequencers issue the same launches but outside its view), like crab_amd/decoder.py does for the decoder layers."""
-    return NATIVE_ENC_LAYERS and ops.PROFILER is None
+    return NATIVE_ENC_LAYERS and not ops.per_launch_profiling()
 
 
 def _dense(lin) -> "_lib.Dense":

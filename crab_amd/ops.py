@@ -45,9 +45,12 @@ class KernelProfiler:
     decode steps GenerationEngine.generate runs eagerly (every `decode_every`-th step; the eager step is bit-identical
     to the HIP-graph replay it stands in for, tests/test_model_gpu.py)."""
 
-    def __init__(self, min_m: int = 512, decode_every: int = 32):
-        self.min_m = min_m
-        self.decode_every = decode_every
+    def __init__(self, min_m: int = 512, decode_every: int = 32, phase_only: bool = False):
+        """phase_only: record nothing but the three phase marks of a generate() call (encode_begin / prefill_end / decode_end) - the SHIPPED path
+        runs underneath (native layer sequencers, every decode step a graph replay); three event records per call are the whole footprint."""
+        self.phase_only = phase_only
+        self.min_m = (1 << 62) if phase_only else min_m
+        self.decode_every = 0 if phase_only else decode_every
         self.decode_ctx = 0          # live KV length of the sampled step (host mirror of the device position word)
         self.decode_eager = False    # set by GenerationEngine.generate around a sampled eager decode step
         self.marks = []              # (phase name, event)
@@ -92,6 +95,12 @@ class KernelProfiler:
 GemmProfiler = KernelProfiler
 
 PROFILER: Optional[KernelProfiler] = None
+
+
+def per_launch_profiling() -> bool:
+    """True while a profiler that times individual launches is attached: the layer sequences then run launch by launch from Python (same launches,
+    same order) so that ops.gemm sees every GEMM; a phase-only profiler leaves the native C sequencers in place."""
+    return PROFILER is not None and not PROFILER.phase_only
 
 
 def _variant(M: int, N: int, batch: int = 1, K: int = 4096) -> str:
