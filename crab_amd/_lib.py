@@ -52,6 +52,7 @@ class AttnDesc(C.Structure):
         ("B", C.c_int32), ("H", C.c_int32), ("Hk", C.c_int32), ("Sq", C.c_int32), ("Skv", C.c_int32),
         ("head_dim", C.c_int32), ("causal", C.c_int32), ("scale", C.c_float),
         ("kv_start", C.c_void_p),
+        ("key_mask", C.c_void_p), ("key_mask_ld", C.c_int64),
     ]
 
 
@@ -164,6 +165,7 @@ SYMBOLS = {
     "crab_qkv_rope_split": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "crab_qkv_rope_split_ids": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i64]),
     "crab_attn_decode_masked": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _vp, _f, _vp]),
+    "crab_attn_decode_keymask": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _vp, _f, _vp, _i64]),
     "crab_attn_fwd": (_i, [_vp, _vp, C.POINTER(AttnDesc)]),
     "crab_attn_decode": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _vp, _f]),
     "crab_swiglu": (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _i, _i]),

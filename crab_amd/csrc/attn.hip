@@ -24,6 +24,7 @@ struct AttnP {
     long q_bs, q_hs, q_ss, k_bs, k_hs, k_ss, vt_bs, vt_hs, vt_ds, o_bs, o_ss;
     const float* bias; const float* gate;
     const int* kv_start;                    // optional [B]: keys j < kv_start[b] are masked (left-pad attention_mask)
+    const uint32_t* key_mask; long key_mask_ld;   // optional [B][key_mask_ld] words: bit (j & 31) of word j >> 5 = key j is visible (any 2-D attention_mask)
     int B, H, Hk, Sq, Skv, causal;
     float scale;
 };
@@ -90,6 +91,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
     // below it are skipped.  A query row that sees no key at all (a pad row) ends with l_run == 0 and stores zeros.
     const int ks0 = p.kv_start ? p.kv_start[b] : 0;
     const int t0 = ks0 / KT;
+    // general 2-D attention_mask (holes anywhere): one visibility bit per key, tested on every tile (block-uniform pointer test)
+    const uint32_t* km = p.key_mask ? p.key_mask + (long)b * p.key_mask_ld : nullptr;
 
     // Software pipeline: the global loads of tile t+1 are issued (into registers) right after tile t has been stored to LDS,
     // so their latency runs under tile t's MFMAs and softmax.  Synchronous staging left the waves parked 70 % of the time
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
         // can contain masked keys (the diagonal tile of a causal block, the ragged last tile): after the software
         // pipelining the kernel is VALU-bound (PMC: VALU active 30 % of wave cycles at two waves per SIMD).
         const float sc2 = p.scale * 1.4426950408889634f;
-        const bool need_mask = (kv0 + KT > p.Skv) || (CAUSAL && (kv0 + KT - 1 > q0 + wave * 16 + koff)) || (kv0 < ks0);
+        const bool need_mask = (kv0 + KT > p.Skv) || (CAUSAL && (kv0 + KT - 1 > q0 + wave * 16 + koff)) || (kv0 < ks0) || km;
         float tmax = -1e30f;
         if (BIAS || need_mask) {
 #pragma unroll
@@ -184,6 +187,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
                     if (BIAS) { if (kv < p.Skv) v += gate * biasrow[kv] * 1.4426950408889634f; }
                     bool ok = kv < p.Skv && kv >= ks0;
                     if (CAUSAL) ok = ok && (kv <= qrow + koff);
+                    if (km) ok = ok && ((km[min(kv, p.Skv - 1) >> 5] >> (kv & 31)) & 1u);
                     v = ok ? v : -INFINITY;
                     s[j][r] = v;
                     tmax = fmaxf(tmax, v);
@@ -307,6 +311,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(AttnP p) {
     const int ntiles = (kv_end + KT - 1) / KT;
     const int ks0 = p.kv_start ? p.kv_start[b] : 0;             // left-pad mask: keys below it are invisible, whole tiles skipped
     const int t0 = ks0 / KT;
+    const uint32_t* km = p.key_mask ? p.key_mask + (long)b * p.key_mask_ld : nullptr;      // general 2-D attention_mask: a visibility bit per key
     constexpr int NKV = (KT * CPR) / 256, NVV = (HD * 8) / 256;
     u32x4 kreg[NKV], vreg[NVV];
 #define ATT_STORE_TILE(BUF_, T_)                                                                               \
@@ -375,7 +380,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(AttnP p) {
             // ---- mask (only on tiles that can hold masked keys: the diagonal of a causal block, the ragged last tile, the tile the
             // left-pad boundary falls in); lane holds keys kv0 + 32 j + 8 (r >> 2) + 4 g + (r & 3) of its query row.  The scores stay RAW:
             // the running maximum is kept in the scaled log2 domain and the scale rides in the exponent's fma, exp2(s * sc2 - m).
-            const bool need_mask = (kv0 + KT > p.Skv) || (CAUSAL && (kv0 + KT - 1 > qw0 + koff)) || (kv0 < ks0);
+            const bool need_mask = (kv0 + KT > p.Skv) || (CAUSAL && (kv0 + KT - 1 > qw0 + koff)) || (kv0 < ks0) || km;
             if (need_mask) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
@@ -384,6 +389,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(AttnP p) {
                         const int kv = kv0 + j * 32 + (r >> 2) * 8 + fg * 4 + (r & 3);
                         bool ok = kv < p.Skv && kv >= ks0;
                         if (CAUSAL) ok = ok && (kv <= qrow + koff);
+                        if (km) ok = ok && ((km[min(kv, p.Skv - 1) >> 5] >> (kv & 31)) & 1u);
                         s[j][r] = ok ? s[j][r] : -INFINITY;
                     }
             }
@@ -562,6 +568,76 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
             O += so[g][tid] * w;
         }
         o[(long)b * ldo + (long)h * HD + tid] = f2bf(O / L);
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------- decode under a general key mask
+// forward()'s one-token shortcut (models/unified_llama.py:125-127) with a 2-D attention_mask that has holes anywhere (HF accepts any
+// mask: modeling_attn_mask_utils' padding mask AND-ed with the causal one): the per-(b, h) kernel above with a visibility bit per cache
+// row - bit (j & 31) of word j >> 5 of the sequence's mask row; invisible rows are skipped before their loads.  A rare path (the eval
+// loop never masks the cache), kept out of the benchmark kernels: plain loads, one key per 16-lane group and trip.
+template <int HD>
+__global__ __launch_bounds__(256) void attn_decode_keymask_kernel(const bf16_t* __restrict__ q, long ldq, const bf16_t* __restrict__ kc,
+                                                                  const bf16_t* __restrict__ vc, bf16_t* __restrict__ o, long ldo, int H, int Hk,
+                                                                  int Tmax, int ctx_host, const int* __restrict__ ctx_dev, float scale,
+                                                                  const uint32_t* __restrict__ key_mask, long key_mask_ld) {
+    constexpr int EPL = HD / 16, WPL = EPL / 2;
+    __shared__ float sm[16], sl[16];
+    __shared__ float so[16][HD];
+    const int tid = threadIdx.x;
+    const int grp = tid >> 4, sub = tid & 15;
+    const int b = blockIdx.y, h = blockIdx.x;
+    const int hk = h / (H / Hk);
+    const int ctx = ctx_host + (ctx_dev ? ctx_dev[0] : 0);
+    const uint32_t* km = key_mask + (long)b * key_mask_ld;
+    const bf16_t* qp = q + (long)b * ldq + (long)h * HD + sub * EPL;
+    float qv[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) qv[e] = bf2f(qp[e]) * scale;
+    const bf16_t* kb = kc + ((long)b * Hk + hk) * (long)Tmax * HD + sub * EPL;
+    const bf16_t* vb = vc + ((long)b * Hk + hk) * (long)Tmax * HD + sub * EPL;
+    float m = -1e30f, l = 0.f, acc[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) acc[e] = 0.f;
+    for (int j = grp; j < ctx; j += 16) {
+        if (!((km[j >> 5] >> (j & 31)) & 1u)) continue;          // group-uniform
+        uint32_t kw[WPL], vw[WPL];
+#pragma unroll
+        for (int w = 0; w < WPL; ++w) {
+            kw[w] = reinterpret_cast<const uint32_t*>(kb + (long)j * HD)[w];
+            vw[w] = reinterpret_cast<const uint32_t*>(vb + (long)j * HD)[w];
+        }
+        float sdot = 0.f;
+#pragma unroll
+        for (int w = 0; w < WPL; ++w) sdot += qv[2 * w] * lo_bf(kw[w]) + qv[2 * w + 1] * hi_bf(kw[w]);
+        sdot = row16_sum(sdot);
+        const float mn = fmaxf(m, sdot);
+        const float a = __expf(m - mn), pw = __expf(sdot - mn);
+        l = l * a + pw;
+#pragma unroll
+        for (int w = 0; w < WPL; ++w) {
+            acc[2 * w] = acc[2 * w] * a + pw * lo_bf(vw[w]);
+            acc[2 * w + 1] = acc[2 * w + 1] * a + pw * hi_bf(vw[w]);
+        }
+        m = mn;
+    }
+    if (sub == 0) { sm[grp] = m; sl[grp] = l; }
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) so[grp][sub * EPL + e] = acc[e];
+    __syncthreads();
+    if (tid < HD) {
+        float M = -1e30f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) M = fmaxf(M, sm[g]);
+        float L = 0.f, O = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const float w = __expf(sm[g] - M);
+            L += sl[g] * w;
+            O += so[g][tid] * w;
+        }
+        o[(long)b * ldo + (long)h * HD + tid] = f2bf(L > 0.f ? O / L : 0.f);     // no visible key at all (a pad row): zeros, like the prefill kernels
     }
 }
 
@@ -996,11 +1072,13 @@ extern "C" int crab_attn_fwd(crab_ctx* ctx, void* stream, const crab_attn_desc* 
         return crab_fail(ctx, CRAB_E_INVALID, "attn_fwd: pointer alignment");
     if (d->causal && d->Skv < d->Sq) return crab_fail(ctx, CRAB_E_INVALID, "attn_fwd: causal needs Skv >= Sq");
     if ((d->bias == nullptr) && d->gate) return crab_fail(ctx, CRAB_E_INVALID, "attn_fwd: gate without bias");
+    if (d->key_mask && (d->key_mask_ld < (d->Skv + 31) / 32 || d->head_dim == 32))
+        return crab_fail(ctx, CRAB_E_INVALID, "attn_fwd: key_mask needs key_mask_ld >= ceil(Skv / 32) words per sequence (head_dim 64 / 128)");
     AttnP p;
     p.q = (const bf16_t*)d->q; p.k = (const bf16_t*)d->k; p.vt = (const bf16_t*)d->vt; p.o = (bf16_t*)d->o;
     p.q_bs = d->q_bs; p.q_hs = d->q_hs; p.q_ss = d->q_ss; p.k_bs = d->k_bs; p.k_hs = d->k_hs; p.k_ss = d->k_ss;
     p.vt_bs = d->vt_bs; p.vt_hs = d->vt_hs; p.vt_ds = d->vt_ds; p.o_bs = d->o_bs; p.o_ss = d->o_ss;
-    p.bias = d->bias; p.gate = d->gate; p.kv_start = d->kv_start; p.B = d->B; p.H = d->H; p.Hk = d->Hk; p.Sq = d->Sq; p.Skv = d->Skv;
+    p.bias = d->bias; p.gate = d->gate; p.kv_start = d->kv_start; p.key_mask = d->key_mask; p.key_mask_ld = d->key_mask_ld; p.B = d->B; p.H = d->H; p.Hk = d->Hk; p.Sq = d->Sq; p.Skv = d->Skv;
     p.causal = d->causal; p.scale = d->scale;
     dim3 grid(((d->Sq + 63) / 64) * d->H * d->B), block(256);
     hipStream_t s = (hipStream_t)stream;
@@ -1066,6 +1144,26 @@ extern "C" int crab_attn_decode_rope(crab_ctx* ctx, void* stream, const void* qk
         hipLaunchKernelGGL((attn_decode_rope_kernel<64>), grid, block, 0, s, (const bf16_t*)qkv, (long)ldqkv, rope_tab, (bf16_t*)k_cache,
                            (bf16_t*)v_cache, (bf16_t*)o, (long)ldo, H, Hk, Tmax, pos0, pos_dev, scale, part, counters);
     return crab_check_launch(ctx, "attn_decode_rope");
+}
+
+extern "C" int crab_attn_decode_keymask(crab_ctx* ctx, void* stream, const void* q, int64_t ldq, const void* k_cache, const void* v_cache,
+                                        void* o, int64_t ldo, int B, int H, int Hk, int d, int Tmax, int ctx_len_host, const int32_t* ctx_dev,
+                                        float scale, const uint32_t* key_mask, int64_t key_mask_ld) {
+    if (!ctx) return CRAB_E_INVALID;
+    if (!q || !k_cache || !v_cache || !o || !key_mask || B <= 0 || H <= 0 || Hk <= 0 || H % Hk) return crab_fail(ctx, CRAB_E_INVALID, "attn_decode_keymask: bad argument");
+    if (d != 64 && d != 128) return crab_fail(ctx, CRAB_E_UNSUPPORTED, "attn_decode_keymask: head_dim must be 64 or 128");
+    if (!ctx_dev && (ctx_len_host <= 0 || ctx_len_host > Tmax)) return crab_fail(ctx, CRAB_E_INVALID, "attn_decode_keymask: ctx_len out of range");
+    if (key_mask_ld < ((ctx_dev ? Tmax : ctx_len_host) + 31) / 32)
+        return crab_fail(ctx, CRAB_E_INVALID, "attn_decode_keymask: key_mask_ld must cover the visible context (ceil(ctx_len / 32) words, Tmax with ctx_dev)");
+    dim3 grid(H, B), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (d == 128)
+        hipLaunchKernelGGL((attn_decode_keymask_kernel<128>), grid, block, 0, s, (const bf16_t*)q, (long)ldq, (const bf16_t*)k_cache, (const bf16_t*)v_cache,
+                           (bf16_t*)o, (long)ldo, H, Hk, Tmax, ctx_len_host, ctx_dev, scale, key_mask, (long)key_mask_ld);
+    else
+        hipLaunchKernelGGL((attn_decode_keymask_kernel<64>), grid, block, 0, s, (const bf16_t*)q, (long)ldq, (const bf16_t*)k_cache, (const bf16_t*)v_cache,
+                           (bf16_t*)o, (long)ldo, H, Hk, Tmax, ctx_len_host, ctx_dev, scale, key_mask, (long)key_mask_ld);
+    return crab_check_launch(ctx, "attn_decode_keymask");
 }
 
 extern "C" int crab_attn_decode_masked(crab_ctx* ctx, void* stream, const void* q, int64_t ldq, const void* k_cache, const void* v_cache,

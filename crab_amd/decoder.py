@@ -386,12 +386,13 @@ class GenerationEngine:
     # ------------------------------------------------------------------ one pass over the layers
     def _layers(self, ws: _Workspace, B: int, S: int, kc: torch.Tensor, vc: torch.Tensor, b0: int, Tmax: int, pos0: int,
                 pos_dev: Optional[torch.Tensor], vt: Optional[torch.Tensor], pos_ids: Optional[torch.Tensor] = None,
-                kv_start: Optional[torch.Tensor] = None):
+                kv_start: Optional[torch.Tensor] = None, key_mask: Optional[torch.Tensor] = None):
         """x (ws.x[:B*S]) -> x after all layers.  Prefill when vt is given (S rows per sequence, positions pos0..),
         decode otherwise (S == 1, position read from pos_dev).  kc/vc: [L, Btot, Hk, Tmax, d]; rows b0..b0+B.
-        pos_ids (int32 [B, S]) / kv_start (int32 [B]): forward()'s position_ids and left-pad attention_mask
-        (unified_llama.py:149-160) - explicit rotary positions and a per-sequence first visible key; they select the
-        per-launch sequence below (RoPE as its own pass), which is not the benchmarked path."""
+        pos_ids (int32 [B, S]) / kv_start (int32 [B]) / key_mask (int32 [B, words], ops.pack_key_mask): forward()'s position_ids and
+        attention_mask (unified_llama.py:149-160) - explicit rotary positions, a per-sequence first visible key (left padding) or a
+        visibility bit per key (any other mask); they select the per-launch sequence below (RoPE as its own pass), which is not the
+        benchmarked path."""
         c = self.cfg
         H, Hk, d = c.num_attention_heads, c.num_key_value_heads, c.head_dim
         M = B * S
@@ -402,7 +403,7 @@ class GenerationEngine:
         layers = self.model.layers
         ops.rmsnorm(x, layers[0].input_layernorm.weight, c.rms_norm_eps, out=h)
         timed = ops.per_launch_profiling() and not torch.cuda.is_current_stream_capturing()
-        masked = pos_ids is not None or kv_start is not None
+        masked = pos_ids is not None or kv_start is not None or key_mask is not None
         if NATIVE_LAYERS and not timed and not masked and kc.is_contiguous() and vc.is_contiguous() and (vt is not None or S == 1):
             self._layers_native(ws, B, S, kc, vc, b0, Tmax, pos0, pos_dev, vt)
             return x, h
@@ -436,11 +437,11 @@ class GenerationEngine:
                 Sp = vt.shape[-1]
                 ops.attn_fwd(qkv, kcl, vt, att, q_strides=(S * ldq, d, ldq), k_strides=(Hk * Tmax * d, Tmax * d, d),
                              vt_strides=(Hk * d * Sp, d * Sp, Sp), o_strides=(S * H * d, H * d), B=B, H=H, Hk=Hk, Sq=S,
-                             Skv=pos0 + S, head_dim=d, scale=scale, causal=True, kv_start=kv_start)
+                             Skv=pos0 + S, head_dim=d, scale=scale, causal=True, kv_start=kv_start, key_mask=key_mask)
             elif fuse_attn:
                 ops.attn_decode_rope(qkv, tab, kcl, vcl, att, B, H, Hk, d, Tmax, pos0, scale, pos_dev=pos_dev, workspace=ws.attn_ws)
             else:
-                ops.attn_decode(qkv, kcl, vcl, att, B, H, Hk, d, Tmax, pos0 + 1, scale, ctx_dev=pos_dev, kv_start=kv_start)
+                ops.attn_decode(qkv, kcl, vcl, att, B, H, Hk, d, Tmax, pos0 + 1, scale, ctx_dev=pos_dev, kv_start=kv_start, key_mask=key_mask)
             # x += o_proj(att); h = rmsnorm(x) * post_attention_layernorm  (norm fused into the GEMM epilogue for small M)
             # (decode regime) the row-owning epilogue that produces h also evaluates the router of the group that consumes h
             ahead_gu = m._gu.routes_ahead(M)
@@ -460,7 +461,7 @@ class GenerationEngine:
     # ------------------------------------------------------------------ prefill
     def prefill(self, embeds: torch.Tensor, kc: torch.Tensor, vc: torch.Tensor, b0: int = 0, all_logits: bool = False,
                 logits_out: Optional[torch.Tensor] = None, hn_out: Optional[torch.Tensor] = None,
-                pos_ids: Optional[torch.Tensor] = None, kv_start: Optional[torch.Tensor] = None):
+                pos_ids: Optional[torch.Tensor] = None, kv_start: Optional[torch.Tensor] = None, key_mask: Optional[torch.Tensor] = None):
         """embeds [B,S,D] bf16 -> (fp32 logits, post-final-norm hidden) of the LAST row ([B,V], [B,D]), or of all
         rows with all_logits ([B,S,V], [B,S,D]); fills cache rows b0..b0+B.  The reference computes lm_head on all
         S rows and discards S-1 of them (modeling_llama.py:1260); generate() only needs the last row
@@ -475,7 +476,7 @@ class GenerationEngine:
         ops.cast_rows(embeds.reshape(M, D), ws.x, M, D)          # bf16 inputs_embeds -> the (fp32) residual stream
         Sp = (S + 7) // 8 * 8
         vt = torch.empty((B, c.num_key_value_heads, c.head_dim, Sp), device=self.device, dtype=BF16)
-        x, hfin = self._layers(ws, B, S, kc, vc, b0, Tmax, 0, None, vt, pos_ids=pos_ids, kv_start=kv_start)   # hfin = model.norm(x), all rows
+        x, hfin = self._layers(ws, B, S, kc, vc, b0, Tmax, 0, None, vt, pos_ids=pos_ids, kv_start=kv_start, key_mask=key_mask)   # hfin = model.norm(x), all rows
         if all_logits:
             hn = hfin.clone()
             logits = ops.gemm(hn, self.lm_head.weight, out_fp32=True, prof_class="head")

@@ -345,9 +345,10 @@ def qkv_rope_split(qkv: torch.Tensor, rope_tab: Optional[torch.Tensor], k_cache:
 
 
 def attn_fwd(q, k, vt, o, *, q_strides, k_strides, vt_strides, o_strides, B, H, Hk, Sq, Skv, head_dim, scale, causal=False,
-             bias=None, gate=None, kv_start=None):
+             bias=None, gate=None, kv_start=None, key_mask=None):
     """Strided flash attention; *_strides = (batch, head, row) element strides, o_strides = (batch, row).
-    kv_start (int32 [B]): keys below kv_start[b] are masked (left-pad attention_mask)."""
+    kv_start (int32 [B]): keys below kv_start[b] are masked (left-pad attention_mask); key_mask (int32 [B, >= ceil(Skv / 32)], one
+    visibility bit per key: pack_key_mask): any 2-D attention_mask."""
     d = _dev(q)
     a = AttnDesc()
     a.q, a.k, a.vt, a.o = q.data_ptr(), k.data_ptr(), vt.data_ptr(), o.data_ptr()
@@ -358,13 +359,37 @@ def attn_fwd(q, k, vt, o, *, q_strides, k_strides, vt_strides, o_strides, B, H, 
     a.bias = bias.data_ptr() if bias is not None else None
     a.gate = gate.data_ptr() if gate is not None else None
     a.kv_start = kv_start.data_ptr() if kv_start is not None else None
+    if key_mask is not None:
+        if key_mask.dtype != torch.int32 or key_mask.dim() != 2 or key_mask.stride(1) != 1 or key_mask.shape[0] != B:
+            raise ValueError("key_mask must be an int32 [B, words] tensor with contiguous rows (ops.pack_key_mask)")
+        a.key_mask, a.key_mask_ld = key_mask.data_ptr(), key_mask.stride(0)
     a.B, a.H, a.Hk, a.Sq, a.Skv, a.head_dim, a.causal, a.scale = B, H, Hk, Sq, Skv, head_dim, 1 if causal else 0, scale
     _lib.check(_lib.load().crab_attn_fwd(_lib.ctx(d), _stream(), C.byref(a)), d)
     return o
 
 
-def attn_decode(q, k_cache, v_cache, o, B, H, Hk, head_dim, Tmax, ctx_len, scale, ctx_dev=None, kv_start=None):
+def pack_key_mask(mask: torch.Tensor) -> torch.Tensor:
+    """2-D attention_mask [B, T] (non-zero = attend) -> int32 [B, ceil(T / 32)] visibility words, bit (j & 31) of word j >> 5 = key j
+    (crab_attn_desc.key_mask's layout), on the mask's device."""
+    m = mask.reshape(mask.shape[0], -1).ne(0)
+    B, T = m.shape
+    W = (T + 31) // 32
+    mp = torch.zeros(B, W * 32, dtype=torch.int64, device=m.device)
+    mp[:, :T] = m
+    v = (mp.view(B, W, 32) << torch.arange(32, device=m.device)).sum(-1)
+    return torch.where(v >= 2 ** 31, v - 2 ** 32, v).to(torch.int32).contiguous()
+
+
+def attn_decode(q, k_cache, v_cache, o, B, H, Hk, head_dim, Tmax, ctx_len, scale, ctx_dev=None, kv_start=None, key_mask=None):
     d = _dev(q)
+    if key_mask is not None:                          # general attention_mask over the cache rows: its own (rare-path) kernel
+        if kv_start is not None:
+            raise ValueError("attn_decode: key_mask already carries the left padding, pass one of the two")
+        if key_mask.dtype != torch.int32 or key_mask.dim() != 2 or key_mask.stride(1) != 1 or key_mask.shape[0] != B:
+            raise ValueError("key_mask must be an int32 [B, words] tensor with contiguous rows (ops.pack_key_mask)")
+        _lib.check(_lib.load().crab_attn_decode_keymask(_lib.ctx(d), _stream(), _p(q), q.stride(0), _p(k_cache), _p(v_cache), _p(o), o.stride(0),
+                                                        B, H, Hk, head_dim, Tmax, ctx_len, _p(ctx_dev), scale, _p(key_mask), key_mask.stride(0)), d)
+        return o
     prof = PROFILER
     sample = prof is not None and prof.decode_eager and prof.decode_ctx > 0 and not torch.cuda.is_current_stream_capturing()
     if sample:

@@ -10,9 +10,10 @@ Differences a caller can observe, all deliberate:
     to the decoder (unified_llama.py:261-267): left pads are attended and positions run 0..S-1 (A.1) -- reproduced.
     The reference's forward() DOES pass them on (unified_llama.py:129-160, the training-time batch path) and so does
     forward() here: a LEFT-padded attention_mask becomes a per-sequence first visible key in the attention kernels and
-    position_ids become explicit rotary positions (golden: forward_masked_tiny_llama.npz).  Masks with interior holes raise
-    NotImplementedError.  The logits of a pad row (a query that sees no key) are undefined in the reference
-    (implementation-dependent softmax over an all-masked row) and finite garbage here; no valid row depends on them.
+    position_ids become explicit rotary positions (golden: forward_masked_tiny_llama.npz); any other 2-D mask (holes anywhere, which
+    HF's mask utilities accept) becomes one visibility bit per key (golden: forward_holes_tiny_llama.npz).  The logits of a query
+    that sees no key at all (a pad row) are undefined in the reference (implementation-dependent softmax over an all-masked row)
+    and finite garbage here; no valid row depends on them.
   * the model lives in bf16 on the GPU (the whole-model bf16 conversion of inference_hyper_lora.py:1470, A.8).
 """
 from __future__ import annotations
@@ -167,7 +168,7 @@ class UnifiedForCausalLM(nn.Module, UnifiedMetaForCausalLM):
                 raise ValueError(f"KV cache is full: position {n} >= capacity {kc.shape[3]} (the prefill call sized it as "
                                  f"round64(S + 64)); re-run the prefill with a longer cache")
             B = input_ids.shape[0]
-            kv_start = self._left_pad_start(attention_mask, B, n + 1)
+            kv_start, key_mask = self._key_visibility(attention_mask, B, n + 1, kc.shape[3])
             pos_ids = None
             if position_ids is not None and not bool((position_ids.reshape(-1) == n).all()):
                 pos_ids = self._rotary_positions(position_ids, B, 1, kc.shape[3])
@@ -176,7 +177,7 @@ class UnifiedForCausalLM(nn.Module, UnifiedMetaForCausalLM):
             ws = eng._workspace(B)
             ops.cast_rows(emb, ws.x, B, emb.shape[1])
             pos = torch.full((1,), n, device=dev, dtype=torch.int32)
-            x, hfin = eng._layers(ws, B, 1, kc, vc, 0, kc.shape[3], 0, pos, None, pos_ids=pos_ids, kv_start=kv_start)
+            x, hfin = eng._layers(ws, B, 1, kc, vc, 0, kc.shape[3], 0, pos, None, pos_ids=pos_ids, kv_start=kv_start, key_mask=key_mask)
             hn = hfin.clone()
             logits = ops.gemm(hn, self.lm_head.weight, out_fp32=True)
             return CausalLMOutput(logits.view(B, 1, -1), (hn.view(B, 1, -1),) if output_hidden_states else None, (kc, vc, n + 1))
@@ -191,29 +192,34 @@ class UnifiedForCausalLM(nn.Module, UnifiedMetaForCausalLM):
         inputs_embeds = inputs_embeds.to(device=dev, dtype=BF16)
         B, S, _ = inputs_embeds.shape
         Tmax = (S + 64 + 63) // 64 * 64 if use_cache else (S + 63) // 64 * 64
-        kv_start = self._left_pad_start(attention_mask, B, S)
+        kv_start, key_mask = self._key_visibility(attention_mask, B, S, S)
         pos_ids = None
         if position_ids is not None and not bool((position_ids.reshape(-1, S).cpu() == torch.arange(S)).all()):
             pos_ids = self._rotary_positions(position_ids, B, S, Tmax)
             eng._rope_tab(self._rope_need)
         kc, vc = eng.alloc_cache(B, Tmax)
-        logits, hn = eng.prefill(inputs_embeds, kc, vc, all_logits=True, pos_ids=pos_ids, kv_start=kv_start)
+        logits, hn = eng.prefill(inputs_embeds, kc, vc, all_logits=True, pos_ids=pos_ids, kv_start=kv_start, key_mask=key_mask)
         return CausalLMOutput(logits, (hn,) if output_hidden_states else None, (kc, vc, S) if use_cache else None)
 
-    def _left_pad_start(self, attention_mask, B: int, T: int):
-        """2-D attention_mask [B, T] over ALL keys (cached + new) -> int32 [B] index of the first visible key per sequence, or None
-        when nothing is masked.  Only left padding (zeros, then ones: what prepare_multimodal_inputs builds, unified_arch.py:344-348)."""
+    def _key_visibility(self, attention_mask, B: int, T: int, width: int):
+        """2-D attention_mask [B, T] over ALL keys (cached + new) -> (kv_start, key_mask) for the attention kernels, at most one of them set:
+        nothing masked -> (None, None); left padding (zeros, then ones: what prepare_multimodal_inputs builds, unified_arch.py:344-348) ->
+        int32 [B] index of the first visible key per sequence (whole key tiles below it are skipped); any other mask (holes anywhere: HF's
+        mask utilities AND the padding mask with the causal one whatever its shape) -> int32 [B, ceil(width / 32)] visibility words
+        (ops.pack_key_mask), `width` >= T bits wide (the cache capacity for the decode shortcut, whose context length travels as a device word)."""
         if attention_mask is None:
-            return None
+            return None, None
         m = attention_mask.to(torch.bool).reshape(B, -1)
         if m.shape[1] != T:
             raise ValueError(f"attention_mask covers {m.shape[1]} keys, expected {T} (cached + new tokens)")
         if bool(m.all()):
-            return None
+            return None, None
         start = (~m).sum(1)
-        if not bool((m == (torch.arange(T, device=m.device)[None] >= start[:, None])).all()):
-            raise NotImplementedError("forward(): only left-padded attention masks (zeros, then ones) are implemented on the HIP path")
-        return start.to(device=self.device, dtype=torch.int32)
+        if bool((m == (torch.arange(T, device=m.device)[None] >= start[:, None])).all()):
+            return start.to(device=self.device, dtype=torch.int32), None
+        full = torch.zeros(B, max(width, T), dtype=torch.bool, device=m.device)
+        full[:, :T] = m
+        return None, ops.pack_key_mask(full).to(self.device)
 
     def _rotary_positions(self, position_ids, B: int, S: int, Tmax: int):
         """position_ids [B | 1, S] -> contiguous int32 [B, S] on the device (the caller grows the RoPE table to cover them)."""

@@ -210,6 +210,11 @@ typedef struct {
      * decoder (models/unified_llama.py:149-160, prepare_multimodal_inputs' mask :344-373).  A query row left without any visible
      * key (a pad row) produces zeros.  NULL = no mask. */
     const int32_t* kv_start;
+    /* optional general 2-D attention_mask over the keys (HF accepts any mask, not only left padding: modeling_attn_mask_utils'
+     * padding mask AND-ed with the causal one): [B][key_mask_ld] 32-bit words, bit (j & 31) of word j >> 5 set = key j of sequence b is
+     * visible; key_mask_ld >= ceil(Skv / 32).  Combines with causal / kv_start; a query row without a visible key produces zeros
+     * (the reference's softmax over an all-masked row is implementation-defined).  NULL = no mask.  head_dim 64 / 128. */
+    const uint32_t* key_mask; int64_t key_mask_ld;
 } crab_attn_desc;
 int crab_attn_fwd(crab_ctx* ctx, void* stream, const crab_attn_desc* d);
 
@@ -224,6 +229,12 @@ int crab_attn_decode(crab_ctx* ctx, void* stream, const void* q, int64_t ldq, co
 int crab_attn_decode_masked(crab_ctx* ctx, void* stream, const void* q, int64_t ldq, const void* k_cache, const void* v_cache,
                             void* o, int64_t ldo, int B, int H, int Hk, int d, int Tmax, int ctx_len_host,
                             const int32_t* ctx_dev, float scale, const int32_t* kv_start);
+/* Same under a general key mask (crab_attn_desc.key_mask's layout; key_mask_ld >= ceil(ctx_len / 32), Tmax-wide with ctx_dev): the
+ * one-token shortcut of forward() (models/unified_llama.py:125-127) with an attention_mask that has holes.  Per-(b, h) kernel for any
+ * H / Hk; a row without a visible key produces zeros. */
+int crab_attn_decode_keymask(crab_ctx* ctx, void* stream, const void* q, int64_t ldq, const void* k_cache, const void* v_cache,
+                             void* o, int64_t ldo, int B, int H, int Hk, int d, int Tmax, int ctx_len_host, const int32_t* ctx_dev,
+                             float scale, const uint32_t* key_mask, int64_t key_mask_ld);
 
 /* Decode attention of the small-batch layer (B * H < 256 blocks would not fill the chip): RoPE of q and of the new k, the KV-cache
  * append (modeling_llama.py:204-236, 408-412) and the attention over keys 0 .. pos in ONE launch, from the RAW packed q|k|v row

@@ -383,6 +383,39 @@ def golden_id_stats(me, n_clips=24, new=12):
     save("id_stats_tiny_llama", meta, ids=ids_out, logits=logits_out, margin=margin)
 
 
+def golden_holes(me):
+    """forward() with a 2-D attention_mask that is NOT left padding (HF's mask utilities accept any mask - the padding
+    mask is AND-ed with the causal one): the hyper-LoRA tiny Llama decoder alone on seeded embeddings [2, 21, D]; row 0 has two interior
+    holes, row 1 three left pads, a hole and a masked LAST key.  Default positions (arange) and, second run, the cumsum-1 positions a
+    caller would derive from the mask.  Then the 1-token decode shortcut (models/unified_llama.py:125-127) on the kept cache with the mask
+    extended by a visible key.  Rows without any visible key (the left pads of row 1) are undefined and excluded by the tests."""
+    model, cfg = build_full_model(me, TINY_DEC)
+    model.eval()
+    table = load_synth(model, "")
+    um = model.base_model.model
+    g = torch.Generator().manual_seed(33)
+    S = 21
+    emb = torch.randn(2, S, TINY_DEC["hidden_size"], generator=g) * 0.5
+    mask = torch.ones(2, S, dtype=torch.long)
+    mask[0, 4] = 0; mask[0, 11] = 0
+    mask[1, :3] = 0; mask[1, 9] = 0; mask[1, S - 1] = 0
+    fo = super(type(um), um).forward(inputs_embeds=emb, attention_mask=mask, use_cache=True, output_hidden_states=True)
+    pos = (mask.cumsum(-1) - 1).clamp(min=0)
+    fp = super(type(um), um).forward(inputs_embeds=emb, attention_mask=mask, position_ids=pos, use_cache=False)
+    fu = super(type(um), um).forward(inputs_embeds=emb, use_cache=False)
+    seen = mask.cumsum(-1) > 0                                    # query rows with at least one visible key at or before them
+    d = float((fu.logits - fo.logits)[seen].abs().max())
+    print(f"holes: masked vs mask-less logits differ by {d:.3e} on defined rows; scale {float(fo.logits[seen].abs().max()):.3f}")
+    assert d > 1e-2
+    tok = fo.logits[:, -1].argmax(-1)
+    mask2 = torch.cat([mask, torch.ones_like(mask[:, :1])], 1)
+    pos2 = torch.full((2, 1), S, dtype=torch.long)
+    fs = um.forward(input_ids=tok[:, None], attention_mask=mask2, position_ids=pos2, past_key_values=fo.past_key_values, use_cache=True)
+    save("forward_holes_tiny_llama", dict(seed=SEED, dec=TINY_DEC, table=table, eseed=33, maskless_diff=d),
+         embeds=emb, mask=mask, logits=fo.logits, hidden=fo.hidden_states[-1], pos=pos, logits_pos=fp.logits, step_tok=tok, step_mask=mask2,
+         step_pos=pos2, step_logits=fs.logits)
+
+
 def golden_qwen(me):
     model, cfg = build_full_model(me, TINY_QWEN, qwen=True)
     model.eval()
@@ -869,6 +902,8 @@ def main():
         golden_full_qwen(me)
     if "id_stats" in which:
         golden_id_stats(me)
+    if "holes" in which:
+        golden_holes(me)
 
 
 if __name__ == "__main__":

@@ -247,3 +247,45 @@ def test_crab_gather_results_two_ranks_when_two_gpus_are_visible(tmp_path):
         p.join(timeout=120)
         assert p.exitcode == 0
     assert got == list(range(5)) + [1000 + i for i in range(5)]
+
+
+def test_attention_key_mask_against_dense_reference():
+    """crab_attn_desc.key_mask / crab_attn_decode_keymask: one visibility bit per key (any 2-D attention_mask) in both prefill kernels
+    (64-row and 128-row blocks, head_dim 64 and 128) and the decode kernel, against fp32 torch attention with the same mask; a query
+    row without a visible key returns zeros."""
+    import math
+    from crab_amd import ops
+    torch.manual_seed(5)
+    for (B, H, Hk, S, d) in [(2, 4, 4, 200, 128), (3, 4, 2, 50, 64), (2, 2, 2, 257, 64)]:
+        q = (torch.randn(B, S, H, d, device="cuda") * 0.5).to(torch.bfloat16)
+        k = (torch.randn(B, Hk, S, d, device="cuda") * 0.5).to(torch.bfloat16)
+        v = (torch.randn(B, Hk, S, d, device="cuda") * 0.5).to(torch.bfloat16)
+        Sp = (S + 7) // 8 * 8
+        vt = torch.zeros(B, Hk, d, Sp, device="cuda", dtype=torch.bfloat16); vt[..., :S] = v.transpose(2, 3)
+        mask = torch.rand(B, S, device="cuda") > 0.3
+        mask[0, :3] = False                                       # rows 0..2 of sequence 0 see nothing
+        mask[:, S // 2] = False
+        km = ops.pack_key_mask(mask)
+        o = torch.empty(B, S, H * d, device="cuda", dtype=torch.bfloat16)
+        scale = 1.0 / math.sqrt(d)
+        ops.attn_fwd(q, k, vt, o, q_strides=(S * H * d, d, H * d), k_strides=(Hk * S * d, S * d, d), vt_strides=(Hk * d * Sp, d * Sp, Sp),
+                     o_strides=(S * H * d, H * d), B=B, H=H, Hk=Hk, Sq=S, Skv=S, head_dim=d, scale=scale, causal=True, key_mask=km)
+        kk = k.float().repeat_interleave(H // Hk, 1); vv = v.float().repeat_interleave(H // Hk, 1)
+        sc = torch.einsum("bshd,bhtd->bhst", q.float(), kk) * scale
+        allow = torch.tril(torch.ones(S, S, device="cuda", dtype=torch.bool))[None, None] & mask[:, None, None, :]
+        sc = sc.masked_fill(~allow, float("-inf"))
+        p = torch.softmax(sc, -1).nan_to_num(0.0)
+        ref = torch.einsum("bhst,bhtd->bshd", p, vv).reshape(B, S, H * d)
+        assert float((o.float() - ref).abs().max()) < 2e-2, (B, H, Hk, S, d)
+        assert float(o[0, :3].float().abs().max()) == 0.0
+        # decode: the last query row against the cache [B, Hk, Tmax, d] with ctx = S keys
+        qd = q[:, -1].reshape(B, H * d).contiguous(); od = torch.empty_like(qd)
+        ops.attn_decode(qd, k, v, od, B, H, Hk, d, S, S, scale, key_mask=km)
+        assert float((od.float() - ref[:, -1]).abs().max()) < 2e-2
+        pos = torch.full((1,), S - 1, device="cuda", dtype=torch.int32)       # context length as a device word: ctx = 1 + pos
+        od2 = torch.empty_like(qd)
+        ops.attn_decode(qd, k, v, od2, B, H, Hk, d, S, 1, scale, ctx_dev=pos, key_mask=km)
+        assert torch.equal(od, od2)
+    with pytest.raises(Exception, match="key_mask"):
+        ops.attn_fwd(q, k, vt, o, q_strides=(S * H * d, d, H * d), k_strides=(Hk * S * d, S * d, d), vt_strides=(Hk * d * Sp, d * Sp, Sp),
+                     o_strides=(S * H * d, H * d), B=B, H=H, Hk=Hk, Sq=S, Skv=S, head_dim=d, scale=scale, causal=True, key_mask=km[:, :2].contiguous())

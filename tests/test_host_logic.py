@@ -2,6 +2,7 @@
 what the HIP path does not implement, results of generate() do not alias engine state."""
 import pytest
 import torch
+from crab_amd import ops
 
 from crab_amd.peft_hyper import LoraConfig, PackedLinearGroup, get_peft_model
 from crab_amd.unified_llama import UnifiedConfig, UnifiedForCausalLM
@@ -57,14 +58,16 @@ def test_forward_mask_handling_and_full_cache():
     um = _tiny().base_model.model
     emb = torch.zeros(2, 5, 64)
     mask = torch.ones(2, 5, dtype=torch.long)
-    mask[1, 2] = 0                                               # an interior hole: only LEFT padding is implemented
-    with pytest.raises(NotImplementedError):
-        um(inputs_embeds=emb, attention_mask=mask)
-    mask = torch.ones(2, 5, dtype=torch.long)
-    mask[1, :2] = 0
-    assert um._left_pad_start(mask, 2, 5).tolist() == [0, 2] and um._left_pad_start(torch.ones(2, 5), 2, 5) is None
+    mask[1, :2] = 0                                              # left padding: a first visible key per sequence
+    ks, km = um._key_visibility(mask, 2, 5, 5)
+    assert ks.tolist() == [0, 2] and km is None and um._key_visibility(torch.ones(2, 5), 2, 5, 5) == (None, None)
     with pytest.raises(ValueError, match="covers 5 keys"):
-        um._left_pad_start(mask, 2, 6)
+        um._key_visibility(mask, 2, 6, 6)
+    mask[1, 3] = 0                                               # a hole behind the padding: one visibility bit per key, `width` bits wide
+    ks, km = um._key_visibility(mask, 2, 5, 64)
+    assert ks is None and km.dtype == torch.int32 and km.shape == (2, 2) and km.tolist() == [[0b11111, 0], [0b10100, 0]]
+    big = torch.ones(1, 70, dtype=torch.long); big[0, 31] = 0; big[0, 64] = 0
+    assert ops.pack_key_mask(big).tolist() == [[2 ** 31 - 1, -1, 0b111110]]        # words above 2^31 - 1 wrap to signed int32
     assert um._rotary_positions(torch.tensor([[0, 0, 0, 1, 2]]), 2, 5, 64).tolist() == [[0, 0, 0, 1, 2]] * 2
     kc = torch.zeros(2, 1, 4, 64, 16)
     with pytest.raises(ValueError, match="KV cache is full"):

@@ -185,9 +185,47 @@ def test_forward_honours_left_pad_mask_and_position_ids_like_the_reference():
     lab = [torch.full_like(A["ids0"], -100), torch.full_like(A["ids1"], -100)]
     mm = um(batch_input_ids=[A["ids0"], A["ids1"]], batch_labels=lab, batch_X_modals=mods, batch_task_names=['avqa', 'avqa'])
     assert _rel(mm.logits.cpu()[valid], A["logits_bs2"][valid], "forward(batch_input_ids=...) left-padded bs 2 vs fp32 reference") < REL_ENC
-    with pytest.raises(NotImplementedError):
-        hole = mask.clone(); hole[0, 5] = 0
-        um(inputs_embeds=A["embeds_bs2"].cuda(), attention_mask=hole.cuda())
+
+
+def test_forward_accepts_any_2d_attention_mask_like_the_reference():
+    """HF's mask utilities accept any 2-D attention_mask (padding mask AND causal mask), not only left padding: reference-recorded logits of
+    the hyper-LoRA tiny Llama under a mask with interior holes, a masked last key and left pads - default (arange) positions, then explicit
+    cumsum-1 position_ids - the kept cache, and the 1-token decode shortcut (models/unified_llama.py:125-127) with the extended mask.  The
+    mask travels as one visibility bit per key (crab_attn_desc.key_mask, crab_attn_decode_keymask).  Query rows that see no key at all
+    (the left pads) are undefined in the reference and excluded."""
+    from crab_amd.peft_hyper import LoraConfig, get_peft_model
+    from crab_amd.unified_llama import UnifiedConfig, UnifiedForCausalLM
+    meta, A = load_fixture("forward_holes_tiny_llama")
+    W = weights_from_table(meta)
+    cfg = UnifiedConfig(**meta["dec"], pad_token_id=2)
+    model = get_peft_model(UnifiedForCausalLM(cfg, device="cuda"), LoraConfig())
+    r = model.load_state_dict(W, strict=False)
+    assert not r.missing_keys and not r.unexpected_keys, r
+    um = model.base_model.model
+    mask = A["mask"]
+    seen = mask.cumsum(-1) > 0
+    emb = A["embeds"].cuda()
+    out = um(inputs_embeds=emb, attention_mask=mask.cuda(), use_cache=True, output_hidden_states=True)
+    assert torch.isfinite(out.logits).all()
+    assert _rel(out.logits.cpu()[seen], A["logits"][seen], "forward() under a mask with interior holes: logits of defined rows vs fp32 reference") < REL_DEC
+    assert _rel(out.hidden_states[-1].float().cpu()[seen], A["hidden"][seen], "forward() under a mask with holes: post-norm hidden") < REL_DEC
+    plain = um(inputs_embeds=emb)
+    assert float((plain.logits.cpu() - A["logits"])[seen].abs().max()) > 0.5          # the mask path is really exercised
+    outp = um(inputs_embeds=emb, attention_mask=mask.cuda(), position_ids=A["pos"].cuda())
+    assert _rel(outp.logits.cpu()[seen], A["logits_pos"][seen], "forward() under a mask with holes + cumsum-1 position_ids") < REL_DEC
+    step = um(input_ids=A["step_tok"][:, None].cuda(), attention_mask=A["step_mask"].cuda(), position_ids=A["step_pos"].cuda(),
+              past_key_values=out.past_key_values)
+    assert _rel(step.logits.cpu(), A["step_logits"], "forward() decode shortcut over a cache with masked rows vs fp32 reference") < REL_DEC
+    # the bit mask and the first-visible-key form are two encodings of the same thing for a left-padded batch: identical logits
+    pad = torch.ones_like(mask); pad[1, :5] = 0
+    a = um(inputs_embeds=emb, attention_mask=pad.cuda()).logits
+    ks, km = um._key_visibility(pad, 2, mask.shape[1], mask.shape[1])
+    assert km is None and ks.tolist() == [0, 5]
+    from crab_amd import ops
+    eng = um._engine
+    kc, vc = eng.alloc_cache(2, 64)
+    b_, _ = eng.prefill(emb.to(BF), kc, vc, all_logits=True, key_mask=ops.pack_key_mask(pad).cuda())
+    assert torch.equal(a[pad.bool()], b_[pad.bool()])
 
 
 @pytest.mark.parametrize("fixture", ["full_tiny_llama", "full_tiny_qwen"])

@@ -133,6 +133,28 @@ def test_forward_with_left_pad_mask_and_position_ids():
     assert float((lu[1] - logits[1])[valid[1]].abs().max()) > 1e-2 and float((lu[0] - logits[0]).abs().max()) < 1e-4
 
 
+def test_forward_with_a_mask_that_has_interior_holes():
+    """HF's mask utilities accept ANY 2-D attention_mask (padding mask AND causal mask), not only left padding: the reference's logits of the
+    hyper-LoRA tiny Llama under a mask with interior holes, a masked last key and left pads (default arange positions, then the
+    cumsum-1 positions), and the 1-token decode shortcut on the kept cache.  Query rows without any visible key are undefined."""
+    meta, A = load_fixture("forward_holes_tiny_llama")
+    W = O.strip_peft_prefix(weights_from_table(meta))
+    cfg = O.DecoderConfig(**meta["dec"])
+    mask = A["mask"]
+    seen = mask.cumsum(-1) > 0
+    assert int((~seen).sum()) == 3 and int((mask == 0).sum()) == 7
+    logits, hn, cache = O.decoder_forward(A["embeds"], W, cfg, attention_mask=mask)
+    _close(logits[seen], A["logits"][seen], 5e-4)
+    _close(hn[seen], A["hidden"][seen], 5e-4)
+    lp, _, _ = O.decoder_forward(A["embeds"], W, cfg, positions=A["pos"], attention_mask=mask)
+    _close(lp[seen], A["logits_pos"][seen], 5e-4)
+    e = W["model.embed_tokens.weight"][A["step_tok"]][:, None]
+    l2, _, _ = O.decoder_forward(e, W, cfg, cache, positions=A["step_pos"], attention_mask=A["step_mask"])
+    _close(l2, A["step_logits"], 5e-4)
+    lu, _, _ = O.decoder_forward(A["embeds"], W, cfg)
+    assert float((lu - logits)[seen].abs().max()) > 0.5           # the holes matter
+
+
 def test_sampling_distribution_matches_transformers_warpers():
     """oracle.sampling_probs (the distribution HF's sample mode draws from: temperature -> top-k -> top-p -> softmax) against the
     installed transformers' own TemperatureLogitsWarper / TopKLogitsWarper / TopPLogitsWarper, incl. the Llama-2-chat defaults the
