@@ -28,27 +28,29 @@ struct Rccl {
 };
 
 Rccl* rccl() {
-    static Rccl r;
-    static bool tried = false;
-    if (tried) return &r;
-    tried = true;
-    const char* names[] = {getenv("CRAB_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char* n : names) {
-        if (!n || !*n) continue;
-        r.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-        if (r.h) break;
-    }
-    if (!r.h) { snprintf(r.why, sizeof(r.why), "librccl.so not found (%s); set CRAB_RCCL_LIB", dlerror()); return &r; }
-    r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.h, "ncclGetUniqueId");
-    r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.h, "ncclCommInitRank");
-    r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.h, "ncclCommDestroy");
-    r.Gather = (decltype(r.Gather))dlsym(r.h, "ncclGather");
-    r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.h, "ncclGetErrorString");
-    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.Gather) {
-        snprintf(r.why, sizeof(r.why), "librccl.so lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclGather");
-        r.h = nullptr;
-    }
-    return &r;
+    // function-local static with an initialiser: C++11 guarantees one thread runs it, the others wait (two contexts on two host threads may
+    // both reach their first crab_dist_* call at once)
+    static Rccl* inst = []() {
+        static Rccl r;
+        const char* names[] = {getenv("CRAB_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* n : names) {
+            if (!n || !*n) continue;
+            r.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (r.h) break;
+        }
+        if (!r.h) { snprintf(r.why, sizeof(r.why), "librccl.so not found (%s); set CRAB_RCCL_LIB", dlerror()); return &r; }
+        r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.h, "ncclGetUniqueId");
+        r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.h, "ncclCommInitRank");
+        r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.h, "ncclCommDestroy");
+        r.Gather = (decltype(r.Gather))dlsym(r.h, "ncclGather");
+        r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.h, "ncclGetErrorString");
+        if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.Gather) {
+            snprintf(r.why, sizeof(r.why), "librccl.so lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclGather");
+            r.h = nullptr;
+        }
+        return &r;
+    }();
+    return inst;
 }
 
 int rccl_fail(crab_ctx* ctx, Rccl* r, const char* what, ncclResult_t rc) {

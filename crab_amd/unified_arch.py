@@ -26,7 +26,31 @@ BF16 = torch.bfloat16
 AVS_TASKS = ('ms3', 's4', 'avss', 'ref-avs')
 
 
-ENC_CHUNK = int(os.environ.get("CRAB_ENC_CHUNK", "64"))      # clips (modality blocks) per encoder call in prepare_multimodal_inputs
+ENC_CHUNK = int(os.environ.get("CRAB_ENC_CHUNK", "96"))      # most clips (modality blocks) per encoder call in prepare_multimodal_inputs
+
+
+def plan_enc_chunks(n: int, rows_per_block: int, cmax: int) -> List[int]:
+    """Sizes of the encoder calls for n equal modality blocks of rows_per_block token rows each, at most cmax blocks per call.  A tower GEMM runs
+    on 256 x 256 tiles, one per CU and round of 256 (csrc/gemm_glds.hip): 64 clips x 8 frames x 257 rows are 514 row tiles, and the width-1024
+    projections (4 column tiles) then need 8.03 rounds = 9, an 11 % loss on half of the tower's GEMM time (measured: encoder class 0.378 ->
+    0.353 of the MFMA peak when the chunking arrived with 64).  So the chunk size is chosen per call: the c in [cmax / 2, cmax] whose whole
+    partition (n // c calls of c blocks + the rest) costs the fewest tile rounds over the tower's four projection shapes, weighted by their K."""
+    if n <= 0:
+        return []
+    if rows_per_block <= 0 or n <= max(1, cmax // 2) or os.environ.get("CRAB_ENC_PLAN") == "0":       # "0": fixed-size chunks (A/B runs)
+        return [n] if n <= cmax else [cmax] * (n // cmax) + ([n % cmax] if n % cmax else [])
+
+    def rounds(m):                                   # (column tiles, K in units of 1024) of q|k|v, out, fc1, fc2 at width 1024 / 4096
+        rt = -(-m * rows_per_block // 256)
+        return sum(-(-rt * ct // 256) * ku for ct, ku in ((12, 1), (4, 1), (16, 1), (4, 4)))
+    best = None
+    for c in range(min(cmax, n), max(1, cmax // 2) - 1, -1):
+        k, r = divmod(n, c)
+        cost = k * rounds(c) + (rounds(r) if r else 0)
+        if best is None or cost < best[0]:
+            best = (cost, c)
+    c = best[1]
+    return [c] * (n // c) + ([n % c] if n % c else [])
 
 class UnifiedMetaModel:
 
@@ -323,10 +347,17 @@ class UnifiedMetaForCausalLM:
             groups.setdefault(tuple(b.shape), []).append(i)
         # at most ENC_CHUNK blocks per encoder call: the towers' scratch is ~60 MB per clip (CLIP: 8 frames x 257 tokens x 29 KB of rows), which at
         # several hundred clips per generate() would take tens of GB away from the KV cache; rows are independent and every chunk is far inside
-        # the large-M regime of the kernels, so the features do not depend on the chunking
+        # the large-M regime of the kernels, so the features do not depend on the chunking.  The sizes come from plan_enc_chunks (whole tile rounds).
         for shape, all_idxs in groups.items():
-            for c0 in range(0, len(all_idxs), ENC_CHUNK):
-                idxs = all_idxs[c0:c0 + ENC_CHUNK]
+            rows = 0
+            if video and len(shape) == 4:                        # [frames, 3, H, W]: frames x (patches + CLS) token rows through the CLIP tower
+                ve = getattr(self.get_model(), "visual_encoder", None)
+                ps = int(ve.vision_tower.config.get("patch_size", 14)) if ve is not None else 14
+                rows = shape[0] * ((shape[2] // ps) * (shape[3] // ps) + 1)
+            c0 = 0
+            for csz in plan_enc_chunks(len(all_idxs), rows, ENC_CHUNK):
+                idxs = all_idxs[c0:c0 + csz]
+                c0 += csz
                 x = torch.stack([blocks[i] for i in idxs], dim=0)
                 if video:
                     vit, qf = self.encode_video(x, batch_first=True)

@@ -131,3 +131,24 @@ def test_generate_batches_refuses_generate_only_arguments():
     for k in ("output_logits", "output_first_logits", "return_dict_in_generate"):
         with pytest.raises(NotImplementedError, match=k):
             UnifiedForCausalLM.generate_batches.__wrapped__(_Stub(), [], **{k: True})
+
+
+def test_encoder_chunks_fill_whole_tile_rounds():
+    """plan_enc_chunks: every partition covers n with calls of at most cmax blocks, and for the benchmark's 448 clips x 8 frames x 257 rows it
+    avoids the 64-clip chunk (514 row tiles: 8.03 rounds of 256 tiles on the width-1024 projections = 9)."""
+    from crab_amd.unified_arch import plan_enc_chunks
+
+    def rounds(m, rows):
+        rt = -(-m * rows // 256)
+        return sum(-(-rt * ct // 256) * ku for ct, ku in ((12, 1), (4, 1), (16, 1), (4, 4)))
+    for rows in (8 * 257, 10 * 257, 2 * 50, 0):
+        for n in (1, 2, 5, 47, 64, 95, 96, 97, 200, 448, 1000):
+            for cmax in (2, 64, 96):
+                ch = plan_enc_chunks(n, rows, cmax)
+                assert sum(ch) == n and all(0 < c <= cmax for c in ch), (n, rows, cmax, ch)
+                if rows:
+                    fixed = [cmax] * (n // cmax) + ([n % cmax] if n % cmax else [])
+                    assert sum(rounds(c, rows) for c in ch) <= sum(rounds(c, rows) for c in fixed), (n, rows, cmax, ch)
+    assert plan_enc_chunks(448, 8 * 257, 96) == [95, 95, 95, 95, 68]
+    assert plan_enc_chunks(448, 8 * 257, 64) == [63] * 7 + [7]
+    assert plan_enc_chunks(0, 100, 96) == [] and plan_enc_chunks(5, 100, 2) == [2, 2, 1]
