@@ -470,7 +470,8 @@ def test_encoder_chunking_does_not_change_the_features():
             outs.append(um.prepare_multimodal_inputs(ids, lab, mods, ['avqa'] * 5)["inputs_embeds"].clone())
     finally:
         unified_arch.ENC_CHUNK = saved
-    assert _rel(outs[1], outs[0].float().cpu(), "inputs_embeds: encoder chunks of 2 clips vs one call over 5 (HIP vs HIP)") < 6e-3
+    # one bf16 ulp of the largest embedding (|x| in [2, 4): 2^-6) is 5.3e-3 of the scale and is what a changed summation order produces: two ulps allowed
+    assert _rel(outs[1], outs[0].float().cpu(), "inputs_embeds: encoder chunks of 2 clips vs one call over 5 (HIP vs HIP)") < 1.1e-2
 
 
 def test_generate_many_clips_vs_oracle():
