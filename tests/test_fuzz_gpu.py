@@ -1,0 +1,19 @@
+"""Differential fuzz through the C-ABI at random shapes around every dispatch boundary (scripts/fuzz_gemm.py, scripts/fuzz_attn.py): the GEMM
+regimes x epilogues and the attention entry points x masks against fp32 torch on the same bf16 operands.  A combination outside a stated limit
+must be REJECTED (CRAB_E_INVALID / CRAB_E_UNSUPPORTED), never computed wrong.  Fixed seeds: the cases are the same on every run."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("script,cases,seed", [("fuzz_gemm.py", 1200, 11), ("fuzz_attn.py", 400, 12)])
+def test_differential_fuzz(script, cases, seed):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", script), str(cases), str(seed)], capture_output=True, text=True, timeout=900)
+    tail = (r.stdout + r.stderr)[-3000:]
+    assert r.returncode == 0, tail
+    assert " 0 failures" in r.stdout, tail
