@@ -1,0 +1,90 @@
+"""Differential fuzz of the whole decoder path (prefill chunks, KV cache, the decode regimes M <= 16 / <= 128 / <= 256 / <= 512, HIP-graph replay and
+eager, the C layer sequencer and the per-launch Python one, hyper-LoRA of every projection, GQA, q|k|v bias) on RANDOM tiny configurations against the
+fp32 CPU oracle: greedy ids where the reference margin allows, per-step logits within the decoder tolerance, the two sequencers bit-identical.
+    python scripts/fuzz_decoder.py [configs] [seed]"""
+import os, random, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from crab_amd import decoder, ops
+from crab_amd.peft_hyper import LoraConfig, get_peft_model
+from oracle import crab_oracle as O
+
+BF = torch.bfloat16
+NCFG = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+REL = 1.2e-2
+bad = []
+worst_all = 0.0
+for ci in range(NCFG):
+    qwen = rng.random() < 0.4
+    d = rng.choice([64, 128])
+    Hk = rng.choice([1, 2, 4])
+    G = rng.choice([1, 1, 2, 4]) if not qwen else rng.choice([1, 2, 7])
+    H = Hk * G
+    if H * d > 1024: continue
+    hid = H * d
+    inter = rng.choice([64, 136, 352, 1000, 2 * hid + 8])
+    L = rng.choice([1, 2, 3])
+    V = rng.choice([320, 515, 1000])
+    r, nl = rng.choice([(8, 3), (8, 3), (4, 2), (16, 3), (4, 8)])
+    if qwen:
+        from crab_amd.unified_qwen import UnifiedConfig, UnifiedForCausalLM
+    else:
+        from crab_amd.unified_llama import UnifiedConfig, UnifiedForCausalLM
+    kw = dict(hidden_size=hid, intermediate_size=inter, num_hidden_layers=L, num_attention_heads=H, num_key_value_heads=Hk, vocab_size=V,
+              rms_norm_eps=rng.choice([1e-5, 1e-6]), rope_theta=rng.choice([1e4, 1e6]))
+    torch.manual_seed(100 + ci)
+    cfg = UnifiedConfig(**kw, pad_token_id=2, **({"attention_bias": True} if qwen else {}))
+    um = UnifiedForCausalLM(cfg, device="cuda")
+    model = get_peft_model(um, LoraConfig(r=r, lora_alpha=2 * r, lora_nums=nl))
+    for n_, p in model.named_parameters():
+        small = 0.2 if ("o_proj" in n_ or "down_proj" in n_ or "lora_B" in n_) else 1.0
+        p.data.copy_((torch.randn(p.shape) * (1.4 / hid ** 0.5) * small).to(BF) if p.dim() > 1 else
+                     ((1 + 0.1 * torch.randn(p.shape)) if "norm" in n_ else 0.1 * torch.randn(p.shape)).to(BF))
+    W = {k: v.detach().float().cpu() for k, v in O.strip_peft_prefix(model.state_dict()).items() if v.dtype.is_floating_point}
+    ocfg = O.DecoderConfig(**kw, lora_r=r, lora_alpha=2 * r, lora_nums=nl)
+    eng = model.base_model.model._engine
+    for B, S in [(rng.choice([1, 2, 5]), rng.choice([1, 6, 33])), (rng.choice([16, 17, 40]), rng.choice([3, 9])), (rng.choice([130, 260]), 4)]:
+        n = 3
+        desc = f"cfg {ci}: {'qwen' if qwen else 'llama'} hid={hid} H={H}/{Hk} d={d} I={inter} L={L} V={V} r={r} nl={nl} B={B} S={S}"
+        emb = (torch.randn(B, S, hid) * 0.5).to(BF).cuda()
+        outs = []
+        try:
+            for native in (True, False):
+                decoder.NATIVE_LAYERS = native
+                for use_graph in ((True, False) if native else (True,)):
+                    eng._dec.clear()
+                    rr = eng.generate(emb, n, eos_token_id=None, pad_token_id=2, return_step_logits=True, use_graph=use_graph)
+                    outs.append((rr[0].clone().cpu(), rr[1].float().cpu()))
+        except Exception as e:      # noqa: BLE001
+            bad.append(desc + f" -> {type(e).__name__}: {str(e)[:200]}"); continue
+        finally:
+            decoder.NATIVE_LAYERS = True
+        for ids, lg in outs[1:]:
+            if not (torch.equal(ids, outs[0][0]) and torch.equal(lg, outs[0][1])):
+                bad.append(desc + " -> sequencers / graph-vs-eager differ"); break
+        rows = list(range(B)) if B <= 8 else sorted(rng.sample(range(B), 6) + [0, B - 1])
+        ref_ids, ref_lg = O.greedy_generate(emb[rows].float().cpu(), W, ocfg, n)
+        # the same oracle with every stored activation rounded to bf16 (fp32 residual stream): what the storage format alone costs on THIS
+        # configuration - tiny random models amplify it; the HIP path may not exceed max(REL, 2.5 x that)
+        emu_ids, emu_lg = O.greedy_generate(emb[rows].float().cpu(), W, ocfg, n, emulate=BF)
+        ids, lg = outs[0][0][rows], outs[0][1][rows]
+        scale = float(ref_lg.abs().max())
+        top2 = ref_lg.topk(2, -1).values
+        margin = top2[..., 0] - top2[..., 1]
+        for b in range(len(rows)):
+            for s in range(n):
+                err = float((lg[b, s] - ref_lg[b, s]).abs().max())
+                emu = float((emu_lg[b, s] - ref_lg[b, s]).abs().max()) if bool((emu_ids[b, :s] == ref_ids[b, :s]).all()) else 0.0
+                worst_all = max(worst_all, err / scale)
+                if err > max(REL * scale, 2.5 * emu):
+                    bad.append(desc + f" -> row {rows[b]} step {s}: logit err {err / scale:.3e} of scale (bf16-storage emulation {emu / scale:.3e})"); break
+                if ids[b, s] != ref_ids[b, s]:
+                    if margin[b, s] > 2 * err: bad.append(desc + f" -> row {rows[b]} step {s}: id differs at margin {float(margin[b, s]):.4f} > 2 x err {err:.4f}")
+                    break
+    del model, um
+    torch.cuda.empty_cache()
+    print(f"cfg {ci} done ({'qwen' if qwen else 'llama'} hid={hid} H={H}/{Hk} d={d} I={inter} L={L} V={V} r={r} nl={nl}); failures so far {len(bad)}", flush=True)
+print(f"worst logit error {worst_all:.3e} of scale; {len(bad)} failures")
+for b_ in bad[:40]: print("FAIL", b_)
+sys.exit(1 if bad else 0)
