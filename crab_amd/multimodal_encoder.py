@@ -586,6 +586,11 @@ class _BeatsEncoder(nn.Module):
     def __init__(self, cfg: BEATsConfig, device):
         super().__init__()
         E = cfg.encoder_embed_dim
+        if E % cfg.conv_pos_groups or (E // cfg.conv_pos_groups) % 8 or E % cfg.encoder_attention_heads or (E // cfg.encoder_attention_heads) not in (32, 64, 128):
+            # the grouped positional convolution runs as one batched GEMM per (group, sequence) whose rows are the group's channels: 16-byte
+            # LDS-DMA pieces need 8 of them (BEATs iter3+: 768 / 16 = 48); the attention kernels cover head sizes 32 / 64 / 128 (iter3+: 64)
+            raise NotImplementedError(f"BEATs on the HIP path: encoder_embed_dim / conv_pos_groups must be a multiple of 8 and the head size one of "
+                                      f"32 / 64 / 128 (got {E} / {cfg.conv_pos_groups}, {cfg.encoder_attention_heads} heads)")
         self.pos_conv = nn.Sequential(_BeatsPosConv(E, cfg.conv_pos_groups, cfg.conv_pos, device))
         self.layers = nn.ModuleList([_BeatsLayer(cfg, device, i == 0) for i in range(cfg.encoder_layers)])
         self.layer_norm = LayerNormP(E, 1e-5, device)
