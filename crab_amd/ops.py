@@ -196,6 +196,13 @@ def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
         _chk_bf16(lRA, lB)
         g.lora_RA, g.lora_ldra, g.lora_nl, g.lora_r, g.lora_scaling = lRA.data_ptr(), lRA.stride(0), lnl, lr, lsc
         g.B2, g.ldb2, g.K2 = lB.data_ptr(), lB.stride(0), lB.shape[1]
+    if rope is not None and len(rope) > 9 and int(rope[9]) <= 1:
+        # the prefill form with ONE row per sequence: the library would read these fields as the decode form (rope_S <= 1: rotation at pos0 /
+        # pos_dev, no rotary position ids) and still answer "not fused" to the prefill question - the caller's split pass would then rotate a
+        # second time (harmless only at position 0).  Nothing to fuse at one row per sequence: plain projection, the caller runs the split.
+        if info is not None:
+            info["fused_prefill_rope"] = 0
+        rope = None
     if rope is not None:
         tab, kcache, vcache, rH, rHk, rd, rT, rp0, rpd = rope[:9]
         g.rope_tab, g.rope_k_cache, g.rope_v_cache = tab.data_ptr(), kcache.data_ptr(), vcache.data_ptr()

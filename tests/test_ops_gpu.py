@@ -900,3 +900,32 @@ def test_prefill_qkv_projection_rotates_in_its_epilogue(B, S, H, Hk, bias, ids, 
     for name, a, b in zip(("q", "k cache", "v cache", "v^T"), outs[0], outs[1]):
         assert torch.equal(a, b), f"fused prefill RoPE: {name} differs from the unfused pair"
     assert float(outs[0][1][:, :, pos0:pos0 + S].float().abs().sum()) > 0
+
+
+def test_prefill_rope_form_with_one_row_per_sequence_is_not_read_as_the_decode_form():
+    """ops.gemm's PREFILL rope tuple with S == 1 (a one-token prompt, or a chunk of one row at a cache offset): the library reads rope_S <= 1 as the
+    decode form and answers 0 to "do you fuse the prefill rotation" - the caller's split pass would then rotate q / k a second time (found by
+    scripts/fuzz_rope_epilogue.py at pos0 > 0; at position 0 the second rotation is the identity, which is why no model test saw it).  The wrapper
+    hands such a call to the library without rope fields."""
+    from crab_amd import ops
+    B, S, H, Hk, d, K, Tmax, pos0 = 3, 1, 4, 2, 128, 256, 64, 9
+    N = (H + 2 * Hk) * d
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn(B * S, K, device="cuda", generator=g).to(BF)
+    w = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).to(BF)
+    tab = ops.rope_table(Tmax, d, 10000.0, "cuda")
+    outs = []
+    for form in ("prefill-tuple", "plain"):
+        kc = torch.zeros(B, Hk, Tmax, d, dtype=BF, device="cuda"); vc = torch.zeros_like(kc)
+        vt = torch.zeros(B, Hk, d, 8, dtype=BF, device="cuda")
+        qkv = torch.empty(B * S, N, dtype=BF, device="cuda")
+        if form == "plain":
+            ops.gemm(x, w, out=qkv)
+        else:
+            info = {}
+            ops.gemm(x, w, out=qkv, rope=(tab, kc, vc, H, Hk, d, Tmax, pos0, None, S, None, vt), info=info)
+            assert info["fused_prefill_rope"] == 0
+        ops.qkv_rope_split(qkv, tab, kc, vc, vt, B, S, H, Hk, d, Tmax, pos0=pos0)
+        outs.append((qkv[:, :H * d].clone(), kc, vc))
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
