@@ -82,6 +82,33 @@ for ci in range(NCFG):
                 if ids[b, s] != ref_ids[b, s]:
                     if margin[b, s] > 2 * err: bad.append(desc + f" -> row {rows[b]} step {s}: id differs at margin {float(margin[b, s]):.4f} > 2 x err {err:.4f}")
                     break
+        # ---- the EOS / min_new_tokens / pad state machine of the device-resident loop, checked against the run's OWN per-step logits (HF semantics,
+        # EOS suppressed while step < min_new_tokens, a finished row emits pad, the loop ends once every row has finished)
+        n2 = 6
+        free = eng.generate(emb, n2, eos_token_id=None, pad_token_id=2, return_step_logits=True)[0].cpu()
+        eos = int(free[rng.randrange(B), rng.randrange(1, n2)])                  # a token some row really produces
+        mn = rng.choice([0, 0, 1, 3])
+        try:
+            eng._dec.clear()
+            ids2, lg2 = eng.generate(emb, n2, eos_token_id=eos, pad_token_id=2, min_new_tokens=mn, return_step_logits=True)
+        except Exception as e:      # noqa: BLE001
+            bad.append(desc + f" eos={eos} min_new={mn} -> {type(e).__name__}: {str(e)[:200]}"); continue
+        ids2, lg2 = ids2.cpu(), lg2.float().cpu()
+        fin = torch.zeros(B, dtype=torch.bool)
+        exp, steps = [], 0
+        for s in range(ids2.shape[1]):
+            l = lg2[:, s].clone()
+            if s < mn: l[:, eos] = float("-inf")
+            tok = l.argmax(-1)
+            tok = torch.where(fin, torch.full_like(tok, 2), tok)
+            exp.append(tok)
+            fin = fin | (tok == eos)
+            steps = s + 1
+            if bool(fin.all()): break
+        exp = torch.stack(exp, 1)
+        want_len = steps if bool(fin.all()) else n2
+        if ids2.shape[1] != want_len or not torch.equal(ids2[:, :exp.shape[1]], exp):
+            bad.append(desc + f" eos={eos} min_new={mn} -> ids {tuple(ids2.shape)} do not follow the EOS / pad rules from their own logits (expected length {want_len})")
     del model, um
     torch.cuda.empty_cache()
     print(f"cfg {ci} done ({'qwen' if qwen else 'llama'} hid={hid} H={H}/{Hk} d={d} I={inter} L={L} V={V} r={r} nl={nl}); failures so far {len(bad)}", flush=True)
