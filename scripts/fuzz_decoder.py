@@ -109,6 +109,38 @@ for ci in range(NCFG):
         want_len = steps if bool(fin.all()) else n2
         if ids2.shape[1] != want_len or not torch.equal(ids2[:, :exp.shape[1]], exp):
             bad.append(desc + f" eos={eos} min_new={mn} -> ids {tuple(ids2.shape)} do not follow the EOS / pad rules from their own logits (expected length {want_len})")
+    # ---- forward() under random 2-D attention masks (left padding, interior holes, both) and optional cumsum-1 position_ids, then the one-token
+    # decode shortcut on the kept cache: logits of every query row that sees at least one key against the oracle
+    for _ in range(2):
+        B, S = rng.choice([1, 2, 4]), rng.choice([5, 17, 40, 70])
+        emb = (torch.randn(B, S, hid) * 0.5).to(BF).cuda()
+        mask = (torch.rand(B, S) < rng.choice([0.6, 0.85, 1.0])).long()
+        for b in range(B):
+            mask[b, :rng.randrange(0, S // 2 + 1)] = 0 if rng.random() < 0.5 else mask[b, :1].item()
+            mask[b, rng.randrange(S // 2, S)] = 1                                  # at least one visible key in the second half
+        use_pos = rng.random() < 0.5
+        pos = (mask.cumsum(-1) - 1).clamp(min=0) if use_pos else None
+        desc = f"cfg {ci}: forward() {'qwen' if qwen else 'llama'} hid={hid} H={H}/{Hk} d={d} L={L} B={B} S={S} masked={int((mask == 0).sum())} pos_ids={use_pos}"
+        try:
+            out = model.base_model.model(inputs_embeds=emb, attention_mask=mask.cuda(), position_ids=pos.cuda() if use_pos else None, use_cache=True)
+            tok = out.logits[:, -1].argmax(-1)
+            mask2 = torch.cat([mask, torch.ones(B, 1, dtype=torch.long)], 1)
+            pos2 = (pos[:, -1:] + 1) if use_pos else torch.full((B, 1), S, dtype=torch.long)
+            step = model.base_model.model(input_ids=tok[:, None], attention_mask=mask2.cuda(), position_ids=pos2.cuda(), past_key_values=out.past_key_values)
+        except Exception as e:      # noqa: BLE001
+            bad.append(desc + f" -> {type(e).__name__}: {str(e)[:200]}"); continue
+        seen = mask.cumsum(-1) > 0
+        ref, _, cache = O.decoder_forward(emb.float().cpu(), W, ocfg, positions=pos, attention_mask=mask)
+        emu, _, cache_e = O.decoder_forward(emb.float().cpu(), W, ocfg, positions=pos, attention_mask=mask, emulate=BF)
+        scale = float(ref[seen].abs().max())
+        e1, e1m = float((out.logits.float().cpu() - ref)[seen].abs().max()), float((emu - ref)[seen].abs().max())
+        worst_all = max(worst_all, e1 / scale)
+        if e1 > max(REL * scale, 2.5 * e1m): bad.append(desc + f" -> prefill logits err {e1 / scale:.3e} of scale (emulation {e1m / scale:.3e})")
+        e_tok = W["model.embed_tokens.weight"][tok.cpu()][:, None]
+        ref2, _, _ = O.decoder_forward(e_tok, W, ocfg, cache, positions=pos2, attention_mask=mask2)
+        emu2, _, _ = O.decoder_forward(e_tok, W, ocfg, cache_e, positions=pos2, attention_mask=mask2, emulate=BF)
+        e2, e2m = float((step.logits.float().cpu() - ref2).abs().max()), float((emu2 - ref2).abs().max())
+        if e2 > max(REL * scale, 2.5 * e2m): bad.append(desc + f" -> decode-shortcut logits err {e2 / scale:.3e} of scale (emulation {e2m / scale:.3e}, prefill err {e1 / scale:.3e})")
     del model, um
     torch.cuda.empty_cache()
     print(f"cfg {ci} done ({'qwen' if qwen else 'llama'} hid={hid} H={H}/{Hk} d={d} I={inter} L={L} V={V} r={r} nl={nl}); failures so far {len(bad)}", flush=True)
