@@ -42,7 +42,8 @@ for case in range(NCASE):
         v = (torch.randn(B, Hk, Skv, d, device="cuda", generator=g) * 0.7).to(BF)
         Sp = (Skv + 7) // 8 * 8
         vt = torch.zeros(B, Hk, d, Sp, device="cuda", dtype=BF); vt[..., :Skv] = v.transpose(2, 3)
-        o = torch.empty(B, Sq, H * d, device="cuda", dtype=BF)
+        obuf = torch.full((B * Sq + 2, H * d), 777.0, device="cuda", dtype=BF)          # guard rows above and below the output
+        o = obuf[1:B * Sq + 1].view(B, Sq, H * d)
         scale = 1.0 / math.sqrt(d)
         keyok = torch.ones(B, Skv, device="cuda", dtype=torch.bool)
         kw = {}
@@ -77,6 +78,7 @@ for case in range(NCASE):
         err = float((o.float() - ref).abs().max())
         done += 1
         if not (err < 2.5e-2) or not torch.isfinite(o.float()).all(): bad.append(desc + f" -> max abs err {err:.3e}")
+        if not (bool((obuf[0] == 777.0).all()) and bool((obuf[-1] == 777.0).all())): bad.append(desc + " -> a store landed outside the output")
     else:
         Tmax = rng.choice([64, 128, 960])
         ctx = rng.randrange(1, Tmax + 1)
@@ -86,7 +88,8 @@ for case in range(NCASE):
         kc = (torch.randn(Bd, Hk, Tmax, d, device="cuda", generator=g) * 0.7).to(BF)
         vc = (torch.randn(Bd, Hk, Tmax, d, device="cuda", generator=g) * 0.7).to(BF)
         q = (torch.randn(Bd, H * d, device="cuda", generator=g) * 0.7).to(BF)
-        o = torch.empty_like(q)
+        obuf = torch.full((Bd + 2, H * d), 777.0, device="cuda", dtype=BF)
+        o = obuf[1:Bd + 1]
         scale = 1.0 / math.sqrt(d)
         keyok = torch.zeros(Bd, Tmax, device="cuda", dtype=torch.bool); keyok[:, :ctx] = True
         kw = {}
@@ -116,6 +119,7 @@ for case in range(NCASE):
         err = float((o.float() - ref).abs().max())
         done += 1
         if not (err < 2.5e-2) or not torch.isfinite(o.float()).all(): bad.append(desc + f" -> max abs err {err:.3e}")
+        if not (bool((obuf[0] == 777.0).all()) and bool((obuf[-1] == 777.0).all())): bad.append(desc + " -> a store landed outside the output")
 print(f"{done} cases computed, {rejected} rejected by the library, {len(bad)} failures")
 for k_, v_ in sorted(why.items(), key=lambda kv: -kv[1]): print(f"  rejected x{v_}: {k_}")
 for b_ in bad[:40]: print("FAIL", b_)

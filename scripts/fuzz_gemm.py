@@ -47,7 +47,11 @@ for case in range(NCASE):
     if res:
         r = torch.randn(M, No, device="cuda", generator=g)
         r = r if res == "fp32" else r.to(BF)
-    out = torch.empty(M, No, device="cuda", dtype=torch.float32 if out32 else BF)
+    # the output sits inside a larger buffer of sentinels: a guard row above and below, and (half of the cases) 8 / 16 guard columns behind every
+    # row - a store outside the M x N block shows up as a changed sentinel
+    gap = rng.choice([0, 0, 8, 16])
+    obuf = torch.full((M + 2, No + gap), 777.0, device="cuda", dtype=torch.float32 if out32 else BF)
+    out = obuf[1:M + 1, :No]
     y = x.float() @ w.float().t()
     if K2: y = y + x2.float() @ w2.float().t()
     if bias: y = y + b.float()
@@ -56,11 +60,13 @@ for case in range(NCASE):
     kw = {}
     if norm:
         nw = (1.0 + 0.1 * torch.randn(N, device="cuda", generator=g)).to(BF)
-        h = torch.empty(M, N, device="cuda", dtype=BF)
+        hbuf = torch.full((M + 2, N + gap), 777.0, device="cuda", dtype=BF)
+        h = hbuf[1:M + 1, :N]
         kw["post_norm"] = (nw, 1e-5, h)
         if route:
             ra = (torch.randn(48, N, device="cuda", generator=g) * 0.05).to(BF)
-            u = torch.empty(M, 96, device="cuda", dtype=BF)
+            ubuf = torch.full((M + 2, 96 + 8), 777.0, device="cuda", dtype=BF)
+            u = ubuf[1:M + 1, :96]
             kw["route"] = (ra, 3, 3, 8, 96, 2.0, u)
     desc = f"case {case}: M={M} N={N} K={K}+{K2} act={act} bias={bias} res={res} out={'fp32' if out32 else 'bf16'} norm={norm} route={route}"
     try:
@@ -74,6 +80,10 @@ for case in range(NCASE):
             continue
         bad.append(desc + " -> " + msg[:200]); continue
     done += 1
+    guards = [("out", obuf, No)] + ([("post-norm out", hbuf, N)] if norm else []) + ([("router out", ubuf, 96)] if route else [])
+    for gname, gb, cols in guards:
+        if not (bool((gb[0] == 777.0).all()) and bool((gb[-1] == 777.0).all()) and bool((gb[:, cols:] == 777.0).all())):
+            bad.append(desc + f" gap={gap} -> {gname}: a store landed outside the M x N block")
     scale = float(y.abs().max()) + 1e-6
     err = float((out.float() - y).abs().max()) / scale
     tol = 6e-3 if out32 else 1.2e-2
