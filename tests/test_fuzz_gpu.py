@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("script,cases,seed", [("fuzz_gemm.py", 1200, 11), ("fuzz_attn.py", 400, 12), ("fuzz_decoder.py", 8, 13), ("fuzz_multimodal.py", 6, 14), ("fuzz_rope_epilogue.py", 120, 15), ("fuzz_frontend.py", 40, 16)])
+@pytest.mark.parametrize("script,cases,seed", [("fuzz_gemm.py", 1200, 11), ("fuzz_attn.py", 400, 12), ("fuzz_decoder.py", 8, 13), ("fuzz_multimodal.py", 6, 14), ("fuzz_rope_epilogue.py", 120, 15), ("fuzz_frontend.py", 40, 16), ("fuzz_ops.py", 600, 17)])
 def test_differential_fuzz(script, cases, seed):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", script), str(cases), str(seed)], capture_output=True, text=True, timeout=900)
     tail = (r.stdout + r.stderr)[-3000:]
