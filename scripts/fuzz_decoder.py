@@ -15,6 +15,7 @@ rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 REL = 1.2e-2
 bad = []
 worst_all = 0.0
+WIDE = os.environ.get("CRAB_FUZZ_WIDE") == "1"      # full-width rows (Llama-2-7B / Qwen2-7B projection shapes, 2 layers): the kernels of the benchmark regimes
 for ci in range(NCFG):
     qwen = rng.random() < 0.4
     d = rng.choice([64, 128])
@@ -27,6 +28,10 @@ for ci in range(NCFG):
     L = rng.choice([1, 2, 3])
     V = rng.choice([320, 515, 1000])
     r, nl = rng.choice([(8, 3), (8, 3), (4, 2), (16, 3), (4, 8)])
+    if WIDE:
+        d, L, (r, nl) = 128, 2, (8, 3)
+        if qwen: H, Hk, hid, inter, V = 28, 4, 3584, 18944, 4000
+        else: H, Hk, hid, inter, V = 32, 32, 4096, 11008, 32017
     if qwen:
         from crab_amd.unified_qwen import UnifiedConfig, UnifiedForCausalLM
     else:
@@ -44,7 +49,9 @@ for ci in range(NCFG):
     W = {k: v.detach().float().cpu() for k, v in O.strip_peft_prefix(model.state_dict()).items() if v.dtype.is_floating_point}
     ocfg = O.DecoderConfig(**kw, lora_r=r, lora_alpha=2 * r, lora_nums=nl)
     eng = model.base_model.model._engine
-    for B, S in [(rng.choice([1, 2, 5]), rng.choice([1, 6, 33])), (rng.choice([16, 17, 40]), rng.choice([3, 9])), (rng.choice([130, 260]), 4)]:
+    regimes = [(rng.choice([1, 2, 5]), rng.choice([1, 6, 33])), (rng.choice([16, 17, 40]), rng.choice([3, 9])), (rng.choice([130, 260]), 4)]
+    if WIDE: regimes = [(rng.choice([1, 8, 16]), 5), (rng.choice([17, 100, 129]), 3), (rng.choice([255, 257, 300, 383]), 2), (rng.choice([448, 511, 512, 513, 600]), 2)]
+    for B, S in regimes:
         n = 3
         desc = f"cfg {ci}: {'qwen' if qwen else 'llama'} hid={hid} H={H}/{Hk} d={d} I={inter} L={L} V={V} r={r} nl={nl} B={B} S={S}"
         emb = (torch.randn(B, S, hid) * 0.5).to(BF).cuda()
