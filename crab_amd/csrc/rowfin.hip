@@ -34,13 +34,18 @@ struct RowfinApplyP {
     float* ssq;                                  // out: [slices][16] partial sums of squares of the STORED values
     unsigned* counter;                           // arrival counter of the route kernel, zeroed here
     int M, N, nl, r; float scaling;
+    // RP instantiation (r04, the two-launch tail without an arrival chain): the NEXT group's router partials are formed HERE, on the un-normalised
+    // row times the norm weight - t = rstd * ((y (.) w) . [R;A]^T), rstd being a per-row scalar the second launch applies - so that the second
+    // launch has nothing to wait for (rowfin_norm_mix_kernel)
+    const bf16_t* nw; const bf16_t* RA; long ldra; int used; float* tpart;
 };
 
-template <bool XF>
+template <bool XF, bool RP = false>
 __global__ __launch_bounds__(256) void rowfin_apply_kernel(RowfinApplyP p) {
     __shared__ uint32_t b2s[RF_CW][17];          // lora_B rows of this slice, 32 k columns as 16 words + 1 pad word (conflict-free row walk)
     __shared__ float us[16][32];
     __shared__ float ts[16][16];
+    __shared__ __attribute__((aligned(16))) bf16_t ras[RP ? RF_TJ : 1][RF_CW];       // RP: the slice of the next group's [R;A] (8 KB)
     const int tid = threadIdx.x, m = tid >> 4, q = tid & 15;
     const int c0 = blockIdx.x * RF_CW, c = c0 + q * 4;
     if (blockIdx.x == 0 && tid == 0) *p.counter = 0u;
@@ -49,6 +54,17 @@ __global__ __launch_bounds__(256) void rowfin_apply_kernel(RowfinApplyP p) {
     const bool live = m < p.M && c < p.N;
     f32x4_t y = {0.f, 0.f, 0.f, 0.f};
     if (live) y = *reinterpret_cast<const f32x4_t*>(p.S + (long)m * p.N + c);
+    u32x4 rv[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+    u32x2 ww = {0u, 0u};
+    const int used16 = RP ? (p.used + 15) & ~15 : 0;
+    if (RP) {                                     // unconditional loads at clamped addresses, masked afterwards (see rowfin_route_kernel)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + i * 256, j = idx >> 3, ch = idx & 7;
+            rv[i] = *reinterpret_cast<const u32x4*>(p.RA + (long)min(j, p.used - 1) * p.ldra + min(c0 + ch * 8, p.N - 8));
+        }
+        ww = *reinterpret_cast<const u32x2*>(p.nw + min(c, p.N - 4));
+    }
     u32x4 bv = {0u, 0u, 0u, 0u};
     float tsum = 0.f;
     if (p.T) {
@@ -64,6 +80,14 @@ __global__ __launch_bounds__(256) void rowfin_apply_kernel(RowfinApplyP p) {
         b2s[row][ch * 4 + 0] = bv[0]; b2s[row][ch * 4 + 1] = bv[1]; b2s[row][ch * 4 + 2] = bv[2]; b2s[row][ch * 4 + 3] = bv[3];
         us[m][q] = 0.f; us[m][q + 16] = 0.f;
         ts[m][q] = tsum;
+    }
+    if (RP) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + i * 256, j = idx >> 3, ch = idx & 7;
+            if (!(j < p.used && c0 + ch * 8 < p.N)) rv[i] = u32x4{0u, 0u, 0u, 0u};
+            if (j < used16) *reinterpret_cast<u32x4*>(&ras[j][ch * 8]) = rv[i];
+        }
     }
     __syncthreads();
     if (p.T && q == 0 && m < p.M) {
@@ -103,6 +127,137 @@ __global__ __launch_bounds__(256) void rowfin_apply_kernel(RowfinApplyP p) {
     }
     ss = row16_sum(ss);
     if (q == 0) p.ssq[blockIdx.x * 16 + m] = m < p.M ? ss : 0.f;
+    if (RP) {
+        // partial router products of this slice on (stored row) * norm weight, fp32.  The row times the weight goes through LDS so that the 256
+        // threads split the work as (router row j = tid / 4, 16 of the slice's 64 columns) and walk only the M live rows: 16 fmas + two lane
+        // exchanges per row and thread (one clip: 16 fmas in all) instead of a 16-lane reduction per router row in every one of the 16 row groups
+        __shared__ __attribute__((aligned(16))) float yws[16][RF_CW];
+        f32x4_t hv = {0.f, 0.f, 0.f, 0.f};
+        if (live) {
+            float x0 = y[0], x1 = y[1], x2 = y[2], x3 = y[3];
+            if (!XF) { x0 = bf2f(f2bf(x0)); x1 = bf2f(f2bf(x1)); x2 = bf2f(f2bf(x2)); x3 = bf2f(f2bf(x3)); }      // the stored bf16 row
+            hv = f32x4_t{x0 * lo_bf(ww[0]), x1 * hi_bf(ww[0]), x2 * lo_bf(ww[1]), x3 * hi_bf(ww[1])};
+        }
+        *reinterpret_cast<f32x4_t*>(&yws[m][q * 4]) = hv;
+        __syncthreads();
+        const int jr = tid >> 2, part = tid & 3;
+        if (jr < used16) {                                       // wave-uniform up to the last wave
+            float wf[16];
+            const u32x4 w0 = *reinterpret_cast<const u32x4*>(&ras[jr][part * 16]), w1 = *reinterpret_cast<const u32x4*>(&ras[jr][part * 16 + 8]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { wf[2 * e] = lo_bf(w0[e]); wf[2 * e + 1] = hi_bf(w0[e]); wf[8 + 2 * e] = lo_bf(w1[e]); wf[8 + 2 * e + 1] = hi_bf(w1[e]); }
+            for (int mm = 0; mm < p.M; ++mm) {
+                float a = 0.f;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const f32x4_t yv = *reinterpret_cast<const f32x4_t*>(&yws[mm][part * 16 + v * 4]);
+                    a += (yv[0] * wf[4 * v] + yv[1] * wf[4 * v + 1]) + (yv[2] * wf[4 * v + 2] + yv[3] * wf[4 * v + 3]);
+                }
+                a += __shfl_xor(a, 1, 64);
+                a += __shfl_xor(a, 2, 64);
+                if (part == 0) p.tpart[((long)blockIdx.x * 16 + mm) * RF_TJ + jr] = a;
+            }
+        }
+    }
+}
+
+// Second launch of the r04 tail: rstd from the slices' sums of squares, h = rmsnorm(x) * w stored for this block's 64 columns, and - every block takes
+// (row, projection) pairs of the next group's router - the slices' partials summed in a fixed order, scaled by rstd, fp32 softmax over the route
+// logits, u = scaling * p (x) (h A^T).  One memory round trip, nothing waits on another block (the arrival ticket, the drained partial stores and
+// the last arriver's acquire + reload of rowfin_route_kernel are gone: 8.4 -> ~4.5 us at one clip).
+struct RowfinMixP {
+    const bf16_t* X; long ldx; const float* ssq; int nb;
+    const bf16_t* nw; float eps; bf16_t* H; long ldh;
+    const float* tpart; bf16_t* U; long ldu; int nproj, nl, r, ucols; float scaling;      // tpart == NULL: no next-group router
+    int M, N;
+};
+
+template <bool XF>
+__global__ __launch_bounds__(256) void rowfin_norm_mix_kernel(RowfinMixP p) {
+    __shared__ float rs[16];
+    __shared__ float Tg[RF_G][RF_TJ];
+    __shared__ float Tm[RF_TJ];
+    const int tid = threadIdx.x, m = tid >> 4, q = tid & 15;
+    const int c0 = blockIdx.x * RF_CW, c = c0 + q * 4;
+    const int nj = p.nl + p.r, npairs = p.tpart ? p.M * p.nproj : 0;
+    const int per = (p.nb + RF_G - 1) / RF_G;
+    // ---- every global load first: the partial sums of squares, x, w, and the router partials of this block's first (row, projection) pair
+    float sp[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sp[i] = p.ssq[min(q + i * 16, p.nb - 1) * 16 + m];       // nb <= 128 (host)
+    const bool live = m < p.M && c < p.N;
+    u32x2 xw = {0u, 0u};
+    f32x4_t xf = {0.f, 0.f, 0.f, 0.f};
+    if (XF) xf = *reinterpret_cast<const f32x4_t*>(reinterpret_cast<const float*>(p.X) + (long)min(m, p.M - 1) * p.ldx + min(c, p.N - 4));
+    else xw = *reinterpret_cast<const u32x2*>(p.X + (long)min(m, p.M - 1) * p.ldx + min(c, p.N - 4));
+    const u32x2 ww = *reinterpret_cast<const u32x2*>(p.nw + min(c, p.N - 4));
+    const int g = tid >> 6, j = tid & 63;
+    float tacc = 0.f;
+    int k = blockIdx.x;
+    constexpr int PER = 128 / RF_G;                              // nb <= 128: at most 32 slices per group, all their loads in flight together
+    float tv[PER];
+    const bool mine = k < npairs && j < nj;
+    {
+        const int kk = mine ? k : 0, jc = mine ? j : 0;
+        const int mm = kk / p.nproj, pj = kk % p.nproj;
+        const float* src = (p.tpart ? p.tpart : p.ssq) + (p.tpart ? (long)mm * RF_TJ + pj * nj + jc : 0);
+        const int b0 = g * per;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) tv[i] = p.tpart ? src[(long)min(b0 + i, p.nb - 1) * 16 * RF_TJ] : 0.f;      // clamped, masked below
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sp[i] = q + i * 16 < p.nb ? sp[i] : 0.f;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ss += sp[i];
+    ss = row16_sum(ss);
+    const float rstd = rsqrtf(ss / (float)p.N + p.eps);
+    if (q == 0) rs[m] = rstd;
+    if (live) {
+        float h0, h1, h2, h3;
+        if (XF) {
+            h0 = xf[0] * rstd * lo_bf(ww[0]); h1 = xf[1] * rstd * hi_bf(ww[0]);
+            h2 = xf[2] * rstd * lo_bf(ww[1]); h3 = xf[3] * rstd * hi_bf(ww[1]);
+        } else {
+            h0 = bf2f(f2bf(lo_bf(xw[0]) * rstd)) * lo_bf(ww[0]); h1 = bf2f(f2bf(hi_bf(xw[0]) * rstd)) * hi_bf(ww[0]);
+            h2 = bf2f(f2bf(lo_bf(xw[1]) * rstd)) * lo_bf(ww[1]); h3 = bf2f(f2bf(hi_bf(xw[1]) * rstd)) * hi_bf(ww[1]);
+        }
+        *reinterpret_cast<u32x2*>(p.H + (long)m * p.ldh + c) = u32x2{pack_bf2(h0, h1), pack_bf2(h2, h3)};
+    }
+    if (mine) {
+        const int b0 = g * per, b1 = min(p.nb, b0 + per);
+#pragma unroll
+        for (int i = 0; i < PER; ++i) tacc += b0 + i < b1 ? tv[i] : 0.f;                   // slice order inside the group
+    }
+    // ---- router of the next group: (row, projection) pairs dealt round-robin to the blocks (one pair per block unless nb < M * nproj)
+    for (; k < npairs; k += gridDim.x) {
+        const int mm = k / p.nproj, pj = k % p.nproj;
+        if (k != (int)blockIdx.x) {                             // further pairs of a narrow projection: their partials are loaded here
+            tacc = 0.f;
+            if (j < nj) {
+                const float* src = p.tpart + (long)mm * RF_TJ + pj * nj + j;
+                const int b0 = g * per, b1 = min(p.nb, b0 + per);
+                for (int b = b0; b < b1; ++b) tacc += src[(long)b * 16 * RF_TJ];
+            }
+        }
+        if (j < nj) Tg[g][j] = tacc;
+        __syncthreads();                                        // also orders rs[] (first trip)
+        if (tid < nj) Tm[tid] = (((Tg[0][tid] + Tg[1][tid]) + Tg[2][tid]) + Tg[3][tid]) * rs[mm];
+        __syncthreads();
+        bf16_t* u = p.U + (long)mm * p.ldu;
+        if (tid == 0) {
+            float e[8], mx = -INFINITY;
+            for (int i = 0; i < p.nl; ++i) mx = fmaxf(mx, Tm[i]);
+            float sum = 0.f;
+            for (int i = 0; i < p.nl; ++i) { e[i] = expf(Tm[i] - mx); sum += e[i]; }
+            const float inv = 1.0f / sum;
+            for (int i = 0; i < p.nl; ++i)
+                for (int jj = 0; jj < p.r; ++jj) u[pj * p.nl * p.r + i * p.r + jj] = f2bf(p.scaling * e[i] * inv * Tm[p.nl + jj]);
+        } else if (tid == 64 && pj == 0) {
+            for (int cc = p.nproj * p.nl * p.r; cc < p.ucols; ++cc) u[cc] = 0;
+        }
+        __syncthreads();                                        // Tg / Tm are reused by the next pair
+    }
 }
 
 struct RowfinRouteP {
@@ -310,8 +465,29 @@ int crab_rowfin_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* d) {
     a.B2 = (const bf16_t*)d->B2; a.ldb2 = d->ldb2; a.k2 = d->K2;
     a.X = (bf16_t*)d->C; a.ldx = d->ldc; a.ssq = ssq; a.counter = counter;
     a.M = d->M; a.N = d->N; a.nl = d->lora_nl; a.r = d->lora_r; a.scaling = d->lora_scaling;
-    if (d->c_fp32) hipLaunchKernelGGL(rowfin_apply_kernel<true>, dim3(nb), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(rowfin_apply_kernel<false>, dim3(nb), dim3(256), 0, s, a);
+    a.nw = (const bf16_t*)d->norm_w; a.RA = (const bf16_t*)d->route_RA; a.ldra = d->route_ldra;
+    a.used = d->route_RA ? d->route_nproj * (d->route_nl + d->route_r) : 0; a.tpart = tpart;
+    // CRAB_ROWFIN_TAIL=1: the r03 pair (apply, then the route kernel with its arrival chain) for A/B runs; default: router partials in the first launch,
+    // a second launch that waits for nothing
+    static const int chain = []() { const char* e = getenv("CRAB_ROWFIN_TAIL"); return e && e[0] == '1' && e[1] == 0; }();
+    if (!chain) {
+        const bool rp = d->route_RA != nullptr;
+        if (d->c_fp32) { if (rp) hipLaunchKernelGGL((rowfin_apply_kernel<true, true>), dim3(nb), dim3(256), 0, s, a); else hipLaunchKernelGGL((rowfin_apply_kernel<true, false>), dim3(nb), dim3(256), 0, s, a); }
+        else { if (rp) hipLaunchKernelGGL((rowfin_apply_kernel<false, true>), dim3(nb), dim3(256), 0, s, a); else hipLaunchKernelGGL((rowfin_apply_kernel<false, false>), dim3(nb), dim3(256), 0, s, a); }
+        int rc0 = crab_check_launch(ctx, "rowfin_apply_kernel");
+        if (rc0) return rc0;
+        RowfinMixP x;
+        x.X = (const bf16_t*)d->C; x.ldx = d->ldc; x.ssq = ssq; x.nb = nb;
+        x.nw = (const bf16_t*)d->norm_w; x.eps = d->norm_eps; x.H = (bf16_t*)d->norm_out; x.ldh = d->ld_norm;
+        x.tpart = rp ? tpart : nullptr; x.U = (bf16_t*)d->route_U; x.ldu = d->route_ldu;
+        x.nproj = d->route_nproj; x.nl = d->route_nl; x.r = d->route_r; x.ucols = d->route_ucols; x.scaling = d->route_scaling;
+        x.M = d->M; x.N = d->N;
+        if (d->c_fp32) hipLaunchKernelGGL(rowfin_norm_mix_kernel<true>, dim3(nb), dim3(256), 0, s, x);
+        else hipLaunchKernelGGL(rowfin_norm_mix_kernel<false>, dim3(nb), dim3(256), 0, s, x);
+        return crab_check_launch(ctx, "rowfin_norm_mix_kernel");
+    }
+    if (d->c_fp32) hipLaunchKernelGGL((rowfin_apply_kernel<true, false>), dim3(nb), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((rowfin_apply_kernel<false, false>), dim3(nb), dim3(256), 0, s, a);
     int rc = crab_check_launch(ctx, "rowfin_apply_kernel");
     if (rc) return rc;
     RowfinRouteP r;

@@ -763,7 +763,19 @@ def test_gemm_post_norm_routes_next_group(M, nproj):
     ops.gemm(x.cuda(), w.cuda(), residual=r2, out=r2, post_norm=(nw.cuda(), 1e-5, h2))
     assert torch.equal(h, h2) and torch.equal(rd, r2)
     u_ref = ops.hyperlora_route(h2, ra.cuda(), nproj, 3, 8, ucols, 2.0)
-    _cmp(u, u_ref.float().cpu(), 1e-6, "route ahead")
+    # M > 16: the row-owning reduction routes on the stored bf16 h, like the stand-alone router: identical.  M <= 16 (the small-batch tail, r04): the
+    # router partials are formed on the UNROUNDED row times the norm weight and scaled by rstd afterwards (rowfin.hip: the second launch then waits for
+    # nothing) - one bf16 rounding less than the reference-shaped order, so u agrees to a bf16 ulp of its largest entry, not bit for bit
+    _cmp(u, u_ref.float().cpu(), 1e-6 if M > 16 else 8e-3, "route ahead")
+    if M <= 16:
+        t = (h2.float() @ ra.cuda().float().t()).cpu()
+        hx = (rd.float() * torch.rsqrt(rd.float().pow(2).mean(-1, keepdim=True) + 1e-5) * nw.cuda().float())
+        tx = (hx @ ra.cuda().float().t()).cpu()                       # router inputs without the bf16 rounding of h: what the tail now computes
+        ux = torch.zeros(M, ucols)
+        for p_ in range(nproj):
+            tt = tx[:, p_ * 11:(p_ + 1) * 11]
+            ux[:, p_ * 24:(p_ + 1) * 24] = (2.0 * torch.softmax(tt[:, :3], -1)[:, :, None] * tt[:, None, 3:]).reshape(M, 24)
+        _cmp(u, ux, 4.5e-3, "route ahead vs the unrounded router (fp32 math, bf16 output)")
     assert (u[:, nproj * 24:] == 0).all()
 
 
