@@ -9,12 +9,17 @@
 //
 //   gemm_skinny_dma_kernel   S = act(A.W^T + bias) + R in fp32, and - 16 extra weight rows = the group's own [R;A] - T = A.[R;A]^T
 //   rowfin_apply_kernel      column slices of 64: y = S + scaling * sum_i softmax(T_route)_i B_i T_A   (the hyper-LoRA update of THIS
-//                            projection, applied here because T only exists once the GEMM launch is over), x = bf16(y) stored,
-//                            partial sum of squares per (slice, row)
-//   rowfin_route_kernel      column slices of 64: rstd from the partials, h = rmsnorm(x) * w stored, partial router products of the NEXT
-//                            group on its slice (6 KB of [R;A] per block instead of 90 KB per row); the LAST block to arrive (one
-//                            returning atomic, nobody waits) sums the slices in slice order and writes u = scaling * p (x) (h A^T).
-// Nothing spins: the only cross-block step is the last-arriver reduction, so the pair cannot hang.  Deterministic (fixed orders).
+//                            projection, applied here because T only exists once the GEMM launch is over), x = y stored (fp32 stream, or bf16),
+//                            partial sum of squares per (slice, row); r04 (<.., true> instantiation): ALSO the partial router products of the
+//                            NEXT group on its slice, formed on the unnormalised row times the norm weight - t = rstd * ((y (.) w) . [R;A]^T), rstd
+//                            being a per-row scalar - with the 256 threads split as (router row, 16 of the 64 columns) over the live rows only
+//   rowfin_norm_mix_kernel   column slices of 64: rstd from the partial sums of squares, h = rmsnorm(x) * w stored; every block also takes one
+//                            (row, projection) pair of the next group: its slices' partials summed in a fixed order, times rstd, fp32 softmax,
+//                            u = scaling * p (x) (h A^T).  One memory round trip; no block waits for another.
+// r03's second launch (rowfin_route_kernel, kept behind CRAB_ROWFIN_TAIL=1 for A/B runs) formed the partials itself, AFTER rstd, and needed an arrival
+// chain for them - drained write-through partial stores, a returning atomic, the last arriver's acquire + reload: five dependent memory round trips,
+// 8.4 us at one clip against 5.3 for the kernel above (the apply launch grows from 5.5 to 6.2 us): 117 -> 112 us per layer, 3.76 -> 3.60 ms per step.
+// Nothing spins in either form.  Deterministic (fixed orders).
 #include "common.h"
 #include "crab_internal.h"
 #include <stdlib.h>
