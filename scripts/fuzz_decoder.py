@@ -79,10 +79,15 @@ for ci in range(NCFG):
         scale = float(ref_lg.abs().max())
         top2 = ref_lg.topk(2, -1).values
         margin = top2[..., 0] - top2[..., 1]
+        emu_seen = 0.0
         for b in range(len(rows)):
             for s in range(n):
                 err = float((lg[b, s] - ref_lg[b, s]).abs().max())
-                emu = float((emu_lg[b, s] - ref_lg[b, s]).abs().max()) if bool((emu_ids[b, :s] == ref_ids[b, :s]).all()) else 0.0
+                # once the EMULATED run has left the reference's token sequence (a sub-noise margin) its logits say nothing about this context: the bound
+                # falls back to the largest emulation error seen on this configuration's earlier rows / steps (at least 2 x REL)
+                emu_ok = bool((emu_ids[b, :s] == ref_ids[b, :s]).all())
+                emu = float((emu_lg[b, s] - ref_lg[b, s]).abs().max()) if emu_ok else max(emu_seen, 0.8 * REL * scale)
+                if emu_ok: emu_seen = max(emu_seen, emu)
                 worst_all = max(worst_all, err / scale)
                 if err > max(REL * scale, 2.5 * emu):
                     bad.append(desc + f" -> row {rows[b]} step {s}: logit err {err / scale:.3e} of scale (bf16-storage emulation {emu / scale:.3e})"); break
