@@ -655,14 +655,14 @@ __global__ __launch_bounds__(256) void attn_decode_keymask_kernel(const bf16_t* 
 //     0.7 TB/s): every split writes its (max, sum, weighted V sum) with write-through stores, takes a ticket on a per-(b, h) counter
 //     and the LAST one merges the splits in split order - nobody waits, the order of arrival does not matter (deterministic).
 //     The counters must be zero at entry; the kernel leaves them zero (the caller zero-fills the workspace once).
-template <int HD>
-__global__ __launch_bounds__(256) void attn_decode_rope_kernel(const bf16_t* __restrict__ qkv, long ldq, const float* __restrict__ tab,
+template <int HD, int NG = 16>                              // NG 16-lane key groups per block: 16 (256 threads) or 32 (512 threads, see the launch)
+__global__ __launch_bounds__(NG * 16) void attn_decode_rope_kernel(const bf16_t* __restrict__ qkv, long ldq, const float* __restrict__ tab,
                                                                bf16_t* __restrict__ kc, bf16_t* __restrict__ vc, bf16_t* __restrict__ o, long ldo,
                                                                int H, int Hk, int Tmax, int pos0, const int* __restrict__ pos_dev, float scale,
                                                                float* part, unsigned* counters) {
     constexpr int EPL = HD / 16, WPL = EPL / 2;                 // elements / 32-bit words per lane
-    __shared__ float sm[16], sl[16];
-    __shared__ float so[16][HD];
+    __shared__ float sm[NG], sl[NG];
+    __shared__ float so[NG][HD];
     __shared__ unsigned s_old;
     const int tid = threadIdx.x;
     const int grp = tid >> 4, sub = tid & 15;
@@ -699,7 +699,7 @@ __global__ __launch_bounds__(256) void attn_decode_rope_kernel(const bf16_t* __r
         for (int u = 0; u < NB; ++u) {
             // clamped in ABSOLUTE rows: an empty split (kb0 beyond pos; nc <= 0) must not read past this head's cache rows - it reads row
             // max(pos - 1, 0) or an earlier one, whose value is never used
-            const int ja = max(min(kb0 + grp + 16 * u, kb0 + nc - 1), 0) - kb0;
+            const int ja = max(min(kb0 + grp + NG * u, kb0 + nc - 1), 0) - kb0;
             kk[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kb + (long)ja * HD));
             vv[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vb + (long)ja * HD));
         }
@@ -736,11 +736,11 @@ __global__ __launch_bounds__(256) void attn_decode_rope_kernel(const bf16_t* __r
     if (EPL == 8) {
         // NB keys per group and trip: NB scores, ONE running-max update and rescale, then the weighted V rows; keys beyond the split are
         // masked (probability 0, V row replaced by zeros: the clamped row may hold anything)
-        for (int j0 = 0; j0 < nc; j0 += 16 * NB) {
+        for (int j0 = 0; j0 < nc; j0 += NG * NB) {
             if (j0 > 0) {
 #pragma unroll
                 for (int u = 0; u < NB; ++u) {
-                    const int jc = min(j0 + grp + 16 * u, nc - 1);
+                    const int jc = min(j0 + grp + NG * u, nc - 1);
                     kk[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kb + (long)jc * HD));
                     vv[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vb + (long)jc * HD));
                 }
@@ -752,7 +752,7 @@ __global__ __launch_bounds__(256) void attn_decode_rope_kernel(const bf16_t* __r
 #pragma unroll
                 for (int e = 0; e < 4; ++e) d += qv[2 * e] * lo_bf(kk[u][e]) + qv[2 * e + 1] * hi_bf(kk[u][e]);
                 d = row16_sum(d);
-                sc[u] = j0 + grp + 16 * u < nc ? d : -INFINITY;  // group-uniform
+                sc[u] = j0 + grp + NG * u < nc ? d : -INFINITY;  // group-uniform
                 mx = fmaxf(mx, sc[u]);
             }
             const float mn = fmaxf(m, mx);
@@ -762,7 +762,7 @@ __global__ __launch_bounds__(256) void attn_decode_rope_kernel(const bf16_t* __r
             for (int e = 0; e < EPL; ++e) t[e] = 0.f;
 #pragma unroll
             for (int u = 0; u < NB; ++u) {
-                const bool ok = j0 + grp + 16 * u < nc;
+                const bool ok = j0 + grp + NG * u < nc;
                 const float pw = __expf(sc[u] - mn);            // exp(-inf) = 0 for the masked keys
                 ps += pw;
 #pragma unroll
@@ -778,7 +778,7 @@ __global__ __launch_bounds__(256) void attn_decode_rope_kernel(const bf16_t* __r
             m = mn;
         }
     } else {
-    for (int j = grp; j < nc; j += 16) {
+    for (int j = grp; j < nc; j += NG) {
         uint32_t kk2[WPL], vv2[WPL];
 #pragma unroll
         for (int i = 0; i < WPL; ++i) {
@@ -821,9 +821,9 @@ __global__ __launch_bounds__(256) void attn_decode_rope_kernel(const bf16_t* __r
     float Mx = -1e30f, L = 0.f, O = 0.f;
     if (tid < HD) {
 #pragma unroll
-        for (int g = 0; g < 16; ++g) Mx = fmaxf(Mx, sm[g]);
+        for (int g = 0; g < NG; ++g) Mx = fmaxf(Mx, sm[g]);
 #pragma unroll
-        for (int g = 0; g < 16; ++g) {
+        for (int g = 0; g < NG; ++g) {
             const float w = __expf(sm[g] - Mx);
             L += sl[g] * w;
             O += so[g][tid] * w;
@@ -1135,8 +1135,17 @@ extern "C" int crab_attn_decode_rope(crab_ctx* ctx, void* stream, const void* qk
         return crab_fail(ctx, CRAB_E_WORKSPACE, "attn_decode_rope: needs crab_attn_decode_rope_workspace(B, H, d) bytes (counters zeroed once)");
     float* part = (float*)workspace;
     unsigned* counters = workspace ? (unsigned*)((char*)workspace + ((int64_t)B * H * 8 * (d + 2) * 4 + 255) / 256 * 256) : nullptr;
-    dim3 grid(H, B, nsplit), block(256);
     hipStream_t s = (hipStream_t)stream;
+    // TWO splits (half of the chip's worth of (b, h) pairs: 5 .. 8 clips of 32 heads - the reference's eval batch) run as ONE block of 32 key
+    // groups per pair instead: the same rows in flight per CU, merged through LDS - no partial stores, arrival ticket and reload by the last of
+    // two blocks (r04: decode step at batch 8 4.36-4.39 -> 4.31-4.32 ms).  CRAB_ATTN_WIDE=0 keeps the two-split form (A/B runs).
+    static const int wide_on = []() { const char* e = getenv("CRAB_ATTN_WIDE"); return !(e && e[0] == '0'); }();
+    if (wide_on && nsplit == 2 && d == 128) {
+        hipLaunchKernelGGL((attn_decode_rope_kernel<128, 32>), dim3(H, B, 1), dim3(512), 0, s, (const bf16_t*)qkv, (long)ldqkv, rope_tab, (bf16_t*)k_cache,
+                           (bf16_t*)v_cache, (bf16_t*)o, (long)ldo, H, Hk, Tmax, pos0, pos_dev, scale, (float*)nullptr, (unsigned*)nullptr);
+        return crab_check_launch(ctx, "attn_decode_rope(wide)");
+    }
+    dim3 grid(H, B, nsplit), block(256);
     if (d == 128)
         hipLaunchKernelGGL((attn_decode_rope_kernel<128>), grid, block, 0, s, (const bf16_t*)qkv, (long)ldqkv, rope_tab, (bf16_t*)k_cache,
                            (bf16_t*)v_cache, (bf16_t*)o, (long)ldo, H, Hk, Tmax, pos0, pos_dev, scale, part, counters);
