@@ -242,10 +242,46 @@ def operating_points(model, um, args, eos):
                              "frac": round(algo / dt / 1e9 / HBM_PEAK_GBS, 4),
                              "note": "every batch streams the weights for itself (separate M = 8 launches): bytes = G x one batch's"}}
 
+    def run_coalesced(name, G, B, spread, note):
+        """G of the reference's eval batches of B clips decoding as ONE ragged batch (generate_batches(coalesce=True) = what
+        harness.run_inference(coalesce=True) calls): every batch keeps its own prepare_multimodal_inputs result, left padding and positions
+        from 0; the weights stream once per decode step for all G x B rows and the encoders see all clips together.  spread > 0: batch g's
+        prompts have 128 - spread + (7 g mod (2 spread + 1)) tokens, so the batches differ in length like a real question set does."""
+        batches = []
+        for g in range(G):
+            nt = 128 if not spread else 128 - spread + (7 * g) % (2 * spread + 1)
+            ids = [synth.synth_prompt_ids(nt, model.base_vocab, tab, clip=9500 + g * B + i) for i in range(B)]
+            batches.append(dict(batch_input_ids=[i.cuda() for i in ids], batch_labels=[torch.full_like(i, -100) for i in ids],
+                                batch_X_modals=[{'<video>': synth.synth_video(args.frames, clip=9500 + g * B + i).cuda(),
+                                                 '<audio>': synth.synth_audio(10, 98, clip=9500 + g * B + i).cuda()} for i in range(B)],
+                                batch_task_names=['avqa'] * B))
+
+        def go():
+            return model.generate_batches(batches, coalesce=True, max_rows=G * B, use_cache=True, max_new_tokens=args.new_tokens,
+                                          min_new_tokens=args.new_tokens, eos_token_id=eos, pad_token_id=um.model.pad_token_id)
+        go()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            r = go()
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        dt = min(ts)
+        assert len(r) == G and all(tuple(x.shape) == (B, args.new_tokens) for x in r)
+        out[name] = {"batches": G, "clips_per_batch": B, "rows_decoding_together": um._engine.last_plan.get("groups"), "frames": args.frames,
+                     "prompt_tokens": "128" if not spread else f"{128 - spread}..{128 + spread} (one length per batch)",
+                     "clips_per_s": round(G * B / dt, 3), "ms_per_call": [round(t * 1e3, 1) for t in ts], "note": note}
+
     run("single_clip", 1, args.frames, 98, "scripts/quick_start.py: one clip per generate() (BASELINE configs[0] shape on the GPU); latency = ms_per_batch")
     run("eval_batch_8", 8, args.frames, 98, "the reference's eval batch size; per-batch latency = ms_per_batch")
     run_in_flight("eval_batch_8_x3_in_flight", 3, 8, "three eval batches of 8 decoding concurrently on separate HIP streams (harness.run_inference in_flight=3)")
     run_in_flight("eval_batch_8_x4_in_flight", 4, 8, "four eval batches of 8 in flight")
+    gco = max(2, min(args.clips, 448) // 8)
+    run_coalesced("eval_batch_8_coalesced", gco, 8, 0, f"{gco} eval batches of 8 (inference_hyper_lora.py:1477) coalesced into one ragged decode batch "
+                  "(harness.run_inference(coalesce=True)); per-batch results = those of separate generate() calls within the decoder's bf16 tolerance")
+    run_coalesced("eval_batch_8_coalesced_ragged", gco, 8, 12, "the same with a different prompt length per batch (116..140 tokens): per-batch prefill, "
+                  "per-row rotary offset and first visible key in the decode kernels")
     nb = min(args.clips, 256)                    # (256: the r01-r03 batch, so that these two lines stay comparable across rounds)
     run("audio_2s_windows", nb, args.frames, 198, "MUSIC-AVQA audio shape [10,198,128] (96 BEATs tokens per window)")
     run("frames_10", nb, 10, 98, "the reference's default video_frame_nums = 10 (S = 766)")

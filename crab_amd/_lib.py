@@ -38,6 +38,7 @@ class GemmDesc(C.Structure):
         ("rope_S", C.c_int32), ("rope_ld_pos", C.c_int64), ("rope_pos_ids", C.c_void_p),
         ("rope_vt", C.c_void_p), ("rope_vt_ld", C.c_int64),
         ("r_fp32", C.c_int32),
+        ("rope_row_off", C.c_void_p),
     ]
 
 
@@ -119,6 +120,7 @@ class LlamaIO(C.Structure):
         ("B", C.c_int32), ("S", C.c_int32), ("Tmax", C.c_int32), ("pos0", C.c_int32), ("u_qkv_ready", C.c_int32),
         ("attn_ws", C.c_void_p), ("attn_ws_bytes", C.c_int64),
         ("x_fp32", C.c_int32),
+        ("row_off", C.c_void_p),
     ]
 
 
@@ -164,6 +166,7 @@ SYMBOLS = {
     "crab_rope_table": (_i, [_vp, _vp, _vp, _i, _i, _f]),
     "crab_qkv_rope_split": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "crab_qkv_rope_split_ids": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i64]),
+    "crab_qkv_rope_split_ragged": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "crab_attn_decode_masked": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _vp, _f, _vp]),
     "crab_attn_decode_keymask": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _vp, _f, _vp, _i64]),
     "crab_attn_fwd": (_i, [_vp, _vp, C.POINTER(AttnDesc)]),

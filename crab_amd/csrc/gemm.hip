@@ -511,7 +511,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_rope_kernel(const float* 
                                                                     const bf16_t* __restrict__ bias, bf16_t* __restrict__ C, long ldc,
                                                                     const float* __restrict__ tab, bf16_t* __restrict__ kc,
                                                                     bf16_t* __restrict__ vc, const int* __restrict__ pos_dev, int pos0,
-                                                                    int H, int Hk, int d, int Tmax) {
+                                                                    int H, int Hk, int d, int Tmax, const int* __restrict__ row_off) {
     constexpr int V = G / 4;                                    // float4 per half
     const int half = d >> 1, gpd = half / G;                    // G-dim groups per half head
     const int nh = H + 2 * Hk;
@@ -564,7 +564,9 @@ __global__ __launch_bounds__(256) void splitk_epilogue_rope_kernel(const float* 
     }
     float o1[G], o2[G];
     if (hh < H + Hk) {
-        const float* t = tab + 2 * ((long)pos * half + G * j);   // (cos, sin) pairs of dims G j .. G j + G - 1
+        // ragged decode batch (crab_gemm_desc.rope_row_off): the row is rotated at slot - row_off[m], its K / V rows stay in slot `pos`
+        const int rp = pos - (row_off ? row_off[m] : 0);
+        const float* t = tab + 2 * ((long)rp * half + G * j);    // (cos, sin) pairs of dims G j .. G j + G - 1
 #pragma unroll
         for (int r = 0; r < G; ++r) {
             const float c = t[2 * r], sn = t[2 * r + 1];
@@ -625,8 +627,8 @@ static int launch_norm_epilogue(crab_ctx* ctx, hipStream_t s, const crab_gemm_de
 static int post_norm(crab_ctx* ctx, void* stream, const crab_gemm_desc* d) {
     if (d->rope_tab && d->rope_S > 1) return CRAB_OK;   // prefill form: fused in the large-M epilogue or left to the caller (crab_gemm_fuses_prefill_rope)
     if (d->rope_tab)          // paths whose epilogue did not fuse the RoPE / KV append: the separate pass over C
-        return crab_qkv_rope_split(ctx, stream, d->C, d->ldc, d->rope_tab, d->rope_k_cache, d->rope_v_cache, nullptr, 0, d->M, 1, d->rope_H,
-                                   d->rope_Hk, d->rope_d, d->rope_Tmax, d->rope_pos0, d->rope_pos_dev);
+        return crab_qkv_rope_split_ragged(ctx, stream, d->C, d->ldc, d->rope_tab, d->rope_k_cache, d->rope_v_cache, nullptr, 0, d->M, 1, d->rope_H,
+                                          d->rope_Hk, d->rope_d, d->rope_Tmax, d->rope_pos0, d->rope_pos_dev, d->rope_row_off);
     if (!d->norm_w) return CRAB_OK;
     int rc = d->c_fp32 ? crab_rmsnorm_f32(ctx, stream, (const float*)d->C, d->ldc, d->norm_w, d->norm_out, d->ld_norm, d->M, d->N, d->norm_eps)
                        : crab_rmsnorm(ctx, stream, d->C, d->ldc, d->norm_w, d->norm_out, d->ld_norm, d->M, d->N, d->norm_eps);
@@ -653,6 +655,8 @@ extern "C" int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc*
         if (d->c_fp32 || d->act != ACT_NONE || d->R || d->norm_w || d->batch > 1 || !d->rope_k_cache || !d->rope_v_cache ||
             d->rope_H <= 0 || d->rope_Hk <= 0 || d->rope_d <= 0 || d->N != (d->rope_H + 2 * d->rope_Hk) * d->rope_d)
             return crab_fail(ctx, CRAB_E_INVALID, "gemm: fused rope needs bf16 C, N == (H + 2 Hk) d, caches, no act / residual / post-norm / batch");
+        if (d->rope_row_off && d->rope_S > 1)
+            return crab_fail(ctx, CRAB_E_INVALID, "gemm: rope_row_off belongs to the decode form (one row per sequence); a prefill call advances its cache pointers instead");
     }
     // prefill form of the fused RoPE (rope_S > 1 rows per sequence): only the large-M kernel implements it; when it will not (shape, alignment,
     // kernel choice - crab_gemm_fuses_prefill_rope, the caller asks the same question and then runs crab_qkv_rope_split itself) the rope
@@ -829,7 +833,8 @@ extern "C" int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc*
             const long nthr = (long)d->M * (d->rope_H + 2 * d->rope_Hk) * (d->rope_d >> (g8 ? 4 : 3));
 #define ROPE_EPI(G_) hipLaunchKernelGGL((splitk_epilogue_rope_kernel<G_>), dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, p.part, splitk, \
                                         d->M, d->N, p.bias, (bf16_t*)d->C, (long)d->ldc, d->rope_tab, (bf16_t*)d->rope_k_cache,                 \
-                                        (bf16_t*)d->rope_v_cache, d->rope_pos_dev, d->rope_pos0, d->rope_H, d->rope_Hk, d->rope_d, d->rope_Tmax)
+                                        (bf16_t*)d->rope_v_cache, d->rope_pos_dev, d->rope_pos0, d->rope_H, d->rope_Hk, d->rope_d, d->rope_Tmax,        \
+                                        d->rope_row_off)
             if (g8) ROPE_EPI(8); else ROPE_EPI(4);
 #undef ROPE_EPI
             return crab_check_launch(ctx, "splitk_epilogue_rope_kernel");

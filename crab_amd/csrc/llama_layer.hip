@@ -72,6 +72,7 @@ int run_group(crab_ctx* ctx, void* stream, const crab_linear_group* g, const cra
     if (c.rope) {
         d.rope_tab = io->rope_tab; d.rope_k_cache = k_cache; d.rope_v_cache = v_cache; d.rope_pos_dev = io->pos_dev;
         d.rope_H = L->H; d.rope_Hk = L->Hk; d.rope_d = L->d; d.rope_Tmax = io->Tmax; d.rope_pos0 = io->pos0;
+        d.rope_row_off = io->row_off;                              // ragged decode batch: row b rotates at slot - row_off[b]
     }
     if (c.rope_prefill_S > 1 && !io->pos_dev) {
         d.rope_tab = io->rope_tab; d.rope_k_cache = k_cache; d.rope_v_cache = v_cache; d.rope_pos_dev = nullptr;
@@ -124,6 +125,7 @@ int check_io(crab_ctx* ctx, const crab_llama_layer* L, const crab_llama_io* io, 
     if (prefill) {
         if (!io->vt || io->vt_ld < io->S) return crab_fail(ctx, CRAB_E_INVALID, "llama_layer_prefill: vt [B, Hk, d, vt_ld >= S] is required");
         if (io->pos0 + io->S > io->Tmax) return crab_fail(ctx, CRAB_E_INVALID, "llama_layer_prefill: rows do not fit the KV cache");
+        if (io->row_off) return crab_fail(ctx, CRAB_E_INVALID, "llama_layer_prefill: row_off is a decode field (a prefill into a right-aligned cache advances k_cache / v_cache instead)");
     } else {
         if (io->S != 1) return crab_fail(ctx, CRAB_E_INVALID, "llama_layer_decode: one row per sequence (S == 1)");
         if (!io->pos_dev && io->pos0 >= io->Tmax) return crab_fail(ctx, CRAB_E_INVALID, "llama_layer_decode: position outside the KV cache");
@@ -141,7 +143,8 @@ int run_layer(crab_ctx* ctx, void* stream, const crab_llama_layer* L, crab_llama
     // ---- q|k|v
     // small batch (B * H blocks cannot fill 256 CUs): the projection leaves its raw row and ONE launch does RoPE + KV append + attention with
     // the context split over several blocks per head (crab_attn_decode_rope) - same choice as crab_amd/decoder.py
-    const bool fuse_attn = !prefill && io->attn_ws && (long)B * H < CRAB_ATTN_SPLIT_BELOW && (d == 64 || d == 128) && (io->ldqkv & 7) == 0 &&
+    // (a ragged batch - io->row_off - takes the general pair: projection with the per-row rotary offset, then the attention with a first visible key per row)
+    const bool fuse_attn = !prefill && !io->row_off && io->attn_ws && (long)B * H < CRAB_ATTN_SPLIT_BELOW && (d == 64 || d == 128) && (io->ldqkv & 7) == 0 &&
                            io->attn_ws_bytes >= crab_attn_decode_rope_workspace(B, H, d);
     GroupCall q{};
     q.x = io->h; q.ldx = io->ldh; q.out = io->qkv; q.ldc = io->ldqkv; q.act = CRAB_ACT_NONE;
@@ -171,8 +174,8 @@ int run_layer(crab_ctx* ctx, void* stream, const crab_llama_layer* L, crab_llama
                                         io->pos_dev, scale, io->attn_ws, io->attn_ws_bytes)))
             return rc;
     } else {
-        if ((rc = crab_attn_decode(ctx, stream, io->qkv, io->ldqkv, kc, vc, io->att, io->ldatt, B, H, Hk, d, io->Tmax, io->pos0 + 1,
-                                   io->pos_dev, scale)))
+        if ((rc = crab_attn_decode_masked(ctx, stream, io->qkv, io->ldqkv, kc, vc, io->att, io->ldatt, B, H, Hk, d, io->Tmax, io->pos0 + 1,
+                                          io->pos_dev, scale, io->row_off)))
             return rc;
     }
     // ---- o: x += o(att); h = rmsnorm(x) * post_attention_layernorm (+ the gate|up router ahead in the decode regime)

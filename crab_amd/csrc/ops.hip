@@ -219,7 +219,7 @@ __global__ void rope_table_kernel(float* tab, int max_pos, int half, float theta
 __global__ void qkv_rope_split_kernel(bf16_t* __restrict__ qkv, long ldqkv, const float* __restrict__ tab,
                                       bf16_t* __restrict__ kc, bf16_t* __restrict__ vc, bf16_t* __restrict__ vt, long vt_ld,
                                       int S, int H, int Hk, int d, int Tmax, int pos0, const int* __restrict__ pos_dev,
-                                      const int* __restrict__ pos_ids, long ld_pos) {
+                                      const int* __restrict__ pos_ids, long ld_pos, const int* __restrict__ row_off) {
     const int t = blockIdx.x;            // token index b*S + s
     const int hh = blockIdx.y;           // 0..H-1 q heads, H..H+Hk-1 k heads, H+Hk.. v heads
     const int b = t / S, s = t % S;
@@ -228,7 +228,8 @@ __global__ void qkv_rope_split_kernel(bf16_t* __restrict__ qkv, long ldqkv, cons
     if (i >= half) return;
     if (!tab && (hh < H || (hh < H + Hk && !kc))) return;      // encoder use: only V^T is materialised
     const int pos = (pos_dev ? pos_dev[0] : 0) + pos0 + s;       // cache slot
-    const int rp = pos_ids ? pos_ids[(long)b * ld_pos + s] : pos;   // rotary position (position_ids of forward())
+    // rotary position: position_ids of forward(), or - ragged decode batch - the slot minus the sequence's first slot
+    const int rp = pos_ids ? pos_ids[(long)b * ld_pos + s] : pos - (row_off ? row_off[b] : 0);
     bf16_t* src = qkv + (long)t * ldqkv + (long)hh * d;
     if (hh < H + Hk) {
         float x1 = bf2f(src[i]), x2 = bf2f(src[i + half]);
@@ -830,14 +831,30 @@ int crab_qkv_rope_split(crab_ctx* ctx, void* stream, void* qkv, int64_t ldqkv, c
     return crab_qkv_rope_split_ids(ctx, stream, qkv, ldqkv, rope_tab, k_cache, v_cache, vt, vt_ld, B, S, H, Hk, d, Tmax, pos0, pos_dev, nullptr, 0);
 }
 
+static int qkv_rope_split_impl(crab_ctx* ctx, void* stream, void* qkv, int64_t ldqkv, const float* rope_tab, void* k_cache, void* v_cache,
+                               void* vt, int64_t vt_ld, int B, int S, int H, int Hk, int d, int Tmax, int pos0, const int32_t* pos_dev,
+                               const int32_t* pos_ids, int64_t ld_pos, const int32_t* row_off);
+
 int crab_qkv_rope_split_ids(crab_ctx* ctx, void* stream, void* qkv, int64_t ldqkv, const float* rope_tab, void* k_cache, void* v_cache,
                             void* vt, int64_t vt_ld, int B, int S, int H, int Hk, int d, int Tmax, int pos0, const int32_t* pos_dev,
                             const int32_t* pos_ids, int64_t ld_pos) {
+    return qkv_rope_split_impl(ctx, stream, qkv, ldqkv, rope_tab, k_cache, v_cache, vt, vt_ld, B, S, H, Hk, d, Tmax, pos0, pos_dev, pos_ids, ld_pos, nullptr);
+}
+
+int crab_qkv_rope_split_ragged(crab_ctx* ctx, void* stream, void* qkv, int64_t ldqkv, const float* rope_tab, void* k_cache, void* v_cache,
+                               void* vt, int64_t vt_ld, int B, int S, int H, int Hk, int d, int Tmax, int pos0, const int32_t* pos_dev,
+                               const int32_t* row_off) {
+    return qkv_rope_split_impl(ctx, stream, qkv, ldqkv, rope_tab, k_cache, v_cache, vt, vt_ld, B, S, H, Hk, d, Tmax, pos0, pos_dev, nullptr, 0, row_off);
+}
+
+static int qkv_rope_split_impl(crab_ctx* ctx, void* stream, void* qkv, int64_t ldqkv, const float* rope_tab, void* k_cache, void* v_cache,
+                               void* vt, int64_t vt_ld, int B, int S, int H, int Hk, int d, int Tmax, int pos0, const int32_t* pos_dev,
+                               const int32_t* pos_ids, int64_t ld_pos, const int32_t* row_off) {
     if (!ctx) return CRAB_E_INVALID;
     if (pos_ids && ld_pos < S) return crab_fail(ctx, CRAB_E_INVALID, "qkv_rope_split: ld_pos < S");
     if (!qkv || B <= 0 || S <= 0 || d > 2048 || (d & 1)) return crab_fail(ctx, CRAB_E_INVALID, "qkv_rope_split: bad argument");
     if ((k_cache || v_cache) && !pos_dev && pos0 + S > Tmax) return crab_fail(ctx, CRAB_E_INVALID, "qkv_rope_split: KV cache overflow");
-    if (S >= 16 && !pos_dev && (d == 32 || d == 64 || d == 128) && (ldqkv & 7) == 0 && (vt == nullptr || (vt_ld & 7) == 0)) {
+    if (S >= 16 && !pos_dev && !row_off && (d == 32 || d == 64 || d == 128) && (ldqkv & 7) == 0 && (vt == nullptr || (vt_ld & 7) == 0)) {
         dim3 grid((S + 63) / 64, H + 2 * Hk, B);
 #define RS_ARGS (bf16_t*)qkv, (long)ldqkv, rope_tab, (bf16_t*)k_cache, (bf16_t*)v_cache, (bf16_t*)vt, (long)vt_ld, S, H, Hk, Tmax, pos0, pos_ids, (long)ld_pos
         if (d == 128) hipLaunchKernelGGL((qkv_rope_split_tile_kernel<128>), grid, dim3(256), 0, S_(stream), RS_ARGS);
@@ -848,7 +865,7 @@ int crab_qkv_rope_split_ids(crab_ctx* ctx, void* stream, void* qkv, int64_t ldqk
     }
     int threads = ((d / 2 + 63) / 64) * 64;
     hipLaunchKernelGGL(qkv_rope_split_kernel, dim3(B * S, H + 2 * Hk), dim3(threads), 0, S_(stream), (bf16_t*)qkv, (long)ldqkv, rope_tab,
-                       (bf16_t*)k_cache, (bf16_t*)v_cache, (bf16_t*)vt, (long)vt_ld, S, H, Hk, d, Tmax, pos0, pos_dev, pos_ids, (long)ld_pos);
+                       (bf16_t*)k_cache, (bf16_t*)v_cache, (bf16_t*)vt, (long)vt_ld, S, H, Hk, d, Tmax, pos0, pos_dev, pos_ids, (long)ld_pos, row_off);
     return crab_check_launch(ctx, "qkv_rope_split");
 }
 

@@ -41,6 +41,7 @@ struct SkinnyP {
     // (v heads keep 16 consecutive rows), so both partners of every pair sit in its 16-column tile, two lane groups apart.
     const float* rope_tab; bf16_t* rope_kc; bf16_t* rope_vc; const int* rope_pos_dev;
     int rope_H, rope_Hk, rope_d, rope_Tmax, rope_pos0;
+    const int* rope_row_off;                 // ragged decode batch: row m rotates at slot - rope_row_off[m] (crab_gemm_desc.rope_row_off)
 };
 
 constexpr int SK_WAVES = 8;
@@ -305,7 +306,8 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_dma_kernel(SkinnyP 
                 return;
             }
             const int idim = 8 * r_j + (cg & 1) * 4;                     // index of the rotation pair (first-half dim)
-            const float* cs = p.rope_tab + ((long)pos * r_half + idim) * 2;
+            const int rp = pos - (p.rope_row_off ? p.rope_row_off[m] : 0);   // rotary position (m < M here); the cache slot stays `pos`
+            const float* cs = p.rope_tab + ((long)rp * r_half + idim) * 2;
             float o[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -608,9 +610,11 @@ int crab_gemm_skinny_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* 
     p.M = d->M; p.N = d->N; p.K = d->K; p.K2 = d->A2 ? d->K2 : 0; p.act = d->act; p.c_fp32 = crab_cflags(d); p.res_scale = d->res_scale;
     p.Bx = nullptr; p.ldbx = 0; p.Tx = nullptr;
     p.rope_tab = nullptr; p.rope_kc = p.rope_vc = nullptr; p.rope_pos_dev = nullptr; p.rope_H = p.rope_Hk = p.rope_d = p.rope_Tmax = p.rope_pos0 = 0;
+    p.rope_row_off = nullptr;
     if (crab_skinny_fuses_rope(d)) {
         p.rope_tab = d->rope_tab; p.rope_kc = (bf16_t*)d->rope_k_cache; p.rope_vc = (bf16_t*)d->rope_v_cache; p.rope_pos_dev = d->rope_pos_dev;
         p.rope_H = d->rope_H; p.rope_Hk = d->rope_Hk; p.rope_d = d->rope_d; p.rope_Tmax = d->rope_Tmax; p.rope_pos0 = d->rope_pos0;
+        p.rope_row_off = d->rope_row_off;
     }
     // M <= 16: the LDS-DMA ring kernel (tune 1 / 2 / 4 keep the register-direct kernel for A/B runs); d->tune == 9: the same with
     // raw fp32 sums to the workspace (used by crab_gemm_bf16 for its fused reduction epilogues)

@@ -280,19 +280,31 @@ class GenerationEngine:
 
     def memory_budget(self, B: int, Tmax: int, slots: int = 1) -> int:
         """Bytes generate() may still claim on this device: what the driver reports free (hipMemGetInfo) + what torch's caching
-        allocator holds but has not handed out + the engine's own persistent KV buffers of the slots the upcoming call will re-allocate
-        (slots 0 .. slots-1: alloc_cache drops a slot's old buffers before allocating the new shape; buffers of OTHER slots are released by
-        _drop_stale_slots before planning, so they show up as free memory, not here).  `kv_budget_bytes` overrides it."""
+        allocator holds but has not handed out + the engine's own persistent KV buffers - those of the slots the upcoming call re-allocates
+        (alloc_cache drops a slot's old buffers before allocating the new shape) AND those of the other slots, which an earlier
+        generate_many / decode_streams > 1 call left behind: alloc_cache evicts them (_drop_stale_slots) the moment a new cache would not fit
+        beside them, so they count as reclaimable.  A pure query: nothing is freed here (a loop that alternates generate_many(G > 1) with
+        generate() keeps its caches and captured graphs as long as the memory is not needed).  `kv_budget_bytes` overrides it."""
         if self.kv_budget_bytes is not None:
             return int(self.kv_budget_bytes)
-        self._drop_stale_slots(slots)
+        self._live_slots = max(1, int(slots))                  # what alloc_cache may NOT evict during the call being planned
         free, _total = torch.cuda.mem_get_info(self.device)
         cached = torch.cuda.memory_reserved(self.device) - torch.cuda.memory_allocated(self.device)
-        own = 0
-        for key, (kcb, vcb) in self._kv.items():
-            if key[0] < slots:
-                own += kcb.numel() * 2 + vcb.numel() * 2
+        own = sum(kcb.numel() * 2 + vcb.numel() * 2 for (kcb, vcb) in self._kv.values())
         return int(free + cached + own)
+
+    def _evict_for(self, need_bytes: int, slot: int, slack: int = 4 << 30) -> bool:
+        """Lazy eviction: the KV caches, decode states and graphs of slots the running call does not use (left by an earlier generate_many /
+        decode_streams > 1) are released only when `need_bytes` (+ slack for workspaces) would not fit beside them - memory_budget() counted
+        them as reclaimable.  Returns whether anything was dropped."""
+        free, _t = torch.cuda.mem_get_info(self.device)
+        cached = torch.cuda.memory_reserved(self.device) - torch.cuda.memory_allocated(self.device)
+        if need_bytes + slack <= free + cached:
+            return False
+        keep = max(getattr(self, "_live_slots", 1), slot + 1)
+        had = any(k[0] >= keep for k in self._kv)
+        self._drop_stale_slots(keep)
+        return had
 
     def plan_batch(self, B: int, S: int, max_new_tokens: int, slots: int = 1) -> List[int]:
         """Split B sequences into groups that are generated one after the other when their KV cache + scratch would not fit the device
@@ -328,6 +340,8 @@ class GenerationEngine:
             hit = None
             if self._dec.pop(slot, None) is not None:    # ... and the decode state (+ graph) that still references them: at
                 torch.cuda.empty_cache()                 # 256 clips the old and new caches (2 x ~65 GB each) do not fit together
+            if self.device.type == "cuda":
+                self._evict_for(2 * 2 * math.prod(shape), slot)
             self._kv[key] = (torch.empty(shape, device=self.device, dtype=BF16), torch.empty(shape, device=self.device, dtype=BF16))
         return self._kv[key]
 
@@ -363,7 +377,7 @@ class GenerationEngine:
         return tab
 
     def _layers_native(self, ws: _Workspace, B: int, S: int, kc: torch.Tensor, vc: torch.Tensor, b0: int, Tmax: int, pos0: int,
-                       pos_dev: Optional[torch.Tensor], vt: Optional[torch.Tensor]):
+                       pos_dev: Optional[torch.Tensor], vt: Optional[torch.Tensor], t0: int = 0, row_off: Optional[torch.Tensor] = None):
         """The whole stack through ONE C call (crab_llama_layers, csrc/llama_layer.hip): the same launches in the same order as the
         per-launch Python sequence below, which is kept for the runs that time individual kernels (ops.PROFILER)."""
         io = _lib.LlamaIO()
@@ -373,7 +387,9 @@ class GenerationEngine:
         sk = ops._splitk_workspace(self.device)
         io.splitk_ws, io.splitk_ws_bytes = sk.data_ptr(), sk.numel()
         io.rope_tab = self._rope_tab(Tmax).data_ptr()
-        io.k_cache, io.v_cache, io.cache_layer_stride = kc[0, b0].data_ptr(), vc[0, b0].data_ptr(), kc.stride(0)
+        shift = t0 * kc.stride(3) * kc.element_size()              # a prefill into a right-aligned cache starts at slot t0 of every head's rows
+        io.k_cache, io.v_cache, io.cache_layer_stride = kc[0, b0].data_ptr() + shift, vc[0, b0].data_ptr() + shift, kc.stride(0)
+        io.row_off = row_off.data_ptr() if row_off is not None else None
         if vt is not None:
             io.vt, io.vt_ld = vt.data_ptr(), vt.stride(-2)
         io.pos_dev = pos_dev.data_ptr() if pos_dev is not None else None
@@ -386,9 +402,13 @@ class GenerationEngine:
     # ------------------------------------------------------------------ one pass over the layers
     def _layers(self, ws: _Workspace, B: int, S: int, kc: torch.Tensor, vc: torch.Tensor, b0: int, Tmax: int, pos0: int,
                 pos_dev: Optional[torch.Tensor], vt: Optional[torch.Tensor], pos_ids: Optional[torch.Tensor] = None,
-                kv_start: Optional[torch.Tensor] = None, key_mask: Optional[torch.Tensor] = None):
+                kv_start: Optional[torch.Tensor] = None, key_mask: Optional[torch.Tensor] = None, t0: int = 0,
+                row_off: Optional[torch.Tensor] = None):
         """x (ws.x[:B*S]) -> x after all layers.  Prefill when vt is given (S rows per sequence, positions pos0..),
         decode otherwise (S == 1, position read from pos_dev).  kc/vc: [L, Btot, Hk, Tmax, d]; rows b0..b0+B.
+        The RAGGED decode batch (generate_many(coalesce=True)): sequences of different prompt lengths are right-aligned in one cache - a
+        prefill writes its rows to slots t0 .. t0 + S - 1 (rotary positions still 0 .. S - 1: only the cache pointers move), a decode step
+        gets row_off (int32 [B]: first slot of every sequence) = per-row rotary offset + first visible key.
         pos_ids (int32 [B, S]) / kv_start (int32 [B]) / key_mask (int32 [B, words], ops.pack_key_mask): forward()'s position_ids and
         attention_mask (unified_llama.py:149-160) - explicit rotary positions, a per-sequence first visible key (left padding) or a
         visibility bit per key (any other mask); they select the per-launch sequence below (RoPE as its own pass), which is not the
@@ -404,22 +424,28 @@ class GenerationEngine:
         ops.rmsnorm(x, layers[0].input_layernorm.weight, c.rms_norm_eps, out=h)
         timed = ops.per_launch_profiling() and not torch.cuda.is_current_stream_capturing()
         masked = pos_ids is not None or kv_start is not None or key_mask is not None
-        if NATIVE_LAYERS and not timed and not masked and kc.is_contiguous() and vc.is_contiguous() and (vt is not None or S == 1):
-            self._layers_native(ws, B, S, kc, vc, b0, Tmax, pos0, pos_dev, vt)
+        if row_off is not None and (vt is not None or masked):
+            raise ValueError("row_off is a decode-step argument (no masks / position ids next to it)")
+        contig = kc.is_contiguous() and vc.is_contiguous()
+        if NATIVE_LAYERS and not timed and not masked and contig and (vt is not None or S == 1):
+            self._layers_native(ws, B, S, kc, vc, b0, Tmax, pos0, pos_dev, vt, t0, row_off)
             return x, h
         u_qkv = None                                   # router output for the q|k|v group when a producer epilogue made it
         # small batch: the projection leaves its raw row, ONE launch does RoPE + KV append + split-context attention (as csrc/llama_layer.hip)
-        fuse_attn = (vt is None and S == 1 and not masked and ws.attn_ws is not None and B * H < ops.ATTN_SPLIT_BELOW and kc.is_contiguous() and
+        fuse_attn = (vt is None and S == 1 and not masked and row_off is None and ws.attn_ws is not None and B * H < ops.ATTN_SPLIT_BELOW and contig and
                      ws.attn_ws.numel() >= ops.attn_decode_rope_bytes(B, H, d))
         for li, layer in enumerate(layers):
             a, m = layer.self_attn, layer.mlp
             kcl, vcl = kc[li, b0:b0 + B], vc[li, b0:b0 + B]
+            lcontig = kcl.is_contiguous()
+            if t0:                                         # same strides, first slot t0: the kernels take the pointer and Tmax
+                kcl, vcl = kcl[:, :, t0:], vcl[:, :, t0:]
             if fuse_attn:
                 a._qkv(h, out=qkv, t_buf=ws.t, u_buf=ws.u, u_ready=u_qkv)
-            elif vt is None and S == 1 and kcl.is_contiguous() and not masked:
+            elif vt is None and S == 1 and lcontig and not masked:
                 # decode: RoPE + KV append ride on the q|k|v projection (fused into its split-K reduction when it has one)
-                a._qkv(h, out=qkv, t_buf=ws.t, u_buf=ws.u, u_ready=u_qkv, rope=(tab, kcl, vcl, H, Hk, d, Tmax, pos0, pos_dev))
-            elif vt is not None and pos_dev is None and kcl.is_contiguous():
+                a._qkv(h, out=qkv, t_buf=ws.t, u_buf=ws.u, u_ready=u_qkv, rope=(tab, kcl, vcl, H, Hk, d, Tmax, pos0, pos_dev), rope_row_off=row_off)
+            elif vt is not None and pos_dev is None and lcontig:
                 # prefill: q and k rotate (and k lands in the cache) in the projection's epilogue when the library says so; the v columns
                 # (cache append + V^T) are then all that is left for the split pass
                 gi = {}
@@ -432,7 +458,7 @@ class GenerationEngine:
                     ops.qkv_rope_split(qkv, tab, kcl, vcl, vt, B, S, H, Hk, d, Tmax, pos0=pos0, pos_dev=pos_dev, pos_ids=pos_ids)
             else:
                 a._qkv(h, out=qkv, t_buf=ws.t, u_buf=ws.u, u_ready=u_qkv)
-                ops.qkv_rope_split(qkv, tab, kcl, vcl, vt, B, S, H, Hk, d, Tmax, pos0=pos0, pos_dev=pos_dev, pos_ids=pos_ids)
+                ops.qkv_rope_split(qkv, tab, kcl, vcl, vt, B, S, H, Hk, d, Tmax, pos0=pos0, pos_dev=pos_dev, pos_ids=pos_ids, row_off=row_off)
             if vt is not None:
                 Sp = vt.shape[-1]
                 ops.attn_fwd(qkv, kcl, vt, att, q_strides=(S * ldq, d, ldq), k_strides=(Hk * Tmax * d, Tmax * d, d),
@@ -441,7 +467,8 @@ class GenerationEngine:
             elif fuse_attn:
                 ops.attn_decode_rope(qkv, tab, kcl, vcl, att, B, H, Hk, d, Tmax, pos0, scale, pos_dev=pos_dev, workspace=ws.attn_ws)
             else:
-                ops.attn_decode(qkv, kcl, vcl, att, B, H, Hk, d, Tmax, pos0 + 1, scale, ctx_dev=pos_dev, kv_start=kv_start, key_mask=key_mask)
+                ops.attn_decode(qkv, kcl, vcl, att, B, H, Hk, d, Tmax, pos0 + 1, scale, ctx_dev=pos_dev,
+                                kv_start=kv_start if row_off is None else row_off, key_mask=key_mask)
             # x += o_proj(att); h = rmsnorm(x) * post_attention_layernorm  (norm fused into the GEMM epilogue for small M)
             # (decode regime) the row-owning epilogue that produces h also evaluates the router of the group that consumes h
             ahead_gu = m._gu.routes_ahead(M)
@@ -461,7 +488,8 @@ class GenerationEngine:
     # ------------------------------------------------------------------ prefill
     def prefill(self, embeds: torch.Tensor, kc: torch.Tensor, vc: torch.Tensor, b0: int = 0, all_logits: bool = False,
                 logits_out: Optional[torch.Tensor] = None, hn_out: Optional[torch.Tensor] = None,
-                pos_ids: Optional[torch.Tensor] = None, kv_start: Optional[torch.Tensor] = None, key_mask: Optional[torch.Tensor] = None):
+                pos_ids: Optional[torch.Tensor] = None, kv_start: Optional[torch.Tensor] = None, key_mask: Optional[torch.Tensor] = None,
+                t0: int = 0):
         """embeds [B,S,D] bf16 -> (fp32 logits, post-final-norm hidden) of the LAST row ([B,V], [B,D]), or of all
         rows with all_logits ([B,S,V], [B,S,D]); fills cache rows b0..b0+B.  The reference computes lm_head on all
         S rows and discards S-1 of them (modeling_llama.py:1260); generate() only needs the last row
@@ -469,14 +497,14 @@ class GenerationEngine:
         c = self.cfg
         B, S, D = embeds.shape
         Tmax = kc.shape[3]
-        if S > Tmax:
+        if S + t0 > Tmax:
             raise ValueError("prompt longer than the KV cache")
         M = B * S
         ws = self._workspace(M)
         ops.cast_rows(embeds.reshape(M, D), ws.x, M, D)          # bf16 inputs_embeds -> the (fp32) residual stream
         Sp = (S + 7) // 8 * 8
         vt = torch.empty((B, c.num_key_value_heads, c.head_dim, Sp), device=self.device, dtype=BF16)
-        x, hfin = self._layers(ws, B, S, kc, vc, b0, Tmax, 0, None, vt, pos_ids=pos_ids, kv_start=kv_start, key_mask=key_mask)   # hfin = model.norm(x), all rows
+        x, hfin = self._layers(ws, B, S, kc, vc, b0, Tmax, 0, None, vt, pos_ids=pos_ids, kv_start=kv_start, key_mask=key_mask, t0=t0)   # hfin = model.norm(x), all rows
         if all_logits:
             hn = hfin.clone()
             logits = ops.gemm(hn, self.lm_head.weight, out_fp32=True, prof_class="head")
@@ -493,7 +521,7 @@ class GenerationEngine:
         B = st.B
         ws = st.ws
         ops.embedding(st.cur_ids, self.model.embed_tokens.weight, out=ws.x[:B])
-        x, hfin = self._layers(ws, B, 1, st.kc, st.vc, 0, st.Tmax, 0, st.pos_dev, None)
+        x, hfin = self._layers(ws, B, 1, st.kc, st.vc, 0, st.Tmax, 0, st.pos_dev, None, row_off=st.row_off)
         ops.gemm(hfin, self.lm_head.weight, out=st.logits)
         if st.want_hidden:
             ops.copy_rows(hfin, st.hn, B, hfin.shape[1])
@@ -509,11 +537,14 @@ class GenerationEngine:
             t, k, p_, seed = st.sampling
             ops.sample_select(st.logits, st.cur_ids, st.out_ids, st.step_dev, st.finished, st.eos, st.pad, st.min_new, t, k, p_, seed + 7919 * st.slot)
 
-    def _start(self, embeds: torch.Tensor, max_new_tokens: int, eos_token_id, pad_token_id, min_new_tokens: int, prefill_chunk: int,
-               return_hidden: bool, slot: int, sink=None, sampling=None) -> "_DecodeState":
-        """Allocate the decode state of one group of sequences, prefill it and select its first token."""
-        B, S, D = embeds.shape
+    def _state(self, B: int, S: int, max_new_tokens: int, eos_token_id, pad_token_id, min_new_tokens: int, return_hidden: bool, slot: int,
+               sampling=None, ragged: bool = False) -> "_DecodeState":
+        """The persistent decode state of `slot` for B sequences whose (longest) prompt has S rows: KV cache, per-row words, logits and the HIP
+        graph captured over them.  Kept per slot and reused by every call whose shapes, flags and buffers are the same: the key holds
+        everything the captured launches bake in (pointers included).  ragged: the state of a coalesced batch (generate_many(coalesce=True)) -
+        it owns a row_off word per row (first cache slot of the row's sequence) that the captured decode step reads."""
         dev = self.device
+        D = self.cfg.hidden_size
         Tmax = _round_up(S + max_new_tokens, 64)
         kc, vc = self.alloc_cache(B, Tmax, slot=slot)
         V = self.lm_head.weight.shape[0]
@@ -521,12 +552,10 @@ class GenerationEngine:
         pad = int(pad_token_id) if pad_token_id is not None else (eos if eos >= 0 else 0)
         ws = self._workspace(B, slot, decode=True)
         tab = self._rope_tab(Tmax)
-        # The decode state (and the HIP graph captured over it) is kept per group and reused by every generate() whose shapes,
-        # flags and buffers are the same: the key holds everything the captured launches bake in (pointers included).
         key = (B, Tmax, max_new_tokens, eos, pad, int(min_new_tokens), bool(return_hidden), kc.data_ptr(), vc.data_ptr(), id(ws),
                tab.data_ptr(), self.lm_head.weight.data_ptr(), self.model.embed_tokens.weight.data_ptr(),
                self.model.layers[0].self_attn._qkv.W.data_ptr(),
-               self.model.layers[0].self_attn._qkv.RA is not None, sampling)
+               self.model.layers[0].self_attn._qkv.RA is not None, sampling, bool(ragged))
         st = self._dec.get(slot)
         if st is None or st.key != key:
             st = _DecodeState()
@@ -539,23 +568,75 @@ class GenerationEngine:
             st.finished = torch.empty((B,), device=dev, dtype=torch.int32)
             st.pos_dev = torch.empty((1,), device=dev, dtype=torch.int32)
             st.step_dev = torch.empty((1,), device=dev, dtype=torch.int32)
+            st.row_off = torch.zeros((B,), device=dev, dtype=torch.int32) if ragged else None
             st.eos, st.pad, st.min_new, st.want_hidden = eos, pad, int(min_new_tokens), bool(return_hidden)
             st.sampling = sampling
             self._dec[slot] = st
         st.S = S
         st.cur_ids.zero_(); st.out_ids.fill_(pad_token_id if pad_token_id is not None else 0); st.finished.zero_()
         st.pos_dev.fill_(S - 1); st.step_dev.zero_()
+        return st
+
+    def _start(self, embeds: torch.Tensor, max_new_tokens: int, eos_token_id, pad_token_id, min_new_tokens: int, prefill_chunk: int,
+               return_hidden: bool, slot: int, sink=None, sampling=None) -> "_DecodeState":
+        """Allocate the decode state of one group of sequences, prefill it and select its first token."""
+        B, S, D = embeds.shape
+        st = self._state(B, S, max_new_tokens, eos_token_id, pad_token_id, min_new_tokens, return_hidden, slot, sampling)
         # ---- prefill in chunks of sequences (bounds activation memory, keeps GEMM M in the MFMA-efficient range)
         chunks = self.plan_prefill_chunks(B, S) if not prefill_chunk else [prefill_chunk] * (B // prefill_chunk) + \
             ([B % prefill_chunk] if B % prefill_chunk else [])
         b0 = 0
         for n in chunks:
-            self.prefill(embeds[b0:b0 + n], kc, vc, b0=b0, logits_out=st.logits[b0:b0 + n], hn_out=st.hn[b0:b0 + n])
+            self.prefill(embeds[b0:b0 + n], st.kc, st.vc, b0=b0, logits_out=st.logits[b0:b0 + n], hn_out=st.hn[b0:b0 + n])
             b0 += n
         if sink is not None:
             sink(st)
         self._select(st)
         ops.advance(st.pos_dev, st.step_dev)           # pos: S-1 -> S (position of the token just selected), step: 0 -> 1
+        return st
+
+    def _start_ragged(self, embeds_list: List[torch.Tensor], max_new_tokens: int, eos_token_id, pad_token_id, min_new_tokens: int,
+                      sink=None, sampling=None) -> "_DecodeState":
+        """The decode state of SEVERAL generate() calls coalesced into one batch.  Group g = [B_g, S_g, D] is one call of the eval loop: its
+        own prompt length and left padding, positions 0 .. S_g - 1 (unified_llama.py:262-267).  All rows share one KV cache [L, sum B_g, Hk,
+        Tmax, d] in which every group is RIGHT-ALIGNED at Smax = max S_g: group g's prompt occupies slots Smax - S_g .. Smax - 1, so the token
+        decoded at step t lands in slot Smax + t - 1 for every row (one device-resident append index, one captured graph), while row_off[row]
+        = Smax - S_g gives the decode kernels the row's rotary offset and its first visible key.  Groups are prefilled exactly as generate()
+        prefills them (consecutive groups of the same length share prefill chunks), only the cache pointers are advanced by row_off."""
+        Bs = [int(e.shape[0]) for e in embeds_list]
+        Ss = [int(e.shape[1]) for e in embeds_list]
+        Bt, Smax = sum(Bs), max(Ss)
+        st = self._state(Bt, Smax, max_new_tokens, eos_token_id, pad_token_id, min_new_tokens, False, 0, sampling, ragged=True)
+        st.row_off.copy_(torch.tensor([Smax - S for B, S in zip(Bs, Ss) for _ in range(B)], dtype=torch.int32), non_blocking=False)
+        # spans of consecutive groups with the same prompt length: one chunk plan each (whole rounds of 256 x 256 tiles, plan_prefill_chunks)
+        g = 0
+        b0 = 0
+        while g < len(embeds_list):
+            g1 = g
+            while g1 + 1 < len(embeds_list) and Ss[g1 + 1] == Ss[g]:
+                g1 += 1
+            span = embeds_list[g:g1 + 1]
+            n_span = sum(Bs[g:g1 + 1])
+            starts = [0]
+            for e in span:
+                starts.append(starts[-1] + e.shape[0])
+            c0 = 0
+            for n in self.plan_prefill_chunks(n_span, Ss[g]):
+                pieces = []
+                for j, e in enumerate(span):                  # the rows c0 .. c0 + n of the span, from whichever groups hold them
+                    lo, hi = max(c0, starts[j]), min(c0 + n, starts[j + 1])
+                    if lo < hi:
+                        pieces.append(e[lo - starts[j]:hi - starts[j]])
+                emb = pieces[0] if len(pieces) == 1 else torch.cat(pieces, 0)
+                self.prefill(emb, st.kc, st.vc, b0=b0 + c0, logits_out=st.logits[b0 + c0:b0 + c0 + n], hn_out=st.hn[b0 + c0:b0 + c0 + n],
+                             t0=Smax - Ss[g])
+                c0 += n
+            b0 += n_span
+            g = g1 + 1
+        if sink is not None:
+            sink(st)
+        self._select(st)
+        ops.advance(st.pos_dev, st.step_dev)           # slot: Smax-1 -> Smax, step: 0 -> 1
         return st
 
     @torch.no_grad()
@@ -667,7 +748,8 @@ class GenerationEngine:
     @torch.no_grad()
     def generate_many(self, embeds_list: List[torch.Tensor], max_new_tokens: int, eos_token_id: Optional[int] = None,
                       pad_token_id: Optional[int] = None, min_new_tokens: int = 0, use_graph: bool = True, sampling=None,
-                      return_first_logits: bool = False):
+                      return_first_logits: bool = False, coalesce: bool = False, max_rows: Optional[int] = None,
+                      return_step_logits: bool = False):
         """Several INDEPENDENT batches in flight: each element of `embeds_list` ([B_i, S_i, D], its own prompt length and left padding, i.e.
         exactly what one generate() call of the reference's eval loop gets) becomes one decode group with its own KV cache, decode state
         and captured HIP graph; the groups are prefilled one after the other and their decode steps are replayed on separate HIP streams.
@@ -675,10 +757,25 @@ class GenerationEngine:
         bandwidth), so the chains of 2-4 batches overlap: 8 clips / 4.6 ms alone, 16 / 6.8 ms, 24 / 8.7 ms, 32 / 11.3 ms in flight
         (profiles/README.md r03) - per-batch RESULTS are those of separate generate() calls (rows never interact, every group runs
         the kernels its own M selects).  Returns a list of id tensors (each trimmed like generate() trims it; with return_first_logits a list
-        of (ids, first-step logits)).  Sample mode: batch g draws with seed + 7919 g (_select), i.e. what generate(seed = seed + 7919 g) draws for it."""
+        of (ids, first-step logits)).  Sample mode: batch g draws with seed + 7919 g (_select), i.e. what generate(seed = seed + 7919 g) draws for it.
+
+        coalesce = True: the batches decode as ONE ragged batch instead (_start_ragged: right-aligned in one KV cache, per-row rotary offset and
+        first visible key), so a decode step streams the 13 GB of weights once for all of them - the eval loop's batches of 8
+        (scripts/finetune/inference_hyper_lora.py:1466-1479) then run at the throughput of one large generate() instead of G latency-bound
+        M = 8 chains (6.6-9.6 clips/s -> the headline's regime).  Every batch keeps the semantics of its own call (own left padding,
+        positions from 0, stops contributing once all ITS rows have finished; ids trimmed per batch); the rows go through the kernels the
+        coalesced M selects, so ids / logits agree with separate calls within the bf16 tolerance of the decoder, not bit for bit.  At most
+        max_rows (default ops.DECODE_MAX_ROWS) rows decode together; more are run as consecutive waves of about equal size.  Sample mode
+        draws per (seed, step, row of the wave): a different random stream than separate calls.
+        return_step_logits (coalesce only; parity audits): every batch's result becomes (ids, fp32 logits of every step [B_g, n_g, V])."""
         if not embeds_list:
             return []
         G = len(embeds_list)
+        if return_step_logits and (not coalesce or return_first_logits):
+            raise NotImplementedError("generate_many: return_step_logits is an audit option of the coalesced form (use generate() per batch otherwise)")
+        if coalesce and (G > 1 or return_step_logits):
+            return self._generate_coalesced(embeds_list, max_new_tokens, eos_token_id, pad_token_id, min_new_tokens, use_graph, sampling,
+                                            return_first_logits, max_rows, return_step_logits)
         if G == 1:
             r = self.generate(embeds_list[0], max_new_tokens, eos_token_id=eos_token_id, pad_token_id=pad_token_id, min_new_tokens=min_new_tokens,
                               use_graph=use_graph, sampling=sampling, return_first_logits=return_first_logits)
@@ -742,6 +839,91 @@ class GenerationEngine:
                 if idx.numel():
                     out = st.out_ids[:, : int(idx[0].item()) + 1]
             outs.append((out.clone(), firsts[g]) if return_first_logits else out.clone())
+        return outs
+
+    def _generate_coalesced(self, embeds_list, max_new_tokens, eos_token_id, pad_token_id, min_new_tokens, use_graph, sampling,
+                            return_first_logits, max_rows, return_step_logits=False):
+        """generate_many(coalesce=True): pack the batches, in order, into waves of at most `cap` rows (the weight-streaming regime of the decode
+        projections, and what the device's memory holds at the longest prompt), run every wave as one ragged batch."""
+        Bs = [int(e.shape[0]) for e in embeds_list]
+        Smax = max(int(e.shape[1]) for e in embeds_list)
+        cap = min(int(max_rows), ops.DECODE_MAX_ROWS) if max_rows else ops.DECODE_MAX_ROWS
+        per = self.bytes_per_sequence(Smax, max_new_tokens)
+        budget = self.memory_budget(0, 0, slots=1)
+        fit = (int(0.94 * budget) - self.fixed_bytes(min(sum(Bs), cap), Smax)) // per
+        cap = max(1, min(cap, fit))
+        total = sum(Bs)
+        n_waves = max(1, -(-total // cap))
+        target = -(-total // n_waves)                          # even waves: 60 batches of 8 at cap 448 run as 240 + 240, not 448 + 32
+        waves, cur, rows = [], [], 0
+        for g, b in enumerate(Bs):
+            if cur and rows + b > min(cap, max(target, b)):
+                waves.append(cur)
+                cur, rows = [], 0
+            cur.append(g)
+            rows += b
+        if cur:
+            waves.append(cur)
+        plan = {"B": total, "groups": [sum(Bs[g] for g in w) for w in waves], "bytes_per_seq": per, "budget": budget, "coalesced": True}
+        outs = [None] * len(embeds_list)
+        for w in waves:
+            if len(w) == 1:                                    # a lone batch (or one larger than the cap: generate() plans its own split)
+                g = w[0]
+                outs[g] = self.generate(embeds_list[g], max_new_tokens, eos_token_id=eos_token_id, pad_token_id=pad_token_id,
+                                        min_new_tokens=min_new_tokens, use_graph=use_graph, sampling=sampling, return_first_logits=return_first_logits,
+                                        return_step_logits=return_step_logits)
+                continue
+            res = self._ragged_wave([embeds_list[g] for g in w], max_new_tokens, eos_token_id, pad_token_id, min_new_tokens, use_graph, sampling,
+                                    return_first_logits, return_step_logits)
+            for g, r in zip(w, res):
+                outs[g] = r
+        self.last_plan = plan
+        return outs
+
+    def _ragged_wave(self, embeds_list, max_new_tokens, eos_token_id, pad_token_id, min_new_tokens, use_graph, sampling, return_first_logits,
+                     return_step_logits=False):
+        firsts, steps = [], []
+
+        def sink(st):
+            if return_first_logits and not firsts:
+                firsts.append(st.logits.clone())
+            if return_step_logits:
+                steps.append(st.logits.clone())
+
+        ops.WS_SLOT = 0
+        st = self._start_ragged(embeds_list, max_new_tokens, eos_token_id, pad_token_id, min_new_tokens, sink, sampling)
+        if ops.PROFILER is not None:
+            ops.PROFILER.mark("prefill_end")
+        graph = self._capture(st) if (use_graph and max_new_tokens > 2) else None
+        eos_on = st.eos >= 0
+        for step in range(1, max_new_tokens):
+            if graph is not None:
+                graph.replay()
+            else:
+                self._decode_step(st)
+            if return_step_logits:
+                sink(st)
+            if eos_on and step % 16 == 0 and bool(st.finished.all().item()):
+                break
+        if ops.PROFILER is not None:
+            ops.PROFILER.mark("decode_end")
+        n_done = int(st.step_dev.item())
+        sl = torch.stack(steps, 1) if return_step_logits else None
+        outs, r0 = [], 0
+        for e in embeds_list:
+            r1 = r0 + int(e.shape[0])
+            out = st.out_ids[r0:r1, :n_done]
+            if eos_on:
+                # what this batch's own generate() call returns: HF stops a call as soon as all of ITS rows have finished
+                fin_cols = (out == st.eos).int().cumsum(1) > 0
+                idx = torch.nonzero(fin_cols.all(0))
+                if idx.numel():
+                    out = st.out_ids[r0:r1, : int(idx[0].item()) + 1]
+            if return_step_logits:
+                outs.append((out.clone(), sl[r0:r1, : out.shape[1]].clone()))
+            else:
+                outs.append((out.clone(), firsts[0][r0:r1].clone()) if return_first_logits else out.clone())
+            r0 = r1
         return outs
 
     def _generate_split(self, groups, embeds, max_new_tokens, eos_token_id, pad_token_id, min_new_tokens, prefill_chunk, use_graph,

@@ -178,13 +178,17 @@ def to_device(data, device="cuda"):
 
 def run_inference(batches: Iterable[Mapping[str, Any]], model, tokenizer, max_new_tokens: int = 500, out_path: Optional[str] = None,
                   device="cuda", rank: int = 0, world: int = 1, on_result: Optional[Callable[[dict], None]] = None, in_flight: int = 1,
-                  **generate_kwargs) -> List[dict]:
+                  coalesce: bool = False, coalesce_rows: int = 448, **generate_kwargs) -> List[dict]:
     """inference_ntp / inference_avqa: for every collated batch, generate -> batch_decode(skip_special_tokens=False) ->
     metadata['predict'], appended to `out_path` as JSON lines when given.  With world > 1 batch i runs on rank i mod world and
     rank 0 receives every record (returned in batch order; other ranks return their own records).
     in_flight > 1: that many of this rank's batches decode TOGETHER (model.generate_batches: every batch keeps its own
     prepare_multimodal_inputs / left padding and gets the ids a separate generate() call returns; at the reference's batch of 8 a
-    decode step is latency-bound, so three batches in flight finish in ~1.9x the time of one)."""
+    decode step is latency-bound, so three batches in flight finish in ~1.9x the time of one).
+    coalesce = True: this rank's batches are collected until they hold `coalesce_rows` clips (or `in_flight` batches when that is given
+    > 1) and then decode as ONE ragged batch (model.generate_batches(coalesce=True)): every batch keeps its own prepare_multimodal_inputs
+    result, left padding and positions, but a decode step streams the weights once for all of them and the encoders see the clips of all
+    batches together - the eval loop's batches of 8 run at the throughput of one large generate()."""
     mine: List[Tuple[int, dict]] = []
     pending: List[Tuple[int, list, dict]] = []
 
@@ -196,6 +200,8 @@ def run_inference(batches: Iterable[Mapping[str, Any]], model, tokenizer, max_ne
         with torch.no_grad():
             if len(pending) == 1:
                 ids_list = [model.generate(**pending[0][2], **kw)]
+            elif coalesce:
+                ids_list = model.generate_batches([s for _, _, s in pending], coalesce=True, max_rows=coalesce_rows, **kw)
             else:
                 ids_list = model.generate_batches([s for _, _, s in pending], **kw)
         for (step_, metas_, _), ids in zip(pending, ids_list):
@@ -212,7 +218,10 @@ def run_inference(batches: Iterable[Mapping[str, Any]], model, tokenizer, max_ne
         sample = dict(sample)
         metas = sample.pop("batch_metadata")
         pending.append((step, metas, to_device(sample, device)))
-        if len(pending) >= max(1, in_flight):
+        if coalesce and in_flight <= 1:
+            if sum(len(p[2]["batch_input_ids"]) for p in pending) >= coalesce_rows:
+                flush()
+        elif len(pending) >= max(1, in_flight):
             flush()
     flush()
     records = mine

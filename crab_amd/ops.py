@@ -145,7 +145,8 @@ def _splitk_workspace(device) -> torch.Tensor:
 def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act: str = "none",
          residual: Optional[torch.Tensor] = None, res_scale: float = 1.0, x2: Optional[torch.Tensor] = None,
          w2: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, out_fp32: bool = False, tune: int = 0,
-         post_norm=None, rope=None, route=None, lora_self=None, info: Optional[dict] = None, prof_class: Optional[str] = None) -> torch.Tensor:
+         post_norm=None, rope=None, route=None, lora_self=None, info: Optional[dict] = None, prof_class: Optional[str] = None,
+         rope_row_off: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[M,N] = res_scale*residual + act(x[M,K] @ w[N,K]^T + x2 @ w2^T + bias).  2-D row-strided operands.
     rope = (tab, k_cache, v_cache, H, Hk, d, Tmax, pos0, pos_dev): packed q|k|v projection of ONE row per sequence followed
     by RoPE + KV-cache append (== qkv_rope_split(B=M, S=1) on out), fused into the split-K reduction when there is one.
@@ -157,6 +158,8 @@ def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     for the NEXT projection group, computed inside the row-owning reduction kernel when that path is taken.
     lora_self = (RA, nl, r, scaling, lora_B) (with post_norm, M <= 16, no x2): the hyper-LoRA update of THIS single-projection group is
     evaluated inside the call - its router rows ride on the projection's launch, the update is applied by the M <= 16 layer tail.
+    rope_row_off (int32 [M], decode form of `rope` only): the RAGGED decode batch - row m is rotated at slot - rope_row_off[m] while its
+    K / V rows land in the common slot (crab_gemm_desc.rope_row_off).
     act == "swiglu_pair": w rows are interleaved (gate_i, up_i) and out is [M, N/2] = silu(gate) * up."""
     _chk_bf16(x, w, bias, x2, w2)
     if residual is not None and residual.dtype not in (BF16, torch.float32):
@@ -208,6 +211,12 @@ def gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
         g.rope_tab, g.rope_k_cache, g.rope_v_cache = tab.data_ptr(), kcache.data_ptr(), vcache.data_ptr()
         g.rope_pos_dev = rpd.data_ptr() if rpd is not None else None
         g.rope_H, g.rope_Hk, g.rope_d, g.rope_Tmax, g.rope_pos0 = rH, rHk, rd, rT, rp0
+        if rope_row_off is not None:
+            if len(rope) > 9:
+                raise ValueError("rope_row_off belongs to the decode form of the fused RoPE")
+            if rope_row_off.dtype != torch.int32 or rope_row_off.numel() < M or not rope_row_off.is_contiguous():
+                raise ValueError("rope_row_off must be a contiguous int32 [M] tensor")
+            g.rope_row_off = rope_row_off.data_ptr()
         if len(rope) > 9:                          # prefill form: S rows per sequence (+ optional rotary positions [B, S] int32)
             g.rope_S = int(rope[9])
             pid = rope[10] if len(rope) > 10 else None
@@ -340,10 +349,18 @@ def rope_table(max_pos: int, head_dim: int, theta: float, device) -> torch.Tenso
 
 def qkv_rope_split(qkv: torch.Tensor, rope_tab: Optional[torch.Tensor], k_cache: Optional[torch.Tensor],
                    v_cache: Optional[torch.Tensor], vt: Optional[torch.Tensor], B: int, S: int, H: int, Hk: int, d_: int,
-                   Tmax: int, pos0: int = 0, pos_dev: Optional[torch.Tensor] = None, pos_ids: Optional[torch.Tensor] = None):
-    """pos_ids (int32 [B, S]): explicit rotary positions (forward()'s position_ids); the cache slot stays pos0 + s."""
+                   Tmax: int, pos0: int = 0, pos_dev: Optional[torch.Tensor] = None, pos_ids: Optional[torch.Tensor] = None,
+                   row_off: Optional[torch.Tensor] = None):
+    """pos_ids (int32 [B, S]): explicit rotary positions (forward()'s position_ids); the cache slot stays pos0 + s.
+    row_off (int32 [B]): the ragged form - sequence b is rotated at slot - row_off[b] (crab_qkv_rope_split_ragged)."""
     d = _dev(qkv)
     vt_ld = vt.stride(-2) if vt is not None else 0
+    if row_off is not None:
+        if pos_ids is not None:
+            raise ValueError("qkv_rope_split: pos_ids and row_off are alternatives")
+        _lib.check(_lib.load().crab_qkv_rope_split_ragged(_lib.ctx(d), _stream(), _p(qkv), qkv.stride(0), _p(rope_tab), _p(k_cache), _p(v_cache),
+                                                          _p(vt), vt_ld, B, S, H, Hk, d_, Tmax, pos0, _p(pos_dev), _p(row_off)), d)
+        return
     if pos_ids is not None and (pos_ids.dtype != torch.int32 or pos_ids.dim() != 2 or pos_ids.stride(1) != 1):
         raise ValueError("pos_ids must be an int32 [B, S] tensor with contiguous rows")
     _lib.check(_lib.load().crab_qkv_rope_split_ids(_lib.ctx(d), _stream(), _p(qkv), qkv.stride(0), _p(rope_tab), _p(k_cache), _p(v_cache),

@@ -162,7 +162,8 @@ class PackedLinearGroup:
                 lin._attach_lora()
 
     def __call__(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-                 t_buf: Optional[torch.Tensor] = None, u_buf: Optional[torch.Tensor] = None, post_norm=None, act: str = "none", rope=None, route_next=None, u_ready=None, info=None) -> torch.Tensor:
+                 t_buf: Optional[torch.Tensor] = None, u_buf: Optional[torch.Tensor] = None, post_norm=None, act: str = "none", rope=None, route_next=None, u_ready=None, info=None,
+                 rope_row_off=None) -> torch.Tensor:
         """y = group(x) (+residual).  post_norm = (rms_weight, eps, h_out): additionally h_out = rmsnorm(y) * rms_weight
         (the LlamaRMSNorm that follows o_proj / down_proj), fused into the GEMM epilogue in the decode regime.
         act = "swiglu_pair" (interleaved groups): returns silu(member0(x)) * member1(x), [M, N/2]."""
@@ -177,7 +178,7 @@ class PackedLinearGroup:
             route = (ng.RA, len(ng.names), ng.nl, ng.r, ng.u_cols, ng.scaling, nu[:M, :ng.u_cols])
         if self.RA is None:
             return ops.gemm(x, self.W, bias=self.bias, residual=residual, out=out, post_norm=post_norm, act=act, rope=rope, route=route, info=info,
-                            prof_class=self.prof_class)
+                            prof_class=self.prof_class, rope_row_off=rope_row_off)
         if u_ready is None and M <= 16 and post_norm is not None and len(self.names) == 1 and ops.ROWFIN and ops.rowfin_lora_ok(self.nl, self.r, self.N):
             # the reference's batch sizes (M <= 16), o_proj / down_proj: no router launches - the [R;A] rows ride on the projection's
             # launch and the update is applied by the wide layer tail (csrc/rowfin.hip) together with the residual row, its RMSNorm and
@@ -191,7 +192,7 @@ class PackedLinearGroup:
             # route logits | lora_A(x) -> softmax mix, K split over blocks (skinny.hip); t_buf is the partial-sum workspace
             ops.hyperlora_route(x, self.RA, len(self.names), self.nl, self.r, self.u_cols, self.scaling, out=u, workspace=t_buf)
         return ops.gemm(x, self.W, bias=self.bias, residual=residual, x2=u, w2=self.B2, out=out, post_norm=post_norm, act=act, rope=rope,
-                        route=route, info=info, prof_class=self.prof_class)
+                        route=route, info=info, prof_class=self.prof_class, rope_row_off=rope_row_off)
 
     def routes_ahead(self, M: int) -> bool:
         """True when a producer GEMM may evaluate this group's router in its fused post-norm epilogue (decode regime)."""

@@ -195,52 +195,78 @@ class UnifiedMetaForCausalLM:
         """unified_arch.py:217-406.  Returns the same dict: input_ids=None, inputs_embeds [bs,S,D], attention_mask,
         labels, position_ids (+ multi_scale_image_features, mask_token_mask, gt_mask on the AVS path).
         The AVS `<image>` is encoded ONCE (the reference encodes it twice, :244 and :297)."""
+        return self.prepare_multimodal_inputs_many(
+            [{"batch_input_ids": batch_input_ids, "batch_labels": batch_labels, "batch_X_modals": batch_X_modals,
+              "batch_task_names": batch_task_names}],
+            return_multi_scale_features=return_multi_scale_features, return_gt_mask=return_gt_mask)[0]
+
+    def prepare_multimodal_inputs_many(self, batches, return_multi_scale_features=False, return_gt_mask=False):
+        """prepare_multimodal_inputs for SEVERAL collated batches of the eval loop at once (scripts/finetune/inference_hyper_lora.py:1466-1479
+        calls generate() once per batch of 8): every batch keeps its own splice, left padding, attention_mask and position_ids - the dict a
+        separate call returns - but the <video> / <audio> blocks of ALL batches go through the encoders together (_encode_blocks: equal shapes
+        stacked, chunks sized for whole tile rounds), so 56 batches of 8 clips cost the towers what one batch of 448 costs them instead of 56
+        small passes.  Rows never interact inside the encoders, so each batch's features are those of its own call up to the kernels'
+        choice of tile schedule for a different M.  Returns one dict per batch."""
         device = self.device
-        bs = len(batch_input_ids)
         special = self.SPECIAL_TOKEN_2_IDS
         key_ids = {special[k]: k for k in self.KEYS}
         emb_w = self.get_model().embed_tokens.weight
         D = emb_w.shape[1]
 
-        # ---- pass 1 (host): segment plan per sample; modality blocks are encoded batched per kind
-        plans = []
+        # ---- pass 1 (host): segment plan per sample; modality blocks of every batch are encoded batched per kind
         vids, auds, msks = [], [], []
-        # one device->host transfer for the ids (and one for the labels) of the whole batch, not one per sample
-        n_ids = [int(x.numel()) for x in batch_input_ids]
-        flat = torch.cat([x.reshape(-1) for x in batch_input_ids]).tolist()
-        ids_ls, o = [], 0
-        for n in n_ids:
-            ids_ls.append(flat[o:o + n])
-            o += n
-        lab_ls = None
-        if batch_labels is not None:
-            flat = torch.cat([x.reshape(-1) for x in batch_labels]).tolist()
-            lab_ls, o = [], 0
+        recs = []
+        for bt in batches:
+            batch_input_ids, batch_labels = bt["batch_input_ids"], bt.get("batch_labels")
+            batch_X_modals = bt["batch_X_modals"]
+            bs = len(batch_input_ids)
+            plans = []
+            # one device->host transfer for the ids (and one for the labels) of the whole batch, not one per sample
+            n_ids = [int(x.numel()) for x in batch_input_ids]
+            flat = torch.cat([x.reshape(-1) for x in batch_input_ids]).tolist()
+            ids_ls, o = [], 0
             for n in n_ids:
-                lab_ls.append(flat[o:o + n])
+                ids_ls.append(flat[o:o + n])
                 o += n
-        for i in range(bs):
-            ids_l = ids_ls[i]
-            segs, pre = [], 0
-            for pos, tok in enumerate(ids_l):
-                if tok in key_ids:
-                    segs.append(("text", pre, pos))
-                    key = key_ids[tok]
-                    if key == '<audio>':
-                        segs.append(("audio", len(auds)))
-                        auds.append(batch_X_modals[i][key])
-                    elif key == '<mask>':                                                # VQGAN mask image -> 256 token ids (:303-307)
-                        segs.append(("mask", len(msks)))
-                        msks.append(batch_X_modals[i][key])
-                    else:
-                        segs.append(("video", len(vids)))
-                        vids.append(batch_X_modals[i][key])
-                    pre = pos + 1
-            segs.append(("text", pre, len(ids_l)))
-            plans.append(segs)
+            lab_ls = None
+            if batch_labels is not None:
+                flat = torch.cat([x.reshape(-1) for x in batch_labels]).tolist()
+                lab_ls, o = [], 0
+                for n in n_ids:
+                    lab_ls.append(flat[o:o + n])
+                    o += n
+            for i in range(bs):
+                ids_l = ids_ls[i]
+                segs, pre = [], 0
+                for pos, tok in enumerate(ids_l):
+                    if tok in key_ids:
+                        segs.append(("text", pre, pos))
+                        key = key_ids[tok]
+                        if key == '<audio>':
+                            segs.append(("audio", len(auds)))
+                            auds.append(batch_X_modals[i][key])
+                        elif key == '<mask>':                                                # VQGAN mask image -> 256 token ids (:303-307)
+                            segs.append(("mask", len(msks)))
+                            msks.append(batch_X_modals[i][key])
+                        else:
+                            segs.append(("video", len(vids)))
+                            vids.append(batch_X_modals[i][key])
+                        pre = pos + 1
+                segs.append(("text", pre, len(ids_l)))
+                plans.append(segs)
+            recs.append((bt, bs, ids_ls, lab_ls, plans))
         vfeat, vvit = self._encode_blocks(vids, video=True, want_vit=return_multi_scale_features)
         afeat, _ = self._encode_blocks(auds, video=False)
         mids = [self.encode_mask(m, batch_first=False) for m in msks]
+        return [self._assemble_inputs(bt, bs, ids_ls, lab_ls, plans, vfeat, vvit, afeat, mids, key_ids, emb_w, D, device,
+                                      return_multi_scale_features, return_gt_mask)
+                for (bt, bs, ids_ls, lab_ls, plans) in recs]
+
+    def _assemble_inputs(self, bt, bs, ids_ls, lab_ls, plans, vfeat, vvit, afeat, mids, key_ids, emb_w, D, device,
+                         return_multi_scale_features, return_gt_mask):
+        """Pass 2 of prepare_multimodal_inputs for ONE batch: lengths, left padding, the spliced output buffer, mask / labels / positions."""
+        special = self.SPECIAL_TOKEN_2_IDS
+        batch_X_modals, batch_task_names = bt["batch_X_modals"], bt.get("batch_task_names")
         img_block = {}                                   # sample -> index of its <image> block (multi-scale features)
         if return_multi_scale_features:
             for i, segs in enumerate(plans):

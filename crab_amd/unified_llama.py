@@ -272,26 +272,38 @@ class UnifiedForCausalLM(nn.Module, UnifiedMetaForCausalLM):
         return res
 
     @torch.no_grad()
-    def generate_batches(self, batches, **kwargs):
+    def generate_batches(self, batches, coalesce: bool = False, max_rows: Optional[int] = None, **kwargs):
         """Throughput form of the eval loop (scripts/finetune/inference_hyper_lora.py:1466-1479 calls generate() once per collated batch of 8):
         `batches` = a list of dicts with the four generate() arguments (batch_input_ids, batch_labels, batch_X_modals, batch_task_names).  Every
-        batch goes through prepare_multimodal_inputs on its own (its own left padding, like a separate call), then all of them decode IN
-        FLIGHT together (GenerationEngine.generate_many).  Returns one id tensor per batch, equal to what generate() returns for it."""
-        for k in ("output_logits", "output_first_logits", "return_dict_in_generate", "inputs_embeds"):
+        batch keeps its own prepare_multimodal_inputs result (its own left padding, like a separate call), then all of them decode together.
+        coalesce = False: IN FLIGHT (GenerationEngine.generate_many: one decode group, graph and HIP stream per batch; ids equal to what
+        generate() returns for each batch, bit for bit).
+        coalesce = True: as ONE ragged decode batch (right-aligned in one KV cache, per-row rotary offset and first visible key): the weights
+        stream once per step for all batches and the encoders run over the clips of all batches together, so batches of 8 reach the
+        throughput of one large generate(); per-batch ids / logits agree with separate calls within the decoder's bf16 tolerance.
+        Returns one id tensor per batch (with output_first_logits=True: (ids, fp32 logits of the first generated position))."""
+        for k in ("output_logits", "return_dict_in_generate", "inputs_embeds"):
             if kwargs.get(k) is not None and kwargs.get(k) is not False:
                 raise NotImplementedError(f"generate_batches returns token ids only: {k} is a generate() argument")
+        want_first = bool(kwargs.get("output_first_logits"))
         sampling = self._sampling(kwargs)
-        embeds = []
-        for b in batches:
-            inputs = self.prepare_multimodal_inputs(batch_input_ids=b["batch_input_ids"], batch_labels=b.get("batch_labels"),
-                                                    batch_X_modals=b["batch_X_modals"], return_multi_scale_features=False, return_gt_mask=False,
-                                                    batch_task_names=b.get("batch_task_names"))
-            embeds.append(inputs['inputs_embeds'].to(device=self.device, dtype=BF16))
+        if ops.PROFILER is not None:
+            ops.PROFILER.mark("encode_begin")
+        if coalesce:
+            inputs = self.prepare_multimodal_inputs_many(batches, return_multi_scale_features=False, return_gt_mask=False)
+            embeds = [d['inputs_embeds'].to(device=self.device, dtype=BF16) for d in inputs]
+        else:
+            embeds = []
+            for b in batches:
+                inputs = self.prepare_multimodal_inputs(batch_input_ids=b["batch_input_ids"], batch_labels=b.get("batch_labels"),
+                                                        batch_X_modals=b["batch_X_modals"], return_multi_scale_features=False, return_gt_mask=False,
+                                                        batch_task_names=b.get("batch_task_names"))
+                embeds.append(inputs['inputs_embeds'].to(device=self.device, dtype=BF16))
         eos = kwargs.get("eos_token_id", self.config.eos_token_id)
         pad = kwargs.get("pad_token_id", self.model.pad_token_id if self.model.pad_token_id is not None else eos)
         return self._engine.generate_many(embeds, int(kwargs.get("max_new_tokens", 20)), eos_token_id=eos, pad_token_id=pad,
                                           min_new_tokens=int(kwargs.get("min_new_tokens", 0) or 0), use_graph=kwargs.get("use_graph", True),
-                                          sampling=sampling)
+                                          sampling=sampling, return_first_logits=want_first, coalesce=coalesce, max_rows=max_rows)
 
     @staticmethod
     def _sampling(kwargs):

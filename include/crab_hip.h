@@ -115,6 +115,13 @@ typedef struct {
     /* R is fp32 [M, ldr] (see the top of this comment).  With norm_w the fused post-norm then reads the fp32 row (c_fp32 must be set too, and
      * the normalised row is bf16(x_hat * w) without the intermediate bf16 rounding of x_hat that the all-bf16 form reproduces).  Unbatched only. */
     int32_t r_fp32;
+    /* optional with the DECODE form of the fused RoPE (rope_S <= 1), ABI 9: int32 [M], row m is rotated at position
+     * (rope_pos0 + rope_pos_dev[0]) - rope_row_off[m] while its K / V rows still land in cache slot rope_pos0 + rope_pos_dev[0].  This is the
+     * RAGGED decode batch: sequences whose prompts have different lengths are right-aligned in one KV cache (sequence m's first key sits in
+     * slot rope_row_off[m]) so that one append index serves every row, yet every row keeps the rotary positions 0 .. S_m - 1 of its own
+     * generate() call (models/unified_llama.py:262-267 gives every call of the eval loop positions from 0; scripts/finetune/
+     * inference_hyper_lora.py:1466-1479).  NULL = no offsets. */
+    const int32_t* rope_row_off;
 } crab_gemm_desc;
 
 /* Rows up to which crab_gemm_bf16 treats a problem as WEIGHT-STREAMING (the decode regime: one row per clip) when a workspace is given:
@@ -189,6 +196,12 @@ int crab_qkv_rope_split(crab_ctx* ctx, void* stream, void* qkv, int64_t ldqkv, c
 int crab_qkv_rope_split_ids(crab_ctx* ctx, void* stream, void* qkv, int64_t ldqkv, const float* rope_tab,
                             void* k_cache, void* v_cache, void* vt, int64_t vt_ld, int B, int S, int H, int Hk, int d,
                             int Tmax, int pos0, const int32_t* pos_dev, const int32_t* pos_ids, int64_t ld_pos);
+
+/* The ragged form (ABI 9): sequence b is rotated at slot - row_off[b] (slot = pos0 + pos_dev[0] + s) - see crab_gemm_desc.rope_row_off.
+ * row_off == NULL is crab_qkv_rope_split. */
+int crab_qkv_rope_split_ragged(crab_ctx* ctx, void* stream, void* qkv, int64_t ldqkv, const float* rope_tab,
+                               void* k_cache, void* v_cache, void* vt, int64_t vt_ld, int B, int S, int H, int Hk, int d,
+                               int Tmax, int pos0, const int32_t* pos_dev, const int32_t* row_off);
 
 /* Encoder-side split: qkv[T, 3*H*d] -> kbuf[B,H,S,d], vt[B,H,d,vt_ld]; q stays in place (no RoPE). */
 
@@ -362,6 +375,13 @@ typedef struct {
     /* x is the FP32 residual stream: fp32 [M, ldx] (ldx in fp32 elements), read and written by the o_proj / down_proj epilogues and read by
      * the norms; h and everything else stay bf16.  0: x is bf16 (the r01-r03 storage). */
     int32_t x_fp32;
+    /* optional, decode only (ABI 9): int32 [B] - the RAGGED decode batch.  Sequence b's first key sits in cache slot row_off[b] (its prompt was
+     * prefilled into slots row_off[b] .. row_off[b] + S_b - 1 by a prefill call whose k_cache / v_cache pointers were advanced by row_off[b] * d
+     * elements), so one append slot pos0 + pos_dev[0] serves every row: the new token of row b is rotated at slot - row_off[b]
+     * (crab_gemm_desc.rope_row_off) and attends keys row_off[b] .. slot (crab_attn_decode_masked's kv_start).  Several generate() calls of the
+     * eval loop (each with its own prompt length and left padding) then decode as ONE batch that streams the weights once per step.
+     * NULL = every sequence starts at slot 0. */
+    const int32_t* row_off;
 } crab_llama_io;
 
 int crab_sizeof_llama_layer(void);

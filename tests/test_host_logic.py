@@ -97,10 +97,12 @@ def test_plan_batch_splits_when_the_kv_cache_would_not_fit():
     assert big.plan_batch(384, 766, 500) == [192, 192]
 
 
-def test_memory_budget_counts_only_the_slots_the_call_will_replace(monkeypatch):
-    """After generate_many (slots 0 .. G-1) a single-group generate() must neither count the other slots' KV buffers as reclaimable
-    while they stay allocated (r03 over-estimated the budget by tens of GB and ran into an OOM instead of splitting) nor leave them
-    allocated: the stale slots' caches, decode states and decode workspaces are dropped before planning."""
+def test_memory_budget_is_a_pure_query_and_stale_slots_are_evicted_lazily(monkeypatch):
+    """After generate_many (slots 0 .. G-1) a single-group generate() counts EVERY persistent KV buffer of the engine as reclaimable - its own
+    slot's (alloc_cache replaces it) and the other slots' (alloc_cache evicts them the moment the new cache does not fit beside them) - but
+    memory_budget() itself frees nothing (a planning query used to drop live slots, graphs included, and a loop alternating
+    generate_many(G > 1) with generate() re-allocated tens of GB per alternation).  r03's failure mode - stale slots counted but never
+    freed, so the plan over-committed and ran out of memory - is closed by _evict_for."""
     from crab_amd.decoder import DecoderConfig, GenerationEngine
     eng = GenerationEngine.__new__(GenerationEngine)
     eng.cfg, eng.lm_head, eng.last_plan, eng.kv_budget_bytes = DecoderConfig(), type("H", (), {"weight": torch.empty(8, 1)})(), None, None
@@ -113,22 +115,31 @@ def test_memory_budget_counts_only_the_slots_the_call_will_replace(monkeypatch):
     monkeypatch.setattr(torch.cuda, "memory_reserved", lambda dev=None: 700)
     monkeypatch.setattr(torch.cuda, "memory_allocated", lambda dev=None: 200)
     monkeypatch.setattr(torch.cuda, "empty_cache", lambda: emptied.append(1))
-    # a call that will use slots 0 and 1: slot 2 is released (and shows up as free memory on a real device), slots 0 / 1 count as reclaimable
-    assert eng.memory_budget(0, 0, slots=2) == 10_000 + 500 + 2 * 2 * (1000 + 3000)
-    assert sorted(eng._kv) == [(0,), (1,)] and sorted(eng._dec) == [0, 1] and ("decode", 8, 2) not in eng._ws and "prefill" in eng._ws and emptied
-    # a single-group generate(): only slot 0 is its own
-    assert eng.memory_budget(0, 0) == 10_000 + 500 + 2 * 2 * 1000
-    assert sorted(eng._kv) == [(0,)] and sorted(eng._dec) == [0] and [k for k in eng._ws if k != "prefill"] == [("decode", 8, 0)]
+    every = 2 * 2 * (1000 + 3000 + 5000)
+    assert eng.memory_budget(0, 0, slots=2) == 10_000 + 500 + every and eng._live_slots == 2
+    assert eng.memory_budget(0, 0) == 10_000 + 500 + every and eng._live_slots == 1
+    assert sorted(eng._kv) == [(0,), (1,), (2,)] and sorted(eng._dec) == [0, 1, 2] and len(eng._ws) == 4 and not emptied      # nothing freed
+    # a new cache for slot 0 that fits beside the stale slots: nothing is evicted
+    assert eng._evict_for(9_000, 0, slack=1_000) is False and sorted(eng._kv) == [(0,), (1,), (2,)] and not emptied
+    # one that does not: the slots the running call does not use (>= _live_slots) go, with their decode states, graphs and workspaces
+    assert eng._evict_for(10_000, 0, slack=1_000) is True
+    assert sorted(eng._kv) == [(0,)] and sorted(eng._dec) == [0] and [k for k in eng._ws if k != "prefill"] == [("decode", 8, 0)] and emptied
+    # a call planned over two slots keeps both while it allocates its second cache
+    eng._kv = {(0,): kv(1000), (1,): kv(3000), (2,): kv(5000)}
+    eng._dec = {0: object(), 1: object(), 2: object()}
+    eng.memory_budget(0, 0, slots=2)
+    assert eng._evict_for(50_000, 1) is True and sorted(eng._kv) == [(0,), (1,)]
     eng.kv_budget_bytes = 123                                     # the override never touches the device or the slots
     assert eng.memory_budget(0, 0) == 123
 
 
 def test_generate_batches_refuses_generate_only_arguments():
-    """generate_batches returns ids only; the per-call extras of generate() are refused loudly instead of being dropped."""
+    """generate_batches returns ids (+ the first-step logits with output_first_logits); the other per-call extras of generate() are refused
+    loudly instead of being dropped."""
     from crab_amd.unified_llama import UnifiedForCausalLM
     class _Stub:
         _sampling = staticmethod(UnifiedForCausalLM._sampling)
-    for k in ("output_logits", "output_first_logits", "return_dict_in_generate"):
+    for k in ("output_logits", "return_dict_in_generate", "inputs_embeds"):
         with pytest.raises(NotImplementedError, match=k):
             UnifiedForCausalLM.generate_batches.__wrapped__(_Stub(), [], **{k: True})
 

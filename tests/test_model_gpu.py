@@ -965,3 +965,139 @@ def test_generate_many_refuses_batches_that_do_not_fit_together_and_returns_firs
     finally:
         eng.kv_budget_bytes = None
     assert eng.generate_many([], 5) == []
+
+
+def _coalesce_setup():
+    meta, A = load_fixture("full_tiny_llama")
+    model = build_tiny_crab(meta)
+    model.load_state_dict(weights_from_table(meta), strict=False)
+    mods = _inputs(meta)
+    lab = [torch.full_like(A["ids0"], -100), torch.full_like(A["ids1"], -100)]
+    batches = [dict(batch_input_ids=[A["ids0"]], batch_labels=[lab[0]], batch_X_modals=[mods[0]], batch_task_names=['avqa']),
+               dict(batch_input_ids=[A["ids0"], A["ids1"]], batch_labels=lab, batch_X_modals=mods, batch_task_names=['avqa', 'avqa']),
+               dict(batch_input_ids=[A["ids1"]], batch_labels=[lab[1]], batch_X_modals=[mods[1]], batch_task_names=['avqa'])]
+    return meta, A, model, batches
+
+
+def test_coalesced_batches_match_the_reference_fixture_per_batch():
+    """generate_batches(coalesce=True): three eval-loop batches of DIFFERENT prompt lengths (1 clip; 2 left-padded clips; 1 shorter clip) decode
+    as one ragged batch - right-aligned in one KV cache, per-row rotary offset and first visible key (crab_llama_io.row_off) - and every batch
+    must come out as its own generate() call does in the REFERENCE: ids and per-step logits against the reference-recorded fixture
+    (full_tiny_llama bs 1 and left-padded bs 2: the pads of the bs-2 batch are attended, positions run from 0 per batch), graph replay ==
+    plain launches bit for bit, the Python per-launch sequencer == the native one, and the public API returns the same ids."""
+    from crab_amd import decoder
+    meta, A, model, batches = _coalesce_setup()
+    um = model.base_model.model
+    eng = um._engine
+    n = meta["new_tokens"]
+    inputs = um.prepare_multimodal_inputs_many(batches)
+    embeds = [d["inputs_embeds"] for d in inputs]
+    assert len({e.shape[1] for e in embeds}) >= 2, "the batches must differ in prompt length for this test to mean anything"
+    assert _rel(embeds[0], A["embeds_bs1"], "coalesced encoders: inputs_embeds of batch 0 (bs 1)") < REL_ENC
+    assert _rel(embeds[1], A["embeds_bs2"], "coalesced encoders: inputs_embeds of batch 1 (left-padded bs 2)") < REL_ENC
+    assert torch.equal(inputs[1]["position_ids"].cpu().long(), A["pos_bs2"].long()) and torch.equal(inputs[1]["attention_mask"].cpu().long(), A["mask_bs2"].long())
+    kw = dict(eos_token_id=None, pad_token_id=2, coalesce=True, return_step_logits=True)
+    res = eng.generate_many(embeds, n, **kw)
+    res_eager = eng.generate_many(embeds, n, use_graph=False, **kw)
+    decoder.NATIVE_LAYERS = False
+    try:
+        res_py = eng.generate_many(embeds, n, use_graph=False, **kw)
+    finally:
+        decoder.NATIVE_LAYERS = True
+    for (i1, l1), (i2, l2), (i3, l3) in zip(res, res_eager, res_py):
+        assert torch.equal(i1, i2) and torch.equal(l1, l2), "HIP-graph replay of the ragged step differs from plain launches"
+        assert torch.equal(i1, i3) and torch.equal(l1, l3), "the Python per-launch sequence of the ragged step differs from the native one"
+    for g, key in ((0, "bs1"), (1, "bs2")):
+        ids, logits = res[g]
+        err = _check_ids(ids, A[f"ids_{key}"], A[f"logits_{key}"], logits)
+        assert err < REL_DEC * A[f"logits_{key}"].abs().max().item(), (g, err)
+    # the public API: ids only, and with output_first_logits the first position's logits
+    pub = model.generate_batches(batches, coalesce=True, use_cache=True, max_new_tokens=n, pad_token_id=2, eos_token_id=None)
+    pub2 = model.generate_batches(batches, coalesce=True, use_cache=True, max_new_tokens=n, pad_token_id=2, eos_token_id=None, output_first_logits=True)
+    for g in range(3):
+        assert torch.equal(pub[g], res[g][0]) and torch.equal(pub2[g][0], res[g][0]) and torch.equal(pub2[g][1], res[g][1][:, 0])
+    # and against separate generate() calls of the same model (HIP vs HIP; other kernels at the other M): ids wherever the margin allows
+    for g, b in enumerate(batches):
+        solo = model.generate(**b, use_cache=True, max_new_tokens=n, pad_token_id=2, eos_token_id=None, output_logits=True, return_dict_in_generate=True)
+        sl = torch.stack(solo.logits, 1).float().cpu()
+        _check_ids(res[g][0], solo.sequences.cpu(), sl, res[g][1])
+        assert _rel(res[g][1], sl, f"coalesced batch {g} vs its own generate() call, per-step logits (HIP vs HIP)") < 2 * REL_DEC
+
+
+def test_coalesced_batches_of_different_lengths_vs_oracle():
+    """Five batches of two unsearched clips each, every batch with its own pair of prompt lengths (so its own left padding AND its own offset
+    inside the right-aligned cache), coalesced into one ragged decode batch of 10 rows and - with max_rows = 4 - into three waves; each batch
+    against the golden-pinned oracle run on THAT batch alone.  Greedy ids exact wherever the oracle's top-2 margin exceeds twice the logit
+    error, per-step logits within REL_DEC."""
+    from crab_amd import synth
+    from oracle import crab_oracle as O
+    from tests.test_oracle_golden import _full_cfg
+    meta, A = load_fixture("full_tiny_llama")
+    W = weights_from_table(meta)
+    model = build_tiny_crab(meta)
+    model.load_state_dict(W, strict=False)
+    um = model.base_model.model
+    Wo = _bf(O.strip_peft_prefix(W))
+    ocfg = _full_cfg(meta)
+    p = meta["prompts"]
+    n = 10
+    batches, refs = [], []
+    for j, c0 in enumerate((51, 63, 75, 87, 99)):
+        nts = (p["n0"] + 2 * j, p["n1"] + (5 * j) % 7)
+        ids = [synth.synth_prompt_ids(nt, ocfg.base_vocab, model.SPECIAL_TOKEN_2_IDS, seed=meta["seed"], clip=c) for nt, c in zip(nts, (c0, c0 + 1))]
+        mods = [{'<video>': synth.synth_video(p["t_v"], seed=meta["seed"], clip=c), '<audio>': synth.synth_audio(p["t_a"], p["l_a"], seed=meta["seed"], clip=c)}
+                for c in (c0, c0 + 1)]
+        batches.append(dict(batch_input_ids=ids, batch_labels=[torch.full_like(i, -100) for i in ids], batch_X_modals=mods, batch_task_names=['avqa'] * 2))
+        refs.append(O.generate(ids, mods, Wo, ocfg, n))
+    embeds = [d["inputs_embeds"] for d in um.prepare_multimodal_inputs_many(batches)]
+    assert len({e.shape[1] for e in embeds}) >= 4
+    worst = 0.0
+    for max_rows in (None, 4):
+        res = um._engine.generate_many(embeds, n, eos_token_id=None, pad_token_id=2, coalesce=True, return_step_logits=True, max_rows=max_rows)
+        assert um._engine.last_plan["groups"] == ([10] if max_rows is None else [4, 4, 2]) and um._engine.last_plan["coalesced"]
+        for (ids, logits), (ref_ids, ref_logits) in zip(res, refs):
+            assert ids.shape == (2, n)
+            worst = max(worst, _check_ids(ids, ref_ids, ref_logits, logits, min_frac=0.9) / ref_logits.abs().max().item())
+    assert worst < REL_DEC, worst
+
+
+def test_coalesced_batches_stop_per_batch_like_separate_calls():
+    """EOS inside a coalesced wave: a batch whose rows have all finished returns what its own generate() call returns (trimmed at the column
+    where its LAST row finished, finished rows padded) although the wave keeps stepping for the other batches."""
+    meta, A, model, batches = _coalesce_setup()
+    eos = int(A["ids_bs1"][0, 3])                                 # batch 0 (bs 1) hits it at its 4th token
+    kw = dict(use_cache=True, max_new_tokens=24, pad_token_id=2, eos_token_id=eos)
+    many = model.generate_batches(batches, coalesce=True, **kw)
+    assert many[0].shape[1] == 4 and torch.equal(many[0][:, :4].cpu(), A["ids_bs1"][:, :4])
+    for g, b in enumerate(batches):
+        solo = model.generate(**b, **kw)
+        assert many[g].shape == solo.shape, (g, many[g].shape, solo.shape)
+        assert torch.equal(many[g], solo), g                      # fixture clips: wide margins, the ids agree across kernel regimes
+    # min_new_tokens suppresses the EOS for every batch of the wave alike
+    many2 = model.generate_batches(batches, coalesce=True, min_new_tokens=6, **kw)
+    assert many2[0].shape[1] >= 6 and torch.equal(many2[0][:, :3], many[0][:, :3])
+
+
+def test_harness_run_inference_coalesced(tmp_path):
+    """harness.run_inference(coalesce=True): the eval loop's batches are collected up to `coalesce_rows` clips and decoded as ragged waves;
+    the records (order, metadata, decoded text) equal the one-batch-at-a-time loop's."""
+    from crab_amd import harness
+    meta, A, model, batches = _coalesce_setup()
+
+    class Tok:
+        def batch_decode(self, ids, skip_special_tokens=False):
+            return [" ".join(str(int(t)) for t in row) for row in ids]
+    def with_meta(bs):
+        out = []
+        for i, b in enumerate(bs):
+            d = dict(b)
+            d["batch_metadata"] = [{"instruction": f"q{i}.{j}", "output": "x"} for j in range(len(b["batch_input_ids"]))]
+            out.append(d)
+        return out
+    loop = batches + batches[:2]                                   # 5 batches, 7 clips
+    kw = dict(max_new_tokens=meta["new_tokens"], pad_token_id=2, eos_token_id=None)
+    a = harness.run_inference(with_meta(loop), model, Tok(), **kw)
+    b = harness.run_inference(with_meta(loop), model, Tok(), coalesce=True, coalesce_rows=4, **kw)     # waves of >= 4 clips, then the rest
+    c = harness.run_inference(with_meta(loop), model, Tok(), coalesce=True, in_flight=5, **kw)
+    assert [r["instruction"] for r in a] == [r["instruction"] for r in b] == [r["instruction"] for r in c] and len(a) == 7
+    assert [r["predict"] for r in a] == [r["predict"] for r in b] == [r["predict"] for r in c]

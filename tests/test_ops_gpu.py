@@ -941,3 +941,49 @@ def test_prefill_rope_form_with_one_row_per_sequence_is_not_read_as_the_decode_f
         outs.append((qkv[:, :H * d].clone(), kc, vc))
     for a, b in zip(outs[0], outs[1]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("M", [1, 8, 16, 40, 256, 448])
+@pytest.mark.parametrize("H,Hk,bias,d", [(4, 4, False, 128), (8, 2, True, 128), (4, 2, True, 64)])
+def test_gemm_fused_rope_ragged_rows_rotate_at_their_own_positions(M, H, Hk, bias, d):
+    """The ragged decode batch (crab_gemm_desc.rope_row_off, ABI 9): row m of the fused q|k|v projection is rotated at slot - row_off[m] while
+    its K / V rows land in the common slot.  Bit-identical, row by row, to the plain fused call issued at position slot - row_off[m] - in the
+    M <= 16 epilogue (skinny.hip), the split-K reduction (gemm.hip, incl. the two-row-group regime above 256 rows) and the stand-alone pass
+    (crab_qkv_rope_split_ragged)."""
+    from crab_amd import ops
+    K, Tmax, K2, slot = 1024, 64, 32, 29
+    N = (H + 2 * Hk) * d
+    x, w = _rand(M, K, seed=1).cuda(), _rand(N, K, seed=2, scale=K ** -0.5).cuda()
+    x2, w2 = _rand(M, K2, seed=3).cuda(), _rand(N, K2, seed=4, scale=0.1).cuda()
+    b = _rand(N, seed=5).cuda() if bias else None
+    tab = ops.rope_table(Tmax, d, 10000.0, "cuda")
+    offs = [0, 3, 11, 29]
+    off = torch.tensor([offs[(5 * m + m // 3) % 4] for m in range(M)], dtype=torch.int32)
+    pos = torch.tensor([slot], dtype=torch.int32, device="cuda")
+
+    def run(p, row_off, split_pass):
+        kc = torch.zeros(M, Hk, Tmax, d, dtype=BF, device="cuda")
+        vc = torch.zeros_like(kc)
+        pd = torch.tensor([p], dtype=torch.int32, device="cuda")
+        if split_pass:
+            y = ops.gemm(x, w, bias=b, x2=x2, w2=w2)
+            ops.qkv_rope_split(y, tab, kc, vc, None, M, 1, H, Hk, d, Tmax, pos0=0, pos_dev=pd, row_off=row_off)
+        else:
+            y = ops.gemm(x, w, bias=b, x2=x2, w2=w2, rope=(tab, kc, vc, H, Hk, d, Tmax, 0, pd), rope_row_off=row_off)
+        return y[:, :H * d].clone(), kc, vc
+
+    for split_pass in (False, True):
+        # the reference of each form is the SAME form without offsets (above 256 rows the projection's K split depends on whether the RoPE is
+        # fused behind it, so the fused and the unfused projection may differ in their fp32 summation order)
+        plain = {o: run(slot - o, None, split_pass) for o in set(off.tolist())}
+        q, kc, vc = run(slot, off.cuda(), split_pass)
+        for m in range(M):
+            o = int(off[m])
+            qp, kp, vp = plain[o]
+            assert torch.equal(q[m], qp[m]), (m, o, split_pass)
+            assert torch.equal(kc[m, :, slot], kp[m, :, slot - o]) and torch.equal(vc[m, :, slot], vp[m, :, slot - o]), (m, o, split_pass)
+        keep = torch.ones(Tmax, dtype=torch.bool); keep[slot] = False
+        assert kc[:, :, keep].abs().sum() == 0 and vc[:, :, keep].abs().sum() == 0        # nothing outside the common slot
+    with pytest.raises(Exception):                       # the prefill form has no row offsets (its caller advances the cache pointers)
+        kc = torch.zeros(1, Hk, Tmax, d, dtype=BF, device="cuda")
+        ops.gemm(x[:1].expand(8, K).contiguous(), w, rope=(tab, kc, kc.clone(), H, Hk, d, Tmax, 0, None, 8, None), rope_row_off=off[:8].cuda())
