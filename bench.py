@@ -69,16 +69,19 @@ def decode_bytes_per_step(B, ctx, V=32017):
 
 
 def cpu_baseline(args):
-    """Bounded CPU sample (target ~20-30 s): 1 CLIP frame (23 layers) and a 4-layer full-width hyper-LoRA decoder: prefill
-    S=702 + 4 decode tokens; every sample runs once untimed (warm-up: page-in, thread pool, allocator) and is then timed
-    NREP = 3 times, the MEDIAN is used and the min-max spread reported ("one warm-up clip, then N >= 3").
-    Extrapolation: x8 frames (+7.5 % for BEATs / Q-Formers by FLOPs), x(32/4) layers, x(256/4) tokens; lm_head timed separately."""
+    """Bounded CPU sample (about 50 s on the GPU box's host cores): 1 CLIP frame (23 layers) and an 8-layer full-width hyper-LoRA decoder -
+    prefill S = 702 and 16 decode tokens spread over the contexts the 256-token generation passes through (6 at 702, 5 at 830, 5 at 958; the
+    KV cache of each point is filled directly instead of being produced by a prefill).  Every sample runs once untimed (warm-up: page-in,
+    thread pool, allocator) and is then timed NREP times; the MEDIAN is used and the min-max spread reported.
+    Extrapolation: x8 frames (+7.5 % for BEATs / Q-Formers by FLOPs), x(32/8) layers, 255 decode tokens at the mean of the three per-token
+    times (the attention term is linear in the context, so the mean over 702 / 830 / 958 is the mean over the generation); lm_head timed separately."""
     from crab_amd import synth
     from oracle import crab_oracle as O
     torch.manual_seed(0)
     nth = torch.get_num_threads()
     g = torch.Generator().manual_seed(1)
-    NREP, NL = 3, 4
+    NREP, NL = 3, 8
+    CTX = ((702, 6), (830, 5), (958, 5))
 
     def rnd(*s):
         return torch.randn(*s, generator=g) * 0.02
@@ -132,21 +135,20 @@ def cpu_baseline(args):
             for j in range(3):
                 Wd[f"{q}.{n}.lora_B{j}.weight"] = rnd(o, 8)
     emb = rnd(1, 702, 4096) * 50
-    state = {}
-
-    def prefill():
-        state["out"] = O.decoder_forward(emb, Wd, dec, last_only=True)
-
-    rec(f"prefill_{NL}l", timed(prefill))
+    rec(f"prefill_{NL}l", timed(lambda: O.decoder_forward(emb, Wd, dec, last_only=True), 2))
     e1 = rnd(1, 1, 4096) * 50
+    for ctx, ntok in CTX:
+        kv = [rnd(1, 32, ctx, 128) * 50 for _ in range(2 * NL)]          # a cache of `ctx` rows per layer: decode cost depends on its LENGTH only
 
-    def decode4():
-        c0 = state["out"][2]                                  # the prefill's cache; decoder_forward appends in place, so copy
-        cache = O.KVCache(k=[x.clone() for x in c0.k], v=[x.clone() for x in c0.v])
-        for _ in range(4):
-            _, _, cache = O.decoder_forward(e1, Wd, dec, cache, last_only=True)
+        def decode(ctx=ctx, ntok=ntok, kv=kv):
+            cache = O.KVCache(k=[x.clone() for x in kv[:NL]], v=[x.clone() for x in kv[NL:]])    # decoder_forward appends in place
+            pos = torch.tensor([[ctx]])
+            for j in range(ntok):
+                _, _, cache = O.decoder_forward(e1, Wd, dec, cache, positions=pos + j, last_only=True)
 
-    rec(f"decode4_{NL}l", timed(decode4, 15))           # short sample (< 1 s), the noisiest and 88 % of the extrapolated time: 15 repetitions
+        r = timed(decode)
+        rec(f"decode_tok_ctx{ctx}_{NL}l", tuple(x / ntok for x in r))
+        del kv
     h = rnd(1, 4096)
     rec("lm_head", timed(lambda: torch.nn.functional.linear(h, Wd["lm_head.weight"])))
     del Wd
@@ -154,10 +156,11 @@ def cpu_baseline(args):
     def per_clip(tt):
         # lm_head is inside the decoder_forward timings (last row): separate it out before scaling by layers
         pre = (tt[f"prefill_{NL}l"] - tt["lm_head"]) * (32 / NL) + tt["lm_head"]
-        dec_tok = (tt[f"decode4_{NL}l"] / 4 - tt["lm_head"]) * (32 / NL) + tt["lm_head"]
+        tok = sum(tt[f"decode_tok_ctx{c}_{NL}l"] for c, _ in CTX) / len(CTX)
+        dec_tok = (tok - tt["lm_head"]) * (32 / NL) + tt["lm_head"]
         # encoders: BEATs + projectors are ~8 % of encoder FLOPs; scale the CLIP time by the FLOP ratio
         enc = tt["clip_frame"] * 8 * (1.242 + 0.0875 + 0.032 + 0.0257) / 1.242
-        return enc + pre + 256 * dec_tok
+        return enc + pre + 255 * dec_tok
 
     cpu = "unknown CPU"
     try:
@@ -167,9 +170,11 @@ def cpu_baseline(args):
         pass
     return {"value": 1.0 / per_clip(t), "unit": "clips/s", "cores": nth, "kind": "port", "cpu": cpu,
             "value_range": [round(1.0 / per_clip(hi), 6), round(1.0 / per_clip(lo), 6)],
-            "sample": (f"oracle fp32 eager, one untimed warm-up then median of {NREP} per sample (15 for the decode sample): 1 CLIP frame x23 layers (x8, +7.5% for "
-                       f"BEATs/Q-Formers by FLOPs), {NL}-layer full-width hyper-LoRA decoder prefill S=702 (x{32 // NL} layers) and 4 decode "
-                       f"tokens (x64 tokens, x{32 // NL} layers); median s: {json.dumps({k: round(v, 3) for k, v in t.items()})}; "
+            "spread_rel": round((per_clip(hi) - per_clip(lo)) / per_clip(t), 3),
+            "sample": (f"oracle fp32 eager, one untimed warm-up then median of {NREP} per sample (2 for the prefill): 1 CLIP frame x23 layers (x8, +7.5% for "
+                       f"BEATs/Q-Formers by FLOPs), {NL}-layer full-width hyper-LoRA decoder prefill S=702 (x{32 // NL} layers) and 16 decode "
+                       f"tokens at contexts 702 / 830 / 958 (6 + 5 + 5; x255 tokens at their mean, x{32 // NL} layers); median s: "
+                       f"{json.dumps({k: round(v, 3) for k, v in t.items()})}; "
                        f"min s: {json.dumps({k: round(v, 3) for k, v in lo.items()})}; max s: {json.dumps({k: round(v, 3) for k, v in hi.items()})}")}
 
 
@@ -195,14 +200,17 @@ def operating_points(model, um, args, eos):
                                   pad_token_id=um.model.pad_token_id, output_logits=False)
         go()
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        r = go()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+        ts = []
+        for _ in range(2):                                 # two timed calls per point (the smaller is reported, both are listed)
+            t0 = time.perf_counter()
+            r = go()
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        dt = min(ts)
         assert tuple(r.shape) == (B, args.new_tokens)
         S_ = 126 + 32 * frames + 320
         out[name] = {"clips_per_batch": B, "frames": frames, "fbank_frames_per_window": l_a, "prefill_len": S_,
-                     "clips_per_s": round(B / dt, 3), "ms_per_batch": round(dt * 1e3, 1), "note": note}
+                     "clips_per_s": round(B / dt, 3), "ms_per_batch": round(dt * 1e3, 1), "ms_per_batch_calls": [round(x * 1e3, 1) for x in ts], "note": note}
         if B <= 16:
             # small batches are weight-streaming bound: HBM floor of the whole call = every decode step reads the decoder + lm_head + adapter
             # weights once and the live KV rows of its B clips (SURVEY 8d "algorithmic bytes per clip, decode"); prefill is <2 % of it
@@ -228,16 +236,19 @@ def operating_points(model, um, args, eos):
                                           pad_token_id=um.model.pad_token_id)
         go()
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        r = go()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+        ts = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            r = go()
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        dt = min(ts)
         assert len(r) == G and all(tuple(x.shape) == (B, args.new_tokens) for x in r)
         S_ = 126 + 32 * args.frames + 320
         steps = args.new_tokens - 1
         algo = G * sum(decode_bytes_per_step(B, S_ + t + 1, V=um.lm_head.weight.shape[0]) for t in range(steps))
         out[name] = {"batches_in_flight": G, "clips_per_batch": B, "frames": args.frames, "prefill_len": S_, "clips_per_s": round(G * B / dt, 3),
-                     "ms_per_call": round(dt * 1e3, 1), "note": note,
+                     "ms_per_call": round(dt * 1e3, 1), "ms_per_call_calls": [round(x * 1e3, 1) for x in ts], "note": note,
                      "hbm": {"bound": "hbm", "algorithmic_bytes": int(algo), "achieved_GBps": round(algo / dt / 1e9, 1), "peak_GBps": HBM_PEAK_GBS,
                              "frac": round(algo / dt / 1e9 / HBM_PEAK_GBS, 4),
                              "note": "every batch streams the weights for itself (separate M = 8 launches): bytes = G x one batch's"}}
@@ -285,6 +296,70 @@ def operating_points(model, um, args, eos):
     nb = min(args.clips, 256)                    # (256: the r01-r03 batch, so that these two lines stay comparable across rounds)
     run("audio_2s_windows", nb, args.frames, 198, "MUSIC-AVQA audio shape [10,198,128] (96 BEATs tokens per window)")
     run("frames_10", nb, 10, 98, "the reference's default video_frame_nums = 10 (S = 766)")
+    return out
+
+
+def _rccl_version():
+    try:
+        return ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception as e:      # noqa: BLE001
+        return f"unknown ({type(e).__name__})"
+
+
+def qwen_variant(llama_model, args):
+    """BASELINE configs[2]'s decoder (Qwen2-7B: GQA 28 / 4, q|k|v bias, vocab 152k; models/unified_qwen.py) on the same AVQA-shaped workload,
+    timed by the same process right after the headline: the Llama model's KV caches and graphs are released first (its weights stay),
+    one warm-up + two timed steps of 448 clips (or what fits), prefill fraction from the three phase marks of a third step.  Never `value`:
+    the same numbers come from `python bench.py --llm qwen` as a line of their own."""
+    from crab_amd import ops, synth
+    from crab_amd.build_model import build_crab
+    llama_model.base_model.model._engine.invalidate()
+    ops._SPLITK_WS.clear()
+    torch.cuda.empty_cache()
+    t0 = time.perf_counter()
+    model = build_crab("qwen", device=torch.device("cuda", torch.cuda.current_device()), seed=42)
+    um = model.base_model.model
+    S = 126 + 32 * args.frames + 320
+    free_now, _ = torch.cuda.mem_get_info()
+    per_clip = um._engine.bytes_per_sequence(S, args.new_tokens) + (70 << 20)
+    B = next((b for b in (448, 384, 320, 256, 128) if b * per_clip + (12 << 30) <= free_now), 64)
+    tab = um.SPECIAL_TOKEN_2_IDS
+    ids = [synth.synth_prompt_ids(128, model.base_vocab, tab, clip=i) for i in range(B)]
+    mods = [{'<video>': synth.synth_video(args.frames, clip=i).cuda(), '<audio>': synth.synth_audio(10, 98, clip=i).cuda()} for i in range(B)]
+    lab = [torch.full_like(i, -100) for i in ids]
+    ids = [i.cuda() for i in ids]
+    build_s = time.perf_counter() - t0
+
+    def go():
+        return model.generate(batch_input_ids=ids, batch_labels=lab, batch_X_modals=mods, batch_task_names=['avqa'] * B, use_cache=True,
+                              max_new_tokens=args.new_tokens, min_new_tokens=args.new_tokens, eos_token_id=um.config.eos_token_id,
+                              pad_token_id=um.model.pad_token_id, output_logits=False)
+    go()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(2):
+        t1 = time.perf_counter()
+        r = go()
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t1)
+    assert tuple(r.shape) == (B, args.new_tokens)
+    prof = ops.KernelProfiler(phase_only=True)
+    ops.PROFILER = prof
+    go()
+    torch.cuda.synchronize()
+    ops.PROFILER = None
+    pre_ms, dec_ms = prof.phase_ms()
+    V = um.lm_head.weight.shape[0]
+    fl = flops_per_clip(args.frames, 10, 48, S, V, um.config)
+    out = {"workload": "AVQA eval shape, Qwen2-7B + BEATs + CLIP-ViT-L/14, bf16 (BASELINE configs[2] decoder)", "clips_per_step": B,
+           "clips_per_s": round(B / min(ts), 3), "ms_per_step_calls": [round(x * 1e3, 1) for x in ts], "build_s": round(build_s, 1),
+           "prefill_tflop_per_clip": round(fl / 1e12, 3),
+           "prefill_roofline": {"bound": "mfma", "achieved": round(fl * B / (pre_ms * 1e-3) / 1e12, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": round(fl * B / (pre_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4), "ms_per_clip": round(pre_ms / B, 3),
+                                "decode_ms_per_clip": round(dec_ms / B, 3)}}
+    um._engine.invalidate()
+    del model, um
+    torch.cuda.empty_cache()
     return out
 
 
@@ -338,6 +413,10 @@ def main():
     if world > 1 and not single_dev and torch.cuda.device_count() < world:
         sys.exit(f"bench.py: {world} ranks need {world} visible GPUs, found {torch.cuda.device_count()} (one process per GPU)")
     torch.cuda.set_device(local)
+    if world > 1:
+        # N ranks share one host: each keeps cores / N threads for its host-side work (input synthesis, the splice plan), instead of every
+        # rank starting a full-width thread pool (8 x 128 threads oversubscribed the host and showed up as warm-up stragglers)
+        torch.set_num_threads(max(1, (os.cpu_count() or 8) // world))
     dist = None
     # CRAB_BENCH_FORCE_DIST=1 (test hook): make the process group even for ONE rank, so that the RCCL code path - communicator init with
     # device_id, barrier, all_reduce, all_gather, the result gather - really executes on a one-GPU box (tests/test_bench_launch.py)
@@ -412,9 +491,16 @@ def main():
         torch.cuda.synchronize()
 
     t_build = time.perf_counter() - t_setup
+    # early, per rank, on stderr: a straggler (slow build, occupied device) is visible long before the JSON line or a launcher timeout
+    print(f"[bench rank {rank}/{world}] built in {t_build:.1f} s on cuda:{local} ({free0 / 2**30:.0f} GiB free), {B} clips per step, "
+          f"{torch.get_num_threads()} host threads", file=sys.stderr, flush=True)
     t_w = time.perf_counter()
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
+        tw = time.perf_counter()
         step()
+        if i == 0:
+            torch.cuda.synchronize()
+            print(f"[bench rank {rank}/{world}] first warm-up step {time.perf_counter() - tw:.1f} s", file=sys.stderr, flush=True)
     torch.cuda.synchronize()
     t_warm = time.perf_counter() - t_w
     # capacity: generate() splits a batch whose KV cache + scratch do not fit the device into groups that run one after the other (with a
@@ -527,6 +613,8 @@ def main():
                        "decode": "greedy, EOS suppressed, device-resident HIP-graph loop", "parallelism": f"per-clip x{world} (contiguous blocks of clips per rank), RCCL gather",
                        "collective_backend": (backend + (" (RCCL)" if backend == "nccl" else "")) if dist is not None else None,
                        "world_size_observed": dist.get_world_size() if dist is not None else 1,
+                       "rccl_version": _rccl_version() if (backend == "nccl" and dist is not None) else None,
+                       "host_threads_per_rank": torch.get_num_threads(),
                        "gathered_per_clip": "clip id + ids" + ("" if args.no_gather_logits else f" + first-step fp32 logits[{V}]"),
                        "gathered_clips": int(res[1].shape[0])},
             "rank_ms_per_step": rank_ms,
@@ -544,6 +632,11 @@ def main():
         }
         if world == 1 and not args.no_operating_points and args.llm == "llama":
             line["reference_operating_points"] = operating_points(model, um, args, eos)
+        if world == 1 and not args.no_operating_points and args.llm == "llama":
+            try:
+                line["qwen2_7b_variant"] = qwen_variant(model, args)
+            except Exception as e:      # the headline must still be reported
+                line["qwen2_7b_variant"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(args)

@@ -64,7 +64,7 @@ class Dense(C.Structure):
 
 class LN(C.Structure):
     """crab_ln"""
-    _fields_ = [("w", C.c_void_p), ("b", C.c_void_p), ("eps", C.c_float)]
+    _fields_ = [("w", C.c_void_p), ("b", C.c_void_p), ("eps", C.c_float), ("fp32", C.c_int32)]
 
 
 class ClipLayerW(C.Structure):
@@ -129,6 +129,8 @@ _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 SYMBOLS = {
     "crab_abi_version": (_i, []),
     "crab_sizeof_gemm_desc": (_i, []),
+    "crab_decode_max_rows": (_i, []),
+    "crab_attn_split_below": (_i, []),
     "crab_gemm_fuses_prefill_rope": (_i, [_vp]),
     "crab_sizeof_attn_desc": (_i, []),
     "crab_sizeof_llama_layer": (_i, []),
@@ -161,6 +163,8 @@ SYMBOLS = {
     "crab_embedding_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i]),
     "crab_rmsnorm_f32": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _i, _i, _f]),
     "crab_layernorm_f32": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _f]),
+    "crab_layernorm_p": (_i, [_vp, _vp, _vp, _i, _i64, _vp, _vp, _i, _vp, _i64, _i, _i, _f]),
+    "crab_clip_embed_ln_p": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _f]),
     "crab_cast_rows_bf16_f32": (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _i, _i]),
     "crab_cast_rows_f32_bf16": (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _i, _i]),
     "crab_rope_table": (_i, [_vp, _vp, _vp, _i, _i, _f]),
@@ -214,6 +218,17 @@ SYMBOLS = {
     "crab_kaldi_fbank": (_i, [_vp, _vp, _vp, _i64, _i, _i, _f, _f, _vp, _vp, _vp, _f, _f]),
 }
 
+def header_const(name: str) -> int:
+    """An integer `#define` of include/crab_hip.h: the single source of the dispatch bounds the Python side mirrors (CRAB_DECODE_MAX_ROWS,
+    CRAB_ATTN_SPLIT_BELOW); load() checks them against the values compiled into the library."""
+    import re
+    with open(os.path.join(os.path.dirname(_HERE), "include", "crab_hip.h")) as f:
+        m = re.search(r"^#define\s+" + re.escape(name) + r"\s+(\d+)", f.read(), re.M)
+    if not m:
+        raise CrabHipError(f"include/crab_hip.h does not define {name}")
+    return int(m.group(1))
+
+
 _lib = None
 _lock = threading.Lock()
 _ctxs = {}
@@ -237,6 +252,9 @@ def load() -> C.CDLL:
                 raise CrabHipError(f"libcrab_hip.so does not export {name}")
             fn.restype = res
             fn.argtypes = args
+        for macro, fn in (("CRAB_DECODE_MAX_ROWS", lib.crab_decode_max_rows), ("CRAB_ATTN_SPLIT_BELOW", lib.crab_attn_split_below)):
+            if fn() != header_const(macro):
+                raise CrabHipError(f"libcrab_hip.so was built with {macro} = {fn()}, include/crab_hip.h says {header_const(macro)}: rebuild (csrc/build.sh)")
         _lib = lib
     return _lib
 

@@ -27,6 +27,23 @@ __device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf2(f, 0.
 __device__ __forceinline__ float lo_bf(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float hi_bf(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
+// Eight consecutive NORM PARAMETERS (LayerNorm weight / bias) starting at element e (a multiple of 8): bf16 storage (one 16-byte load) or,
+// WF, fp32 storage (two) - the non-matrix parameters of the encoders may stay in fp32 (crab_ln.fp32): they are not MFMA operands, and their
+// bf16 rounding is a systematic 2^-9 relative error on every channel of every LayerNorm output (scripts/parity_floor.py).
+template <bool WF>
+__device__ __forceinline__ void ld_par8(const void* p, long e, float (&o)[8]) {
+    if (WF) {
+        const f32x4_t a = *reinterpret_cast<const f32x4_t*>(reinterpret_cast<const float*>(p) + e);
+        const f32x4_t b = *reinterpret_cast<const f32x4_t*>(reinterpret_cast<const float*>(p) + e + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { o[j] = a[j]; o[4 + j] = b[j]; }
+    } else {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint16_t*>(p) + e);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { o[2 * j] = lo_bf(v[j]); o[2 * j + 1] = hi_bf(v[j]); }
+    }
+}
+
 // Cross-lane exchange inside a 16-lane row by DPP (data-parallel primitives: the exchange rides on a VALU instruction).  The compiler lowers
 // __shfl_xor(v, 1..8) to ds_bpermute_b32, an LDS-crossbar instruction: the key loop of the decode-attention kernels issued 4-15 of them
 // per key row (ISA, profiles/README.md r03).  lane ^ 1 and ^ 2 are quad permutes, ^ 8 is a rotation of the row by 8, ^ 4 = half-row

@@ -54,8 +54,7 @@ int attention(crab_ctx* ctx, void* stream, const crab_enc_io* io, const uint16_t
 
 // LayerNorm of bf16 rows, or of fp32 rows (the fp32 residual stream / fp32 pre-LN sums)
 int ln(crab_ctx* ctx, void* stream, int x_fp32, const void* x, int64_t ldx, const crab_ln* w, void* y, int64_t ldy, int M, int D) {
-    return x_fp32 ? crab_layernorm_f32(ctx, stream, (const float*)x, ldx, w->w, w->b, y, ldy, M, D, w->eps)
-                  : crab_layernorm(ctx, stream, x, ldx, w->w, w->b, y, ldy, M, D, w->eps);
+    return crab_layernorm_p(ctx, stream, x, x_fp32, ldx, w->w, w->b, w->fp32, y, ldy, M, D, w->eps);
 }
 
 int check_io(crab_ctx* ctx, const crab_enc_io* io, bool need_f, const char* who) {

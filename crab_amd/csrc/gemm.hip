@@ -696,7 +696,7 @@ extern "C" int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc*
     //                      the weights once.  Only with a workspace, automatic tuning and never for the prefill form of the fused RoPE.
     static const int dec_on_ = []() { const char* e = getenv("CRAB_DEC_GEMM"); return !(e && e[0] == '0'); }();
     const bool dec512 = d->M > 256 && d->M <= CRAB_DECODE_MAX_ROWS && d->batch <= 1 && d->workspace != nullptr && dec_on_ &&
-                        (d->tune == 0 || (d->tune >= 70000 && d->tune < 80000)) &&          // 7BBSS: a forced (panel width, K slices), benchmarking
+                        (d->tune == 0 || (d->tune >= 70000 && d->tune < 80000) || (d->tune >= 400 && d->tune < 500)) &&   // 7BBSS: a forced (panel width, K slices); 4SS: the 256 x 256 ring kernel with SS K slices (benchmarking)
                         nk_all >= 8 && !(d->rope_tab && d->rope_S > 1) && (int64_t)d->M * d->N * 4 <= d->workspace_bytes;
     if (d->batch <= 1 && (d->M <= 256 || dec512) && (d->M <= 128 || d->workspace != nullptr)) {
         bool want_split = d->M > 16 && d->workspace != nullptr && nk_all >= 8;

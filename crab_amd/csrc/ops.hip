@@ -11,9 +11,9 @@ namespace {
 // One wave per row (4 rows per 256-thread block); the row stays in registers between the two passes.
 // MAXV = vectors of 8 per lane the row may need: 16 (D <= 8192) or 4 (D <= 2048: CLIP / BEATs / Q-Former widths - a quarter of the
 // registers, so twice the resident waves for rows that are only 2-4 KB long)
-template <bool RMS, int MAXV = 16>
-__global__ __launch_bounds__(256) void norm_kernel(const bf16_t* __restrict__ x, long ldx, const bf16_t* __restrict__ w,
-                                                   const bf16_t* __restrict__ b, bf16_t* __restrict__ y, long ldy,
+template <bool RMS, int MAXV = 16, bool WF = false>            // WF: w / b are fp32 (crab_ln.fp32)
+__global__ __launch_bounds__(256) void norm_kernel(const bf16_t* __restrict__ x, long ldx, const void* __restrict__ w,
+                                                   const void* __restrict__ b, bf16_t* __restrict__ y, long ldy,
                                                    int M, int D, float eps) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -63,9 +63,9 @@ __global__ __launch_bounds__(256) void norm_kernel(const bf16_t* __restrict__ x,
     for (int i = 0; i < MAXV; ++i) {
         int vi = lane + i * 64;
         if (vi < nvec) {
-            u32x4 wv = *reinterpret_cast<const u32x4*>(w + vi * 8);
-            u32x4 bv = {0u, 0u, 0u, 0u};
-            if (!RMS && b) bv = *reinterpret_cast<const u32x4*>(b + vi * 8);
+            float wv[8], bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            ld_par8<WF>(w, (long)vi * 8, wv);
+            if (!RMS && b) ld_par8<WF>(b, (long)vi * 8, bv);
             u32x4 o;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -73,8 +73,8 @@ __global__ __launch_bounds__(256) void norm_kernel(const bf16_t* __restrict__ x,
                 if (RMS) {   // modeling_llama.py:116-117: weight * x_hat.to(input_dtype)
                     a = bf2f(f2bf(a)); c = bf2f(f2bf(c));
                 }
-                a = a * lo_bf(wv[j]) + lo_bf(bv[j]);
-                c = c * hi_bf(wv[j]) + hi_bf(bv[j]);
+                a = a * wv[2 * j] + bv[2 * j];
+                c = c * wv[2 * j + 1] + bv[2 * j + 1];
                 o[j] = pack_bf2(a, c);
             }
             *reinterpret_cast<u32x4*>(yr + vi * 8) = o;
@@ -85,9 +85,9 @@ __global__ __launch_bounds__(256) void norm_kernel(const bf16_t* __restrict__ x,
 // The same for an fp32 input row (the fp32 residual stream of the decoder / CLIP tower: x stays fp32 between the projection epilogues,
 // only the normalised row that feeds the next MFMA GEMM is bf16).  No intermediate rounding of x_hat: the reference runs this norm in fp32
 // (scripts/quick_start.sh:42-44 --bf16 False; modeling_llama.py:112-117 with an fp32 input is exact), so y = bf16(x_hat * w [+ b]).
-template <bool RMS, int MAXV = 16>
-__global__ __launch_bounds__(256) void norm_f32in_kernel(const float* __restrict__ x, long ldx, const bf16_t* __restrict__ w,
-                                                         const bf16_t* __restrict__ b, bf16_t* __restrict__ y, long ldy,
+template <bool RMS, int MAXV = 16, bool WF = false>
+__global__ __launch_bounds__(256) void norm_f32in_kernel(const float* __restrict__ x, long ldx, const void* __restrict__ w,
+                                                         const void* __restrict__ b, bf16_t* __restrict__ y, long ldy,
                                                          int M, int D, float eps) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -137,15 +137,15 @@ __global__ __launch_bounds__(256) void norm_f32in_kernel(const float* __restrict
     for (int i = 0; i < MAXV; ++i) {
         int vi = lane + i * 64;
         if (vi < nvec) {
-            u32x4 wv = *reinterpret_cast<const u32x4*>(w + vi * 8);
-            u32x4 bv = {0u, 0u, 0u, 0u};
-            if (!RMS && b) bv = *reinterpret_cast<const u32x4*>(b + vi * 8);
+            float wv[8], bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            ld_par8<WF>(w, (long)vi * 8, wv);
+            if (!RMS && b) ld_par8<WF>(b, (long)vi * 8, bv);
             u32x4 o;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float a = (v[i][j >> 1][(2 * j) & 3] - mean) * rstd, c = (v[i][j >> 1][(2 * j + 1) & 3] - mean) * rstd;
-                a = a * lo_bf(wv[j]) + lo_bf(bv[j]);
-                c = c * hi_bf(wv[j]) + hi_bf(bv[j]);
+                a = a * wv[2 * j] + bv[2 * j];
+                c = c * wv[2 * j + 1] + bv[2 * j + 1];
                 o[j] = pack_bf2(a, c);
             }
             *reinterpret_cast<u32x4*>(yr + vi * 8) = o;
@@ -477,9 +477,10 @@ __global__ __launch_bounds__(256) void im2col_patch_kernel(const TI* __restrict_
 }
 
 // CLIP: assemble [cls | patches] + position embedding, then pre_layrnorm; one wave per token row
+template <bool WF>
 __global__ __launch_bounds__(256) void clip_embed_ln_kernel(const bf16_t* __restrict__ patch, const bf16_t* __restrict__ cls,
-                                                            const bf16_t* __restrict__ pos, const bf16_t* __restrict__ lnw,
-                                                            const bf16_t* __restrict__ lnb, bf16_t* __restrict__ y, int N, int P,
+                                                            const bf16_t* __restrict__ pos, const void* __restrict__ lnw,
+                                                            const void* __restrict__ lnb, bf16_t* __restrict__ y, int N, int P,
                                                             int D, float eps) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -494,8 +495,8 @@ __global__ __launch_bounds__(256) void clip_embed_ln_kernel(const bf16_t* __rest
     for (int i = 0; i < MAXE; ++i) {
         int e = lane + i * 64;
         if (e < D) {
-            // bf16 reference rounds the sum of two bf16 tensors to bf16 before the LayerNorm
-            v[i] = bf2f(f2bf(bf2f(src[e]) + bf2f(pe[e])));
+            // the sum feeds the LayerNorm unrounded (r05: the fp32 reference does not round it; r01-r04 rounded it to bf16 like a bf16 model would)
+            v[i] = bf2f(src[e]) + bf2f(pe[e]);
             s1 += v[i];
         }
     }
@@ -511,15 +512,20 @@ __global__ __launch_bounds__(256) void clip_embed_ln_kernel(const bf16_t* __rest
 #pragma unroll
     for (int i = 0; i < MAXE; ++i) {
         int e = lane + i * 64;
-        if (e < D) yr[e] = f2bf((v[i] - mean) * rstd * bf2f(lnw[e]) + bf2f(lnb[e]));
+        if (e < D) {
+            const float w_ = WF ? reinterpret_cast<const float*>(lnw)[e] : bf2f(reinterpret_cast<const bf16_t*>(lnw)[e]);
+            const float b_ = WF ? reinterpret_cast<const float*>(lnb)[e] : bf2f(reinterpret_cast<const bf16_t*>(lnb)[e]);
+            yr[e] = f2bf((v[i] - mean) * rstd * w_ + b_);
+        }
     }
 }
 
 // D % 8 == 0: each lane owns 16-byte chunks (8 consecutive elements), so every global access of the row is a full-width
 // coalesced dwordx4 (the scalar kernel above moves 2 bytes per lane and reaches 1.6 TB/s; this one is HBM-copy bound)
+template <bool WF>
 __global__ __launch_bounds__(256) void clip_embed_ln_vec_kernel(const bf16_t* __restrict__ patch, const bf16_t* __restrict__ cls,
-                                                                const bf16_t* __restrict__ pos, const bf16_t* __restrict__ lnw,
-                                                                const bf16_t* __restrict__ lnb, bf16_t* __restrict__ y, int N, int P,
+                                                                const bf16_t* __restrict__ pos, const void* __restrict__ lnw,
+                                                                const void* __restrict__ lnb, bf16_t* __restrict__ y, int N, int P,
                                                                 int D, float eps) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -540,7 +546,7 @@ __global__ __launch_bounds__(256) void clip_embed_ln_vec_kernel(const bf16_t* __
             b.r = *reinterpret_cast<const u32x4*>(pe + e);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                v[i][j] = bf2f(f2bf(bf2f(a.h[j]) + bf2f(b.h[j])));      // the bf16 sum of two bf16 tensors, as the reference
+                v[i][j] = bf2f(a.h[j]) + bf2f(b.h[j]);                  // unrounded (see clip_embed_ln_kernel)
                 s1 += v[i][j];
             }
         }
@@ -560,11 +566,12 @@ __global__ __launch_bounds__(256) void clip_embed_ln_vec_kernel(const bf16_t* __
     for (int i = 0; i < MAXC; ++i) {
         const int e = (lane + i * 64) * 8;
         if (e < D) {
-            V8 w, b, o;
-            w.r = *reinterpret_cast<const u32x4*>(lnw + e);
-            b.r = *reinterpret_cast<const u32x4*>(lnb + e);
+            V8 o;
+            float w8[8], b8[8];
+            ld_par8<WF>(lnw, (long)e, w8);
+            ld_par8<WF>(lnb, (long)e, b8);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o.h[j] = f2bf((v[i][j] - mean) * rstd * bf2f(w.h[j]) + bf2f(b.h[j]));
+            for (int j = 0; j < 8; ++j) o.h[j] = f2bf((v[i][j] - mean) * rstd * w8[j] + b8[j]);
             *reinterpret_cast<u32x4*>(yr + e) = o.r;
         }
     }
@@ -732,58 +739,51 @@ static inline unsigned cdiv(long a, long b) { return (unsigned)((a + b - 1) / b)
 
 extern "C" {
 
-int crab_rmsnorm(crab_ctx* ctx, void* stream, const void* x, int64_t ldx, const void* w, void* y, int64_t ldy, int M, int D, float eps) {
+// The four public norm entry points and their parameter-storage variant share one launcher: x bf16 | fp32, RMS | LayerNorm, w / b bf16 | fp32
+static int norm_launch(crab_ctx* ctx, void* stream, const char* what, const void* x, int x_fp32, int64_t ldx, const void* w, const void* b, int w_fp32,
+                       void* y, int64_t ldy, int M, int D, float eps, bool rms) {
     if (!ctx) return CRAB_E_INVALID;
-    if (!x || !w || !y || M <= 0) return crab_fail(ctx, CRAB_E_INVALID, "rmsnorm: bad argument");
-    if ((D & 7) || D > 8192 || (ldx & 7) || (ldy & 7)) return crab_fail(ctx, CRAB_E_INVALID, "rmsnorm: D must be a multiple of 8 and <= 8192");
-    if (D <= 2048)
-        hipLaunchKernelGGL((norm_kernel<true, 4>), dim3(cdiv(M, 4)), dim3(256), 0, S_(stream), (const bf16_t*)x, (long)ldx, (const bf16_t*)w,
-                           (const bf16_t*)nullptr, (bf16_t*)y, (long)ldy, M, D, eps);
-    else
-        hipLaunchKernelGGL((norm_kernel<true>), dim3(cdiv(M, 4)), dim3(256), 0, S_(stream), (const bf16_t*)x, (long)ldx, (const bf16_t*)w,
-                           (const bf16_t*)nullptr, (bf16_t*)y, (long)ldy, M, D, eps);
-    return crab_check_launch(ctx, "rmsnorm");
+    char msg[160];
+    if (!x || !w || !y || M <= 0) { snprintf(msg, sizeof(msg), "%s: bad argument", what); return crab_fail(ctx, CRAB_E_INVALID, msg); }
+    if ((D & 7) || D > 8192 || (ldx & (x_fp32 ? 3 : 7)) || (ldy & 7) || (x_fp32 && ((uintptr_t)x & 15)) ||
+        (w_fp32 && (((uintptr_t)w | (uintptr_t)b) & 15))) {
+        snprintf(msg, sizeof(msg), "%s: D must be a multiple of 8 and <= 8192%s", what, x_fp32 ? ", 16-byte aligned rows" : "");
+        return crab_fail(ctx, CRAB_E_INVALID, msg);
+    }
+    const dim3 grid(cdiv(M, 4)), block(256);
+    hipStream_t s = S_(stream);
+#define NL(K_, RMS_, MV_, WF_, XT_) hipLaunchKernelGGL((K_<RMS_, MV_, WF_>), grid, block, 0, s, (const XT_*)x, (long)ldx, w, b, (bf16_t*)y, (long)ldy, M, D, eps)
+#define NL_X(RMS_, MV_, WF_) do { if (x_fp32) NL(norm_f32in_kernel, RMS_, MV_, WF_, float); else NL(norm_kernel, RMS_, MV_, WF_, bf16_t); } while (0)
+#define NL_W(RMS_, MV_) do { if (w_fp32) NL_X(RMS_, MV_, true); else NL_X(RMS_, MV_, false); } while (0)
+    if (rms) { if (D <= 2048) NL_W(true, 4); else NL_W(true, 16); }
+    else { if (D <= 2048) NL_W(false, 4); else NL_W(false, 16); }
+#undef NL_W
+#undef NL_X
+#undef NL
+    return crab_check_launch(ctx, what);
+}
+
+int crab_rmsnorm(crab_ctx* ctx, void* stream, const void* x, int64_t ldx, const void* w, void* y, int64_t ldy, int M, int D, float eps) {
+    return norm_launch(ctx, stream, "rmsnorm", x, 0, ldx, w, nullptr, 0, y, ldy, M, D, eps, true);
 }
 
 int crab_layernorm(crab_ctx* ctx, void* stream, const void* x, int64_t ldx, const void* w, const void* b, void* y, int64_t ldy, int M,
                    int D, float eps) {
-    if (!ctx) return CRAB_E_INVALID;
-    if (!x || !w || !y || M <= 0) return crab_fail(ctx, CRAB_E_INVALID, "layernorm: bad argument");
-    if ((D & 7) || D > 8192 || (ldx & 7) || (ldy & 7)) return crab_fail(ctx, CRAB_E_INVALID, "layernorm: D must be a multiple of 8 and <= 8192");
-    if (D <= 2048)
-        hipLaunchKernelGGL((norm_kernel<false, 4>), dim3(cdiv(M, 4)), dim3(256), 0, S_(stream), (const bf16_t*)x, (long)ldx, (const bf16_t*)w,
-                           (const bf16_t*)b, (bf16_t*)y, (long)ldy, M, D, eps);
-    else
-        hipLaunchKernelGGL((norm_kernel<false>), dim3(cdiv(M, 4)), dim3(256), 0, S_(stream), (const bf16_t*)x, (long)ldx, (const bf16_t*)w,
-                           (const bf16_t*)b, (bf16_t*)y, (long)ldy, M, D, eps);
-    return crab_check_launch(ctx, "layernorm");
+    return norm_launch(ctx, stream, "layernorm", x, 0, ldx, w, b, 0, y, ldy, M, D, eps, false);
 }
 
 int crab_rmsnorm_f32(crab_ctx* ctx, void* stream, const float* x, int64_t ldx, const void* w, void* y, int64_t ldy, int M, int D, float eps) {
-    if (!ctx) return CRAB_E_INVALID;
-    if (!x || !w || !y || M <= 0) return crab_fail(ctx, CRAB_E_INVALID, "rmsnorm_f32: bad argument");
-    if ((D & 7) || D > 8192 || (ldx & 3) || (ldy & 7) || ((uintptr_t)x & 15)) return crab_fail(ctx, CRAB_E_INVALID, "rmsnorm_f32: D must be a multiple of 8 and <= 8192, 16-byte aligned rows");
-    if (D <= 2048)
-        hipLaunchKernelGGL((norm_f32in_kernel<true, 4>), dim3(cdiv(M, 4)), dim3(256), 0, S_(stream), x, (long)ldx, (const bf16_t*)w,
-                           (const bf16_t*)nullptr, (bf16_t*)y, (long)ldy, M, D, eps);
-    else
-        hipLaunchKernelGGL((norm_f32in_kernel<true>), dim3(cdiv(M, 4)), dim3(256), 0, S_(stream), x, (long)ldx, (const bf16_t*)w,
-                           (const bf16_t*)nullptr, (bf16_t*)y, (long)ldy, M, D, eps);
-    return crab_check_launch(ctx, "rmsnorm_f32");
+    return norm_launch(ctx, stream, "rmsnorm_f32", x, 1, ldx, w, nullptr, 0, y, ldy, M, D, eps, true);
 }
 
 int crab_layernorm_f32(crab_ctx* ctx, void* stream, const float* x, int64_t ldx, const void* w, const void* b, void* y, int64_t ldy, int M,
                        int D, float eps) {
-    if (!ctx) return CRAB_E_INVALID;
-    if (!x || !w || !y || M <= 0) return crab_fail(ctx, CRAB_E_INVALID, "layernorm_f32: bad argument");
-    if ((D & 7) || D > 8192 || (ldx & 3) || (ldy & 7) || ((uintptr_t)x & 15)) return crab_fail(ctx, CRAB_E_INVALID, "layernorm_f32: D must be a multiple of 8 and <= 8192, 16-byte aligned rows");
-    if (D <= 2048)
-        hipLaunchKernelGGL((norm_f32in_kernel<false, 4>), dim3(cdiv(M, 4)), dim3(256), 0, S_(stream), x, (long)ldx, (const bf16_t*)w,
-                           (const bf16_t*)b, (bf16_t*)y, (long)ldy, M, D, eps);
-    else
-        hipLaunchKernelGGL((norm_f32in_kernel<false>), dim3(cdiv(M, 4)), dim3(256), 0, S_(stream), x, (long)ldx, (const bf16_t*)w,
-                           (const bf16_t*)b, (bf16_t*)y, (long)ldy, M, D, eps);
-    return crab_check_launch(ctx, "layernorm_f32");
+    return norm_launch(ctx, stream, "layernorm_f32", x, 1, ldx, w, b, 0, y, ldy, M, D, eps, false);
+}
+
+int crab_layernorm_p(crab_ctx* ctx, void* stream, const void* x, int x_fp32, int64_t ldx, const void* w, const void* b, int w_fp32, void* y,
+                     int64_t ldy, int M, int D, float eps) {
+    return norm_launch(ctx, stream, "layernorm_p", x, x_fp32 ? 1 : 0, ldx, w, b, w_fp32 ? 1 : 0, y, ldy, M, D, eps, false);
 }
 
 int crab_embedding_f32(crab_ctx* ctx, void* stream, const int64_t* ids, const void* table, float* out, int64_t ldo, int T, int D, int vocab) {
@@ -916,18 +916,22 @@ int crab_im2col_patch(crab_ctx* ctx, void* stream, const void* in, int in_fp32, 
     return crab_check_launch(ctx, "im2col_patch");
 }
 
-int crab_clip_embed_ln(crab_ctx* ctx, void* stream, const void* patch, const void* cls, const void* pos, const void* lnw, const void* lnb,
-                       void* y, int N, int P, int D, float eps) {
+int crab_clip_embed_ln_p(crab_ctx* ctx, void* stream, const void* patch, const void* cls, const void* pos, const void* lnw, const void* lnb,
+                         int ln_fp32, void* y, int N, int P, int D, float eps) {
     if (!ctx) return CRAB_E_INVALID;
     if (!patch || !cls || !pos || !lnw || !lnb || !y || D > 2048) return crab_fail(ctx, CRAB_E_INVALID, "clip_embed_ln: bad argument");
     const bool vec = (D & 7) == 0 && (((uintptr_t)patch | (uintptr_t)cls | (uintptr_t)pos | (uintptr_t)lnw | (uintptr_t)lnb | (uintptr_t)y) & 15) == 0;
-    if (vec)
-        hipLaunchKernelGGL(clip_embed_ln_vec_kernel, dim3(cdiv((long)N * (P + 1), 4)), dim3(256), 0, S_(stream), (const bf16_t*)patch,
-                           (const bf16_t*)cls, (const bf16_t*)pos, (const bf16_t*)lnw, (const bf16_t*)lnb, (bf16_t*)y, N, P, D, eps);
-    else
-        hipLaunchKernelGGL(clip_embed_ln_kernel, dim3(cdiv((long)N * (P + 1), 4)), dim3(256), 0, S_(stream), (const bf16_t*)patch,
-                           (const bf16_t*)cls, (const bf16_t*)pos, (const bf16_t*)lnw, (const bf16_t*)lnb, (bf16_t*)y, N, P, D, eps);
+    const dim3 grid(cdiv((long)N * (P + 1), 4)), block(256);
+#define CE(K_, WF_) hipLaunchKernelGGL((K_<WF_>), grid, block, 0, S_(stream), (const bf16_t*)patch, (const bf16_t*)cls, (const bf16_t*)pos, lnw, lnb, (bf16_t*)y, N, P, D, eps)
+    if (vec) { if (ln_fp32) CE(clip_embed_ln_vec_kernel, true); else CE(clip_embed_ln_vec_kernel, false); }
+    else { if (ln_fp32) CE(clip_embed_ln_kernel, true); else CE(clip_embed_ln_kernel, false); }
+#undef CE
     return crab_check_launch(ctx, "clip_embed_ln");
+}
+
+int crab_clip_embed_ln(crab_ctx* ctx, void* stream, const void* patch, const void* cls, const void* pos, const void* lnw, const void* lnb,
+                       void* y, int N, int P, int D, float eps) {
+    return crab_clip_embed_ln_p(ctx, stream, patch, cls, pos, lnw, lnb, 0, y, N, P, D, eps);
 }
 
 int crab_beats_posconv_pad(crab_ctx* ctx, void* stream, const void* x, void* xp, int B, int n, int E, int G, int Kc) {

@@ -49,6 +49,8 @@ def _dense(lin) -> "_lib.Dense":
 def _ln(ln) -> "_lib.LN":
     r = _lib.LN()
     r.w, r.b, r.eps = ln.weight.data_ptr(), ln.bias.data_ptr(), ln.eps
+    r.fp32 = 1 if ln.weight.dtype == torch.float32 else 0
+    assert ln.bias.dtype == ln.weight.dtype
     return r
 
 
@@ -73,8 +75,8 @@ class _EncScratch:
         return io
 
 
-def _p(t, device, *shape, fill=0.0):
-    return nn.Parameter(torch.full(shape, fill, device=device, dtype=BF16), requires_grad=False)
+def _p(t, device, *shape, fill=0.0, dtype=BF16):
+    return nn.Parameter(torch.full(shape, fill, device=device, dtype=dtype), requires_grad=False)
 
 
 class LinearP(nn.Module):
@@ -94,10 +96,13 @@ class LinearP(nn.Module):
 
 
 class LayerNormP(nn.Module):
+    """torch.nn.LayerNorm's parameters; fp32 by default (ops.NORM_DTYPE: not matrix operands, see crab_amd/ops.py), so a checkpoint's fp32
+    weight / bias load unrounded."""
+
     def __init__(self, dim: int, eps: float, device):
         super().__init__()
-        self.weight = _p(None, device, dim, fill=1.0)
-        self.bias = _p(None, device, dim)
+        self.weight = _p(None, device, dim, fill=1.0, dtype=ops.NORM_DTYPE)
+        self.bias = _p(None, device, dim, dtype=ops.NORM_DTYPE)
         self.eps = eps
 
     def forward(self, x, out=None):
@@ -731,7 +736,7 @@ class AudioEncoder(nn.Module):
         bc.encoder_layerdrop = 0.
         self.audio_encoder = BEATs(bc, device=device)
         if model_sd is not None:
-            self.audio_encoder.load_state_dict({k: v.to(BF16) for k, v in model_sd.items()}, strict=False)
+            self.audio_encoder.load_state_dict(model_sd, strict=False)       # copy_ casts to each parameter's storage (LayerNorm: fp32)
 
     @torch.no_grad()
     def encode_audio(self, audio):

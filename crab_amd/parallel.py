@@ -33,7 +33,10 @@ def gather_results(ids: torch.Tensor, clip0: int, world: int, rank: int, logits:
     logits [sum B, V] or None) ordered by clip id; other ranks return None.  B may DIFFER between ranks (a clip count the world size does
     not divide; a rank may even hold zero clips): every rank pads its records to the largest B (one all_reduce(MAX) of a single word) with
     clip id -1 and rank 0 drops the padding, so the gather itself stays a fixed-size `dist.gather` per payload (RCCL: one peer->root
-    transfer per rank over its own xGMI link)."""
+    transfer per rank over its own xGMI link).  The SEQUENCE of collectives is the same on every rank whatever it holds: one all_reduce
+    reconciles {largest B, whether anyone carries logits, n_new, V}; a rank without clips may pass `logits=None` (or ids of width 0) and
+    takes the widths of the others, a rank WITH clips whose n_new / V / logits-presence disagrees with another's raises on every rank alike
+    (before the first gather, so nobody hangs in a mismatched collective)."""
     B = ids.shape[0]
     cid = torch.arange(clip0, clip0 + B, device=ids.device, dtype=torch.int64)
     import torch.distributed as dist
@@ -42,9 +45,24 @@ def gather_results(ids: torch.Tensor, clip0: int, world: int, rank: int, logits:
     if dist.get_backend() == "gloo":                      # CPU tests / one-GPU rehearsals: gloo gathers host tensors
         ids, cid = ids.cpu(), cid.cpu()
         logits = logits.cpu() if logits is not None else None
-    bmax = torch.tensor([B], device=ids.device, dtype=torch.int64)
-    dist.all_reduce(bmax, op=dist.ReduceOp.MAX)
-    Bm = int(bmax.item())
+    # one word vector, reduced with MAX: [B, has_logits, n_new, V, -n_new, -V, -has_logits] - the negated entries give the MIN over the ranks
+    # that hold clips (a rank without clips contributes the identity of both)
+    BIG = 1 << 40
+    has = 1 if logits is not None else 0
+    nn_, vv = int(ids.shape[1]), (int(logits.shape[1]) if logits is not None else 0)
+    if B > 0:
+        words = [B, has, nn_, vv, -nn_, (-vv if has else -BIG), -has]      # V only constrains ranks that carry logits
+    else:
+        words = [0, 0, 0, 0, -BIG, -BIG, -1]
+    w = torch.tensor(words, device=ids.device, dtype=torch.int64)
+    dist.all_reduce(w, op=dist.ReduceOp.MAX)
+    Bm, any_logits, n_max, v_max, n_min, v_min, all_logits = int(w[0]), int(w[1]), int(w[2]), int(w[3]), -int(w[4]), -int(w[5]), -int(w[6])
+    if Bm > 0 and (n_min != n_max or (any_logits and (all_logits != 1 or (v_min != v_max and v_min < BIG)))):
+        raise ValueError(f"gather_results: ranks disagree on the record (n_new {n_min}..{n_max}, logits on some ranks only: {all_logits != any_logits}, "
+                         f"V {v_min}..{v_max}): every rank that holds clips must pass the same n_new, and logits either everywhere or nowhere")
+    if B == 0:                                            # nothing to send: take the record widths of the others
+        ids = torch.empty((0, n_max), device=ids.device, dtype=torch.int64)
+        logits = torch.empty((0, v_max), device=ids.device, dtype=torch.float32) if any_logits else None
     rec = torch.cat([cid[:, None], ids.to(torch.int64)], dim=1)
     if B < Bm:                                            # uneven shard: pad with clip id -1 (dropped on rank 0)
         rec = torch.cat([rec, torch.full((Bm - B, rec.shape[1]), -1, device=rec.device, dtype=torch.int64)], 0)

@@ -51,9 +51,10 @@ static crab_dense next_dense(int N, int K) {
     return d;
 }
 
+/* LayerNorm parameters travel in fp32 (crab_ln.fp32 = 1, ABI 9), as crab_amd's encoder modules hold them: they are not matrix operands */
 static crab_ln next_ln(int n, float eps) {
     crab_ln l;
-    l.w = next_bf16((size_t)n); l.b = next_bf16((size_t)n); l.eps = eps;
+    l.w = next_raw((size_t)n * 4); l.b = next_raw((size_t)n * 4); l.eps = eps; l.fp32 = 1;
     return l;
 }
 
@@ -93,9 +94,9 @@ static projector load_projector(int enc_w, int hq, int Hhq, int iq, int Lq, int 
 static void* run_projector(hipStream_t s, const projector* p, const void* feat, int B, int m, int enc_w, int hq, int iq, int Lq, int nq, int D, int Hhq) {
     const int Menc = B * m, M = B * nq, rows = Menc > M ? Menc : M;
     void* enc = dev_alloc((size_t)Menc * enc_w * 2);
-    CRAB_OK_(crab_layernorm(ctx, s, feat, enc_w, p->in_ln.w, p->in_ln.b, enc, enc_w, Menc, enc_w, p->in_ln.eps));
+    CRAB_OK_(crab_layernorm_p(ctx, s, feat, 0, enc_w, p->in_ln.w, p->in_ln.b, p->in_ln.fp32, enc, enc_w, Menc, enc_w, p->in_ln.eps));
     void* z0 = dev_alloc((size_t)nq * hq * 2);
-    CRAB_OK_(crab_layernorm(ctx, s, p->query, hq, p->emb_ln.w, p->emb_ln.b, z0, hq, nq, hq, p->emb_ln.eps));
+    CRAB_OK_(crab_layernorm_p(ctx, s, p->query, 0, hq, p->emb_ln.w, p->emb_ln.b, p->emb_ln.fp32, z0, hq, nq, hq, p->emb_ln.eps));
     void* z = z0;
     if (B > 1) {                                          /* the learned query tokens, broadcast to every block */
         z = dev_alloc((size_t)M * hq * 2);
@@ -164,7 +165,7 @@ int main(int argc, char** argv) {
     void* pe = dev_alloc((size_t)Tv * Pn * Dc * 2);
     gemm(s, patches, Kp, &patch_w, pe, Dc, Tv * Pn, CRAB_ACT_NONE);                                  /* conv14/14, no bias */
     void* hc = dev_alloc((size_t)Mv * Dc * 2);
-    CRAB_OK_(crab_clip_embed_ln(ctx, s, pe, cls, pos, pre_ln.w, pre_ln.b, hc, Tv, Pn, Dc, pre_ln.eps));
+    CRAB_OK_(crab_clip_embed_ln_p(ctx, s, pe, cls, pos, pre_ln.w, pre_ln.b, pre_ln.fp32, hc, Tv, Pn, Dc, pre_ln.eps));
     {
         crab_enc_io io;
         memset(&io, 0, sizeof(io));
@@ -212,7 +213,7 @@ int main(int argc, char** argv) {
     void* af = dev_alloc((size_t)Ma * emb * 2);
     gemm(s, apatch, Pb * Pb, &bpatch, af, emb, Ma, CRAB_ACT_NONE);
     void* ax0 = dev_alloc((size_t)Ma * emb * 2);
-    CRAB_OK_(crab_layernorm(ctx, s, af, emb, b_ln.w, b_ln.b, ax0, emb, Ma, emb, b_ln.eps));
+    CRAB_OK_(crab_layernorm_p(ctx, s, af, 0, emb, b_ln.w, b_ln.b, b_ln.fp32, ax0, emb, Ma, emb, b_ln.eps));
     void* ax = dev_alloc((size_t)Ma * E * 2);
     gemm(s, ax0, emb, &post, ax, E, Ma, CRAB_ACT_NONE);
     void* xp = dev_alloc((size_t)G * Ta * npad * cg * 2);                                            /* x + gelu(pos_conv(x)): sliding-window GEMM */
@@ -230,7 +231,7 @@ int main(int argc, char** argv) {
         CRAB_OK_(crab_gemm_bf16(ctx, s, &g));
     }
     void* bx = dev_alloc((size_t)Ma * E * 2);
-    CRAB_OK_(crab_layernorm_f32(ctx, s, (const float*)ay, E, enc_ln.w, enc_ln.b, bx, E, Ma, E, enc_ln.eps));
+    CRAB_OK_(crab_layernorm_p(ctx, s, ay, 1, E, enc_ln.w, enc_ln.b, enc_ln.fp32, bx, E, Ma, E, enc_ln.eps));
     float* relb = (float*)dev_alloc((size_t)Hb * n * n * 4);
     CRAB_OK_(crab_beats_relpos_bias(ctx, s, table, relb, n, Hb, c[C_BUCKETS], c[C_MAXDIST]));
     {

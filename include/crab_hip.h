@@ -128,6 +128,8 @@ typedef struct {
  * the weights are read once per call whatever M; crab_llama_layers / crab_amd/decoder.py fuse the routers and norms into the reductions up
  * to the same bound.  256 until r03; 512 since r04 (two 256-row groups per launch sharing each weight panel through an XCD's L2). */
 #define CRAB_DECODE_MAX_ROWS 512
+int crab_decode_max_rows(void);   /* the value compiled into the library (bindings check their mirror of the macro against it) */
+int crab_attn_split_below(void);  /* likewise for CRAB_ATTN_SPLIT_BELOW */
 int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc* d);
 int crab_gemm_fuses_prefill_rope(const crab_gemm_desc* d);   /* 0: no; 1: this call rotates q / k and appends k in its epilogue (see rope_S); 2: and handles the v columns (rope_vt) */
 /* bytes of crab_gemm_desc.workspace the M <= 16 layer tail needs (fp32 sums + router product + per-slice partials) */
@@ -166,6 +168,12 @@ int crab_rmsnorm_f32(crab_ctx* ctx, void* stream, const float* x, int64_t ldx, c
                      int M, int D, float eps);
 int crab_layernorm_f32(crab_ctx* ctx, void* stream, const float* x, int64_t ldx, const void* w, const void* b, void* y,
                        int64_t ldy, int M, int D, float eps);
+/* LayerNorm with the storage of both the input row (x_fp32) and the PARAMETERS (w_fp32: w and b are fp32 [D], 16-byte aligned) stated by the
+ * caller (ABI 9).  The LayerNorm weights / biases of the encoders are not matrix operands: kept in fp32 they cost 4 KB per norm and remove a
+ * systematic 2^-9 relative error from every channel of every LayerNorm output (the encoder features move from 2x to 1.2x the
+ * bf16-operand floor).  y is bf16. */
+int crab_layernorm_p(crab_ctx* ctx, void* stream, const void* x, int x_fp32, int64_t ldx, const void* w, const void* b, int w_fp32, void* y,
+                     int64_t ldy, int M, int D, float eps);
 
 /* out[t,:] = table[ids[t],:]  (embed_tokens; unified_arch.py:213-214, unified_llama.py:125-127).  Rows with ids[t] < 0 are
  * left untouched (the multimodal splice fills them with projector features, unified_arch.py:283-300); ids >= vocab clamp. */
@@ -279,6 +287,9 @@ int crab_im2col_patch(crab_ctx* ctx, void* stream, const void* in, int in_fp32, 
 /* CLIP token assembly + pre_layrnorm: x[n,0]=cls+pos[0], x[n,1+p]=patch[n,p]+pos[1+p]; y = LN(x) */
 int crab_clip_embed_ln(crab_ctx* ctx, void* stream, const void* patch, const void* cls, const void* pos, const void* lnw,
                        const void* lnb, void* y, int N, int P, int D, float eps);
+/* the same with pre_layrnorm's weight / bias in fp32 when ln_fp32 != 0 (ABI 9) */
+int crab_clip_embed_ln_p(crab_ctx* ctx, void* stream, const void* patch, const void* cls, const void* pos, const void* lnw,
+                         const void* lnb, int ln_fp32, void* y, int N, int P, int D, float eps);
 
 /* BEATs helpers (models/beats/backbone.py):
  *  posconv_pad: x[B,n,E] -> xp[G][B][n+Kc-1][E/G] zero padded (Kc/2 in front), the sliding-window GEMM operand
@@ -402,12 +413,12 @@ int crab_llama_layers(crab_ctx* ctx, void* stream, const crab_llama_layer* layer
  *                      io->gate [B, H, S] fp32 scratch for crab_beats_gru_gate; grep_w == NULL: no gate
  *   crab_qformer_layer models/Qformer.py:404-476 with cross_attention_freq = 1 and the query FFN (:483-486): x = the B * S query rows,
  *                      io->enc = the B * enc_rows encoder rows (already layer-normed by the projector, multimodal_encoder.py:119-144, 226-244)
- * crab_dense = one nn.Linear (W [N, K] row stride ldw, bias [N] or NULL); crab_ln = LayerNorm weight / bias / eps.
+ * crab_dense = one nn.Linear (W [N, K] row stride ldw, bias [N] or NULL); crab_ln = LayerNorm weight / bias / eps (+ fp32: the parameters are fp32).
  * crab_enc_io: caller-owned rows for M = B * S tokens.  x [M, width] in / out (dense rows); a [M, width], y [M, width] scratch;
  *   qkv [max(M, B * enc_rows), 3 * width (2 * width for the Q-Former)]; att [M, width]; f [M, ffn width];
  *   vt: V^T scratch of vt_bytes >= B * H * d * round8(keys) * 2; workspace: the crab_gemm_desc.workspace handed to every GEMM with <= CRAB_DECODE_MAX_ROWS rows. */
 typedef struct { const void* W; const void* bias; int64_t ldw; int32_t N, K; } crab_dense;
-typedef struct { const void* w; const void* b; float eps; } crab_ln;
+typedef struct { const void* w; const void* b; float eps; int32_t fp32; /* ABI 9: w and b are fp32 [D] (0: bf16) */ } crab_ln;
 typedef struct { crab_ln ln1, ln2; crab_dense qkv, out, fc1, fc2; int32_t H; } crab_clip_layer_w;
 typedef struct { crab_dense qkv, out, fc1, fc2; crab_ln ln_attn, ln_final; const void* grep_w; const void* grep_b; const void* grep_a; int32_t H; float alpha; } crab_beats_layer_w;
 typedef struct { crab_dense sq, skv, so; crab_ln sln; crab_dense cq, ckv, co; crab_ln cln; crab_dense iq, oq; crab_ln oln; int32_t H; } crab_qformer_layer_w;

@@ -16,6 +16,12 @@ reference runs on transformers 5.15 here instead of the pinned 4.37.2, see SURVE
 All weights are addressed by the reference's own state-dict key names (minus PEFT's
 `base_model.model.` prefix), so a `finetune_weights.bin`-style dict drives the oracle directly.
 
+Device: the functions are plain PyTorch and run wherever their inputs live.  The fixtures, bench.py's cpu_baseline and most tests run them
+on the HOST (fp32 eager).  The decoder functions create their index tensors on the input's device, so the three full-depth tests of
+tests/test_fullsize_gpu.py may hand in weights and embeddings that sit on the GPU (torch's own fp32 kernels, TF32 off): the same fp32
+arithmetic up to summation order (tests/test_fullsize_gpu.py::test_oracle_on_the_gpu_equals_the_oracle_on_the_host pins the two to 2e-5)
+in seconds instead of minutes of host time that varied 2.5x between GPU boxes (profiles/README.md r05).
+
 `emulate` argument: when a torch dtype (bf16) is given, activations are rounded to that dtype at the
 same points where the HIP path stores bf16 tensors (GEMM outputs, norm outputs, attention output),
 with all inner arithmetic in fp32.  emulate=None is the exact fp32 path of the reference as shipped
@@ -34,11 +40,46 @@ Tensor = torch.Tensor
 WDict = Dict[str, Tensor]
 
 
-def _r(x: Tensor, emulate) -> Tensor:
-    """Round-trip through the emulated storage dtype (identity when emulate is None)."""
-    if emulate is None:
+class OperandRounding:
+    """emulate=OPERANDS: the bf16-OPERAND FLOOR of any MFMA implementation of this path.  Only what a matrix instruction consumes is rounded,
+    once, at the point of consumption: the weights, the input rows of every linear layer / convolution (incl. the routed rank-r activations
+    `u` of the hyper-LoRA update) and the attention operands q (after RoPE), k (after RoPE) and v.  Everything else - residual streams, norm
+    statistics and outputs as residual terms, pre-rotation q / k, softmax probabilities, GEMM outputs that are not themselves operands -
+    stays fp32.  No storage format can do better with bf16 matrix operands, so max|floor - fp32| is the part of a measured HIP error that is
+    irreducible; the distance between the floor and the storage emulation (emulate=torch.bfloat16) is what removable storage points cost."""
+
+    def __init__(self, dtype=torch.bfloat16):
+        self.dtype = dtype
+
+
+OPERANDS = OperandRounding()
+
+
+# Storage points (by tag) that the storage emulation treats as fp32: the ablation switch of scripts/parity_floor.py (which storage point costs
+# what) and the place a storage point REMOVED from the HIP path is recorded.  Tags: "ln" (LayerNorm outputs of the post-LN encoders, which are
+# residual terms as well as operands), "p" (softmax probabilities), "embed" (patch / position embedding sums), "kept" (CLIP hidden states
+# handed to the projector), "out" (projector outputs).
+STORAGE_FP32: set = set()
+
+
+def _r(x: Tensor, emulate, tag: Optional[str] = None) -> Tensor:
+    """A STORAGE point of the HIP path: round-trip through the emulated storage dtype (identity for emulate=None and for the operand floor)."""
+    if emulate is None or isinstance(emulate, OperandRounding) or (tag is not None and tag in STORAGE_FP32):
         return x
     return x.to(emulate).to(torch.float32)
+
+
+def _op(x: Tensor, emulate) -> Tensor:
+    """A matrix OPERAND at its point of consumption: rounded to bf16 in both emulation modes (idempotent in the storage emulation wherever the
+    producer already rounded it where the HIP path stores it; emulate=None is exact)."""
+    if emulate is None:
+        return x
+    return x.to(emulate.dtype if isinstance(emulate, OperandRounding) else emulate).to(torch.float32)
+
+
+def _ro(x: Tensor, emulate) -> Tensor:
+    """Both a storage point and an operand (rotated q / k, the routed activations u): rounded once in either emulation mode."""
+    return _op(_r(x, emulate), emulate)
 
 
 # With emulate=bfloat16: the RESIDUAL STREAM (decoder x, CLIP tower x) stays fp32 and RMSNorm's x_hat is not rounded before the
@@ -78,27 +119,35 @@ def strip_peft_prefix(sd: WDict) -> WDict:
 # B.1 hyper-LoRA Linear                       reference peft_hyper/tuners/lora.py:338-350
 # =====================================================================================
 
-def linear(x: Tensor, W: WDict, prefix: str, emulate=None) -> Tensor:
+def linear(x: Tensor, W: WDict, prefix: str, emulate=None, store: bool = True) -> Tensor:
+    """store=False: the output is not a storage point of the HIP path (consumed inside a fused epilogue in fp32)."""
     w = W[prefix + ".weight"]
     b = W.get(prefix + ".bias")
-    return _r(F.linear(x, w, b), emulate)
+    y = F.linear(_op(x, emulate), _op(w, emulate), b)
+    return _r(y, emulate) if store else y
 
 
 def hyperlora_linear(x: Tensor, W: WDict, prefix: str, scaling: float = 2.0, lora_nums: int = 3,
-                     emulate=None) -> Tensor:
+                     emulate=None, store: bool = True) -> Tensor:
     """y = x W^T (+b) + sum_i softmax_fp32(x R^T)_i * (B_i (A x)) * scaling   (lora.py:341-350).
 
-    Falls back to a plain Linear when the prefix carries no lora_A (module not wrapped)."""
+    Falls back to a plain Linear when the prefix carries no lora_A (module not wrapped).
+    Emulation: the routed activations u_i = scaling * softmax_i * (A x) are an operand of the K-extended GEMM of the HIP path (bf16 `u`,
+    crab_hyperlora_mix), so they are rounded once in both emulation modes; in fp32 the order of the scalar factors is the reference's."""
     w = W[prefix + ".weight"]
     b = W.get(prefix + ".bias")
-    y = F.linear(x, w, b)
+    xo = _op(x, emulate)
+    y = F.linear(xo, _op(w, emulate), b)
     if (prefix + ".lora_A.weight") not in W:
-        return _r(y, emulate)
-    route = torch.softmax(F.linear(x, W[prefix + ".lora_route.weight"]).float(), dim=-1)   # lora.py:346
-    h = F.linear(x, W[prefix + ".lora_A.weight"])                                          # lora.py:349
+        return _r(y, emulate) if store else y
+    route = torch.softmax(F.linear(xo, _op(W[prefix + ".lora_route.weight"], emulate)).float(), dim=-1)   # lora.py:346
+    h = F.linear(xo, _op(W[prefix + ".lora_A.weight"], emulate))                                          # lora.py:349
     for i in range(lora_nums):
-        y = y + route[..., i:i + 1] * F.linear(h, W[prefix + f".lora_B{i}.weight"]) * scaling
-    return _r(y, emulate)
+        if emulate is None:
+            y = y + route[..., i:i + 1] * F.linear(h, W[prefix + f".lora_B{i}.weight"]) * scaling
+        else:
+            y = y + F.linear(_ro(route[..., i:i + 1] * h * scaling, emulate), _op(W[prefix + f".lora_B{i}.weight"], emulate))
+    return _r(y, emulate) if store else y
 
 
 # =====================================================================================
@@ -149,7 +198,7 @@ def rmsnorm(x: Tensor, w: Tensor, eps: float, emulate=None) -> Tensor:
 
 def rope_cos_sin(positions: Tensor, head_dim: int, theta: float) -> Tuple[Tensor, Tensor]:
     """modeling_llama.py:130-156: inv_freq_i = theta^(-2i/d); emb = cat(freqs, freqs)."""
-    inv = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float32) / head_dim))
+    inv = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float32, device=positions.device) / head_dim))
     fr = positions.float()[..., None] * inv            # [..., d/2]
     emb = torch.cat([fr, fr], dim=-1)
     return emb.cos(), emb.sin()
@@ -194,7 +243,7 @@ def decoder_layer(x: Tensor, W: WDict, i: int, cfg: DecoderConfig, cache: KVCach
     v = hyperlora_linear(h, W, p + ".self_attn.v_proj", sc, ln, emulate).view(b, s, Hk, d).transpose(1, 2)
     cos, sin = rope_cos_sin(positions, d, cfg.rope_theta)
     q, k = apply_rope(q, k, cos, sin)
-    q, k = _r(q, emulate), _r(k, emulate)
+    q, k, v = _ro(q, emulate), _ro(k, emulate), _op(v, emulate)             # the attention operands (k / v as the cache holds them)
     while len(cache.k) <= i:
         cache.k.append(None)
         cache.v.append(None)
@@ -211,21 +260,21 @@ def decoder_layer(x: Tensor, W: WDict, i: int, cfg: DecoderConfig, cache: KVCach
         vv = vv[:, :, None].expand(b, Hk, g, t, d).reshape(b, H, t, d)
     a = torch.matmul(q, kk.transpose(2, 3)) / math.sqrt(d)                    # :417
     # causal mask: query row r (absolute index t-s+r) sees keys 0..t-s+r       (:420-428)
-    qi = torch.arange(t - s, t)[:, None]
-    kj = torch.arange(t)[None, :]
+    qi = torch.arange(t - s, t, device=x.device)[:, None]
+    kj = torch.arange(t, device=x.device)[None, :]
     a = a.masked_fill((kj > qi)[None, None], torch.finfo(torch.float32).min)
     if key_mask is not None:
         a = a.masked_fill((key_mask[:, None, None, :t] == 0), torch.finfo(torch.float32).min)
     pr = torch.softmax(a.float(), dim=-1)                                      # :431 fp32 softmax
     o = torch.matmul(_r(pr, emulate), vv).transpose(1, 2).reshape(b, s, H * d)
     o = _r(o, emulate)
-    x = _rres(x + hyperlora_linear(o, W, p + ".self_attn.o_proj", sc, ln, None), emulate)
+    x = _rres(x + hyperlora_linear(o, W, p + ".self_attn.o_proj", sc, ln, emulate, store=False), emulate)
 
     h = rmsnorm(x, W[p + ".post_attention_layernorm.weight"], cfg.rms_norm_eps, emulate)
-    g_ = hyperlora_linear(h, W, p + ".mlp.gate_proj", sc, ln, None)
-    u_ = hyperlora_linear(h, W, p + ".mlp.up_proj", sc, ln, None)
+    g_ = hyperlora_linear(h, W, p + ".mlp.gate_proj", sc, ln, emulate, store=False)
+    u_ = hyperlora_linear(h, W, p + ".mlp.up_proj", sc, ln, emulate, store=False)
     m = _r(F.silu(g_) * u_, emulate)                                           # :269
-    x = _rres(x + hyperlora_linear(m, W, p + ".mlp.down_proj", sc, ln, None), emulate)
+    x = _rres(x + hyperlora_linear(m, W, p + ".mlp.down_proj", sc, ln, emulate, store=False), emulate)
     return x
 
 
@@ -239,13 +288,13 @@ def decoder_forward(embeds: Tensor, W: WDict, cfg: DecoderConfig, cache: Optiona
     cache = cache if cache is not None else KVCache()
     past = cache.length()
     if positions is None:
-        positions = torch.arange(past, past + s)[None].expand(b, s)
+        positions = torch.arange(past, past + s, device=embeds.device)[None].expand(b, s)
     x = _r(embeds.float(), emulate)
     for i in range(cfg.num_hidden_layers):
         x = decoder_layer(x, W, i, cfg, cache, positions, emulate, key_mask=attention_mask)
     hn = rmsnorm(x, W["model.norm.weight"], cfg.rms_norm_eps, emulate)
     hh = hn[:, -1:] if last_only else hn
-    logits = F.linear(hh, W["lm_head.weight"]).float()
+    logits = F.linear(_op(hh, emulate), _op(W["lm_head.weight"], emulate)).float()
     return logits, hn, cache
 
 
@@ -259,7 +308,7 @@ def greedy_generate(embeds: Tensor, W: WDict, cfg: DecoderConfig, max_new_tokens
     cache = KVCache()
     logits, hn, cache = decoder_forward(embeds, W, cfg, cache, last_only=True, emulate=emulate)
     ids, step_logits, hiddens = [], [], []
-    unfinished = torch.ones(b, dtype=torch.bool)
+    unfinished = torch.ones(b, dtype=torch.bool, device=embeds.device)
     pad = pad_token_id if pad_token_id is not None else (eos_token_id if eos_token_id is not None else 0)
     for step in range(max_new_tokens):
         lg = logits[:, -1].clone()
@@ -324,9 +373,9 @@ class ClipConfig:
         return (self.image_size // self.patch_size) ** 2
 
 
-def layernorm(x: Tensor, W: WDict, prefix: str, eps: float, emulate=None) -> Tensor:
+def layernorm(x: Tensor, W: WDict, prefix: str, eps: float, emulate=None, tag: Optional[str] = "ln") -> Tensor:
     return _r(F.layer_norm(x.float(), (x.shape[-1],), W[prefix + ".weight"].float(), W[prefix + ".bias"].float(), eps),
-              emulate)
+              emulate, tag)
 
 
 def _mha(q: Tensor, k: Tensor, v: Tensor, heads: int, scale: float, bias: Optional[Tensor] = None,
@@ -335,13 +384,13 @@ def _mha(q: Tensor, k: Tensor, v: Tensor, heads: int, scale: float, bias: Option
     b, n, D = q.shape
     m = k.shape[1]
     d = D // heads
-    qh = q.view(b, n, heads, d).transpose(1, 2)
-    kh = k.view(b, m, heads, d).transpose(1, 2)
-    vh = v.view(b, m, heads, d).transpose(1, 2)
+    qh = _op(q, emulate).view(b, n, heads, d).transpose(1, 2)
+    kh = _op(k, emulate).view(b, m, heads, d).transpose(1, 2)
+    vh = _op(v, emulate).view(b, m, heads, d).transpose(1, 2)
     a = torch.matmul(qh, kh.transpose(2, 3)) * scale
     if bias is not None:
         a = a + bias
-    p = _r(torch.softmax(a.float(), dim=-1), emulate)
+    p = _r(torch.softmax(a.float(), dim=-1), emulate, "p")
     o = torch.matmul(p, vh).transpose(1, 2).reshape(b, n, D)
     return _r(o, emulate)
 
@@ -354,12 +403,12 @@ def clip_vision(pixels: Tensor, W: WDict, cfg: ClipConfig, prefix: str = "model.
     N = pixels.shape[0]
     ps = cfg.patch_size
     w = W[prefix + ".embeddings.patch_embedding.weight"]
-    x = F.conv2d(pixels.float(), w, None, stride=ps)                     # [N,D,g,g], no bias
-    x = _r(x.flatten(2).transpose(1, 2), emulate)                        # [N,P,D]
+    x = F.conv2d(_op(pixels.float(), emulate), _op(w, emulate), None, stride=ps)   # [N,D,g,g], no bias
+    x = _r(x.flatten(2).transpose(1, 2), emulate, "embed")               # [N,P,D]
     cls = W[prefix + ".embeddings.class_embedding"].float().expand(N, 1, -1)
     x = torch.cat([cls, x], dim=1) + W[prefix + ".embeddings.position_embedding.weight"].float()[None]
-    x = _r(x, emulate)
-    h = layernorm(x, W, prefix + ".pre_layrnorm", cfg.layer_norm_eps, emulate)
+    # (the sum [cls | patches] + positions feeds pre_layrnorm unrounded: clip_embed_ln_kernel, r05)
+    h = layernorm(x, W, prefix + ".pre_layrnorm", cfg.layer_norm_eps, emulate, "embed")
     hs = [h]
     H = cfg.num_attention_heads
     d = cfg.hidden_size // H
@@ -371,12 +420,12 @@ def clip_vision(pixels: Tensor, W: WDict, cfg: ClipConfig, prefix: str = "model.
         k = linear(a, W, p + ".self_attn.k_proj", emulate)
         v = linear(a, W, p + ".self_attn.v_proj", emulate)
         o = _mha(q, k, v, H, d ** -0.5, None, emulate)
-        h = _rres(h + linear(o, W, p + ".self_attn.out_proj", None), emulate)
+        h = _rres(h + linear(o, W, p + ".self_attn.out_proj", emulate, store=False), emulate)
         a = layernorm(h, W, p + ".layer_norm2", cfg.layer_norm_eps, emulate)
-        f1 = linear(a, W, p + ".mlp.fc1", None)
+        f1 = linear(a, W, p + ".mlp.fc1", emulate, store=False)
         f1 = _r(f1 * torch.sigmoid(1.702 * f1), emulate)                 # quick_gelu
-        h = _rres(h + linear(f1, W, p + ".mlp.fc2", None), emulate)
-        hs.append(_r(h, emulate))                                        # the kept states are bf16 (what the projectors read)
+        h = _rres(h + linear(f1, W, p + ".mlp.fc2", emulate, store=False), emulate)
+        hs.append(_r(h, emulate, "kept"))                                # the kept states are bf16 (what the projectors read)
     return hs
 
 
@@ -424,18 +473,18 @@ def qformer(query: Tensor, enc: Tensor, W: WDict, prefix: str, cfg: QFormerConfi
         k = linear(z, W, p + ".attention.self.key", emulate)
         v = linear(z, W, p + ".attention.self.value", emulate)
         c = _mha(q, k, v, H, 1.0 / math.sqrt(d), None, emulate)
-        z = layernorm(linear(c, W, p + ".attention.output.dense", None) + z, W, p + ".attention.output.LayerNorm",
+        z = layernorm(linear(c, W, p + ".attention.output.dense", emulate, store=False) + z, W, p + ".attention.output.LayerNorm",
                       eps, emulate)                                                    # :287-291
         # cross attention every layer (cross_attention_freq=1)
         q = linear(z, W, p + ".crossattention.self.query", emulate)
         k = linear(enc, W, p + ".crossattention.self.key", emulate)
         v = linear(enc, W, p + ".crossattention.self.value", emulate)
         c = _mha(q, k, v, H, 1.0 / math.sqrt(d), None, emulate)
-        z = layernorm(linear(c, W, p + ".crossattention.output.dense", None) + z, W,
+        z = layernorm(linear(c, W, p + ".crossattention.output.dense", emulate, store=False) + z, W,
                       p + ".crossattention.output.LayerNorm", eps, emulate)
         # query FFN (:483-486)
-        f = _r(_gelu(linear(z, W, p + ".intermediate_query.dense", None)), emulate)
-        z = layernorm(linear(f, W, p + ".output_query.dense", None) + z, W, p + ".output_query.LayerNorm", eps,
+        f = _r(_gelu(linear(z, W, p + ".intermediate_query.dense", emulate, store=False)), emulate)
+        z = layernorm(linear(f, W, p + ".output_query.dense", emulate, store=False) + z, W, p + ".output_query.LayerNorm", eps,
                       emulate)
     return z
 
@@ -449,7 +498,7 @@ def vl_projector(feat: Tensor, W: WDict, cfg: QFormerConfig, image_token_nums: i
     x = layernorm(x, W, prefix + ".visual_ln", 1e-5, emulate)
     qt = W[prefix + ".visual_query_tokens"].float().expand(b * t, -1, -1)
     z = qformer(qt, x, W, prefix + ".visual_Qformer.bert", cfg, emulate)[:, :cfg.num_query_token]
-    y = _r(_gelu(linear(z, W, prefix + ".visual_proj.0", None)), emulate)
+    y = _r(_gelu(linear(z, W, prefix + ".visual_proj.0", emulate, store=False)), emulate)
     y = linear(y, W, prefix + ".visual_proj.2", emulate)
     return y.reshape(b, t * cfg.num_query_token, -1)
 
@@ -462,7 +511,7 @@ def al_projector(feat: Tensor, W: WDict, cfg: QFormerConfig, prefix: str = "mode
     qt = W[prefix + ".audio_query_tokens"].float().expand(b * t, -1, -1)
     z = qformer(qt, x, W, prefix + ".audio_Qformer.bert", cfg, emulate)[:, :cfg.num_query_token]
     z = z.reshape(b, t * cfg.num_query_token, -1)
-    y = _r(_gelu(linear(z, W, prefix + ".audio_proj.0", None)), emulate)
+    y = _r(_gelu(linear(z, W, prefix + ".audio_proj.0", emulate, store=False)), emulate)
     return linear(y, W, prefix + ".audio_proj.2", emulate)
 
 
@@ -512,9 +561,9 @@ def beats(fbank: Tensor, W: WDict, cfg: BeatsConfig, prefix: str = "model.audio_
     E = cfg.encoder_embed_dim
     H = cfg.encoder_attention_heads
     d = E // H
-    x = F.conv2d(fbank.float()[:, None], W[prefix + ".patch_embedding.weight"],
+    x = F.conv2d(_op(fbank.float()[:, None], emulate), _op(W[prefix + ".patch_embedding.weight"], emulate),
                  W.get(prefix + ".patch_embedding.bias"), stride=P)                     # [B,512,L/16,8]
-    x = _r(x.reshape(B, x.shape[1], -1).transpose(1, 2), emulate)                       # time-major tokens
+    x = _r(x.reshape(B, x.shape[1], -1).transpose(1, 2), emulate, "embed")              # time-major tokens
     x = layernorm(x, W, prefix + ".layer_norm", cfg.layer_norm_eps, emulate)
     if (prefix + ".post_extract_proj.weight") in W:
         x = linear(x, W, prefix + ".post_extract_proj", emulate)
@@ -523,7 +572,7 @@ def beats(fbank: Tensor, W: WDict, cfg: BeatsConfig, prefix: str = "model.audio_
     # pos_conv: weight-normed grouped Conv1d + SamePad + GELU (backbone.py:33-46,114-116)
     g_, v_ = W[e + ".pos_conv.0.weight_g"].float(), W[e + ".pos_conv.0.weight_v"].float()
     wn = g_ * v_ / v_.norm(p=2, dim=(0, 1), keepdim=True)                               # weight_norm dim=2
-    pc = F.conv1d(x.transpose(1, 2), wn, W[e + ".pos_conv.0.bias"].float(), padding=cfg.conv_pos // 2,
+    pc = F.conv1d(_op(x, emulate).transpose(1, 2), _op(wn, emulate), W[e + ".pos_conv.0.bias"].float(), padding=cfg.conv_pos // 2,
                   groups=cfg.conv_pos_groups)
     if cfg.conv_pos % 2 == 0:
         pc = pc[:, :, :-1]
@@ -549,10 +598,10 @@ def beats(fbank: Tensor, W: WDict, cfg: BeatsConfig, prefix: str = "model.audio_
             bias = gate * pos_bias[None]
         # (q*scaling/32 k^T - max)*32 + bias == q k^T scaling + bias up to a per-row shift (:513-515,623-667)
         o = _mha(q0, k, v, H, scaling, bias, emulate)
-        a = linear(o, W, p + ".self_attn.out_proj", None)
+        a = linear(o, W, p + ".self_attn.out_proj", emulate, store=False)
         x = layernorm(x * alpha + a, W, p + ".self_attn_layer_norm", cfg.layer_norm_eps, emulate)
-        f = _r(_gelu(linear(x, W, p + ".fc1", None)), emulate)
-        f = linear(f, W, p + ".fc2", None)
+        f = _r(_gelu(linear(x, W, p + ".fc1", emulate, store=False)), emulate)
+        f = linear(f, W, p + ".fc2", emulate, store=False)
         x = layernorm(x * alpha + f, W, p + ".final_layer_norm", cfg.layer_norm_eps, emulate)
     return x
 

@@ -10,6 +10,8 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box via gpurun)")
+    config.addinivalue_line("markers", "gpu_slow: long GPU soaks kept OUT of `-m gpu` (the driver's suite has a time limit): run by hand with "
+                                       "`pytest -m gpu_slow` on a GPU box (tests/test_slow_gpu.py)")
 
 
 def pytest_collection_modifyitems(config, items):
@@ -18,7 +20,7 @@ def pytest_collection_modifyitems(config, items):
         return
     skip = pytest.mark.skip(reason="no GPU in this container")
     for it in items:
-        if "gpu" in it.keywords:
+        if "gpu" in it.keywords or "gpu_slow" in it.keywords:
             it.add_marker(skip)
 
 

@@ -9,6 +9,7 @@
   fuzz_rope_epilogue.py  the RoPE / KV-append fusions of the q|k|v projection against the unfused pair, bit for bit,
   fuzz_frontend.py       CLIP frame preprocessing and the kaldi fbank on random sizes / lengths against the numpy restatements,
   fuzz_ops.py            norms, embedding, casts, copies, the stand-alone router, SwiGLU, arg-max against torch.
+(r05: half the r04 case count here - the suite has a time limit; tests/test_slow_gpu.py runs 4x under `-m gpu_slow`.)
 A combination outside a stated limit must be REJECTED (CRAB_E_INVALID / CRAB_E_UNSUPPORTED), never computed wrong; outputs sit inside sentinel guards."""
 import os
 import subprocess
@@ -22,7 +23,7 @@ FUZZERS = ["fuzz_gemm.py", "fuzz_attn.py", "fuzz_decoder.py", "fuzz_multimodal.p
 
 
 def test_differential_fuzz():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_all.py"), "1"], capture_output=True, text=True, timeout=1200)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_all.py"), "0.5"], capture_output=True, text=True, timeout=1200)
     tail = (r.stdout + r.stderr)[-4000:]
     assert r.returncode == 0, tail
     results = {l.split()[1]: l for l in r.stdout.splitlines() if l.startswith("RESULT ")}

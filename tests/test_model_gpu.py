@@ -6,7 +6,10 @@ Tolerances: north_star asks for "logits within 1e-3 bf16"; what bf16 STORAGE del
 bf16-storage execution of these decoders is already 3.4e-3 .. 5.6e-3 of the logit scale away from fp32).  Every comparison below is
 recorded (tests/util.py:record_parity) and each tolerance is at most twice the worst error measured on MI355X
 (profiles/r02_parity_report.json), relative to max |reference|:
-  * REL_ENC  encoder features / projector outputs / spliced inputs_embeds vs the fp32 reference fixture   (r04, fp32 residual stream / fp32 pre-LN sums: worst 1.29e-2; r03: 1.40e-2, tolerance 2.8e-2)
+  * REL_ENC  encoder features / projector outputs / spliced inputs_embeds vs the fp32 reference fixture   (r05, fp32 LayerNorm parameters: worst 1.01e-2, inputs_embeds 8.6e-3; r04: 1.29e-2; r03: 1.40e-2, tolerance 2.8e-2)
+             Every tolerance is <= 1.5 x the worst error measured on MI355X; tests/test_parity_floor.py puts the bf16-OPERAND FLOOR (what no bf16-MFMA
+             implementation can beat) next to each: the HIP path sits at 1.1 .. 2.3 x the floor on the tiny encoder stacks, 1.1 .. 1.4 x on the
+             decoder fixtures and 0.97 x (i.e. AT it) on the 32-layer Llama-2-7B-size decoder.
   * REL_DEC  decoder logits / hidden states / layer outputs vs the fp32 reference fixture                 (r04: worst 6.7e-3 = a standalone bf16 rmsnorm, stacks 5.8e-3; r03: 8.9e-3, tolerance 1.8e-2)
   * REL_EMU  vs the oracle emulating bf16 storage at the same points (accumulation order, 1-ulp flips)     (r04: worst 1.01e-2; r03: 1.34e-2, tolerance 2.5e-2)
   * greedy token ids: exact wherever the fp32 reference's top-2 logit margin exceeds twice the measured logit error.
@@ -18,9 +21,9 @@ from tests.util import build_tiny_crab, load_fixture, weights_from_table, bert_c
 
 pytestmark = pytest.mark.gpu
 BF = torch.bfloat16
-REL_EMU = 1.5e-2
-REL_ENC = 1.4e-2
-REL_DEC = 9e-3
+REL_EMU = 1.5e-2      # worst measured r05: 1.33e-2 (beats_tiny L = 98: BEATs' post-LN stack at width 128 amplifies 1-ulp flips)
+REL_ENC = 1.3e-2      # worst measured r05: 1.01e-2 (ALProjector, tiny) - 1.55 x the bf16-OPERAND FLOOR of that component (6.5e-3); r04: 1.29e-2 under 1.4e-2
+REL_DEC = 9e-3        # worst measured r05: 7.6e-3 (a rank-16 adapter stack), fixtures 3.8e-3 .. 5.5e-3 = 1.1 .. 1.4 x their operand floor
 
 
 def _rel(got, ref, what=""):
@@ -29,7 +32,8 @@ def _rel(got, ref, what=""):
 
 
 def _bf(W):
-    return {k: v.to(BF).float() for k, v in W.items()}
+    from tests.util import stored_params
+    return stored_params(W)             # bf16 everywhere except the encoders' LayerNorm parameters (fp32 in the HIP modules since r05)
 
 
 def test_clip_tower_vs_reference_fixture_and_oracle():
@@ -779,7 +783,7 @@ def test_decode_batch_between_256_and_512_rows_two_row_groups_tiny():
     rows = [0, 255, 256, 299]
     eng = model.base_model.model._engine
     sids, slog = eng.generate(emb[rows], n, eos_token_id=None, pad_token_id=2, return_step_logits=True)
-    Wo = {k: v.to(BF).float() for k, v in O.strip_peft_prefix(W).items() if v.dtype.is_floating_point}
+    Wo = {k: v for k, v in _bf(O.strip_peft_prefix(W)).items() if v.dtype.is_floating_point}
     ocfg = O.DecoderConfig(**meta["dec"])
     ref_ids, ref_logits = O.greedy_generate(emb[rows].float().cpu(), Wo, ocfg, n)
     worst = _check_ids(ids[rows], ref_ids, ref_logits, logits[rows], min_frac=0.75)

@@ -100,6 +100,21 @@ def test_rmsnorm_layernorm():
         _cmp(y, O.rmsnorm(x.float(), w.float(), 1e-5), 1e-2, f"rmsnorm {D}")
         y = ops.layernorm(x.cuda(), w.cuda(), b.cuda(), 1e-5)
         _cmp(y, F.layer_norm(x.float(), (D,), w.float(), b.float(), 1e-5), 1e-2, f"layernorm {D}")
+        # LayerNorm parameters in fp32 (crab_layernorm_p: what the encoder modules hold since r05), bf16 and fp32 input rows: the only
+        # rounding left is the bf16 output
+        g = torch.Generator().manual_seed(D)
+        w32, b32 = 1 + 0.1 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g)
+        xf = torch.randn(37, D, generator=g)
+        ref = F.layer_norm(x.float(), (D,), w32, b32, 1e-5)
+        y = ops.layernorm(x.cuda(), w32.cuda(), b32.cuda(), 1e-5)
+        _cmp(y, ref, 4.5e-3, f"layernorm {D}, fp32 parameters")
+        assert torch.equal(y.cpu(), ref.to(BF)) or (y.cpu().float() - ref.to(BF).float()).abs().max() <= 2 * ref.abs().max() * 2 ** -8
+        y = ops.layernorm(xf.cuda(), w32.cuda(), b32.cuda(), 1e-5)
+        _cmp(y, F.layer_norm(xf, (D,), w32, b32, 1e-5), 4.5e-3, f"layernorm {D}, fp32 rows and fp32 parameters")
+        y = ops.layernorm(xf.cuda(), w32.cuda(), None, 1e-5)
+        _cmp(y, F.layer_norm(xf, (D,), w32, None, 1e-5), 4.5e-3, f"layernorm {D}, fp32 rows, fp32 weight, no bias")
+        with pytest.raises(Exception):
+            ops.layernorm(x.cuda(), w32.cuda(), b.cuda(), 1e-5)          # weight and bias must share their storage
 
 
 def test_embedding_swiglu_argmax_cast():
@@ -403,7 +418,15 @@ def test_im2col_and_clip_embed():
     patch, cls, pos, w, b = _rand(N * P, D, seed=1), _rand(D, seed=2), _rand(P + 1, D, seed=3), _rand(D, seed=4), _rand(D, seed=5)
     y = ops.clip_embed_ln(patch.cuda(), cls.cuda(), pos.cuda(), w.cuda(), b.cuda(), N, P, D, 1e-5)
     xx = torch.cat([cls.float().expand(N, 1, D), patch.float().view(N, P, D)], 1) + pos.float()
-    _cmp(y, F.layer_norm(xx.to(BF).float(), (D,), w.float(), b.float(), 1e-5).reshape(-1, D), TOL_BF16, "clip embed ln")
+    _cmp(y, F.layer_norm(xx, (D,), w.float(), b.float(), 1e-5).reshape(-1, D), TOL_BF16, "clip embed ln")
+    # pre_layrnorm's parameters in fp32 (crab_clip_embed_ln_p, what the modules hold since r05), vector and scalar kernel (odd width)
+    for D2 in (128, 100):
+        g = torch.Generator().manual_seed(D2)
+        patch, cls, pos = _rand(N * P, D2, seed=1), _rand(D2, seed=2), _rand(P + 1, D2, seed=3)
+        w32, b32 = 1 + 0.1 * torch.randn(D2, generator=g), 0.1 * torch.randn(D2, generator=g)
+        y = ops.clip_embed_ln(patch.cuda(), cls.cuda(), pos.cuda(), w32.cuda(), b32.cuda(), N, P, D2, 1e-5)
+        xx = torch.cat([cls.float().expand(N, 1, D2), patch.float().view(N, P, D2)], 1) + pos.float()
+        _cmp(y, F.layer_norm(xx, (D2,), w32, b32, 1e-5).reshape(-1, D2), TOL_BF16, f"clip embed ln, fp32 parameters, D={D2}")
 
 
 def test_beats_helpers_match_golden_buckets():
@@ -777,6 +800,32 @@ def test_gemm_post_norm_routes_next_group(M, nproj):
             ux[:, p_ * 24:(p_ + 1) * 24] = (2.0 * torch.softmax(tt[:, :3], -1)[:, :, None] * tt[:, None, 3:]).reshape(M, 24)
         _cmp(u, ux, 4.5e-3, "route ahead vs the unrounded router (fp32 math, bf16 output)")
     assert (u[:, nproj * 24:] == 0).all()
+
+
+@pytest.mark.parametrize("res_fp32", [False, True])
+def test_router_ahead_is_batch_invariant_to_a_bf16_ulp_across_the_m16_boundary(res_fp32):
+    """the M <= 16 layer tail (rowfin.hip) forms the NEXT group's router logits on the unrounded product (y * w) * rstd, every
+    M > 16 path routes on the stored bf16 row h - so a clip's router input is not bit-identical between a batch of 16 and a batch of 17.
+    Stated in DESIGN.md 3 (kernel table, rowfin) and bounded here: the same 16 rows through both paths give u within one bf16 ulp of its
+    largest entry, and the stored rows (x, h) are identical."""
+    from crab_amd import ops
+    K, N, nproj = 1024, 2048, 3
+    tcols, ucols = 48, 96
+    x, w, nw = _rand(17, K, seed=1), _rand(N, K, seed=2, scale=K ** -0.5), (1 + 0.1 * _rand(N, seed=4).float()).to(BF)
+    r = _rand(17, N, seed=3)
+    ra = _rand(tcols, N, seed=5, scale=N ** -0.5)
+    ra[nproj * 11:] = 0
+    outs = []
+    for M in (16, 17):
+        rd = (r[:M].float() if res_fp32 else r[:M]).cuda().clone()
+        h = torch.empty(M, N, dtype=BF, device="cuda")
+        u = torch.zeros((M, ucols), dtype=BF, device="cuda")
+        ops.gemm(x[:M].cuda(), w.cuda(), residual=rd, out=rd, post_norm=(nw.cuda(), 1e-5, h), route=(ra.cuda(), nproj, 3, 8, ucols, 2.0, u))
+        outs.append((rd[:16].float().cpu(), h[:16].float().cpu(), u[:16].float().cpu()))
+    (x16, h16, u16), (x17, h17, u17) = outs
+    _cmp(x16, x17, 1.2e-5 if res_fp32 else 1e-6 + 4e-3, "residual row, M = 16 tail vs M = 17 reduction")      # different K splits: fp32 summation order (+ one bf16 rounding when stored in bf16)
+    _cmp(h16, h17, 4.5e-3, "normalised row, M = 16 tail vs M = 17 reduction")
+    _cmp(u16, u17, 8e-3, "router output u of the same rows at M = 16 (unrounded router input) vs M = 17 (stored bf16 row)")
 
 
 @pytest.mark.parametrize("M", [1, 3, 8, 16, 40, 256])

@@ -62,13 +62,25 @@ def _worker_uneven(rank, world, port, q):
     for n_total in (7, 2):                          # 7 clips over 3 ranks: 3 + 2 + 2; 2 clips over 3 ranks: the last rank holds none
         clip0, B = block_of(n_total, world, rank)
         n_new, V = 4, 5
-        ids = torch.stack([torch.arange(n_new) + 100 * (clip0 + i) for i in range(B)]) if B else torch.empty((0, n_new), dtype=torch.int64)
-        logits = torch.stack([torch.full((V,), float(clip0 + i)) for i in range(B)]) if B else torch.empty((0, V))
+        # a rank WITHOUT clips knows neither n_new nor V and has no logits to pass: it still issues the same collectives
+        ids = torch.stack([torch.arange(n_new) + 100 * (clip0 + i) for i in range(B)]) if B else torch.empty((0, 0), dtype=torch.int64)
+        logits = torch.stack([torch.full((V,), float(clip0 + i)) for i in range(B)]) if B else None
         res = gather_results(ids, clip0, world, rank, logits)
         if rank == 0:
             out.append((res[0].tolist(), res[1].tolist(), res[2][:, 0].tolist()))
         else:
             assert res is None
+    # ranks that disagree on the record (one passes a longer id row, one drops its logits) must ALL raise before the first gather - no hang
+    raised = []
+    for bad in ("n_new", "logits"):
+        ids = torch.zeros((2, 5 if (bad == "n_new" and rank == 1) else 4), dtype=torch.int64)
+        logits = None if (bad == "logits" and rank == 2) else torch.zeros((2, 5))
+        try:
+            gather_results(ids, 2 * rank, world, rank, logits)
+            raised.append(False)
+        except ValueError:
+            raised.append(True)
+    assert raised == [True, True], (rank, raised)
     if rank == 0:
         q.put(out)
     dist.barrier()

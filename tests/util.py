@@ -47,6 +47,25 @@ def rel_err(got: torch.Tensor, ref: torch.Tensor, what: str = "", tol=None) -> f
     return err / (scale + 1e-9)
 
 
+_RMS_KEYS = ("input_layernorm.weight", "post_attention_layernorm.weight", "model.norm.weight")
+
+
+def stored_params(W: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """A checkpoint as the HIP modules HOLD it, in fp32 for the oracle's emulation runs: every floating tensor rounded to bf16 except the
+    LayerNorm weights / biases of the encoders, which crab_amd keeps in fp32 (crab_amd.ops.NORM_PARAMS_FP32; the decoder's RMSNorm weights and the
+    VQGAN's GroupNorms stay bf16).  A LayerNorm weight is recognised structurally - a 1-D `.weight` - and its bias by the sibling name."""
+    from crab_amd import ops
+    ln_w = {k for k, v in W.items() if k.endswith(".weight") and v.dim() == 1 and not k.endswith(_RMS_KEYS) and "mask_encoder" not in k}
+    out = {}
+    for k, v in W.items():
+        if not v.is_floating_point():
+            out[k] = v
+            continue
+        keep = ops.NORM_PARAMS_FP32 and (k in ln_w or (k.endswith(".bias") and k[:-5] + ".weight" in ln_w))
+        out[k] = v.float() if keep else v.to(torch.bfloat16).float()
+    return out
+
+
 def load_fixture(name: str) -> Tuple[dict, Dict[str, torch.Tensor]]:
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
     meta = json.loads(bytes(z["meta"]).decode())
