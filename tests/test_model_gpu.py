@@ -335,9 +335,9 @@ def test_seg_module_vs_reference_fixture_and_oracle():
     assert tuple(out[0].shape) == (71, 224, 224) and tuple(out[1].shape) == (1, 224, 224)
     ref = O.seg_module(pred.to(BF).float(), [f.to(BF).float() for f in feats], meta["tasks"], _bf(W))
     for i in range(2):
-        assert _rel(out[i], ref[i], f"SegModule sample {i} vs oracle on bf16-rounded weights") < 1.8e-2, f"sample {i} vs oracle on bf16-rounded weights"
-    assert _rel(out[0][:, 3::8, 5::8], A["avss_sub"], "SegModule avss vs fp32 reference") < 3.2e-2
-    assert _rel(out[1][:, 1::2, ::2], A["s4_sub"], "SegModule s4 vs fp32 reference") < 3.2e-2
+        assert _rel(out[i], ref[i], f"SegModule sample {i} vs oracle on bf16-rounded weights") < 1.3e-2, f"sample {i} vs oracle on bf16-rounded weights"
+    assert _rel(out[0][:, 3::8, 5::8], A["avss_sub"], "SegModule avss vs fp32 reference") < 2.1e-2          # r05 (fp32 LayerNorm parameters): 1.15e-2 / 1.39e-2 measured (r04: 1.36e-2 / 1.77e-2 under 3.2e-2)
+    assert _rel(out[1][:, 1::2, ::2], A["s4_sub"], "SegModule s4 vs fp32 reference") < 2.1e-2
 
 
 def _avs_setup():
@@ -410,7 +410,7 @@ def test_generate_avs_pipeline_vs_oracle():
         assert float(top2[0] - top2[1]) < 0.1 * float(olog.abs().max()), f"generate_avs ids diverge from the oracle at step {j} at a super-margin step"
         pytest.skip(f"ids diverge at sub-margin step {j}: masks are not comparable")
     else:
-        assert _rel(res['pred_masks'][0], ref[0], "generate_avs masks vs oracle pipeline") < 2e-2
+        assert _rel(res['pred_masks'][0], ref[0], "generate_avs masks vs oracle pipeline") < 1.3e-2      # measured 8.5e-3
 
 
 def test_harness_pixel_task_loop_writes_the_masks(tmp_path):
