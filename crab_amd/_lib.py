@@ -121,6 +121,7 @@ class LlamaIO(C.Structure):
         ("attn_ws", C.c_void_p), ("attn_ws_bytes", C.c_int64),
         ("x_fp32", C.c_int32),
         ("row_off", C.c_void_p),
+        ("pos_ids", C.c_void_p), ("ld_pos", C.c_int64), ("kv_start", C.c_void_p),
     ]
 
 

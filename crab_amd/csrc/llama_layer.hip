@@ -78,6 +78,7 @@ int run_group(crab_ctx* ctx, void* stream, const crab_linear_group* g, const cra
         d.rope_tab = io->rope_tab; d.rope_k_cache = k_cache; d.rope_v_cache = v_cache; d.rope_pos_dev = nullptr;
         d.rope_H = L->H; d.rope_Hk = L->Hk; d.rope_d = L->d; d.rope_Tmax = io->Tmax; d.rope_pos0 = io->pos0; d.rope_S = c.rope_prefill_S;
         d.rope_vt = io->vt; d.rope_vt_ld = io->vt_ld;
+        d.rope_pos_ids = io->pos_ids; d.rope_ld_pos = io->ld_pos;      // explicit rotary positions (NULL: pos0 + s)
         if (c.fused_prefill_rope) *c.fused_prefill_rope = crab_gemm_fuses_prefill_rope(&d);      // a function of shapes / pointers set above only
     }
     if (g->RA && !c.u_ready && M <= 16 && c.norm_w && g->nproj == 1 && crab_rowfin_enabled() && crab_rowfin_lora_ok(g->nl, g->r, g->N)) {
@@ -126,8 +127,10 @@ int check_io(crab_ctx* ctx, const crab_llama_layer* L, const crab_llama_io* io, 
         if (!io->vt || io->vt_ld < io->S) return crab_fail(ctx, CRAB_E_INVALID, "llama_layer_prefill: vt [B, Hk, d, vt_ld >= S] is required");
         if (io->pos0 + io->S > io->Tmax) return crab_fail(ctx, CRAB_E_INVALID, "llama_layer_prefill: rows do not fit the KV cache");
         if (io->row_off) return crab_fail(ctx, CRAB_E_INVALID, "llama_layer_prefill: row_off is a decode field (a prefill into a right-aligned cache advances k_cache / v_cache instead)");
+        if (io->pos_ids && io->ld_pos < io->S) return crab_fail(ctx, CRAB_E_INVALID, "llama_layer_prefill: ld_pos < S");
     } else {
         if (io->S != 1) return crab_fail(ctx, CRAB_E_INVALID, "llama_layer_decode: one row per sequence (S == 1)");
+        if (io->pos_ids || io->kv_start) return crab_fail(ctx, CRAB_E_INVALID, "llama_layer_decode: pos_ids / kv_start are prefill fields (a ragged decode step takes row_off)");
         if (!io->pos_dev && io->pos0 >= io->Tmax) return crab_fail(ctx, CRAB_E_INVALID, "llama_layer_decode: position outside the KV cache");
     }
     return CRAB_OK;
@@ -157,8 +160,8 @@ int run_layer(crab_ctx* ctx, void* stream, const crab_llama_layer* L, crab_llama
         // fused_rope 1: q and k already rotated (k in the cache) by the projection's epilogue, only the v columns are left (cache append + V^T);
         // 2: those too
         if (fused_rope != 2 &&
-            (rc = crab_qkv_rope_split(ctx, stream, io->qkv, io->ldqkv, fused_rope ? nullptr : io->rope_tab, fused_rope ? nullptr : kc, vc, io->vt,
-                                      io->vt_ld, B, S, H, Hk, d, io->Tmax, io->pos0, io->pos_dev)))
+            (rc = crab_qkv_rope_split_ids(ctx, stream, io->qkv, io->ldqkv, fused_rope ? nullptr : io->rope_tab, fused_rope ? nullptr : kc, vc, io->vt,
+                                          io->vt_ld, B, S, H, Hk, d, io->Tmax, io->pos0, io->pos_dev, fused_rope ? nullptr : io->pos_ids, io->ld_pos)))
             return rc;
         crab_attn_desc a;
         memset(&a, 0, sizeof(a));
@@ -168,6 +171,7 @@ int run_layer(crab_ctx* ctx, void* stream, const crab_llama_layer* L, crab_llama
         a.vt_bs = (int64_t)Hk * d * io->vt_ld; a.vt_hs = (int64_t)d * io->vt_ld; a.vt_ds = io->vt_ld;
         a.o_bs = (int64_t)S * io->ldatt; a.o_ss = io->ldatt;
         a.B = B; a.H = H; a.Hk = Hk; a.Sq = S; a.Skv = io->pos0 + S; a.head_dim = d; a.causal = 1; a.scale = scale;
+        a.kv_start = io->kv_start;                                  // left-pad mask (NULL: every key visible)
         if ((rc = crab_attn_fwd(ctx, stream, &a))) return rc;
     } else if (fuse_attn) {
         if ((rc = crab_attn_decode_rope(ctx, stream, io->qkv, io->ldqkv, io->rope_tab, kc, vc, io->att, io->ldatt, B, H, Hk, d, io->Tmax, io->pos0,

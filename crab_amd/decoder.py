@@ -26,6 +26,7 @@ from . import _lib, ops
 from .peft_hyper import PackedLinearGroup
 
 BF16 = torch.bfloat16
+RAGGED_PAD_MAX = 0.06     # a coalesced wave whose batches differ in length is prefilled as ONE padded batch while the padding costs at most this fraction of the prefill rows
 NATIVE_LAYERS = True      # False: issue every launch of a layer from Python (A/B runs and the sequencer-equivalence tests)
 
 
@@ -377,7 +378,8 @@ class GenerationEngine:
         return tab
 
     def _layers_native(self, ws: _Workspace, B: int, S: int, kc: torch.Tensor, vc: torch.Tensor, b0: int, Tmax: int, pos0: int,
-                       pos_dev: Optional[torch.Tensor], vt: Optional[torch.Tensor], t0: int = 0, row_off: Optional[torch.Tensor] = None):
+                       pos_dev: Optional[torch.Tensor], vt: Optional[torch.Tensor], t0: int = 0, row_off: Optional[torch.Tensor] = None,
+                       pos_ids: Optional[torch.Tensor] = None, kv_start: Optional[torch.Tensor] = None):
         """The whole stack through ONE C call (crab_llama_layers, csrc/llama_layer.hip): the same launches in the same order as the
         per-launch Python sequence below, which is kept for the runs that time individual kernels (ops.PROFILER)."""
         io = _lib.LlamaIO()
@@ -390,6 +392,9 @@ class GenerationEngine:
         shift = t0 * kc.stride(3) * kc.element_size()              # a prefill into a right-aligned cache starts at slot t0 of every head's rows
         io.k_cache, io.v_cache, io.cache_layer_stride = kc[0, b0].data_ptr() + shift, vc[0, b0].data_ptr() + shift, kc.stride(0)
         io.row_off = row_off.data_ptr() if row_off is not None else None
+        if pos_ids is not None:                                    # prefill under forward()'s position_ids / left-pad mask (the ragged prefill of _start_ragged)
+            io.pos_ids, io.ld_pos = pos_ids.data_ptr(), pos_ids.stride(0)
+        io.kv_start = kv_start.data_ptr() if kv_start is not None else None
         if vt is not None:
             io.vt, io.vt_ld = vt.data_ptr(), vt.stride(-2)
         io.pos_dev = pos_dev.data_ptr() if pos_dev is not None else None
@@ -427,8 +432,12 @@ class GenerationEngine:
         if row_off is not None and (vt is not None or masked):
             raise ValueError("row_off is a decode-step argument (no masks / position ids next to it)")
         contig = kc.is_contiguous() and vc.is_contiguous()
-        if NATIVE_LAYERS and not timed and not masked and contig and (vt is not None or S == 1):
-            self._layers_native(ws, B, S, kc, vc, b0, Tmax, pos0, pos_dev, vt, t0, row_off)
+        # the native sequencer takes a prefill's rotary positions / first visible keys as well (crab_llama_io.pos_ids / kv_start); a general key
+        # mask and the masked one-token step of forward() stay on the per-launch sequence below
+        native_ok = key_mask is None and (not masked or (vt is not None and pos_dev is None and
+                                                         (pos_ids is None or (pos_ids.dtype == torch.int32 and pos_ids.stride(1) == 1))))
+        if NATIVE_LAYERS and not timed and native_ok and contig and (vt is not None or S == 1):
+            self._layers_native(ws, B, S, kc, vc, b0, Tmax, pos0, pos_dev, vt, t0, row_off, pos_ids, kv_start)
             return x, h
         u_qkv = None                                   # router output for the q|k|v group when a producer epilogue made it
         # small batch: the projection leaves its raw row, ONE launch does RoPE + KV append + split-context attention (as csrc/llama_layer.hip)
@@ -595,20 +604,9 @@ class GenerationEngine:
         ops.advance(st.pos_dev, st.step_dev)           # pos: S-1 -> S (position of the token just selected), step: 0 -> 1
         return st
 
-    def _start_ragged(self, embeds_list: List[torch.Tensor], max_new_tokens: int, eos_token_id, pad_token_id, min_new_tokens: int,
-                      sink=None, sampling=None) -> "_DecodeState":
-        """The decode state of SEVERAL generate() calls coalesced into one batch.  Group g = [B_g, S_g, D] is one call of the eval loop: its
-        own prompt length and left padding, positions 0 .. S_g - 1 (unified_llama.py:262-267).  All rows share one KV cache [L, sum B_g, Hk,
-        Tmax, d] in which every group is RIGHT-ALIGNED at Smax = max S_g: group g's prompt occupies slots Smax - S_g .. Smax - 1, so the token
-        decoded at step t lands in slot Smax + t - 1 for every row (one device-resident append index, one captured graph), while row_off[row]
-        = Smax - S_g gives the decode kernels the row's rotary offset and its first visible key.  Groups are prefilled exactly as generate()
-        prefills them (consecutive groups of the same length share prefill chunks), only the cache pointers are advanced by row_off."""
-        Bs = [int(e.shape[0]) for e in embeds_list]
-        Ss = [int(e.shape[1]) for e in embeds_list]
-        Bt, Smax = sum(Bs), max(Ss)
-        st = self._state(Bt, Smax, max_new_tokens, eos_token_id, pad_token_id, min_new_tokens, False, 0, sampling, ragged=True)
-        st.row_off.copy_(torch.tensor([Smax - S for B, S in zip(Bs, Ss) for _ in range(B)], dtype=torch.int32), non_blocking=False)
-        # spans of consecutive groups with the same prompt length: one chunk plan each (whole rounds of 256 x 256 tiles, plan_prefill_chunks)
+    def _prefill_groups(self, st, embeds_list, Bs, Ss, Smax):
+        """Per-group prefill into the right-aligned cache: spans of consecutive groups with the same prompt length share one chunk plan (whole
+        rounds of 256 x 256 tiles, plan_prefill_chunks); the cache pointers are advanced by the span's offset (t0), nothing else changes."""
         g = 0
         b0 = 0
         while g < len(embeds_list):
@@ -633,6 +631,48 @@ class GenerationEngine:
                 c0 += n
             b0 += n_span
             g = g1 + 1
+
+    def _start_ragged(self, embeds_list: List[torch.Tensor], max_new_tokens: int, eos_token_id, pad_token_id, min_new_tokens: int,
+                      sink=None, sampling=None) -> "_DecodeState":
+        """The decode state of SEVERAL generate() calls coalesced into one batch.  Group g = [B_g, S_g, D] is one call of the eval loop: its
+        own prompt length and left padding, positions 0 .. S_g - 1 (unified_llama.py:262-267).  All rows share one KV cache [L, sum B_g, Hk,
+        Tmax, d] in which every group is RIGHT-ALIGNED at Smax = max S_g: group g's prompt occupies slots Smax - S_g .. Smax - 1, so the token
+        decoded at step t lands in slot Smax + t - 1 for every row (one device-resident append index, one captured graph), while row_off[row]
+        = Smax - S_g gives the decode kernels the row's rotary offset and its first visible key.  Prefill: groups of ONE length are prefilled
+        exactly as generate() prefills them (shared chunks, the cache pointers advanced by row_off: _prefill_groups); groups of different
+        lengths as one front-padded batch under forward()'s left-pad mask + position_ids (merged form below) unless the padding would cost
+        more than RAGGED_PAD_MAX of the rows."""
+        Bs = [int(e.shape[0]) for e in embeds_list]
+        Ss = [int(e.shape[1]) for e in embeds_list]
+        Bt, Smax = sum(Bs), max(Ss)
+        st = self._state(Bt, Smax, max_new_tokens, eos_token_id, pad_token_id, min_new_tokens, False, 0, sampling, ragged=True)
+        st.row_off.copy_(torch.tensor([Smax - S for B, S in zip(Bs, Ss) for _ in range(B)], dtype=torch.int32), non_blocking=False)
+        waste = sum(B * (Smax - S) for B, S in zip(Bs, Ss)) / max(1, sum(B * S for B, S in zip(Bs, Ss)))
+        if len(set(Ss)) > 1 and waste <= RAGGED_PAD_MAX:
+            # MERGED prefill (batches of different lengths, the normal case of a real question set): every sequence is padded IN FRONT to Smax
+            # rows (zero rows: never attended, their outputs never read), its real tokens keep the rotary positions 0 .. S_g - 1 (pos_ids) and
+            # see no key below their own first row (kv_start = row_off) - forward()'s left-pad mask + position_ids, which both prefill kernels
+            # take (crab_llama_io.pos_ids / kv_start) - so the chunks are planned over ALL rows of the wave (whole rounds of 256 x 256 tiles,
+            # as for one large generate()) instead of per batch of 8 (22 row tiles: 4.1 / 1.4 / 7.4 rounds).  The cache rows land right-aligned
+            # by construction.  Cost: the (Smax - S_g) padded rows, `waste` of the prefill work (a few % at most, else the per-group form below).
+            D = embeds_list[0].shape[2]
+            emb = torch.zeros((Bt, Smax, D), device=self.device, dtype=BF16)
+            r0 = 0
+            for e, B, S in zip(embeds_list, Bs, Ss):
+                emb[r0:r0 + B, Smax - S:] = e
+                r0 += B
+            pos_ids = (torch.arange(Smax, device=self.device, dtype=torch.int32)[None] - st.row_off[:, None]).clamp_(min=0).contiguous()
+            self._rope_tab(st.Tmax)
+            b0 = 0
+            for n in self.plan_prefill_chunks(Bt, Smax):
+                self.prefill(emb[b0:b0 + n], st.kc, st.vc, b0=b0, logits_out=st.logits[b0:b0 + n], hn_out=st.hn[b0:b0 + n],
+                             pos_ids=pos_ids[b0:b0 + n], kv_start=st.row_off[b0:b0 + n])
+                b0 += n
+            del emb
+            self.last_ragged_prefill = "merged"
+        else:
+            self.last_ragged_prefill = "per_group"
+            self._prefill_groups(st, embeds_list, Bs, Ss, Smax)
         if sink is not None:
             sink(st)
         self._select(st)

@@ -393,6 +393,14 @@ typedef struct {
      * eval loop (each with its own prompt length and left padding) then decode as ONE batch that streams the weights once per step.
      * NULL = every sequence starts at slot 0. */
     const int32_t* row_off;
+    /* optional, PREFILL only (ABI 9): the left-pad attention_mask and position_ids of forward() (models/unified_llama.py:149-160) behind the
+     * sequencer - pos_ids int32 [B, ld_pos >= S]: token (b, s) is rotated at pos_ids[b * ld_pos + s] (its K / V rows still land in cache slot
+     * pos0 + s: crab_gemm_desc.rope_pos_ids / crab_qkv_rope_split_ids); kv_start int32 [B]: keys below kv_start[b] are invisible to sequence b
+     * (crab_attn_desc.kv_start).  Together they prefill sequences of DIFFERENT lengths in one call, right-aligned: sequence b padded in front
+     * to S rows, kv_start[b] = S - S_b, pos_ids[b][s] = max(s - kv_start[b], 0) - every real token sees exactly the keys and positions of its
+     * own call, and its cache rows land where the ragged decode batch (row_off = kv_start) expects them.  NULL = positions pos0 + s, no mask. */
+    const int32_t* pos_ids; int64_t ld_pos;
+    const int32_t* kv_start;
 } crab_llama_io;
 
 int crab_sizeof_llama_layer(void);

@@ -155,8 +155,9 @@ def test_oracle_on_the_gpu_equals_the_oracle_on_the_host(crab):
         assert _rel(lg.cpu(), lc, f"oracle on the GPU vs on the host ({'fp32' if mode is None else 'emulation'})") < (2e-5 if mode is None else 2.5e-3)
 
 
-def test_decode_batch_448_regime_vs_cpu_oracle_full_size(crab):
-    _decode_regime_vs_cpu_oracle(crab, 448)
+@pytest.mark.parametrize("B", [256, 448])
+def test_decode_batch_regime_vs_cpu_oracle_full_size(crab, B):
+    _decode_regime_vs_cpu_oracle(crab, B)
 
 
 def _decode_regime_vs_cpu_oracle(crab, B):

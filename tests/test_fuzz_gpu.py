@@ -9,7 +9,7 @@
   fuzz_rope_epilogue.py  the RoPE / KV-append fusions of the q|k|v projection against the unfused pair, bit for bit,
   fuzz_frontend.py       CLIP frame preprocessing and the kaldi fbank on random sizes / lengths against the numpy restatements,
   fuzz_ops.py            norms, embedding, casts, copies, the stand-alone router, SwiGLU, arg-max against torch.
-(r05: half the r04 case count here - the suite has a time limit; tests/test_slow_gpu.py runs 4x under `-m gpu_slow`.)
+(r05: half the r04 case count here - the suite has a time limit; tests/test_slow_gpu.py runs 8x that (scale 4) under `-m gpu_slow`.)
 A combination outside a stated limit must be REJECTED (CRAB_E_INVALID / CRAB_E_UNSUPPORTED), never computed wrong; outputs sit inside sentinel guards."""
 import os
 import subprocess

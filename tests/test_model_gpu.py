@@ -1001,20 +1001,30 @@ def test_coalesced_batches_match_the_reference_fixture_per_batch():
     assert _rel(embeds[1], A["embeds_bs2"], "coalesced encoders: inputs_embeds of batch 1 (left-padded bs 2)") < REL_ENC
     assert torch.equal(inputs[1]["position_ids"].cpu().long(), A["pos_bs2"].long()) and torch.equal(inputs[1]["attention_mask"].cpu().long(), A["mask_bs2"].long())
     kw = dict(eos_token_id=None, pad_token_id=2, coalesce=True, return_step_logits=True)
-    res = eng.generate_many(embeds, n, **kw)
-    res_eager = eng.generate_many(embeds, n, use_graph=False, **kw)
-    decoder.NATIVE_LAYERS = False
+    # both prefill forms of a ragged wave: per group into the right-aligned cache (cache pointers advanced), and MERGED - one front-padded batch
+    # under forward()'s left-pad mask + position_ids through the native sequencer (crab_llama_io.pos_ids / kv_start), what a real question set gets
+    saved = decoder.RAGGED_PAD_MAX
     try:
-        res_py = eng.generate_many(embeds, n, use_graph=False, **kw)
+        for pad_max, form in ((0.0, "per_group"), (0.5, "merged")):
+            decoder.RAGGED_PAD_MAX = pad_max
+            res = eng.generate_many(embeds, n, **kw)
+            assert eng.last_ragged_prefill == form
+            res_eager = eng.generate_many(embeds, n, use_graph=False, **kw)
+            decoder.NATIVE_LAYERS = False
+            try:
+                res_py = eng.generate_many(embeds, n, use_graph=False, **kw)
+            finally:
+                decoder.NATIVE_LAYERS = True
+            for (i1, l1), (i2, l2), (i3, l3) in zip(res, res_eager, res_py):
+                assert torch.equal(i1, i2) and torch.equal(l1, l2), "HIP-graph replay of the ragged step differs from plain launches"
+                assert torch.equal(i1, i3) and torch.equal(l1, l3), f"the Python per-launch sequence differs from the native one ({form} prefill)"
+            for g, key in ((0, "bs1"), (1, "bs2")):
+                ids, logits = res[g]
+                err = _check_ids(ids, A[f"ids_{key}"], A[f"logits_{key}"], logits)
+                assert err < REL_DEC * A[f"logits_{key}"].abs().max().item(), (g, form, err)
     finally:
-        decoder.NATIVE_LAYERS = True
-    for (i1, l1), (i2, l2), (i3, l3) in zip(res, res_eager, res_py):
-        assert torch.equal(i1, i2) and torch.equal(l1, l2), "HIP-graph replay of the ragged step differs from plain launches"
-        assert torch.equal(i1, i3) and torch.equal(l1, l3), "the Python per-launch sequence of the ragged step differs from the native one"
-    for g, key in ((0, "bs1"), (1, "bs2")):
-        ids, logits = res[g]
-        err = _check_ids(ids, A[f"ids_{key}"], A[f"logits_{key}"], logits)
-        assert err < REL_DEC * A[f"logits_{key}"].abs().max().item(), (g, err)
+        decoder.RAGGED_PAD_MAX = saved
+    res = eng.generate_many(embeds, n, **kw)                    # the default rule (these lengths: merged)
     # the public API: ids only, and with output_first_logits the first position's logits
     pub = model.generate_batches(batches, coalesce=True, use_cache=True, max_new_tokens=n, pad_token_id=2, eos_token_id=None)
     pub2 = model.generate_batches(batches, coalesce=True, use_cache=True, max_new_tokens=n, pad_token_id=2, eos_token_id=None, output_first_logits=True)
@@ -1055,13 +1065,20 @@ def test_coalesced_batches_of_different_lengths_vs_oracle():
         refs.append(O.generate(ids, mods, Wo, ocfg, n))
     embeds = [d["inputs_embeds"] for d in um.prepare_multimodal_inputs_many(batches)]
     assert len({e.shape[1] for e in embeds}) >= 4
+    from crab_amd import decoder
     worst = 0.0
-    for max_rows in (None, 4):
-        res = um._engine.generate_many(embeds, n, eos_token_id=None, pad_token_id=2, coalesce=True, return_step_logits=True, max_rows=max_rows)
-        assert um._engine.last_plan["groups"] == ([10] if max_rows is None else [4, 4, 2]) and um._engine.last_plan["coalesced"]
-        for (ids, logits), (ref_ids, ref_logits) in zip(res, refs):
-            assert ids.shape == (2, n)
-            worst = max(worst, _check_ids(ids, ref_ids, ref_logits, logits, min_frac=0.9) / ref_logits.abs().max().item())
+    saved = decoder.RAGGED_PAD_MAX
+    try:
+        for max_rows, pad_max in ((None, 0.5), (None, 0.0), (4, 0.5)):          # one wave merged / per group, three waves
+            decoder.RAGGED_PAD_MAX = pad_max
+            res = um._engine.generate_many(embeds, n, eos_token_id=None, pad_token_id=2, coalesce=True, return_step_logits=True, max_rows=max_rows)
+            assert um._engine.last_plan["groups"] == ([10] if max_rows is None else [4, 4, 2]) and um._engine.last_plan["coalesced"]
+            assert um._engine.last_ragged_prefill == ("merged" if pad_max else "per_group")
+            for (ids, logits), (ref_ids, ref_logits) in zip(res, refs):
+                assert ids.shape == (2, n)
+                worst = max(worst, _check_ids(ids, ref_ids, ref_logits, logits, min_frac=0.9) / ref_logits.abs().max().item())
+    finally:
+        decoder.RAGGED_PAD_MAX = saved
     assert worst < REL_DEC, worst
 
 

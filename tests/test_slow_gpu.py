@@ -1,9 +1,8 @@
 """Long GPU soaks, kept out of `-m gpu` so that the driver's suite stays well inside its time limit (580 s of 1200): run with
     python -m pytest tests/test_slow_gpu.py -m gpu_slow -q
 on a GPU box.  r05 results on MI355X: profiles/r05_slow_suite.log.
-  * the B = 256 decode regime (gemm_dec_ws_kernel panels) against the CPU oracle - the r01-r03 benchmark batch; `-m gpu` keeps the B = 448
-    regime (two row groups per block), which is what bench.py runs;
-  * the seven differential fuzzers at 4x the case count of the `-m gpu` run."""
+  * the seven differential fuzzers at 8x the case count of the `-m gpu` run (3 min 40 s on the r05 box; their decoder / multimodal cases
+    run the CPU oracle on the host)."""
 import os
 import subprocess
 import sys
@@ -12,17 +11,6 @@ import pytest
 
 pytestmark = pytest.mark.gpu_slow
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-
-
-@pytest.fixture(scope="module")
-def crab():
-    from crab_amd.build_model import build_crab
-    return build_crab("llama", visual=False, audio=False, conditioned=True)
-
-
-def test_decode_batch_256_regime_vs_cpu_oracle_full_size(crab):
-    from tests.test_fullsize_gpu import _decode_regime_vs_cpu_oracle
-    _decode_regime_vs_cpu_oracle(crab, 256)
 
 
 def test_differential_fuzz_soak():
