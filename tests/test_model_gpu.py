@@ -971,8 +971,8 @@ def test_generate_many_refuses_batches_that_do_not_fit_together_and_returns_firs
     assert eng.generate_many([], 5) == []
 
 
-def _coalesce_setup():
-    meta, A = load_fixture("full_tiny_llama")
+def _coalesce_setup(fixture="full_tiny_llama"):
+    meta, A = load_fixture(fixture)
     model = build_tiny_crab(meta)
     model.load_state_dict(weights_from_table(meta), strict=False)
     mods = _inputs(meta)
@@ -983,14 +983,17 @@ def _coalesce_setup():
     return meta, A, model, batches
 
 
-def test_coalesced_batches_match_the_reference_fixture_per_batch():
-    """generate_batches(coalesce=True): three eval-loop batches of DIFFERENT prompt lengths (1 clip; 2 left-padded clips; 1 shorter clip) decode
+@pytest.mark.parametrize("fixture", ["full_tiny_llama", "full_tiny_qwen"])
+def test_coalesced_batches_match_the_reference_fixture_per_batch(fixture):
+    """(full_tiny_qwen: the same through the Qwen2 decoder - grouped-query decode attention with a first visible key per row, q / k / v bias in
+    the fused RoPE epilogues.)
+    generate_batches(coalesce=True): three eval-loop batches of DIFFERENT prompt lengths (1 clip; 2 left-padded clips; 1 shorter clip) decode
     as one ragged batch - right-aligned in one KV cache, per-row rotary offset and first visible key (crab_llama_io.row_off) - and every batch
     must come out as its own generate() call does in the REFERENCE: ids and per-step logits against the reference-recorded fixture
     (full_tiny_llama bs 1 and left-padded bs 2: the pads of the bs-2 batch are attended, positions run from 0 per batch), graph replay ==
     plain launches bit for bit, the Python per-launch sequencer == the native one, and the public API returns the same ids."""
     from crab_amd import decoder
-    meta, A, model, batches = _coalesce_setup()
+    meta, A, model, batches = _coalesce_setup(fixture)
     um = model.base_model.model
     eng = um._engine
     n = meta["new_tokens"]
