@@ -64,6 +64,16 @@ def flops_per_clip(T_v=8, T_a=10, n_a=48, S=702, V=32017, cfg=None):
     return (T_v * (155.3e9 + 4.0e9) + T_a * (f_beats + 2.57e9) + S * (2 * lin + lora) + 2 * S * S * attn_w + 2 * V * D)
 
 
+def dead_last_layer_flops(S, cfg):
+    """What generate()'s prefill does NOT execute of the algorithmic work above (crab_llama_io.last_rows_only): attention, o_proj, gate|up, down
+    of the last layer for the S - 1 rows nobody reads (lm_head takes the last row; the reference computes and drops them, modeling_llama.py:1260)."""
+    D, I = cfg.hidden_size, cfg.intermediate_size
+    H, d = cfg.num_attention_heads, cfg.hidden_size // cfg.num_attention_heads
+    lin = H * d * D + 3 * D * I
+    lora = 11 * (H * d + D + I) + 24 * (D + 2 * I + D)                   # routers + A of the o / gate|up / down inputs, B of their outputs
+    return (S - 1) * 2.0 * (lin + lora) + 2.0 * S * S * H * d - 4.0 * S * H * d
+
+
 def decode_bytes_per_step(B, ctx, V=32017):
     return (6.476e9 + V * 4096) * 2 + 45e6 * 2 + B * 2 * 32 * 4096 * 2 * ctx
 
@@ -297,6 +307,17 @@ def operating_points(model, um, args, eos):
     run("audio_2s_windows", nb, args.frames, 198, "MUSIC-AVQA audio shape [10,198,128] (96 BEATs tokens per window)")
     run("frames_10", nb, 10, 98, "the reference's default video_frame_nums = 10 (S = 766)")
     return out
+
+
+def _executed_block(algo_flops_per_clip, S, cfg, ms_per_clip):
+    """`frac` above prices the ALGORITHMIC FLOPs of SURVEY.md 8d (every row through every layer).  The shipped prefill skips the dead rows of the
+    last layer (crab_llama_io.last_rows_only): the same phase priced on the FLOPs it actually executes, so that the skipped work is not read as
+    matrix-pipe efficiency."""
+    from crab_amd import decoder
+    dead = dead_last_layer_flops(S, cfg) if decoder.LAST_ROWS_ONLY else 0.0
+    ex = algo_flops_per_clip - dead
+    return {"last_rows_only": bool(decoder.LAST_ROWS_ONLY), "tflop_per_clip": round(ex / 1e12, 3), "dead_tflop_per_clip_skipped": round(dead / 1e12, 3),
+            "achieved": round(ex / (ms_per_clip * 1e-3) / 1e12, 1), "frac": round(ex / (ms_per_clip * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)}
 
 
 def _rccl_version():
@@ -598,6 +619,7 @@ def main():
                         "achieved": round(pre_flops / (pre_ms * 1e-3) / 1e12, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(pre_flops / (pre_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
                         "ms_per_clip": round(pre_ms / B, 3), "decode_ms_per_clip": round(dec_ms / B, 3),
+                        "executed": _executed_block(pre_flops / B, S, um.config, pre_ms / B),
                         "source": "one un-timed step of the shipped path with three phase marks (HIP events); the per-launch instrumented step "
                                   f"measures {round(pre_ms_instr / B, 3)} ms per clip for the same phase"}
         line = {

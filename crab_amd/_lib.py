@@ -122,6 +122,7 @@ class LlamaIO(C.Structure):
         ("x_fp32", C.c_int32),
         ("row_off", C.c_void_p),
         ("pos_ids", C.c_void_p), ("ld_pos", C.c_int64), ("kv_start", C.c_void_p),
+        ("last_rows_only", C.c_int32),
     ]
 
 

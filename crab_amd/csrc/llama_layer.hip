@@ -136,7 +136,7 @@ int check_io(crab_ctx* ctx, const crab_llama_layer* L, const crab_llama_io* io, 
     return CRAB_OK;
 }
 
-int run_layer(crab_ctx* ctx, void* stream, const crab_llama_layer* L, crab_llama_io* io, int layer_index, bool prefill) {
+int run_layer(crab_ctx* ctx, void* stream, const crab_llama_layer* L, crab_llama_io* io, int layer_index, bool prefill, bool last_rows = false) {
     const int B = io->B, S = io->S, M = B * S;
     const int H = L->H, Hk = L->Hk, d = L->d;
     uint16_t* kc = (uint16_t*)io->k_cache + (int64_t)layer_index * io->cache_layer_stride;
@@ -156,6 +156,44 @@ int run_layer(crab_ctx* ctx, void* stream, const crab_llama_layer* L, crab_llama
     int fused_rope = 0;
     if (prefill) { q.rope_prefill_S = S; q.fused_prefill_rope = &fused_rope; }
     if ((rc = run_group(ctx, stream, &L->qkv, io, L, M, q, kc, vc))) return rc;
+    if (prefill && last_rows) {
+        // ---- the LAST layer of a generate() prefill (io->last_rows_only): the cache has every row's k / v now; everything downstream is needed
+        // for the last row of each sequence only.  One-row-per-sequence step over buffers the layer no longer needs:
+        //   ql  = act[0:B, 0:H d]   (the rotated q of the last rows)      att = att[0:B]      xl = qkv's storage as [B, D] residual rows (fp32 | bf16)
+        //   hl  = h[0:B] (post-attention norm, then overwritten by the final norm = the result)                 actl = act[0:B]
+        if (fused_rope != 2 &&
+            (rc = crab_qkv_rope_split_ids(ctx, stream, io->qkv, io->ldqkv, fused_rope ? nullptr : io->rope_tab, fused_rope ? nullptr : kc, vc, nullptr,
+                                          0, B, S, H, Hk, d, io->Tmax, io->pos0, io->pos_dev, fused_rope ? nullptr : io->pos_ids, io->ld_pos)))
+            return rc;                                                  // (no V^T: the flash kernel does not run in this layer)
+        const int D = L->o.N;
+        const uint16_t* qlast = (const uint16_t*)io->qkv + (int64_t)(S - 1) * io->ldqkv;
+        if ((rc = crab_copy_rows(ctx, stream, qlast, (int64_t)S * io->ldqkv, io->act, io->ldact, B, H * d))) return rc;
+        if ((rc = crab_attn_decode_masked(ctx, stream, io->act, io->ldact, kc, vc, io->att, io->ldatt, B, H, Hk, d, io->Tmax, io->pos0 + S, nullptr,
+                                          scale, io->kv_start)))
+            return rc;
+        // residual rows of the last tokens, gathered into qkv's storage (fp32: D floats = 2 D 16-bit words per row)
+        const int wpr = io->x_fp32 ? 2 * D : D;
+        const uint16_t* xlast = (const uint16_t*)io->x + (int64_t)(S - 1) * io->ldx * (io->x_fp32 ? 2 : 1);
+        if ((rc = crab_copy_rows(ctx, stream, xlast, (int64_t)S * io->ldx * (io->x_fp32 ? 2 : 1), io->qkv, wpr, B, wpr))) return rc;
+        crab_llama_io t = *io;                                          // the B-row view the group calls below see
+        t.S = 1; t.x = io->qkv; t.ldx = D;
+        const bool ahead = L->gu.RA != nullptr && B <= CRAB_DECODE_MAX_ROWS;
+        GroupCall o{};
+        o.x = io->att; o.ldx = io->ldatt; o.out = t.x; o.ldc = t.ldx; o.residual = t.x; o.ldr = t.ldx; o.act = CRAB_ACT_NONE;
+        o.norm_w = L->post_attention_norm_w; o.norm_out = io->h; o.ld_norm = io->ldh; o.eps = L->rms_eps;
+        if (ahead) { o.route_next = &L->gu; o.route_u = io->u2; }
+        if ((rc = run_group(ctx, stream, &L->o, &t, L, B, o, nullptr, nullptr))) return rc;
+        GroupCall g{};
+        g.x = io->h; g.ldx = io->ldh; g.out = io->act; g.ldc = io->ldact; g.act = CRAB_ACT_SWIGLU_PAIR;
+        g.u_ready = ahead ? io->u2 : nullptr;
+        if ((rc = run_group(ctx, stream, &L->gu, &t, L, B, g, nullptr, nullptr))) return rc;
+        GroupCall w{};
+        w.x = io->act; w.ldx = io->ldact; w.out = t.x; w.ldc = t.ldx; w.residual = t.x; w.ldr = t.ldx; w.act = CRAB_ACT_NONE;
+        w.norm_w = L->next_norm_w; w.norm_out = io->h; w.ld_norm = io->ldh; w.eps = L->rms_eps;
+        if ((rc = run_group(ctx, stream, &L->down, &t, L, B, w, nullptr, nullptr))) return rc;
+        io->u_qkv_ready = 0;
+        return CRAB_OK;
+    }
     if (prefill) {
         // fused_rope 1: q and k already rotated (k in the cache) by the projection's epilogue, only the v columns are left (cache append + V^T);
         // 2: those too
@@ -234,8 +272,14 @@ int crab_llama_layers(crab_ctx* ctx, void* stream, const crab_llama_layer* layer
         int rc = check_io(ctx, &layers[l], io, prefill);
         if (rc) return rc;
     }
+    const bool last_rows = prefill && io->last_rows_only != 0;
+    if (last_rows) {
+        const crab_llama_layer* L = &layers[n_layers - 1];
+        if (io->S <= 1 || io->ldact < L->H * L->d || (io->ldact & 7) || (int64_t)io->B * io->S * io->ldqkv * 2 < (int64_t)io->B * L->o.N * (io->x_fp32 ? 4 : 2))
+            return crab_fail(ctx, CRAB_E_INVALID, "llama_layers: last_rows_only needs S > 1, ldact >= H d (multiple of 8) and qkv storage of at least B rows of the residual stream");
+    }
     for (int l = 0; l < n_layers; ++l) {
-        int rc = run_layer(ctx, stream, &layers[l], io, l, prefill);
+        int rc = run_layer(ctx, stream, &layers[l], io, l, prefill, last_rows && l == n_layers - 1);
         if (rc) return rc;
     }
     return CRAB_OK;

@@ -26,6 +26,10 @@ from . import _lib, ops
 from .peft_hyper import PackedLinearGroup
 
 BF16 = torch.bfloat16
+# generate()'s prefill needs one row per sequence after the last layer: its attention / o_proj / MLP run for the last rows only (crab_llama_io.last_rows_only;
+# the reference computes all S rows and lm_head drops S - 1 of them, modeling_llama.py:1260).  CRAB_PREFILL_LAST_ROWS=0: every row through every layer (A/B runs).
+import os as _os
+LAST_ROWS_ONLY = _os.environ.get("CRAB_PREFILL_LAST_ROWS", "1") != "0"
 RAGGED_PAD_MAX = 0.06     # a coalesced wave whose batches differ in length is prefilled as ONE padded batch while the padding costs at most this fraction of the prefill rows
 NATIVE_LAYERS = True      # False: issue every launch of a layer from Python (A/B runs and the sequencer-equivalence tests)
 
@@ -379,7 +383,7 @@ class GenerationEngine:
 
     def _layers_native(self, ws: _Workspace, B: int, S: int, kc: torch.Tensor, vc: torch.Tensor, b0: int, Tmax: int, pos0: int,
                        pos_dev: Optional[torch.Tensor], vt: Optional[torch.Tensor], t0: int = 0, row_off: Optional[torch.Tensor] = None,
-                       pos_ids: Optional[torch.Tensor] = None, kv_start: Optional[torch.Tensor] = None):
+                       pos_ids: Optional[torch.Tensor] = None, kv_start: Optional[torch.Tensor] = None, last_rows: bool = False):
         """The whole stack through ONE C call (crab_llama_layers, csrc/llama_layer.hip): the same launches in the same order as the
         per-launch Python sequence below, which is kept for the runs that time individual kernels (ops.PROFILER)."""
         io = _lib.LlamaIO()
@@ -402,18 +406,22 @@ class GenerationEngine:
             io.attn_ws, io.attn_ws_bytes = ws.attn_ws.data_ptr(), ws.attn_ws.numel()
         io.B, io.S, io.Tmax, io.pos0, io.u_qkv_ready = B, S, Tmax, pos0, 0
         io.x_fp32 = 1 if ws.x.dtype == torch.float32 else 0
+        io.last_rows_only = 1 if last_rows else 0
         ops.llama_layers(self._layer_table(), len(self.model.layers), io, self.device)
 
     # ------------------------------------------------------------------ one pass over the layers
     def _layers(self, ws: _Workspace, B: int, S: int, kc: torch.Tensor, vc: torch.Tensor, b0: int, Tmax: int, pos0: int,
                 pos_dev: Optional[torch.Tensor], vt: Optional[torch.Tensor], pos_ids: Optional[torch.Tensor] = None,
                 kv_start: Optional[torch.Tensor] = None, key_mask: Optional[torch.Tensor] = None, t0: int = 0,
-                row_off: Optional[torch.Tensor] = None):
+                row_off: Optional[torch.Tensor] = None, last_rows: bool = False):
         """x (ws.x[:B*S]) -> x after all layers.  Prefill when vt is given (S rows per sequence, positions pos0..),
         decode otherwise (S == 1, position read from pos_dev).  kc/vc: [L, Btot, Hk, Tmax, d]; rows b0..b0+B.
         The RAGGED decode batch (generate_many(coalesce=True)): sequences of different prompt lengths are right-aligned in one cache - a
         prefill writes its rows to slots t0 .. t0 + S - 1 (rotary positions still 0 .. S - 1: only the cache pointers move), a decode step
         gets row_off (int32 [B]: first slot of every sequence) = per-row rotary offset + first visible key.
+        last_rows (prefill): the caller reads ONE row per sequence after the last layer (generate()): the returned h then holds, in its first
+        B rows, rmsnorm(last row of sequence b) * model.norm - the last layer ran its attention / o_proj / MLP for those rows only
+        (crab_llama_io.last_rows_only; _last_layer_last_rows is the per-launch form) - and x is not updated for the last layer.
         pos_ids (int32 [B, S]) / kv_start (int32 [B]) / key_mask (int32 [B, words], ops.pack_key_mask): forward()'s position_ids and
         attention_mask (unified_llama.py:149-160) - explicit rotary positions, a per-sequence first visible key (left padding) or a
         visibility bit per key (any other mask); they select the per-launch sequence below (RoPE as its own pass), which is not the
@@ -436,8 +444,9 @@ class GenerationEngine:
         # mask and the masked one-token step of forward() stay on the per-launch sequence below
         native_ok = key_mask is None and (not masked or (vt is not None and pos_dev is None and
                                                          (pos_ids is None or (pos_ids.dtype == torch.int32 and pos_ids.stride(1) == 1))))
+        last_rows = bool(last_rows) and vt is not None and S > 1 and key_mask is None and pos_dev is None
         if NATIVE_LAYERS and not timed and native_ok and contig and (vt is not None or S == 1):
-            self._layers_native(ws, B, S, kc, vc, b0, Tmax, pos0, pos_dev, vt, t0, row_off, pos_ids, kv_start)
+            self._layers_native(ws, B, S, kc, vc, b0, Tmax, pos0, pos_dev, vt, t0, row_off, pos_ids, kv_start, last_rows)
             return x, h
         u_qkv = None                                   # router output for the q|k|v group when a producer epilogue made it
         # small batch: the projection leaves its raw row, ONE launch does RoPE + KV append + split-context attention (as csrc/llama_layer.hip)
@@ -449,6 +458,9 @@ class GenerationEngine:
             lcontig = kcl.is_contiguous()
             if t0:                                         # same strides, first slot t0: the kernels take the pointer and Tmax
                 kcl, vcl = kcl[:, :, t0:], vcl[:, :, t0:]
+            if last_rows and li + 1 == len(layers):
+                self._last_layer_last_rows(ws, layer, B, S, kcl, vcl, lcontig, Tmax, pos0, vt, pos_ids, kv_start, u_qkv)
+                return x, h
             if fuse_attn:
                 a._qkv(h, out=qkv, t_buf=ws.t, u_buf=ws.u, u_ready=u_qkv)
             elif vt is None and S == 1 and lcontig and not masked:
@@ -494,6 +506,44 @@ class GenerationEngine:
             u_qkv = ws.u2 if ahead_q else None
         return x, h
 
+    def _last_layer_last_rows(self, ws, layer, B, S, kcl, vcl, lcontig, Tmax, pos0, vt, pos_ids, kv_start, u_qkv):
+        """Per-launch form of crab_llama_io.last_rows_only (csrc/llama_layer.hip, same launches, same buffers): q|k|v for all rows, then the last
+        row of every sequence through attention (one query row over the S cached keys), o_proj, the MLP and model.norm -> ws.h[0:B]."""
+        c = self.cfg
+        H, Hk, d = c.num_attention_heads, c.num_key_value_heads, c.head_dim
+        D = c.hidden_size
+        M = B * S
+        a, m = layer.self_attn, layer.mlp
+        h, qkv = ws.h[:M], ws.qkv[:M]
+        tab = self._rope_tab(Tmax)
+        ldq = qkv.stride(0)
+        if lcontig:
+            gi = {}
+            a._qkv(h, out=qkv, t_buf=ws.t, u_buf=ws.u, u_ready=u_qkv, rope=(tab, kcl, vcl, H, Hk, d, Tmax, pos0, None, S, pos_ids, vt), info=gi)
+            if gi.get("fused_prefill_rope") == 1:
+                ops.qkv_rope_split(qkv, None, None, vcl, None, B, S, H, Hk, d, Tmax, pos0=pos0)
+            elif gi.get("fused_prefill_rope") != 2:
+                ops.qkv_rope_split(qkv, tab, kcl, vcl, None, B, S, H, Hk, d, Tmax, pos0=pos0, pos_ids=pos_ids)
+        else:
+            a._qkv(h, out=qkv, t_buf=ws.t, u_buf=ws.u, u_ready=u_qkv)
+            ops.qkv_rope_split(qkv, tab, kcl, vcl, None, B, S, H, Hk, d, Tmax, pos0=pos0, pos_ids=pos_ids)
+        ql = ws.act[:B]
+        ops.copy_rows(qkv[S - 1:], ql, B, H * d, lds=S * ldq)                      # the rotated q of the last rows
+        attl = ws.att[:B]
+        ops.attn_decode(ql, kcl, vcl, attl, B, H, Hk, d, Tmax, pos0 + S, 1.0 / math.sqrt(d), kv_start=kv_start)
+        # the residual rows of the last tokens, gathered into qkv's storage
+        x = ws.x[:M]
+        words = 2 * D if x.dtype == torch.float32 else D
+        xl = ws.qkv.view(-1)[: B * words].view(B, words)                          # bf16 words: [B, D] fp32 rows when the stream is fp32
+        ops.copy_rows(x.view(BF16)[S - 1:], xl, B, words, lds=S * x.view(BF16).stride(0))
+        xl = xl.view(x.dtype) if x.dtype == torch.float32 else xl
+        hl, actl = ws.h[:B], ws.act[:B]
+        ahead = m._gu.routes_ahead(B)
+        a._o(attl, residual=xl, out=xl, t_buf=ws.t, u_buf=ws.u, post_norm=(layer.post_attention_layernorm.weight, c.rms_norm_eps, hl),
+             route_next=(m._gu, ws.u2) if ahead else None)
+        m._gu(hl, out=actl, t_buf=ws.t, u_buf=ws.u, act="swiglu_pair", u_ready=ws.u2 if ahead else None)
+        m._down(actl, residual=xl, out=xl, t_buf=ws.t, u_buf=ws.u, post_norm=(self.model.norm.weight, c.rms_norm_eps, hl))
+
     # ------------------------------------------------------------------ prefill
     def prefill(self, embeds: torch.Tensor, kc: torch.Tensor, vc: torch.Tensor, b0: int = 0, all_logits: bool = False,
                 logits_out: Optional[torch.Tensor] = None, hn_out: Optional[torch.Tensor] = None,
@@ -513,7 +563,15 @@ class GenerationEngine:
         ops.cast_rows(embeds.reshape(M, D), ws.x, M, D)          # bf16 inputs_embeds -> the (fp32) residual stream
         Sp = (S + 7) // 8 * 8
         vt = torch.empty((B, c.num_key_value_heads, c.head_dim, Sp), device=self.device, dtype=BF16)
-        x, hfin = self._layers(ws, B, S, kc, vc, b0, Tmax, 0, None, vt, pos_ids=pos_ids, kv_start=kv_start, key_mask=key_mask, t0=t0)   # hfin = model.norm(x), all rows
+        last_rows = (LAST_ROWS_ONLY and not all_logits and S > 1 and key_mask is None and
+                     c.intermediate_size >= c.num_attention_heads * c.head_dim and c.intermediate_size % 8 == 0)      # (the q rows are staged in act's first B rows)
+        x, hfin = self._layers(ws, B, S, kc, vc, b0, Tmax, 0, None, vt, pos_ids=pos_ids, kv_start=kv_start, key_mask=key_mask, t0=t0,
+                               last_rows=last_rows)                       # hfin = model.norm(x): all rows, or the B last rows in hfin[0:B]
+        if last_rows:
+            hn = hn_out if hn_out is not None else torch.empty((B, D), device=self.device, dtype=BF16)
+            ops.copy_rows(hfin, hn, B, D)
+            logits = ops.gemm(hn, self.lm_head.weight, out=logits_out, out_fp32=True)
+            return logits, hn
         if all_logits:
             hn = hfin.clone()
             logits = ops.gemm(hn, self.lm_head.weight, out_fp32=True, prof_class="head")

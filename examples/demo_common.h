@@ -130,8 +130,13 @@ static int run_decoder(void* embeds, const char* outpath, int D, int I, int L, i
     CRAB_OK_(crab_cast_rows_bf16_f32(ctx, stream, embeds, D, (float*)io.x, D, Mp, D));
     CRAB_OK_(crab_rmsnorm_f32(ctx, stream, (const float*)io.x, D, ln_in[0], io.h, D, Mp, D, eps));
     io.B = B; io.S = S; io.vt = vt; io.vt_ld = Sp; io.pos_dev = NULL; io.u_qkv_ready = 0;
+    /* lm_head needs one row per sequence: the last layer runs its attention / o_proj / MLP for the B last rows only and leaves
+     * rmsnorm(x_last) * model.norm in h[0:B] (crab_llama_io.last_rows_only, ABI 9; what crab_amd/decoder.py::prefill does for generate()) */
+    io.last_rows_only = S > 1 ? 1 : 0;
     CRAB_OK_(crab_llama_layers(ctx, stream, layers, L, &io));
-    CRAB_OK_(crab_copy_rows(ctx, stream, (const uint16_t*)io.h + (size_t)(S - 1) * D, (int64_t)S * D, hn, D, B, D));
+    if (io.last_rows_only) CRAB_OK_(crab_copy_rows(ctx, stream, io.h, D, hn, D, B, D));
+    else CRAB_OK_(crab_copy_rows(ctx, stream, (const uint16_t*)io.h + (size_t)(S - 1) * D, (int64_t)S * D, hn, D, B, D));
+    io.last_rows_only = 0;
     CRAB_OK_(crab_gemm_bf16(ctx, stream, &head));
     {
         int32_t p0 = S - 1;

@@ -401,6 +401,15 @@ typedef struct {
      * own call, and its cache rows land where the ragged decode batch (row_off = kv_start) expects them.  NULL = positions pos0 + s, no mask. */
     const int32_t* pos_ids; int64_t ld_pos;
     const int32_t* kv_start;
+    /* optional, PREFILL through crab_llama_layers only (ABI 9): the caller needs nothing but the LAST row of every sequence after the last
+     * layer (generate(): lm_head reads one row per sequence; the reference computes all S and drops S - 1, modeling_llama.py:1260).  The last
+     * layer then projects q|k|v for all rows (the cache needs every row's k / v) and runs attention, o_proj, the MLP and the final norm for
+     * the B last rows only, as a one-row-per-sequence step (crab_attn_decode over the S cached keys, the decode-regime GEMMs): the other
+     * S - 1 rows of the last layer's attention / MLP are dead compute (2.6 % of a 32-layer prefill).  Out: h[b, :] (row b of h, b < B) =
+     * rmsnorm(x_last_row_of_sequence_b) * next_norm_w; x is NOT updated for the last layer; att, act, qkv, h are scratch as before (their
+     * first B rows and qkv's storage are reused).  Needs S > 1, M = B * S rows of act with ldact >= H * d, qkv storage >= B * D * 4 bytes
+     * (true for every decoder: M * ldqkv * 2 bytes).  0: every row through every layer (forward(): all logits). */
+    int32_t last_rows_only;
 } crab_llama_io;
 
 int crab_sizeof_llama_layer(void);

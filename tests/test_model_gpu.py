@@ -1125,3 +1125,34 @@ def test_harness_run_inference_coalesced(tmp_path):
     c = harness.run_inference(with_meta(loop), model, Tok(), coalesce=True, in_flight=5, **kw)
     assert [r["instruction"] for r in a] == [r["instruction"] for r in b] == [r["instruction"] for r in c] and len(a) == 7
     assert [r["predict"] for r in a] == [r["predict"] for r in b] == [r["predict"] for r in c]
+
+
+@pytest.mark.parametrize("fixture", ["full_tiny_llama", "full_tiny_qwen"])
+def test_prefill_last_rows_only_equals_the_full_last_layer(fixture):
+    """generate()'s prefill runs the LAST layer's attention / o_proj / MLP for the last row of every sequence only (crab_llama_io.last_rows_only:
+    lm_head reads one row per sequence, the reference computes all S and drops S - 1, modeling_llama.py:1260).  Against the full last layer
+    (CRAB_PREFILL_LAST_ROWS=0 = decoder.LAST_ROWS_ONLY False): the same ids, the first-step logits within what another kernel regime of the same
+    rows costs (the B last rows go through the decode-regime GEMMs and the one-row attention instead of the prefill tiles), the KV cache of the
+    last layer bit-identical (it is written by the same q|k|v projection), and both against the reference-recorded fixture."""
+    from crab_amd import decoder
+    meta, A, model, batches = _coalesce_setup(fixture)
+    um = model.base_model.model
+    eng = um._engine
+    n = meta["new_tokens"]
+    emb = um.prepare_multimodal_inputs(**batches[1])["inputs_embeds"]            # the left-padded batch of 2
+    outs = {}
+    for on in (True, False):
+        decoder.LAST_ROWS_ONLY = on
+        try:
+            eng.invalidate()
+            ids, logits = eng.generate(emb, n, eos_token_id=None, pad_token_id=2, return_step_logits=True)
+            kc = eng._kv[(0,)][0][-1].clone()                                     # last layer's K cache
+            outs[on] = (ids.cpu(), logits.float().cpu(), kc[:, :, : emb.shape[1]].clone())
+        finally:
+            decoder.LAST_ROWS_ONLY = True
+    assert torch.equal(outs[True][0], outs[False][0])
+    assert torch.equal(outs[True][2], outs[False][2]), "the last layer's prompt K rows differ"
+    assert _rel(outs[True][1], outs[False][1], f"{fixture}: last-rows-only prefill vs the full last layer, per-step logits (HIP vs HIP)") < REL_DEC
+    for on in (True, False):
+        err = _check_ids(outs[on][0], A["ids_bs2"], A["logits_bs2"], outs[on][1])
+        assert err < REL_DEC * A["logits_bs2"].abs().max().item(), (on, err)
