@@ -647,7 +647,7 @@ def _layer_prefill_and_decode_step(fixture, qwen):
     eng = um._engine
     S, D = A["layer_x"].shape[1], A["layer_x"].shape[2]
     kc, vc = eng.alloc_cache(1, 64)
-    eng.prefill(A["layer_x"].to(BF).cuda(), kc, vc, b0=0)
+    eng.prefill(A["layer_x"].to(BF).cuda(), kc, vc, b0=0, all_logits=True)      # every row through the layer (generate()'s prefill finishes the last rows only)
     ws = eng._workspace(S)
     assert _rel(ws.x[:S], A["layer_y"][0], f"{fixture}: layer output, prefill") < REL_DEC
     assert _rel(kc[0, 0, :, :S], A["cache_k"][0][:, :S], f"{fixture}: K cache rows, prefill") < 1.2e-2
