@@ -39,6 +39,7 @@ class GemmDesc(C.Structure):
         ("rope_vt", C.c_void_p), ("rope_vt_ld", C.c_int64),
         ("r_fp32", C.c_int32),
         ("rope_row_off", C.c_void_p),
+        ("norm_w_fp32", C.c_int32),
     ]
 
 
@@ -105,6 +106,7 @@ class LlamaLayer(C.Structure):
         ("qkv", LinearGroup), ("o", LinearGroup), ("gu", LinearGroup), ("down", LinearGroup),
         ("post_attention_norm_w", C.c_void_p), ("next_norm_w", C.c_void_p), ("next_qkv", C.POINTER(LinearGroup)),
         ("H", C.c_int32), ("Hk", C.c_int32), ("d", C.c_int32), ("rms_eps", C.c_float),
+        ("norm_w_fp32", C.c_int32),
     ]
 
 
@@ -165,6 +167,7 @@ SYMBOLS = {
     "crab_embedding_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i]),
     "crab_rmsnorm_f32": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _i64, _i, _i, _f]),
     "crab_layernorm_f32": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _f]),
+    "crab_rmsnorm_p": (_i, [_vp, _vp, _vp, _i, _i64, _vp, _i, _vp, _i64, _i, _i, _f]),
     "crab_layernorm_p": (_i, [_vp, _vp, _vp, _i, _i64, _vp, _vp, _i, _vp, _i64, _i, _i, _f]),
     "crab_clip_embed_ln_p": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _f]),
     "crab_cast_rows_bf16_f32": (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _i, _i]),

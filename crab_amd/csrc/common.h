@@ -30,6 +30,19 @@ __device__ __forceinline__ float hi_bf(uint32_t w) { return __uint_as_float(w & 
 // Eight consecutive NORM PARAMETERS (LayerNorm weight / bias) starting at element e (a multiple of 8): bf16 storage (one 16-byte load) or,
 // WF, fp32 storage (two) - the non-matrix parameters of the encoders may stay in fp32 (crab_ln.fp32): they are not MFMA operands, and their
 // bf16 rounding is a systematic 2^-9 relative error on every channel of every LayerNorm output (scripts/parity_floor.py).
+// four consecutive parameters (8-byte bf16 load | 16-byte fp32 load)
+template <bool WF>
+__device__ __forceinline__ void ld_par4(const void* p, long e, float (&o)[4]) {
+    if (WF) {
+        const f32x4_t a = *reinterpret_cast<const f32x4_t*>(reinterpret_cast<const float*>(p) + e);
+        o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3];
+    } else {
+        typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_;
+        const u32x2_ v = *reinterpret_cast<const u32x2_*>(reinterpret_cast<const uint16_t*>(p) + e);      // one 8-byte load
+        o[0] = lo_bf(v[0]); o[1] = hi_bf(v[0]); o[2] = lo_bf(v[1]); o[3] = hi_bf(v[1]);
+    }
+}
+
 template <bool WF>
 __device__ __forceinline__ void ld_par8(const void* p, long e, float (&o)[8]) {
     if (WF) {

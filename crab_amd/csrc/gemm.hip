@@ -251,11 +251,11 @@ struct RouteP {                                   // router of the next projecti
 // (LlamaRMSNorm, modeling_llama.py:112-117, fused behind o_proj / down_proj in the decode regime).  N <= 8192.
 // XF: R and C are the FP32 residual stream (ldr / ldc in fp32 elements): the row is stored unrounded, the norm sees that fp32 row and the
 // normalised row is bf16(x * rstd * w) without the intermediate rounding of x_hat.
-template <bool XF>
+template <bool XF, bool WF = false>                           // WF: the norm weight is fp32 (crab_gemm_desc.norm_w_fp32)
 __global__ __launch_bounds__(256) void splitk_epilogue_norm_kernel(const float* __restrict__ part, int S, int M, int N,
                                                                     const bf16_t* __restrict__ bias, int act, const bf16_t* __restrict__ R,
                                                                     long ldr, float res_scale, bf16_t* __restrict__ C, long ldc,
-                                                                    const bf16_t* __restrict__ nw, float eps, bf16_t* __restrict__ H, long ldh,
+                                                                    const void* __restrict__ nw, float eps, bf16_t* __restrict__ H, long ldh,
                                                                     RouteP rt) {
     __shared__ float red[4];
     const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -332,10 +332,11 @@ __global__ __launch_bounds__(256) void splitk_epilogue_norm_kernel(const float* 
     for (int q = 0; q < MAXQ; ++q) {
         const int n = (tid + q * 256) * 8;
         if (n < N) {
-            const u32x4 wv = *reinterpret_cast<const u32x4*>(nw + n);
+            float wv[8];
+            ld_par8<WF>(nw, (long)n, wv);
             float h8[8];
 #pragma unroll
-            for (int r = 0; r < 8; ++r) h8[r] = (XF ? xv[q][r] * rstd : bf2f(f2bf(xv[q][r] * rstd))) * ((r & 1) ? hi_bf(wv[r >> 1]) : lo_bf(wv[r >> 1]));
+            for (int r = 0; r < 8; ++r) h8[r] = (XF ? xv[q][r] * rstd : bf2f(f2bf(xv[q][r] * rstd))) * wv[r];
             u32x4 o;
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[r] = pack_bf2(h8[2 * r], h8[2 * r + 1]);
@@ -605,20 +606,20 @@ static int launch_norm_epilogue(crab_ctx* ctx, hipStream_t s, const crab_gemm_de
         rf.RA = (const bf16_t*)d->route_RA; rf.U = (bf16_t*)d->route_U; rf.ldra = d->route_ldra; rf.ldu = d->route_ldu;
         rf.nproj = d->route_nproj; rf.nl = d->route_nl; rf.r = d->route_r; rf.ucols = d->route_ucols; rf.scaling = d->route_scaling;
         const int P = (rf.RA && rf.nproj > 1 && rf.nl + rf.r == 11) ? rf.nproj : 1;
-#define NE_LAUNCH(XF_) hipLaunchKernelGGL((splitk_epilogue_norm_kernel<XF_>), dim3(d->M, P), dim3(256), 0, s, part, splitk, d->M, d->N, (const bf16_t*)nullptr, ACT_NONE, \
-                           (const bf16_t*)nullptr, 0L, 1.0f, (bf16_t*)d->C, (long)d->ldc, (const bf16_t*)d->norm_w, d->norm_eps,                      \
+#define NE_LAUNCH(XF_, WF_) hipLaunchKernelGGL((splitk_epilogue_norm_kernel<XF_, WF_>), dim3(d->M, P), dim3(256), 0, s, part, splitk, d->M, d->N, (const bf16_t*)nullptr, ACT_NONE, \
+                           (const bf16_t*)nullptr, 0L, 1.0f, (bf16_t*)d->C, (long)d->ldc, d->norm_w, d->norm_eps,                      \
                            (bf16_t*)d->norm_out, (long)d->ld_norm, rf)
-        if (d->c_fp32) NE_LAUNCH(true); else NE_LAUNCH(false);
+        if (d->norm_w_fp32) NE_LAUNCH(true, true); else if (d->c_fp32) NE_LAUNCH(true, false); else NE_LAUNCH(false, false);
 #undef NE_LAUNCH
         return crab_check_launch(ctx, "splitk_epilogue_norm_kernel");
     }
     RouteP rt;
     rt.RA = (const bf16_t*)d->route_RA; rt.U = (bf16_t*)d->route_U; rt.ldra = d->route_ldra; rt.ldu = d->route_ldu;
     rt.nproj = d->route_nproj; rt.nl = d->route_nl; rt.r = d->route_r; rt.ucols = d->route_ucols; rt.scaling = d->route_scaling;
-#define NE_LAUNCH(XF_) hipLaunchKernelGGL((splitk_epilogue_norm_kernel<XF_>), dim3(d->M), dim3(256), 0, s, part, splitk, d->M, d->N, (const bf16_t*)d->bias, d->act, \
-                       (const bf16_t*)d->R, (long)d->ldr, d->res_scale, (bf16_t*)d->C, (long)d->ldc, (const bf16_t*)d->norm_w, d->norm_eps,             \
+#define NE_LAUNCH(XF_, WF_) hipLaunchKernelGGL((splitk_epilogue_norm_kernel<XF_, WF_>), dim3(d->M), dim3(256), 0, s, part, splitk, d->M, d->N, (const bf16_t*)d->bias, d->act, \
+                       (const bf16_t*)d->R, (long)d->ldr, d->res_scale, (bf16_t*)d->C, (long)d->ldc, d->norm_w, d->norm_eps,             \
                        (bf16_t*)d->norm_out, (long)d->ld_norm, rt)
-    if (d->c_fp32) NE_LAUNCH(true); else NE_LAUNCH(false);
+    if (d->norm_w_fp32) NE_LAUNCH(true, true); else if (d->c_fp32) NE_LAUNCH(true, false); else NE_LAUNCH(false, false);
 #undef NE_LAUNCH
     return crab_check_launch(ctx, "splitk_epilogue_norm_kernel");
 }
@@ -630,8 +631,7 @@ static int post_norm(crab_ctx* ctx, void* stream, const crab_gemm_desc* d) {
         return crab_qkv_rope_split_ragged(ctx, stream, d->C, d->ldc, d->rope_tab, d->rope_k_cache, d->rope_v_cache, nullptr, 0, d->M, 1, d->rope_H,
                                           d->rope_Hk, d->rope_d, d->rope_Tmax, d->rope_pos0, d->rope_pos_dev, d->rope_row_off);
     if (!d->norm_w) return CRAB_OK;
-    int rc = d->c_fp32 ? crab_rmsnorm_f32(ctx, stream, (const float*)d->C, d->ldc, d->norm_w, d->norm_out, d->ld_norm, d->M, d->N, d->norm_eps)
-                       : crab_rmsnorm(ctx, stream, d->C, d->ldc, d->norm_w, d->norm_out, d->ld_norm, d->M, d->N, d->norm_eps);
+    int rc = crab_rmsnorm_p(ctx, stream, d->C, d->c_fp32, d->ldc, d->norm_w, d->norm_w_fp32, d->norm_out, d->ld_norm, d->M, d->N, d->norm_eps);
     if (rc || !d->route_RA) return rc;
     return crab_hyperlora_route(ctx, stream, d->norm_out, d->ld_norm, d->route_RA, d->route_ldra, d->M, d->N, d->route_nproj, d->route_nl,
                                 d->route_r, d->route_U, d->route_ldu, d->route_ucols, d->route_scaling, d->workspace, d->workspace_bytes);
@@ -646,6 +646,8 @@ extern "C" int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc*
         return crab_fail(ctx, CRAB_E_INVALID, "gemm: r_fp32 needs R (16-byte aligned, ldr % 4 == 0), no batch");
     if (d && d->norm_w && d->R && (!!d->c_fp32 != !!d->r_fp32))
         return crab_fail(ctx, CRAB_E_INVALID, "gemm: with a post-norm R and C must have the same storage (both bf16, or c_fp32 = r_fp32 = 1)");
+    if (d && d->norm_w && d->norm_w_fp32 && (!d->c_fp32 || ((uintptr_t)d->norm_w & 15)))
+        return crab_fail(ctx, CRAB_E_INVALID, "gemm: norm_w_fp32 needs the fp32 residual stream (c_fp32) and a 16-byte aligned norm_w");
     if (d && d->norm_w && d->c_fp32 && ((d->ldc & 3) || ((uintptr_t)d->C & 15)))
         return crab_fail(ctx, CRAB_E_INVALID, "gemm: an fp32 C under a post-norm needs 16-byte aligned rows");
     if (!d || !d->A || !d->B || !d->C) return crab_fail(ctx, CRAB_E_INVALID, "gemm: null operand");

@@ -63,7 +63,7 @@ int run_group(crab_ctx* ctx, void* stream, const crab_linear_group* g, const cra
     d.res_scale = 1.0f;
     d.batch = 1; d.nb0 = 1;
     if (M <= CRAB_DECODE_MAX_ROWS) { d.workspace = io->splitk_ws; d.workspace_bytes = io->splitk_ws_bytes; }
-    if (c.norm_w) { d.norm_w = c.norm_w; d.norm_out = c.norm_out; d.ld_norm = c.ld_norm; d.norm_eps = c.eps; }
+    if (c.norm_w) { d.norm_w = c.norm_w; d.norm_out = c.norm_out; d.ld_norm = c.ld_norm; d.norm_eps = c.eps; d.norm_w_fp32 = L->norm_w_fp32; }
     if (c.route_next && c.route_next->RA && c.norm_w && M <= CRAB_DECODE_MAX_ROWS) {
         const crab_linear_group* n = c.route_next;
         d.route_RA = n->RA; d.route_ldra = n->ldra; d.route_U = c.route_u; d.route_ldu = io->ldu;
@@ -106,6 +106,7 @@ int check_io(crab_ctx* ctx, const crab_llama_layer* L, const crab_llama_io* io, 
     if (!L || !io) return crab_fail(ctx, CRAB_E_INVALID, "llama_layer: null layer / io");
     if (L->H <= 0 || L->Hk <= 0 || L->d <= 0 || L->H % L->Hk) return crab_fail(ctx, CRAB_E_INVALID, "llama_layer: H, Hk, d must be positive, H % Hk == 0");
     if (!L->post_attention_norm_w || !L->next_norm_w) return crab_fail(ctx, CRAB_E_INVALID, "llama_layer: post_attention_norm_w / next_norm_w missing");
+    if (L->norm_w_fp32 && !io->x_fp32) return crab_fail(ctx, CRAB_E_INVALID, "llama_layer: fp32 norm weights need the fp32 residual stream (x_fp32)");
     int rc;
     if ((rc = check_group(ctx, &L->qkv, "qkv")) || (rc = check_group(ctx, &L->o, "o")) || (rc = check_group(ctx, &L->gu, "gate|up")) ||
         (rc = check_group(ctx, &L->down, "down")))

@@ -781,6 +781,11 @@ int crab_layernorm_f32(crab_ctx* ctx, void* stream, const float* x, int64_t ldx,
     return norm_launch(ctx, stream, "layernorm_f32", x, 1, ldx, w, b, 0, y, ldy, M, D, eps, false);
 }
 
+int crab_rmsnorm_p(crab_ctx* ctx, void* stream, const void* x, int x_fp32, int64_t ldx, const void* w, int w_fp32, void* y, int64_t ldy, int M,
+                   int D, float eps) {
+    return norm_launch(ctx, stream, "rmsnorm_p", x, x_fp32 ? 1 : 0, ldx, w, nullptr, w_fp32 ? 1 : 0, y, ldy, M, D, eps, true);
+}
+
 int crab_layernorm_p(crab_ctx* ctx, void* stream, const void* x, int x_fp32, int64_t ldx, const void* w, const void* b, int w_fp32, void* y,
                      int64_t ldy, int M, int D, float eps) {
     return norm_launch(ctx, stream, "layernorm_p", x, x_fp32 ? 1 : 0, ldx, w, b, w_fp32 ? 1 : 0, y, ldy, M, D, eps, false);

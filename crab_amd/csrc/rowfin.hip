@@ -42,10 +42,10 @@ struct RowfinApplyP {
     // RP instantiation (r04, the two-launch tail without an arrival chain): the NEXT group's router partials are formed HERE, on the un-normalised
     // row times the norm weight - t = rstd * ((y (.) w) . [R;A]^T), rstd being a per-row scalar the second launch applies - so that the second
     // launch has nothing to wait for (rowfin_norm_mix_kernel)
-    const bf16_t* nw; const bf16_t* RA; long ldra; int used; float* tpart;
+    const void* nw; const bf16_t* RA; long ldra; int used; float* tpart;      // nw: bf16, or fp32 in the WF instantiations (crab_gemm_desc.norm_w_fp32)
 };
 
-template <bool XF, bool RP = false>
+template <bool XF, bool RP = false, bool WF = false>
 __global__ __launch_bounds__(256) void rowfin_apply_kernel(RowfinApplyP p) {
     __shared__ uint32_t b2s[RF_CW][17];          // lora_B rows of this slice, 32 k columns as 16 words + 1 pad word (conflict-free row walk)
     __shared__ float us[16][32];
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void rowfin_apply_kernel(RowfinApplyP p) {
     f32x4_t y = {0.f, 0.f, 0.f, 0.f};
     if (live) y = *reinterpret_cast<const f32x4_t*>(p.S + (long)m * p.N + c);
     u32x4 rv[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
-    u32x2 ww = {0u, 0u};
+    float ww[4] = {0.f, 0.f, 0.f, 0.f};
     const int used16 = RP ? (p.used + 15) & ~15 : 0;
     if (RP) {                                     // unconditional loads at clamped addresses, masked afterwards (see rowfin_route_kernel)
 #pragma unroll
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void rowfin_apply_kernel(RowfinApplyP p) {
             const int idx = tid + i * 256, j = idx >> 3, ch = idx & 7;
             rv[i] = *reinterpret_cast<const u32x4*>(p.RA + (long)min(j, p.used - 1) * p.ldra + min(c0 + ch * 8, p.N - 8));
         }
-        ww = *reinterpret_cast<const u32x2*>(p.nw + min(c, p.N - 4));
+        ld_par4<WF>(p.nw, min(c, p.N - 4), ww);
     }
     u32x4 bv = {0u, 0u, 0u, 0u};
     float tsum = 0.f;
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void rowfin_apply_kernel(RowfinApplyP p) {
         if (live) {
             float x0 = y[0], x1 = y[1], x2 = y[2], x3 = y[3];
             if (!XF) { x0 = bf2f(f2bf(x0)); x1 = bf2f(f2bf(x1)); x2 = bf2f(f2bf(x2)); x3 = bf2f(f2bf(x3)); }      // the stored bf16 row
-            hv = f32x4_t{x0 * lo_bf(ww[0]), x1 * hi_bf(ww[0]), x2 * lo_bf(ww[1]), x3 * hi_bf(ww[1])};
+            hv = f32x4_t{x0 * ww[0], x1 * ww[1], x2 * ww[2], x3 * ww[3]};
         }
         *reinterpret_cast<f32x4_t*>(&yws[m][q * 4]) = hv;
         __syncthreads();
@@ -172,12 +172,12 @@ __global__ __launch_bounds__(256) void rowfin_apply_kernel(RowfinApplyP p) {
 // the last arriver's acquire + reload of rowfin_route_kernel are gone: 8.4 -> ~4.5 us at one clip).
 struct RowfinMixP {
     const bf16_t* X; long ldx; const float* ssq; int nb;
-    const bf16_t* nw; float eps; bf16_t* H; long ldh;
+    const void* nw; float eps; bf16_t* H; long ldh;
     const float* tpart; bf16_t* U; long ldu; int nproj, nl, r, ucols; float scaling;      // tpart == NULL: no next-group router
     int M, N;
 };
 
-template <bool XF>
+template <bool XF, bool WF = false>
 __global__ __launch_bounds__(256) void rowfin_norm_mix_kernel(RowfinMixP p) {
     __shared__ float rs[16];
     __shared__ float Tg[RF_G][RF_TJ];
@@ -195,7 +195,8 @@ __global__ __launch_bounds__(256) void rowfin_norm_mix_kernel(RowfinMixP p) {
     f32x4_t xf = {0.f, 0.f, 0.f, 0.f};
     if (XF) xf = *reinterpret_cast<const f32x4_t*>(reinterpret_cast<const float*>(p.X) + (long)min(m, p.M - 1) * p.ldx + min(c, p.N - 4));
     else xw = *reinterpret_cast<const u32x2*>(p.X + (long)min(m, p.M - 1) * p.ldx + min(c, p.N - 4));
-    const u32x2 ww = *reinterpret_cast<const u32x2*>(p.nw + min(c, p.N - 4));
+    float ww[4];
+    ld_par4<WF>(p.nw, min(c, p.N - 4), ww);
     const int g = tid >> 6, j = tid & 63;
     float tacc = 0.f;
     int k = blockIdx.x;
@@ -221,11 +222,11 @@ __global__ __launch_bounds__(256) void rowfin_norm_mix_kernel(RowfinMixP p) {
     if (live) {
         float h0, h1, h2, h3;
         if (XF) {
-            h0 = xf[0] * rstd * lo_bf(ww[0]); h1 = xf[1] * rstd * hi_bf(ww[0]);
-            h2 = xf[2] * rstd * lo_bf(ww[1]); h3 = xf[3] * rstd * hi_bf(ww[1]);
+            h0 = xf[0] * rstd * ww[0]; h1 = xf[1] * rstd * ww[1];
+            h2 = xf[2] * rstd * ww[2]; h3 = xf[3] * rstd * ww[3];
         } else {
-            h0 = bf2f(f2bf(lo_bf(xw[0]) * rstd)) * lo_bf(ww[0]); h1 = bf2f(f2bf(hi_bf(xw[0]) * rstd)) * hi_bf(ww[0]);
-            h2 = bf2f(f2bf(lo_bf(xw[1]) * rstd)) * lo_bf(ww[1]); h3 = bf2f(f2bf(hi_bf(xw[1]) * rstd)) * hi_bf(ww[1]);
+            h0 = bf2f(f2bf(lo_bf(xw[0]) * rstd)) * ww[0]; h1 = bf2f(f2bf(hi_bf(xw[0]) * rstd)) * ww[1];
+            h2 = bf2f(f2bf(lo_bf(xw[1]) * rstd)) * ww[2]; h3 = bf2f(f2bf(hi_bf(xw[1]) * rstd)) * ww[3];
         }
         *reinterpret_cast<u32x2*>(p.H + (long)m * p.ldh + c) = u32x2{pack_bf2(h0, h1), pack_bf2(h2, h3)};
     }
@@ -440,6 +441,7 @@ bool crab_rowfin_enabled() {
 
 bool crab_rowfin_ok(const crab_gemm_desc* d) {
     if (!d->norm_w || !d->norm_out || d->M > 16 || !d->workspace) return false;
+    if (d->norm_w_fp32 && (!d->c_fp32 || ((uintptr_t)d->norm_w & 15))) return false;          // fp32 norm weights: with the fp32 residual stream only
     if (d->c_fp32 && (((uintptr_t)d->C & 15) || (d->R && !d->r_fp32))) return false;      // the fp32 residual stream: R and C both fp32
     if ((d->N & 7) || (d->ldc & 3) || (d->ld_norm & 3) || (((uintptr_t)d->C | (uintptr_t)d->norm_out | (uintptr_t)d->norm_w) & 7)) return false;
     if (crab_rowfin_workspace(d->M, d->N) > d->workspace_bytes || d->N > 128 * RF_CW) return false;
@@ -470,25 +472,27 @@ int crab_rowfin_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* d) {
     a.B2 = (const bf16_t*)d->B2; a.ldb2 = d->ldb2; a.k2 = d->K2;
     a.X = (bf16_t*)d->C; a.ldx = d->ldc; a.ssq = ssq; a.counter = counter;
     a.M = d->M; a.N = d->N; a.nl = d->lora_nl; a.r = d->lora_r; a.scaling = d->lora_scaling;
-    a.nw = (const bf16_t*)d->norm_w; a.RA = (const bf16_t*)d->route_RA; a.ldra = d->route_ldra;
+    a.nw = d->norm_w; a.RA = (const bf16_t*)d->route_RA; a.ldra = d->route_ldra;
     a.used = d->route_RA ? d->route_nproj * (d->route_nl + d->route_r) : 0; a.tpart = tpart;
     // CRAB_ROWFIN_TAIL=1: the r03 pair (apply, then the route kernel with its arrival chain) for A/B runs; default: router partials in the first launch,
     // a second launch that waits for nothing
     static const int chain = []() { const char* e = getenv("CRAB_ROWFIN_TAIL"); return e && e[0] == '1' && e[1] == 0; }();
-    if (!chain) {
+    if (!chain || d->norm_w_fp32) {                                    // (the r03 chain pair exists for bf16 norm weights only)
         const bool rp = d->route_RA != nullptr;
-        if (d->c_fp32) { if (rp) hipLaunchKernelGGL((rowfin_apply_kernel<true, true>), dim3(nb), dim3(256), 0, s, a); else hipLaunchKernelGGL((rowfin_apply_kernel<true, false>), dim3(nb), dim3(256), 0, s, a); }
+        if (d->norm_w_fp32) { if (rp) hipLaunchKernelGGL((rowfin_apply_kernel<true, true, true>), dim3(nb), dim3(256), 0, s, a); else hipLaunchKernelGGL((rowfin_apply_kernel<true, false, true>), dim3(nb), dim3(256), 0, s, a); }
+        else if (d->c_fp32) { if (rp) hipLaunchKernelGGL((rowfin_apply_kernel<true, true>), dim3(nb), dim3(256), 0, s, a); else hipLaunchKernelGGL((rowfin_apply_kernel<true, false>), dim3(nb), dim3(256), 0, s, a); }
         else { if (rp) hipLaunchKernelGGL((rowfin_apply_kernel<false, true>), dim3(nb), dim3(256), 0, s, a); else hipLaunchKernelGGL((rowfin_apply_kernel<false, false>), dim3(nb), dim3(256), 0, s, a); }
         int rc0 = crab_check_launch(ctx, "rowfin_apply_kernel");
         if (rc0) return rc0;
         RowfinMixP x;
         x.X = (const bf16_t*)d->C; x.ldx = d->ldc; x.ssq = ssq; x.nb = nb;
-        x.nw = (const bf16_t*)d->norm_w; x.eps = d->norm_eps; x.H = (bf16_t*)d->norm_out; x.ldh = d->ld_norm;
+        x.nw = d->norm_w; x.eps = d->norm_eps; x.H = (bf16_t*)d->norm_out; x.ldh = d->ld_norm;
         x.tpart = rp ? tpart : nullptr; x.U = (bf16_t*)d->route_U; x.ldu = d->route_ldu;
         x.nproj = d->route_nproj; x.nl = d->route_nl; x.r = d->route_r; x.ucols = d->route_ucols; x.scaling = d->route_scaling;
         x.M = d->M; x.N = d->N;
-        if (d->c_fp32) hipLaunchKernelGGL(rowfin_norm_mix_kernel<true>, dim3(nb), dim3(256), 0, s, x);
-        else hipLaunchKernelGGL(rowfin_norm_mix_kernel<false>, dim3(nb), dim3(256), 0, s, x);
+        if (d->norm_w_fp32) hipLaunchKernelGGL((rowfin_norm_mix_kernel<true, true>), dim3(nb), dim3(256), 0, s, x);
+        else if (d->c_fp32) hipLaunchKernelGGL((rowfin_norm_mix_kernel<true, false>), dim3(nb), dim3(256), 0, s, x);
+        else hipLaunchKernelGGL((rowfin_norm_mix_kernel<false, false>), dim3(nb), dim3(256), 0, s, x);
         return crab_check_launch(ctx, "rowfin_norm_mix_kernel");
     }
     if (d->c_fp32) hipLaunchKernelGGL((rowfin_apply_kernel<true, false>), dim3(nb), dim3(256), 0, s, a);

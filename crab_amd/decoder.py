@@ -63,7 +63,7 @@ class DecoderConfig:
 class RMSNorm(nn.Module):
     def __init__(self, dim: int, eps: float, device):
         super().__init__()
-        self.weight = nn.Parameter(torch.ones(dim, device=device, dtype=BF16), requires_grad=False)
+        self.weight = nn.Parameter(torch.ones(dim, device=device, dtype=ops.RMS_DTYPE), requires_grad=False)      # fp32 beside the fp32 residual stream
         self.variance_epsilon = eps
 
 
@@ -378,6 +378,7 @@ class GenerationEngine:
             if not last:
                 e.next_qkv = C.pointer(tab[i + 1].qkv)
             e.H, e.Hk, e.d, e.rms_eps = c.num_attention_heads, c.num_key_value_heads, c.head_dim, c.rms_norm_eps
+            e.norm_w_fp32 = 1 if l.post_attention_layernorm.weight.dtype == torch.float32 else 0
         self._table = (fp, tab)
         return tab
 

@@ -37,6 +37,9 @@ static void* next_bf16(size_t elems) {
     return dev;
 }
 
+/* next `elems` fp32 elements (norm parameters) */
+static void* next_f32(size_t elems) { return next_bf16(elems * 2); }
+
 static void* dev_alloc(size_t bytes) {
     void* p = NULL;
     HIP_OK(hipMalloc(&p, bytes));
@@ -75,11 +78,12 @@ static int run_decoder(void* embeds, const char* outpath, int D, int I, int L, i
         load_group(&layers[l].o, D, H * d, 1, nl, r, 0);
         load_group(&layers[l].gu, 2 * I, D, 2, nl, r, 0);          /* rows interleaved (gate_i, up_i) as crab_amd packs them */
         load_group(&layers[l].down, D, I, 1, nl, r, 0);
-        ln_in[l] = next_bf16(D);
-        layers[l].post_attention_norm_w = next_bf16(D);
+        ln_in[l] = next_f32(D);                                /* RMSNorm weights travel in fp32 (crab_llama_layer.norm_w_fp32, ABI 9) */
+        layers[l].post_attention_norm_w = next_f32(D);
+        layers[l].norm_w_fp32 = 1;
         layers[l].H = H; layers[l].Hk = Hk; layers[l].d = d; layers[l].rms_eps = eps;
     }
-    void* final_norm = next_bf16(D);
+    void* final_norm = next_f32(D);
     void* lm_head = next_bf16((size_t)V * D);
     void* embed_tokens = next_bf16((size_t)V * D);
     for (int l = 0; l < L; ++l) {
@@ -128,7 +132,7 @@ static int run_decoder(void* embeds, const char* outpath, int D, int I, int L, i
 
     /* ---- prefill: x = embeds; h = rmsnorm(x) * layer 0 input_layernorm; all layers; logits of the last row of each sequence */
     CRAB_OK_(crab_cast_rows_bf16_f32(ctx, stream, embeds, D, (float*)io.x, D, Mp, D));
-    CRAB_OK_(crab_rmsnorm_f32(ctx, stream, (const float*)io.x, D, ln_in[0], io.h, D, Mp, D, eps));
+    CRAB_OK_(crab_rmsnorm_p(ctx, stream, io.x, 1, D, ln_in[0], 1, io.h, D, Mp, D, eps));
     io.B = B; io.S = S; io.vt = vt; io.vt_ld = Sp; io.pos_dev = NULL; io.u_qkv_ready = 0;
     /* lm_head needs one row per sequence: the last layer runs its attention / o_proj / MLP for the B last rows only and leaves
      * rmsnorm(x_last) * model.norm in h[0:B] (crab_llama_io.last_rows_only, ABI 9; what crab_amd/decoder.py::prefill does for generate()) */
@@ -165,7 +169,7 @@ static int run_decoder(void* embeds, const char* outpath, int D, int I, int L, i
         if (!exec) {
             if (capture) HIP_OK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
             CRAB_OK_(crab_embedding_f32(ctx, stream, cur_ids, embed_tokens, (float*)io.x, D, B, D, V));
-            CRAB_OK_(crab_rmsnorm_f32(ctx, stream, (const float*)io.x, D, ln_in[0], io.h, D, B, D, eps));
+            CRAB_OK_(crab_rmsnorm_p(ctx, stream, io.x, 1, D, ln_in[0], 1, io.h, D, B, D, eps));
             io.u_qkv_ready = 0;
             CRAB_OK_(crab_llama_layers(ctx, stream, layers, L, &io));
             CRAB_OK_(crab_gemm_bf16(ctx, stream, &head));

@@ -122,6 +122,9 @@ typedef struct {
      * generate() call (models/unified_llama.py:262-267 gives every call of the eval loop positions from 0; scripts/finetune/
      * inference_hyper_lora.py:1466-1479).  NULL = no offsets. */
     const int32_t* rope_row_off;
+    /* norm_w is fp32 [N] (16-byte aligned) instead of bf16 (ABI 9): the RMSNorm weight is not a matrix operand; kept in fp32 it removes a
+     * 2^-9 relative error from every channel of every normalised row.  With the fp32 residual stream only (c_fp32 = r_fp32 = 1). */
+    int32_t norm_w_fp32;
 } crab_gemm_desc;
 
 /* Rows up to which crab_gemm_bf16 treats a problem as WEIGHT-STREAMING (the decode regime: one row per clip) when a workspace is given:
@@ -174,6 +177,9 @@ int crab_layernorm_f32(crab_ctx* ctx, void* stream, const float* x, int64_t ldx,
  * bf16-operand floor).  y is bf16. */
 int crab_layernorm_p(crab_ctx* ctx, void* stream, const void* x, int x_fp32, int64_t ldx, const void* w, const void* b, int w_fp32, void* y,
                      int64_t ldy, int M, int D, float eps);
+/* RMSNorm likewise (the decoder's input_layernorm / post_attention_layernorm / model.norm weights in fp32: crab_llama_layer.norm_w_fp32) */
+int crab_rmsnorm_p(crab_ctx* ctx, void* stream, const void* x, int x_fp32, int64_t ldx, const void* w, int w_fp32, void* y, int64_t ldy,
+                   int M, int D, float eps);
 
 /* out[t,:] = table[ids[t],:]  (embed_tokens; unified_arch.py:213-214, unified_llama.py:125-127).  Rows with ids[t] < 0 are
  * left untouched (the multimodal splice fills them with projector features, unified_arch.py:283-300); ids >= vocab clamp. */
@@ -366,6 +372,7 @@ typedef struct {
     const crab_linear_group* next_qkv;   /* NULL after the last layer */
     int32_t H, Hk, d;
     float rms_eps;
+    int32_t norm_w_fp32;                 /* ABI 9: post_attention_norm_w / next_norm_w are fp32 [D] (needs crab_llama_io.x_fp32); 0: bf16 */
 } crab_llama_layer;
 
 typedef struct {

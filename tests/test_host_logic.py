@@ -38,8 +38,12 @@ def test_module_apply_keeps_views_bound_and_refuses_dtype_changes():
     assert q.lora_A.weight.data_ptr() == g2.RA[g2.nl:].data_ptr()
     with pytest.raises(TypeError):
         model.float()
-    # the refusal happens BEFORE anything is converted: norms / embeddings still bf16, the views still alias the packed buffers
-    assert all(p.dtype == torch.bfloat16 for p in model.parameters())
+    # the refusal happens BEFORE anything is converted: every parameter keeps its storage (bf16; the norm weights fp32 since r05), the views
+    # still alias the packed buffers
+    from crab_amd import ops
+    for name, p in model.named_parameters():
+        want = ops.RMS_DTYPE if (p.dim() == 1 and "norm" in name) else torch.bfloat16
+        assert p.dtype == want, (name, p.dtype)
     q = um.model.layers[0].self_attn.q_proj
     assert q.weight.data_ptr() == um.model.layers[0].self_attn._qkv.W.data_ptr()
 

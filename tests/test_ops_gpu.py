@@ -1036,3 +1036,44 @@ def test_gemm_fused_rope_ragged_rows_rotate_at_their_own_positions(M, H, Hk, bia
     with pytest.raises(Exception):                       # the prefill form has no row offsets (its caller advances the cache pointers)
         kc = torch.zeros(1, Hk, Tmax, d, dtype=BF, device="cuda")
         ops.gemm(x[:1].expand(8, K).contiguous(), w, rope=(tab, kc, kc.clone(), H, Hk, d, Tmax, 0, None, 8, None), rope_row_off=off[:8].cuda())
+
+
+@pytest.mark.parametrize("M", [1, 8, 16, 40, 300, 448, 2048])
+@pytest.mark.parametrize("with_route", [False, True])
+def test_fp32_norm_weights_equal_the_same_values_in_bf16(M, with_route):
+    """crab_gemm_desc.norm_w_fp32 (ABI 9): the RMSNorm weight behind o_proj / down_proj held in fp32.  With bf16-representable VALUES the fp32
+    storage must give bit-identical rows to the bf16 storage in every regime that owns a fused or stand-alone post-norm - the M <= 16 tail
+    (rowfin.hip, with the projection's own adapter riding along), the row-owning split-K reduction (16 < M <= 512, with the next group's router),
+    the stand-alone norm behind the large-M kernels - and with genuinely fp32 values it must match fp32 arithmetic; a bf16 residual stream is refused."""
+    from crab_amd import ops
+    K, N, nl, r = 1024, 2048, 3, 8
+    x, w, res = _rand(M, K, seed=1).cuda(), _rand(N, K, seed=2, scale=K ** -0.5).cuda(), _rand(M, N, seed=3)
+    g = torch.Generator().manual_seed(9)
+    nw16 = (1 + 0.1 * torch.randn(N, generator=g)).to(BF)
+    RA = torch.zeros(16, K, dtype=BF); RA[:nl + r] = _rand(nl + r, K, seed=5, scale=K ** -0.5)
+    B2 = torch.zeros(N, 32, dtype=BF); B2[:, :nl * r] = _rand(N, nl * r, seed=6, scale=0.2)
+    ra_next = _rand(48, N, seed=7, scale=N ** -0.5); ra_next[33:] = 0
+    outs = []
+    for nw in (nw16.cuda(), nw16.float().cuda()):
+        xd = res.float().cuda()
+        h = torch.empty(M, N, dtype=BF, device="cuda")
+        u = torch.zeros((M, 96), dtype=BF, device="cuda")
+        kw = {}
+        if with_route and M <= ops.DECODE_MAX_ROWS:
+            kw["route"] = (ra_next.cuda(), 3, nl, r, 96, 2.0, u)
+        if M <= 16:
+            kw["lora_self"] = (RA.cuda(), nl, r, 2.0, B2.cuda())
+        ops.gemm(x, w, residual=xd, out=xd, post_norm=(nw, 1e-5, h), **kw)
+        outs.append((xd.clone(), h.clone(), u.clone()))
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b), "fp32-stored norm weights changed the result although their values are bf16-representable"
+    nw32 = 1 + 0.1 * torch.randn(N, generator=g)                                   # genuinely fp32 values
+    xd = res.float().cuda()
+    h = torch.empty(M, N, dtype=BF, device="cuda")
+    ops.gemm(x, w, residual=xd, out=xd, post_norm=(nw32.cuda(), 1e-5, h))
+    xr = xd.float().cpu()
+    _cmp(h, xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + 1e-5) * nw32, 4.5e-3, f"post-norm with fp32 norm weights, M={M}")
+    _cmp(ops.rmsnorm(xd, nw32.cuda(), 1e-5), xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + 1e-5) * nw32, 4.5e-3, f"stand-alone rmsnorm, fp32 weights, M={M}")
+    with pytest.raises(Exception):
+        xb = res.cuda().clone()
+        ops.gemm(x, w, residual=xb, out=xb, post_norm=(nw32.cuda(), 1e-5, h))       # fp32 norm weights need the fp32 residual stream

@@ -52,10 +52,11 @@ _RMS_KEYS = ("input_layernorm.weight", "post_attention_layernorm.weight", "model
 
 def stored_params(W: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
     """A checkpoint as the HIP modules HOLD it, in fp32 for the oracle's emulation runs: every floating tensor rounded to bf16 except the
-    LayerNorm weights / biases of the encoders, which crab_amd keeps in fp32 (crab_amd.ops.NORM_PARAMS_FP32; the decoder's RMSNorm weights and the
-    VQGAN's GroupNorms stay bf16).  A LayerNorm weight is recognised structurally - a 1-D `.weight` - and its bias by the sibling name."""
+    LayerNorm weights / biases of the encoders and the decoder's RMSNorm weights, which crab_amd keeps in fp32 (crab_amd.ops.NORM_PARAMS_FP32 /
+    RMS_DTYPE; the VQGAN's GroupNorms stay bf16).  A LayerNorm weight is recognised structurally - a 1-D `.weight` - and its bias by the sibling name."""
     from crab_amd import ops
-    ln_w = {k for k, v in W.items() if k.endswith(".weight") and v.dim() == 1 and not k.endswith(_RMS_KEYS) and "mask_encoder" not in k}
+    rms_fp32 = ops.RMS_DTYPE == torch.float32                  # r05: the decoder's RMSNorm weights are fp32 beside the fp32 residual stream
+    ln_w = {k for k, v in W.items() if k.endswith(".weight") and v.dim() == 1 and (rms_fp32 or not k.endswith(_RMS_KEYS)) and "mask_encoder" not in k}
     out = {}
     for k, v in W.items():
         if not v.is_floating_point():
