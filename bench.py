@@ -345,8 +345,8 @@ def qwen_variant(llama_model, args):
     um = model.base_model.model
     S = 126 + 32 * args.frames + 320
     free_now, _ = torch.cuda.mem_get_info()
-    per_clip = um._engine.bytes_per_sequence(S, args.new_tokens) + (70 << 20)
-    B = next((b for b in (448, 384, 320, 256, 128) if b * per_clip + (12 << 30) <= free_now), 64)
+    per_clip = um._engine.bytes_per_sequence(S, args.new_tokens) + (16 << 20)
+    B = next((b for b in (512, 448, 384, 320, 256, 128) if b * per_clip + ((20 if b == 512 else 12) << 30) <= free_now), 64)
     tab = um.SPECIAL_TOKEN_2_IDS
     ids = [synth.synth_prompt_ids(128, model.base_vocab, tab, clip=i) for i in range(B)]
     mods = [{'<video>': synth.synth_video(args.frames, clip=i).cuda(), '<audio>': synth.synth_audio(10, 98, clip=i).cuda()} for i in range(B)]
@@ -393,8 +393,8 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--clips", type=int, default=int(os.environ.get("CRAB_BENCH_CLIPS", "0")),
-                    help="clips per GPU per step (with --strong: in total); 0 = as many of 448 / 384 / 320 / 256 as the device's free memory holds "
-                         "(KV cache 0.47 GiB per clip; 448 on an idle 288 GB MI355X): decode streams the weights once per step for all of them")
+                    help="clips per GPU per step (with --strong: in total); 0 = as many of 512 / 448 / 384 / 320 / 256 as the device's free memory holds "
+                         "(KV cache 0.47 GiB per clip; 512 on an idle 288 GB MI355X): decode streams the weights once per step for all of them")
     ap.add_argument("--new-tokens", type=int, default=256)
     ap.add_argument("--frames", type=int, default=8)
     ap.add_argument("--prefill-chunk", type=int, default=0, help="sequences per prefill chunk; 0 = planned per batch (whole tile rounds)")
@@ -474,8 +474,12 @@ def main():
         # csrc/gemm_decode.hip), so the step takes as many clips as the KV cache has room for.  Every rank evaluates the same rule on its own
         # device; the smallest answer is used by all (weak scaling keeps clips per GPU equal).
         free_now, _ = torch.cuda.mem_get_info(local)
-        per_clip = um._engine.bytes_per_sequence(126 + 32 * args.frames + 320, args.new_tokens) + (70 << 20)     # + encoder scratch per clip
-        pick = next((b for b in (448, 384, 320, 256) if b * per_clip + (12 << 30) <= free_now), 256)
+        # per clip: its KV cache + decode rows (bytes_per_sequence) + its resident inputs and encoder outputs - measured r05: the allocator's peak grows by
+        # 515 MB per clip between 448 and 512 clips (503.5 MB of it KV cache), 16.8 GiB are fixed (14.4 of them the weights, loaded before this line);
+        # the rule keeps 12 GiB + 4.5 MB per clip beyond that.  512 = CRAB_DECODE_MAX_ROWS: both 256-row groups of the decode projections full
+        per_clip = um._engine.bytes_per_sequence(126 + 32 * args.frames + 320, args.new_tokens) + (16 << 20)
+        # (512 keeps 20 GiB beyond its estimate: an idle device has 272.9 GiB free here and ends its warm-up with 17.5 GiB to spare)
+        pick = next((b for b in (512, 448, 384, 320, 256) if b * per_clip + ((20 if b == 512 else 12) << 30) <= free_now), 256)
         if dist is not None:
             tpick = torch.tensor([pick], device="cuda" if backend == "nccl" else "cpu", dtype=torch.int64)
             dist.all_reduce(tpick, op=dist.ReduceOp.MIN)

@@ -155,7 +155,7 @@ def test_oracle_on_the_gpu_equals_the_oracle_on_the_host(crab):
         assert _rel(lg.cpu(), lc, f"oracle on the GPU vs on the host ({'fp32' if mode is None else 'emulation'})") < (2e-5 if mode is None else 2.5e-3)
 
 
-@pytest.mark.parametrize("B", [256, 448])
+@pytest.mark.parametrize("B", [256, 448, 512])
 def test_decode_batch_regime_vs_cpu_oracle_full_size(crab, B):
     _decode_regime_vs_cpu_oracle(crab, B)
 
@@ -179,7 +179,7 @@ def _decode_regime_vs_cpu_oracle(crab, B):
     eng = um._engine
     D = um.config.hidden_size
     S, n_new = 702, 8
-    rows = [0, 131, 255] + ([447] if B > 256 else [])
+    rows = [0, 131, 255] + ([B - 1] if B > 256 else [])      # (B = 512, r05: both row groups full = CRAB_DECODE_MAX_ROWS, bench.py's batch on an idle device)
     W = _regime_weights(crab)
     cfg = O.DecoderConfig(vocab_size=um.lm_head.weight.shape[0])
     emb = _regime_embeds(B, S, D)
