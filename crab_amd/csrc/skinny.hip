@@ -589,6 +589,93 @@ __global__ __launch_bounds__(256) void lora_route_row_kernel(const bf16_t* __res
         for (int j = 0; j < r; ++j) u[tid * nl * r + i * r + j] = f2bf(scaling * e[i] * inv * t[nl + j]);
 }
 
+// The same router for TWO rows per block (r05; 256 < M <= CRAB_DECODE_MAX_ROWS, K > 8192): what bounds the one-row kernel at these M is the L2 traffic of
+// [R;A] - every block re-reads all of it (down group: 33 rows x 11008 x 2 B = 0.7 MB x 512 blocks = 370 MB per launch, ~20 us) - so every chunk of
+// [R;A] a thread loads serves both rows of the block.  Per (row, router row) the arithmetic and its order are those of lora_route_row_kernel
+// (per-thread partial over the thread's chunks in q order, 4 quarter sums of 64 threads in index order, (q0 + q1) + (q2 + q3)): bit-identical
+// results.  The LDS reduction runs per trip (RPT router rows x 2 rows: 23 KB instead of 2 x 49 KB for whole rows).
+template <int MAXQ>
+__global__ __launch_bounds__(256) void lora_route_row2_kernel(const bf16_t* __restrict__ X, long ldx, const bf16_t* __restrict__ RA, long ldra, int M, int K,
+                                                              bf16_t* __restrict__ U, long ldu, int nproj, int nl, int r, int ucols, float scaling) {
+    constexpr int RMAX = 11;
+    __shared__ float tp[2][RMAX][257];
+    __shared__ float tq[2][RMAX][4];
+    __shared__ float T[2][48];
+    const int tid = threadIdx.x;
+    const int m0 = blockIdx.x * 2;
+    float xv[2][MAXQ][8];
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const int m = min(m0 + rr, M - 1);                     // (an odd M: the last block computes its only row twice and stores it once)
+#pragma unroll
+        for (int q = 0; q < MAXQ; ++q) {
+            const int n = (tid + q * 256) * 8;
+            u32x4 w = {0u, 0u, 0u, 0u};
+            if (n < K) w = *reinterpret_cast<const u32x4*>(X + (long)m * ldx + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { xv[rr][q][2 * e] = lo_bf(w[e]); xv[rr][q][2 * e + 1] = hi_bf(w[e]); }
+        }
+    }
+    const int rows = nproj * (nl + r);                         // <= 48
+#define ROUTE2_TRIPS(RPT_, NTRIPS_)                                                                       \
+    for (int tr = 0; tr < (NTRIPS_); ++tr) {                                                              \
+        const int c0 = tr * (RPT_);                                                                       \
+        float p[2][RPT_];                                                                                 \
+        _Pragma("unroll") for (int cc = 0; cc < (RPT_); ++cc) { p[0][cc] = 0.f; p[1][cc] = 0.f; }         \
+        _Pragma("unroll") for (int q = 0; q < MAXQ; ++q) {                                                \
+            const int n = (tid + q * 256) * 8;                                                            \
+            if (n < K) {                                                                                  \
+                u32x4 w[RPT_];                                                                            \
+                _Pragma("unroll") for (int cc = 0; cc < (RPT_); ++cc)                                     \
+                    w[cc] = c0 + cc < rows ? *reinterpret_cast<const u32x4*>(RA + (long)(c0 + cc) * ldra + n) : u32x4{0u, 0u, 0u, 0u};   \
+                _Pragma("unroll") for (int rr = 0; rr < 2; ++rr)                                          \
+                _Pragma("unroll") for (int cc = 0; cc < (RPT_); ++cc) {                                   \
+                    float a = 0.f;                                                                        \
+                    _Pragma("unroll") for (int e = 0; e < 4; ++e)                                         \
+                        a += xv[rr][q][2 * e] * lo_bf(w[cc][e]) + xv[rr][q][2 * e + 1] * hi_bf(w[cc][e]); \
+                    p[rr][cc] += a;                                                                       \
+                }                                                                                         \
+            }                                                                                             \
+        }                                                                                                 \
+        _Pragma("unroll") for (int rr = 0; rr < 2; ++rr)                                                  \
+        _Pragma("unroll") for (int cc = 0; cc < (RPT_); ++cc) tp[rr][cc][tid] = p[rr][cc];                \
+        __syncthreads();                                                                                  \
+        if (tid < 2 * (RPT_) * 4) {                                                                       \
+            const int rr = tid / ((RPT_) * 4), c = (tid % ((RPT_) * 4)) >> 2, qt = tid & 3;               \
+            float a = 0.f;                                                                                \
+            for (int i = qt * 64; i < qt * 64 + 64; ++i) a += tp[rr][c][i];                               \
+            tq[rr][c][qt] = a;                                                                            \
+        }                                                                                                 \
+        __syncthreads();                                                                                  \
+        if (tid < 2 * (RPT_)) {                                                                           \
+            const int rr = tid / (RPT_), c = tid % (RPT_);                                                \
+            if (c0 + c < rows) T[rr][c0 + c] = (tq[rr][c][0] + tq[rr][c][1]) + (tq[rr][c][2] + tq[rr][c][3]);   \
+        }                                                                                                 \
+    }
+    static_assert(RMAX * 4 * 2 <= 256, "quarter sums: one thread per (row, router row, quarter)");
+    if (nl + r == 11) { ROUTE2_TRIPS(11, nproj) }
+    else { ROUTE2_TRIPS(8, (rows + 7) / 8) }
+#undef ROUTE2_TRIPS
+    __syncthreads();
+    const int rr = tid >> 7, lt = tid & 127;                   // threads 0..127: row m0, 128..255: row m0 + 1
+    const int m = m0 + rr;
+    if (m >= M || lt > nproj) return;
+    bf16_t* u = U + (long)m * ldu;
+    const int used = nproj * nl * r;
+    if (lt == nproj) {
+        for (int c = used; c < ucols; ++c) u[c] = 0;
+        return;
+    }
+    const float* t = &T[rr][lt * (nl + r)];
+    float e[8], mx = -INFINITY;
+    for (int i = 0; i < nl; ++i) mx = fmaxf(mx, t[i]);
+    float sum = 0.f;
+    for (int i = 0; i < nl; ++i) { e[i] = expf(t[i] - mx); sum += e[i]; }
+    const float inv = 1.0f / sum;
+    for (int i = 0; i < nl; ++i)
+        for (int j = 0; j < r; ++j) u[lt * nl * r + i * r + j] = f2bf(scaling * e[i] * inv * t[nl + j]);
+}
+
 }  // namespace
 
 float* crab_rowfin_T(const crab_gemm_desc* d);      // rowfin.hip: where the router product of a deferred hyper-LoRA update goes
@@ -703,6 +790,15 @@ extern "C" int crab_hyperlora_route(crab_ctx* ctx, void* stream, const void* X, 
         hipStream_t s0 = (hipStream_t)stream;
 #define RR_LAUNCH(Q_) hipLaunchKernelGGL((lora_route_row_kernel<Q_>), dim3(M), dim3(256), 0, s0, (const bf16_t*)X, (long)ldx, (const bf16_t*)RA, (long)ldra, K, \
                                          (bf16_t*)U, (long)ldu, nproj, nl, r, ucols, scaling)
+        // two rows per block beyond 256 rows of a LONG row (r05; the down group, K = 11008: the [R;A] traffic halves - 17.6 -> 12.6 us at 512 rows;
+        // at K = 4096 the one-row kernel is not traffic-bound: 9.6 / 11.6 us either way, scripts/exp/route_rows2.py).  Bit-identical.
+        // CRAB_ROUTE_ROWS=1 keeps one row per block (A/B runs, tests)
+        const char* e1 = getenv("CRAB_ROUTE_ROWS");
+        if (M > 256 && K > 4 * 2048 && !(e1 && e1[0] == '1' && e1[1] == 0)) {
+            hipLaunchKernelGGL((lora_route_row2_kernel<6>), dim3((M + 1) / 2), dim3(256), 0, s0, (const bf16_t*)X, (long)ldx, (const bf16_t*)RA, (long)ldra, M, K,
+                               (bf16_t*)U, (long)ldu, nproj, nl, r, ucols, scaling);
+            return crab_check_launch(ctx, "lora_route_row2_kernel");
+        }
         if (K <= 2 * 2048) RR_LAUNCH(2); else if (K <= 4 * 2048) RR_LAUNCH(4); else RR_LAUNCH(6);
 #undef RR_LAUNCH
         return crab_check_launch(ctx, "lora_route_row_kernel");

@@ -1077,3 +1077,40 @@ def test_fp32_norm_weights_equal_the_same_values_in_bf16(M, with_route):
     with pytest.raises(Exception):
         xb = res.cuda().clone()
         ops.gemm(x, w, residual=xb, out=xb, post_norm=(nw32.cuda(), 1e-5, h))       # fp32 norm weights need the fp32 residual stream
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,K,nproj,nl,r", [(300, 11008, 3, 3, 8), (301, 11008, 1, 3, 8), (512, 8200, 2, 3, 8), (257, 12288, 3, 4, 4), (512, 4096, 3, 3, 8), (448, 18944, 1, 3, 8)])
+def test_router_two_rows_per_block_equals_one_row_per_block(M, K, nproj, nl, r):
+    """lora_route_row2_kernel (256 < M <= 512 and K > 8192: two rows per block share every [R;A] chunk, csrc/skinny.hip) against lora_route_row_kernel forced by
+    CRAB_ROUTE_ROWS=1: bit-identical U (same per-row arithmetic and order), odd M and the pad columns included; and against fp32 torch
+    (peft_hyper/tuners/lora.py:346-350).  K = 18944 (Qwen2's down projection) is beyond the row kernels' 12288: both calls take the general pair."""
+    import os
+    from crab_amd import ops
+    torch.manual_seed(M + K)
+    x = (torch.randn(M, K, device="cuda") * 0.7).to(BF)
+    tcols = (nproj * (nl + r) + 15) // 16 * 16
+    ra = torch.zeros(tcols, K, device="cuda", dtype=BF)
+    ra[: nproj * (nl + r)] = (torch.randn(nproj * (nl + r), K, device="cuda") * 0.02).to(BF)
+    ucols = (nproj * nl * r + 7) // 8 * 8 + 8
+    outs = []
+    for env in (None, "1"):
+        if env is None:
+            os.environ.pop("CRAB_ROUTE_ROWS", None)
+        else:
+            os.environ["CRAB_ROUTE_ROWS"] = env
+        try:
+            u = torch.full((M, ucols), 7.0, device="cuda", dtype=BF)
+            ops.hyperlora_route(x, ra, nproj, nl, r, ucols, 2.0, out=u)
+            torch.cuda.synchronize()
+            outs.append(u.clone())
+        finally:
+            os.environ.pop("CRAB_ROUTE_ROWS", None)
+    assert torch.equal(outs[0], outs[1])
+    t = x.float() @ ra.float().t()
+    ref = torch.zeros(M, ucols, device="cuda")
+    for pj in range(nproj):
+        tt = t[:, pj * (nl + r):(pj + 1) * (nl + r)]
+        p = torch.softmax(tt[:, :nl], -1)
+        ref[:, pj * nl * r:(pj + 1) * nl * r] = (2.0 * p[:, :, None] * tt[:, None, nl:]).reshape(M, nl * r)
+    assert (outs[0].float() - ref).abs().max().item() <= 2e-2 * ref.abs().max().item() + 1e-6
