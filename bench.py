@@ -41,6 +41,16 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+T_PROCESS0 = time.perf_counter()   # the ONE JSON line is printed last: everything optional behind the headline is admitted against --time-budget
+                                   # (seconds of this process), so that a launcher's time limit never costs the line itself
+
+
+def time_left(args) -> float:
+    return args.time_budget - (time.perf_counter() - T_PROCESS0)
+
+
+QWEN_RESERVE_S, CPU_RESERVE_S = 80.0, 75.0      # what the blocks behind the operating points take (Qwen2 build + three steps: 63-75 s; the CPU sample: 30-66 s)
+
 MFMA_PEAK_TFLOPS = 2500.0        # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
 # HBM bytes per algorithmic byte of attn_decode_kernel, from a separate `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` pass at
@@ -189,7 +199,7 @@ def cpu_baseline(args):
                        f"min s: {json.dumps({k: round(v, 3) for k, v in lo.items()})}; max s: {json.dumps({k: round(v, 3) for k, v in hi.items()})}")}
 
 
-def operating_points(model, um, args, eos):
+def operating_points(model, um, args, eos, t_step):
     """The reference's own operating points, reported NEXT TO the headline (never as `value`): one clip per call (scripts/quick_start.py:43),
     its eval batch of 8 clips (scripts/finetune/inference_hyper_lora.py:1477), its default 10 sampled frames (dataset/quick_start_dataset.py:83 -> S = 766)
     and the MUSIC-AVQA 2-s audio windows ([10,198,128], dataset/unified_dataset.py:1811-1828).  One warm-up + one timed
@@ -197,8 +207,20 @@ def operating_points(model, um, args, eos):
     from crab_amd import synth
     tab = um.SPECIAL_TOKEN_2_IDS
     out = {}
+    per_clip_s = t_step / max(args.clips, 1)              # the headline's seconds per clip: the estimate of what a big point's call costs
 
-    def run(name, B, frames, l_a, note):
+    def admit(name, est_call_s, clips, reserve):
+        """Timed calls this point gets (after its warm-up call): 2 when 1 + 2 calls and the input synthesis fit in what is left of --time-budget
+        beyond `reserve`, 1 when 1 + 1 fit, 0 = skipped (recorded in the line).  est_call_s: expected seconds of one call."""
+        setup = 0.04 * clips + 1.0
+        room = time_left(args) - reserve
+        n = 2 if room >= 3 * est_call_s + setup else (1 if room >= 2 * est_call_s + setup else 0)
+        if n == 0:
+            out[name] = {"skipped": f"--time-budget {args.time_budget:.0f} s: {max(room, 0):.0f} s left for the operating points, this one needs ~{2 * est_call_s + setup:.0f} s "
+                                    "(the builder-run lines under profiles/ carry it)"}
+        return n
+
+    def run(name, B, frames, l_a, note, n_timed=2):
         ids = [synth.synth_prompt_ids(128, model.base_vocab, tab, clip=9000 + i) for i in range(B)]
         mods = [{'<video>': synth.synth_video(frames, clip=9000 + i).cuda(), '<audio>': synth.synth_audio(10, l_a, clip=9000 + i).cuda()}
                 for i in range(B)]
@@ -212,7 +234,7 @@ def operating_points(model, um, args, eos):
         go()
         torch.cuda.synchronize()
         ts = []
-        for _ in range(2):                                 # two timed calls per point (the smaller is reported, both are listed)
+        for _ in range(n_timed):                           # two timed calls per point when the time budget allows (the smaller is reported, both are listed)
             t0 = time.perf_counter()
             r = go()
             torch.cuda.synchronize()
@@ -231,7 +253,7 @@ def operating_points(model, um, args, eos):
                                 "frac": round(algo / dt / 1e9 / HBM_PEAK_GBS, 4), "ms_per_token": round(dt * 1e3 / args.new_tokens, 3),
                                 "note": "whole generate() call (encoders + prefill included in the time, not in the bytes)"}
 
-    def run_in_flight(name, G, B, note):
+    def run_in_flight(name, G, B, note, n_timed=2):
         """G of the reference's eval batches (B clips each, separate prepare_multimodal_inputs / KV caches / HIP graphs) decoding in flight
         together: UnifiedForCausalLM.generate_batches = what harness.run_inference(in_flight=G) calls; ids per batch = those of G generate() calls."""
         batches = []
@@ -248,7 +270,7 @@ def operating_points(model, um, args, eos):
         go()
         torch.cuda.synchronize()
         ts = []
-        for _ in range(2):
+        for _ in range(n_timed):
             t0 = time.perf_counter()
             r = go()
             torch.cuda.synchronize()
@@ -264,7 +286,7 @@ def operating_points(model, um, args, eos):
                              "frac": round(algo / dt / 1e9 / HBM_PEAK_GBS, 4),
                              "note": "every batch streams the weights for itself (separate M = 8 launches): bytes = G x one batch's"}}
 
-    def run_coalesced(name, G, B, spread, note):
+    def run_coalesced(name, G, B, spread, note, n_timed=2):
         """G of the reference's eval batches of B clips decoding as ONE ragged batch (generate_batches(coalesce=True) = what
         harness.run_inference(coalesce=True) calls): every batch keeps its own prepare_multimodal_inputs result, left padding and positions
         from 0; the weights stream once per decode step for all G x B rows and the encoders see all clips together.  spread > 0: batch g's
@@ -284,7 +306,7 @@ def operating_points(model, um, args, eos):
         go()
         torch.cuda.synchronize()
         ts = []
-        for _ in range(2):
+        for _ in range(n_timed):
             t0 = time.perf_counter()
             r = go()
             torch.cuda.synchronize()
@@ -295,21 +317,43 @@ def operating_points(model, um, args, eos):
                      "prompt_tokens": "128" if not spread else f"{128 - spread}..{128 + spread} (one length per batch)",
                      "clips_per_s": round(G * B / dt, 3), "ms_per_call": [round(t * 1e3, 1) for t in ts], "note": note}
 
-    run("single_clip", 1, args.frames, 98, "scripts/quick_start.py: one clip per generate() (BASELINE configs[0] shape on the GPU); latency = ms_per_batch")
-    run("eval_batch_8", 8, args.frames, 98, "the reference's eval batch size; per-batch latency = ms_per_batch")
-    run_in_flight("eval_batch_8_x3_in_flight", 3, 8, "three eval batches of 8 decoding concurrently on separate HIP streams (harness.run_inference in_flight=3)")
-    run_in_flight("eval_batch_8_x4_in_flight", 4, 8, "four eval batches of 8 in flight")
+    # in order of importance; a point is skipped (and says so) rather than letting the process outlive --time-budget.  Behind these the line still
+    # needs the Qwen2 variant and the CPU sample: the first group leaves room for the CPU sample only (the Qwen2 block is itself admitted against what
+    # is left), the second group leaves room for both
     gco = max(2, min(args.clips, 448) // 8)
-    run_coalesced("eval_batch_8_coalesced", gco, 8, 0, f"{gco} eval batches of 8 (inference_hyper_lora.py:1477) coalesced into one ragged decode batch "
-                  "(harness.run_inference(coalesce=True)); per-batch results = those of separate generate() calls within the decoder's bf16 tolerance")
-    run_coalesced("eval_batch_8_coalesced_ragged", gco, 8, 12, "the same with a different prompt length per batch (116..140 tokens): per-batch prefill, "
-                  "per-row rotary offset and first visible key in the decode kernels")
     nb = min(args.clips, 256)                    # (256: the r01-r03 batch, so that these lines stay comparable across rounds)
+    A, Bq = CPU_RESERVE_S, CPU_RESERVE_S + QWEN_RESERVE_S
+    n = admit("single_clip", 1.0, 1, A)
+    if n:
+        run("single_clip", 1, args.frames, 98, "scripts/quick_start.py: one clip per generate() (BASELINE configs[0] shape on the GPU); latency = ms_per_batch", n)
+    n = admit("eval_batch_8", 1.3, 8, A)
+    if n:
+        run("eval_batch_8", 8, args.frames, 98, "the reference's eval batch size; per-batch latency = ms_per_batch", n)
+    n = admit("eval_batch_8_coalesced", per_clip_s * gco * 8 * 1.03, gco * 8, A)
+    if n:
+        run_coalesced("eval_batch_8_coalesced", gco, 8, 0, f"{gco} eval batches of 8 (inference_hyper_lora.py:1477) coalesced into one ragged decode batch "
+                      "(harness.run_inference(coalesce=True)); per-batch results = those of separate generate() calls within the decoder's bf16 tolerance", n)
     if args.clips > 256:
-        run("batch_256", 256, args.frames, 98, "the headline workload at the 256 clips per step of r01-r03 (the headline's batch is chosen from free memory: "
-            "this point keeps the rounds comparable)")
-    run("audio_2s_windows", nb, args.frames, 198, "MUSIC-AVQA audio shape [10,198,128] (96 BEATs tokens per window)")
-    run("frames_10", nb, 10, 98, "the reference's default video_frame_nums = 10 (S = 766)")
+        n = admit("batch_256", per_clip_s * 256 * 1.06, 256, Bq)
+        if n:
+            run("batch_256", 256, args.frames, 98, "the headline workload at the 256 clips per step of r01-r03 (the headline's batch is chosen from free memory: "
+                "this point keeps the rounds comparable)", n)
+    n = admit("eval_batch_8_coalesced_ragged", per_clip_s * gco * 8 * 1.05, gco * 8, Bq)
+    if n:
+        run_coalesced("eval_batch_8_coalesced_ragged", gco, 8, 12, "the same with a different prompt length per batch (116..140 tokens): per-batch prefill, "
+                      "per-row rotary offset and first visible key in the decode kernels", n)
+    n = admit("audio_2s_windows", per_clip_s * nb * 1.08, nb, Bq)
+    if n:
+        run("audio_2s_windows", nb, args.frames, 198, "MUSIC-AVQA audio shape [10,198,128] (96 BEATs tokens per window)", n)
+    n = admit("frames_10", per_clip_s * nb * 1.15, nb, Bq)
+    if n:
+        run("frames_10", nb, 10, 98, "the reference's default video_frame_nums = 10 (S = 766)", n)
+    n = admit("eval_batch_8_x3_in_flight", 2.7, 24, Bq)
+    if n:
+        run_in_flight("eval_batch_8_x3_in_flight", 3, 8, "three eval batches of 8 decoding concurrently on separate HIP streams (harness.run_inference in_flight=3)", n)
+    n = admit("eval_batch_8_x4_in_flight", 3.5, 32, Bq)
+    if n:
+        run_in_flight("eval_batch_8_x4_in_flight", 4, 8, "four eval batches of 8 in flight", n)
     return out
 
 
@@ -407,6 +451,10 @@ def main():
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: --clips is the TOTAL over all ranks (contiguous blocks, the first total %% N ranks hold one more clip); "
                          "default is weak scaling (--clips per GPU)")
+    ap.add_argument("--time-budget", type=float, default=float(os.environ.get("CRAB_BENCH_TIME_BUDGET", "780")),
+                    help="seconds this process may take in all (N = 1): the reference operating points and the Qwen2 variant behind the headline are admitted "
+                         "against it in order of importance and say so when skipped - the JSON line is printed last and must not be lost to a launcher's limit "
+                         "(the driver runs --steps 20 --warmup 5: 27 steps of 16.6 s before anything optional)")
     ap.add_argument("--no-operating-points", action="store_true",
                     help="skip the extra (untimed-region) runs at the reference's own operating points: eval batch 8, 10 frames, 2-s audio windows")
     args = ap.parse_args()
@@ -661,12 +709,17 @@ def main():
             "roofline_mfma": roof_mfma,
         }
         if world == 1 and not args.no_operating_points and args.llm == "llama":
-            line["reference_operating_points"] = operating_points(model, um, args, eos)
+            line["reference_operating_points"] = operating_points(model, um, args, eos, dt / args.steps)
         if world == 1 and not args.no_operating_points and args.llm == "llama":
-            try:
-                line["qwen2_7b_variant"] = qwen_variant(model, args)
-            except Exception as e:      # the headline must still be reported
-                line["qwen2_7b_variant"] = {"error": f"{type(e).__name__}: {e}"}
+            if time_left(args) < QWEN_RESERVE_S + CPU_RESERVE_S:
+                line["qwen2_7b_variant"] = {"skipped": f"--time-budget {args.time_budget:.0f} s: {max(time_left(args), 0):.0f} s left; `python bench.py --llm qwen` gives it as a line "
+                                                       "of its own (profiles/r05_bench_default_512clips.json: 56.1 clips/s)"}
+            else:
+                try:
+                    line["qwen2_7b_variant"] = qwen_variant(model, args)
+                except Exception as e:      # the headline must still be reported
+                    line["qwen2_7b_variant"] = {"error": f"{type(e).__name__}: {e}"}
+        line["process_s"] = {"time_budget": args.time_budget, "before_cpu_baseline": round(time.perf_counter() - T_PROCESS0, 1)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(args)
