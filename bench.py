@@ -451,7 +451,7 @@ def main():
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: --clips is the TOTAL over all ranks (contiguous blocks, the first total %% N ranks hold one more clip); "
                          "default is weak scaling (--clips per GPU)")
-    ap.add_argument("--time-budget", type=float, default=float(os.environ.get("CRAB_BENCH_TIME_BUDGET", "780")),
+    ap.add_argument("--time-budget", type=float, default=float(os.environ.get("CRAB_BENCH_TIME_BUDGET", "740")),
                     help="seconds this process may take in all (N = 1): the reference operating points and the Qwen2 variant behind the headline are admitted "
                          "against it in order of importance and say so when skipped - the JSON line is printed last and must not be lost to a launcher's limit "
                          "(the driver runs --steps 20 --warmup 5: 27 steps of 16.6 s before anything optional)")
