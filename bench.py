@@ -49,7 +49,7 @@ def time_left(args) -> float:
     return args.time_budget - (time.perf_counter() - T_PROCESS0)
 
 
-QWEN_RESERVE_S, CPU_RESERVE_S = 80.0, 75.0      # what the blocks behind the operating points take (Qwen2 build + three steps: 63-75 s; the CPU sample: 30-66 s)
+QWEN_RESERVE_S, CPU_RESERVE_S = 70.0, 85.0      # what the blocks behind the operating points take (Qwen2 build + three steps: 55-65 s; the CPU sample: 50-90 s by box)
 
 MFMA_PEAK_TFLOPS = 2500.0        # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
@@ -101,7 +101,7 @@ def cpu_baseline(args):
     torch.manual_seed(0)
     nth = torch.get_num_threads()
     g = torch.Generator().manual_seed(1)
-    NREP, NL = 3, 8
+    NREP, NL = 2, 8          # (two timed runs per sample after its warm-up: min / max are the spread; three cost 15-25 s more of a process whose line is printed last)
     CTX = ((702, 6), (830, 5), (958, 5))
 
     def rnd(*s):
@@ -113,7 +113,8 @@ def cpu_baseline(args):
         for _ in range(nrep):
             t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
         ts.sort()
-        return ts[len(ts) // 2], ts[0], ts[-1]
+        n = len(ts)
+        return (ts[n // 2] if n & 1 else 0.5 * (ts[n // 2 - 1] + ts[n // 2])), ts[0], ts[-1]
 
     t, lo, hi = {}, {}, {}
 
@@ -378,7 +379,7 @@ def _rccl_version():
 def qwen_variant(llama_model, args):
     """BASELINE configs[2]'s decoder (Qwen2-7B: GQA 28 / 4, q|k|v bias, vocab 152k; models/unified_qwen.py) on the same AVQA-shaped workload,
     timed by the same process right after the headline: the Llama model's KV caches and graphs are released first (its weights stay),
-    one warm-up + two timed steps of 448 clips (or what fits), prefill fraction from the three phase marks of a third step.  Never `value`:
+    one warm-up + two timed steps of 512 clips (or what fits), prefill fraction from the three phase marks recorded in the second of them.  Never `value`:
     the same numbers come from `python bench.py --llm qwen` as a line of their own."""
     from crab_amd import ops, synth
     from crab_amd.build_model import build_crab
@@ -406,17 +407,16 @@ def qwen_variant(llama_model, args):
     go()
     torch.cuda.synchronize()
     ts = []
-    for _ in range(2):
+    prof = ops.KernelProfiler(phase_only=True)
+    for i in range(2):
+        if i == 1:
+            ops.PROFILER = prof                        # the second timed step carries the three phase marks (three HIP event records: nothing else changes)
         t1 = time.perf_counter()
         r = go()
         torch.cuda.synchronize()
         ts.append(time.perf_counter() - t1)
+        ops.PROFILER = None
     assert tuple(r.shape) == (B, args.new_tokens)
-    prof = ops.KernelProfiler(phase_only=True)
-    ops.PROFILER = prof
-    go()
-    torch.cuda.synchronize()
-    ops.PROFILER = None
     pre_ms, dec_ms = prof.phase_ms()
     V = um.lm_head.weight.shape[0]
     fl = flops_per_clip(args.frames, 10, 48, S, V, um.config)
@@ -451,7 +451,7 @@ def main():
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: --clips is the TOTAL over all ranks (contiguous blocks, the first total %% N ranks hold one more clip); "
                          "default is weak scaling (--clips per GPU)")
-    ap.add_argument("--time-budget", type=float, default=float(os.environ.get("CRAB_BENCH_TIME_BUDGET", "740")),
+    ap.add_argument("--time-budget", type=float, default=float(os.environ.get("CRAB_BENCH_TIME_BUDGET", "760")),
                     help="seconds this process may take in all (N = 1): the reference operating points and the Qwen2 variant behind the headline are admitted "
                          "against it in order of importance and say so when skipped - the JSON line is printed last and must not be lost to a launcher's limit "
                          "(the driver runs --steps 20 --warmup 5: 27 steps of 16.6 s before anything optional)")
