@@ -259,18 +259,56 @@ def default_palette(n: int = 71) -> np.ndarray:
     return pal
 
 
+def summarise_avs(records: Sequence[Mapping[str, Any]]) -> Dict[str, Any]:
+    """The closing lines of the reference's pixel-task loops over the per-sample records of run_inference_avs (in record order):
+      binary tasks   miou = sum(iou) / count (an fp32 tensor sum there), f-score = sum(fscore) / count (Python floats)   quick_start.py:120-135, 200-206
+      null refs      ms = sum(s) / count                                                                                 quick_start.py:343-358
+      avss           per-class IoU / F sums over the samples divided by the class counts, NaN -> 0, mean over the classes with and without
+                     the last one                                                                                        quick_start.py:399-447
+    Only the keys whose inputs occur in the records are present."""
+    out: Dict[str, Any] = {}
+    ious = [r["iou"] for r in records if r.get("iou") is not None]
+    if ious:
+        acc = np.float32(0)
+        for v in ious:
+            acc = np.float32(acc + np.float32(v))
+        out.update(miou=float(np.float32(acc / np.float32(len(ious)))), f_score=sum(r["fscore"] for r in records if r.get("iou") is not None) / len(ious),
+                   count=len(ious))
+    ss = [r["s"] for r in records if r.get("s") is not None]
+    if ss:
+        out.update(ms=sum(ss) / len(ss), count_null=len(ss))
+    av = [r["_avss"] for r in records if r.get("_avss") is not None]
+    if av:
+        sums = [np.zeros(len(av[0][0]), np.float32) for _ in range(3)]
+        for triple in av:
+            for acc, v in zip(sums, triple):
+                acc += np.asarray(v, np.float32)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            mi, fs = sums[0] / sums[2], sums[1] / sums[2]
+        mi[np.isnan(mi)] = 0
+        fs[np.isnan(fs)] = 0
+        out["avss"] = {"miou": float(mi.mean(dtype=np.float32)), "miou_noBg": float(mi[:-1].mean(dtype=np.float32)),
+                       "f_score": float(fs.mean(dtype=np.float32)), "f_score_noBg": float(fs[:-1].mean(dtype=np.float32)), "count": len(av)}
+    return out
+
+
 def run_inference_avs(batches: Iterable[Mapping[str, Any]], model, tokenizer, out_dir: str, max_new_tokens: int = 100, device="cuda",
                       rank: int = 0, world: int = 1, palette: Optional[np.ndarray] = None, out_path: Optional[str] = None,
-                      on_result: Optional[Callable[[dict], None]] = None, **generate_kwargs) -> List[dict]:
+                      on_result: Optional[Callable[[dict], None]] = None, metrics: bool = True, null_reference: bool = False,
+                      summary: Optional[dict] = None, **generate_kwargs) -> List[dict]:
     """The pixel-task loops of the reference (scripts/quick_start.py:270-359 inference_ms3 / _s4 / _ref_avs, :361-450 inference_avss): for every
     collated batch (one sample per batch, like the reference, which reads batch_metadata[0]) generate_avs -> text + masks -> files:
       binary tasks (one class plane):  `<out_dir>/mask_img_dir/<video>/<frame>_pred.png`, mode 'P', 255 where sigmoid(pred) > 0.5 (:313-319)
       avss (71 class planes):          `<out_dir>/avss_result/<video>/<frame>_pred.png`, RGB, palette[argmax over classes] (avss_utils.py:281-312)
     <video> / <frame> come from metadata['mask_path'] (`.../<video>/<fid>/<frame>.png`, :308-311) when present, else from the batch index.
     The thresholding / argmax runs on the device (crab_mask_labels); PNG encoding is host work (Pillow).  A sample whose generation did not
-    produce the six <mask_i> tokens has no masks: its record carries pred_path None, as the reference skips it (:303-306).  Metrics (mIoU,
-    F-score, S) are outside the path.  Batch i runs on rank i mod world; rank 0 returns every record in batch order and
-    appends them to `out_path` as JSON lines when given."""
+    produce the six <mask_i> tokens has no masks: its record carries pred_path None, as the reference skips it (:303-306).
+    Metrics (`metrics=True`, a sample whose X_modals carry the ground truth '<mask>', quick_start_dataset.py:692-694): computed on the DEVICE
+    from the predicted mask where the reference first moves it to the host (crab_amd.avss_utils = utils/avss_utils.py): binary tasks get
+    'iou' + 'fscore' (mask_iou, Eval_Fmeasure; quick_start.py:118-119, 198-199, 267-268), with `null_reference=True` (the loop over the null
+    split, :270-358) 's' instead (metric_s_for_null, :342); avss gets the per-class IoU / F sums of calc_color_miou_fscore (:395-403).
+    `summary` (a dict, filled on rank 0) receives summarise_avs(records) = the loops' closing averages.
+    Batch i runs on rank i mod world; rank 0 returns every record in batch order and appends them to `out_path` as JSON lines when given."""
     import os
     from PIL import Image
     from . import ops
@@ -282,6 +320,7 @@ def run_inference_avs(batches: Iterable[Mapping[str, Any]], model, tokenizer, ou
         sample = dict(sample)
         meta = dict(sample.pop("batch_metadata")[0])
         task = sample["batch_task_names"][0]
+        gt = sample["batch_X_modals"][0].get("<mask>") if metrics else None            # [1, 224, 224]: {0, 1} fp32, or class ids (avss)
         kw = {"use_cache": True, "max_new_tokens": max_new_tokens}
         kw.update(generate_kwargs)
         with torch.no_grad():
@@ -305,6 +344,17 @@ def run_inference_avs(batches: Iterable[Mapping[str, Any]], model, tokenizer, ou
             rec["pred_path"] = os.path.join(d, frame + "_pred.png")
             img.save(rec["pred_path"], format="PNG")
             rec["task"], rec["num_classes"] = task, int(pred.shape[0])
+            if gt is not None:
+                from . import avss_utils
+                g = gt.to(pred.device)
+                if pred.shape[0] > 1:
+                    i_pc, f_pc, c_pc, _ = avss_utils.calc_color_miou_fscore(pred=pred.unsqueeze(0), target=g, T=1)
+                    rec["_avss"] = [i_pc.tolist(), f_pc.tolist(), c_pc.tolist()]
+                elif null_reference:
+                    rec["s"] = avss_utils.metric_s_for_null(pred).item()
+                else:
+                    rec["iou"] = avss_utils.mask_iou(pred=pred, target=g).item()
+                    rec["fscore"] = avss_utils.Eval_Fmeasure(pred=pred, gt=g)
         mine.append((step, rec))
     records = mine
     if world > 1:
@@ -315,7 +365,10 @@ def run_inference_avs(batches: Iterable[Mapping[str, Any]], model, tokenizer, ou
             records = sorted((r for part in gathered for r in part), key=lambda t: t[0])
     out = [r for _, r in records]
     if rank == 0:
+        if summary is not None:
+            summary.update(summarise_avs(out))
         for rec in out:
+            rec.pop("_avss", None)                                      # 3 x classes floats per sample: summed above, not part of the record
             if on_result is not None:
                 on_result(rec)
         if out_path is not None:

@@ -490,6 +490,30 @@ int crab_act_inplace(crab_ctx* ctx, void* stream, void* x, int64_t n, int act);
 int crab_mask_labels(crab_ctx* ctx, void* stream, const float* pred, int C, int64_t hw, uint8_t* out);
 
 /* ---------------------------------------------------------------------------------------------
+ * Segmentation metrics (SURVEY.md 8 f-1 anchors utils/avss_utils.py:8-96, 379-435): what the reference's pixel-task eval loops compute
+ * from a predicted mask right behind generate_avs, on `pred_mask.cpu()` (scripts/quick_start.py:118-119, 198-199, 267-268, 342, 395;
+ * scripts/finetune/inference_hyper_lora.py:658-659, 804-805, 981-982, 1063, 1177).  All buffers are DEVICE memory owned by the caller; every
+ * pixel count is an exact int32; the fp32 ratios are formed from the counts in the reference's operation order, one rounding per operation.
+ *  crab_mask_iou     : replaces mask_iou (avss_utils.py:22-47) and metric_s_for_null (:8-19).  pred [N, hw] fp32 logits (mask where pred > 0 =
+ *      sigmoid(pred) > 0.5), target [N, hw] fp32 in {0, 1} or NULL (metric_s only).  counts [N][6] int32 = {pred, target, pred & target,
+ *      pred | target, !pred & !target, target pixels outside {0, 1}}; out[0] = sum_n inter_n / (union_n + eps) / N with an empty target's
+ *      {inter, union} replaced by {!pred & !target, hw}; out[1] = sqrt(sum_n pred_n / (N hw)).
+ *  crab_fmeasure     : replaces Eval_Fmeasure + _eval_pr (:50-96).  pred / gt [N, hw] fp32 (gt in {0, 1}), thresholds [T] ascending fp32
+ *      (the reference: torch.linspace(0, 1 - 1e-10, 255)), T <= 1024.  ge [N][2][T] int32 = {#(gt & sigmoid(pred) >= th_i), #(sigmoid(pred) >= th_i)},
+ *      ysum [N][2] int32 = {gt pixels, gt pixels outside {0, 1}}, fscore [N][T] = (1 + beta2) P R / (beta2 P + R) with NaN -> 0,
+ *      score [T] = mean of fscore over the images whose gt is not empty (image order), best [2] = {max_i score[i], images counted}.
+ *  crab_miou_fscore  : replaces calc_color_miou_fscore / _batch_miou_fscore (:379-435).  pred [BF, C, hw] fp32 class logits (argmax of the
+ *      logits = argmax of their softmax, first maximum), target [BF, hw] int64 class ids (ids outside [0, C) are counted nowhere; a negative id
+ *      also removes the pixel's prediction, as the reference's `predict * (target > 0)` does after its +1 shift), C <= 1024.
+ *      areas [BF][3][C] int32 = {TP, TP + FP, TP + FN} (the three torch.histc calls), iou_fc [BF][C] = TP / (2.22e-16 + union),
+ *      ious / fscores / cls_count [C] = the per-class sums over the frames in frame order, vid_miou [BF] = sum_c iou / #{iou != 0}. */
+int crab_mask_iou(crab_ctx* ctx, void* stream, const float* pred, const float* target, int N, int64_t hw, float eps, int32_t* counts, float* out);
+int crab_fmeasure(crab_ctx* ctx, void* stream, const float* pred, const float* gt, int N, int64_t hw, const float* thresholds, int T, double beta2,
+                  int32_t* ge, int32_t* ysum, float* fscore, float* score, float* best);
+int crab_miou_fscore(crab_ctx* ctx, void* stream, const float* pred, const int64_t* target, int BF, int C, int64_t hw, double beta2, int32_t* areas,
+                     float* iou_fc, float* ious, float* fscores, float* cls_count, float* vid_miou);
+
+/* ---------------------------------------------------------------------------------------------
  * Input front-end: what the reference's dataset code does on the CPU right before generate().
  *  crab_bicubic_ksize / crab_bicubic_coeffs (HOST arrays): Pillow 10.4 Resample.c precompute_coeffs + normalize_coeffs_8bpc
  *      for BICUBIC over the whole image: bounds[out][2] = {first tap, tap count}, kk[out][ksize] 22-bit fixed-point taps.

@@ -803,6 +803,52 @@ def golden_harness():
     print("harness:", {k: len(v) for k, v in out["instructions"].items()}, "frames", rec["frames"], "windows", len(rec["windows"]))
 
 
+def golden_metrics():
+    """Segmentation metrics (SURVEY.md 8 f-1 anchors): the reference's utils/avss_utils.py functions on small seeded masks.
+    Inputs are stored (small); outputs are the reference's return values, plus the integer counts formed with the reference's own
+    tensor expressions (fp32 torch.sigmoid, torch.linspace thresholds) for the threshold sweep."""
+    from utils import avss_utils as R
+    g = torch.Generator().manual_seed(SEED + 77)
+    N, H, W = 4, 40, 56
+    pred = torch.randn(N, H, W, generator=g) * 3
+    gt = torch.zeros(N, H, W)
+    gt[0] = (torch.rand(H, W, generator=g) > 0.7).float()
+    gt[2] = ((pred[2] + torch.randn(H, W, generator=g)) > 0.5).float()            # correlated with the prediction
+    gt[3] = 1.0                                                                    # image 1 stays black: no object
+    out = {"bin_pred": pred, "bin_gt": gt}
+    out["iou_all"] = R.mask_iou(pred, gt)
+    out["iou_each"] = torch.stack([R.mask_iou(pred[n:n + 1], gt[n:n + 1]) for n in range(N)])
+    out["f_all"] = np.float64(R.Eval_Fmeasure(pred, gt))
+    out["f_each"] = np.array([R.Eval_Fmeasure(pred[n:n + 1], gt[n:n + 1]) for n in range(N)], np.float64)
+    out["f_black_only"] = np.float64(R.Eval_Fmeasure(pred[1:2], gt[1:2]))
+    out["s_each"] = torch.stack([R.metric_s_for_null(pred[n:n + 1]) for n in range(N)])
+    th = torch.linspace(0, 1 - 1e-10, 255)
+    out["thlist"] = th
+    sp = torch.sigmoid(pred)
+    out["ge_tp"] = torch.stack([torch.stack([((sp[n] >= th[i]).float() * gt[n]).sum() for i in range(255)]) for n in range(N)]).to(torch.int64)
+    out["ge_cnt"] = torch.stack([torch.stack([(sp[n] >= th[i]).float().sum() for i in range(255)]) for n in range(N)]).to(torch.int64)
+    pr = [R._eval_pr(sp[n], gt[n], 255) for n in range(N)]
+    out["prec"] = torch.stack([p for p, _ in pr])
+    out["recall"] = torch.stack([r for _, r in pr])
+
+    BF, C, h, w = 3, 7, 24, 40
+    cp = torch.randn(BF, C, h, w, generator=g)
+    ct = torch.randint(0, C, (BF, h, w), generator=g)
+    ct[1][ct[1] == 5] = 2                                                          # class 5 absent from frame 1 ...
+    ct[1, :3] = 255                                                                # ... whose first rows carry an out-of-range label
+    agree = torch.rand(h, w, generator=g) < 0.8
+    ct[2] = torch.where(agree, cp[2].argmax(0), ct[2])                             # frame 2 mostly right
+    ct[2, -2:] = -1                                                                # and two rows of a negative (ignore) label
+    cp[0, 6] = -10.0                                                               # class 6 never predicted in frame 0
+    out["cls_pred"], out["cls_tgt"] = cp, ct
+    mi, fs, cc, vid = R.calc_color_miou_fscore(cp, ct, T=1)
+    out["cls_miou"], out["cls_fscore"], out["cls_count"], out["cls_vid"] = mi, fs, cc, torch.stack(vid)
+    each = [R.calc_color_miou_fscore(cp[f:f + 1], ct[f:f + 1], T=1) for f in range(BF)]
+    out["cls_iou_fc"] = torch.stack([e[0] for e in each])
+    out["cls_fs_fc"] = torch.stack([e[1] for e in each])
+    save("seg_metrics", {"seed": SEED + 77, "note": "reference utils/avss_utils.py outputs; torch " + torch.__version__}, **out)
+
+
 def golden_llama_ops():
     """The in-tree statement of the decoder arithmetic, models/modeling_llama.py (HF 4.37.2 as vendored by the reference):
     LlamaRMSNorm (:103-117), LlamaRotaryEmbedding + apply_rotary_pos_emb (:120-236) and one LlamaDecoderLayer with eager
@@ -904,6 +950,8 @@ def main():
         golden_id_stats(me)
     if "holes" in which:
         golden_holes(me)
+    if "metrics" in which:
+        golden_metrics()
 
 
 if __name__ == "__main__":

@@ -267,3 +267,23 @@ def test_make_instance_pipeline_gpu():
     from crab_amd.frontend import CLIPImageProcessor
     ref = np.asarray(Image.fromarray(img).resize((224, 224)))
     assert np.array_equal(CLIPImageProcessor().resize_exact(img, 224, 224).cpu().numpy(), ref)          # bit-exact with Pillow
+
+
+def test_summarise_avs_is_the_closing_arithmetic_of_the_pixel_task_loops():
+    """scripts/quick_start.py:120-135 (miou: an fp32 running sum / count; f-score: Python floats), :343-358 (ms), :437-447 (avss: per-class
+    sums / counts, NaN -> 0, class means with and without the last class) over the records run_inference_avs produces."""
+    from oracle import metrics_oracle as MO
+    A = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "seg_metrics.npz")))
+    recs = [{"iou": float(v), "fscore": float(f)} for v, f in zip(A["iou_each"], A["f_each"])] + [{"pred_path": None}]
+    recs += [{"s": float(v)} for v in A["s_each"]]
+    per_frame = [MO.batch_miou_fscore(A["cls_pred"][f:f + 1], A["cls_tgt"][f:f + 1])[:3] for f in range(A["cls_pred"].shape[0])]
+    recs += [{"_avss": [v.tolist() for v in t]} for t in per_frame]
+    out = harness.summarise_avs(recs)
+    acc = np.float32(0)
+    for v in A["iou_each"]:
+        acc = np.float32(acc + v)
+    assert out["count"] == 4 and out["miou"] == float(acc / np.float32(4)) and out["f_score"] == float(sum(A["f_each"].tolist()) / 4)
+    assert out["count_null"] == 4 and out["ms"] == sum(float(v) for v in A["s_each"]) / 4
+    want = MO.avss_final(A["cls_miou"], A["cls_fscore"], A["cls_count"])          # the reference's batch call sums the frames the same way
+    assert out["avss"]["count"] == 3 and all(abs(out["avss"][k] - want[k]) < 1e-7 for k in want)
+    assert harness.summarise_avs([{"pred_path": None}]) == {}

@@ -416,6 +416,7 @@ def test_generate_avs_pipeline_vs_oracle():
 def test_harness_pixel_task_loop_writes_the_masks(tmp_path):
     """harness.run_inference_avs = scripts/quick_start.py:270-450: generate_avs -> text + mask files.  Binary task: a mode-'P' PNG with 255 where
     sigmoid(pred) > 0.5; avss: an RGB PNG of palette[argmax over the 71 class planes]; a sample without the six mask tokens: no file."""
+    import json
     import numpy as np
     from PIL import Image
     from crab_amd import harness, ops
@@ -444,6 +445,31 @@ def test_harness_pixel_task_loop_writes_the_masks(tmp_path):
     assert recs[1]["pred_path"].endswith("avss_result/vidB/7_pred.png") and np.array_equal(p1, harness.default_palette()[cls]) and len(np.unique(cls)) > 1
     assert np.array_equal(ops.mask_labels(direct[1]).cpu().numpy(), cls.astype(np.uint8))
     assert len(open(tmp_path / "res.jsonl").read().strip().splitlines()) == 2
+    assert "iou" not in recs[0] and "_avss" not in recs[1]                     # no ground truth in X_modals: no metrics
+    # with the ground truth '<mask>' in X_modals the loop scores each sample on the device (utils/avss_utils.py through crab_amd.avss_utils):
+    # the records and the closing averages equal the CPU restatement on the same masks
+    from oracle import metrics_oracle as MO
+    g = torch.Generator().manual_seed(3)
+    gt_bin = (torch.rand(1, 224, 224, generator=g) > 0.5).float()
+    gt_cls = torch.randint(0, 71, (1, 224, 224), generator=g)
+    gt_cls[0, :100] = torch.argmax(direct[1], 0)[:100].cpu()
+    withgt = lambda task, path, m: dict(mk(task, path), batch_X_modals=[dict(mods[0], **{"<mask>": m})])
+    summ = {}
+    rec2 = harness.run_inference_avs([withgt("s4", "/data/avs/vidD/0/3.png", gt_bin), withgt("ms3", "/data/avs/vidD/0/4.png", 1 - gt_bin),
+                                      withgt("avss", "/data/avs/vidE/0/7.png", gt_cls)], model, tok, str(tmp_path), max_new_tokens=n, pad_token_id=2,
+                                     eos_token_id=None, summary=summ, out_path=str(tmp_path / "res2.jsonl"))
+    d0 = direct[0].cpu().numpy()
+    for r, gtm in ((rec2[0], gt_bin), (rec2[1], 1 - gt_bin)):
+        assert r["iou"] == float(MO.mask_iou(d0, gtm.numpy())) and r["fscore"] == MO.eval_fmeasure(d0, gtm.numpy())
+    assert summ["count"] == 2 and summ["miou"] == float(np.float32(np.float32(rec2[0]["iou"]) + np.float32(rec2[1]["iou"])) / np.float32(2))
+    assert abs(summ["f_score"] - (rec2[0]["fscore"] + rec2[1]["fscore"]) / 2) < 1e-12
+    want = MO.avss_final(*MO.batch_miou_fscore(direct[1].cpu().numpy()[None], gt_cls.numpy())[:3])
+    assert summ["avss"]["count"] == 1 and all(abs(summ["avss"][k] - want[k]) <= 1e-6 for k in want) and want["miou"] > 0
+    assert "_avss" not in rec2[2] and all("_avss" not in json.loads(l) for l in open(tmp_path / "res2.jsonl"))
+    summ_n = {}
+    rn = harness.run_inference_avs([withgt("ref-avs", "/data/avs/vidF/0/1.png", torch.zeros(1, 224, 224))], model, tok, str(tmp_path), max_new_tokens=n,
+                                   pad_token_id=2, eos_token_id=None, null_reference=True, summary=summ_n)
+    assert rn[0]["s"] == float(MO.metric_s_for_null(d0)) == summ_n["ms"] and "iou" not in rn[0]
     # no mask tokens in the output -> no masks, no file, the record says so (quick_start.py:303-306)
     for i in range(6):
         sp[f'<mask_{i}>'] = meta["base_vocab"] + 11 + i
