@@ -9,6 +9,7 @@ with the caller, who hands over uint8 frames and a 16 kHz mono waveform).
   prepare_sample                               utils/util.py:33-47              to_device
   inference_ntp / inference_avqa               quick_start.py:30-50, inference_hyper_lora.py:158-212   run_inference
   inference_ms3 / _s4 / _avss / _ref_avs       quick_start.py:270-450 (generate_avs -> mask -> PNG + record)   run_inference_avs
+  mask_iou / Eval_Fmeasure / metric_s_for_null / calc_color_miou_fscore + the loops' closing averages   utils/avss_utils.py, quick_start.py:118-135, 342-358, 395-447   crab_amd.avss_utils (device), summarise_avs
 
 Image and audio preprocessing run on the device through crab_amd.frontend (HIP kernels); prompts and ids are host work.
 The reference loops clip by clip on one GPU; run_inference shards the batches over ranks (crab_amd.parallel) and rank 0
