@@ -289,3 +289,54 @@ def test_attention_key_mask_against_dense_reference():
     with pytest.raises(Exception, match="key_mask"):
         ops.attn_fwd(q, k, vt, o, q_strides=(S * H * d, d, H * d), k_strides=(Hk * S * d, S * d, d), vt_strides=(Hk * d * Sp, d * Sp, Sp),
                      o_strides=(S * H * d, H * d), B=B, H=H, Hk=Hk, Sq=S, Skv=S, head_dim=d, scale=scale, causal=True, key_mask=km[:, :2].contiguous())
+
+
+def test_c_caller_of_the_segmentation_metrics_matches_the_python_mirror(tmp_path):
+    """examples/metrics_demo.c: crab_mask_iou / crab_fmeasure / crab_miou_fscore called from C on buffers it uploads itself; every output array
+    equals what crab_amd.avss_utils returns for the same masks, bit for bit (same library, same launches), and the CPU restatement's counts."""
+    from crab_amd import avss_utils as AU
+    from oracle import metrics_oracle as MO
+    exe = str(tmp_path / "metrics_demo")
+    subprocess.check_call(["gcc", "-O1", "-std=c99", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include",
+                           os.path.join(ROOT, "examples", "metrics_demo.c"), "-o", exe, "-L" + os.path.join(ROOT, "crab_amd"), "-lcrab_hip", "-L/opt/rocm/lib",
+                           "-lamdhip64", "-Wl,-rpath," + os.path.join(ROOT, "crab_amd"), "-Wl,-rpath,/opt/rocm/lib"])
+    rng = np.random.default_rng(9)
+    N, H, W, T, BF, C, h, w = 3, 37, 53, 255, 2, 71, 32, 48
+    pred = (rng.standard_normal((N, H, W)) * 3).astype(np.float32)
+    gt = (rng.random((N, H, W)) > 0.5).astype(np.float32)
+    gt[1] = 0
+    th = AU.fmeasure_thresholds(T)
+    cp = rng.standard_normal((BF, C, h, w)).astype(np.float32)
+    ct = rng.integers(-1, C + 2, (BF, h, w)).astype(np.int64)
+    with open(tmp_path / "in.bin", "wb") as f:
+        for a in (pred, gt, th, cp, ct):
+            f.write(a.tobytes())
+    r = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")] + [str(v) for v in (N, H * W, T, BF, C, h * w)],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "fmeasure" in r.stdout and "T <= 1024" in r.stdout                   # the rejected call left its message in crab_last_error
+    raw = open(tmp_path / "out.bin", "rb").read()
+    off = 0
+
+    def take(shape, dt):
+        nonlocal off
+        n = int(np.prod(shape)) * np.dtype(dt).itemsize
+        a = np.frombuffer(raw[off:off + n], dt).reshape(shape)
+        off += n
+        return a
+    counts, out2 = take((N, 6), np.int32), take((2,), np.float32)
+    ge, ysum, fscore, score, best = take((N, 2, T), np.int32), take((N, 2), np.int32), take((N, T), np.float32), take((T,), np.float32), take((2,), np.float32)
+    areas, iou_fc = take((BF, 3, C), np.int32), take((BF, C), np.float32)
+    ious, fsc, cls, vid = take((C,), np.float32), take((C,), np.float32), take((C,), np.float32), take((BF,), np.float32)
+    assert off == len(raw)
+    P, G = torch.from_numpy(pred).cuda(), torch.from_numpy(gt).cuda()
+    iou, pc = AU.mask_iou(P, G, details=True)
+    assert np.array_equal(counts, pc.numpy()) and out2[0] == iou.item() and out2[1] == AU.metric_s_for_null(P).item()
+    assert np.array_equal(counts[:, :5], MO.mask_counts(pred, gt))
+    val, d = AU.Eval_Fmeasure(P, G, details=True)
+    assert np.array_equal(ge, d["ge"].numpy()) and np.array_equal(ysum, d["ysum"].numpy()) and np.array_equal(fscore, d["fscore"].numpy())
+    assert np.array_equal(score, d["score"].numpy()) and best[0] == val and best[1] == 2
+    mi, fs, cc, vd, dd = AU.calc_color_miou_fscore(torch.from_numpy(cp).cuda(), torch.from_numpy(ct).cuda(), details=True)
+    assert np.array_equal(areas, dd["areas"].numpy()) and np.array_equal(areas, MO.class_areas(cp, ct)) and np.array_equal(iou_fc, dd["iou_fc"].numpy())
+    assert np.array_equal(ious, mi.cpu().numpy()) and np.array_equal(fsc, fs.cpu().numpy()) and np.array_equal(cls, cc.cpu().numpy())
+    assert np.array_equal(vid, torch.stack(vd).cpu().numpy(), equal_nan=True)
