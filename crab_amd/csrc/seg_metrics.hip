@@ -41,56 +41,86 @@ __device__ __forceinline__ int wave_sum(int v) {
     return v;
 }
 
-// counts[n][6] += {pred, target != 0, pred & target, pred | target, !pred & !target, target not in {0, 1}} over a slice of image n
+// counts[n][6] += {pred, target != 0, pred & target, pred | target, !pred & !target, target not in {0, 1}} over a slice of image n.
+// V4: four pixels per 16-byte load (hw % 4 == 0 and 16-byte aligned planes: the 224 x 224 masks of the eval loops).
+template <bool V4>
 __global__ __launch_bounds__(256) void mask_counts_kernel(const float* __restrict__ pred, const float* __restrict__ target, long hw, int* __restrict__ counts) {
     const int n = blockIdx.y;
     const float* p = pred + (long)n * hw;
     const float* t = target ? target + (long)n * hw : nullptr;
     int c[6] = {0, 0, 0, 0, 0, 0};
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += (long)gridDim.x * blockDim.x) {
-        const int pb = p[i] > 0.0f ? 1 : 0;
-        int tb = 0;
-        if (t) {
-            const float tv = t[i];
-            tb = tv != 0.0f ? 1 : 0;
-            c[5] += (tv != 0.0f && tv != 1.0f) ? 1 : 0;
-        }
+    auto one = [&](float pv, float tv) {
+        const int pb = pv > 0.0f ? 1 : 0, tb = tv != 0.0f ? 1 : 0;
+        c[5] += (tv != 0.0f && tv != 1.0f) ? 1 : 0;
         c[0] += pb; c[1] += tb; c[2] += pb & tb; c[3] += pb | tb; c[4] += (1 - pb) & (1 - tb);
+    };
+    const long step = (long)gridDim.x * blockDim.x, i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (V4) {
+        const long nv = hw >> 2;
+        for (long i = i0; i < nv; i += step) {
+            const f32x4_t pv = reinterpret_cast<const f32x4_t*>(p)[i];
+            f32x4_t tv = {0.f, 0.f, 0.f, 0.f};
+            if (t) tv = reinterpret_cast<const f32x4_t*>(t)[i];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) one(pv[k], tv[k]);
+        }
+    } else {
+        for (long i = i0; i < hw; i += step) one(p[i], t ? t[i] : 0.0f);
     }
+    // one global atomic per (block, counter): per-wave atomics serialised on the 6 words of an image (25 blocks x 4 waves each: 20 of the launch's 33 us)
+    __shared__ int blk[6];
+    if (threadIdx.x < 6) blk[threadIdx.x] = 0;
+    __syncthreads();
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
         const int s = wave_sum(c[k]);
-        if ((threadIdx.x & 63) == 0 && s) atomicAdd(&counts[n * 6 + k], s);
+        if ((threadIdx.x & 63) == 0 && s) atomicAdd(&blk[k], s);
     }
+    __syncthreads();
+    if (threadIdx.x < 6 && blk[threadIdx.x]) atomicAdd(&counts[n * 6 + threadIdx.x], blk[threadIdx.x]);
 }
 
-// out[0] = sum_n inter_n / (union_n + eps) / N  with the empty-target substitution (avss_utils.py:35-45); out[1] = sqrt(sum_n pred_n / (N hw))
-__global__ void mask_iou_finish_kernel(const int* __restrict__ counts, int N, long hw, float eps, int has_target, float* __restrict__ out) {
-    if (threadIdx.x || blockIdx.x) return;
+// out[0] = sum_n inter_n / (union_n + eps) / N  with the empty-target substitution (avss_utils.py:35-45); out[1] = sqrt(sum_n pred_n / (N hw)).
+// The per-image ratios are formed by the block's threads side by side (a single thread walking the images pays one memory latency per image:
+// 64 images took 40 us); thread 0 then adds them in image order, chunk after chunk.
+__global__ __launch_bounds__(256) void mask_iou_finish_kernel(const int* __restrict__ counts, int N, long hw, float eps, int has_target, float* __restrict__ out) {
+    __shared__ float term[256];
+    __shared__ long long px;
+    const int tid = threadIdx.x;
+    if (tid == 0) px = 0;
+    __syncthreads();
     float acc = 0.f;
-    long px = 0;
-    for (int n = 0; n < N; ++n) {
-        const int* c = counts + n * 6;
-        px += c[0];
-        if (has_target) {
+    for (int n0 = 0; n0 < N; n0 += 256) {
+        const int n = n0 + tid;
+        if (n < N) {
+            const int* c = counts + n * 6;
             float inter = (float)c[2], uni = (float)c[3];
             if (c[1] == 0) { inter = (float)c[4]; uni = (float)hw; }
-            acc = add_rn(acc, div_rn(inter, add_rn(uni, eps)));
+            term[tid] = div_rn(inter, add_rn(uni, eps));
+            atomicAdd((unsigned long long*)&px, (unsigned long long)c[0]);
         }
+        __syncthreads();
+        if (tid == 0 && has_target)
+            for (int k = 0; k < min(256, N - n0); ++k) acc = add_rn(acc, term[k]);
+        __syncthreads();
     }
-    out[0] = has_target ? div_rn(acc, (float)N) : 0.f;
-    out[1] = sqrtf(div_rn((float)px, (float)((long)N * hw)));
+    if (tid == 0) {
+        out[0] = has_target ? div_rn(acc, (float)N) : 0.f;
+        out[1] = sqrtf(div_rn((float)px, (float)((long)N * hw)));
+    }
 }
 
-// One block per image.  ge[n][0][i] = #{gt & sigmoid(pred) >= th_i}, ge[n][1][i] = #{sigmoid(pred) >= th_i}; ysum[n] = {gt pixels, gt not in {0,1}};
-// fscore[n][i] = (1 + b2) P R / (b2 P + R), NaN -> 0, with P = tp / (count + 1e-20), R = tp / (gt pixels + 1e-20)      (avss_utils.py:50-64, 88-89)
-__global__ __launch_bounds__(1024) void fmeasure_image_kernel(const float* __restrict__ pred, const float* __restrict__ gt, long hw,
-                                                              const float* __restrict__ thresholds, int T, float one_b2, float b2,
-                                                              int* __restrict__ ge, int* __restrict__ ysum, float* __restrict__ fscore) {
+// Pass 1, FM_SPLIT blocks per image: the histogram of sigmoid(pred) over the threshold table.  Bin k = #{j : th_j <= s} in [0, T]; bin 0 (below
+// every threshold) is counted nowhere, bins 1..T go to ge[n][1][k-1] (all pixels) and ge[n][0][k-1] (gt pixels) through an LDS histogram and one
+// global atomic per non-empty bin and block; ysum[n] += {gt pixels, gt pixels outside {0, 1}}.  ge / ysum are zeroed by the caller (memset).
+// (One block per image did all of this in 58 us at 224 x 224 - fp64 sigmoid + LDS atomics of 49 pixels per thread in a row.)
+constexpr int FM_SPLIT_MAX = 16;
+__global__ __launch_bounds__(256) void fmeasure_hist_kernel(const float* __restrict__ pred, const float* __restrict__ gt, long hw,
+                                                            const float* __restrict__ thresholds, int T, int* __restrict__ ge, int* __restrict__ ysum) {
     __shared__ float th[SM_MAXT];
     __shared__ int cnt[SM_MAXT + 1], tp[SM_MAXT + 1];
     __shared__ int ys, bad;
-    const int n = blockIdx.x, tid = threadIdx.x;
+    const int n = blockIdx.y, tid = threadIdx.x;
     for (int i = tid; i < T; i += blockDim.x) th[i] = thresholds[i];
     for (int i = tid; i <= T; i += blockDim.x) { cnt[i] = 0; tp[i] = 0; }
     if (tid == 0) { ys = 0; bad = 0; }
@@ -98,7 +128,7 @@ __global__ __launch_bounds__(1024) void fmeasure_image_kernel(const float* __res
     const float* p = pred + (long)n * hw;
     const float* g = gt + (long)n * hw;
     int my_y = 0, my_bad = 0;
-    for (long i = tid; i < hw; i += blockDim.x) {
+    for (long i = (long)blockIdx.x * blockDim.x + tid; i < hw; i += (long)gridDim.x * blockDim.x) {
         const float s = sigmoid_rn(p[i]);
         const float gv = g[i];
         int lo = 0, hi = T;                                     // k = #{j : th_j <= s}  (ascending thresholds; NaN -> 0, as `NaN >= th` is false)
@@ -112,10 +142,26 @@ __global__ __launch_bounds__(1024) void fmeasure_image_kernel(const float* __res
     my_y = wave_sum(my_y); my_bad = wave_sum(my_bad);
     if ((tid & 63) == 0) { if (my_y) atomicAdd(&ys, my_y); if (my_bad) atomicAdd(&bad, my_bad); }
     __syncthreads();
-    if (tid == 0) { ysum[n * 2] = ys; ysum[n * 2 + 1] = bad; }
+    if (tid == 0) { if (ys) atomicAdd(&ysum[n * 2], ys); if (bad) atomicAdd(&ysum[n * 2 + 1], bad); }
+    for (int k = 1 + tid; k <= T; k += blockDim.x) {
+        if (tp[k]) atomicAdd(&ge[((long)n * 2 + 0) * T + k - 1], tp[k]);
+        if (cnt[k]) atomicAdd(&ge[((long)n * 2 + 1) * T + k - 1], cnt[k]);
+    }
+}
+
+// Pass 2, one block per image: the bins become suffix sums in place - ge[n][0][i] = #{gt & sigmoid(pred) >= th_i}, ge[n][1][i] = #{sigmoid(pred) >= th_i}
+// = the reference's 255 `(y_pred >= th_i)` sweeps - and fscore[n][i] = (1 + b2) P R / (b2 P + R), NaN -> 0, with P = tp / (count + 1e-20),
+// R = tp / (gt pixels + 1e-20)      (avss_utils.py:50-64, 88-89)
+__global__ __launch_bounds__(1024) void fmeasure_image_kernel(int T, float one_b2, float b2, int* __restrict__ ge, const int* __restrict__ ysum,
+                                                              float* __restrict__ fscore) {
+    __shared__ int cnt[SM_MAXT], tp[SM_MAXT];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    for (int i = tid; i < T; i += blockDim.x) { tp[i] = ge[((long)n * 2 + 0) * T + i]; cnt[i] = ge[((long)n * 2 + 1) * T + i]; }
+    const int ys = ysum[n * 2];
+    __syncthreads();
     for (int i = tid; i < T; i += blockDim.x) {
         int c = 0, t = 0;
-        for (int k = i + 1; k <= T; ++k) { c += cnt[k]; t += tp[k]; }
+        for (int k = i; k < T; ++k) { c += cnt[k]; t += tp[k]; }                           // bins i+1 .. T live at indices i .. T-1
         ge[((long)n * 2 + 0) * T + i] = t;
         ge[((long)n * 2 + 1) * T + i] = c;
         const float ft = (float)t;
@@ -133,12 +179,28 @@ __global__ __launch_bounds__(1024) void fmeasure_finish_kernel(const float* __re
     __shared__ float mx[1024];
     const int tid = threadIdx.x;
     float m = 0.f;                                              // scores are >= 0 (NaN already 0); no image counted -> zeros(pr_num).max() = 0
-    int cnt = 0;
-    for (int n = 0; n < N; ++n) cnt += ysum[n * 2] > 0 ? 1 : 0;
+    __shared__ int cnt_s;
+    if (tid == 0) cnt_s = 0;
+    __syncthreads();
+    for (int n = tid; n < N; n += blockDim.x)
+        if (ysum[n * 2] > 0) atomicAdd(&cnt_s, 1);
+    __syncthreads();
+    const int cnt = cnt_s;
     for (int i = tid; i < T; i += blockDim.x) {
         float acc = 0.f;
-        for (int n = 0; n < N; ++n)
-            if (ysum[n * 2] > 0) acc = add_rn(acc, fscore[(long)n * T + i]);
+        for (int n0 = 0; n0 < N; n0 += 8) {                     // eight images' loads in flight, then the adds in image order
+            float v[8];
+            int ok[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int n = min(n0 + j, N - 1);
+                v[j] = fscore[(long)n * T + i];
+                ok[j] = ysum[n * 2] > 0;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (n0 + j < N && ok[j]) acc = add_rn(acc, v[j]);
+        }
         const float s = cnt ? div_rn(acc, (float)cnt) : 0.f;
         score[i] = s;
         m = fmaxf(m, s);
@@ -155,6 +217,9 @@ __global__ __launch_bounds__(1024) void fmeasure_finish_kernel(const float* __re
 // areas[f][0][c] += #{argmax == c == target}, [f][1][c] += #{argmax == c, target >= 0}, [f][2][c] += #{target == c} over a slice of frame f.
 // The reference shifts both maps by one, zeroes the prediction where target + 1 <= 0, and counts with histc over [1, nclass]: values outside
 // that range (a negative or >= nclass label) fall out of every histogram (avss_utils.py:386-402).
+// PX pixels per thread (PX = 4: one 16-byte load per class plane, hw % 4 == 0), the class loop unrolled 8 deep so that eight plane loads are
+// in flight per thread - a pixel's C values are C separate planes, [C][hw]: with one pixel and one load at a time the pass ran at 3.0 TB/s.
+template <int PX>
 __global__ __launch_bounds__(256) void class_areas_kernel(const float* __restrict__ pred, const long long* __restrict__ target, int C, long hw,
                                                           int* __restrict__ areas) {
     __shared__ int h[3][SM_MAXT];
@@ -163,19 +228,46 @@ __global__ __launch_bounds__(256) void class_areas_kernel(const float* __restric
     __syncthreads();
     const float* p = pred + (long)f * C * hw;
     const long long* t = target + (long)f * hw;
-    for (long i = (long)blockIdx.x * blockDim.x + tid; i < hw; i += (long)gridDim.x * blockDim.x) {
-        float best = p[i];
-        int bi = 0;
-        for (int c = 1; c < C; ++c) {
-            const float v = p[(long)c * hw + i];
-            if (v > best) { best = v; bi = c; }
+    typedef __attribute__((ext_vector_type(PX))) float vec_t;
+    const long nv = hw / PX;
+    for (long i = (long)blockIdx.x * blockDim.x + tid; i < nv; i += (long)gridDim.x * blockDim.x) {
+        float best[PX];
+        int bi[PX];
+        {
+            const vec_t v = *reinterpret_cast<const vec_t*>(p + i * PX);
+#pragma unroll
+            for (int k = 0; k < PX; ++k) { best[k] = PX == 1 ? ((const float*)&v)[0] : v[k]; bi[k] = 0; }
         }
-        const long long tv = t[i];
-        if (tv >= 0) {
-            atomicAdd(&h[1][bi], 1);
-            if (tv < C) {
-                atomicAdd(&h[2][(int)tv], 1);
-                if (tv == bi) atomicAdd(&h[0][bi], 1);
+        int c = 1;
+        for (; c + 8 <= C; c += 8) {
+            vec_t v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const vec_t*>(p + (long)(c + j) * hw + i * PX);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int k = 0; k < PX; ++k) {
+                    const float x = PX == 1 ? ((const float*)&v[j])[0] : v[j][k];
+                    if (x > best[k]) { best[k] = x; bi[k] = c + j; }
+                }
+        }
+        for (; c < C; ++c) {
+            const vec_t v = *reinterpret_cast<const vec_t*>(p + (long)c * hw + i * PX);
+#pragma unroll
+            for (int k = 0; k < PX; ++k) {
+                const float x = PX == 1 ? ((const float*)&v)[0] : v[k];
+                if (x > best[k]) { best[k] = x; bi[k] = c; }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PX; ++k) {
+            const long long tv = t[i * PX + k];
+            if (tv >= 0) {
+                atomicAdd(&h[1][bi[k]], 1);
+                if (tv < C) {
+                    atomicAdd(&h[2][(int)tv], 1);
+                    if (tv == bi[k]) atomicAdd(&h[0][bi[k]], 1);
+                }
             }
         }
     }
@@ -186,39 +278,54 @@ __global__ __launch_bounds__(256) void class_areas_kernel(const float* __restric
     }
 }
 
-// Thread c: the per-class sums over the frames in frame order; then thread f: the frame's mean IoU over its classes with a non-zero IoU.
+// One block.  Frames are taken in chunks of floor(4096 / C): every (frame, class) pair of a chunk gets its IoU, F and union flag from one thread
+// (the correctly rounded divisions are ~100 dependent instructions per pair: with one thread per CLASS walking 64 frames the launch took 38 us
+// on 71 busy lanes), staged in LDS; then thread c adds its class over the chunk's frames IN FRAME ORDER and thread f adds its frame over the classes
+// in class order - the reference's `ious += iou` per frame and `torch.sum(iou)` restated as index-order sums.
+constexpr int MF_PAIRS = 4096;
 __global__ __launch_bounds__(1024) void miou_finish_kernel(const int* __restrict__ areas, int BF, int C, float one_b2, float b2, float* __restrict__ iou_fc,
                                                            float* __restrict__ ious, float* __restrict__ fscores, float* __restrict__ cls_count,
                                                            float* __restrict__ vid_miou) {
-    const int tid = threadIdx.x;
-    for (int c = tid; c < C; c += blockDim.x) {
-        float si = 0.f, sf = 0.f, sc = 0.f;
-        for (int f = 0; f < BF; ++f) {
+    __shared__ float iou_s[MF_PAIRS], fs_s[MF_PAIRS], un_s[MF_PAIRS];
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int chunk = min(MF_PAIRS / C, nthr);                  // >= 4 frames (C <= 1024), at most one frame per thread
+    // per-class running sums live in the registers of thread c (c = tid, tid + nthr, ...: C <= 1024 = nthr, so one class per thread)
+    float si = 0.f, sf = 0.f, sc = 0.f;
+    for (int f0 = 0; f0 < BF; f0 += chunk) {
+        const int nf = min(chunk, BF - f0);
+        for (int q = tid; q < nf * C; q += nthr) {
+            const int fi = q / C, c = q % C, f = f0 + fi;
             const float ai = (float)areas[((long)f * 3 + 0) * C + c], ap = (float)areas[((long)f * 3 + 1) * C + c], al = (float)areas[((long)f * 3 + 2) * C + c];
             const float au = sub_rn(add_rn(ap, al), ai);
             const float iou = div_rn(ai, add_rn(2.220446049250313e-16f, au));
-            iou_fc[(long)f * C + c] = iou;
-            si = add_rn(si, iou);
-            if (au != 0.f) sc = add_rn(sc, 1.f);
             const float prec = div_rn(ai, ap), rec = div_rn(ai, al);                    // 0 / 0 = NaN, as in the reference
             float fs = div_rn(mul_rn(mul_rn(one_b2, prec), rec), add_rn(mul_rn(b2, prec), rec));
             if (fs != fs) fs = 0.f;
-            sf = add_rn(sf, fs);
+            iou_fc[(long)f * C + c] = iou;
+            iou_s[q] = iou; fs_s[q] = fs; un_s[q] = au != 0.f ? 1.f : 0.f;
         }
-        ious[c] = si; fscores[c] = sf; cls_count[c] = sc;
-    }
-    __threadfence();                                            // iou_fc rows are read below by other threads of this block
-    __syncthreads();
-    for (int f = tid; f < BF; f += blockDim.x) {
-        float s = 0.f;
-        int nz = 0;
-        for (int c = 0; c < C; ++c) {
-            const float v = iou_fc[(long)f * C + c];
-            s = add_rn(s, v);
-            nz += v != 0.f ? 1 : 0;
+        __syncthreads();
+        if (tid < C)
+            for (int fi = 0; fi < nf; ++fi) {
+                si = add_rn(si, iou_s[fi * C + tid]);
+                sf = add_rn(sf, fs_s[fi * C + tid]);
+                if (un_s[fi * C + tid] != 0.f) sc = add_rn(sc, 1.f);
+            }
+        // the chunk's frames: one thread per frame, taken from the top of the block so that they do not queue behind the class threads' waves
+        const int fi = nthr - 1 - tid;
+        if (fi < nf) {
+            float s = 0.f;
+            int nz = 0;
+            for (int c = 0; c < C; ++c) {
+                const float v = iou_s[fi * C + c];
+                s = add_rn(s, v);
+                nz += v != 0.f ? 1 : 0;
+            }
+            vid_miou[f0 + fi] = div_rn(s, (float)nz);           // no class with a non-zero IoU: 0 / 0 = NaN, as torch.sum(iou) / 0
         }
-        vid_miou[f] = div_rn(s, (float)nz);                  // no class with a non-zero IoU: 0 / 0 = NaN, as torch.sum(iou) / 0
+        __syncthreads();
     }
+    if (tid < C) { ious[tid] = si; fscores[tid] = sf; cls_count[tid] = sc; }
 }
 
 }  // namespace
@@ -232,12 +339,14 @@ int crab_mask_iou(crab_ctx* ctx, void* stream, const float* pred, const float* t
     if (!pred || !counts || !out || N <= 0 || hw <= 0 || (int64_t)N * hw >= ((int64_t)1 << 31))
         return crab_fail(ctx, CRAB_E_INVALID, "mask_iou: pred [N, hw] fp32, counts [N, 6] int32, out [2] fp32, N hw < 2^31");
     CRAB_HIP_TRY(ctx, hipMemsetAsync(counts, 0, (size_t)N * 6 * sizeof(int32_t), S_(stream)));
-    long bx = (hw + 256 * 8 - 1) / (256 * 8);
+    const bool v4 = (hw & 3) == 0 && (((uintptr_t)pred | (uintptr_t)target) & 15) == 0;
+    long bx = (hw + 256 * 16 - 1) / (256 * 16);                // 16 pixels per thread (four 16-byte loads per plane in the vector form)
     if (bx > 1024) bx = 1024;
-    hipLaunchKernelGGL(mask_counts_kernel, dim3((unsigned)bx, (unsigned)N), dim3(256), 0, S_(stream), pred, target, (long)hw, counts);
+    if (v4) hipLaunchKernelGGL((mask_counts_kernel<true>), dim3((unsigned)bx, (unsigned)N), dim3(256), 0, S_(stream), pred, target, (long)hw, counts);
+    else hipLaunchKernelGGL((mask_counts_kernel<false>), dim3((unsigned)bx, (unsigned)N), dim3(256), 0, S_(stream), pred, target, (long)hw, counts);
     int rc = crab_check_launch(ctx, "mask_counts_kernel");
     if (rc) return rc;
-    hipLaunchKernelGGL(mask_iou_finish_kernel, dim3(1), dim3(64), 0, S_(stream), (const int*)counts, N, (long)hw, eps, target ? 1 : 0, out);
+    hipLaunchKernelGGL(mask_iou_finish_kernel, dim3(1), dim3(256), 0, S_(stream), (const int*)counts, N, (long)hw, eps, target ? 1 : 0, out);
     return crab_check_launch(ctx, "mask_iou_finish_kernel");
 }
 
@@ -247,8 +356,15 @@ int crab_fmeasure(crab_ctx* ctx, void* stream, const float* pred, const float* g
     if (!pred || !gt || !thresholds || !ge || !ysum || !fscore || !score || !best || N <= 0 || hw <= 0 || hw >= ((int64_t)1 << 31) || T <= 0 || T > SM_MAXT)
         return crab_fail(ctx, CRAB_E_INVALID, "fmeasure: pred / gt [N, hw] fp32, 1 <= T <= 1024 ascending thresholds, hw < 2^31");
     const float one_b2 = (float)(1.0 + beta2), b2 = (float)beta2;
-    hipLaunchKernelGGL(fmeasure_image_kernel, dim3((unsigned)N), dim3(1024), 0, S_(stream), pred, gt, (long)hw, thresholds, T, one_b2, b2, (int*)ge, (int*)ysum, fscore);
-    int rc = crab_check_launch(ctx, "fmeasure_image_kernel");
+    CRAB_HIP_TRY(ctx, hipMemsetAsync(ge, 0, (size_t)N * 2 * T * sizeof(int32_t), S_(stream)));
+    CRAB_HIP_TRY(ctx, hipMemsetAsync(ysum, 0, (size_t)N * 2 * sizeof(int32_t), S_(stream)));
+    long split = (hw + 256 * 16 - 1) / (256 * 16);             // ~16 pixels per thread; a few images fill the chip through the split, many through N
+    if (split > FM_SPLIT_MAX) split = FM_SPLIT_MAX;
+    hipLaunchKernelGGL(fmeasure_hist_kernel, dim3((unsigned)split, (unsigned)N), dim3(256), 0, S_(stream), pred, gt, (long)hw, thresholds, T, (int*)ge, (int*)ysum);
+    int rc = crab_check_launch(ctx, "fmeasure_hist_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(fmeasure_image_kernel, dim3((unsigned)N), dim3(1024), 0, S_(stream), T, one_b2, b2, (int*)ge, (const int*)ysum, fscore);
+    rc = crab_check_launch(ctx, "fmeasure_image_kernel");
     if (rc) return rc;
     hipLaunchKernelGGL(fmeasure_finish_kernel, dim3(1), dim3(1024), 0, S_(stream), (const float*)fscore, (const int*)ysum, N, T, score, best);
     return crab_check_launch(ctx, "fmeasure_finish_kernel");
@@ -261,9 +377,11 @@ int crab_miou_fscore(crab_ctx* ctx, void* stream, const float* pred, const int64
         hw >= ((int64_t)1 << 31))
         return crab_fail(ctx, CRAB_E_INVALID, "miou_fscore: pred [BF, C, hw] fp32, target [BF, hw] int64, 1 <= C <= 1024, hw < 2^31");
     CRAB_HIP_TRY(ctx, hipMemsetAsync(areas, 0, (size_t)BF * 3 * C * sizeof(int32_t), S_(stream)));
-    long bx = (hw + 255) / 256;                                // one pixel per thread: a pixel already costs C strided loads
+    const bool v4 = (hw & 3) == 0 && ((uintptr_t)pred & 15) == 0;
+    long bx = ((v4 ? hw / 4 : hw) + 255) / 256;                // one pixel group per thread: it already costs C plane loads
     if (bx > 4096) bx = 4096;
-    hipLaunchKernelGGL(class_areas_kernel, dim3((unsigned)bx, (unsigned)BF), dim3(256), 0, S_(stream), pred, (const long long*)target, C, (long)hw, (int*)areas);
+    if (v4) hipLaunchKernelGGL((class_areas_kernel<4>), dim3((unsigned)bx, (unsigned)BF), dim3(256), 0, S_(stream), pred, (const long long*)target, C, (long)hw, (int*)areas);
+    else hipLaunchKernelGGL((class_areas_kernel<1>), dim3((unsigned)bx, (unsigned)BF), dim3(256), 0, S_(stream), pred, (const long long*)target, C, (long)hw, (int*)areas);
     int rc = crab_check_launch(ctx, "class_areas_kernel");
     if (rc) return rc;
     hipLaunchKernelGGL(miou_finish_kernel, dim3(1), dim3(1024), 0, S_(stream), (const int*)areas, BF, C, (float)(1.0 + beta2), (float)beta2, iou_fc, ious, fscores,

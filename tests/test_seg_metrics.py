@@ -213,6 +213,14 @@ def test_hip_metrics_full_size_and_edges_vs_oracle():
     assert np.array_equal(d["areas"].numpy(), MO.class_areas(cp, ct)) and d["areas"][:, 1].sum().item() == BF * H * W
     assert np.array_equal(mi.cpu().numpy(), omi) and np.array_equal(fs.cpu().numpy(), ofs) and np.array_equal(cc.cpu().numpy(), occ)
     assert np.array_equal(d["iou_fc"].numpy(), oiou) and np.array_equal(torch.stack(vid).cpu().numpy(), ovid)
+    for (bf, c, hh, ww) in ((2, 5, 7, 9), (1, 20, 3, 4), (3, 9, 1, 1), (70, 71, 4, 4), (1100, 2, 2, 2)):   # the last two: frames beyond one LDS chunk of the finish                   # odd planes (scalar loads), C across the 8-deep unroll
+        xp = rng.standard_normal((bf, c, hh, ww)).astype(np.float32)
+        xt = rng.integers(-1, c + 1, (bf, hh, ww)).astype(np.int64)
+        r = AU.calc_color_miou_fscore(_dev(xp), _dev(xt), details=True)
+        o = MO.batch_miou_fscore(xp, xt)
+        assert np.array_equal(r[4]["areas"].numpy(), MO.class_areas(xp, xt))
+        for got, want in zip((r[0], r[1], r[2], torch.stack(r[3])), o[:4]):
+            assert np.array_equal(got.cpu().numpy(), want, equal_nan=True)
     meter = AU.AVSSMeter(C)
     sums = [np.zeros(C, np.float32) for _ in range(3)]
     for f in range(BF):
