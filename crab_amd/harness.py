@@ -365,11 +365,12 @@ def run_inference_avs(batches: Iterable[Mapping[str, Any]], model, tokenizer, ou
         if rank == 0:
             records = sorted((r for part in gathered for r in part), key=lambda t: t[0])
     out = [r for _, r in records]
+    if rank == 0 and summary is not None:
+        summary.update(summarise_avs(out))
+    for rec in out:
+        rec.pop("_avss", None)                                          # 3 x classes floats per sample: summed above, not part of the record
     if rank == 0:
-        if summary is not None:
-            summary.update(summarise_avs(out))
         for rec in out:
-            rec.pop("_avss", None)                                      # 3 x classes floats per sample: summed above, not part of the record
             if on_result is not None:
                 on_result(rec)
         if out_path is not None:
