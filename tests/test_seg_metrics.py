@@ -120,6 +120,8 @@ def test_hip_binary_metrics_match_fixture_and_oracle():
     assert np.array_equal(counts[:, :5].numpy(), MO.mask_counts(pred, gt)) and int(counts[:, 5].sum()) == 0
     assert iou.dim() == 0 and iou.dtype == torch.float32
     _close(iou.item(), A["iou_all"])
+    from tests.util import record_parity
+    record_parity("seg metrics: mask_iou (4 masks) vs the reference's value", abs(iou.item() - float(A["iou_all"])), float(A["iou_all"]), tol=REL, counts_exact=True)
     assert iou.item() == float(MO.mask_iou(pred, gt))                                      # both add in image order
     for n in range(N):
         assert AU.mask_iou(P[n:n + 1], G[n:n + 1]).item() == float(A["iou_each"][n])
@@ -130,6 +132,8 @@ def test_hip_binary_metrics_match_fixture_and_oracle():
     oval, od = MO.eval_fmeasure(pred, gt, details=True)
     assert np.array_equal(d["fscore"].numpy(), od["fscore"]) and np.array_equal(d["score"].numpy(), od["score"]) and val == oval
     _close(val, float(A["f_all"]))
+    record_parity("seg metrics: Eval_Fmeasure (4 masks, 255 thresholds) vs the reference's value", abs(val - float(A["f_all"])), float(A["f_all"]), tol=REL,
+                  threshold_counts_exact=True)
     for n in range(N):
         assert AU.Eval_Fmeasure(P[n:n + 1], G[n:n + 1]) == float(A["f_each"][n])
     assert AU.Eval_Fmeasure(P[1:2], G[1:2]) == 0.0
@@ -146,6 +150,9 @@ def test_hip_class_metrics_match_fixture_and_oracle():
     assert np.array_equal(cc.cpu().numpy(), A["cls_count"]) and np.array_equal(d["iou_fc"].numpy(), A["cls_iou_fc"])
     assert isinstance(vid, list) and len(vid) == cp.shape[0] and vid[0].dim() == 0
     _close(torch.stack(vid).cpu().numpy(), A["cls_vid"])
+    from tests.util import record_parity
+    record_parity("seg metrics: calc_color_miou_fscore per-frame mean IoU vs the reference's values (per-class sums bit-equal)",
+                  float(np.abs(torch.stack(vid).cpu().numpy() - A["cls_vid"]).max()), float(np.abs(A["cls_vid"]).max()), tol=REL, areas_exact=True)
     assert np.array_equal(torch.stack(vid).cpu().numpy(), MO.batch_miou_fscore(cp, ct)[3])
     # int32 / uint8 label maps are accepted (cast to the reference's int64), float ones are not
     mi2, *_ = AU.calc_color_miou_fscore(_dev(cp), _dev(np.where(ct < 0, 200, ct).astype(np.uint8)))
