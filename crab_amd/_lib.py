@@ -211,6 +211,7 @@ SYMBOLS = {
     "crab_mask_iou": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _f, _vp, _vp]),
     "crab_fmeasure": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _vp, _i, C.c_double, _vp, _vp, _vp, _vp, _vp]),
     "crab_miou_fscore": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i64, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "crab_color_to_label": (_i, [_vp, _vp, _vp, _i64, _vp, _i, _vp]),
     "crab_bicubic_ksize": (_i, [_i, _i]),
     "crab_bicubic_coeffs": (_i, [_i, _i, _vp, _vp, _i]),
     "crab_resample_u8": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _i]),

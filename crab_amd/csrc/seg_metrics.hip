@@ -328,6 +328,23 @@ __global__ __launch_bounds__(1024) void miou_finish_kernel(const int* __restrict
     if (tid < C) { ious[tid] = si; fscores[tid] = sf; cls_count[tid] = sc; }
 }
 
+// AVSS ground truth, colour map -> class ids (dataset/quick_start_dataset.py:63-73 color_mask_to_label, called on the PIL mask right before it
+// becomes X_modals['<mask>'], :534-539): out[p] = the FIRST palette entry equal to the pixel's (r, g, b), 0 when none is (the reference stacks one
+// equality plane per colour and takes the argmax, which is 0 for an all-zero row).  One thread per pixel, the palette (<= 256 x 3 bytes) in LDS.
+__global__ __launch_bounds__(256) void color_to_label_kernel(const uint8_t* __restrict__ rgb, long hw, const uint8_t* __restrict__ palette, int n,
+                                                             long long* __restrict__ out) {
+    __shared__ uint32_t pal[256];
+    for (int i = threadIdx.x; i < n; i += blockDim.x) pal[i] = (uint32_t)palette[i * 3] | ((uint32_t)palette[i * 3 + 1] << 8) | ((uint32_t)palette[i * 3 + 2] << 16);
+    __syncthreads();
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= hw) return;
+    const uint32_t v = (uint32_t)rgb[p * 3] | ((uint32_t)rgb[p * 3 + 1] << 8) | ((uint32_t)rgb[p * 3 + 2] << 16);
+    int lab = 0;
+    for (int i = n - 1; i >= 0; --i)
+        if (pal[i] == v) lab = i;                               // descending: the lowest matching index survives
+    out[p] = lab;
+}
+
 }  // namespace
 
 #define S_(x) ((hipStream_t)(x))
@@ -387,6 +404,13 @@ int crab_miou_fscore(crab_ctx* ctx, void* stream, const float* pred, const int64
     hipLaunchKernelGGL(miou_finish_kernel, dim3(1), dim3(1024), 0, S_(stream), (const int*)areas, BF, C, (float)(1.0 + beta2), (float)beta2, iou_fc, ious, fscores,
                        cls_count, vid_miou);
     return crab_check_launch(ctx, "miou_finish_kernel");
+}
+
+int crab_color_to_label(crab_ctx* ctx, void* stream, const uint8_t* rgb, int64_t hw, const uint8_t* palette, int n, int64_t* out) {
+    if (!ctx) return CRAB_E_INVALID;
+    if (!rgb || !palette || !out || hw <= 0 || n <= 0 || n > 256) return crab_fail(ctx, CRAB_E_INVALID, "color_to_label: rgb [hw, 3] uint8, palette [n <= 256, 3] uint8, out [hw] int64");
+    hipLaunchKernelGGL(color_to_label_kernel, dim3((unsigned)((hw + 255) / 256)), dim3(256), 0, S_(stream), rgb, (long)hw, palette, n, (long long*)out);
+    return crab_check_launch(ctx, "color_to_label_kernel");
 }
 
 }  // extern "C"

@@ -245,9 +245,9 @@ def run_inference(batches: Iterable[Mapping[str, Any]], model, tokenizer, max_ne
 
 
 def default_palette(n: int = 71) -> np.ndarray:
-    """A deterministic [n, 3] uint8 colour table for the AVSS class map (the PASCAL-VOC bit-shuffle palette; background = class 0 = black).
-    The reference builds its table from a dataset file on its cluster (utils/avss_utils.py get_v2_pallete over label2idx.json), which is
-    data, not code: hand that table in as `palette=` to reproduce its colours."""
+    """The [n, 3] uint8 colour table of the AVSS class map: the PASCAL-VOC bit-shuffle palette (background = class 0 = black).  This IS the
+    reference's table: get_v2_pallete (dataset/quick_start_dataset.py:35-59) builds it with the same bit shuffle and reads its cluster file
+    label2idx.json only to assert the class count (pinned by tests/golden/seg_metrics.npz: `v2_pallete`)."""
     pal = np.zeros((n, 3), np.uint8)
     for i in range(n):
         c, r, g, b = i, 0, 0, 0
@@ -290,6 +290,29 @@ def summarise_avs(records: Sequence[Mapping[str, Any]]) -> Dict[str, Any]:
         fs[np.isnan(fs)] = 0
         out["avss"] = {"miou": float(mi.mean(dtype=np.float32)), "miou_noBg": float(mi[:-1].mean(dtype=np.float32)),
                        "f_score": float(fs.mean(dtype=np.float32)), "f_score_noBg": float(fs[:-1].mean(dtype=np.float32)), "count": len(av)}
+    return out
+
+
+get_v2_pallete = default_palette                                    # the reference's name for it (its argument is the class count here)
+
+
+def color_mask_to_label(mask, v_pallete: Optional[np.ndarray] = None, device="cuda") -> torch.Tensor:
+    """dataset/quick_start_dataset.py:63-73 (called at :537 on the mask after `.convert('RGB').resize((224, 224), NEAREST)`): the AVSS colour map
+    -> class ids, on the device (crab_color_to_label): `mask` = a PIL RGB image / uint8 array / uint8 tensor [H, W, 3] -> int64 [H, W] = the first
+    palette index whose colour equals the pixel, 0 where none does.  `.unsqueeze(0)` of it is the '<mask>' of the avss sample (:538)."""
+    from . import _lib
+    from .ops import _dev, _p, _stream
+    pal = default_palette() if v_pallete is None else np.asarray(v_pallete)
+    if pal.ndim != 2 or pal.shape[1] != 3 or not 1 <= pal.shape[0] <= 256 or pal.min() < 0 or pal.max() > 255:
+        raise _lib.CrabHipError("color_mask_to_label: palette [n <= 256, 3] with entries in 0..255 expected")
+    m = mask if isinstance(mask, torch.Tensor) else torch.from_numpy(np.array(mask))          # (a copy: np.asarray of a PIL image is read-only)
+    if m.dtype != torch.uint8 or m.dim() != 3 or m.shape[2] != 3:
+        raise _lib.CrabHipError(f"color_mask_to_label: uint8 [H, W, 3] expected, got {m.dtype} {tuple(m.shape)}")
+    m = m.to(device).contiguous()
+    d = _dev(m)
+    p = torch.from_numpy(np.ascontiguousarray(pal.astype(np.uint8))).to(m.device)
+    out = torch.empty(m.shape[:2], device=m.device, dtype=torch.int64)
+    _lib.check(_lib.load().crab_color_to_label(_lib.ctx(d), _stream(), _p(m), m.shape[0] * m.shape[1], _p(p), int(pal.shape[0]), _p(out)), d)
     return out
 
 

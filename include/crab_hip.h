@@ -512,6 +512,10 @@ int crab_fmeasure(crab_ctx* ctx, void* stream, const float* pred, const float* g
                   int32_t* ge, int32_t* ysum, float* fscore, float* score, float* best);
 int crab_miou_fscore(crab_ctx* ctx, void* stream, const float* pred, const int64_t* target, int BF, int C, int64_t hw, double beta2, int32_t* areas,
                      float* iou_fc, float* ious, float* fscores, float* cls_count, float* vid_miou);
+/* color_to_label: the AVSS ground truth from its colour map (dataset/quick_start_dataset.py:63-73 color_mask_to_label, :534-539): rgb [hw, 3] uint8
+ * (the PIL mask after `.convert('RGB').resize((224, 224), NEAREST)`), palette [n, 3] uint8 (get_v2_pallete :35-59 = the PASCAL-VOC bit-shuffle table,
+ * n = 71), both DEVICE; out [hw] int64 = the first palette index whose colour equals the pixel, 0 when none does. */
+int crab_color_to_label(crab_ctx* ctx, void* stream, const uint8_t* rgb, int64_t hw, const uint8_t* palette, int n, int64_t* out);
 
 /* ---------------------------------------------------------------------------------------------
  * Input front-end: what the reference's dataset code does on the CPU right before generate().

@@ -161,3 +161,26 @@ def avss_final(miou_pc: np.ndarray, fs_pc: np.ndarray, cls_pc: np.ndarray) -> di
     fs[np.isnan(fs)] = 0
     return {"miou": float(mi.mean(dtype=F32)), "miou_noBg": float(mi[:-1].mean(dtype=F32)),
             "f_score": float(fs.mean(dtype=F32)), "f_score_noBg": float(fs[:-1].mean(dtype=F32))}
+
+
+def get_v2_pallete(num_cls: int = 71) -> np.ndarray:
+    """dataset/quick_start_dataset.py:35-59 (_getpallete): the PASCAL-VOC bit shuffle, [num_cls, 3]."""
+    pal = np.zeros((num_cls, 3), np.int64)
+    for j in range(num_cls):
+        lab, i = j, 0
+        while lab > 0:
+            pal[j, 0] |= ((lab >> 0) & 1) << (7 - i)
+            pal[j, 1] |= ((lab >> 1) & 1) << (7 - i)
+            pal[j, 2] |= ((lab >> 2) & 1) << (7 - i)
+            i += 1
+            lab >>= 3
+    return pal
+
+
+def color_mask_to_label(mask: np.ndarray, v_pallete: np.ndarray) -> np.ndarray:
+    """dataset/quick_start_dataset.py:63-73: one equality plane per colour, argmax over the planes (first match; 0 when no colour matches)."""
+    mask_array = np.asarray(mask).astype("int32")
+    semantic_map = []
+    for colour in v_pallete:
+        semantic_map.append(np.all(np.equal(mask_array, colour), axis=-1))
+    return np.argmax(np.stack(semantic_map, axis=-1).astype(np.float32), axis=-1)

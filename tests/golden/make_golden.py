@@ -846,7 +846,30 @@ def golden_metrics():
     each = [R.calc_color_miou_fscore(cp[f:f + 1], ct[f:f + 1], T=1) for f in range(BF)]
     out["cls_iou_fc"] = torch.stack([e[0] for e in each])
     out["cls_fs_fc"] = torch.stack([e[1] for e in each])
-    save("seg_metrics", {"seed": SEED + 77, "note": "reference utils/avss_utils.py outputs; torch " + torch.__version__}, **out)
+    # the AVSS ground truth side: palette + colour map -> class ids, from the reference's dataset module (decord / librosa / cv2 stubbed: unused here)
+    import tempfile
+    import types as _t
+    for name in ("decord", "librosa", "cv2"):
+        if name not in sys.modules:
+            m = _t.ModuleType(name)
+            m.__spec__ = importlib.machinery.ModuleSpec(name, None)
+            if name == "decord":
+                m.VideoReader = object
+            sys.modules[name] = m
+    import dataset.quick_start_dataset as QD
+    from PIL import Image
+    with tempfile.TemporaryDirectory() as td:
+        json.dump({f"c{i}": i for i in range(71)}, open(os.path.join(td, "label2idx.json"), "w"))
+        pal = QD.get_v2_pallete(label_to_idx_path=os.path.join(td, "label2idx.json"), num_cls=71)
+    out["v2_pallete"] = np.asarray(pal, np.int64)
+    cls = torch.randint(0, 71, (36, 52), generator=g).numpy()
+    rgb = np.asarray(pal, np.uint8)[cls]
+    off = torch.rand(36, 52, generator=g).numpy() < 0.1
+    rgb[off] = torch.randint(0, 256, (int(off.sum()), 3), generator=g).numpy().astype(np.uint8)      # colours outside the table -> label 0
+    rgb[0, :4] = (1, 0, 0)                                                                             # one channel off the background colour
+    out["color_mask"] = rgb
+    out["color_label"] = QD.color_mask_to_label(Image.fromarray(rgb, "RGB"), pal).astype(np.int64)
+    save("seg_metrics", {"seed": SEED + 77, "note": "reference utils/avss_utils.py + dataset/quick_start_dataset.py outputs; torch " + torch.__version__}, **out)
 
 
 def golden_llama_ops():

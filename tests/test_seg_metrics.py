@@ -91,6 +91,17 @@ def test_oracle_class_metrics_match_the_reference_fixture():
     assert np.all(areas[:, 0] <= np.minimum(areas[:, 1], areas[:, 2]))
 
 
+def test_oracle_palette_and_colour_map_match_the_reference_fixture():
+    """dataset/quick_start_dataset.py:35-73: the palette of get_v2_pallete (= harness.default_palette: the reference's table is code, not data)
+    and color_mask_to_label on a map with colours outside the table."""
+    from crab_amd import harness
+    A = _fx()
+    assert np.array_equal(MO.get_v2_pallete(71), A["v2_pallete"]) and np.array_equal(harness.default_palette(71), A["v2_pallete"])
+    assert harness.get_v2_pallete is harness.default_palette
+    lab = MO.color_mask_to_label(A["color_mask"], A["v2_pallete"])
+    assert np.array_equal(lab, A["color_label"]) and (lab[0, :4] == 0).all() and len(np.unique(lab)) == 71
+
+
 def test_host_tensors_and_bad_shapes_are_refused_without_a_gpu():
     from crab_amd import _lib, avss_utils as AU
     p, t = torch.zeros(1, 4, 4), torch.zeros(1, 4, 4)
@@ -99,6 +110,12 @@ def test_host_tensors_and_bad_shapes_are_refused_without_a_gpu():
         with pytest.raises(_lib.CrabHipError):
             call()
     lib = _lib.load()
+    assert lib.crab_color_to_label(None, None, None, 16, None, 71, None) == -1
+    from crab_amd import harness
+    with pytest.raises(_lib.CrabHipError):
+        harness.color_mask_to_label(np.zeros((4, 4), np.uint8))                            # not [H, W, 3]
+    with pytest.raises(_lib.CrabHipError):
+        harness.color_mask_to_label(np.zeros((4, 4, 3), np.uint8), np.zeros((300, 3)))     # more than 256 colours
     assert lib.crab_mask_iou(None, None, None, None, 1, 16, 1e-7, None, None) == -1       # CRAB_E_INVALID before any HIP call
     assert lib.crab_fmeasure(None, None, None, None, 1, 16, None, 255, 0.3, None, None, None, None, None) == -1
     assert lib.crab_miou_fscore(None, None, None, None, 1, 3, 16, 0.3, None, None, None, None, None, None) == -1
@@ -241,3 +258,33 @@ def test_hip_metrics_full_size_and_edges_vs_oracle():
         _close(got[k], want[k])
     one = AU.calc_color_miou_fscore(_dev(cp[:1, :1]), _dev(np.zeros((1, H, W), np.int64)))
     assert one[0].item() == 1.0 and one[2].item() == 1.0                                   # a single class: everything is that class
+
+
+@pytest.mark.gpu
+def test_hip_colour_map_to_labels_matches_fixture_and_oracle():
+    from PIL import Image
+    from crab_amd import harness
+    A = _fx()
+    got = harness.color_mask_to_label(A["color_mask"], A["v2_pallete"])
+    assert got.dtype == torch.int64 and got.is_cuda and np.array_equal(got.cpu().numpy(), A["color_label"])
+    assert np.array_equal(harness.color_mask_to_label(Image.fromarray(A["color_mask"], "RGB")).cpu().numpy(), A["color_label"])   # PIL in, default table
+    rng = np.random.default_rng(2)
+    pal = harness.default_palette(71)
+    for (h, w) in ((224, 224), (7, 9), (1, 1)):
+        cls = rng.integers(0, 71, (h, w))
+        rgb = pal[cls].copy()
+        off = rng.random((h, w)) < 0.2
+        rgb[off] = rng.integers(0, 256, (int(off.sum()), 3)).astype(np.uint8)
+        want = MO.color_mask_to_label(rgb, pal)
+        assert np.array_equal(harness.color_mask_to_label(torch.from_numpy(rgb).cuda(), pal).cpu().numpy(), want)
+        # the label map is what the AVSS metric takes: a prediction that is the map itself scores IoU 1 on every class present
+        if h == 224:
+            from crab_amd import avss_utils as AU
+            lab = harness.color_mask_to_label(rgb, pal)
+            onehot = torch.nn.functional.one_hot(lab, 71).permute(2, 0, 1).float()[None]
+            mi, fs, cc, vid = AU.calc_color_miou_fscore(onehot, lab[None])
+            assert torch.equal(mi, cc) and vid[0].item() == 1.0
+    dup = np.array([[5, 5, 5], [9, 9, 9], [5, 5, 5]], np.uint8)                            # a repeated colour: the first index wins (argmax)
+    img = np.array([[[5, 5, 5], [9, 9, 9], [1, 2, 3]]], np.uint8)
+    assert harness.color_mask_to_label(img, dup).cpu().tolist() == [[0, 1, 0]]
+    assert harness.color_mask_to_label(img, dup[1:2]).cpu().tolist() == [[0, 0, 0]]        # one colour: index 0 whether it matches or not
