@@ -331,6 +331,8 @@ def run_inference_avs(batches: Iterable[Mapping[str, Any]], model, tokenizer, ou
     from the predicted mask where the reference first moves it to the host (crab_amd.avss_utils = utils/avss_utils.py): binary tasks get
     'iou' + 'fscore' (mask_iou, Eval_Fmeasure; quick_start.py:118-119, 198-199, 267-268), with `null_reference=True` (the loop over the null
     split, :270-358) 's' instead (metric_s_for_null, :342); avss gets the per-class IoU / F sums of calc_color_miou_fscore (:395-403).
+    The ground truth is written next to the prediction as `<frame>_gt.png` ('gt_path'); the resized copy of the input image the reference also
+    saves (`_image.jpg`, :111-115) needs the image file and stays with the caller.
     `summary` (a dict, filled on rank 0) receives summarise_avs(records) = the loops' closing averages.
     Batch i runs on rank i mod world; rank 0 returns every record in batch order and appends them to `out_path` as JSON lines when given."""
     import os
@@ -371,6 +373,15 @@ def run_inference_avs(batches: Iterable[Mapping[str, Any]], model, tokenizer, ou
             if gt is not None:
                 from . import avss_utils
                 g = gt.to(pred.device)
+                # the ground truth beside the prediction, as the reference's loops write it: `<frame>_gt.png`, (sigmoid(gt) > 0.5) * 255 in mode 'P'
+                # (quick_start.py:104-109) or palette[gt] with ids outside the table left black (avss_utils.py:315-345 save_gt_mask)
+                if pred.shape[0] == 1:
+                    gimg = Image.fromarray(ops.mask_labels(g.float().reshape(1, *g.shape[-2:]).contiguous()).cpu().numpy()).convert("P")
+                else:
+                    gl = g.reshape(g.shape[-2:]).cpu().numpy()
+                    gimg = Image.fromarray(np.where(((gl >= 0) & (gl < len(pal)))[..., None], pal[np.clip(gl, 0, len(pal) - 1)], 0).astype(np.uint8))
+                rec["gt_path"] = os.path.join(d, frame + "_gt.png")
+                gimg.save(rec["gt_path"], format="PNG")
                 if pred.shape[0] > 1:
                     i_pc, f_pc, c_pc, _ = avss_utils.calc_color_miou_fscore(pred=pred.unsqueeze(0), target=g, T=1)
                     rec["_avss"] = [i_pc.tolist(), f_pc.tolist(), c_pc.tolist()]

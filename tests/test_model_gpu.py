@@ -466,6 +466,10 @@ def test_harness_pixel_task_loop_writes_the_masks(tmp_path):
     want = MO.avss_final(*MO.batch_miou_fscore(direct[1].cpu().numpy()[None], gt_cls.numpy())[:3])
     assert summ["avss"]["count"] == 1 and all(abs(summ["avss"][k] - want[k]) <= 1e-6 for k in want) and want["miou"] > 0
     assert "_avss" not in rec2[2] and all("_avss" not in json.loads(l) for l in open(tmp_path / "res2.jsonl"))
+    # the ground truths beside the predictions (quick_start.py:104-109, avss_utils.py save_gt_mask)
+    assert rec2[0]["gt_path"].endswith("mask_img_dir/vidD/3_gt.png") and Image.open(rec2[0]["gt_path"]).mode == "P"
+    assert np.array_equal(np.array(Image.open(rec2[0]["gt_path"])), (gt_bin[0].numpy() * 255).astype(np.uint8))
+    assert np.array_equal(np.array(Image.open(rec2[2]["gt_path"])), harness.default_palette()[gt_cls[0].numpy()]) and "gt_path" not in recs[0]
     summ_n = {}
     rn = harness.run_inference_avs([withgt("ref-avs", "/data/avs/vidF/0/1.png", torch.zeros(1, 224, 224))], model, tok, str(tmp_path), max_new_tokens=n,
                                    pad_token_id=2, eos_token_id=None, null_reference=True, summary=summ_n)
