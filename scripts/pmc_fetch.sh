@@ -18,7 +18,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == c: vals[(r["Kernel_Name"][:64], r["Grid_Size"])].append(float(r["Counter_Value"]))
     for k, v in sorted(vals.items()):
-        if any(s in k[0] for s in ("gemm", "attn", "epilogue", "lora")):
+        if any(s in k[0] for s in ("gemm", "attn", "epilogue", "lora", "class_areas", "mask_counts", "fmeasure_hist")):
             print(f"{c}: {k[0]} grid {k[1]}: {len(v)} dispatches, mean {sum(v)/len(v):.6g} KiB")
 PY
 cat $GRAFT_REPO_ROOT/gpurun_out/$tag.txt
