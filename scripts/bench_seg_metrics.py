@@ -53,7 +53,7 @@ for N in (1, 64):
     ge, ys = torch.empty(N, 2, 255, device="cuda", dtype=torch.int32), torch.empty(N, 2, device="cuda", dtype=torch.int32)
     fs, sc, best = torch.empty(N, 255, device="cuda"), torch.empty(255, device="cuda"), torch.empty(2, device="cuda")
     us = timeit(lambda: lib.crab_fmeasure(ctx, _stream(), _p(pred), _p(gt), N, H * W, _p(th), 255, 0.3, _p(ge), _p(ys), _p(fs), _p(sc), _p(best)))
-    print(f"Eval_Fmeasure   N={N:3d}: {us:8.1f} us per call (one block per image + finish)  {byt / us / 1e3:8.1f} GB/s", flush=True)
+    print(f"Eval_Fmeasure   N={N:3d}: {us:8.1f} us per call (histogram pass + per-image finish + mean)  {byt / us / 1e3:8.1f} GB/s", flush=True)
     wall = host(lambda: (AU.mask_iou(pred, gt).item(), AU.Eval_Fmeasure(pred, gt)))
     print(f"  both through crab_amd.avss_utils, values read back: {wall:9.1f} us wall", flush=True)
     pc, gc = pred.cpu().numpy(), gt.cpu().numpy()
