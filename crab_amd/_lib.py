@@ -153,6 +153,8 @@ SYMBOLS = {
     "crab_ctx_destroy": (None, [_vp]),
     "crab_last_error": (C.c_char_p, [_vp]),
     "crab_sync": (_i, [_vp, _vp]),
+    "crab_trace_begin": (_i, [_vp]),
+    "crab_trace_end": (_i64, [_vp, C.c_char_p, _i64]),
     "crab_gemm_bf16": (_i, [_vp, _vp, C.POINTER(GemmDesc)]),
     "crab_rowfin_workspace": (_i64, [_i, _i]),
     "crab_rowfin_lora_ok": (_i, [_i, _i, _i]),

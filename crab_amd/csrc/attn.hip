@@ -1095,7 +1095,8 @@ extern "C" int crab_attn_fwd(crab_ctx* ctx, void* stream, const crab_attn_desc* 
             if (d->causal) hipLaunchKernelGGL((attn_fwd32_kernel<64, true>), grid32, block, 0, s, p);
             else hipLaunchKernelGGL((attn_fwd32_kernel<64, false>), grid32, block, 0, s, p);
         }
-        return crab_check_launch(ctx, "attn_fwd32_kernel");
+        return crab_check_launch(ctx, d->head_dim == 128 ? (d->causal ? "attn_fwd32_kernel<128,causal>" : "attn_fwd32_kernel<128>")
+                                                         : (d->causal ? "attn_fwd32_kernel<64,causal>" : "attn_fwd32_kernel<64>"));
     }
     if (d->head_dim == 32) {
         hipLaunchKernelGGL((attn_fwd_kernel<32, false, false>), grid, block, 0, s, p);
@@ -1108,7 +1109,8 @@ extern "C" int crab_attn_fwd(crab_ctx* ctx, void* stream, const crab_attn_desc* 
         else if (hb) hipLaunchKernelGGL((attn_fwd_kernel<64, false, true>), grid, block, 0, s, p);
         else hipLaunchKernelGGL((attn_fwd_kernel<64, false, false>), grid, block, 0, s, p);
     }
-    return crab_check_launch(ctx, "attn_fwd");
+    return crab_check_launch(ctx, d->head_dim == 32 ? "attn_fwd_kernel<32>" : d->head_dim == 128 ? (d->causal ? "attn_fwd_kernel<128,causal>" : hb ? "attn_fwd_kernel<128,bias>" : "attn_fwd_kernel<128>")
+                                                                            : (d->causal ? "attn_fwd_kernel<64,causal>" : hb ? "attn_fwd_kernel<64,bias>" : "attn_fwd_kernel<64>"));
 }
 
 extern "C" int64_t crab_attn_decode_rope_workspace(int B, int H, int d) {
@@ -1143,7 +1145,7 @@ extern "C" int crab_attn_decode_rope(crab_ctx* ctx, void* stream, const void* qk
     if (wide_on && nsplit == 2 && d == 128) {
         hipLaunchKernelGGL((attn_decode_rope_kernel<128, 32>), dim3(H, B, 1), dim3(512), 0, s, (const bf16_t*)qkv, (long)ldqkv, rope_tab, (bf16_t*)k_cache,
                            (bf16_t*)v_cache, (bf16_t*)o, (long)ldo, H, Hk, Tmax, pos0, pos_dev, scale, (float*)nullptr, (unsigned*)nullptr);
-        return crab_check_launch(ctx, "attn_decode_rope(wide)");
+        return crab_check_launch(ctx, "attn_decode_rope_kernel<128,32>");
     }
     dim3 grid(H, B, nsplit), block(256);
     if (d == 128)
@@ -1152,7 +1154,7 @@ extern "C" int crab_attn_decode_rope(crab_ctx* ctx, void* stream, const void* qk
     else
         hipLaunchKernelGGL((attn_decode_rope_kernel<64>), grid, block, 0, s, (const bf16_t*)qkv, (long)ldqkv, rope_tab, (bf16_t*)k_cache,
                            (bf16_t*)v_cache, (bf16_t*)o, (long)ldo, H, Hk, Tmax, pos0, pos_dev, scale, part, counters);
-    return crab_check_launch(ctx, "attn_decode_rope");
+    return crab_check_launch(ctx, d == 128 ? "attn_decode_rope_kernel<128>" : "attn_decode_rope_kernel<64>");
 }
 
 extern "C" int crab_attn_decode_keymask(crab_ctx* ctx, void* stream, const void* q, int64_t ldq, const void* k_cache, const void* v_cache,
@@ -1193,7 +1195,7 @@ extern "C" int crab_attn_decode_masked(crab_ctx* ctx, void* stream, const void* 
                        (const bf16_t*)v_cache, (bf16_t*)o, (long)ldo, Hk, Tmax, ctx_len_host, ctx_dev, scale, kv_start)
         if (G == 2) CRAB_GQA(2); else if (G == 4) CRAB_GQA(4); else if (G == 7) CRAB_GQA(7); else CRAB_GQA(8);
 #undef CRAB_GQA
-        return crab_check_launch(ctx, "attn_decode_gqa");
+        return crab_check_launch(ctx, G == 2 ? "attn_decode_gqa_kernel<128,2>" : G == 4 ? "attn_decode_gqa_kernel<128,4>" : G == 7 ? "attn_decode_gqa_kernel<128,7>" : "attn_decode_gqa_kernel<128,8>");
     }
     if (d == 128)
         hipLaunchKernelGGL((attn_decode_kernel<128>), grid, block, 0, s, (const bf16_t*)q, (long)ldq, (const bf16_t*)k_cache,
@@ -1201,7 +1203,7 @@ extern "C" int crab_attn_decode_masked(crab_ctx* ctx, void* stream, const void* 
     else
         hipLaunchKernelGGL((attn_decode_kernel<64>), grid, block, 0, s, (const bf16_t*)q, (long)ldq, (const bf16_t*)k_cache,
                            (const bf16_t*)v_cache, (bf16_t*)o, (long)ldo, H, Hk, Tmax, ctx_len_host, ctx_dev, scale, kv_start);
-    return crab_check_launch(ctx, "attn_decode");
+    return crab_check_launch(ctx, d == 128 ? "attn_decode_kernel<128>" : "attn_decode_kernel<64>");
 }
 
 extern "C" int crab_attn_decode(crab_ctx* ctx, void* stream, const void* q, int64_t ldq, const void* k_cache, const void* v_cache,

@@ -5,10 +5,28 @@
 #include <string.h>
 #include "../../include/crab_hip.h"
 
+// the launch trace (crab_trace_begin / crab_trace_end, include/crab_hip.h): which kernels the entry points of this context launched and how
+// often, by the name each launch site hands to crab_check_launch - a test can then hold a parity comparison to the kernel instantiation it
+// claims to cover (attn_decode_kernel<128>, the 256 x 256 ring GEMM, ...).  Host-side bookkeeping only: off by default, no device work.
+#define CRAB_TRACE_MAX 160
+struct crab_trace_row { char name[64]; long count; };
 struct crab_ctx {
     int device;
     char err[512];
+    int trace_on;
+    int trace_n;
+    crab_trace_row trace[CRAB_TRACE_MAX];
 };
+
+static inline void crab_trace_note(crab_ctx* ctx, const char* what) {
+    for (int i = 0; i < ctx->trace_n; ++i)
+        if (strncmp(ctx->trace[i].name, what, sizeof(ctx->trace[i].name) - 1) == 0) { ++ctx->trace[i].count; return; }
+    if (ctx->trace_n >= CRAB_TRACE_MAX) return;
+    crab_trace_row* r = &ctx->trace[ctx->trace_n++];
+    strncpy(r->name, what, sizeof(r->name) - 1);
+    r->name[sizeof(r->name) - 1] = 0;
+    r->count = 1;
+}
 
 static inline int crab_fail(crab_ctx* ctx, int code, const char* msg) {
     if (ctx) { strncpy(ctx->err, msg, sizeof(ctx->err) - 1); ctx->err[sizeof(ctx->err) - 1] = 0; }
@@ -23,6 +41,7 @@ static inline int crab_check_launch(crab_ctx* ctx, const char* what) {
         if (ctx) snprintf(ctx->err, sizeof(ctx->err), "%s: %s", what, hipGetErrorString(e));
         return CRAB_E_HIP;
     }
+    if (ctx && ctx->trace_on) crab_trace_note(ctx, what);
     return CRAB_OK;
 }
 

@@ -599,7 +599,7 @@ int crab_gemm_glds_launch(crab_ctx* ctx, hipStream_t s, const crab_gemm_desc* d,
             p.rope_vc = (bf16_t*)d->rope_v_cache; p.rope_vt = crab_gemm_fuses_prefill_rope(d) == 2 ? (bf16_t*)d->rope_vt : nullptr; p.rope_vt_ld = d->rope_vt_ld;
         }
         hipLaunchKernelGGL((gemm_bt_ring_kernel<256, 256, 2, 4>), grid, dim3(512), 0, s, p);
-        return crab_check_launch(ctx, "gemm_bt_ring_kernel");
+        return crab_check_launch(ctx, !p.rope_tab ? "gemm_bt_ring_kernel" : p.rope_vt ? "gemm_bt_ring_kernel+rope2" : "gemm_bt_ring_kernel+rope1");
     }
     p.tiles_m = (d->M + 127) / 128; p.tiles_n = (d->N + 127) / 128;
     dim3 grid(p.tiles_m * p.tiles_n, p.splitk > 1 ? p.splitk : batch);

@@ -38,6 +38,34 @@ def _chk_bf16(*ts):
             raise _lib.CrabHipError(f"expected bfloat16 storage, got {t.dtype}")
 
 
+class launch_trace:
+    """`with ops.launch_trace(device) as t: ...` -> t.counts = {launch-site name: launches} of every kernel the C-ABI entry points issued inside the
+    block (crab_trace_begin / crab_trace_end, include/crab_hip.h).  Names carry the template instantiation where the dispatch has one
+    ("attn_decode_kernel<128>", "gemm_bt_ring_kernel+rope2").  The parity tests use it to prove which kernel a fixture was compared through."""
+
+    def __init__(self, device: int = 0):
+        self.device = device
+        self.counts = {}
+
+    def __enter__(self):
+        _lib.check(_lib.load().crab_trace_begin(_lib.ctx(self.device)), self.device)
+        return self
+
+    def __exit__(self, *exc):
+        lib, h = _lib.load(), _lib.ctx(self.device)
+        need = lib.crab_trace_end(h, None, 0)
+        buf = C.create_string_buffer(int(need) + 1)
+        lib.crab_trace_end(h, buf, len(buf))
+        self.counts = {}
+        for line in buf.value.decode().splitlines():
+            name, _, n = line.rpartition("\t")
+            self.counts[name] = int(n)
+        return False
+
+    def launched(self, name: str) -> int:
+        return self.counts.get(name, 0)
+
+
 class KernelProfiler:
     """Optional HIP-event timing of kernel launches on the current stream (bench.py roofline leg).  Only used outside
     graph capture; adds two event records per profiled launch.  GEMM launches (M >= min_m) are bucketed by kernel

@@ -36,6 +36,14 @@ void crab_ctx_destroy(crab_ctx* ctx);
 const char* crab_last_error(crab_ctx* ctx);
 int crab_sync(crab_ctx* ctx, void* stream);
 int crab_abi_version(void);
+/* The launch trace (ABI 11; diagnostics, host-side bookkeeping only): between crab_trace_begin and crab_trace_end every kernel launch an entry
+ * point of this context issues is counted under the name of its launch site, template instantiation included where the dispatch has one
+ * ("attn_decode_kernel<128>", "attn_fwd32_kernel<128,causal>", "gemm_bt_ring_kernel+rope2", ...).  crab_trace_end stops the trace and
+ * writes "name\tcount\n" lines (NUL-terminated) into the HOST buffer `buf` of `n` bytes; it returns the bytes the full listing needs, so a
+ * caller whose buffer was short asks again with a larger one (the counts stay until the next crab_trace_begin).  No reference counterpart:
+ * the reference is eager PyTorch.  Used by the parity tests to prove WHICH kernel a reference-generated fixture was compared through. */
+int crab_trace_begin(crab_ctx* ctx);
+int64_t crab_trace_end(crab_ctx* ctx, char* buf /* host */, int64_t n);
 /* sizeof(crab_gemm_desc) / sizeof(crab_attn_desc) as compiled into the library: lets a binding verify its struct mirror */
 int crab_sizeof_gemm_desc(void);
 int crab_sizeof_attn_desc(void);

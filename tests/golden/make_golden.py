@@ -10,7 +10,9 @@ tests/golden/ref_shims.py, nothing copied).  For every hot-path component it
 tests/test_oracle_golden.py then pins oracle/crab_oracle.py against these files, and the GPU parity
 tests compare the HIP path with the same numbers.
 
-    python tests/golden/make_golden.py            # rewrite all fixtures
+    python tests/golden/make_golden.py            # rewrite ALL fixtures (every entry of tests/golden/registry.py, one interpreter each)
+    python tests/golden/make_golden.py fullwidth  # the six full-width fixtures (r06)
+    python tests/golden/make_golden.py metrics    # one generator, in this process
 """
 from __future__ import annotations
 
@@ -142,21 +144,21 @@ def golden_beats():
     save("beats_buckets", dict(num_buckets=320, max_distance=800), **b)
 
 
-def build_clip():
+def build_clip(clip_cfg=None):
     from transformers import CLIPVisionConfig, CLIPVisionModel
-    cfg = CLIPVisionConfig(**TINY_CLIP, hidden_act="quick_gelu", attention_dropout=0.0, projection_dim=64)
+    cfg = CLIPVisionConfig(**(clip_cfg or TINY_CLIP), hidden_act="quick_gelu", attention_dropout=0.0, projection_dim=64)
     cfg._attn_implementation = "eager"
     return CLIPVisionModel(cfg).eval()
 
 
-def build_visual_encoder(me):
+def build_visual_encoder(me, clip_cfg=None, select=None):
     class VE(me.VisualEncoder):
         def __init__(self, tower, select):
             torch.nn.Module.__init__(self)
             self.select_layer_list = select
             self.select_feature = 'patch'
             self.vision_tower = tower
-    return VE(build_clip(), TINY_CLIP_SELECT).eval()
+    return VE(build_clip(clip_cfg), select or TINY_CLIP_SELECT).eval()
 
 
 def golden_clip(me):
@@ -755,6 +757,7 @@ def golden_harness():
         rec["windows"].append(source[0].numpy().astype(np.float32).copy())
         return torch.zeros(1, 2, 128)
 
+    saved = (QD.preprocess, QD.get_v2_pallete)          # restored below: nothing this generator patches outlives it (`harness metrics` in one process died)
     QD.preprocess = _rec_preprocess
     tok = tiny_tokenizer()
     tok.add_tokens(MM_SPECIAL, special_tokens=True)
@@ -793,6 +796,7 @@ def golden_harness():
                         assert col["batch_task_names"][i] == task and sorted(col["batch_X_modals"][i]) == ["<audio>", "<video>"]
         finally:
             os.chdir(cwd)
+            QD.preprocess, QD.get_v2_pallete = saved
     out["frames"] = rec["frames"]
     out["n_windows"] = [len(w) for w in rec["windows"]]
     for i, w in enumerate(rec["windows"]):
@@ -939,42 +943,212 @@ def golden_llama_ops():
          layer_x=x, layer_y=y, layer_x1=x1, layer_y1=y1, cache_k=cache.k, cache_v=cache.v)
 
 
+
+# ------------------------------------------------------------------ full-width, shallow fixtures
+# The kernels the benchmark spends its time in are OTHER template instantiations than the tiny fixtures reach (head_dim 128, GQA group 7,
+# RoPE at d = 128, the 256 x 256 ring GEMM at K = 11008 / 18944 / 1024, 12 x 64 BEATs heads with the gated bias at n = 48 / 96, 768-wide
+# Q-Former layers with 1024-wide cross-attention keys, the SegModule under d_model 4096 / 1024-wide image features).  Each generator below
+# runs ONE or a FEW layers of the reference at the real widths on seeded synth weights and stores outputs only (fp32; rows sampled with a
+# stride coprime to every tile height so that all tile residues are covered); weights travel as (name, shape, checksum), inputs as seeds.
+WIDE_LLAMA = dict(hidden_size=4096, intermediate_size=11008, num_attention_heads=32, num_key_value_heads=32, rms_norm_eps=1e-5,
+                  rope_theta=10000.0)
+WIDE_QWEN = dict(hidden_size=3584, intermediate_size=18944, num_attention_heads=28, num_key_value_heads=4, rms_norm_eps=1e-6,
+                 rope_theta=1000000.0)
+# prefill batch x rows per sequence: M >= 2560 rows so that every projection of the layer takes the 256 x 256 ring kernel (csrc/gemm_glds.hip
+# ring_chosen), S > 64 for the 128-row flash forward; Llama decodes 20 x 32 heads >= 257 (attn_decode_kernel<128>), Qwen 64 x 4 kv heads >= 256
+# (attn_decode_gqa_kernel<128, 7>).  Row samples: a stride coprime to every tile height
+WIDE_SHAPE = {"llama": (20, 128, 23), "qwen": (64, 72, 41)}
+WIDE_STEPS = 2
+WIDE_CLIP = dict(hidden_size=1024, intermediate_size=4096, num_hidden_layers=4, num_attention_heads=16, image_size=224, patch_size=14,
+                 layer_norm_eps=1e-5)
+WIDE_CLIP_SELECT = [1, 2, 3]                                          # the last layer is dead, as layer 24 of the real tower is
+WIDE_BEATS = dict(TINY_BEATS, embed_dim=512, encoder_embed_dim=768, encoder_ffn_embed_dim=3072, encoder_attention_heads=12, encoder_layers=2)
+WIDE_QF = dict(hidden=768, heads=12, inter=3072)                      # bert-base (the checkpoint multimodal_encoder.py:90,192 names)
+
+
+def bf16_exact(t):
+    """Inputs of the full-width fixtures are bf16-REPRESENTABLE fp32 values: the HIP entry points take bf16 activations, so with these the
+    reference (fp32 arithmetic on the same values) and the HIP path start from identical numbers - no input-quantisation term in the comparison."""
+    return t.to(torch.bfloat16).float()
+
+
+def wide_inputs(D, seed, B, S, steps=WIDE_STEPS):
+    """The decoder-layer inputs of the *_layer_wide fixtures, regenerated by the tests (same generator call order)."""
+    g = torch.Generator().manual_seed(seed)
+    x = bf16_exact(torch.randn(B, S, D, generator=g))
+    xs = [bf16_exact(torch.randn(B, 1, D, generator=g)) for _ in range(steps)]
+    return x, xs
+
+
+def _wide_layer(layer, D, H, Hk, d, name, meta, cache, seed, shape):
+    """Prefill of B sequences x S rows through one reference decoder layer, then WIDE_STEPS cached one-token steps."""
+    import time
+    B, S, stride = shape
+    x, xs = wide_inputs(D, seed, B, S)
+    mask = torch.full((S, S), torch.finfo(torch.float32).min).triu(1)[None, None].expand(B, 1, S, S)
+    pos = torch.arange(S)[None].expand(B, S)
+    t0 = time.time()
+    out = layer(x, attention_mask=mask, position_ids=pos, past_key_value=cache, use_cache=True)[0]
+    y = out[0] if isinstance(out, tuple) else out                      # the in-tree Llama layer returns (hidden, route weights)
+    ys = []
+    for t, x1 in enumerate(xs):
+        o = layer(x1, attention_mask=torch.zeros(B, 1, 1, S + t + 1), position_ids=torch.full((B, 1), S + t), past_key_value=cache, use_cache=True)[0]
+        ys.append(o[0] if isinstance(o, tuple) else o)
+    print(f"{name}: reference layer ran in {time.time() - t0:.1f} s; |y| max {float(y.abs().max()):.3f}")
+    M = B * S
+    rows = torch.arange(0, M, stride)
+    step_seqs = torch.arange(0, B, 3 if B > 32 else 1)                  # decode-step outputs: every sequence, or every third of a large batch (incl. the last)
+    assert int(step_seqs[-1]) == B - 1
+    kc, vc = (cache.k[0], cache.v[0]) if isinstance(cache.k, dict) else (cache.k, cache.v)
+    assert kc.shape == (B, Hk, S + len(xs), d), kc.shape
+    heads = [0, Hk - 1]
+    meta = dict(meta, B=B, S=S, steps=len(xs), row_stride=stride, xseed=seed, cache_seq=B - 1, cache_heads=heads)
+    save(name, meta, rows=rows, y_rows=y.reshape(M, D)[rows], step_seqs=step_seqs, y_steps=torch.stack([t[step_seqs, 0] for t in ys]),
+         cache_k=kc[B - 1, heads], cache_v=vc[B - 1, heads])
+
+
+def golden_llama_layer_wide():
+    """models/modeling_llama.py:765-837 (LlamaDecoderLayer, eager attention :352-465) with its seven projections wrapped as
+    peft_hyper/tuners/lora.py:260-369 hyper-LoRA Linears, at Llama-2-7B widths (4096 / 11008, 32 heads x 128)."""
+    import types as _t
+    import transformers.utils.import_utils as iu
+    if not hasattr(iu, "is_torch_fx_available"):
+        iu.is_torch_fx_available = lambda: False
+    import models.modeling_llama as ML
+    from peft_hyper.tuners.lora import Linear as HyperLinear
+    c = WIDE_LLAMA
+    cfg = _t.SimpleNamespace(**c, max_position_embeddings=256, rope_scaling=None, attention_bias=False, attention_dropout=0.0, hidden_act="silu",
+                             pretraining_tp=1, _attn_implementation="eager")
+    layer = ML.LlamaDecoderLayer(cfg, 0)
+    for mod, names in ((layer.self_attn, ("q_proj", "k_proj", "v_proj", "o_proj")), (layer.mlp, ("gate_proj", "up_proj", "down_proj"))):
+        for n in names:
+            old = getattr(mod, n)
+            setattr(mod, n, HyperLinear(old.in_features, old.out_features, r=8, lora_alpha=16, lora_nums=3, lora_dropout=0.05, bias=False))
+    layer.eval()
+    table = load_synth(layer, "model.layers.0.")
+
+    class Cache:
+        def __init__(self):
+            self.k, self.v = None, None
+
+        def get_usable_length(self, new_len, layer_idx=0):
+            return 0 if self.k is None else self.k.shape[-2]
+
+        def update(self, k, v, layer_idx, cache_kwargs=None):
+            self.k = k if self.k is None else torch.cat([self.k, k], dim=-2)
+            self.v = v if self.v is None else torch.cat([self.v, v], dim=-2)
+            return self.k, self.v
+    _wide_layer(layer, c["hidden_size"], 32, 32, 128, "llama_layer_wide", dict(seed=SEED, cfg=c, table=table), Cache(), SEED + 101, WIDE_SHAPE["llama"])
+
+
+def golden_qwen_layer_wide():
+    """models/qwen/modeling_qwen2.py:712-809 (Qwen2DecoderLayer, eager GQA attention with q/k/v bias :202-317) with hyper-LoRA projections, at
+    Qwen2-7B widths (3584 / 18944, 28 query heads / 4 kv heads x 128, theta 1e6, eps 1e-6)."""
+    c = WIDE_QWEN
+    layers, MQ = _intree_layers(_qwen_ns(c), 1, None)
+    table = load_synth(layers[0], "model.layers.0.")
+    _wide_layer(layers[0], c["hidden_size"], 28, 4, 128, "qwen_layer_wide", dict(seed=SEED, cfg=c, table=table, qkv_bias=True), _MiniCache(), SEED + 102, WIDE_SHAPE["qwen"])
+
+
+def golden_clip_wide(me):
+    """CLIP ViT-L/14 widths (1024 / 16 heads x 64 / 4096, 257 tokens a frame), 4 layers, 36 frames through the reference's VisualEncoder
+    (models/multimodal_encoder.py:52-84): patch embedding + pre-LN at width 1024, head_dim 64 attention at S = 257, and M = 9252 rows so that
+    all four projections of a layer (K = 1024 and 4096, N = 3072 / 1024 / 4096 / 1024) fill the ring kernel's grid as they do in the benchmark."""
+    ve = build_visual_encoder(me, WIDE_CLIP, WIDE_CLIP_SELECT)
+    table = load_synth(ve, "model.visual_encoder.")
+    T = 36
+    video = bf16_exact(synth.synth_video(T, seed=SEED, clip=9)[None])
+    feats = ve(video)
+    rows = torch.arange(0, feats[0].shape[1], 79)
+    save("clip_wide", dict(seed=SEED, cfg=WIDE_CLIP, select=WIDE_CLIP_SELECT, table=table, t_v=T, clip=9, row_stride=79),
+         rows=rows, f0=feats[0][0, rows], f1=feats[1][0, rows], f2=feats[2][0, rows])
+
+
+def golden_beats_wide():
+    """BEATs iter3+ widths (patch embed 512 -> 768, 12 heads x 64, FFN 3072, 320 buckets / max distance 800, deep-norm, gated relative position
+    bias), 2 encoder layers, at both audio window lengths: L = 98 (n = 48 tokens) and L = 198 (n = 96); models/beats/BEATs.py:134-182,
+    models/beats/backbone.py."""
+    m = build_beats(WIDE_BEATS)
+    table = load_synth(m, "model.audio_encoder.audio_encoder.", alias_groups=beats_alias(m))
+    # L = 98: 256 one-second windows = 12288 token rows (the 768-wide GEMMs then run on the ring kernel, as at the benchmark's 256 clips x 10
+    # windows), sampled rows stored; L = 198 (the 2-second windows of MUSIC-AVQA, gated bias at n = 96): 3 windows, stored whole
+    outs, t_a = {}, {"98": 256, "198": 3}
+    for L in (98, 198):
+        x = bf16_exact(synth.synth_audio(t_a[str(L)], L, seed=SEED, clip=L + 1))
+        y, _ = m.extract_features(x, padding_mask=torch.zeros(x.shape[:-1]).bool(), feature_only=True)
+        outs[f"y{L}"] = y
+    rows98 = torch.arange(0, outs["y98"].shape[0] * outs["y98"].shape[1], 113)
+    outs["rows98"] = rows98
+    outs["y98"] = outs["y98"].reshape(-1, outs["y98"].shape[-1])[rows98]
+    save("beats_wide", dict(seed=SEED, cfg=WIDE_BEATS, table=table, clips={"98": 99, "198": 199}, t_a=t_a), **outs)
+
+
+def golden_projectors_wide():
+    """Both Q-Former projectors at their real configuration (models/multimodal_encoder.py:87-262 over models/Qformer.py: bert-base layers 768 /
+    12 heads / 3072, 2 layers, 32 queries; cross-attention keys 1024 wide (CLIP) and 768 wide (BEATs); output MLP 768 -> 4096 -> 4096)."""
+    me = ref_shims.patch_bert_config(lambda: ref_shims.tiny_bert_config(**WIDE_QF))
+    vl = me.VLProjector(hidden_size=1024, image_token_nums=256, num_query_token=32, num_hidden_layers=2, d_model=4096, depth=2).eval()
+    tv = load_synth(vl, "model.vl_projector.")
+    g = torch.Generator().manual_seed(111)
+    feat = bf16_exact(torch.randn(1, 2 * 256, 1024, generator=g))
+    yv = vl(feat)
+    al = me.ALProjector(hidden_size=768, num_query_token=32, num_hidden_layers=2, d_model=4096, depth=2).eval()
+    ta = load_synth(al, "model.al_projector.")
+    g = torch.Generator().manual_seed(112)
+    af = bf16_exact(torch.randn(1, 2, 96, 768, generator=g))
+    ya = al(af)
+    save("projectors_wide", dict(seed=SEED, qf=WIDE_QF, d_model=4096, table=tv + ta, vseed=111, aseed=112, vshape=[1, 512, 1024], ashape=[1, 2, 96, 768]),
+         vout=yv, aout=ya)
+
+
+def golden_seg_wide(me):
+    """SegModule as scripts/quick_start.py:505-529 builds it (models/unified_arch.py:91-106): d_model 4096, CLIP features 1024 wide, prompt
+    dim 256, 300 queries, two mask-decoder levels of depth 2; one `avss` (71 classes) and one `s4` sample."""
+    D = 4096
+    seg = me.SegModule(d_model=D, vit_image_embedding_dim=1024, prompt_embed_dim=256, image_scale_nums=2, mask_decoder_transformer_depth=2,
+                       token_nums_per_scale=3, avs_query_num=300, num_classes=1, query_generator_num_layers=2, image_size=224, patch_size=14,
+                       image_embedding_size=16).eval()
+    table = load_synth(seg, "model.seg_module.")
+    g = torch.Generator().manual_seed(131)
+    pred = bf16_exact(torch.randn(2, 6, D, generator=g))
+    feats = [bf16_exact(torch.randn(2, 256, 1024, generator=g)) for _ in range(2)]
+    tasks = ['avss', 's4']
+    out = seg(pred_embeddings=pred, multi_scale_image_feature_list=feats, low_res_mask_size=112, gt_mask=None, batch_task_names=tasks)['pred_masks']
+    print("seg_wide shapes", [tuple(o.shape) for o in out], float(out[0].abs().max()), float(out[1].abs().max()))
+    save("seg_wide", dict(seed=SEED, d_model=D, vit_dim=1024, table=table, tasks=tasks, pseed=131, cks=[synth.checksum(out[0]), synth.checksum(out[1])]),
+         avss_sub=out[0][:, 3::8, 5::8].contiguous(), s4_sub=out[1][:, 1::2, ::2].contiguous())
+
+
 def main():
+    """No argument: every generator of tests/golden/registry.py, each in its own interpreter (order-independent by construction).  One name: that
+    generator in this process.  Several names / a group name (`fullwidth`): one interpreter each."""
+    import inspect
+    import subprocess
+    from registry import GENERATORS, GROUPS
+    names = []
+    for a in sys.argv[1:] or list(GENERATORS):
+        names += GROUPS.get(a, [a])
+    unknown = [n for n in names if n not in GENERATORS]
+    if unknown:
+        raise SystemExit(f"unknown generator(s) {unknown}; known: {sorted(GENERATORS)} + groups {sorted(GROUPS)}")
+    if len(names) > 1:
+        failed = []
+        for n in names:
+            print(f"==== {n}", flush=True)
+            kind, entry, _ = GENERATORS[n]
+            cmd = [sys.executable, os.path.join(HERE, entry)] if kind == "script" else [sys.executable, os.path.abspath(__file__), n]
+            if subprocess.run(cmd).returncode != 0:
+                failed.append(n)
+        if failed:
+            raise SystemExit(f"generators failed: {failed}")
+        return
+    kind, entry, _ = GENERATORS[names[0]]
+    if kind == "script":
+        raise SystemExit(subprocess.run([sys.executable, os.path.join(HERE, entry)]).returncode)
     ref_shims.install()
     me = ref_shims.patch_bert_config(lambda: ref_shims.tiny_bert_config(**TINY_QF))
-    which = sys.argv[1:] or ["lora", "beats", "clip", "proj", "full", "qwen", "seg"]
-    if "lora" in which:
-        build_lora_linear()
-    if "beats" in which:
-        golden_beats()
-    if "clip" in which:
-        golden_clip(me)
-    if "proj" in which:
-        golden_projectors(me)
-    if "full" in which:
-        golden_full(me)
-    if "qwen" in which:
-        golden_qwen(me)
-    if "seg" in which:
-        golden_seg(me)
-    if "frontend" in which:
-        golden_frontend()
-    if "vqgan" in which:
-        golden_vqgan()
-    if "harness" in which:
-        golden_harness()
-    if "llama_ops" in which:
-        golden_llama_ops()
-    if "qwen_ops" in which:
-        golden_qwen_ops()
-    if "full_qwen" in which:
-        golden_full_qwen(me)
-    if "id_stats" in which:
-        golden_id_stats(me)
-    if "holes" in which:
-        golden_holes(me)
-    if "metrics" in which:
-        golden_metrics()
+    fn = globals()[entry]
+    fn(me) if inspect.signature(fn).parameters else fn()
 
 
 if __name__ == "__main__":

@@ -144,6 +144,42 @@ def seg_inputs(meta):
     return pred, feats
 
 
+def wide_layer_inputs(meta):
+    """Inputs of the llama_layer_wide / qwen_layer_wide fixtures (tests/golden/make_golden.py wide_inputs: same generator call order):
+    prefill rows [B, S, D] and the `steps` one-token decode inputs [B, 1, D]."""
+    g = torch.Generator().manual_seed(meta["xseed"])
+    D = meta["cfg"]["hidden_size"]
+    x = bf16_exact(torch.randn(meta["B"], meta["S"], D, generator=g))
+    xs = [bf16_exact(torch.randn(meta["B"], 1, D, generator=g)) for _ in range(meta["steps"])]
+    return x, xs
+
+
+def bf16_exact(t):
+    """The full-width fixtures' inputs are bf16-representable fp32 values (make_golden.py bf16_exact): reference and HIP path start from the same numbers."""
+    return t.to(torch.bfloat16).float()
+
+
+def seg_wide_inputs(meta):
+    g = torch.Generator().manual_seed(meta["pseed"])
+    pred = bf16_exact(torch.randn(2, 6, meta["d_model"], generator=g))
+    feats = [bf16_exact(torch.randn(2, 256, meta["vit_dim"], generator=g)) for _ in range(2)]
+    return pred, feats
+
+
+def projectors_wide_inputs(meta):
+    vf = bf16_exact(torch.randn(*meta["vshape"], generator=torch.Generator().manual_seed(meta["vseed"])))
+    af = bf16_exact(torch.randn(*meta["ashape"], generator=torch.Generator().manual_seed(meta["aseed"])))
+    return vf, af
+
+
+def clip_wide_video(meta):
+    return bf16_exact(synth.synth_video(meta["t_v"], seed=meta["seed"], clip=meta["clip"])[None])
+
+
+def beats_wide_audio(meta, L):
+    return bf16_exact(synth.synth_audio(meta["t_a"][str(L)], L, seed=meta["seed"], clip=meta["clips"][str(L)]))
+
+
 # ------------------------------------------------------------------ tiny tokenizer for the harness tests / golden
 HARNESS_WORDS = ("this is a an video audio image please answer question describe the events and time range that occurred in "
                  "determine occur based on visual information as well start end of these output location coordinates sounding "
