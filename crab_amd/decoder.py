@@ -692,7 +692,7 @@ class GenerationEngine:
             g = g1 + 1
 
     def _start_ragged(self, embeds_list: List[torch.Tensor], max_new_tokens: int, eos_token_id, pad_token_id, min_new_tokens: int,
-                      sink=None, sampling=None) -> "_DecodeState":
+                      sink=None, sampling=None, return_hidden: bool = False) -> "_DecodeState":
         """The decode state of SEVERAL generate() calls coalesced into one batch.  Group g = [B_g, S_g, D] is one call of the eval loop: its
         own prompt length and left padding, positions 0 .. S_g - 1 (unified_llama.py:262-267).  All rows share one KV cache [L, sum B_g, Hk,
         Tmax, d] in which every group is RIGHT-ALIGNED at Smax = max S_g: group g's prompt occupies slots Smax - S_g .. Smax - 1, so the token
@@ -704,7 +704,7 @@ class GenerationEngine:
         Bs = [int(e.shape[0]) for e in embeds_list]
         Ss = [int(e.shape[1]) for e in embeds_list]
         Bt, Smax = sum(Bs), max(Ss)
-        st = self._state(Bt, Smax, max_new_tokens, eos_token_id, pad_token_id, min_new_tokens, False, 0, sampling, ragged=True)
+        st = self._state(Bt, Smax, max_new_tokens, eos_token_id, pad_token_id, min_new_tokens, return_hidden, 0, sampling, ragged=True)
         st.row_off.copy_(torch.tensor([Smax - S for B, S in zip(Bs, Ss) for _ in range(B)], dtype=torch.int32), non_blocking=False)
         waste = sum(B * (Smax - S) for B, S in zip(Bs, Ss)) / max(1, sum(B * S for B, S in zip(Bs, Ss)))
         if len(set(Ss)) > 1 and waste <= RAGGED_PAD_MAX:
@@ -848,7 +848,7 @@ class GenerationEngine:
     def generate_many(self, embeds_list: List[torch.Tensor], max_new_tokens: int, eos_token_id: Optional[int] = None,
                       pad_token_id: Optional[int] = None, min_new_tokens: int = 0, use_graph: bool = True, sampling=None,
                       return_first_logits: bool = False, coalesce: bool = False, max_rows: Optional[int] = None,
-                      return_step_logits: bool = False):
+                      return_step_logits: bool = False, return_hidden: bool = False):
         """Several INDEPENDENT batches in flight: each element of `embeds_list` ([B_i, S_i, D], its own prompt length and left padding, i.e.
         exactly what one generate() call of the reference's eval loop gets) becomes one decode group with its own KV cache, decode state
         and captured HIP graph; the groups are prefilled one after the other and their decode steps are replayed on separate HIP streams.
@@ -866,15 +866,17 @@ class GenerationEngine:
         coalesced M selects, so ids / logits agree with separate calls within the bf16 tolerance of the decoder, not bit for bit.  At most
         max_rows (default ops.DECODE_MAX_ROWS) rows decode together; more are run as consecutive waves of about equal size.  Sample mode
         draws per (seed, step, row of the wave): a different random stream than separate calls.
-        return_step_logits (coalesce only; parity audits): every batch's result becomes (ids, fp32 logits of every step [B_g, n_g, V])."""
+        return_step_logits (coalesce only; parity audits): every batch's result becomes (ids, fp32 logits of every step [B_g, n_g, V]).
+        return_hidden (coalesce only; the pixel tasks, generate_avs): every batch's result becomes (ids, post-final-norm hidden state of every
+        step [B_g, n_g, D]) - what generate(return_hidden=True) returns for that batch."""
         if not embeds_list:
             return []
         G = len(embeds_list)
-        if return_step_logits and (not coalesce or return_first_logits):
-            raise NotImplementedError("generate_many: return_step_logits is an audit option of the coalesced form (use generate() per batch otherwise)")
-        if coalesce and (G > 1 or return_step_logits):
+        if (return_step_logits or return_hidden) and (not coalesce or return_first_logits or (return_step_logits and return_hidden)):
+            raise NotImplementedError("generate_many: return_step_logits / return_hidden are options of the coalesced form, one at a time (use generate() per batch otherwise)")
+        if coalesce and (G > 1 or return_step_logits or return_hidden):
             return self._generate_coalesced(embeds_list, max_new_tokens, eos_token_id, pad_token_id, min_new_tokens, use_graph, sampling,
-                                            return_first_logits, max_rows, return_step_logits)
+                                            return_first_logits, max_rows, return_step_logits, return_hidden)
         if G == 1:
             r = self.generate(embeds_list[0], max_new_tokens, eos_token_id=eos_token_id, pad_token_id=pad_token_id, min_new_tokens=min_new_tokens,
                               use_graph=use_graph, sampling=sampling, return_first_logits=return_first_logits)
@@ -941,7 +943,7 @@ class GenerationEngine:
         return outs
 
     def _generate_coalesced(self, embeds_list, max_new_tokens, eos_token_id, pad_token_id, min_new_tokens, use_graph, sampling,
-                            return_first_logits, max_rows, return_step_logits=False):
+                            return_first_logits, max_rows, return_step_logits=False, return_hidden=False):
         """generate_many(coalesce=True): pack the batches, in order, into waves of at most `cap` rows (the weight-streaming regime of the decode
         projections, and what the device's memory holds at the longest prompt), run every wave as one ragged batch."""
         Bs = [int(e.shape[0]) for e in embeds_list]
@@ -970,17 +972,17 @@ class GenerationEngine:
                 g = w[0]
                 outs[g] = self.generate(embeds_list[g], max_new_tokens, eos_token_id=eos_token_id, pad_token_id=pad_token_id,
                                         min_new_tokens=min_new_tokens, use_graph=use_graph, sampling=sampling, return_first_logits=return_first_logits,
-                                        return_step_logits=return_step_logits)
+                                        return_step_logits=return_step_logits, return_hidden=return_hidden)
                 continue
             res = self._ragged_wave([embeds_list[g] for g in w], max_new_tokens, eos_token_id, pad_token_id, min_new_tokens, use_graph, sampling,
-                                    return_first_logits, return_step_logits)
+                                    return_first_logits, return_step_logits, return_hidden)
             for g, r in zip(w, res):
                 outs[g] = r
         self.last_plan = plan
         return outs
 
     def _ragged_wave(self, embeds_list, max_new_tokens, eos_token_id, pad_token_id, min_new_tokens, use_graph, sampling, return_first_logits,
-                     return_step_logits=False):
+                     return_step_logits=False, return_hidden=False):
         firsts, steps = [], []
 
         def sink(st):
@@ -988,9 +990,11 @@ class GenerationEngine:
                 firsts.append(st.logits.clone())
             if return_step_logits:
                 steps.append(st.logits.clone())
+            if return_hidden:
+                steps.append(st.hn.clone())
 
         ops.WS_SLOT = 0
-        st = self._start_ragged(embeds_list, max_new_tokens, eos_token_id, pad_token_id, min_new_tokens, sink, sampling)
+        st = self._start_ragged(embeds_list, max_new_tokens, eos_token_id, pad_token_id, min_new_tokens, sink, sampling, return_hidden)
         if ops.PROFILER is not None:
             ops.PROFILER.mark("prefill_end")
         graph = self._capture(st) if (use_graph and max_new_tokens > 2) else None
@@ -1000,14 +1004,14 @@ class GenerationEngine:
                 graph.replay()
             else:
                 self._decode_step(st)
-            if return_step_logits:
+            if return_step_logits or return_hidden:
                 sink(st)
             if eos_on and step % 16 == 0 and bool(st.finished.all().item()):
                 break
         if ops.PROFILER is not None:
             ops.PROFILER.mark("decode_end")
         n_done = int(st.step_dev.item())
-        sl = torch.stack(steps, 1) if return_step_logits else None
+        sl = torch.stack(steps, 1) if (return_step_logits or return_hidden) else None
         outs, r0 = [], 0
         for e in embeds_list:
             r1 = r0 + int(e.shape[0])
@@ -1018,7 +1022,7 @@ class GenerationEngine:
                 idx = torch.nonzero(fin_cols.all(0))
                 if idx.numel():
                     out = st.out_ids[r0:r1, : int(idx[0].item()) + 1]
-            if return_step_logits:
+            if return_step_logits or return_hidden:
                 outs.append((out.clone(), sl[r0:r1, : out.shape[1]].clone()))
             else:
                 outs.append((out.clone(), firsts[0][r0:r1].clone()) if return_first_logits else out.clone())

@@ -319,7 +319,8 @@ def color_mask_to_label(mask, v_pallete: Optional[np.ndarray] = None, device="cu
 def run_inference_avs(batches: Iterable[Mapping[str, Any]], model, tokenizer, out_dir: str, max_new_tokens: int = 100, device="cuda",
                       rank: int = 0, world: int = 1, palette: Optional[np.ndarray] = None, out_path: Optional[str] = None,
                       on_result: Optional[Callable[[dict], None]] = None, metrics: bool = True, null_reference: bool = False,
-                      summary: Optional[dict] = None, **generate_kwargs) -> List[dict]:
+                      summary: Optional[dict] = None, coalesce: bool = False, coalesce_rows: int = 128, write_png: bool = True,
+                      **generate_kwargs) -> List[dict]:
     """The pixel-task loops of the reference (scripts/quick_start.py:270-359 inference_ms3 / _s4 / _ref_avs, :361-450 inference_avss): for every
     collated batch (one sample per batch, like the reference, which reads batch_metadata[0]) generate_avs -> text + masks -> files:
       binary tasks (one class plane):  `<out_dir>/mask_img_dir/<video>/<frame>_pred.png`, mode 'P', 255 where sigmoid(pred) > 0.5 (:313-319)
@@ -334,23 +335,22 @@ def run_inference_avs(batches: Iterable[Mapping[str, Any]], model, tokenizer, ou
     The ground truth is written next to the prediction as `<frame>_gt.png` ('gt_path'); the resized copy of the input image the reference also
     saves (`_image.jpg`, :111-115) needs the image file and stays with the caller.
     `summary` (a dict, filled on rank 0) receives summarise_avs(records) = the loops' closing averages.
-    Batch i runs on rank i mod world; rank 0 returns every record in batch order and appends them to `out_path` as JSON lines when given."""
+    Batch i runs on rank i mod world; rank 0 returns every record in batch order and appends them to `out_path` as JSON lines when given.
+    coalesce = True (r06; BASELINE configs[4] as a throughput path): this rank's samples are collected until `coalesce_rows` of them are pending
+    and then run as ONE model.generate_avs_many call - every sample keeps the semantics of its own generate_avs call (own prompt, positions,
+    mask-token picks), but the decoder streams its weights once per step for all of them and the SegModule runs batched; the records, files
+    and metrics are those of the one-by-one loop (masks agree with it within the mask decoder's bf16 tolerance: different GEMM tile shapes).
+    write_png = False skips the PNG encoding / file writes (host work of the reference's loops; the benchmark times the device path)."""
     import os
     from PIL import Image
     from . import ops
     pal = default_palette() if palette is None else np.asarray(palette, np.uint8)
     mine: List[Tuple[int, dict]] = []
-    for step, sample in enumerate(batches):
-        if step % world != rank:
-            continue
-        sample = dict(sample)
-        meta = dict(sample.pop("batch_metadata")[0])
-        task = sample["batch_task_names"][0]
-        gt = sample["batch_X_modals"][0].get("<mask>") if metrics else None            # [1, 224, 224]: {0, 1} fp32, or class ids (avss)
-        kw = {"use_cache": True, "max_new_tokens": max_new_tokens}
-        kw.update(generate_kwargs)
-        with torch.no_grad():
-            result = model.generate_avs(**to_device(sample, device), **kw)
+    pending: List[tuple] = []
+    kw = {"use_cache": True, "max_new_tokens": max_new_tokens}
+    kw.update(generate_kwargs)
+
+    def finish(step, meta, task, gt, result):
         rec = {"instruction": meta.get("instruction"), "label": meta.get("output"), "image_path": meta.get("image_path"),
                "predict": tokenizer.decode(result["output_ids"][0], skip_special_tokens=False), "pred_path": None}
         masks = result.get("pred_masks")
@@ -359,29 +359,29 @@ def run_inference_avs(batches: Iterable[Mapping[str, Any]], model, tokenizer, ou
             parts = (meta.get("mask_path") or "").split("/")
             video = parts[-3] if len(parts) >= 3 else f"sample_{step:06d}"
             frame = os.path.splitext(parts[-1])[0] if parts[-1:] and parts[-1] else "0"
-            lab = ops.mask_labels(pred).cpu().numpy()                   # uint8 [224, 224]: 0 / 255, or the class index
-            if pred.shape[0] == 1:
-                d = os.path.join(out_dir, "mask_img_dir", video)
-                img = Image.fromarray(lab).convert("P")
-            else:
-                d = os.path.join(out_dir, "avss_result", video)
-                img = Image.fromarray(pal[np.minimum(lab, len(pal) - 1)])
-            os.makedirs(d, exist_ok=True)
-            rec["pred_path"] = os.path.join(d, frame + "_pred.png")
-            img.save(rec["pred_path"], format="PNG")
+            d = os.path.join(out_dir, "mask_img_dir" if pred.shape[0] == 1 else "avss_result", video)
+            if write_png:
+                lab = ops.mask_labels(pred).cpu().numpy()               # uint8 [224, 224]: 0 / 255, or the class index
+                img = Image.fromarray(lab).convert("P") if pred.shape[0] == 1 else Image.fromarray(pal[np.minimum(lab, len(pal) - 1)])
+                os.makedirs(d, exist_ok=True)
+                rec["pred_path"] = os.path.join(d, frame + "_pred.png")
+                img.save(rec["pred_path"], format="PNG")
             rec["task"], rec["num_classes"] = task, int(pred.shape[0])
             if gt is not None:
                 from . import avss_utils
                 g = gt.to(pred.device)
                 # the ground truth beside the prediction, as the reference's loops write it: `<frame>_gt.png`, (sigmoid(gt) > 0.5) * 255 in mode 'P'
                 # (quick_start.py:104-109) or palette[gt] with ids outside the table left black (avss_utils.py:315-345 save_gt_mask)
-                if pred.shape[0] == 1:
+                if not write_png:
+                    gimg = None
+                elif pred.shape[0] == 1:
                     gimg = Image.fromarray(ops.mask_labels(g.float().reshape(1, *g.shape[-2:]).contiguous()).cpu().numpy()).convert("P")
                 else:
                     gl = g.reshape(g.shape[-2:]).cpu().numpy()
                     gimg = Image.fromarray(np.where(((gl >= 0) & (gl < len(pal)))[..., None], pal[np.clip(gl, 0, len(pal) - 1)], 0).astype(np.uint8))
-                rec["gt_path"] = os.path.join(d, frame + "_gt.png")
-                gimg.save(rec["gt_path"], format="PNG")
+                if write_png:
+                    rec["gt_path"] = os.path.join(d, frame + "_gt.png")
+                    gimg.save(rec["gt_path"], format="PNG")
                 if pred.shape[0] > 1:
                     i_pc, f_pc, c_pc, _ = avss_utils.calc_color_miou_fscore(pred=pred.unsqueeze(0), target=g, T=1)
                     rec["_avss"] = [i_pc.tolist(), f_pc.tolist(), c_pc.tolist()]
@@ -391,6 +391,30 @@ def run_inference_avs(batches: Iterable[Mapping[str, Any]], model, tokenizer, ou
                     rec["iou"] = avss_utils.mask_iou(pred=pred, target=g).item()
                     rec["fscore"] = avss_utils.Eval_Fmeasure(pred=pred, gt=g)
         mine.append((step, rec))
+
+    def flush():
+        if not pending:
+            return
+        with torch.no_grad():
+            if len(pending) == 1:
+                results = [model.generate_avs(**pending[0][4], **kw)]
+            else:
+                results = model.generate_avs_many([p[4] for p in pending], **kw)
+        for (step_, meta_, task_, gt_, _), result in zip(pending, results):
+            finish(step_, meta_, task_, gt_, result)
+        pending.clear()
+
+    for step, sample in enumerate(batches):
+        if step % world != rank:
+            continue
+        sample = dict(sample)
+        meta = dict(sample.pop("batch_metadata")[0])
+        task = sample["batch_task_names"][0]
+        gt = sample["batch_X_modals"][0].get("<mask>") if metrics else None            # [1, 224, 224]: {0, 1} fp32, or class ids (avss)
+        pending.append((step, meta, task, gt, to_device(sample, device)))
+        if not coalesce or len(pending) >= max(1, coalesce_rows):
+            flush()
+    flush()
     records = mine
     if world > 1:
         import torch.distributed as dist

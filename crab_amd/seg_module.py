@@ -101,17 +101,17 @@ class Attention(nn.Module):
         self._packed = (key, pk)
         return pk
 
-    def forward(self, q, k, v, residual=None):
-        """q [Sq,E], k/v [Skv,E] token-major (batch 1) -> out_proj(attn) (+ residual)."""
+    def forward(self, q, k, v, residual=None, B=1):
+        """q [B*Sq,E], k/v [B*Skv,E] token-major, the B samples stacked -> out_proj(attn) (+ residual)."""
         qw, qb, kw, kb, vw, vb, ow, dp = self._pack()
         H = self.num_heads
-        Sq, Skv = q.shape[0], k.shape[0]
+        Sq, Skv = q.shape[0] // B, k.shape[0] // B
         ip = H * dp
         qp = ops.gemm(q, qw, bias=qb)
-        kv = torch.empty((Skv, 2 * ip), device=q.device, dtype=BF16)
+        kv = torch.empty((B * Skv, 2 * ip), device=q.device, dtype=BF16)
         ops.gemm(k, kw, bias=kb, out=kv[:, :ip])
         ops.gemm(v, vw, bias=vb, out=kv[:, ip:])
-        att = _attend(qp, kv, 1, H, Sq, Skv, dp, 1.0 / math.sqrt(self.internal_dim // H))
+        att = _attend(qp, kv, B, H, Sq, Skv, dp, 1.0 / math.sqrt(self.internal_dim // H))
         return ops.gemm(att, ow, bias=self.out_proj.bias, residual=residual)
 
 
@@ -151,19 +151,20 @@ class TwoWayAttentionBlock(nn.Module):
         self.cross_attn_image_to_token = Attention(dim, heads, down, device=device)
         self.skip_first_layer_pe = skip_first_layer_pe
 
-    def forward(self, queries, keys, query_pe, key_pe):
+    def forward(self, queries, keys, query_pe, key_pe, B=1):
+        """queries / query_pe [B*Nq, C], keys [B*hw, C] (samples stacked), key_pe [hw, C] shared by the samples (add_rows broadcasts it)."""
         if self.skip_first_layer_pe:
-            queries = self.self_attn(queries, queries, queries)
+            queries = self.self_attn(queries, queries, queries, B=B)
         else:
             q = ops.add_rows(queries, query_pe)
-            queries = self.self_attn(q, q, queries, residual=queries)
+            queries = self.self_attn(q, q, queries, residual=queries, B=B)
         queries = self.norm1(queries)
         q, k = ops.add_rows(queries, query_pe), ops.add_rows(keys, key_pe)
-        queries = self.norm2(self.cross_attn_token_to_image(q, k, keys, residual=queries))
+        queries = self.norm2(self.cross_attn_token_to_image(q, k, keys, residual=queries, B=B))
         m = self.mlp.lin2(self.mlp.lin1(queries, act="relu"), residual=queries)
         queries = self.norm3(m)
         q = ops.add_rows(queries, query_pe)
-        keys = self.norm4(self.cross_attn_image_to_token(k, q, queries, residual=keys))
+        keys = self.norm4(self.cross_attn_image_to_token(k, q, queries, residual=keys, B=B))
         return queries, keys
 
 
@@ -177,13 +178,13 @@ class TwoWayTransformer(nn.Module):
         self.final_attn_token_to_image = Attention(embedding_dim, num_heads, attention_downsample_rate, device=device)
         self.norm_final_attn = LayerNormP(embedding_dim, 1e-5, device)
 
-    def forward(self, keys, key_pe, point_embedding):
-        """keys [h*w, C] (= image_embedding flattened), key_pe [h*w, C], point_embedding [Nq, C]."""
+    def forward(self, keys, key_pe, point_embedding, B=1):
+        """keys [B*h*w, C] (= image_embedding flattened, samples stacked), key_pe [h*w, C], point_embedding [B*Nq, C]."""
         queries = point_embedding
         for layer in self.layers:
-            queries, keys = layer(queries, keys, point_embedding, key_pe)
+            queries, keys = layer(queries, keys, point_embedding, key_pe, B=B)
         q, k = ops.add_rows(queries, point_embedding), ops.add_rows(keys, key_pe)
-        queries = self.norm_final_attn(self.final_attn_token_to_image(q, k, keys, residual=queries))
+        queries = self.norm_final_attn(self.final_attn_token_to_image(q, k, keys, residual=queries, B=B))
         return queries, keys
 
 
@@ -197,11 +198,11 @@ class _TorchMHA(nn.Module):
         self.in_proj_bias = _p(None, device, 3 * E)
         self.out_proj = LinearP(E, E, device)
 
-    def forward(self, q, kv, residual):
+    def forward(self, q, kv, residual, B=1):
         E, H = self.embed_dim, self.num_heads
         qp = ops.gemm(q, self.in_proj_weight[:E], bias=self.in_proj_bias[:E])
-        kvp = ops.gemm(kv, self.in_proj_weight[E:], bias=self.in_proj_bias[E:])                # [Skv, 2E] = [k | v]
-        att = _attend(qp, kvp, 1, H, q.shape[0], kv.shape[0], E // H, 1.0 / math.sqrt(E // H))
+        kvp = ops.gemm(kv, self.in_proj_weight[E:], bias=self.in_proj_bias[E:])                # [B*Skv, 2E] = [k | v]
+        att = _attend(qp, kvp, B, H, q.shape[0] // B, kv.shape[0] // B, E // H, 1.0 / math.sqrt(E // H))
         return self.out_proj(att, residual=residual)
 
 
@@ -215,9 +216,16 @@ class _QGLayer(nn.Module):
         self.norm2 = LayerNormP(E, 1e-5, device)
         self.norm3 = LayerNormP(E, 1e-5, device)
 
-    def forward(self, query, feat):
+    def forward(self, query, feat, B=1):
+        """query [Nq, E] (the learned queries: the same for every sample), feat [B, E] = one sparse prompt row per sample -> [B*Nq, E].
+        The self-attention does not see the sample, so it runs once; its output is replicated (a device copy) in front of the cross-attention."""
         query = self.norm1(self.self_attn(query, query, residual=query))
-        query = self.norm2(self.cross_attn(query, feat, residual=query))
+        if B > 1:
+            Nq, E = query.shape
+            rep = torch.empty((B * Nq, E), device=query.device, dtype=BF16)
+            ops.copy_rows_batched(query, E, 0, rep, E, Nq * E, B, Nq, E)
+            query = rep
+        query = self.norm2(self.cross_attn(query, feat, residual=query, B=B))
         f = self.ffn[2](self.ffn[0](query, act="gelu"), residual=query)
         return self.norm3(f)
 
@@ -229,8 +237,8 @@ class QueryGenerator(nn.Module):
         super().__init__()
         self.layers = nn.ModuleList([_QGLayer(embed_dim, num_heads, hidden_dim, device) for _ in range(num_layers)])
 
-    def forward(self, avs_query, sparse_embedding):
-        return self.layers[-1](avs_query, sparse_embedding)         # earlier layers' outputs are discarded by the reference
+    def forward(self, avs_query, sparse_embedding, B=1):
+        return self.layers[-1](avs_query, sparse_embedding, B=B)    # earlier layers' outputs are discarded by the reference
 
 
 class _MLP(nn.Module):
@@ -283,32 +291,44 @@ class MaskDecoderMultiScale(nn.Module):
         self._packed = (key, pk)
         return pk
 
-    def predict_masks(self, img, image_pe, sparse, no_mask, level, prev, task_name, h, w):
-        """img [h*w, D] token-major, sparse [1, D], prev [(h'*w'), ncls] masks of the previous level (or None)
-        -> (masks [(2h')(2w'), ncls] token-major, h_out, w_out)."""
+    def predict_masks(self, img, image_pe, sparse, no_mask, level, prev, task_name, h, w, B=1):
+        """B samples of one task stacked sample-major: img [B*h*w, D] token-major, sparse [B, D] (row b = sample b's prompt of this level; any
+        row stride), prev [B*(h'*w'), ncls] masks of the previous level (or None) -> (masks [B*(2h')(2w'), ncls] token-major, h_out, w_out).
+        Every step is row-wise (GEMMs, norms, gates), an attention with a batch dimension, or a 2x pixel shuffle - which sees the stacked samples
+        as ONE image of B*h rows (the shuffle never mixes rows of different samples) - except the query x pixel product, a batched GEMM."""
         pk = self._pack()
         D, nq = self.transformer_dim, self.avs_query_num
-        tokens = self.query_generator(self.avs_query_tokens.weight, sparse)
+        tokens = self.query_generator(self.avs_query_tokens.weight, sparse, B=B)
         tokens = ops.add_rows(tokens, self.level_embed.weight[level:level + 1])
         src = img
         if level > 0:
             g = ops.gemm(src, pk["up2"])
-            src = ops.pixel_shuffle2x(g, self.upsample_2x[0].bias, h, w, D)
+            src = ops.pixel_shuffle2x(g, self.upsample_2x[0].bias, B * h, w, D)
             h, w = 2 * h, 2 * w
             src = ops.act_inplace(self.upsample_2x[1](src), "gelu")
             ops.mask_gate(prev, src)
             image_pe = self.pe1((h, w))
         src = ops.add_rows(src, no_mask)          # dense prompt = no_mask_embed broadcast (its bilinear resize is the identity)
-        hs, keys = self.transformer[level](src, image_pe, tokens)
-        t = hs[:nq]
+        hs, keys = self.transformer[level](src, image_pe, tokens, B=B)
+        assert hs.shape[0] == B * nq
+        t = hs
         lay = self.hyper_mlp.layers
-        t = lay[2](lay[1](lay[0](t, act="relu"), act="relu"))                               # [nq, D/8]
+        t = lay[2](lay[1](lay[0](t, act="relu"), act="relu"))                               # [B*nq, D/8]
         g = ops.gemm(keys, pk["ups"])
-        up = ops.pixel_shuffle2x(g, self.output_upscaling[0].bias, h, w, D // 8)
+        up = ops.pixel_shuffle2x(g, self.output_upscaling[0].bias, B * h, w, D // 8)
         h2, w2 = 2 * h, 2 * w
-        up = ops.act_inplace(self.output_upscaling[1](up), "gelu")                          # [h2*w2, D/8]
-        masks = torch.zeros((h2 * w2, pk["nqp"]), device=up.device, dtype=BF16)             # K of the next GEMM padded to 8
-        ops.gemm(up, t, out=masks[:, :nq])                                                  # masks[pix, q] = <up[pix], t[q]>
+        up = ops.act_inplace(self.output_upscaling[1](up), "gelu")                          # [B*h2*w2, D/8]
+        masks = torch.zeros((B * h2 * w2, pk["nqp"]), device=up.device, dtype=BF16)         # K of the next GEMM padded to 8
+        if B == 1:
+            ops.gemm(up, t, out=masks[:, :nq])                                              # masks[pix, q] = <up[pix], t[q]>
+        else:                                                                               # the same product per sample: one batched launch
+            gd = ops.GemmDesc()
+            gd.A, gd.B, gd.C = up.data_ptr(), t.data_ptr(), masks.data_ptr()
+            gd.lda, gd.ldb, gd.ldc = up.stride(0), t.stride(0), masks.stride(0)
+            gd.M, gd.N, gd.K = h2 * w2, nq, up.shape[1]
+            gd.res_scale, gd.batch, gd.nb0 = 1.0, B, B
+            gd.sA0, gd.sB0, gd.sC0 = h2 * w2 * up.stride(0), nq * t.stride(0), h2 * w2 * masks.stride(0)
+            ops.gemm_desc(gd, up.device.index or 0)
         mo = self.hyper_mlp_out.layers
         x = ops.gemm(masks, pk["w0p"], bias=mo[0].bias, act="relu")
         x = ops.gemm(x, pk["w1"], bias=mo[1].bias, act="relu")
@@ -353,37 +373,68 @@ class SegModule(nn.Module):
             self._packed = (key, (w1, w3))
         return self._packed[1]
 
+    # samples of one class count that go through the mask decoder together (the final masks are fp32 [B, ncls, 224, 224]: 14 MB per avss sample)
+    BATCH_BINARY, BATCH_AVSS = 128, 32
+
     @torch.no_grad()
     def forward(self, pred_embeddings, multi_scale_image_feature_list, low_res_mask_size=112, gt_mask=None, batch_task_names=[]):
+        """multimodal_encoder.py:368-448 (inference branch).  The reference walks the samples one by one (:381); here the samples that share a
+        class count (`71 if 'avss' else 1`, :419) run through the neck and both mask-decoder levels TOGETHER (rows stacked sample-major, attention
+        with a batch dimension) - a sample's result does not depend on its companions (no step mixes rows of different samples).  Returns the
+        reference's structure: {'pred_masks': [per sample fp32 [num_classes, 224, 224]]}."""
         if gt_mask is not None:
             raise NotImplementedError("mask losses are training-only (multimodal_encoder.py:450-497)")
-        S, T, es = self.image_scale_nums, self.token_nums_per_scale, self.image_embedding_size
         dev = self.no_mask_embed.weight.device
         pe_in = pred_embeddings.to(device=dev, dtype=BF16)
         bs, n, dm = pe_in.shape
         fcs = self.text_hidden_fcs[0]
         e = fcs[2](fcs[0](pe_in.reshape(bs * n, dm), act="relu"))                             # [bs*n, P]
-        P = e.shape[1]
-        w1, w3 = self._pack()
-        pe = self.get_dense_pe()
-        pred_masks = []
+        pred_masks = [None] * bs
+        groups = {}
         for i in range(bs):
-            task = batch_task_names[i]
-            ncls = 71 if task == 'avss' else 1
-            # sparse prompt per scale: sum_k (1/T) e[scale, k]  (multiseg_scalar = 1/T constants, appendix A.5)
-            sparse = ops.group_mean(e[i * n:(i + 1) * n], S, T, 1.0 / T)                      # [S, P], object 0 (obj_nums == 1)
-            # neck over both levels at once: conv1x1 -> LN2d -> conv3x3 -> LN2d
-            feats = torch.stack([f[i].to(device=dev, dtype=BF16)[: es * es] for f in multi_scale_image_feature_list]).reshape(S * es * es, -1)
-            x = self.image_feature_neck[1](ops.gemm(feats, w1))
-            x = self.image_feature_neck[3](ops.gemm(ops.im2col3x3(x, S, es, es), w3))        # [S*es*es, P]
-            low = torch.zeros((ncls, low_res_mask_size, low_res_mask_size), device=dev, dtype=torch.float32)
-            prev = None
-            for l in range(S):
-                prev, h2, w2 = self.mask_decoder.predict_masks(x[l * es * es:(l + 1) * es * es], pe, sparse[l:l + 1],
-                                                               self.no_mask_embed.weight, l, prev, task, es, es)
-                ops.bilinear(prev, (1, w2 * ncls, ncls), ncls, h2, w2, low, alpha=1.0 / S, beta=1.0 if l else 0.0)
-            out = torch.empty((ncls, self.image_size, self.image_size), device=dev, dtype=torch.float32)
-            ops.bilinear(low, (low_res_mask_size * low_res_mask_size, low_res_mask_size, 1), ncls, low_res_mask_size,
-                         low_res_mask_size, out)
-            pred_masks.append(out)
+            groups.setdefault(71 if batch_task_names[i] == 'avss' else 1, []).append(i)
+        for ncls, idx in groups.items():
+            cap = self.BATCH_AVSS if ncls > 1 else self.BATCH_BINARY
+            for c0 in range(0, len(idx), cap):
+                part = idx[c0:c0 + cap]
+                out = self._forward_group(e, n, part, multi_scale_image_feature_list, low_res_mask_size, ncls, batch_task_names[part[0]])
+                for j, i in enumerate(part):
+                    pred_masks[i] = out[j]
         return {'pred_masks': pred_masks}
+
+    def _forward_group(self, e, n, idx, feats_list, low_res, ncls, task):
+        """The samples `idx` (one class count) through neck + mask decoder + the two bilinear resizes -> fp32 [len(idx), ncls, 224, 224]."""
+        S, T, es = self.image_scale_nums, self.token_nums_per_scale, self.image_embedding_size
+        dev = e.device
+        B = len(idx)
+        hw = es * es
+        contiguous_run = idx == list(range(idx[0], idx[0] + B))
+        sel = None if contiguous_run else torch.tensor(idx, device=dev)
+        # sparse prompt per (sample, scale): sum_k (1/T) e[sample, scale, k]  (multiseg_scalar = 1/T constants, appendix A.5; obj_nums == 1)
+        eg = e.view(-1, n, e.shape[1])[idx[0]:idx[0] + B] if contiguous_run else e.view(-1, n, e.shape[1])[sel]
+        sparse = ops.group_mean(eg.reshape(B * n, -1), B * S, T, 1.0 / T).view(B, S, -1)       # [B, S, P]
+        # neck over both levels of every sample at once, level-major so that each level is one contiguous [B*hw, P] slab:
+        # conv1x1 -> LN2d -> conv3x3 -> LN2d
+        fl = []
+        for f in feats_list[:S]:
+            f = f.to(device=dev, dtype=BF16)
+            fl.append((f[idx[0]:idx[0] + B] if contiguous_run else f[sel])[:, :hw])
+        feats = torch.cat(fl, 0).reshape(S * B * hw, -1) if B > 1 or S > 1 else fl[0].reshape(hw, -1)
+        w1, w3 = self._pack()
+        x = self.image_feature_neck[1](ops.gemm(feats, w1))
+        x = self.image_feature_neck[3](ops.gemm(ops.im2col3x3(x, S * B, es, es), w3))         # [S*B*hw, P]
+        pe = self.get_dense_pe()
+        low = torch.empty((B, ncls, low_res, low_res), device=dev, dtype=torch.float32)
+        prev = None
+        for l in range(S):
+            prev, h2, w2 = self.mask_decoder.predict_masks(x[l * B * hw:(l + 1) * B * hw], pe, sparse[:, l], self.no_mask_embed.weight, l, prev,
+                                                           task, es, es, B=B)
+            if ncls == 1:                       # one plane per sample: the B planes are the "channels" of ONE resize launch
+                ops.bilinear(prev, (h2 * w2, w2, 1), B, h2, w2, low.view(B, low_res, low_res), alpha=1.0 / S, beta=1.0 if l else 0.0)
+            else:
+                pv = prev.view(B, h2 * w2, ncls)
+                for b in range(B):
+                    ops.bilinear(pv[b], (1, w2 * ncls, ncls), ncls, h2, w2, low[b], alpha=1.0 / S, beta=1.0 if l else 0.0)
+        out = torch.empty((B, ncls, self.image_size, self.image_size), device=dev, dtype=torch.float32)
+        ops.bilinear(low, (low_res * low_res, low_res, 1), B * ncls, low_res, low_res, out.view(B * ncls, self.image_size, self.image_size))
+        return out

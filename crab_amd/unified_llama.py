@@ -328,36 +328,75 @@ class UnifiedForCausalLM(nn.Module, UnifiedMetaForCausalLM):
         """unified_llama.py:270-361: greedy generation with the post-final-norm hidden state of every step kept; the states
         of the steps j with output_ids[0, j+1] in {<mask_0..5>} (bs == 1 assumed, :338) become the 6 prompt embeddings
         of the SegModule.  Returns {'output_ids', 'pred_masks'} (only 'output_ids' when != 6 mask tokens were produced).
-        One deviation: step 0 contributes its LAST-row state (the reference's step-0 entry holds all S prompt rows)."""
+        One deviation: step 0 contributes its LAST-row state (the reference's step-0 entry holds all S prompt rows).
+
+        bs > 1 (r06): the reference's own bs > 1 behaviour is unusable (it reads row 0's mask positions for every row, :338, and its pixel loops
+        call it with one sample, scripts/quick_start.py:270-450), so a batch here means `bs` INDEPENDENT bs-1 calls executed together
+        (generate_avs_many): every sample keeps the prompt, positions and picks of its own call.  'output_ids' is then [bs, n_max] (rows that
+        stopped earlier padded with pad_token_id, as HF pads finished rows) and 'pred_masks' a list with None for the rows that did not produce
+        six mask tokens (the reference prints and returns ids only for such a sample, :345-352)."""
+        if len(batch_input_ids) > 1:
+            samples = [{"batch_input_ids": [batch_input_ids[i]], "batch_labels": [batch_labels[i]] if batch_labels is not None else None,
+                        "batch_X_modals": [batch_X_modals[i]], "batch_task_names": [batch_task_names[i]]} for i in range(len(batch_input_ids))]
+            res = self.generate_avs_many(samples, **kwargs)
+            eos = kwargs.get("eos_token_id", self.config.eos_token_id)
+            pad = kwargs.get("pad_token_id", self.model.pad_token_id if self.model.pad_token_id is not None else eos)
+            n_max = max(r['output_ids'].shape[1] for r in res)
+            ids = torch.full((len(res), n_max), int(pad if pad is not None else 0), device=res[0]['output_ids'].device, dtype=res[0]['output_ids'].dtype)
+            for i, r in enumerate(res):
+                ids[i, :r['output_ids'].shape[1]] = r['output_ids'][0]
+            return {'output_ids': ids, 'pred_masks': [r['pred_masks'][0] if r.get('pred_masks') is not None else None for r in res]}
+        return self.generate_avs_many([{"batch_input_ids": batch_input_ids, "batch_labels": batch_labels, "batch_X_modals": batch_X_modals,
+                                        "batch_task_names": batch_task_names}], **kwargs)[0]
+
+    @torch.no_grad()
+    def generate_avs_many(self, samples, max_rows: Optional[int] = None, **kwargs):
+        """The pixel-task loops as a THROUGHPUT path (BASELINE configs[4]): `samples` = a list of dicts with the four generate_avs() arguments, each
+        one call of the reference's loops (scripts/quick_start.py:270-450: one sample per call).  Every call keeps its own
+        prepare_multimodal_inputs result, prompt length and positions; all of them decode as ONE ragged batch (GenerationEngine.generate_many
+        (coalesce=True, return_hidden=True): the weights stream once per step for every sample, the encoders see all images / audio windows
+        together), the <mask_i> picks are made PER ROW (:333-352), and the rows that produced six mask tokens go through the SegModule together
+        (crab_amd/seg_module.py: samples of one class count batched).  Returns one dict per call, exactly what generate_avs returns for it:
+        {'output_ids', 'pred_masks'} - or {'output_ids'} alone when the call's row produced != 6 mask tokens (with the reference's message)."""
         sampling = self._sampling(kwargs)
-        inputs = self.prepare_multimodal_inputs(batch_input_ids=batch_input_ids, batch_labels=batch_labels,
-                                                batch_X_modals=batch_X_modals, return_multi_scale_features=True,
-                                                return_gt_mask=True, batch_task_names=batch_task_names)
-        embeds = inputs['inputs_embeds']
+        if ops.PROFILER is not None:
+            ops.PROFILER.mark("encode_begin")
+        inputs = self.prepare_multimodal_inputs_many(samples, return_multi_scale_features=True, return_gt_mask=True)
+        embeds = [d['inputs_embeds'].to(device=self.device, dtype=BF16) for d in inputs]
         eos = kwargs.get("eos_token_id", self.config.eos_token_id)
         pad = kwargs.get("pad_token_id", self.model.pad_token_id if self.model.pad_token_id is not None else eos)
-        ids, hidden = self._engine.generate(embeds, int(kwargs.get("max_new_tokens", 20)), eos_token_id=eos, pad_token_id=pad,
-                                            min_new_tokens=int(kwargs.get("min_new_tokens", 0) or 0),
-                                            use_graph=kwargs.get("use_graph", True), return_hidden=True, sampling=sampling)
-        result = {'output_ids': ids}
+        outs = self._engine.generate_many(embeds, int(kwargs.get("max_new_tokens", 20)), eos_token_id=eos, pad_token_id=pad,
+                                          min_new_tokens=int(kwargs.get("min_new_tokens", 0) or 0), use_graph=kwargs.get("use_graph", True),
+                                          sampling=sampling, coalesce=True, max_rows=max_rows, return_hidden=True)
         seg_ids = {self.SPECIAL_TOKEN_2_IDS[f'<mask_{i}>'] for i in range(6)}
-        row0 = ids[0].tolist()
-        picks = [j for j in range(len(row0) - 1) if row0[j + 1] in seg_ids]
-        if len(picks) == 0:
-            print('len(pred_embeddings) == 0')
-            return result
-        if len(picks) > 6:
-            print(f'pred_embeddings.shape[1] > 6, shape: {len(picks)}')
-            picks = picks[-6:]
-        elif len(picks) < 6:
-            print(f'pred_embeddings.shape[1] < 6, shape: {len(picks)}')
-            return result
-        pred_embeddings = torch.stack([hidden[:, j] for j in picks], dim=1)              # [bs, 6, D]
-        result = self.model.postprocess_seg(pred_embeddings=pred_embeddings,
-                                            multi_scale_image_feature_list=inputs['multi_scale_image_features'],
-                                            gt_mask=None, batch_task_names=batch_task_names)
-        result['output_ids'] = ids
-        return result
+        results = [{'output_ids': ids} for ids, _ in outs]
+        chosen = []                                           # (call, row, the six step indices)
+        n_tok = [ids.shape[1] for ids, _ in outs]
+        flat = torch.cat([ids.reshape(-1) for ids, _ in outs]).tolist()      # one device -> host transfer for every call's ids
+        o = 0
+        for g, (ids, _) in enumerate(outs):
+            for r in range(ids.shape[0]):
+                row = flat[o:o + n_tok[g]]
+                o += n_tok[g]
+                picks = [j for j in range(len(row) - 1) if row[j + 1] in seg_ids]
+                if len(picks) == 0:
+                    print('len(pred_embeddings) == 0')
+                elif len(picks) < 6:
+                    print(f'pred_embeddings.shape[1] < 6, shape: {len(picks)}')
+                else:
+                    if len(picks) > 6:
+                        print(f'pred_embeddings.shape[1] > 6, shape: {len(picks)}')
+                    chosen.append((g, r, picks[-6:]))
+        if not chosen:
+            return results
+        pred_embeddings = torch.stack([torch.stack([outs[g][1][r, j] for j in picks]) for g, r, picks in chosen])          # [n, 6, D]
+        ms = [torch.stack([inputs[g]['multi_scale_image_features'][lv][r] for g, r, _ in chosen]) for lv in range(len(inputs[0]['multi_scale_image_features']))]
+        tasks = [samples[g]["batch_task_names"][r] for g, r, _ in chosen]
+        seg = self.model.postprocess_seg(pred_embeddings=pred_embeddings, multi_scale_image_feature_list=ms, gt_mask=None, batch_task_names=tasks)
+        for (g, r, _), m in zip(chosen, seg['pred_masks']):
+            bs_g = outs[g][0].shape[0]
+            results[g].setdefault('pred_masks', [None] * bs_g)[r] = m
+        return results
 
     def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
         """Checkpoints are fp32 (reference ships --bf16 False); tensors are cast to the resident bf16 storage."""

@@ -413,6 +413,92 @@ def test_generate_avs_pipeline_vs_oracle():
         assert _rel(res['pred_masks'][0], ref[0], "generate_avs masks vs oracle pipeline") < 1.3e-2      # measured 8.5e-3
 
 
+def _avs_samples(model, meta, sp, ids, image, mods, n):
+    """Seven one-sample calls of the pixel loops: the margin-checked sample under three tasks (two class counts), the same clip behind a longer
+    prompt, and other clips (whose greedy ids do not hit the six re-pointed <mask_i> ids: the ids-only outcome)."""
+    from crab_amd import synth
+    p = meta["prompts"]
+    mk = lambda ids_, mods_, task: {"batch_input_ids": [ids_], "batch_labels": [torch.full_like(ids_, -100)], "batch_X_modals": [mods_], "batch_task_names": [task]}
+    longer = torch.cat([ids[:2], torch.tensor([7, 9, 11, 13, 15]), ids[2:]])
+    samples = [mk(ids, mods[0], 's4'), mk(ids, mods[0], 'avss'), mk(longer, mods[0], 'ms3'), mk(ids, mods[0], 'ms3')]
+    for c in (31, 32, 33):
+        m2 = {'<image>': synth.synth_video(1, seed=meta["seed"], clip=c), '<audio>': synth.synth_audio(p["t_a"], p["l_a"], seed=meta["seed"], clip=c)}
+        samples.append(mk(ids, m2, 'avss' if c == 32 else 's4'))
+    return samples
+
+
+def test_generate_avs_many_equals_one_sample_calls():
+    """generate_avs_many / generate_avs(bs > 1) (r06): several calls of the pixel loops executed together - one ragged decode batch with per-step
+    hidden states, per-row <mask_i> picks, the SegModule batched per class count - against the SAME calls made one by one (the reference's loops,
+    scripts/quick_start.py:270-450): ids equal (up to a sub-margin step of the coalesced decode kernels), masks within the mask decoder's tolerance,
+    the ids-only outcome for rows without six mask tokens, mixed class counts in one batch."""
+    model, meta, A, W, sp, ids, image, mods, lab, n, plain = _avs_setup()
+    samples = _avs_samples(model, meta, sp, ids, image, mods, n)
+    kw = dict(max_new_tokens=n, pad_token_id=2, eos_token_id=None)
+    one = [model.generate_avs(**s_, **kw) for s_ in samples]
+    many = model.generate_avs_many(samples, **kw)
+    assert len(many) == len(samples)
+    n_masks = 0
+    for i, (a, b) in enumerate(zip(one, many)):
+        if not torch.equal(a['output_ids'], b['output_ids']):
+            # the coalesced wave runs the decode kernels of ITS row count: a step may flip only where the one-sample call's own top-2 margin is tiny
+            lg = model.generate(**samples[i], **kw, output_logits=True, return_dict_in_generate=True)
+            j = int((a['output_ids'][0] != b['output_ids'][0]).nonzero()[0])
+            top2 = lg.logits[j][0].float().topk(2).values
+            assert float(top2[0] - top2[1]) < 0.05 * float(lg.logits[j].abs().max()), (i, j)
+            continue
+        assert ('pred_masks' in a) == ('pred_masks' in b), i
+        if 'pred_masks' in a:
+            n_masks += 1
+            assert a['pred_masks'][0].shape == b['pred_masks'][0].shape == ((71, 224, 224) if samples[i]["batch_task_names"][0] == 'avss' else (1, 224, 224))
+            assert _rel(b['pred_masks'][0], a['pred_masks'][0], f"generate_avs_many sample {i} ({samples[i]['batch_task_names'][0]}) masks vs its own generate_avs call (HIP vs HIP)") < 1.3e-2
+    assert n_masks >= 3 and any('pred_masks' not in a for a in one), "the sample set must cover both outcomes"
+    # the public bs > 1 form: ids padded to one tensor, masks as a list with None for the ids-only rows
+    merged = model.generate_avs(batch_input_ids=[s_["batch_input_ids"][0] for s_ in samples], batch_labels=[s_["batch_labels"][0] for s_ in samples],
+                                batch_X_modals=[s_["batch_X_modals"][0] for s_ in samples], batch_task_names=[s_["batch_task_names"][0] for s_ in samples], **kw)
+    assert merged['output_ids'].shape == (len(samples), n) and len(merged['pred_masks']) == len(samples)
+    for i, b in enumerate(many):
+        assert torch.equal(merged['output_ids'][i, :b['output_ids'].shape[1]], b['output_ids'][0])
+        assert (merged['pred_masks'][i] is None) == ('pred_masks' not in b)
+        if 'pred_masks' in b:
+            assert torch.equal(merged['pred_masks'][i], b['pred_masks'][0])                 # the same wave, the same kernels: bit-identical
+    # waves: at most 3 rows decode together -> three waves, same results up to the kernels' choice for another row count
+    waved = model.generate_avs_many(samples, max_rows=3, **kw)
+    assert model._engine.last_plan["groups"] == [3, 3, 1]
+    for i, (b, c) in enumerate(zip(many, waved)):
+        if torch.equal(b['output_ids'], c['output_ids']) and 'pred_masks' in b:
+            assert _rel(c['pred_masks'][0], b['pred_masks'][0], f"generate_avs_many in waves of 3, sample {i} (HIP vs HIP)") < 1.3e-2
+
+
+def test_seg_module_batched_equals_sample_by_sample():
+    """SegModule over a batch with mixed class counts (r06: samples of one class count run through the mask decoder together) against the same
+    module called sample by sample, on the reference fixture's inputs repeated / permuted: per-sample masks within 2e-3 of their scale (the GEMMs
+    pick other tile shapes for other row counts; nothing mixes rows of different samples), and against the fixture itself."""
+    from crab_amd.seg_module import SegModule
+    from tests.util import seg_inputs
+    meta, A = load_fixture("seg_tiny")
+    W = weights_from_table(meta)
+    seg = SegModule(d_model=meta["d_model"], vit_image_embedding_dim=128, device="cuda")
+    seg.load_state_dict({k[len("model.seg_module."):]: v for k, v in W.items()}, strict=True)
+    pred, feats = seg_inputs(meta)
+    order = [0, 1, 1, 0, 1, 0, 0]                                   # fixture samples, repeated and interleaved
+    tasks = ['avss', 's4', 'ms3', 'avss', 'ref-avs', 'avss', 'avss']
+    P = pred[order].to(BF).cuda()
+    F_ = [f[order].to(BF).cuda() for f in feats]
+    batched = seg(pred_embeddings=P, multi_scale_image_feature_list=F_, low_res_mask_size=112, gt_mask=None, batch_task_names=tasks)['pred_masks']
+    for i, t in enumerate(tasks):
+        solo = seg(pred_embeddings=P[i:i + 1], multi_scale_image_feature_list=[f[i:i + 1] for f in F_], low_res_mask_size=112, gt_mask=None,
+                   batch_task_names=[t])['pred_masks'][0]
+        assert batched[i].shape == solo.shape == ((71, 224, 224) if t == 'avss' else (1, 224, 224))
+        assert _rel(batched[i], solo, f"SegModule batched sample {i} ({t}) vs the sample alone (HIP vs HIP)") < 2e-3
+    assert _rel(batched[0][:, 3::8, 5::8], A["avss_sub"], "SegModule batched, avss sample vs fp32 reference") < 2.1e-2
+    assert _rel(batched[1][:, 1::2, ::2], A["s4_sub"], "SegModule batched, s4 sample vs fp32 reference") < 2.1e-2
+    seg.BATCH_AVSS, seg.BATCH_BINARY = 2, 2                         # chunked groups give the same per-sample results as any other batch size
+    chunked = seg(pred_embeddings=P, multi_scale_image_feature_list=F_, low_res_mask_size=112, gt_mask=None, batch_task_names=tasks)['pred_masks']
+    for i in range(len(tasks)):
+        assert _rel(chunked[i], batched[i], f"SegModule in chunks of 2, sample {i} (HIP vs HIP)") < 2e-3
+
+
 def test_harness_pixel_task_loop_writes_the_masks(tmp_path):
     """harness.run_inference_avs = scripts/quick_start.py:270-450: generate_avs -> text + mask files.  Binary task: a mode-'P' PNG with 255 where
     sigmoid(pred) > 0.5; avss: an RGB PNG of palette[argmax over the 71 class planes]; a sample without the six mask tokens: no file."""
@@ -474,6 +560,19 @@ def test_harness_pixel_task_loop_writes_the_masks(tmp_path):
     rn = harness.run_inference_avs([withgt("ref-avs", "/data/avs/vidF/0/1.png", torch.zeros(1, 224, 224))], model, tok, str(tmp_path), max_new_tokens=n,
                                    pad_token_id=2, eos_token_id=None, null_reference=True, summary=summ_n)
     assert rn[0]["s"] == float(MO.metric_s_for_null(d0)) == summ_n["ms"] and "iou" not in rn[0]
+    # coalesce = True (r06): the same three samples as ONE generate_avs_many call - same records, metrics within what the mask decoder's other
+    # tile shapes leave (the thresholded maps may differ in pixels whose logit is within bf16 noise of 0)
+    summ_c = {}
+    rc = harness.run_inference_avs([withgt("s4", "/data/avs/vidG/0/3.png", gt_bin), withgt("ms3", "/data/avs/vidG/0/4.png", 1 - gt_bin),
+                                    withgt("avss", "/data/avs/vidH/0/7.png", gt_cls)], model, tok, str(tmp_path), max_new_tokens=n, pad_token_id=2,
+                                   eos_token_id=None, summary=summ_c, coalesce=True, coalesce_rows=8)
+    assert [r["predict"] for r in rc] == [r["predict"] for r in rec2] and [r["num_classes"] for r in rc] == [1, 1, 71]
+    assert all(abs(a["iou"] - b["iou"]) < 2e-3 and abs(a["fscore"] - b["fscore"]) < 2e-3 for a, b in zip(rc[:2], rec2[:2]))
+    assert summ_c["count"] == 2 and abs(summ_c["miou"] - summ["miou"]) < 2e-3 and abs(summ_c["avss"]["miou"] - summ["avss"]["miou"]) < 2e-3
+    assert rc[2]["pred_path"].endswith("avss_result/vidH/7_pred.png") and np.mean(np.array(Image.open(rc[2]["pred_path"])) != np.array(Image.open(rec2[2]["pred_path"]))) < 5e-3
+    nop = harness.run_inference_avs([withgt("s4", "/data/avs/vidI/0/3.png", gt_bin)] * 2, model, tok, str(tmp_path), max_new_tokens=n, pad_token_id=2,
+                                    eos_token_id=None, coalesce=True, write_png=False)
+    assert nop[0]["pred_path"] is None and "gt_path" not in nop[0] and abs(nop[1]["iou"] - rec2[0]["iou"]) < 2e-3 and not (tmp_path / "mask_img_dir" / "vidI").exists()
     # no mask tokens in the output -> no masks, no file, the record says so (quick_start.py:303-306)
     for i in range(6):
         sp[f'<mask_{i}>'] = meta["base_vocab"] + 11 + i
