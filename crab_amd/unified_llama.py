@@ -358,18 +358,8 @@ class UnifiedForCausalLM(nn.Module, UnifiedMetaForCausalLM):
         together), the <mask_i> picks are made PER ROW (:333-352), and the rows that produced six mask tokens go through the SegModule together
         (crab_amd/seg_module.py: samples of one class count batched).  Returns one dict per call, exactly what generate_avs returns for it:
         {'output_ids', 'pred_masks'} - or {'output_ids'} alone when the call's row produced != 6 mask tokens (with the reference's message)."""
-        sampling = self._sampling(kwargs)
-        if ops.PROFILER is not None:
-            ops.PROFILER.mark("encode_begin")
-        inputs = self.prepare_multimodal_inputs_many(samples, return_multi_scale_features=True, return_gt_mask=True)
-        embeds = [d['inputs_embeds'].to(device=self.device, dtype=BF16) for d in inputs]
-        eos = kwargs.get("eos_token_id", self.config.eos_token_id)
-        pad = kwargs.get("pad_token_id", self.model.pad_token_id if self.model.pad_token_id is not None else eos)
-        outs = self._engine.generate_many(embeds, int(kwargs.get("max_new_tokens", 20)), eos_token_id=eos, pad_token_id=pad,
-                                          min_new_tokens=int(kwargs.get("min_new_tokens", 0) or 0), use_graph=kwargs.get("use_graph", True),
-                                          sampling=sampling, coalesce=True, max_rows=max_rows, return_hidden=True)
+        inputs, outs = self._avs_generate(samples, max_rows, kwargs)
         seg_ids = {self.SPECIAL_TOKEN_2_IDS[f'<mask_{i}>'] for i in range(6)}
-        results = [{'output_ids': ids} for ids, _ in outs]
         chosen = []                                           # (call, row, the six step indices)
         n_tok = [ids.shape[1] for ids, _ in outs]
         flat = torch.cat([ids.reshape(-1) for ids, _ in outs]).tolist()      # one device -> host transfer for every call's ids
@@ -387,6 +377,26 @@ class UnifiedForCausalLM(nn.Module, UnifiedMetaForCausalLM):
                     if len(picks) > 6:
                         print(f'pred_embeddings.shape[1] > 6, shape: {len(picks)}')
                     chosen.append((g, r, picks[-6:]))
+        return self._avs_segment(samples, inputs, outs, chosen)
+
+    def _avs_generate(self, samples, max_rows, kwargs):
+        """First half of generate_avs_many: inputs of every call (multi-scale CLIP features kept) and the ragged decode with per-step hidden states."""
+        sampling = self._sampling(kwargs)
+        if ops.PROFILER is not None:
+            ops.PROFILER.mark("encode_begin")
+        inputs = self.prepare_multimodal_inputs_many(samples, return_multi_scale_features=True, return_gt_mask=True)
+        embeds = [d['inputs_embeds'].to(device=self.device, dtype=BF16) for d in inputs]
+        eos = kwargs.get("eos_token_id", self.config.eos_token_id)
+        pad = kwargs.get("pad_token_id", self.model.pad_token_id if self.model.pad_token_id is not None else eos)
+        outs = self._engine.generate_many(embeds, int(kwargs.get("max_new_tokens", 20)), eos_token_id=eos, pad_token_id=pad,
+                                          min_new_tokens=int(kwargs.get("min_new_tokens", 0) or 0), use_graph=kwargs.get("use_graph", True),
+                                          sampling=sampling, coalesce=True, max_rows=max_rows, return_hidden=True)
+        return inputs, outs
+
+    def _avs_segment(self, samples, inputs, outs, chosen):
+        """Second half: `chosen` = [(call, row, six step indices)] -> the picked states of those rows through the SegModule (batched per class
+        count), one result dict per call."""
+        results = [{'output_ids': ids} for ids, _ in outs]
         if not chosen:
             return results
         pred_embeddings = torch.stack([torch.stack([outs[g][1][r, j] for j in picks]) for g, r, picks in chosen])          # [n, 6, D]
