@@ -225,6 +225,10 @@ SYMBOLS = {
     "crab_softmax_rows": (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _i, _i, _f]),
     "crab_row_sqnorm": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp]),
     "crab_vq_argmin": (_i, [_vp, _vp, _vp, _i64, _vp, _i, _i, _vp, _i64]),
+    "crab_row_sqnorm_f32": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp]),
+    "crab_vq_nearest_f32_workspace": (_i64, [_i, _i]),
+    "crab_vq_nearest_f32": (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _i, _i, _i, _vp, _i64, _vp, _i64]),
+    "crab_groupnorm_p": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _i, _i, _vp, _i64]),
     "crab_kaldi_fbank_frames": (_i, [_i]),
     "crab_kaldi_fbank": (_i, [_vp, _vp, _vp, _i64, _i, _i, _f, _f, _vp, _vp, _vp, _f, _f]),
 }

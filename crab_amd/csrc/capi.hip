@@ -4,7 +4,7 @@
 
 extern "C" {
 
-int crab_abi_version(void) { return 11; }   // 11: crab_trace_begin / crab_trace_end (which kernels the entry points launched: tests pin a comparison to a kernel instantiation); 10: segmentation metrics of the pixel-task eval loops (crab_mask_iou, crab_fmeasure, crab_miou_fscore, crab_color_to_label; seg_metrics.hip); 9: the ragged decode batch - crab_gemm_desc.rope_row_off, crab_llama_io.row_off, crab_qkv_rope_split_ragged (several generate() calls of different prompt lengths decode as one right-aligned batch); 8: crab_attn_desc.key_mask / key_mask_ld (general 2-D attention_mask), crab_attn_decode_keymask; 7: fp32 residual stream (crab_gemm_desc.r_fp32, crab_llama_io / crab_enc_io.x_fp32, crab_rmsnorm_f32 / crab_layernorm_f32 / crab_embedding_f32 / crab_cast_rows_*); 6: crab_gemm_desc.rope_S / rope_pos_ids (prefill RoPE in the q|k|v epilogue), crab_gemm_fuses_prefill_rope; 2: fused RoPE / KV-append fields in crab_gemm_desc; 3: next-group router fields; 4: crab_llama_layer*; 5: crab_attn_desc.kv_start, crab_qkv_rope_split_ids, crab_attn_decode_masked
+int crab_abi_version(void) { return 12; }   // 12: crab_vq_nearest_f32 / crab_row_sqnorm_f32 (codebook ids from fp32 latents, fp32 codebook, fp32 distances), crab_groupnorm_p (fp32 GroupNorm parameters); 11: crab_trace_begin / crab_trace_end (which kernels the entry points launched: tests pin a comparison to a kernel instantiation); 10: segmentation metrics of the pixel-task eval loops (crab_mask_iou, crab_fmeasure, crab_miou_fscore, crab_color_to_label; seg_metrics.hip); 9: the ragged decode batch - crab_gemm_desc.rope_row_off, crab_llama_io.row_off, crab_qkv_rope_split_ragged (several generate() calls of different prompt lengths decode as one right-aligned batch); 8: crab_attn_desc.key_mask / key_mask_ld (general 2-D attention_mask), crab_attn_decode_keymask; 7: fp32 residual stream (crab_gemm_desc.r_fp32, crab_llama_io / crab_enc_io.x_fp32, crab_rmsnorm_f32 / crab_layernorm_f32 / crab_embedding_f32 / crab_cast_rows_*); 6: crab_gemm_desc.rope_S / rope_pos_ids (prefill RoPE in the q|k|v epilogue), crab_gemm_fuses_prefill_rope; 2: fused RoPE / KV-append fields in crab_gemm_desc; 3: next-group router fields; 4: crab_llama_layer*; 5: crab_attn_desc.kv_start, crab_qkv_rope_split_ids, crab_attn_decode_masked
 
 int crab_decode_max_rows(void) { return CRAB_DECODE_MAX_ROWS; }
 int crab_attn_split_below(void) { return CRAB_ATTN_SPLIT_BELOW; }

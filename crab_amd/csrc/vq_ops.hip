@@ -58,9 +58,11 @@ __global__ __launch_bounds__(256) void groupnorm_stats_kernel(const bf16_t* __re
 }
 
 // grid (ceil(HW*C/8/256), B)
+// WF: weight / bias are fp32 (r06: the GroupNorm parameters are not matrix operands; their bf16 rounding is a systematic 2^-9 error on every channel)
+template <bool WF>
 __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, int HW, int C, int G,
-                                                              int chunks, const float* __restrict__ partial, const bf16_t* __restrict__ weight,
-                                                              const bf16_t* __restrict__ bias, float eps, int swish) {
+                                                              int chunks, const float* __restrict__ partial, const void* __restrict__ weight_,
+                                                              const void* __restrict__ bias_, float eps, int swish) {
     __shared__ float mean_s[64], rstd_s[64];
     const int tid = threadIdx.x, b = blockIdx.y;
     if (tid < G) {
@@ -78,8 +80,16 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const bf16_t* __re
     const int c0 = (int)((v8 * 8) % C);
     const long off = (long)b * HW * C + v8 * 8;
     const u32x4 xv = *reinterpret_cast<const u32x4*>(x + off);
-    const u32x4 wv = *reinterpret_cast<const u32x4*>(weight + c0);
-    const u32x4 bv = *reinterpret_cast<const u32x4*>(bias + c0);
+    float wf[8], bfv[8];
+    if (WF) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { wf[e] = ((const float*)weight_)[c0 + e]; bfv[e] = ((const float*)bias_)[c0 + e]; }
+    } else {
+        const u32x4 wv = *reinterpret_cast<const u32x4*>((const bf16_t*)weight_ + c0);
+        const u32x4 bv = *reinterpret_cast<const u32x4*>((const bf16_t*)bias_ + c0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { wf[2 * e] = lo_bf(wv[e]); wf[2 * e + 1] = hi_bf(wv[e]); bfv[2 * e] = lo_bf(bv[e]); bfv[2 * e + 1] = hi_bf(bv[e]); }
+    }
     const int cpg = C / G;
     u32x4 o;
 #pragma unroll
@@ -89,8 +99,8 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const bf16_t* __re
         for (int hlf = 0; hlf < 2; ++hlf) {
             const int c = c0 + 2 * e + hlf, g = c / cpg;
             const float xx = hlf ? hi_bf(xv[e]) : lo_bf(xv[e]);
-            const float ww = hlf ? hi_bf(wv[e]) : lo_bf(wv[e]);
-            const float bb = hlf ? hi_bf(bv[e]) : lo_bf(bv[e]);
+            const float ww = wf[2 * e + hlf];
+            const float bb = bfv[2 * e + hlf];
             float v = (xx - mean_s[g]) * rstd_s[g] * ww + bb;
             if (swish) v = v / (1.0f + __expf(-v));
             y[hlf] = v;
@@ -172,6 +182,104 @@ __global__ __launch_bounds__(256) void vq_argmin_kernel(const float* __restrict_
     }
 }
 
+// ---- the quantiser in fp32 (r06; quantize.py:272-313): idx[m] = first argmin_n (|z_m|^2 + |e_n|^2) - 2 z_m . e_n with z (the latents of the
+// last conv, unrounded) and e (the codebook) in fp32 and the reference's fp32 expression (A + B) - 2 C per entry.  The codebook ids are INDEX
+// work: with bf16 operands an id flips wherever the nearest / second-nearest margin is below the bf16 distance error (~1e-2 of |z||e|); in
+// fp32 only where it is below fp32 summation noise.  2 M N D flops (2.1 GF per 256 x 256 mask: irrelevant next to the encoder), vector FMAs.
+// grid (ceil(M / 16), nsplit): a block owns 16 latent rows (LDS, broadcast reads) and every nsplit-th 64-entry tile of the codebook (staged through
+// LDS, row stride D + 1: conflict-free); a wave owns 4 of the rows, a lane one entry of the tile; k ascends in both the dot product and the
+// tile walk, so a thread meets its entries in ascending n (first minimum kept by strict <).  part[m][split] = (best d, its n).
+constexpr int VQ_RT = 16, VQ_NT = 64, VQ_MAXD = 256;
+
+__global__ __launch_bounds__(256) void vq_nearest_f32_kernel(const float* __restrict__ z, long ldz, const float* __restrict__ e, long lde,
+                                                             const float* __restrict__ e2, int M, int N, int D, float* __restrict__ pbest,
+                                                             int* __restrict__ pidx) {
+    extern __shared__ float vq_lds[];
+    float* zs = vq_lds;                                  // [VQ_RT][D]
+    float* es = vq_lds + VQ_RT * D;                      // [VQ_NT][D + 1]
+    __shared__ float z2s[VQ_RT];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int m0 = blockIdx.x * VQ_RT, split = blockIdx.y, nsplit = gridDim.y;
+    for (int i = tid; i < VQ_RT * D; i += 256) {
+        const int r = i / D, k = i % D;
+        zs[i] = (m0 + r < M) ? z[(long)(m0 + r) * ldz + k] : 0.f;
+    }
+    __syncthreads();
+    for (int j = 0; j < 4; ++j) {                        // |z|^2 of the wave's rows (the reference's torch.sum(z ** 2, dim = 1))
+        const int r = wv * 4 + j;
+        float s = 0.f;
+        for (int k = lane; k < D; k += 64) s += zs[r * D + k] * zs[r * D + k];
+        s = wave_sum(s);
+        if (lane == 0) z2s[r] = s;
+    }
+    float best[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
+    int besti[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+    const int ntiles = (N + VQ_NT - 1) / VQ_NT;
+    for (int t = split; t < ntiles; t += nsplit) {
+        const int n0 = t * VQ_NT;
+        __syncthreads();                                 // the previous tile has been consumed (and z2s is visible)
+        for (int i = tid; i < VQ_NT * (D >> 2); i += 256) {
+            const int r = i / (D >> 2), k4 = i % (D >> 2);
+            float4 v = {0.f, 0.f, 0.f, 0.f};
+            if (n0 + r < N) v = *reinterpret_cast<const float4*>(e + (long)(n0 + r) * lde + k4 * 4);
+            float* d = es + r * (D + 1) + k4 * 4;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+        __syncthreads();
+        const int n = n0 + lane;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        const float* er = es + lane * (D + 1);
+        const float* zr = zs + wv * 4 * D;
+        for (int k = 0; k < D; ++k) {
+            const float ev = er[k];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = fmaf(zr[j * D + k], ev, acc[j]);
+        }
+        if (n < N) {
+            const float en = e2[n];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float dv = (z2s[wv * 4 + j] + en) - 2.0f * acc[j];
+                if (dv < best[j]) { best[j] = dv; besti[j] = n; }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float b = best[j]; int bi = besti[j];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(b, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov < b || (ov == b && oi < bi)) { b = ov; bi = oi; }
+        }
+        const int m = m0 + wv * 4 + j;
+        if (lane == 0 && m < M) { pbest[(long)m * nsplit + split] = b; pidx[(long)m * nsplit + split] = bi; }
+    }
+}
+
+__global__ void vq_nearest_finish_kernel(const float* __restrict__ pbest, const int* __restrict__ pidx, int M, int nsplit, int64_t* __restrict__ idx,
+                                         int64_t offset) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    float b = INFINITY; int bi = 0x7fffffff;
+    for (int s = 0; s < nsplit; ++s) {
+        const float v = pbest[(long)m * nsplit + s];
+        const int i = pidx[(long)m * nsplit + s];
+        if (v < b || (v == b && i < bi)) { b = v; bi = i; }
+    }
+    idx[m] = (int64_t)bi + offset;
+}
+
+__global__ void row_sqnorm_f32_kernel(const float* __restrict__ e, long lde, int N, int D, float* __restrict__ out) {
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int i = lane; i < D; i += 64) { const float v = e[(long)n * lde + i]; s += v * v; }
+    s = wave_sum(s);
+    if (lane == 0) out[n] = s;
+}
+
 }  // namespace
 
 #define S_(x) ((hipStream_t)(x))
@@ -193,8 +301,16 @@ extern "C" int64_t crab_groupnorm_workspace(int B, int HW, int G) {
     return (int64_t)B * chunks * G * 2 * (int64_t)sizeof(float);
 }
 
+extern "C" int crab_groupnorm_p(crab_ctx* ctx, void* stream, const void* x, void* out, int B, int HW, int C, int G, float eps, const void* weight,
+                                const void* bias, int w_fp32, int swish, void* workspace, int64_t workspace_bytes);
+
 extern "C" int crab_groupnorm(crab_ctx* ctx, void* stream, const void* x, void* out, int B, int HW, int C, int G, float eps, const void* weight,
                               const void* bias, int swish, void* workspace, int64_t workspace_bytes) {
+    return crab_groupnorm_p(ctx, stream, x, out, B, HW, C, G, eps, weight, bias, 0, swish, workspace, workspace_bytes);
+}
+
+extern "C" int crab_groupnorm_p(crab_ctx* ctx, void* stream, const void* x, void* out, int B, int HW, int C, int G, float eps, const void* weight,
+                                const void* bias, int w_fp32, int swish, void* workspace, int64_t workspace_bytes) {
     if (!ctx) return CRAB_E_INVALID;
     if (!x || !out || !weight || !bias || !workspace || B <= 0 || HW <= 0 || C <= 0 || G <= 0 || G > 64 || C % G || (C & 7) || C > GN_MAXC)
         return crab_fail(ctx, CRAB_E_INVALID, "groupnorm: bad argument (C % 8 == 0, C <= 1024, G <= 64)");
@@ -206,9 +322,13 @@ extern "C" int crab_groupnorm(crab_ctx* ctx, void* stream, const void* x, void* 
     hipLaunchKernelGGL(groupnorm_stats_kernel, dim3(chunks, B), dim3(256), 0, S_(stream), (const bf16_t*)x, HW, C, G, rows, (float*)workspace);
     int rc = crab_check_launch(ctx, "groupnorm_stats_kernel");
     if (rc) return rc;
-    hipLaunchKernelGGL(groupnorm_apply_kernel, dim3(cdiv_((long)HW * C / 8, 256), B), dim3(256), 0, S_(stream), (const bf16_t*)x, (bf16_t*)out, HW, C,
-                       G, chunks, (const float*)workspace, (const bf16_t*)weight, (const bf16_t*)bias, eps, swish);
-    return crab_check_launch(ctx, "groupnorm_apply_kernel");
+    if (w_fp32)
+        hipLaunchKernelGGL((groupnorm_apply_kernel<true>), dim3(cdiv_((long)HW * C / 8, 256), B), dim3(256), 0, S_(stream), (const bf16_t*)x, (bf16_t*)out, HW, C,
+                           G, chunks, (const float*)workspace, weight, bias, eps, swish);
+    else
+        hipLaunchKernelGGL((groupnorm_apply_kernel<false>), dim3(cdiv_((long)HW * C / 8, 256), B), dim3(256), 0, S_(stream), (const bf16_t*)x, (bf16_t*)out, HW, C,
+                           G, chunks, (const float*)workspace, weight, bias, eps, swish);
+    return crab_check_launch(ctx, w_fp32 ? "groupnorm_apply_kernel<fp32 params>" : "groupnorm_apply_kernel");
 }
 
 extern "C" int crab_upsample_nearest2x(crab_ctx* ctx, void* stream, const void* in, void* out, int B, int h, int w, int C) {
@@ -239,4 +359,43 @@ extern "C" int crab_vq_argmin(crab_ctx* ctx, void* stream, const float* dots, in
     if (!dots || !e2 || !idx || M <= 0 || N <= 0) return crab_fail(ctx, CRAB_E_INVALID, "vq_argmin: bad argument");
     hipLaunchKernelGGL(vq_argmin_kernel, dim3(M), dim3(256), 0, S_(stream), dots, (long)ldd, e2, N, idx, offset);
     return crab_check_launch(ctx, "vq_argmin");
+}
+
+extern "C" int crab_row_sqnorm_f32(crab_ctx* ctx, void* stream, const float* e, int64_t lde, int N, int D, float* out) {
+    if (!ctx) return CRAB_E_INVALID;
+    if (!e || !out || N <= 0 || D <= 0) return crab_fail(ctx, CRAB_E_INVALID, "row_sqnorm_f32: bad argument");
+    hipLaunchKernelGGL(row_sqnorm_f32_kernel, dim3(cdiv_(N, 4)), dim3(256), 0, S_(stream), e, (long)lde, N, D, out);
+    return crab_check_launch(ctx, "row_sqnorm_f32");
+}
+
+static int vq_nsplit(int M, int N) {
+    const int rb = (M + VQ_RT - 1) / VQ_RT, nt = (N + VQ_NT - 1) / VQ_NT;
+    int ns = (1024 + rb - 1) / rb;                       // ~4 blocks per CU
+    if (ns > nt) ns = nt;
+    if (ns > 64) ns = 64;
+    return ns < 1 ? 1 : ns;
+}
+
+extern "C" int64_t crab_vq_nearest_f32_workspace(int M, int N) { return (int64_t)M * vq_nsplit(M, N) * 8; }
+
+extern "C" int crab_vq_nearest_f32(crab_ctx* ctx, void* stream, const float* z, int64_t ldz, const float* e, int64_t lde, const float* e2, int M, int N,
+                                   int D, int64_t* idx, int64_t offset, void* workspace, int64_t workspace_bytes) {
+    if (!ctx) return CRAB_E_INVALID;
+    if (!z || !e || !e2 || !idx || M <= 0 || N <= 0 || D <= 0 || D > VQ_MAXD || (D & 3) || (lde & 3) || ((uintptr_t)e & 15))
+        return crab_fail(ctx, CRAB_E_INVALID, "vq_nearest_f32: bad argument (D % 4 == 0, D <= 256, 16-byte aligned codebook rows)");
+    if (!workspace || workspace_bytes < crab_vq_nearest_f32_workspace(M, N)) return crab_fail(ctx, CRAB_E_WORKSPACE, "vq_nearest_f32: needs crab_vq_nearest_f32_workspace(M, N) bytes");
+    const int ns = vq_nsplit(M, N);
+    float* pbest = (float*)workspace;
+    int* pidx = (int*)((char*)workspace + (int64_t)M * ns * 4);
+    const size_t lds = (size_t)(VQ_RT * D + VQ_NT * (D + 1)) * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        CRAB_HIP_TRY(ctx, hipFuncSetAttribute((const void*)vq_nearest_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((VQ_RT * VQ_MAXD + VQ_NT * (VQ_MAXD + 1)) * sizeof(float))));
+        attr = true;
+    }
+    hipLaunchKernelGGL(vq_nearest_f32_kernel, dim3((M + VQ_RT - 1) / VQ_RT, ns), dim3(256), lds, S_(stream), z, (long)ldz, e, (long)lde, e2, M, N, D, pbest, pidx);
+    int rc = crab_check_launch(ctx, "vq_nearest_f32_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(vq_nearest_finish_kernel, dim3(cdiv_(M, 256)), dim3(256), 0, S_(stream), pbest, pidx, M, ns, idx, offset);
+    return crab_check_launch(ctx, "vq_nearest_finish_kernel");
 }

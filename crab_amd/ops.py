@@ -712,8 +712,11 @@ def groupnorm(x: torch.Tensor, B: int, HW: int, G: int, weight: torch.Tensor, bi
         out = torch.empty_like(x)
     need = int(_lib.load().crab_groupnorm_workspace(B, HW, G))
     ws = torch.empty((need,), device=x.device, dtype=torch.uint8)
-    _lib.check(_lib.load().crab_groupnorm(_lib.ctx(d), _stream(), _p(x), _p(out), B, HW, Cc, G, eps, _p(weight), _p(bias), 1 if swish else 0,
-                                          _p(ws), need), d)
+    wf = weight.dtype == torch.float32
+    if (bias.dtype == torch.float32) != wf or (not wf and weight.dtype != BF16):
+        raise _lib.CrabHipError("groupnorm: weight and bias are both bf16 or both fp32")
+    _lib.check(_lib.load().crab_groupnorm_p(_lib.ctx(d), _stream(), _p(x), _p(out), B, HW, Cc, G, eps, _p(weight), _p(bias), 1 if wf else 0,
+                                            1 if swish else 0, _p(ws), need), d)
     return out
 
 
@@ -740,6 +743,30 @@ def row_sqnorm(e: torch.Tensor) -> torch.Tensor:
     N, D = e.shape
     out = torch.empty((N,), device=e.device, dtype=torch.float32)
     _lib.check(_lib.load().crab_row_sqnorm(_lib.ctx(d), _stream(), _p(e), e.stride(0), N, D, _p(out)), d)
+    return out
+
+
+def row_sqnorm_f32(e: torch.Tensor) -> torch.Tensor:
+    d = _dev(e)
+    assert e.dtype == torch.float32 and e.stride(1) == 1
+    N, D = e.shape
+    out = torch.empty((N,), device=e.device, dtype=torch.float32)
+    _lib.check(_lib.load().crab_row_sqnorm_f32(_lib.ctx(d), _stream(), _p(e), e.stride(0), N, D, _p(out)), d)
+    return out
+
+
+def vq_nearest_f32(z: torch.Tensor, e: torch.Tensor, e2: torch.Tensor, offset: int = 0) -> torch.Tensor:
+    """z fp32 [M, D] latents, e fp32 [N, D] codebook, e2 = row_sqnorm_f32(e) -> int64 [M]: offset + first argmin_n (|z|^2 + e2[n]) - 2 z . e_n,
+    every term in fp32 (quantize.py:286-290): codebook ids are index work."""
+    d = _dev(z)
+    if z.dtype != torch.float32 or e.dtype != torch.float32 or e2.dtype != torch.float32 or z.stride(1) != 1 or e.stride(1) != 1:
+        raise _lib.CrabHipError("vq_nearest_f32: fp32 row-major operands")
+    M, D = z.shape
+    N = e.shape[0]
+    out = torch.empty((M,), device=z.device, dtype=torch.int64)
+    need = int(_lib.load().crab_vq_nearest_f32_workspace(M, N))
+    ws = torch.empty((need,), device=z.device, dtype=torch.uint8)
+    _lib.check(_lib.load().crab_vq_nearest_f32(_lib.ctx(d), _stream(), _p(z), z.stride(0), _p(e), e.stride(0), _p(e2), M, N, D, _p(out), offset, _p(ws), need), d)
     return out
 
 

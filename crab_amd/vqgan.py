@@ -9,8 +9,12 @@ Layout: feature maps are token-major `[b*h*w, C]` bf16 (as in seg_module.py).  C
 fused in the GEMM epilogue), Conv1x1 = GEMM, GroupNorm(32)+swish = one two-pass kernel, Downsample = strided im2col
 (the reference's asymmetric (0,1,0,1) padding), Upsample = nearest 2x + conv.  AttnBlock is single-head attention over
 h*w = 256 positions with 512 channels: scores and P.V are plain GEMMs around a row-softmax kernel (V is produced
-transposed by swapping the GEMM operands; its bias is added after P.V, rows of P sum to one).  The quantiser is one GEMM
-against the codebook + a row argmin of |e|^2 - 2 z.e (first minimum wins, as torch.argmin)."""
+transposed by swapping the GEMM operands; its bias is added after P.V, rows of P sum to one).
+
+The quantiser is INDEX work and runs in fp32 (r06): quant_conv leaves its latents unrounded (fp32 GEMM output), the codebook is
+held in fp32 (16 MB at 16384 x 256) and ops.vq_nearest_f32 evaluates the reference's fp32 expression (|z|^2 + |e|^2) - 2 z.e per
+entry with vector FMAs, first minimum wins as torch.argmin - given the same latents the ids equal the reference's wherever its
+margin exceeds fp32 summation noise.  GroupNorm weights / biases are fp32 as well (not matrix operands; ops.NORM_PARAMS_FP32)."""
 from __future__ import annotations
 
 import math
@@ -54,8 +58,9 @@ class Conv2d(nn.Module):
 class GroupNorm(nn.Module):
     def __init__(self, c: int, device):
         super().__init__()
-        self.weight = _p(None, device, c, fill=1.0)
-        self.bias = _p(None, device, c)
+        dt = torch.float32 if ops.NORM_PARAMS_FP32 else BF16
+        self.weight = _p(None, device, c, fill=1.0, dtype=dt)
+        self.bias = _p(None, device, c, dtype=dt)
 
     def __call__(self, x: torch.Tensor, B: int, HW: int, swish: bool) -> torch.Tensor:
         return ops.groupnorm(x, B, HW, GROUPS, self.weight, self.bias, 1e-6, swish)
@@ -65,8 +70,8 @@ def _conv3x3(x: torch.Tensor, conv: Conv2d, B: int, h: int, w: int, residual: Op
     return ops.gemm(ops.im2col3x3(x, B, h, w), conv.packed(), bias=conv.bias, residual=residual)
 
 
-def _conv1x1(x: torch.Tensor, conv: Conv2d, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
-    return ops.gemm(x, conv.packed(), bias=conv.bias, residual=residual)
+def _conv1x1(x: torch.Tensor, conv: Conv2d, residual: Optional[torch.Tensor] = None, out_fp32: bool = False) -> torch.Tensor:
+    return ops.gemm(x, conv.packed(), bias=conv.bias, residual=residual, out_fp32=out_fp32)
 
 
 class ResnetBlock(nn.Module):
@@ -249,7 +254,7 @@ class Decoder(nn.Module):
 class _Embedding(nn.Module):
     def __init__(self, n: int, d: int, device):
         super().__init__()
-        self.weight = _p(None, device, n, d)
+        self.weight = _p(None, device, n, d, dtype=torch.float32)       # the codebook: fp32, as the checkpoint holds it (the ids are index work)
 
 
 class VectorQuantizer(nn.Module):
@@ -260,21 +265,26 @@ class VectorQuantizer(nn.Module):
         self.n_e, self.e_dim = n_e, e_dim
         self.embedding = _Embedding(n_e, e_dim, device)
         self._e2 = None
+        self._w16 = None
 
     def _norms(self) -> torch.Tensor:
         w = self.embedding.weight
         key = (w.data_ptr(), w._version)
         if self._e2 is None or self._e2[0] != key:
-            self._e2 = (key, ops.row_sqnorm(w))
+            self._e2 = (key, ops.row_sqnorm_f32(w))
         return self._e2[1]
 
     def indices(self, z: torch.Tensor, offset: int = 0) -> torch.Tensor:
-        """z [M, e_dim] bf16 -> int64 [M] = offset + argmin_n |z - e_n|^2."""
-        dots = ops.gemm(z, self.embedding.weight, out_fp32=True)
-        return ops.vq_argmin(dots, self._norms(), offset)
+        """z [M, e_dim] fp32 (unrounded latents) -> int64 [M] = offset + argmin_n |z - e_n|^2, every term in fp32."""
+        return ops.vq_nearest_f32(z, self.embedding.weight, self._norms(), offset)
 
     def get_codebook_entry(self, indices: torch.Tensor) -> torch.Tensor:
-        return ops.embedding(indices.reshape(-1).to(torch.int64), self.embedding.weight)
+        """The decode side consumes the entry as a matrix operand (post_quant_conv): a bf16 copy of the codebook, made once per weight version."""
+        w = self.embedding.weight
+        key = (w.data_ptr(), w._version)
+        if self._w16 is None or self._w16[0] != key:
+            self._w16 = (key, ops.cast_bf16(w))
+        return ops.embedding(indices.reshape(-1).to(torch.int64), self._w16[1])
 
 
 class VQModel(nn.Module):
@@ -292,8 +302,9 @@ class VQModel(nn.Module):
             self.load_state_dict(torch.load(ckpt_path, map_location="cpu"), strict=False)     # vqgan.py:42-52
 
     def encode_latents(self, x: torch.Tensor) -> Tuple[torch.Tensor, int, int]:
+        """-> fp32 latents [b*h*w, embed_dim]: the output of quant_conv is what the quantiser measures distances from, so it is not rounded."""
         h, hh, ww = self.encoder(x)
-        return _conv1x1(h, self.quant_conv), hh, ww
+        return _conv1x1(h, self.quant_conv, out_fp32=True), hh, ww
 
     @torch.no_grad()
     def get_codebook_indices(self, x: torch.Tensor, offset: int = 0) -> torch.Tensor:

@@ -570,6 +570,17 @@ int crab_upsample_nearest2x(crab_ctx* ctx, void* stream, const void* in, void* o
 int crab_softmax_rows(crab_ctx* ctx, void* stream, const float* in, int64_t ldi, void* out, int64_t ldo, int M, int N, float scale);
 int crab_row_sqnorm(crab_ctx* ctx, void* stream, const void* e, int64_t lde, int N, int D, float* out);
 int crab_vq_argmin(crab_ctx* ctx, void* stream, const float* dots, int64_t ldd, const float* e2, int M, int N, int64_t* idx, int64_t offset);
+/* r06 (ABI 12): the quantiser in fp32 - codebook ids are INDEX work.  z [M, D] fp32 (the unrounded latents of quant_conv), e [N, D] fp32 (the
+ * codebook as the checkpoint holds it), e2 = crab_row_sqnorm_f32(e): idx[m] = offset + first argmin_n (|z_m|^2 + e2[n]) - 2 z_m . e_n, the fp32
+ * expression of VectorQuantizer2.forward (quantize.py:286-290); equals the reference's ids wherever its nearest / second-nearest margin exceeds
+ * fp32 summation noise GIVEN THE SAME LATENTS.  D % 4 == 0, D <= 256; workspace = crab_vq_nearest_f32_workspace(M, N) bytes.
+ * crab_groupnorm_p = crab_groupnorm with fp32 weight / bias when w_fp32 != 0 (GroupNorm parameters are not matrix operands). */
+int crab_row_sqnorm_f32(crab_ctx* ctx, void* stream, const float* e, int64_t lde, int N, int D, float* out);
+int64_t crab_vq_nearest_f32_workspace(int M, int N);
+int crab_vq_nearest_f32(crab_ctx* ctx, void* stream, const float* z, int64_t ldz, const float* e, int64_t lde, const float* e2, int M, int N, int D,
+                        int64_t* idx, int64_t offset, void* workspace, int64_t workspace_bytes);
+int crab_groupnorm_p(crab_ctx* ctx, void* stream, const void* x, void* out, int B, int HW, int C, int G, float eps, const void* weight, const void* bias,
+                     int w_fp32, int swish, void* workspace, int64_t workspace_bytes);
 
 /* ---------------------------------------------------------------------------------------------
  * Multi-GPU: per-clip sharding, one process per GPU, full weight replica; the ONLY exchange is a gather of fixed-size result

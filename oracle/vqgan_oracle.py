@@ -30,6 +30,42 @@ class VQConfig:
     groups: int = 32
 
 
+# Emulation modes (as oracle/crab_oracle.py has them for the transformer stacks): what a bf16-MFMA implementation of this path rounds.
+#   None              : fp32 (the reference)
+#   "floor"           : the bf16-OPERAND FLOOR - only what a matrix instruction consumes is rounded, once: conv / 1x1 weights and input maps, the
+#                       attention operands q, k, v and the softmax probabilities as the P.V operand.  Everything else (residual stream, GroupNorm
+#                       parameters, biases, statistics) stays fp32.  No bf16-MFMA implementation can be closer to the fp32 reference.
+#   "storage"         : additionally the HIP path's storage points: the residual stream x between blocks is stored in bf16
+#   "storage_fp32res" : the storage emulation with the residual stream kept in fp32 (what an fp32-stream implementation would store)
+EMULATE = None
+
+
+class emulate:
+    """`with emulate("floor"):` run the oracle in that emulation mode."""
+
+    def __init__(self, mode):
+        assert mode in (None, "floor", "storage", "storage_fp32res")
+        self.mode = mode
+
+    def __enter__(self):
+        global EMULATE
+        self.prev, EMULATE = EMULATE, self.mode
+
+    def __exit__(self, *a):
+        global EMULATE
+        EMULATE = self.prev
+
+
+def _op(x):
+    """a matrix operand at its point of consumption"""
+    return x if EMULATE is None else x.to(torch.bfloat16).float()
+
+
+def _res(x):
+    """the residual stream between blocks: a storage point of the all-bf16 form"""
+    return x.to(torch.bfloat16).float() if EMULATE == "storage" else x
+
+
 def _gn(x, W, pre, groups):
     return F.group_norm(x, groups, W[pre + ".weight"].float(), W[pre + ".bias"].float(), 1e-6)
 
@@ -39,7 +75,7 @@ def _swish(x):
 
 
 def _conv(x, W, pre, stride=1, padding=1):
-    return F.conv2d(x, W[pre + ".weight"].float(), W[pre + ".bias"].float(), stride=stride, padding=padding)
+    return F.conv2d(_op(x), _op(W[pre + ".weight"].float()), W[pre + ".bias"].float(), stride=stride, padding=padding)
 
 
 def resnet_block(x, W, pre, cin, cout, groups):
@@ -48,7 +84,7 @@ def resnet_block(x, W, pre, cin, cout, groups):
     h = _conv(_swish(_gn(h, W, pre + ".norm2", groups)), W, pre + ".conv2")
     if cin != cout:
         x = _conv(x, W, pre + ".nin_shortcut", padding=0)
-    return x + h
+    return _res(x + h)
 
 
 def attn_block(x, W, pre, groups):
@@ -58,17 +94,17 @@ def attn_block(x, W, pre, groups):
     b, c, h, w = q.shape
     q = q.reshape(b, c, h * w).permute(0, 2, 1)
     k = k.reshape(b, c, h * w)
-    w_ = torch.softmax(torch.bmm(q, k) * (int(c) ** (-0.5)), dim=2)
+    w_ = torch.softmax(torch.bmm(_op(q), _op(k)) * (int(c) ** (-0.5)), dim=2)
     v = v.reshape(b, c, h * w)
-    h_ = torch.bmm(v, w_.permute(0, 2, 1)).reshape(b, c, h, w)
-    return x + _conv(h_, W, pre + ".proj_out", padding=0)
+    h_ = torch.bmm(_op(v), _op(w_).permute(0, 2, 1)).reshape(b, c, h, w)
+    return _res(x + _conv(h_, W, pre + ".proj_out", padding=0))
 
 
 def encoder(x, W: Dict[str, torch.Tensor], cfg: VQConfig, pre="encoder"):
     """modules.py:406-433."""
     nres = len(cfg.ch_mult)
     in_mult = (1,) + tuple(cfg.ch_mult)
-    h = _conv(x.float(), W, pre + ".conv_in")
+    h = _res(_conv(x.float(), W, pre + ".conv_in"))
     res = cfg.resolution
     for i in range(nres):
         cin, cout = cfg.ch * in_mult[i], cfg.ch * cfg.ch_mult[i]
@@ -78,7 +114,7 @@ def encoder(x, W: Dict[str, torch.Tensor], cfg: VQConfig, pre="encoder"):
             if res in cfg.attn_resolutions:
                 h = attn_block(h, W, f"{pre}.down.{i}.attn.{j}", cfg.groups)
         if i != nres - 1:
-            h = _conv(F.pad(h, (0, 1, 0, 1)), W, f"{pre}.down.{i}.downsample.conv", stride=2, padding=0)
+            h = _res(_conv(F.pad(h, (0, 1, 0, 1)), W, f"{pre}.down.{i}.downsample.conv", stride=2, padding=0))
             res //= 2
     c = cfg.ch * cfg.ch_mult[-1]
     h = resnet_block(h, W, pre + ".mid.block_1", c, c, cfg.groups)
@@ -92,7 +128,7 @@ def decoder(z, W: Dict[str, torch.Tensor], cfg: VQConfig, pre="decoder"):
     nres = len(cfg.ch_mult)
     c = cfg.ch * cfg.ch_mult[-1]
     res = cfg.resolution // 2 ** (nres - 1)
-    h = _conv(z.float(), W, pre + ".conv_in")
+    h = _res(_conv(z.float(), W, pre + ".conv_in"))
     h = resnet_block(h, W, pre + ".mid.block_1", c, c, cfg.groups)
     h = attn_block(h, W, pre + ".mid.attn_1", cfg.groups)
     h = resnet_block(h, W, pre + ".mid.block_2", c, c, cfg.groups)
@@ -105,7 +141,7 @@ def decoder(z, W: Dict[str, torch.Tensor], cfg: VQConfig, pre="decoder"):
             if res in cfg.attn_resolutions:
                 h = attn_block(h, W, f"{pre}.up.{i}.attn.{j}", cfg.groups)
         if i != 0:
-            h = _conv(F.interpolate(h, scale_factor=2.0, mode="nearest"), W, f"{pre}.up.{i}.upsample.conv")
+            h = _res(_conv(F.interpolate(h, scale_factor=2.0, mode="nearest"), W, f"{pre}.up.{i}.upsample.conv"))
             res *= 2
     return _conv(_swish(_gn(h, W, pre + ".norm_out", cfg.groups)), W, pre + ".conv_out")
 
