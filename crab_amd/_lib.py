@@ -229,6 +229,10 @@ SYMBOLS = {
     "crab_vq_nearest_f32_workspace": (_i64, [_i, _i]),
     "crab_vq_nearest_f32": (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _i, _i, _i, _vp, _i64, _vp, _i64]),
     "crab_groupnorm_p": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _i, _i, _vp, _i64]),
+    "crab_split3": (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _i, _i, _i]),
+    "crab_groupnorm_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _i, _vp, _i64]),
+    "crab_add_bias_f32": (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _i]),
+    "crab_softmax_rows_f32": (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _i, _i, _f]),
     "crab_kaldi_fbank_frames": (_i, [_i]),
     "crab_kaldi_fbank": (_i, [_vp, _vp, _vp, _i64, _i, _i, _f, _f, _vp, _vp, _vp, _f, _f]),
 }

@@ -31,18 +31,22 @@ __global__ void im2col3x3s_kernel(const bf16_t* __restrict__ in, bf16_t* __restr
 constexpr int GN_MAXC = 1024;                          // channels per block pass (4 per thread)
 
 // grid (chunks, B); partial[b][chunk][g] = {sum, sum of squares} over the chunk's pixels and the group's channels
-__global__ __launch_bounds__(256) void groupnorm_stats_kernel(const bf16_t* __restrict__ x, int HW, int C, int G, int rows_per_chunk,
+template <bool XF>
+__global__ __launch_bounds__(256) void groupnorm_stats_kernel(const void* __restrict__ x_, int HW, int C, int G, int rows_per_chunk,
                                                               float* __restrict__ partial) {
     __shared__ float cs[GN_MAXC], cq[GN_MAXC];
     const int tid = threadIdx.x, b = blockIdx.y, ch = blockIdx.x;
     const int p0 = ch * rows_per_chunk, p1 = min(HW, p0 + rows_per_chunk);
     float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
-    const bf16_t* xb = x + (long)b * HW * C;
+    const long base = (long)b * HW * C;
     for (int p = p0; p < p1; ++p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int c = tid + j * 256;
-            if (c < C) { const float v = bf2f(xb[(long)p * C + c]); s[j] += v; q[j] += v * v; }
+            if (c < C) {
+                const float v = XF ? ((const float*)x_)[base + (long)p * C + c] : bf2f(((const bf16_t*)x_)[base + (long)p * C + c]);
+                s[j] += v; q[j] += v * v;
+            }
         }
     }
 #pragma unroll
@@ -280,6 +284,82 @@ __global__ void row_sqnorm_f32_kernel(const float* __restrict__ e, long lde, int
     if (lane == 0) out[n] = s;
 }
 
+// ---- the PRECISE form of the VQGAN encoder (r06): the codebook ids are index work, and an id flips wherever the nearest / second-nearest margin is
+// below the error of the latents - which with bf16 conv operands is ~6e-3 of their scale however the rest is stored (the operand floor,
+// oracle/vqgan_oracle.py emulate("floor"): two flips on the reference fixture).  The encoder in front of the quantiser therefore keeps its
+// activations in fp32 and feeds the MFMA GEMMs SPLIT operands: x = hi + lo with hi = bf16(x), lo = bf16(x - hi) (16 mantissa bits), and
+//     x . w  ~=  x_hi . w_hi  +  x_lo . w_hi  +  x_hi . w_lo          (the dropped lo . lo term is 2^-18 relative)
+// as ONE bf16 GEMM over a 3x longer K: the activation map is written as [hi | lo | hi] channels, the weight as [hi | hi | lo], fp32 accumulation
+// inside the matrix pipe - no new GEMM kernel, 3x the FLOPs of a path that is 0.25 TFLOP per mask.
+//   split3_kernel            fp32 [M, C] -> bf16 [M, 3C] in pattern 0 ([hi | lo | hi], activations) or 1 ([hi | hi | lo], weights / the B operand)
+//   groupnorm_f32_apply      GroupNorm (+ swish) fp32 -> fp32 (statistics as before, from the fp32 map)
+//   add_bias_f32             x[m, c] += b[c] in fp32 (the GEMM epilogue's bias is a bf16 operand)
+//   softmax_rows_f32         the AttnBlock's row softmax, fp32 -> fp32
+__global__ void split3_kernel(const float* __restrict__ x, long ldx, bf16_t* __restrict__ out, long ldo, int M, int C, int Cp, int pattern) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;          // over M * Cp (Cp = C padded to 8: padded channels are zero)
+    if (i >= (long)M * Cp) return;
+    const int c = (int)(i % Cp);
+    const long m = i / Cp;
+    const float v = c < C ? x[m * ldx + c] : 0.f;
+    const bf16_t hi = f2bf(v);
+    const bf16_t lo = f2bf(v - bf2f(hi));
+    bf16_t* o = out + m * ldo + c;
+    o[0] = hi;
+    o[Cp] = pattern ? hi : lo;
+    o[2 * Cp] = pattern ? lo : hi;
+}
+
+__global__ __launch_bounds__(256) void groupnorm_f32_apply_kernel(const float* __restrict__ x, float* __restrict__ out, int HW, int C, int G, int chunks,
+                                                                  const float* __restrict__ partial, const float* __restrict__ weight,
+                                                                  const float* __restrict__ bias, float eps, int swish) {
+    __shared__ float mean_s[64], rstd_s[64];
+    const int tid = threadIdx.x, b = blockIdx.y;
+    if (tid < G) {
+        float a = 0.f, q = 0.f;
+        for (int ch = 0; ch < chunks; ++ch) { const float* o = partial + (((long)b * chunks + ch) * G + tid) * 2; a += o[0]; q += o[1]; }
+        const float n = (float)HW * (float)(C / G);
+        const float m = a / n;
+        const float var = fmaxf(q / n - m * m, 0.f);
+        mean_s[tid] = m; rstd_s[tid] = rsqrtf(var + eps);
+    }
+    __syncthreads();
+    const long i = (long)blockIdx.x * 256 + tid;
+    if (i >= (long)HW * C) return;
+    const int c = (int)(i % C), g = c / (C / G);
+    const long off = (long)b * HW * C + i;
+    float v = (x[off] - mean_s[g]) * rstd_s[g] * weight[c] + bias[c];
+    if (swish) v = v / (1.0f + expf(-v));
+    out[off] = v;
+}
+
+__global__ void add_bias_f32_kernel(float* __restrict__ x, long ldx, const float* __restrict__ b, long M, int C) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * C) return;
+    x[(i / C) * ldx + i % C] += b[i % C];
+}
+
+__global__ __launch_bounds__(256) void softmax_rows_f32_kernel(const float* __restrict__ in, long ldi, float* __restrict__ out, long ldo, int N, float scale) {
+    __shared__ float red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const float* x = in + (long)blockIdx.x * ldi;
+    float mx = -INFINITY;
+    for (int i = tid; i < N; i += 256) mx = fmaxf(mx, x[i] * scale);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if (lane == 0) red[wv] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float s = 0.f;
+    for (int i = tid; i < N; i += 256) s += expf(x[i] * scale - mx);
+    s = wave_sum(s);
+    if (lane == 0) red[wv] = s;
+    __syncthreads();
+    const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
+    float* o = out + (long)blockIdx.x * ldo;
+    for (int i = tid; i < N; i += 256) o[i] = expf(x[i] * scale - mx) * inv;
+}
+
 }  // namespace
 
 #define S_(x) ((hipStream_t)(x))
@@ -319,7 +399,7 @@ extern "C" int crab_groupnorm_p(crab_ctx* ctx, void* stream, const void* x, void
     if (chunks > 64) chunks = 64;
     const int rows = (HW + chunks - 1) / chunks;
     chunks = (HW + rows - 1) / rows;
-    hipLaunchKernelGGL(groupnorm_stats_kernel, dim3(chunks, B), dim3(256), 0, S_(stream), (const bf16_t*)x, HW, C, G, rows, (float*)workspace);
+    hipLaunchKernelGGL((groupnorm_stats_kernel<false>), dim3(chunks, B), dim3(256), 0, S_(stream), x, HW, C, G, rows, (float*)workspace);
     int rc = crab_check_launch(ctx, "groupnorm_stats_kernel");
     if (rc) return rc;
     if (w_fp32)
@@ -398,4 +478,45 @@ extern "C" int crab_vq_nearest_f32(crab_ctx* ctx, void* stream, const float* z, 
     if (rc) return rc;
     hipLaunchKernelGGL(vq_nearest_finish_kernel, dim3(cdiv_(M, 256)), dim3(256), 0, S_(stream), pbest, pidx, M, ns, idx, offset);
     return crab_check_launch(ctx, "vq_nearest_finish_kernel");
+}
+
+// ---- precise (split-operand) encoder entry points, see the kernels' header
+extern "C" int crab_split3(crab_ctx* ctx, void* stream, const float* x, int64_t ldx, void* out, int64_t ldo, int M, int C, int pattern) {
+    if (!ctx) return CRAB_E_INVALID;
+    const int Cp = (C + 7) / 8 * 8;
+    if (!x || !out || M <= 0 || C <= 0 || ldo < 3 * Cp || (pattern != 0 && pattern != 1)) return crab_fail(ctx, CRAB_E_INVALID, "split3: bad argument (ldo >= 3 * round_up(C, 8))");
+    hipLaunchKernelGGL(split3_kernel, dim3(cdiv_((long)M * Cp, 256)), dim3(256), 0, S_(stream), x, (long)ldx, (bf16_t*)out, (long)ldo, M, C, Cp, pattern);
+    return crab_check_launch(ctx, "split3_kernel");
+}
+
+extern "C" int crab_groupnorm_f32(crab_ctx* ctx, void* stream, const float* x, float* out, int B, int HW, int C, int G, float eps, const float* weight,
+                                  const float* bias, int swish, void* workspace, int64_t workspace_bytes) {
+    if (!ctx) return CRAB_E_INVALID;
+    if (!x || !out || !weight || !bias || !workspace || B <= 0 || HW <= 0 || C <= 0 || G <= 0 || G > 64 || C % G || C > GN_MAXC)
+        return crab_fail(ctx, CRAB_E_INVALID, "groupnorm_f32: bad argument (C <= 1024, G <= 64)");
+    if (workspace_bytes < crab_groupnorm_workspace(B, HW, G)) return crab_fail(ctx, CRAB_E_WORKSPACE, "groupnorm_f32: workspace too small");
+    int chunks = (HW + 63) / 64;
+    if (chunks > 64) chunks = 64;
+    const int rows = (HW + chunks - 1) / chunks;
+    chunks = (HW + rows - 1) / rows;
+    hipLaunchKernelGGL((groupnorm_stats_kernel<true>), dim3(chunks, B), dim3(256), 0, S_(stream), (const void*)x, HW, C, G, rows, (float*)workspace);
+    int rc = crab_check_launch(ctx, "groupnorm_stats_kernel<fp32>");
+    if (rc) return rc;
+    hipLaunchKernelGGL(groupnorm_f32_apply_kernel, dim3(cdiv_((long)HW * C, 256), B), dim3(256), 0, S_(stream), x, out, HW, C, G, chunks, (const float*)workspace,
+                       weight, bias, eps, swish);
+    return crab_check_launch(ctx, "groupnorm_f32_apply_kernel");
+}
+
+extern "C" int crab_add_bias_f32(crab_ctx* ctx, void* stream, float* x, int64_t ldx, const float* bias, int64_t M, int C) {
+    if (!ctx) return CRAB_E_INVALID;
+    if (!x || !bias || M <= 0 || C <= 0) return crab_fail(ctx, CRAB_E_INVALID, "add_bias_f32: bad argument");
+    hipLaunchKernelGGL(add_bias_f32_kernel, dim3(cdiv_(M * C, 256)), dim3(256), 0, S_(stream), x, (long)ldx, bias, (long)M, C);
+    return crab_check_launch(ctx, "add_bias_f32_kernel");
+}
+
+extern "C" int crab_softmax_rows_f32(crab_ctx* ctx, void* stream, const float* in, int64_t ldi, float* out, int64_t ldo, int M, int N, float scale) {
+    if (!ctx) return CRAB_E_INVALID;
+    if (!in || !out || M <= 0 || N <= 0) return crab_fail(ctx, CRAB_E_INVALID, "softmax_rows_f32: bad argument");
+    hipLaunchKernelGGL(softmax_rows_f32_kernel, dim3(M), dim3(256), 0, S_(stream), in, (long)ldi, out, (long)ldo, N, scale);
+    return crab_check_launch(ctx, "softmax_rows_f32");
 }

@@ -746,6 +746,46 @@ def row_sqnorm(e: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def split3(x: torch.Tensor, pattern: int) -> torch.Tensor:
+    """fp32 [M, C] -> bf16 [M, 3 * round_up(C, 8)] split operand: x = hi + lo; pattern 0 = [hi | lo | hi] (A side), 1 = [hi | hi | lo] (B side).
+    gemm(split3(x, 0), split3(w, 1)) = x_hi.w_hi + x_lo.w_hi + x_hi.w_lo with fp32 accumulation (crab_split3)."""
+    d = _dev(x)
+    if x.dtype != torch.float32 or x.dim() != 2 or x.stride(1) != 1:
+        raise _lib.CrabHipError("split3: fp32 [M, C] rows expected")
+    M, Cc = x.shape
+    Cp = (Cc + 7) // 8 * 8
+    out = torch.empty((M, 3 * Cp), device=x.device, dtype=BF16)
+    _lib.check(_lib.load().crab_split3(_lib.ctx(d), _stream(), _p(x), x.stride(0), _p(out), out.stride(0), M, Cc, pattern), d)
+    return out
+
+
+def groupnorm_f32(x: torch.Tensor, B: int, HW: int, G: int, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-6, swish: bool = False) -> torch.Tensor:
+    """GroupNorm (+ swish) with fp32 input, output and parameters (the precise VQGAN encoder)."""
+    d = _dev(x)
+    assert x.dtype == weight.dtype == bias.dtype == torch.float32 and x.is_contiguous()
+    out = torch.empty_like(x)
+    need = int(_lib.load().crab_groupnorm_workspace(B, HW, G))
+    ws = torch.empty((need,), device=x.device, dtype=torch.uint8)
+    _lib.check(_lib.load().crab_groupnorm_f32(_lib.ctx(d), _stream(), _p(x), _p(out), B, HW, x.shape[1], G, eps, _p(weight), _p(bias), 1 if swish else 0, _p(ws), need), d)
+    return out
+
+
+def add_bias_f32(x: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    d = _dev(x)
+    assert x.dtype == bias.dtype == torch.float32 and x.stride(1) == 1 and bias.numel() == x.shape[1]
+    _lib.check(_lib.load().crab_add_bias_f32(_lib.ctx(d), _stream(), _p(x), x.stride(0), _p(bias), x.shape[0], x.shape[1]), d)
+    return x
+
+
+def softmax_rows_f32(x: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
+    d = _dev(x)
+    assert x.dtype == torch.float32 and x.stride(1) == 1
+    M, N = x.shape
+    out = torch.empty((M, N), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().crab_softmax_rows_f32(_lib.ctx(d), _stream(), _p(x), x.stride(0), _p(out), out.stride(0), M, N, scale), d)
+    return out
+
+
 def row_sqnorm_f32(e: torch.Tensor) -> torch.Tensor:
     d = _dev(e)
     assert e.dtype == torch.float32 and e.stride(1) == 1

@@ -28,18 +28,26 @@ from .multimodal_encoder import _p
 
 BF16 = torch.bfloat16
 GROUPS = 32
+# the encoder in front of the quantiser runs in its PRECISE form (fp32 activations, split-bf16 MFMA operands: csrc/vq_ops.hip) unless
+# CRAB_VQ_PRECISE=0 (A/B: the bf16-operand form, whose latents sit at the bf16 operand floor and flip ids at sub-floor margins)
+import os as _os
+VQ_PRECISE = _os.environ.get("CRAB_VQ_PRECISE", "1") != "0"
 
 
 class Conv2d(nn.Module):
     """nn.Conv2d parameter container (weight [out,in,k,k], bias [out]); `packed()` is the GEMM operand [out, k*k*in_pad]
     in (ky, kx, ci) order with the input channels zero-padded to a multiple of 8 (16-byte im2col vectors)."""
 
-    def __init__(self, cin: int, cout: int, k: int, device):
+    def __init__(self, cin: int, cout: int, k: int, device, dtype=BF16):
+        """dtype = storage of weight / bias: bf16 (the decoder: plain MFMA operands) or fp32 (the encoder in front of the quantiser, whose
+        precise form splits the fp32 weight into hi + lo bf16 operands; a bf16-rounded weight alone would cost 2^-9 of every product)."""
         super().__init__()
         self.cin, self.cout, self.k = cin, cout, k
-        self.weight = _p(None, device, cout, cin, k, k)
-        self.bias = _p(None, device, cout)
+        self.weight = _p(None, device, cout, cin, k, k, dtype=dtype)
+        self.bias = _p(None, device, cout, dtype=dtype)
         self._pk = None
+        self._pk3 = None
+        self._b16 = None
 
     @property
     def cin_pad(self) -> int:
@@ -48,11 +56,30 @@ class Conv2d(nn.Module):
     def packed(self) -> torch.Tensor:
         key = (self.weight.data_ptr(), self.weight._version)
         if self._pk is None or self._pk[0] != key:
-            w = self.weight.permute(0, 2, 3, 1)                                # [Co, ky, kx, Ci]
+            w = self.weight if self.weight.dtype == BF16 else ops.cast_bf16(self.weight)
+            w = w.permute(0, 2, 3, 1)                                          # [Co, ky, kx, Ci]
             if self.cin_pad != self.cin:
                 w = torch.nn.functional.pad(w, (0, self.cin_pad - self.cin))
             self._pk = (key, w.reshape(self.cout, -1).contiguous())
         return self._pk[1]
+
+    def bias16(self) -> torch.Tensor:
+        """the bf16 GEMM epilogue's bias operand"""
+        if self.bias.dtype == BF16:
+            return self.bias
+        key = (self.bias.data_ptr(), self.bias._version)
+        if self._b16 is None or self._b16[0] != key:
+            self._b16 = (key, ops.cast_bf16(self.bias))
+        return self._b16[1]
+
+    def packed3(self) -> torch.Tensor:
+        """The split operand of the precise form: [Co, k*k * 3*cin_pad], per tap [w_hi | w_hi | w_lo] (ops.split3 pattern 1) against the
+        activation map's [x_hi | x_lo | x_hi]."""
+        key = (self.weight.data_ptr(), self.weight._version)
+        if self._pk3 is None or self._pk3[0] != key:
+            w = self.weight.float().permute(0, 2, 3, 1).reshape(self.cout * self.k * self.k, self.cin).contiguous()      # layout glue
+            self._pk3 = (key, ops.split3(w, 1).reshape(self.cout, -1))
+        return self._pk3[1]
 
 
 class GroupNorm(nn.Module):
@@ -63,29 +90,37 @@ class GroupNorm(nn.Module):
         self.bias = _p(None, device, c, dtype=dt)
 
     def __call__(self, x: torch.Tensor, B: int, HW: int, swish: bool) -> torch.Tensor:
+        if x.dtype == torch.float32:                          # the precise encoder: fp32 in / out / parameters
+            return ops.groupnorm_f32(x, B, HW, GROUPS, self.weight.float(), self.bias.float(), 1e-6, swish)
         return ops.groupnorm(x, B, HW, GROUPS, self.weight, self.bias, 1e-6, swish)
 
 
 def _conv3x3(x: torch.Tensor, conv: Conv2d, B: int, h: int, w: int, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
-    return ops.gemm(ops.im2col3x3(x, B, h, w), conv.packed(), bias=conv.bias, residual=residual)
+    if x.dtype == torch.float32:                              # precise form: fp32 map -> split operand -> MFMA GEMM over 3x K -> fp32 (+ fp32 residual)
+        y = ops.gemm(ops.im2col3x3(ops.split3(x, 0), B, h, w), conv.packed3(), residual=residual, out_fp32=True)
+        return ops.add_bias_f32(y, conv.bias.float())
+    return ops.gemm(ops.im2col3x3(x, B, h, w), conv.packed(), bias=conv.bias16(), residual=residual)
 
 
 def _conv1x1(x: torch.Tensor, conv: Conv2d, residual: Optional[torch.Tensor] = None, out_fp32: bool = False) -> torch.Tensor:
-    return ops.gemm(x, conv.packed(), bias=conv.bias, residual=residual, out_fp32=out_fp32)
+    if x.dtype == torch.float32:
+        y = ops.gemm(ops.split3(x, 0), conv.packed3(), residual=residual, out_fp32=True)
+        return ops.add_bias_f32(y, conv.bias.float())
+    return ops.gemm(x, conv.packed(), bias=conv.bias16(), residual=residual, out_fp32=out_fp32)
 
 
 class ResnetBlock(nn.Module):
     """modules.py:78-137 (no timestep embedding: temb_channels = 0 in Encoder / Decoder)."""
 
-    def __init__(self, cin: int, cout: int, device):
+    def __init__(self, cin: int, cout: int, device, dtype=BF16):
         super().__init__()
         self.in_channels, self.out_channels = cin, cout
         self.norm1 = GroupNorm(cin, device)
-        self.conv1 = Conv2d(cin, cout, 3, device)
+        self.conv1 = Conv2d(cin, cout, 3, device, dtype)
         self.norm2 = GroupNorm(cout, device)
-        self.conv2 = Conv2d(cout, cout, 3, device)
+        self.conv2 = Conv2d(cout, cout, 3, device, dtype)
         if cin != cout:
-            self.nin_shortcut = Conv2d(cin, cout, 1, device)
+            self.nin_shortcut = Conv2d(cin, cout, 1, device, dtype)
 
     def forward(self, x, B, h, w):
         t = _conv3x3(self.norm1(x, B, h * w, True), self.conv1, B, h, w)
@@ -97,13 +132,32 @@ class ResnetBlock(nn.Module):
 class AttnBlock(nn.Module):
     """modules.py:140-192."""
 
-    def __init__(self, c: int, device):
+    def __init__(self, c: int, device, dtype=BF16):
         super().__init__()
         self.in_channels = c
         self.norm = GroupNorm(c, device)
-        self.q, self.k, self.v, self.proj_out = (Conv2d(c, c, 1, device) for _ in range(4))
+        self.q, self.k, self.v, self.proj_out = (Conv2d(c, c, 1, device, dtype) for _ in range(4))
+
+    def _forward_precise(self, x, B, h, w):
+        """The same block on fp32 maps with split operands: scores, V^T and P.V are MFMA GEMMs over a tripled K, the softmax stays in fp32."""
+        C, HW = self.in_channels, h * w
+        hn = self.norm(x, B, HW, False)
+        q = _conv1x1(hn, self.q)
+        k = _conv1x1(hn, self.k)
+        wv3 = ops.split3(self.v.weight.float().reshape(C, C), 0)                  # V^T = Wv . hn^T: the weight is the A operand here
+        o = torch.empty((B * HW, C), device=x.device, dtype=torch.float32)
+        for b in range(B):
+            sl = slice(b * HW, (b + 1) * HW)
+            scores = ops.gemm(ops.split3(q[sl], 0), ops.split3(k[sl], 1), out_fp32=True)
+            p = ops.softmax_rows_f32(scores, float(int(C) ** (-0.5)))
+            vt = ops.gemm(wv3, ops.split3(hn[sl], 1), out_fp32=True)                # [C, HW] (bias added after P.V: rows of P sum to one)
+            ops.gemm(ops.split3(p, 0), ops.split3(vt, 1), out=o[sl])
+        ops.add_bias_f32(o, self.v.bias.float())
+        return _conv1x1(o, self.proj_out, residual=x)
 
     def forward(self, x, B, h, w):
+        if x.dtype == torch.float32:
+            return self._forward_precise(x, B, h, w)
         C, HW = self.in_channels, h * w
         hn = self.norm(x, B, HW, False)
         q = _conv1x1(hn, self.q)
@@ -115,19 +169,22 @@ class AttnBlock(nn.Module):
             scores = ops.gemm(q[sl], k[sl], out_fp32=True)                        # [HW, HW] = q . k^T
             p = ops.softmax_rows(scores, float(int(C) ** (-0.5)))
             vt = ops.gemm(wv, hn[sl])                                             # V^T [C, HW] (bias added after P.V)
-            ops.gemm(p, vt, bias=self.v.bias, out=o[sl])
+            ops.gemm(p, vt, bias=self.v.bias16(), out=o[sl])
         return _conv1x1(o, self.proj_out, residual=x)
 
 
 class Downsample(nn.Module):
-    def __init__(self, c: int, device):
+    def __init__(self, c: int, device, dtype=BF16):
         super().__init__()
-        self.conv = Conv2d(c, c, 3, device)
+        self.conv = Conv2d(c, c, 3, device, dtype)
 
     def forward(self, x, B, h, w):
         oh, ow = (h + 1 - 3) // 2 + 1, (w + 1 - 3) // 2 + 1                         # F.pad (0,1,0,1) then k3 s2 p0
+        if x.dtype == torch.float32:
+            cols = ops.im2col3x3_strided(ops.split3(x, 0), B, h, w, 2, 0, 0, oh, ow)
+            return ops.add_bias_f32(ops.gemm(cols, self.conv.packed3(), out_fp32=True), self.conv.bias.float()), oh, ow
         cols = ops.im2col3x3_strided(x, B, h, w, 2, 0, 0, oh, ow)
-        return ops.gemm(cols, self.conv.packed(), bias=self.conv.bias), oh, ow
+        return ops.gemm(cols, self.conv.packed(), bias=self.conv.bias16()), oh, ow
 
 
 class Upsample(nn.Module):
@@ -147,11 +204,11 @@ class _Level(nn.Module):
 
 
 class _Mid(nn.Module):
-    def __init__(self, c: int, device):
+    def __init__(self, c: int, device, dtype=BF16):
         super().__init__()
-        self.block_1 = ResnetBlock(c, c, device)
-        self.attn_1 = AttnBlock(c, device)
-        self.block_2 = ResnetBlock(c, c, device)
+        self.block_1 = ResnetBlock(c, c, device, dtype)
+        self.attn_1 = AttnBlock(c, device, dtype)
+        self.block_2 = ResnetBlock(c, c, device, dtype)
 
     def forward(self, x, B, h, w):
         return self.block_2(self.attn_1(self.block_1(x, B, h, w), B, h, w), B, h, w)
@@ -176,7 +233,9 @@ class Encoder(nn.Module):
     def __init__(self, *, ch, ch_mult, num_res_blocks, attn_resolutions, in_channels, resolution, z_channels, device, **_ignore):
         super().__init__()
         self.ch, self.num_resolutions, self.num_res_blocks, self.resolution = ch, len(ch_mult), num_res_blocks, resolution
-        self.conv_in = Conv2d(in_channels, ch, 3, device)
+        dt = torch.float32 if VQ_PRECISE else BF16          # the encoder's weights stay as the checkpoint holds them when the precise form runs
+        self.precise = VQ_PRECISE
+        self.conv_in = Conv2d(in_channels, ch, 3, device, dt)
         in_mult = (1,) + tuple(ch_mult)
         self.down = nn.ModuleList()
         curr = resolution
@@ -185,21 +244,26 @@ class Encoder(nn.Module):
             lvl = _Level()
             block_in, block_out = ch * in_mult[i], ch * ch_mult[i]
             for _ in range(num_res_blocks):
-                lvl.block.append(ResnetBlock(block_in, block_out, device))
+                lvl.block.append(ResnetBlock(block_in, block_out, device, dt))
                 block_in = block_out
                 if curr in attn_resolutions:
-                    lvl.attn.append(AttnBlock(block_in, device))
+                    lvl.attn.append(AttnBlock(block_in, device, dt))
             if i != self.num_resolutions - 1:
-                lvl.downsample = Downsample(block_in, device)
+                lvl.downsample = Downsample(block_in, device, dt)
                 curr //= 2
             self.down.append(lvl)
-        self.mid = _Mid(block_in, device)
+        self.mid = _Mid(block_in, device, dt)
         self.norm_out = GroupNorm(block_in, device)
-        self.conv_out = Conv2d(block_in, z_channels, 3, device)
+        self.conv_out = Conv2d(block_in, z_channels, 3, device, dt)
 
     def forward(self, img: torch.Tensor) -> Tuple[torch.Tensor, int, int]:
+        """-> (conv_out map [B*h*w, z_channels], h, w): fp32 in the precise form (every step below then takes its fp32 branch), bf16 otherwise."""
         B, _, h, w = img.shape
-        x = _conv3x3(_to_tokens(img, self.conv_in.cin_pad), self.conv_in, B, h, w)
+        if self.precise:
+            x0 = img.to(torch.float32).permute(0, 2, 3, 1).reshape(B * h * w, -1).contiguous()       # token-major fp32 (layout glue)
+        else:
+            x0 = _to_tokens(img, self.conv_in.cin_pad)
+        x = _conv3x3(x0, self.conv_in, B, h, w)
         for i, lvl in enumerate(self.down):
             for j, blk in enumerate(lvl.block):
                 x = blk(x, B, h, w)
@@ -296,7 +360,7 @@ class VQModel(nn.Module):
         self.encoder = Encoder(**ddconfig, device=device)
         self.decoder = Decoder(**ddconfig, device=device)
         self.quantize = VectorQuantizer(n_embed, embed_dim, device)
-        self.quant_conv = Conv2d(ddconfig["z_channels"], embed_dim, 1, device)
+        self.quant_conv = Conv2d(ddconfig["z_channels"], embed_dim, 1, device, torch.float32 if VQ_PRECISE else BF16)
         self.post_quant_conv = Conv2d(embed_dim, ddconfig["z_channels"], 1, device)
         if ckpt_path is not None:
             self.load_state_dict(torch.load(ckpt_path, map_location="cpu"), strict=False)     # vqgan.py:42-52

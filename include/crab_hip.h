@@ -581,6 +581,18 @@ int crab_vq_nearest_f32(crab_ctx* ctx, void* stream, const float* z, int64_t ldz
                         int64_t* idx, int64_t offset, void* workspace, int64_t workspace_bytes);
 int crab_groupnorm_p(crab_ctx* ctx, void* stream, const void* x, void* out, int B, int HW, int C, int G, float eps, const void* weight, const void* bias,
                      int w_fp32, int swish, void* workspace, int64_t workspace_bytes);
+/* r06 (ABI 12): the PRECISE form of the encoder in front of the quantiser (MaskEncoder.encode_mask; vqgan.py:54-63, modules.py:342-433).  Codebook
+ * ids are index work and flip wherever the latents' error exceeds the nearest / second-nearest margin; bf16 conv operands alone cost ~6e-3 of the
+ * latents' scale (the operand floor).  The precise form keeps activations in fp32 and gives the MFMA GEMM split operands x = hi + lo:
+ *   crab_split3        fp32 [M, C] -> bf16 [M, 3 * round_up(C, 8)]: pattern 0 = [hi | lo | hi] (the A side), 1 = [hi | hi | lo] (the B side), so that
+ *                      crab_gemm_bf16 over the tripled K forms x_hi.w_hi + x_lo.w_hi + x_hi.w_lo with fp32 accumulation (~2^-17 relative);
+ *   crab_groupnorm_f32 GroupNorm(G, C, eps) (+ swish), fp32 in / out / parameters;  crab_add_bias_f32: x[m, c] += bias[c];
+ *   crab_softmax_rows_f32: the AttnBlock's row softmax (modules.py:178-181), fp32 in / out. */
+int crab_split3(crab_ctx* ctx, void* stream, const float* x, int64_t ldx, void* out, int64_t ldo, int M, int C, int pattern);
+int crab_groupnorm_f32(crab_ctx* ctx, void* stream, const float* x, float* out, int B, int HW, int C, int G, float eps, const float* weight,
+                       const float* bias, int swish, void* workspace, int64_t workspace_bytes);
+int crab_add_bias_f32(crab_ctx* ctx, void* stream, float* x, int64_t ldx, const float* bias, int64_t M, int C);
+int crab_softmax_rows_f32(crab_ctx* ctx, void* stream, const float* in, int64_t ldi, float* out, int64_t ldo, int M, int N, float scale);
 
 /* ---------------------------------------------------------------------------------------------
  * Multi-GPU: per-clip sharding, one process per GPU, full weight replica; the ONLY exchange is a gather of fixed-size result
