@@ -6,7 +6,8 @@ transformers-5.15 hidden-state recorder carry process-wide state: an encoder pas
 generator stubs decord / librosa / cv2 - so generators are only order-independent when they do not share a process).
 
 kind "ref":    a golden_* function of make_golden.py that imports /root/reference;
-kind "script": a stand-alone script in this directory (its own docstring says what it pins and why it is separate)."""
+kind "script": a stand-alone script in this directory (its own docstring says what it pins and why it is separate);
+kind "script_optional": the same, but its fixture may be absent (the script exits 3 where it cannot run)."""
 
 GENERATORS = {
     # name: (kind, entry, [fixtures it writes])
@@ -37,11 +38,14 @@ GENERATORS = {
     "ckpt_manifest": ("script", "make_ckpt_manifest.py", ["ckpt_manifest"]),
     "fbank_hf": ("script", "make_fbank_hf.py", ["fbank_hf"]),
     "fbank_kat": ("script", "make_fbank_kat.py", ["fbank_kat"]),
+    # needs torchaudio (absent in the build container): writes its fixture only where `import torchaudio` works, exit code 3 otherwise
+    "fbank_torchaudio": ("script_optional", "make_fbank_torchaudio.py", ["fbank_torchaudio"]),
 }
 
 # `make_golden.py fullwidth` = the six full-width generators
 GROUPS = {"fullwidth": ["llama_layer_wide", "qwen_layer_wide", "clip_wide", "beats_wide", "projectors_wide", "seg_wide"]}
 
 
-def fixtures():
-    return sorted(f for _, _, fs in GENERATORS.values() for f in fs)
+def fixtures(optional: bool = False):
+    """Fixtures every checkout must hold (optional=True: also those that only some boxes can generate)."""
+    return sorted(f for kind, _, fs in GENERATORS.values() for f in fs if optional or kind != "script_optional")

@@ -57,6 +57,32 @@ def test_bench_strong_scaling_with_a_clip_count_the_world_does_not_divide():
 
 
 @pytest.mark.gpu
+def test_bench_gpus_8_strong_uneven_split_eight_ranks_on_one_device():
+    """The node-sized launch (BASELINE configs[3] = 8 x MI355X) rehearsed on one device, so that the first real 8-GPU run is not also the first
+    8-rank run: `python bench.py --gpus 8` self-spawns eight ranks (free rendezvous port on 127.0.0.1, one process each, all mapped to cuda:0 by
+    the rehearsal hook: 8 weight replicas = 115 GB of the 288, gloo in place of RCCL), the host threads are divided by the world size, `--strong`
+    splits 11 clips 2 2 2 1 1 1 1 1 (contiguous blocks, the first 11 % 8 ranks hold one more), the padded gather delivers every clip to rank 0
+    exactly once in clip order, all_gather_object collects the eight per-rank records, value = 11 clips / max-over-ranks time."""
+    env = dict(os.environ, CRAB_BENCH_SINGLE_DEVICE="1", CRAB_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--clips", "11", "--strong", "--new-tokens", "4", "--steps", "1", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-operating-points"], env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    c = j["config"]
+    assert j["n_gpus"] == 8 and c["world_size_observed"] == 8 and j["scaling"] == "strong"
+    assert c["total_clips_per_step"] == 11 and c["gathered_clips"] == 11 and c["clips_per_gpu_per_step"] == [2, 2, 2, 1, 1, 1, 1, 1]
+    assert [ri["rank"] for ri in j["ranks"]] == list(range(8)) and all(ri["build_s"] > 0 and ri["decode_groups"] == 1 for ri in j["ranks"])
+    assert c["host_threads_per_rank"] == max(1, (os.cpu_count() or 8) // 8)
+    assert len(j["rank_ms_per_step"]) == 8 and max(j["rank_ms_per_step"]) == pytest.approx(j["ms_per_step"], rel=1e-3)
+    assert abs(j["value"] - 11 / (j["ms_per_step"] * 1e-3)) < 1e-2 * j["value"]
+    assert all(f"[bench rank {k}/8]" in r.stderr for k in range(8)), "every rank reports its build on stderr"
+
+
+@pytest.mark.gpu
 def test_bench_runs_its_collectives_on_rccl_with_one_rank():
     """CRAB_BENCH_FORCE_DIST=1: `python bench.py --gpus 1` makes the `nccl` (= RCCL) process group for its single rank and takes every
     distributed branch of the line's path on it - init_process_group(device_id=...), barrier, the all_reduce(MIN) of the batch choice, the padded

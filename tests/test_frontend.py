@@ -201,3 +201,40 @@ def test_fbank_device_matches_transformers_kaldi_compatible_fbank():
         record_parity(f"kaldi fbank vs transformers' Kaldi-compatible fbank, {name}: max |dlog| over bins within e^-12 of the frame max",
                       float(np.abs(fb - ref)[strong].max()) if strong.any() else 0.0, 1.0, 2e-3)
         assert ex <= 0.0, (name, ex)
+
+
+# ------------------------------------------------------------------ kaldi fbank vs the REFERENCE'S OWN CALL (tests/golden/make_fbank_torchaudio.py)
+def _ta():
+    """tests/golden/fbank_torchaudio.npz = the reference's dataset/audio_processor.py preprocess() (torchaudio.compliance.kaldi.fbank + the AudioSet
+    normalisation) on the nine edge-case waveforms.  Only a box with torchaudio can write it (the build container cannot): until then these two
+    tests skip and the fbank stays pinned by the Kaldi-spec vectors and transformers' filter bank above."""
+    import json
+    path = os.path.join(os.path.dirname(__file__), "golden", "fbank_torchaudio.npz")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/fbank_torchaudio.npz absent: `python tests/golden/make_fbank_torchaudio.py` writes it on a box where torchaudio imports")
+    z = np.load(path)
+    return json.loads(bytes(z["meta"]).decode()), z
+
+
+def test_fbank_oracle_matches_reference_torchaudio_call():
+    meta, z = _ta()
+    _, kz = _kat()
+    for name in meta["names"]:
+        ref = z["norm_" + name].astype(np.float64) * (2 * meta["fbank_std"]) + meta["fbank_mean"]          # back to log-mel energies
+        fb = FO.kaldi_fbank(kz["wave_" + name].astype(np.float32) * np.float32(2 ** 15))
+        assert fb.shape == ref.shape, name
+        assert _fbank_agrees(fb, ref) <= 0.0, (name, _fbank_agrees(fb, ref))
+        got = FO.audio_preprocess(kz["wave_" + name][None].astype(np.float32))[0]
+        assert np.abs(got - z["norm_" + name]).max() < 2e-3, name
+
+
+@pytest.mark.gpu
+def test_fbank_device_matches_reference_torchaudio_call():
+    from crab_amd import frontend
+    meta, z = _ta()
+    _, kz = _kat()
+    for name in meta["names"]:
+        ref = z["norm_" + name].astype(np.float64) * (2 * meta["fbank_std"]) + meta["fbank_mean"]
+        fb = frontend.kaldi_fbank(torch.from_numpy(kz["wave_" + name]).cuda(), in_scale=float(2 ** 15))[0].cpu().numpy()
+        assert fb.shape == ref.shape, name
+        assert _fbank_agrees(fb, ref, rel=2e-3, abs_of_frame_max=1e-8) <= 0.0, name
