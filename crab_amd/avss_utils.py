@@ -28,13 +28,13 @@ _TH: Dict[Tuple[int, int], torch.Tensor] = {}
 
 
 def fmeasure_thresholds(pr_num: int = 255) -> np.ndarray:
-    """The thresholds of _eval_pr, `torch.linspace(0, 1 - 1e-10, num)` in fp32 (avss_utils.py:56): 1 - 1e-10 rounds to 1.0f, so th_i = i / (num - 1),
-    here rounded once from fp64.  (torch's own CPU kernel forms them as a vectorised base + i * step, whose last bit depends on the vector width
-    of the host it runs on: 1 ulp from these on 10 of the 255 entries on the host that made tests/golden/seg_metrics.npz.)"""
-    end = float(np.float32(1 - 1e-10))
-    if pr_num == 1:
-        return np.zeros((1,), np.float32)
-    return (np.arange(pr_num, dtype=np.float64) * (end / (pr_num - 1))).astype(np.float32)
+    """The thresholds of _eval_pr: the reference's own expression, `torch.linspace(0, 1 - 1e-10, num)` (avss_utils.py:56), evaluated by the same
+    library on the host (fp32; 1 - 1e-10 rounds to 1.0f) and uploaded once per device.  ADVICE r05: a table rounded from fp64 (r05) differed from
+    torch's tensor by one ulp on 10 of the 255 entries - a pixel whose sigmoid falls into such a gap would flip one `>=` count.  What remains: the
+    kernel's sigmoid is 1 / (1 + exp(-x)) with the device's expf where the reference calls torch.sigmoid on its host (both fp32, each within
+    an ulp or two of the true value), so a pixel whose sigmoid lies within ~2 ulp of a threshold may be counted differently; on the
+    reference-generated fixture every count is equal (tests/test_seg_metrics.py)."""
+    return torch.linspace(0, 1 - 1e-10, pr_num).numpy().astype(np.float32)
 
 
 def _thresholds(device: torch.device, pr_num: int) -> torch.Tensor:

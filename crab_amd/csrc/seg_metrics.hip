@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void class_areas_kernel(const float* __restric
 #pragma unroll
                 for (int k = 0; k < PX; ++k) {
                     const float x = PX == 1 ? ((const float*)&v[j])[0] : v[j][k];
-                    if (x > best[k]) { best[k] = x; bi[k] = c + j; }
+                    if (x > best[k] || (x != x && best[k] == best[k])) { best[k] = x; bi[k] = c + j; }      // (a NaN is the maximum, as for torch.argmax: the first one wins)
                 }
         }
         for (; c < C; ++c) {
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void class_areas_kernel(const float* __restric
 #pragma unroll
             for (int k = 0; k < PX; ++k) {
                 const float x = PX == 1 ? ((const float*)&v)[0] : v[k];
-                if (x > best[k]) { best[k] = x; bi[k] = c; }
+                if (x > best[k] || (x != x && best[k] == best[k])) { best[k] = x; bi[k] = c; }
             }
         }
 #pragma unroll

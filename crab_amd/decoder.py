@@ -443,6 +443,10 @@ class GenerationEngine:
         contig = kc.is_contiguous() and vc.is_contiguous()
         # the native sequencer takes a prefill's rotary positions / first visible keys as well (crab_llama_io.pos_ids / kv_start); a general key
         # mask and the masked one-token step of forward() stay on the per-launch sequence below
+        for nm, t in (("kv_start", kv_start), ("row_off", row_off)):
+            # the kernels read these as int32 [B] through a raw pointer: an int64 or strided tensor would be misread silently
+            if t is not None and (t.dtype != torch.int32 or t.dim() != 1 or t.shape[0] < B or not t.is_contiguous() or t.device != x.device):
+                raise ValueError(f"{nm} must be a contiguous int32 [B] tensor on {x.device}, got {t.dtype} {tuple(t.shape)} on {t.device}")
         native_ok = key_mask is None and (not masked or (vt is not None and pos_dev is None and
                                                          (pos_ids is None or (pos_ids.dtype == torch.int32 and pos_ids.stride(1) == 1))))
         last_rows = bool(last_rows) and vt is not None and S > 1 and key_mask is None and pos_dev is None
@@ -738,11 +742,32 @@ class GenerationEngine:
         ops.advance(st.pos_dev, st.step_dev)           # slot: Smax-1 -> Smax, step: 0 -> 1
         return st
 
+    def _retry_after_eviction(self, fn, *a, **k):
+        """memory_budget() counts the KV caches of stale slots (left by an earlier generate_many / decode_streams > 1) as reclaimable, but
+        only a KV allocation evicts them (_evict_for); a later allocation planned against that budget - prefill workspace, logits, the merged
+        ragged `emb` - could run out of memory beside them.  One retry: on an out-of-memory error every slot, decode state, graph and workspace is
+        dropped (the call rebuilds what it needs) and the call runs once more; a second failure is the caller's."""
+        try:
+            return fn(*a, **k)
+        except torch.cuda.OutOfMemoryError:
+            if not (self._kv or self._dec or self._ws):
+                raise
+            self.invalidate()
+            torch.cuda.empty_cache()
+            return fn(*a, **k)
+
     @torch.no_grad()
     def generate(self, embeds: torch.Tensor, max_new_tokens: int, eos_token_id: Optional[int] = None,
                  pad_token_id: Optional[int] = None, min_new_tokens: int = 0, prefill_chunk: int = 0, use_graph: bool = True,
                  return_step_logits: bool = False, return_hidden: bool = False, decode_streams: int = 1,
                  return_first_logits: bool = False, sampling=None):
+        return self._retry_after_eviction(self._generate, embeds, max_new_tokens, eos_token_id, pad_token_id, min_new_tokens, prefill_chunk, use_graph,
+                                          return_step_logits, return_hidden, decode_streams, return_first_logits, sampling)
+
+    def _generate(self, embeds: torch.Tensor, max_new_tokens: int, eos_token_id: Optional[int] = None,
+                  pad_token_id: Optional[int] = None, min_new_tokens: int = 0, prefill_chunk: int = 0, use_graph: bool = True,
+                  return_step_logits: bool = False, return_hidden: bool = False, decode_streams: int = 1,
+                  return_first_logits: bool = False, sampling=None):
         """Greedy generation from inputs_embeds only, as UnifiedForCausalLM.generate drives HF generate
         (unified_llama.py:262-267): positions 0..S-1 (left pads attended), returns ONLY new ids.
 
@@ -849,6 +874,13 @@ class GenerationEngine:
                       pad_token_id: Optional[int] = None, min_new_tokens: int = 0, use_graph: bool = True, sampling=None,
                       return_first_logits: bool = False, coalesce: bool = False, max_rows: Optional[int] = None,
                       return_step_logits: bool = False, return_hidden: bool = False):
+        return self._retry_after_eviction(self._generate_many, embeds_list, max_new_tokens, eos_token_id, pad_token_id, min_new_tokens, use_graph, sampling,
+                                          return_first_logits, coalesce, max_rows, return_step_logits, return_hidden)
+
+    def _generate_many(self, embeds_list: List[torch.Tensor], max_new_tokens: int, eos_token_id: Optional[int] = None,
+                       pad_token_id: Optional[int] = None, min_new_tokens: int = 0, use_graph: bool = True, sampling=None,
+                       return_first_logits: bool = False, coalesce: bool = False, max_rows: Optional[int] = None,
+                       return_step_logits: bool = False, return_hidden: bool = False):
         """Several INDEPENDENT batches in flight: each element of `embeds_list` ([B_i, S_i, D], its own prompt length and left padding, i.e.
         exactly what one generate() call of the reference's eval loop gets) becomes one decode group with its own KV cache, decode state
         and captured HIP graph; the groups are prefilled one after the other and their decode steps are replayed on separate HIP streams.

@@ -511,7 +511,9 @@ int crab_mask_labels(crab_ctx* ctx, void* stream, const float* pred, int C, int6
  *      ysum [N][2] int32 = {gt pixels, gt pixels outside {0, 1}}, fscore [N][T] = (1 + beta2) P R / (beta2 P + R) with NaN -> 0,
  *      score [T] = mean of fscore over the images whose gt is not empty (image order), best [2] = {max_i score[i], images counted}.
  *  crab_miou_fscore  : replaces calc_color_miou_fscore / _batch_miou_fscore (:379-435).  pred [BF, C, hw] fp32 class logits (argmax of the
- *      logits = argmax of their softmax, first maximum), target [BF, hw] int64 class ids (ids outside [0, C) are counted nowhere; a negative id
+ *      logits, first maximum, a NaN counting as the maximum like torch.argmax; the reference takes the argmax of softmax(pred, dim = 1), which is the
+ *      same index except where two DISTINCT logits round to the same fp32 probability - then the reference keeps the first of them and this kernel the
+ *      larger one: a tie of the probabilities at the top needs logits within ~6e-8 relative of each other), target [BF, hw] int64 class ids (ids outside [0, C) are counted nowhere; a negative id
  *      also removes the pixel's prediction, as the reference's `predict * (target > 0)` does after its +1 shift), C <= 1024.
  *      areas [BF][3][C] int32 = {TP, TP + FP, TP + FN} (the three torch.histc calls), iou_fc [BF][C] = TP / (2.22e-16 + union),
  *      ious / fscores / cls_count [C] = the per-class sums over the frames in frame order, vid_miou [BF] = sum_c iou / #{iou != 0}. */

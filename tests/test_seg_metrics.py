@@ -66,12 +66,12 @@ def test_oracle_fmeasure_matches_the_reference_fixture(table):
 def test_threshold_table_is_within_one_ulp_of_torch_linspace():
     from crab_amd.avss_utils import fmeasure_thresholds
     A = _fx()
-    own = fmeasure_thresholds(255)
-    assert np.array_equal(own, MO.thresholds(255))
+    own = fmeasure_thresholds(255)                                                         # r06: torch.linspace itself, the reference's own tensor on this host
+    assert np.array_equal(own, torch.linspace(0, 1 - 1e-10, 255).numpy())
     assert own[0] == 0.0 and own[-1] == 1.0 and np.all(np.diff(own) > 0)
     recorded = A["thlist"]                                                                 # torch.linspace(0, 1 - 1e-10, 255) on the fixture's host
-    ulp = np.spacing(np.maximum(own, recorded))
-    assert np.all(np.abs(own - recorded) <= ulp)
+    for other in (recorded, MO.thresholds(255)):                                           # another host's vector width / the fp64-rounded table: <= 1 ulp
+        assert np.all(np.abs(own - other) <= np.spacing(np.maximum(own, other)))
     assert np.array_equal(fmeasure_thresholds(1), np.zeros(1, np.float32))
 
 
