@@ -83,6 +83,44 @@ def rows(hip=None):
             logits, _, _ = O.decoder_forward(torch.cat([emb, O._r(toks, e)], 1), W, cfg.decoder, emulate=e)
             return logits[:, -n:]
         three(f"{fx}: end to end, per-step logits of {n} teacher-forced greedy steps", gen, W)
+    # ---- forward() under masks (unified_llama.py:129-160 fixtures): logits of the defined rows + the one-token shortcut on the kept cache
+    meta, A = load_fixture("forward_masked_tiny_llama")
+    W = O.strip_peft_prefix(weights_from_table(meta))
+    dcfg = _full_cfg(meta).decoder
+    valid = A["mask_bs2"].bool()
+
+    def masked(W, e):
+        logits, hn, cache = O.decoder_forward(A["embeds_bs2"].to(BF).float(), W, dcfg, positions=A["pos_bs2"], attention_mask=A["mask_bs2"], emulate=e)
+        tok = W["model.embed_tokens.weight"].float()[A["step_tok"]][:, None]
+        l2, _, _ = O.decoder_forward(O._r(tok, e), W, dcfg, cache, positions=A["step_pos"], attention_mask=A["step_mask"], emulate=e)
+        return [logits[valid], hn[valid], l2]
+    three("forward_masked_tiny_llama: left-pad mask + position_ids (valid logits | post-norm hidden | decode-shortcut logits)", masked, W)
+    meta, A = load_fixture("forward_holes_tiny_llama")
+    W = O.strip_peft_prefix(weights_from_table(meta))
+    hcfg = O.DecoderConfig(**meta["dec"])
+    seen = A["mask"].cumsum(-1) > 0
+
+    def holes(W, e):
+        logits, hn, cache = O.decoder_forward(A["embeds"].to(BF).float(), W, hcfg, attention_mask=A["mask"], emulate=e)
+        lp, _, _ = O.decoder_forward(A["embeds"].to(BF).float(), W, hcfg, positions=A["pos"], attention_mask=A["mask"], emulate=e)
+        tok = W["model.embed_tokens.weight"].float()[A["step_tok"]][:, None]
+        l2, _, _ = O.decoder_forward(O._r(tok, e), W, hcfg, cache, positions=A["step_pos"], attention_mask=A["step_mask"], emulate=e)
+        return [logits[seen], hn[seen], lp[seen], l2]
+    three("forward_holes_tiny_llama: mask with interior holes (logits | hidden | logits under cumsum positions | decode-shortcut logits)", holes, W)
+    # ---- one layer of the reference's vendored modeling files: prefill + cached decode step (layer output = the residual stream)
+    for fx in ("llama_ops", "qwen_ops"):
+        meta, A = load_fixture(fx)
+        W = weights_from_table(meta)
+        c = dict(meta["cfg"])
+        lcfg = O.DecoderConfig(**{**c, "num_hidden_layers": 1, "vocab_size": 320})
+        S = A["layer_x"].shape[1]
+
+        def layer(W, e, A=A, lcfg=lcfg, S=S):
+            cache = O.KVCache()
+            y = O.decoder_layer(A["layer_x"].to(BF).float(), W, 0, lcfg, cache, torch.arange(S)[None], emulate=e)
+            y1 = O.decoder_layer(A["layer_x1"].to(BF).float(), W, 0, lcfg, cache, torch.tensor([[S]]), emulate=e)
+            return [y, y1]
+        three(f"{fx}: one hyper-LoRA decoder layer (prefill output | cached decode-step output)", layer, W)
     return out
 
 

@@ -385,6 +385,54 @@ def golden_id_stats(me, n_clips=24, new=12):
     save("id_stats_tiny_llama", meta, ids=ids_out, logits=logits_out, margin=margin)
 
 
+def golden_sharp(me, n_keep=8, new=8, min_margin=0.15, n_cand=800):
+    """The ids clause of north_star on fixtures whose margins make it decidable: the tiny full model of `full_tiny_llama` (same
+    seeded weights) on the first `n_keep` clips of indices 400.. whose reference top-2 logit margin is >= `min_margin` on EVERY one of the
+    `new` greedy steps - 0.15 on a logit scale of ~3.8 is 10 x the logit error a bf16-MFMA implementation of this stack shows (operand floor /
+    storage emulation ~4e-3 of the scale = 0.015).  A random decoder's top-2 gap has a median of 0.23 and no lower bound (the unsearched clips of
+    id_stats_tiny_llama.npz: the best of 24 has a minimum gap of 0.106 over 12 steps), so such clips are ~2 % of all candidates: the first
+    `n_keep` of the clip indices 400, 401, ... that qualify are recorded, and how many were tried.  On these clips greedy ids must be
+    EQUAL to the reference's, step for step, with no margin escape.  Stored: clip indices, prompt lengths, ids, per-step last-row logits, margins."""
+    model, cfg = build_full_model(me, TINY_DEC)
+    inner = model.get_model()
+    inner.pad_token_id = 2
+    beats = _attach_tiny_encoders(me, inner, D_MODEL)
+    tok = _Tok(TINY_DEC["vocab_size"] - 17)
+    base_vocab = len(tok)
+    model.base_model.model.initialize_MM_tokenizer(tok, mask_token_nums=6, use_vqgan=False)
+    model.eval()
+    alias = [("base_model.model.model.audio_encoder.audio_encoder." + c, ["base_model.model.model.audio_encoder.audio_encoder." + o for o in os_])
+             for c, os_ in beats_alias(beats)]
+    table = load_synth(model, "", alias_groups=alias)
+    um = model.base_model.model
+    tab = dict(um.SPECIAL_TOKEN_2_IDS)
+    gen_kw = dict(use_cache=True, max_new_tokens=new, do_sample=False, output_logits=True, return_dict_in_generate=True, pad_token_id=2, eos_token_id=None)
+    clips = list(range(400, 400 + n_cand))
+    nts = [16 + (c * 5) % 19 for c in clips]
+    preps = []
+    for c, nt in zip(clips, nts):                                  # every encoder pass BEFORE the first generate() (transformers-5.15 artefact)
+        ids = synth.synth_prompt_ids(nt, base_vocab, tab, seed=SEED, clip=c)
+        mods = {'<video>': synth.synth_video(2, seed=SEED, clip=c), '<audio>': synth.synth_audio(3, 98, seed=SEED, clip=c)}
+        preps.append(um.prepare_multimodal_inputs([ids], [torch.full_like(ids, -100)], [mods], ['avqa'])["inputs_embeds"])
+    keep = []
+    for i, e in enumerate(preps):
+        r = super(type(um), um).generate(inputs_embeds=e, **gen_kw)
+        lg = torch.stack(r.logits, dim=1)[0]
+        t2 = lg.topk(2, dim=-1).values
+        m_ = t2[:, 0] - t2[:, 1]
+        if float(m_.min()) >= min_margin:
+            keep.append((clips[i], nts[i], r.sequences[0], lg, m_))
+            if len(keep) == n_keep:
+                break
+    assert len(keep) == n_keep, f"only {len(keep)} of {n_cand} candidate clips have every margin >= {min_margin}"
+    scale = max(float(k[3].abs().max()) for k in keep)
+    print(f"sharp: kept clips {[k[0] for k in keep]} after {i + 1} candidates; min margin {min(float(k[4].min()) for k in keep):.3f}, logit scale {scale:.3f}")
+    meta = dict(seed=SEED, dec=TINY_DEC, clip=TINY_CLIP, select=TINY_CLIP_SELECT, beats=TINY_BEATS, qf=TINY_QF, d_model=D_MODEL, base_vocab=base_vocab,
+                pad_token_id=2, special=tab, table=table, new_tokens=new, clips=[k[0] for k in keep], prompt_tokens=[k[1] for k in keep], t_v=2, t_a=3, l_a=98,
+                min_margin=min_margin, candidates_tried=i + 1, note="clips selected for margins >= 10 x the bf16 logit error on every step: ids must be EQUAL, no escape")
+    save("sharp_tiny_llama", meta, ids=torch.stack([k[2] for k in keep]), logits=torch.stack([k[3] for k in keep]), margin=torch.stack([k[4] for k in keep]))
+
+
 def golden_holes(me):
     """forward() with a 2-D attention_mask that is NOT left padding (HF's mask utilities accept any mask - the padding
     mask is AND-ed with the causal one): the hyper-LoRA tiny Llama decoder alone on seeded embeddings [2, 21, D]; row 0 has two interior

@@ -132,6 +132,19 @@ def _regime_emulations(W, cfg, emb_row0, ref_ids, want_floor):
     return _ORACLE[("emu", 0)], _ORACLE.get(("floor", 0))
 
 
+def _regime_row_bounds(W, cfg, emb, rows, ref):
+    """Per sampled row: max over the steps of |bf16-storage emulation - fp32 oracle| along the oracle's own token path (one batched teacher-forced
+    emulation run over the rows that are not cached yet): the COMPUTED bound of that row's HIP error is 1.5 x this."""
+    need = [r for r in rows if ("emu_err", r) not in _ORACLE]
+    if need:
+        ids = torch.cat([ref[rows.index(r)][0] for r in need], 0)
+        emu = _oracle_teacher_forced(W, cfg, emb[need].float().cpu(), ids, emulate=BF)
+        for j, r in enumerate(need):
+            rl = ref[rows.index(r)][1]
+            _ORACLE[("emu_err", r)] = max((emu[j, s] - rl[0, s]).abs().max().item() for s in range(rl.shape[1]))
+    return [_ORACLE[("emu_err", r)] for r in rows]
+
+
 def test_oracle_on_the_gpu_equals_the_oracle_on_the_host(crab):
     """The full-depth tests below execute the fp32 oracle with its tensors on the GPU (_odev).  Pinned here: two full-width hyper-LoRA layers of
     the benchmark's decoder, prefill S = 160 + 3 greedy tokens, oracle on the host cores vs the same oracle on the GPU - ids equal, logits within
@@ -185,7 +198,8 @@ def _decode_regime_vs_cpu_oracle(crab, B):
     emb = _regime_embeds(B, S, D)
     ref = _regime_oracle_rows(W, cfg, emb, rows, n_new)
     scale = max(l.abs().max().item() for _, l in ref)
-    TOL = 5.5e-3          # <= 1.4 x measured: 3.9e-3 (r04 / r05, fp32 residual stream; r03: 1.59e-2 under 3e-2)
+    row_emu = _regime_row_bounds(W, cfg, emb, rows, ref)
+    TOL = 1.5 * max(row_emu) / scale          # r06: COMPUTED (1.5 x the bf16-storage emulation's own distance from fp32 on these rows; r05 used the constant 5.5e-3, measured 3.9e-3)
     # (1) the public path: graph-replayed decode at M = 256
     ids, logits = eng.generate(emb, n_new, eos_token_id=None, pad_token_id=2, return_step_logits=True)
     st = eng._dec[0]
@@ -221,7 +235,7 @@ def _decode_regime_vs_cpu_oracle(crab, B):
             errs.append(e)
             top2 = rlog[0, s].topk(2).values
             ok = int(lg[j].argmax()) == int(rid[0, s])
-            assert e < TOL * scale, (f"teacher-forced B={B}", rows[j], s, e, scale)
+            assert e < 1.5 * row_emu[j], (f"teacher-forced B={B}", rows[j], s, e, row_emu[j], scale)
             assert ok or float(top2[0] - top2[1]) <= 2 * e, (f"teacher-forced argmax B={B}", rows[j], s, e, float(top2[0] - top2[1]))
             agree += ok
             total += 1
@@ -331,27 +345,39 @@ def test_full_width_layer_prefill_and_greedy_vs_cpu_oracle():
 
 def test_full_size_encoders_vs_cpu_oracle():
     """CLIP ViT-L/14 (23 live layers) + VLProjector and BEATs iter3+ + ALProjector at their full configurations on a short clip
-    (2 frames, 2 audio segments of 98 fbank frames) against the bf16-storage-emulating CPU oracle on the same weights: the
-    encoder kernels at their real widths (K = 1024 / 768 / 4096 GEMMs, head_dim 64 attention with and without the gated
-    relative-position bias, the 128-tap grouped positional convolution, both Q-Formers)."""
+    (2 frames, 2 audio segments of 98 fbank frames): the encoder kernels at their real widths (K = 1024 / 768 / 4096 GEMMs, head_dim 64
+    attention with and without the gated relative-position bias, the 128-tap grouped positional convolution, both Q-Formers) against the
+    fp32 oracle on the same weights, with the bound COMPUTED here (r06): the oracle's bf16-operand floor and bf16-storage emulation against
+    that same fp32 result; HIP <= 1.5 x the larger of the two per output."""
     from crab_amd import synth
     from crab_amd.build_model import build_crab
     from oracle import crab_oracle as O
+    from tests.util import record_parity, stored_params
     model = build_crab("llama", num_hidden_layers=1)
     um = model.base_model.model
-    W = {k: v.detach().float().cpu() for k, v in O.strip_peft_prefix(model.state_dict()).items() if v.dtype.is_floating_point}
+    dev = _odev()
+    W32 = {k: v.detach().float() for k, v in O.strip_peft_prefix(model.state_dict()).items() if v.dtype.is_floating_point}
+    Wf = {k: v.to(dev) for k, v in W32.items()}
+    Ws = {k: v.to(dev) for k, v in stored_params({k: v.cpu() for k, v in W32.items()}).items()}
     cfg = O.CrabConfig(decoder=O.DecoderConfig(num_hidden_layers=1), clip=O.ClipConfig(), beats=O.BeatsConfig())
-    video = synth.synth_video(2, clip=3)[None]                               # [1, 2, 3, 224, 224] fp32, CLIP-normalised
-    audio = synth.synth_audio(2, 98, clip=3)[None]                            # [1, 2, 98, 128]
+    video = synth.synth_video(2, clip=3)[None].to(BF).float()                # [1, 2, 3, 224, 224] CLIP-normalised, bf16-representable
+    audio = synth.synth_audio(2, 98, clip=3)[None].to(BF).float()            # [1, 2, 98, 128]
     vit, qf = um.encode_video(video)
-    ref_vit, ref_q = O.encode_video(video.to(BF).float(), W, cfg, emulate=BF)
-    for lvl in range(3):
-        assert _rel(vit[lvl].cpu(), ref_vit[lvl], f"full-size CLIP ViT-L/14 level {lvl} vs bf16-emulating oracle") < 8.5e-3, f"CLIP level {lvl}"     # r04 / r05: 4.7e-3 .. 6.0e-3 (r03: 1.9e-2)
-    assert _rel(qf[-1].cpu(), ref_q[-1], "full-size VLProjector vs bf16-emulating oracle") < 6e-3      # r05 (fp32 LayerNorm parameters): 4.1e-3 (r04: 7.7e-3)
     a = um.encode_audio(audio)
-    ref_a = O.encode_audio(audio.to(BF).float(), W, cfg, emulate=BF)
     assert a.shape == (1, 64, 4096)
-    assert _rel(a.cpu(), ref_a, "full-size BEATs + ALProjector vs bf16-emulating oracle") < 5.5e-3      # r04 / r05: 3.9e-3 (r03: 7.5e-3)
+    runs = {}
+    for name, Wm, mode in (("fp32", Wf, None), ("floor", Wf, O.OPERANDS), ("emu", Ws, BF)):
+        rv, rq = O.encode_video(video.to(dev), Wm, cfg, emulate=mode)
+        runs[name] = [t.cpu() for t in rv] + [rq[-1].cpu(), O.encode_audio(audio.to(dev), Wm, cfg, emulate=mode).cpu()]
+    got = [t.cpu().float() for t in vit] + [qf[-1].cpu().float(), a.cpu().float()]
+    names = [f"full-size CLIP ViT-L/14 level {l}" for l in range(3)] + ["full-size VLProjector", "full-size BEATs + ALProjector"]
+    for i, nm in enumerate(names):
+        ref = runs["fp32"][i]
+        sc = ref.abs().max().item()
+        hip, flo, emu = ((x - ref).abs().max().item() for x in (got[i], runs["floor"][i], runs["emu"][i]))
+        record_parity(nm + " vs fp32 oracle", hip, sc, 1.5 * max(flo, emu) / sc, bf16_operand_floor_abs=flo, bf16_storage_emulation_abs=emu, hip_over_floor=hip / flo)
+        assert flo > 1e-3 * sc, (nm, flo, sc)
+        assert hip <= 1.5 * max(flo, emu), (nm, hip, flo, emu, sc)
 
 
 def _oracle_teacher_forced(W, cfg, emb, ids, emulate=None):
@@ -389,12 +415,13 @@ def _greedy_vs_oracle(um, W, cfg, emb, n_new, what, tol, min_same=None, emu_fact
     r = um._engine.generate(emb.cuda(), n_new, eos_token_id=None, pad_token_id=2, return_step_logits=True)
     ids, logits = r[0].cpu(), r[1].float().cpu()
     same = 0
+    gen_errs = []
     for s in range(n_new):
         e = (logits[0, s] - ref_logits[0, s]).abs().max().item()
         if ids[0, s] != ref_ids[0, s]:
             assert margin[s].item() <= 2 * e, (what, "generate()", s, ids[0, s].item(), ref_ids[0, s].item(), e, margin[s].item())
             break
-        assert e < tol * scale, (what, "generate()", s, e, scale)
+        gen_errs.append(e)
         same += 1
     if min_same is not None:
         assert same >= min_same, (what, same)
@@ -410,9 +437,10 @@ def _greedy_vs_oracle(um, W, cfg, emb, n_new, what, tol, min_same=None, emu_fact
         errs.append((lg - ref_logits[0, s]).abs().max().item())
         agree.append(int(lg.argmax()) == int(ref_ids[0, s]))
     for s in range(n_new):
-        assert errs[s] < tol * scale, (what, "teacher-forced", s, errs[s], scale)
         assert agree[s] or margin[s].item() <= 2 * errs[s], (what, "teacher-forced argmax", s, errs[s], margin[s].item())
     extra = {}
+    if emu_factor is None:
+        emu_factor = 1.5                # r06: every comparison carries the COMPUTED bound; `tol` (the r05 constant) is recorded next to it, not asserted
     if emu_factor is not None:
         # a bound that does NOT come from measuring the HIP path: the oracle itself executed with bf16 STORAGE at the points where the
         # HIP path stores (exact arithmetic in between) on the same token path.  Its distance from the fp32 oracle is what bf16 storage
@@ -422,6 +450,7 @@ def _greedy_vs_oracle(um, W, cfg, emb, n_new, what, tol, min_same=None, emu_fact
         emu_err = max((emu[0, s] - ref_logits[0, s]).abs().max().item() for s in range(n_new))
         extra = dict(bf16_storage_emulation_abs=emu_err, hip_over_emulation=max(errs) / emu_err)
         assert max(errs) <= emu_factor * emu_err, (what, "HIP error vs exact bf16-storage emulation", max(errs), emu_err)
+        assert max(gen_errs, default=0.0) <= emu_factor * emu_err, (what, "generate() steps before the first divergence vs the emulation bound", max(gen_errs), emu_err)
     if floor:
         # the bf16-OPERAND floor (oracle emulate=O.OPERANDS: only weights, linear-layer inputs and q / k / v rounded, once): what no bf16-MFMA
         # implementation can beat.  Recorded next to the HIP error; north_star's 1e-3 must lie below it for the tolerance above to be honest

@@ -2,17 +2,12 @@
   (1) the reference-generated golden fixtures (fp32 reference outputs), and
   (2) the oracle on the same seeded weights, in fp32 and in bf16-storage emulation.
 
-Tolerances: north_star asks for "logits within 1e-3 bf16"; what bf16 STORAGE delivers is measured (an exact
-bf16-storage execution of these decoders is already 3.4e-3 .. 5.6e-3 of the logit scale away from fp32).  Every comparison below is
-recorded (tests/util.py:record_parity) and each tolerance is at most twice the worst error measured on MI355X
-(profiles/r02_parity_report.json), relative to max |reference|:
-  * REL_ENC  encoder features / projector outputs / spliced inputs_embeds vs the fp32 reference fixture   (r05, fp32 LayerNorm parameters: worst 1.01e-2, inputs_embeds 8.6e-3; r04: 1.29e-2; r03: 1.40e-2, tolerance 2.8e-2)
-             Every tolerance is <= 1.5 x the worst error measured on MI355X; tests/test_parity_floor.py puts the bf16-OPERAND FLOOR (what no bf16-MFMA
-             implementation can beat) next to each: the HIP path sits at 1.1 .. 2.3 x the floor on the tiny encoder stacks, 1.1 .. 1.4 x on the
-             decoder fixtures and 0.97 x (i.e. AT it) on the 32-layer Llama-2-7B-size decoder.
-  * REL_DEC  decoder logits / hidden states / layer outputs vs the fp32 reference fixture                 (r04: worst 6.7e-3 = a standalone bf16 rmsnorm, stacks 5.8e-3; r03: 8.9e-3, tolerance 1.8e-2)
-  * REL_EMU  vs the oracle emulating bf16 storage at the same points (accumulation order, 1-ulp flips)     (r04: worst 1.01e-2; r03: 1.34e-2, tolerance 2.5e-2)
-  * greedy token ids: exact wherever the fp32 reference's top-2 logit margin exceeds twice the measured logit error.
+Tolerances (r06): north_star asks for "logits within 1e-3 bf16"; what bf16 MATRIX OPERANDS allow is computed, not asserted from memory: for
+every component the oracle is executed as the bf16-operand floor and as the bf16-storage emulation on the same fixture (tests/bounds.py over
+scripts/parity_floor.py, ~10 s of CPU per session), and the HIP path must stay within 1.5 x the larger of the two - measured against the SAME
+fp32 reference values.  The floors are 2.9e-3 ... 6.9e-3 on these stacks (tests/test_parity_floor.py pins "> 1e-3" on the CPU).
+  * greedy token ids: exact wherever the fp32 reference's top-2 logit margin exceeds twice the measured logit error; on the sharpened-logit
+    fixture (tests/golden/sharp_tiny_llama.npz, margins >= 10 x the bf16 error) exact on every step, no escape.
 """
 import pytest
 import torch
@@ -21,9 +16,11 @@ from tests.util import build_tiny_crab, load_fixture, weights_from_table, bert_c
 
 pytestmark = pytest.mark.gpu
 BF = torch.bfloat16
-REL_EMU = 1.5e-2      # worst measured r05: 1.33e-2 (beats_tiny L = 98: BEATs' post-LN stack at width 128 amplifies 1-ulp flips)
-REL_ENC = 1.3e-2      # worst measured r05: 1.01e-2 (ALProjector, tiny) - 1.55 x the bf16-OPERAND FLOOR of that component (6.5e-3); r04: 1.29e-2 under 1.4e-2
-REL_DEC = 9e-3        # worst measured r05: 7.6e-3 (a rank-16 adapter stack), fixtures 3.8e-3 .. 5.5e-3 = 1.1 .. 1.4 x their operand floor
+# r06: NO tolerance constants.  Every bound below is COMPUTED in the test session from the oracle (tests/bounds.py over scripts/parity_floor.py):
+#     hip  <=  1.5 x max(bf16-operand floor, bf16-storage emulation)  of the component under test,
+# both measured against the same fp32 reference the HIP path is compared with (PB.bound(<component>)); a comparison with the storage emulation
+# itself gets 2.5 x (two executions within that distance of fp32), HIP-vs-HIP comparisons of two kernel regimes 2 x the component's bound.
+from tests import bounds as PB
 
 
 def _rel(got, ref, what=""):
@@ -51,8 +48,8 @@ def test_clip_tower_vs_reference_fixture_and_oracle():
     cfg = O.ClipConfig(**meta["cfg"], select_layers=tuple(meta["select"]))
     emu = O.visual_encoder(video.to(BF).float(), _bf(W), cfg, emulate=BF)
     for i in range(3):
-        assert _rel(feats[i], A[f"f{i}"], f"clip_tiny level {i} vs fp32 reference") < REL_ENC, f"level {i} vs reference"
-        assert _rel(feats[i], emu[i], f"clip_tiny level {i} vs bf16-emulating oracle") < REL_EMU, f"level {i} vs bf16-emulating oracle"
+        assert _rel(feats[i], A[f"f{i}"], f"clip_tiny level {i} vs fp32 reference") < PB.bound(f"clip_tiny feature levels [{i}]"), f"level {i} vs reference"
+        assert _rel(feats[i], emu[i], f"clip_tiny level {i} vs bf16-emulating oracle") < PB.bound(f"clip_tiny feature levels [{i}]", PB.FACTOR_VS_EMULATION), f"level {i} vs bf16-emulating oracle"
 
 
 def test_beats_vs_reference_fixture_and_oracle():
@@ -69,8 +66,8 @@ def test_beats_vs_reference_fixture_and_oracle():
     for L in (98, 198):
         x = A[f"x{L}"]
         y = ae(ops.cast_bf16(x.cuda()))
-        assert _rel(y, A[f"y{L}"], f"beats_tiny L={L} vs fp32 reference") < REL_ENC, f"L={L} vs reference"
-        assert _rel(y, O.beats(x.to(BF).float(), _bf(W), cfg, emulate=BF), f"beats_tiny L={L} vs bf16-emulating oracle") < REL_EMU, f"L={L} vs emulating oracle"
+        assert _rel(y, A[f"y{L}"], f"beats_tiny L={L} vs fp32 reference") < PB.bound(f"beats_tiny L={L}"), f"L={L} vs reference"
+        assert _rel(y, O.beats(x.to(BF).float(), _bf(W), cfg, emulate=BF), f"beats_tiny L={L} vs bf16-emulating oracle") < PB.bound(f"beats_tiny L={L}", PB.FACTOR_VS_EMULATION), f"L={L} vs emulating oracle"
 
 
 def test_projectors_vs_reference_fixture():
@@ -82,12 +79,12 @@ def test_projectors_vs_reference_fixture():
                      depth=2, bert_config=bc, device="cuda")
     r = vl.load_state_dict({k[len("model.vl_projector."):]: v for k, v in W.items() if k.startswith("model.vl_projector.")}, strict=False)
     assert not r.missing_keys, r.missing_keys
-    assert _rel(vl(A["vfeat"].to(BF).cuda()), A["vout"], "VLProjector vs fp32 reference") < REL_ENC
+    assert _rel(vl(A["vfeat"].to(BF).cuda()), A["vout"], "VLProjector vs fp32 reference") < PB.bound("VLProjector")
     al = ALProjector(hidden_size=128, num_query_token=32, num_hidden_layers=2, d_model=meta["d_model"], depth=2, bert_config=bc,
                      device="cuda")
     r = al.load_state_dict({k[len("model.al_projector."):]: v for k, v in W.items() if k.startswith("model.al_projector.")}, strict=False)
     assert not r.missing_keys, r.missing_keys
-    assert _rel(al(A["afeat"].to(BF).cuda()), A["aout"], "ALProjector vs fp32 reference") < REL_ENC
+    assert _rel(al(A["afeat"].to(BF).cuda()), A["aout"], "ALProjector vs fp32 reference") < PB.bound("ALProjector")
 
 
 def test_native_encoder_layer_sequencers_equal_python_sequences():
@@ -176,19 +173,19 @@ def test_forward_honours_left_pad_mask_and_position_ids_like_the_reference():
     valid = mask.bool()
     out = um(inputs_embeds=A["embeds_bs2"].cuda(), attention_mask=mask.cuda(), position_ids=pos.cuda(), use_cache=True, output_hidden_states=True)
     assert torch.isfinite(out.logits).all()
-    assert _rel(out.logits.cpu()[valid], A["logits_bs2"][valid], "forward() with left-pad mask + position_ids: logits of valid rows vs fp32 reference") < REL_DEC
-    assert _rel(out.hidden_states[-1].float().cpu()[valid], A["hidden_bs2"][valid], "forward() with left-pad mask: post-norm hidden of valid rows") < REL_DEC
+    assert _rel(out.logits.cpu()[valid], A["logits_bs2"][valid], "forward() with left-pad mask + position_ids: logits of valid rows vs fp32 reference") < PB.bound("forward_masked_tiny_llama")
+    assert _rel(out.hidden_states[-1].float().cpu()[valid], A["hidden_bs2"][valid], "forward() with left-pad mask: post-norm hidden of valid rows") < PB.bound("forward_masked_tiny_llama")
     # without the mask the padded row is far off (the reference: 3.3 on a logit scale of 3.8) - the mask path is really exercised
     plain = um(inputs_embeds=A["embeds_bs2"].cuda())
     assert float((plain.logits.cpu()[1] - A["logits_bs2"][1])[valid[1]].abs().max()) > 0.5
     step = um(input_ids=A["step_tok"][:, None].cuda(), attention_mask=A["step_mask"].cuda(), position_ids=A["step_pos"].cuda(),
               past_key_values=out.past_key_values)
-    assert _rel(step.logits.cpu(), A["step_logits"], "forward() decode shortcut with extended mask + per-row positions vs fp32 reference") < REL_DEC
+    assert _rel(step.logits.cpu(), A["step_logits"], "forward() decode shortcut with extended mask + per-row positions vs fp32 reference") < PB.bound("forward_masked_tiny_llama")
     # the multimodal branch: encoders -> splice -> left pad -> decoder with mask / positions
     mods = _inputs(meta)
     lab = [torch.full_like(A["ids0"], -100), torch.full_like(A["ids1"], -100)]
     mm = um(batch_input_ids=[A["ids0"], A["ids1"]], batch_labels=lab, batch_X_modals=mods, batch_task_names=['avqa', 'avqa'])
-    assert _rel(mm.logits.cpu()[valid], A["logits_bs2"][valid], "forward(batch_input_ids=...) left-padded bs 2 vs fp32 reference") < REL_ENC
+    assert _rel(mm.logits.cpu()[valid], A["logits_bs2"][valid], "forward(batch_input_ids=...) left-padded bs 2 vs fp32 reference") < PB.bound("full_tiny_llama: end to end")      # (encoders in front: the end-to-end row of this stack)
 
 
 def test_forward_accepts_any_2d_attention_mask_like_the_reference():
@@ -211,15 +208,15 @@ def test_forward_accepts_any_2d_attention_mask_like_the_reference():
     emb = A["embeds"].cuda()
     out = um(inputs_embeds=emb, attention_mask=mask.cuda(), use_cache=True, output_hidden_states=True)
     assert torch.isfinite(out.logits).all()
-    assert _rel(out.logits.cpu()[seen], A["logits"][seen], "forward() under a mask with interior holes: logits of defined rows vs fp32 reference") < REL_DEC
-    assert _rel(out.hidden_states[-1].float().cpu()[seen], A["hidden"][seen], "forward() under a mask with holes: post-norm hidden") < REL_DEC
+    assert _rel(out.logits.cpu()[seen], A["logits"][seen], "forward() under a mask with interior holes: logits of defined rows vs fp32 reference") < PB.bound("forward_holes_tiny_llama")
+    assert _rel(out.hidden_states[-1].float().cpu()[seen], A["hidden"][seen], "forward() under a mask with holes: post-norm hidden") < PB.bound("forward_holes_tiny_llama")
     plain = um(inputs_embeds=emb)
     assert float((plain.logits.cpu() - A["logits"])[seen].abs().max()) > 0.5          # the mask path is really exercised
     outp = um(inputs_embeds=emb, attention_mask=mask.cuda(), position_ids=A["pos"].cuda())
-    assert _rel(outp.logits.cpu()[seen], A["logits_pos"][seen], "forward() under a mask with holes + cumsum-1 position_ids") < REL_DEC
+    assert _rel(outp.logits.cpu()[seen], A["logits_pos"][seen], "forward() under a mask with holes + cumsum-1 position_ids") < PB.bound("forward_holes_tiny_llama")
     step = um(input_ids=A["step_tok"][:, None].cuda(), attention_mask=A["step_mask"].cuda(), position_ids=A["step_pos"].cuda(),
               past_key_values=out.past_key_values)
-    assert _rel(step.logits.cpu(), A["step_logits"], "forward() decode shortcut over a cache with masked rows vs fp32 reference") < REL_DEC
+    assert _rel(step.logits.cpu(), A["step_logits"], "forward() decode shortcut over a cache with masked rows vs fp32 reference") < PB.bound("forward_holes_tiny_llama")
     # the bit mask and the first-visible-key form are two encodings of the same thing for a left-padded batch: identical logits
     pad = torch.ones_like(mask); pad[1, :5] = 0
     a = um(inputs_embeds=emb, attention_mask=pad.cuda()).logits
@@ -246,15 +243,15 @@ def test_full_tiny_generate_matches_reference(fixture):
     mods = _inputs(meta)
     lab = [torch.full_like(A["ids0"], -100), torch.full_like(A["ids1"], -100)]
     inp1 = model.prepare_multimodal_inputs([A["ids0"]], [lab[0]], [mods[0]], ['avqa'])
-    assert _rel(inp1["inputs_embeds"], A["embeds_bs1"], f"{fixture}: inputs_embeds bs1 (encoders + projectors + splice)") < REL_ENC
+    assert _rel(inp1["inputs_embeds"], A["embeds_bs1"], f"{fixture}: inputs_embeds bs1 (encoders + projectors + splice)") < PB.bound(f"{fixture}: inputs_embeds")
     inp2 = model.prepare_multimodal_inputs([A["ids0"], A["ids1"]], lab, mods, ['avqa', 'avqa'])
-    assert _rel(inp2["inputs_embeds"], A["embeds_bs2"], f"{fixture}: inputs_embeds left-padded bs2") < REL_ENC
+    assert _rel(inp2["inputs_embeds"], A["embeds_bs2"], f"{fixture}: inputs_embeds left-padded bs2") < PB.bound(f"{fixture}: inputs_embeds")
     assert torch.equal(inp2["position_ids"].cpu().long(), A["pos_bs2"].long())
     assert torch.equal(inp2["attention_mask"].cpu().long(), A["mask_bs2"].long())
     # prefill, all rows (LlamaForCausalLM.forward)
     out = model.base_model.model(inputs_embeds=A["embeds_bs1"].to(BF).cuda(), output_hidden_states=True)
-    assert _rel(out.logits, A["prefill_logits_bs1"], f"{fixture}: prefill logits, all rows") < REL_DEC
-    assert _rel(out.hidden_states[-1], A["prefill_hidden_bs1"], f"{fixture}: post-norm hidden, all rows") < REL_DEC
+    assert _rel(out.logits, A["prefill_logits_bs1"], f"{fixture}: prefill logits, all rows") < PB.bound(f"{fixture}: decoder prefill logits")
+    assert _rel(out.hidden_states[-1], A["prefill_hidden_bs1"], f"{fixture}: post-norm hidden, all rows") < PB.bound(f"{fixture}: decoder prefill logits")
     # generate: public API, bs=1 and left-padded bs=2, graph replay and plain launches must agree bit for bit
     n = meta["new_tokens"]
     kw = dict(use_cache=True, max_new_tokens=n, do_sample=False, pad_token_id=2, eos_token_id=None,
@@ -268,7 +265,7 @@ def test_full_tiny_generate_matches_reference(fixture):
         got = torch.stack(r1.logits, 1)
         assert torch.equal(got, torch.stack(r2.logits, 1))
         err = _check_ids(r1.sequences, A[f"ids_{key}"], A[f"logits_{key}"], got)
-        assert err < REL_DEC * A[f"logits_{key}"].abs().max().item(), err
+        assert err < PB.bound(f"{fixture}: end to end") * A[f"logits_{key}"].abs().max().item(), err
         plain = model.generate(batch_input_ids=bi, batch_labels=lab[:bs], batch_X_modals=mods[:bs], batch_task_names=['avqa'] * bs,
                                use_cache=True, max_new_tokens=n, pad_token_id=2, eos_token_id=None)
         assert torch.equal(plain, r1.sequences) and plain.shape == (bs, n)
@@ -287,7 +284,8 @@ def test_tiny_qwen2_gqa_bias_generate_matches_reference():
                          eos_token_id=None, output_logits=True, return_dict_in_generate=True)
     got = torch.stack(res.logits, 1)
     err = _check_ids(res.sequences, A["ids"], A["logits"], got)
-    assert err < REL_DEC * A["logits"].abs().max().item(), err
+    from oracle import crab_oracle as O
+    assert err < PB.decoder_bound(A["embeds"].to(BF), O.strip_peft_prefix(W), O.DecoderConfig(**meta["dec"]), A["ids"]) * A["logits"].abs().max().item(), err
 
 
 def test_eos_and_min_new_tokens_semantics():
@@ -640,7 +638,38 @@ def test_generate_many_clips_vs_oracle():
         # these clips are NOT searched for wide margins (unlike the fixtures): with the fp32 residual stream (r04) clip 11 flips one step whose
         # reference top-2 margin is below twice the logit error (asserted inside) - 20 of 21 steps covered there, all steps elsewhere
         worst = max(worst, _check_ids(r.sequences, ref_ids, ref_logits, torch.stack(r.logits, 1), min_frac=0.9) / ref_logits.abs().max().item())
-    assert worst < REL_DEC, worst
+    assert worst < PB.bound("full_tiny_llama: end to end"), worst          # (other clips of the fixture's stack: its end-to-end row)
+
+
+def test_sharp_margin_clips_decode_to_the_reference_ids_without_escape():
+    """north_star's ids clause where it is decidable: tests/golden/sharp_tiny_llama.npz = eight clips recorded from the reference whose top-2
+    logit margin is >= 0.15 on EVERY greedy step (10 x the bf16 logit error of this stack; 8 of the first 154 candidate clips qualify).  Greedy
+    ids must be EQUAL to the reference's on every step of every clip - torch.equal, no margin escape - alone (bs 1), all eight in one generate()
+    (left-padded batch: the reference's generate attends the pads, so only the ids of the longest prompt are comparable there), and as eight
+    calls coalesced into one ragged decode batch; the per-step logits stay inside the computed end-to-end bound."""
+    from crab_amd import synth
+    meta, A = load_fixture("sharp_tiny_llama")
+    model = build_tiny_crab(meta)
+    model.load_state_dict(weights_from_table(meta), strict=False)
+    n = meta["new_tokens"]
+    scale = A["logits"].abs().max().item()
+    batches = []
+    worst = 0.0
+    for i, (c, nt) in enumerate(zip(meta["clips"], meta["prompt_tokens"])):
+        ids = synth.synth_prompt_ids(nt, meta["base_vocab"], meta["special"], seed=meta["seed"], clip=c)
+        mods = [{'<video>': synth.synth_video(meta["t_v"], seed=meta["seed"], clip=c), '<audio>': synth.synth_audio(meta["t_a"], meta["l_a"], seed=meta["seed"], clip=c)}]
+        b = dict(batch_input_ids=[ids], batch_labels=[torch.full_like(ids, -100)], batch_X_modals=mods, batch_task_names=['avqa'])
+        batches.append(b)
+        r = model.generate(**b, use_cache=True, max_new_tokens=n, pad_token_id=2, eos_token_id=None, output_logits=True, return_dict_in_generate=True)
+        assert torch.equal(r.sequences[0].cpu(), A["ids"][i]), (c, r.sequences[0].tolist(), A["ids"][i].tolist())
+        worst = max(worst, (torch.stack(r.logits, 1)[0].float().cpu() - A["logits"][i]).abs().max().item())
+    from tests.util import record_parity
+    record_parity("sharp-margin clips (8 clips x 8 steps, reference margins >= 0.15): ids EQUAL on every step; worst per-step logit error", worst, scale,
+                  PB.bound("full_tiny_llama: end to end"), min_ref_margin=float(A["margin"].min()), margin_over_error=float(A["margin"].min()) / worst)
+    assert worst < PB.bound("full_tiny_llama: end to end") * scale and float(A["margin"].min()) > 5 * worst
+    many = model.generate_batches(batches, coalesce=True, use_cache=True, max_new_tokens=n, pad_token_id=2, eos_token_id=None)
+    for i, ids in enumerate(many):
+        assert torch.equal(ids[0].cpu(), A["ids"][i]), ("coalesced", meta["clips"][i])
 
 
 def test_unfiltered_id_parity_statistic_on_unsearched_clips():
@@ -648,7 +677,7 @@ def test_unfiltered_id_parity_statistic_on_unsearched_clips():
     reference's generate() without any margin search), one clip per generate() call.  REPORTED in the parity report: the fraction of greedy
     steps identical to the reference's, how many clips agree on all 12 steps, and at each first divergence the reference's top-2 margin next to
     the logit error there.  Gated only on what must hold physically: a divergence happens where margin <= 2 x the logit error, and the logit error
-    stays under REL_DEC."""
+    stays under the computed end-to-end bound of this stack (tests/bounds.py)."""
     from crab_amd import synth
     from tests.util import record_parity
     meta, A = load_fixture("id_stats_tiny_llama")
@@ -680,7 +709,7 @@ def test_unfiltered_id_parity_statistic_on_unsearched_clips():
     record_parity("UNSEARCHED clips 200..223 (tiny Llama, bs 1): greedy steps identical to the reference's before the first divergence / all steps",
                   worst, scale, None, steps_identical=steps_same, steps_total=total, fraction=round(steps_same / total, 4), clips_fully_identical=clips_same,
                   clips=len(meta["clips"]), first_divergences=divergences, min_ref_margin=float(A["margin"].min()), median_ref_margin=float(A["margin"].median()))
-    assert worst < REL_DEC * scale, worst
+    assert worst < PB.bound("full_tiny_llama: end to end") * scale, worst
     assert steps_same >= 0.5 * total, (steps_same, total, divergences)            # sanity only: the statistic itself is the report row
 
 
@@ -783,14 +812,14 @@ def _layer_prefill_and_decode_step(fixture, qwen):
     kc, vc = eng.alloc_cache(1, 64)
     eng.prefill(A["layer_x"].to(BF).cuda(), kc, vc, b0=0, all_logits=True)      # every row through the layer (generate()'s prefill finishes the last rows only)
     ws = eng._workspace(S)
-    assert _rel(ws.x[:S], A["layer_y"][0], f"{fixture}: layer output, prefill") < REL_DEC
+    assert _rel(ws.x[:S], A["layer_y"][0], f"{fixture}: layer output, prefill") < PB.bound(f"{fixture}: one hyper-LoRA decoder layer")
     assert _rel(kc[0, 0, :, :S], A["cache_k"][0][:, :S], f"{fixture}: K cache rows, prefill") < 1.2e-2
     assert _rel(vc[0, 0, :, :S], A["cache_v"][0][:, :S], f"{fixture}: V cache rows, prefill") < 1.2e-2
     # the decode row: position S, device-resident position word, KV append fused behind the q|k|v projection
     ops.cast_rows(A["layer_x1"][0].to(BF).cuda(), ws.x, 1, D)
     pos = torch.full((1,), S, device="cuda", dtype=torch.int32)
     x, _ = eng._layers(ws, 1, 1, kc, vc, 0, 64, 0, pos, None)
-    assert _rel(x[:1], A["layer_y1"][0], f"{fixture}: layer output, 1-token decode step") < REL_DEC
+    assert _rel(x[:1], A["layer_y1"][0], f"{fixture}: layer output, 1-token decode step") < PB.bound(f"{fixture}: one hyper-LoRA decoder layer")
     assert _rel(kc[0, 0, :, S], A["cache_k"][0][:, S], f"{fixture}: K cache row, decode step") < 1.2e-2
     assert _rel(vc[0, 0, :, S], A["cache_v"][0][:, S], f"{fixture}: V cache row, decode step") < 1.2e-2
 
@@ -891,7 +920,7 @@ def test_adapter_rank_outside_the_small_batch_tail_limits_still_generates(r, nl)
             assert torch.equal(ids, outs[0][0]) and torch.equal(logits, outs[0][1])
         ref_ids, ref_logits = O.greedy_generate(emb.float().cpu(), W, ocfg, 4)
         err = _check_ids(outs[0][0], ref_ids, ref_logits, outs[0][1], min_frac=0.5)
-        assert err < REL_DEC * ref_logits.abs().max().item(), (B, err)
+        assert err < PB.decoder_bound(emb.cpu(), W, ocfg, ref_ids) * ref_logits.abs().max().item(), (B, err)
 
 
 def test_decode_batch_between_256_and_512_rows_two_row_groups_tiny():
@@ -921,9 +950,10 @@ def test_decode_batch_between_256_and_512_rows_two_row_groups_tiny():
     ocfg = O.DecoderConfig(**meta["dec"])
     ref_ids, ref_logits = O.greedy_generate(emb[rows].float().cpu(), Wo, ocfg, n)
     worst = _check_ids(ids[rows], ref_ids, ref_logits, logits[rows], min_frac=0.75)
-    assert worst < REL_DEC * ref_logits.abs().max().item(), worst
+    bnd = PB.decoder_bound(emb[rows].cpu(), Wo, ocfg, ref_ids, W_stored=Wo)          # (the oracle above runs on the stored parameters: so does the bound)
+    assert worst < bnd * ref_logits.abs().max().item(), worst
     _check_ids(sids.cpu(), ref_ids, ref_logits, slog.float().cpu(), min_frac=0.75)
-    assert _rel(logits[rows][:, 0], slog.float().cpu()[:, 0], "tiny Llama: rows of a 300-row decode batch vs the same rows as a batch of 4, first step (HIP vs HIP)") < REL_DEC
+    assert _rel(logits[rows][:, 0], slog.float().cpu()[:, 0], "tiny Llama: rows of a 300-row decode batch vs the same rows as a batch of 4, first step (HIP vs HIP)") < 2 * bnd
 
 
 def test_single_layer_entry_points_equal_the_stack_call():
@@ -1134,8 +1164,8 @@ def test_coalesced_batches_match_the_reference_fixture_per_batch(fixture):
     inputs = um.prepare_multimodal_inputs_many(batches)
     embeds = [d["inputs_embeds"] for d in inputs]
     assert len({e.shape[1] for e in embeds}) >= 2, "the batches must differ in prompt length for this test to mean anything"
-    assert _rel(embeds[0], A["embeds_bs1"], "coalesced encoders: inputs_embeds of batch 0 (bs 1)") < REL_ENC
-    assert _rel(embeds[1], A["embeds_bs2"], "coalesced encoders: inputs_embeds of batch 1 (left-padded bs 2)") < REL_ENC
+    assert _rel(embeds[0], A["embeds_bs1"], "coalesced encoders: inputs_embeds of batch 0 (bs 1)") < PB.bound(f"{fixture}: inputs_embeds")
+    assert _rel(embeds[1], A["embeds_bs2"], "coalesced encoders: inputs_embeds of batch 1 (left-padded bs 2)") < PB.bound(f"{fixture}: inputs_embeds")
     assert torch.equal(inputs[1]["position_ids"].cpu().long(), A["pos_bs2"].long()) and torch.equal(inputs[1]["attention_mask"].cpu().long(), A["mask_bs2"].long())
     kw = dict(eos_token_id=None, pad_token_id=2, coalesce=True, return_step_logits=True)
     # both prefill forms of a ragged wave: per group into the right-aligned cache (cache pointers advanced), and MERGED - one front-padded batch
@@ -1158,7 +1188,7 @@ def test_coalesced_batches_match_the_reference_fixture_per_batch(fixture):
             for g, key in ((0, "bs1"), (1, "bs2")):
                 ids, logits = res[g]
                 err = _check_ids(ids, A[f"ids_{key}"], A[f"logits_{key}"], logits)
-                assert err < REL_DEC * A[f"logits_{key}"].abs().max().item(), (g, form, err)
+                assert err < PB.bound(f"{fixture}: end to end") * A[f"logits_{key}"].abs().max().item(), (g, form, err)
     finally:
         decoder.RAGGED_PAD_MAX = saved
     res = eng.generate_many(embeds, n, **kw)                    # the default rule (these lengths: merged)
@@ -1172,14 +1202,14 @@ def test_coalesced_batches_match_the_reference_fixture_per_batch(fixture):
         solo = model.generate(**b, use_cache=True, max_new_tokens=n, pad_token_id=2, eos_token_id=None, output_logits=True, return_dict_in_generate=True)
         sl = torch.stack(solo.logits, 1).float().cpu()
         _check_ids(res[g][0], solo.sequences.cpu(), sl, res[g][1])
-        assert _rel(res[g][1], sl, f"coalesced batch {g} vs its own generate() call, per-step logits (HIP vs HIP)") < 2 * REL_DEC
+        assert _rel(res[g][1], sl, f"coalesced batch {g} vs its own generate() call, per-step logits (HIP vs HIP)") < 2 * PB.bound(f"{fixture}: end to end")
 
 
 def test_coalesced_batches_of_different_lengths_vs_oracle():
     """Five batches of two unsearched clips each, every batch with its own pair of prompt lengths (so its own left padding AND its own offset
     inside the right-aligned cache), coalesced into one ragged decode batch of 10 rows and - with max_rows = 4 - into three waves; each batch
     against the golden-pinned oracle run on THAT batch alone.  Greedy ids exact wherever the oracle's top-2 margin exceeds twice the logit
-    error, per-step logits within REL_DEC."""
+    error, per-step logits within the computed end-to-end bound of the stack."""
     from crab_amd import synth
     from oracle import crab_oracle as O
     from tests.test_oracle_golden import _full_cfg
@@ -1216,7 +1246,7 @@ def test_coalesced_batches_of_different_lengths_vs_oracle():
                 worst = max(worst, _check_ids(ids, ref_ids, ref_logits, logits, min_frac=0.9) / ref_logits.abs().max().item())
     finally:
         decoder.RAGGED_PAD_MAX = saved
-    assert worst < REL_DEC, worst
+    assert worst < PB.bound("full_tiny_llama: end to end"), worst
 
 
 def test_coalesced_batches_stop_per_batch_like_separate_calls():
@@ -1286,7 +1316,7 @@ def test_prefill_last_rows_only_equals_the_full_last_layer(fixture):
             decoder.LAST_ROWS_ONLY = True
     assert torch.equal(outs[True][0], outs[False][0])
     assert torch.equal(outs[True][2], outs[False][2]), "the last layer's prompt K rows differ"
-    assert _rel(outs[True][1], outs[False][1], f"{fixture}: last-rows-only prefill vs the full last layer, per-step logits (HIP vs HIP)") < REL_DEC
+    assert _rel(outs[True][1], outs[False][1], f"{fixture}: last-rows-only prefill vs the full last layer, per-step logits (HIP vs HIP)") < 2 * PB.bound(f"{fixture}: end to end")
     for on in (True, False):
         err = _check_ids(outs[on][0], A["ids_bs2"], A["logits_bs2"], outs[on][1])
-        assert err < REL_DEC * A["logits_bs2"].abs().max().item(), (on, err)
+        assert err < PB.bound(f"{fixture}: end to end") * A["logits_bs2"].abs().max().item(), (on, err)

@@ -346,3 +346,29 @@ def test_id_stats_unsearched_clips_oracle_reproduces_the_reference():
             same += 1
         total += n
     assert same >= total - 2
+
+
+def test_sharp_margin_clips_ids_and_logits():
+    """tests/golden/sharp_tiny_llama.npz (r06): eight clips whose reference top-2 margin is >= 0.15 (10 x the bf16 logit error of this stack) on every
+    one of their greedy steps - the fixture on which ids must be equal WITHOUT a margin escape (tests/test_model_gpu.py).  Here: the oracle
+    reproduces the reference's ids and logits, and its own bf16 emulations (operand floor, storage) decode the same ids, i.e. the margins
+    really are beyond what bf16 operands can move."""
+    from crab_amd import synth
+    from tests.util import stored_params
+    meta, A = load_fixture("sharp_tiny_llama")
+    W = O.strip_peft_prefix(weights_from_table(meta))
+    cfg = _full_cfg(meta)
+    n = meta["new_tokens"]
+    assert float(A["margin"].min()) >= meta["min_margin"] >= 0.15
+    for i, (c, nt) in enumerate(zip(meta["clips"], meta["prompt_tokens"])):
+        ids = synth.synth_prompt_ids(nt, meta["base_vocab"], meta["special"], seed=meta["seed"], clip=c)
+        mods = [{'<video>': synth.synth_video(meta["t_v"], seed=meta["seed"], clip=c), '<audio>': synth.synth_audio(meta["t_a"], meta["l_a"], seed=meta["seed"], clip=c)}]
+        got_ids, got_logits = O.generate([ids], mods, W, cfg, n)
+        assert torch.equal(got_ids[0], A["ids"][i])
+        _close(got_logits[0], A["logits"][i], 1e-3)
+        if i < 3:                                                        # (three clips keep the CPU suite short)
+            emb = O.prepare_multimodal_inputs([ids], mods, W, cfg, O.OPERANDS)["inputs_embeds"]
+            assert torch.equal(O.greedy_generate(emb, W, cfg.decoder, n, emulate=O.OPERANDS)[0][0], A["ids"][i]), "operand floor flips an id"
+            Ws = stored_params(W)
+            emb = O.prepare_multimodal_inputs([ids], [{k: v.to(torch.bfloat16).float() for k, v in mods[0].items()}], Ws, cfg, torch.bfloat16)["inputs_embeds"]
+            assert torch.equal(O.greedy_generate(emb, Ws, cfg.decoder, n, emulate=torch.bfloat16)[0][0], A["ids"][i]), "storage emulation flips an id"

@@ -27,13 +27,15 @@ def test_bf16_operand_floor_is_above_the_1e3_the_north_star_names():
     per-step logits) rounding nothing but the MFMA operands to bf16 already moves the logits by 2.9e-3 ... 4.0e-3 of their scale; the
     encoder features by 3.5e-3 ... 6.9e-3.  A tolerance of 1e-3 against the fp32 reference is therefore unreachable with bf16 matrix
     operands whatever the kernels do; the storage emulation (what the HIP path's storage points cost on top) stays within 2.1x of the floor."""
-    R = _rows()
-    assert len(R) >= 13
+    R = [r for r in _rows() if not any(k in r["what"] for k in ("_ops:", "forward_masked", "forward_holes"))]      # the component rows of r05 (the r06
+    assert len(R) >= 13                                             # rows of the masked forwards / single layers are bounds for tests/test_model_gpu.py)
     for r in R:
         assert r["floor"] > 1.0e-3, r                               # measured: >= 2.88e-3 on every row
         assert r["storage_emulation"] < 2.5 * r["floor"], r        # measured: <= 2.05 (beats_tiny L=198)
     dec = [r for r in R if "logits" in r["what"]]
     assert len(dec) == 4 and min(r["floor"] for r in dec) > 2.5e-3
+    extra = [r for r in _rows() if r not in R]
+    assert len(extra) >= 11 and all(r["floor"] > 5e-4 and r["storage_emulation"] < 2.5 * r["floor"] for r in extra), extra
 
 
 @pytest.mark.gpu
@@ -87,7 +89,9 @@ def test_hip_path_against_the_operand_floor_and_the_storage_emulation():
     R = _rows(hip)
     worst = 0.0
     for r in R:
-        assert "hip" in r, r["what"]
+        if "hip" not in r:                                          # the masked-forward / single-layer rows: bounded in tests/test_model_gpu.py through tests/bounds.py
+            assert any(k in r["what"] for k in ("_ops:", "forward_masked", "forward_holes")), r["what"]
+            continue
         record_parity("TRIPLET " + r["what"], r["hip"] * r["scale"], r["scale"], None, floor=r["floor"], storage_emulation=r["storage_emulation"],
                       hip=r["hip"], hip_over_floor=r["hip"] / r["floor"], hip_over_storage_emulation=r["hip"] / r["storage_emulation"])
         # the HIP path sits at the level of its storage format (accumulation order and 1-ulp flips on top): never beyond 1.5x the larger emulation
