@@ -779,7 +779,11 @@ extern "C" int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc*
     // ---- decode regime, 128 < M <= 256: the batch-tall narrow-panel kernel (gemm_decode.hip); tune 70000 + BN * 100 + S forces
     // a decomposition (80000 + ...: on the 8-wave kernel instead of the producer / consumer one), any other non-zero tune keeps the older kernels (A/B runs), CRAB_DEC_GEMM=0 disables it process-wide
     int dec_bn = 0;
-    if (sk_bm == 128 && d->M > 128 && d->workspace) {
+    // r06: the panel kernel's row floor.  64 < M <= 128 used to take the 128 x 128 LDS-DMA kernel with K slices (two blocks per CU re-reading their
+    // activation tile per weight tile); the panel kernel streams every weight byte once for the whole batch whatever M is (idle row fragments are
+    // masked), which is the better trade from ~80 rows up (scripts/exp/dec_min_rows.py).  CRAB_DEC_MIN_ROWS overrides the floor (A/B runs).
+    static const int dec_min_rows = []() { const char* e = getenv("CRAB_DEC_MIN_ROWS"); return e ? atoi(e) : 128; }();
+    if (sk_bm == 128 && d->M > dec_min_rows && d->workspace) {
         static const int dec_on = []() { const char* e = getenv("CRAB_DEC_GEMM"); return !(e && e[0] == '0'); }();
         const int nk32 = (d->K + 63) / 64 + (d->A2 ? (d->K2 + 63) / 64 : 0);      // K slots of the panel kernel (64 wide)
         if (d->tune >= 70000 && d->tune < 90000) {                      // 8xxxx: the same decomposition on the 8-wave kernel (A/B, tests)

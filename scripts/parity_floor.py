@@ -25,6 +25,17 @@ def bfw(W):
     return stored_params(W)              # what the HIP modules hold: bf16, the encoders' LayerNorm parameters fp32
 
 
+def q(x, e):
+    """An INPUT of the component as the execution mode `e` receives it: the fp32 reference (e is None) gets the fixture's own fp32 values, every bf16
+    execution - floor, storage emulation, and the HIP entry points, whose activations are bf16 - their bf16 rounding.  (r06: the reference side used
+    to be rounded as well, which left the input quantisation out of the floors while the HIP path was compared with the unrounded fixture.)"""
+    if isinstance(x, dict):
+        return {k: q(v, e) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [q(v, e) for v in x]
+    return x if e is None else x.to(BF).float()
+
+
 def rel(a, b):
     return float((a.float() - b.float()).abs().max() / b.float().abs().max())
 
@@ -52,33 +63,32 @@ def rows(hip=None):
     from crab_amd import synth
     cfg = O.ClipConfig(**meta["cfg"], select_layers=tuple(meta["select"]))
     video = synth.synth_video(meta["t_v"], seed=meta["seed"], clip=meta["clip"])[None]
-    three("clip_tiny feature levels", lambda W, e: O.visual_encoder(video.to(BF).float(), W, cfg, e), weights_from_table(meta))
+    three("clip_tiny feature levels", lambda W, e: O.visual_encoder(q(video, e), W, cfg, e), weights_from_table(meta))
 
     meta, A = load_fixture("beats_tiny")
     bc = _beats_cfg(meta["cfg"])
     for L in (98, 198):
-        three(f"beats_tiny L={L}", lambda W, e: O.beats(A[f"x{L}"].to(BF).float(), W, bc, emulate=e), weights_from_table(meta))
+        three(f"beats_tiny L={L}", lambda W, e, L=L: O.beats(q(A[f"x{L}"], e), W, bc, emulate=e), weights_from_table(meta))
 
     meta, A = load_fixture("projectors_tiny")
     qf = O.QFormerConfig(hidden_size=meta["qf"]["hidden"], num_attention_heads=meta["qf"]["heads"], intermediate_size=meta["qf"]["inter"])
     W = weights_from_table(meta)
-    three("VLProjector (tiny)", lambda W, e: O.vl_projector(A["vfeat"], W, qf, emulate=e), W)
-    three("ALProjector (tiny)", lambda W, e: O.al_projector(A["afeat"], W, qf, emulate=e), W)
+    three("VLProjector (tiny)", lambda W, e: O.vl_projector(q(A["vfeat"], e), W, qf, emulate=e), W)
+    three("ALProjector (tiny)", lambda W, e: O.al_projector(q(A["afeat"], e), W, qf, emulate=e), W)
 
     for fx in ("full_tiny_llama", "full_tiny_qwen"):
         meta, A = load_fixture(fx)
         W = O.strip_peft_prefix(weights_from_table(meta))
         cfg = _full_cfg(meta)
         mods = _full_inputs(meta)
-        mods = [{k: v.to(BF).float() for k, v in m.items()} for m in mods]
         three(f"{fx}: inputs_embeds bs2 (encoders + projectors + splice)",
-              lambda W, e: O.prepare_multimodal_inputs([A["ids0"], A["ids1"]], mods, W, cfg, e)["inputs_embeds"], W)
+              lambda W, e: O.prepare_multimodal_inputs([A["ids0"], A["ids1"]], q(mods, e), W, cfg, e)["inputs_embeds"], W)
         three(f"{fx}: decoder prefill logits, all rows (from the reference's inputs_embeds)",
-              lambda W, e: O.decoder_forward(A["embeds_bs1"].to(BF).float(), W, cfg.decoder, emulate=e)[0], W)
+              lambda W, e: O.decoder_forward(q(A["embeds_bs1"], e), W, cfg.decoder, emulate=e)[0], W)
         n = meta["new_tokens"]
 
         def gen(W, e):          # teacher-forced on the reference's ids: per-step logits of the SAME contexts
-            emb = O.prepare_multimodal_inputs([A["ids0"]], mods[:1], W, cfg, e)["inputs_embeds"]
+            emb = O.prepare_multimodal_inputs([A["ids0"]], q(mods[:1], e), W, cfg, e)["inputs_embeds"]
             toks = W["model.embed_tokens.weight"].float()[A["ids_bs1"][0, :n - 1]][None]
             logits, _, _ = O.decoder_forward(torch.cat([emb, O._r(toks, e)], 1), W, cfg.decoder, emulate=e)
             return logits[:, -n:]
@@ -90,19 +100,27 @@ def rows(hip=None):
     valid = A["mask_bs2"].bool()
 
     def masked(W, e):
-        logits, hn, cache = O.decoder_forward(A["embeds_bs2"].to(BF).float(), W, dcfg, positions=A["pos_bs2"], attention_mask=A["mask_bs2"], emulate=e)
+        logits, hn, cache = O.decoder_forward(q(A["embeds_bs2"], e), W, dcfg, positions=A["pos_bs2"], attention_mask=A["mask_bs2"], emulate=e)
         tok = W["model.embed_tokens.weight"].float()[A["step_tok"]][:, None]
         l2, _, _ = O.decoder_forward(O._r(tok, e), W, dcfg, cache, positions=A["step_pos"], attention_mask=A["step_mask"], emulate=e)
         return [logits[valid], hn[valid], l2]
     three("forward_masked_tiny_llama: left-pad mask + position_ids (valid logits | post-norm hidden | decode-shortcut logits)", masked, W)
+    mcfg = _full_cfg(meta)
+    mmods = _full_inputs(meta)
+
+    def multimodal(W, e):          # the multimodal branch of forward(): encoders -> splice -> left pad -> decoder under the mask; logits of EVERY valid row
+        inp = O.prepare_multimodal_inputs([A["ids0"], A["ids1"]], q(mmods, e), W, mcfg, e)
+        logits, _, _ = O.decoder_forward(inp["inputs_embeds"], W, dcfg, positions=inp["position_ids"], attention_mask=inp["attention_mask"], emulate=e)
+        return logits[valid]
+    three("multimodal forward_masked_tiny_llama: forward(batch_input_ids=...) logits of all valid rows", multimodal, W)
     meta, A = load_fixture("forward_holes_tiny_llama")
     W = O.strip_peft_prefix(weights_from_table(meta))
     hcfg = O.DecoderConfig(**meta["dec"])
     seen = A["mask"].cumsum(-1) > 0
 
     def holes(W, e):
-        logits, hn, cache = O.decoder_forward(A["embeds"].to(BF).float(), W, hcfg, attention_mask=A["mask"], emulate=e)
-        lp, _, _ = O.decoder_forward(A["embeds"].to(BF).float(), W, hcfg, positions=A["pos"], attention_mask=A["mask"], emulate=e)
+        logits, hn, cache = O.decoder_forward(q(A["embeds"], e), W, hcfg, attention_mask=A["mask"], emulate=e)
+        lp, _, _ = O.decoder_forward(q(A["embeds"], e), W, hcfg, positions=A["pos"], attention_mask=A["mask"], emulate=e)
         tok = W["model.embed_tokens.weight"].float()[A["step_tok"]][:, None]
         l2, _, _ = O.decoder_forward(O._r(tok, e), W, hcfg, cache, positions=A["step_pos"], attention_mask=A["step_mask"], emulate=e)
         return [logits[seen], hn[seen], lp[seen], l2]
@@ -117,8 +135,8 @@ def rows(hip=None):
 
         def layer(W, e, A=A, lcfg=lcfg, S=S):
             cache = O.KVCache()
-            y = O.decoder_layer(A["layer_x"].to(BF).float(), W, 0, lcfg, cache, torch.arange(S)[None], emulate=e)
-            y1 = O.decoder_layer(A["layer_x1"].to(BF).float(), W, 0, lcfg, cache, torch.tensor([[S]]), emulate=e)
+            y = O.decoder_layer(q(A["layer_x"], e), W, 0, lcfg, cache, torch.arange(S)[None], emulate=e)
+            y1 = O.decoder_layer(q(A["layer_x1"], e), W, 0, lcfg, cache, torch.tensor([[S]]), emulate=e)
             return [y, y1]
         three(f"{fx}: one hyper-LoRA decoder layer (prefill output | cached decode-step output)", layer, W)
     return out

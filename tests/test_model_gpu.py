@@ -173,19 +173,19 @@ def test_forward_honours_left_pad_mask_and_position_ids_like_the_reference():
     valid = mask.bool()
     out = um(inputs_embeds=A["embeds_bs2"].cuda(), attention_mask=mask.cuda(), position_ids=pos.cuda(), use_cache=True, output_hidden_states=True)
     assert torch.isfinite(out.logits).all()
-    assert _rel(out.logits.cpu()[valid], A["logits_bs2"][valid], "forward() with left-pad mask + position_ids: logits of valid rows vs fp32 reference") < PB.bound("forward_masked_tiny_llama")
-    assert _rel(out.hidden_states[-1].float().cpu()[valid], A["hidden_bs2"][valid], "forward() with left-pad mask: post-norm hidden of valid rows") < PB.bound("forward_masked_tiny_llama")
+    assert _rel(out.logits.cpu()[valid], A["logits_bs2"][valid], "forward() with left-pad mask + position_ids: logits of valid rows vs fp32 reference") < PB.bound("forward_masked_tiny_llama: left-pad")
+    assert _rel(out.hidden_states[-1].float().cpu()[valid], A["hidden_bs2"][valid], "forward() with left-pad mask: post-norm hidden of valid rows") < PB.bound("forward_masked_tiny_llama: left-pad")
     # without the mask the padded row is far off (the reference: 3.3 on a logit scale of 3.8) - the mask path is really exercised
     plain = um(inputs_embeds=A["embeds_bs2"].cuda())
     assert float((plain.logits.cpu()[1] - A["logits_bs2"][1])[valid[1]].abs().max()) > 0.5
     step = um(input_ids=A["step_tok"][:, None].cuda(), attention_mask=A["step_mask"].cuda(), position_ids=A["step_pos"].cuda(),
               past_key_values=out.past_key_values)
-    assert _rel(step.logits.cpu(), A["step_logits"], "forward() decode shortcut with extended mask + per-row positions vs fp32 reference") < PB.bound("forward_masked_tiny_llama")
+    assert _rel(step.logits.cpu(), A["step_logits"], "forward() decode shortcut with extended mask + per-row positions vs fp32 reference") < PB.bound("forward_masked_tiny_llama: left-pad")
     # the multimodal branch: encoders -> splice -> left pad -> decoder with mask / positions
     mods = _inputs(meta)
     lab = [torch.full_like(A["ids0"], -100), torch.full_like(A["ids1"], -100)]
     mm = um(batch_input_ids=[A["ids0"], A["ids1"]], batch_labels=lab, batch_X_modals=mods, batch_task_names=['avqa', 'avqa'])
-    assert _rel(mm.logits.cpu()[valid], A["logits_bs2"][valid], "forward(batch_input_ids=...) left-padded bs 2 vs fp32 reference") < PB.bound("full_tiny_llama: end to end")      # (encoders in front: the end-to-end row of this stack)
+    assert _rel(mm.logits.cpu()[valid], A["logits_bs2"][valid], "forward(batch_input_ids=...) left-padded bs 2 vs fp32 reference") < PB.bound("multimodal forward_masked_tiny_llama")
 
 
 def test_forward_accepts_any_2d_attention_mask_like_the_reference():
