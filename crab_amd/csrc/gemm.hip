@@ -779,10 +779,11 @@ extern "C" int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc*
     // ---- decode regime, 128 < M <= 256: the batch-tall narrow-panel kernel (gemm_decode.hip); tune 70000 + BN * 100 + S forces
     // a decomposition (80000 + ...: on the 8-wave kernel instead of the producer / consumer one), any other non-zero tune keeps the older kernels (A/B runs), CRAB_DEC_GEMM=0 disables it process-wide
     int dec_bn = 0;
-    // r06: the panel kernel's row floor.  64 < M <= 128 used to take the 128 x 128 LDS-DMA kernel with K slices (two blocks per CU re-reading their
-    // activation tile per weight tile); the panel kernel streams every weight byte once for the whole batch whatever M is (idle row fragments are
-    // masked), which is the better trade from ~80 rows up (scripts/exp/dec_min_rows.py).  CRAB_DEC_MIN_ROWS overrides the floor (A/B runs).
-    static const int dec_min_rows = []() { const char* e = getenv("CRAB_DEC_MIN_ROWS"); return e ? atoi(e) : 128; }();
+    // r06: the panel kernel's row floor is 64 (r02-r05: 128).  64 < M <= 128 used to take the 128 x 128 LDS-DMA kernel with K slices (two blocks per CU,
+    // each re-reading its activation tile per weight tile); the panel kernel streams every weight byte once for the whole batch whatever M is (the row
+    // fragments beyond M are masked).  Measured, 32 layers + lm_head of Llama-2-7B (scripts/exp/dec_min_rows.py, profiles/r06_dec_min_rows.txt):
+    // M = 72: 4.89 -> 4.47 ms, 96: 5.06 -> 4.47, 128: 5.36 -> 4.58.  CRAB_DEC_MIN_ROWS=128 restores the old floor (A/B runs).
+    static const int dec_min_rows = []() { const char* e = getenv("CRAB_DEC_MIN_ROWS"); return e ? atoi(e) : 64; }();
     if (sk_bm == 128 && d->M > dec_min_rows && d->workspace) {
         static const int dec_on = []() { const char* e = getenv("CRAB_DEC_GEMM"); return !(e && e[0] == '0'); }();
         const int nk32 = (d->K + 63) / 64 + (d->A2 ? (d->K2 + 63) / 64 : 0);      // K slots of the panel kernel (64 wide)

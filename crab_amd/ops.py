@@ -135,7 +135,7 @@ def _variant(M: int, N: int, batch: int = 1, K: int = 4096) -> str:
     """Mirror of the tile choice in csrc/gemm.hip (crab_gemm_bf16) - the bucket NAME of the profiler's records."""
     if batch == 1 and 256 < M <= DECODE_MAX_ROWS:
         return "gemm_dec2_kernel"                     # two 256-row groups per block (a workspace is always handed in at these row counts)
-    if batch == 1 and 128 < M <= 256:
+    if batch == 1 and 64 < M <= 256:
         return "gemm_dec_ws_kernel"
     big = ((M + 127) // 128) * ((N + 127) // 128) * batch
     if M <= 64 or N <= 64 or big < 192:

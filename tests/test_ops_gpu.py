@@ -551,10 +551,10 @@ def test_gemm_decode_panel_kernel_two_row_groups(M):
             assert torch.equal(y[lo:hi], part), f"rows {lo}:{hi} of the two-group launch differ from a launch on those rows alone"
 
 
-@pytest.mark.parametrize("M", [129, 200, 256])
+@pytest.mark.parametrize("M", [65, 96, 128, 129, 200, 256])
 @pytest.mark.parametrize("tune", [79601, 79602, 76401, 76404, 79605, 89602, 86404, 91601, 0])
 def test_gemm_decode_panel_kernel(M, tune):
-    """The decode panel kernels (128 < M <= 256: the whole batch x a 96- or 64-wide weight panel per block; tune = 70000 + BN * 100 + K
+    """The decode panel kernels (64 < M <= 256 - r06: the row floor moved from 128 to 64, the row fragments beyond M are masked: the whole batch x a 96- or 64-wide weight panel per block; tune = 70000 + BN * 100 + K
     slices on the producer / consumer kernel, 80000 + ... on the 8-wave kernel, 91601 = 160-wide panels (projections wider than one round of
     96-wide panels), 0 = automatic choice): ragged N (last panel partly outside),
     K not a multiple of the 64-wide slot, a second K segment, every epilogue input (bias, GELU, residual), fp32 and bf16 outputs;
@@ -579,7 +579,7 @@ def test_gemm_decode_panel_kernel(M, tune):
 
 @pytest.mark.parametrize("name,N,K,K2", [("qkv", 12288, 4096, 96), ("o", 4096, 4096, 32), ("gate|up", 22016, 4096, 64), ("down", 4096, 11008, 32),
                                           ("qwen qkv", 4608, 3584, 96), ("qwen gate|up", 37888, 3584, 64), ("qwen down", 3584, 18944, 32)])
-@pytest.mark.parametrize("M", [256, 448])
+@pytest.mark.parametrize("M", [80, 128, 256, 448])
 def test_gemm_decode_panel_kernel_projection_shapes(name, N, K, K2, M):
     """The automatic decomposition on the real decoder projections at M = 256 and M = 448 (two row groups) (Llama-2-7B and Qwen2-7B widths)
     against fp32 arithmetic, and against the older split-K kernels (tune 104: 128x128 tiles, 4 slices) on the same operands."""
@@ -594,6 +594,9 @@ def test_gemm_decode_panel_kernel_projection_shapes(name, N, K, K2, M):
     _cmp(y, z.cpu(), TOL_F32 * 4, f"decode panel kernel, {name} at M={M} (vs torch fp32 matmul on the GPU)")
     y1 = ops.gemm(x[:256], w, x2=x2[:256], w2=w2, out_fp32=True, tune=104)
     _cmp(y[:256], y1.cpu(), TOL_F32, f"decode panel kernel vs 128x128 split-K kernel, {name}")
+    with ops.launch_trace() as tr:
+        ops.gemm(x, w, x2=x2, w2=w2, out_fp32=True)
+    assert tr.launched("gemm_dec2_kernel" if M > 256 else "gemm_dec_ws_kernel") + tr.launched("gemm_dec_kernel<160>") == 1, tr.counts
 
 
 @pytest.mark.parametrize("res_fp32", [True, False])
