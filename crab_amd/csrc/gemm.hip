@@ -637,6 +637,11 @@ static int post_norm(crab_ctx* ctx, void* stream, const crab_gemm_desc* d) {
                                 d->route_r, d->route_U, d->route_ldu, d->route_ucols, d->route_scaling, d->workspace, d->workspace_bytes);
 }
 
+static int crab_dec_min_rows() {
+    static const int v = []() { const char* e = getenv("CRAB_DEC_MIN_ROWS"); const int x = e ? atoi(e) : 64; return x < 16 ? 16 : x; }();
+    return v;
+}
+
 extern "C" int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc* d) {
     if (!ctx) return CRAB_E_INVALID;
     if (d && d->norm_w && (!d->norm_out || d->batch > 1)) return crab_fail(ctx, CRAB_E_INVALID, "gemm: post-norm needs norm_out, no batch");
@@ -729,7 +734,7 @@ extern "C" int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc*
             if (rc || crab_skinny_fuses_rope(d)) return rc;             // M <= 16: the rotation and the cache append ran in the epilogue
             return post_norm(ctx, stream, d);
         }
-        if (want_split) sk_bm = d->M <= 64 ? 64 : 128;
+        if (want_split) sk_bm = (d->M <= 64 && d->M <= crab_dec_min_rows()) ? 64 : 128;      // (above the panel kernel's row floor: its regime, sk_bm = 128)
     }
     if (sk_bm) {
         sk_bn = (sk_bm == 64 && d->N <= 4096) ? 64 : 128;          // narrow outputs: 64-wide tiles double the grid instead of the split
@@ -783,7 +788,7 @@ extern "C" int crab_gemm_bf16(crab_ctx* ctx, void* stream, const crab_gemm_desc*
     // each re-reading its activation tile per weight tile); the panel kernel streams every weight byte once for the whole batch whatever M is (the row
     // fragments beyond M are masked).  Measured, 32 layers + lm_head of Llama-2-7B (scripts/exp/dec_min_rows.py, profiles/r06_dec_min_rows.txt):
     // M = 72: 4.89 -> 4.47 ms, 96: 5.06 -> 4.47, 128: 5.36 -> 4.58.  CRAB_DEC_MIN_ROWS=128 restores the old floor (A/B runs).
-    static const int dec_min_rows = []() { const char* e = getenv("CRAB_DEC_MIN_ROWS"); return e ? atoi(e) : 64; }();
+    const int dec_min_rows = crab_dec_min_rows();
     if (sk_bm == 128 && d->M > dec_min_rows && d->workspace) {
         static const int dec_on = []() { const char* e = getenv("CRAB_DEC_GEMM"); return !(e && e[0] == '0'); }();
         const int nk32 = (d->K + 63) / 64 + (d->A2 ? (d->K2 + 63) / 64 : 0);      // K slots of the panel kernel (64 wide)

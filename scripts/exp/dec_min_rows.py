@@ -26,7 +26,7 @@ def timeit(fn, n=30):
 
 
 print("CRAB_DEC_MIN_ROWS =", os.environ.get("CRAB_DEC_MIN_ROWS", "128 (default)"))
-for M in (72, 80, 96, 112, 128, 160, 256):
+for M in ([int(x) for x in sys.argv[1:]] or [72, 80, 96, 112, 128, 160, 256]):
     tot, row = 0.0, []
     for name, N, K, K2, act in shapes:
         ncopy = max(2, int(700e6 // (N * K * 2)) + 1)
