@@ -57,6 +57,7 @@ HBM_PEAK_GBS = 8000.0
 # the benchmark shape (scripts/pmc_attn.sh).  profiles/r05_pmc_attn_decode_512clips.txt, 512 clips x ctx 830: FETCH_SIZE 3.40178e6 KiB x 2 (the guide's
 # gfx950 correction for wide coalesced reads) + WRITE_SIZE 4096 KiB = 6.9711 GB against 6.9709 GB algorithmic (ratio 1.00002); profiles/r05_pmc_attn_decode.txt,
 # 448 clips: 2.97656e6 KiB x 2 + 3584 KiB = 6.0997 GB against 6.0996 (1.0002; r04: the same; r03 at 256 clips: 3.4856 / 3.4850).  The larger of the two is used.
+# r06 (profiles/r06_pmc_attn_decode.txt, 512 clips x ctx 830, the kernel unchanged): 3.40178e6 KiB x 2 + 4096 KiB again.
 ATTN_DECODE_TRAFFIC_PER_ALGO_BYTE = 1.0002
 
 
@@ -759,7 +760,7 @@ def main():
                      "frac": round(ach / HBM_PEAK_GBS, 4),
                      "traffic": round(d["work"] / d["launches"] * ATTN_DECODE_TRAFFIC_PER_ALGO_BYTE),
                      "algorithmic_bytes_per_launch": round(d["work"] / d["launches"]),
-                     "traffic_source": "PMC ratio from profiles/r05_pmc_attn_decode_512clips.txt / r05_pmc_attn_decode.txt (separate --pmc passes at 512 / 448 clips) x this run's bytes"}
+                     "traffic_source": "PMC ratio from profiles/r06_pmc_attn_decode.txt (= r05_pmc_attn_decode_512clips.txt; separate --pmc passes at 512 clips x ctx 830) x this run's bytes"}
             else:
                 total_launches = d["launches"] * args.steps                            # the instrumented step's launches x the K timed steps
                 ach = d["work"] / (d["ms"] * 1e-3) / 1e12
