@@ -433,6 +433,75 @@ def golden_sharp(me, n_keep=8, new=8, min_margin=0.15, n_cand=800):
     save("sharp_tiny_llama", meta, ids=torch.stack([k[2] for k in keep]), logits=torch.stack([k[3] for k in keep]), margin=torch.stack([k[4] for k in keep]))
 
 
+def golden_avs_loop(me, new=8):
+    """The pixel-task loop of the reference, looped (a batched fixture made by looping the reference): the tiny full model +
+    SegModule, `generate_avs` (models/unified_llama.py:270-361) called ONE SAMPLE AT A TIME like scripts/quick_start.py:270-450 does, on five
+    samples - one clip under three tasks (s4 / avss / ms3: one and 71 class planes) whose six re-pointed <mask_i> ids it emits, and two other clips
+    (which produce fewer than six mask tokens: the ids-only outcome, with the reference's message).  A random decoder never emits real mask
+    tokens, so the six <mask_i> ids are re-pointed at the tokens sample 0 emits at steps 1..6 (as the GPU tests do).  Stored per sample: the ids,
+    whether masks came back, strided samples + checksums of the masks.  Every encoder pass runs BEFORE the first generate() (transformers-5.15
+    hidden-state recorder artefact, see golden_full_qwen): prepare_multimodal_inputs is evaluated for all samples first and its results are handed
+    to generate_avs in the loop - the reference's own function results, in another call order.  The per-step hidden state the reference picks
+    (`output.hidden_states[step][-1]`) is checked to be the POST-final-norm state under this transformers version (lm_head of it = the step's logits)."""
+    model, cfg = build_full_model(me, TINY_DEC)
+    inner = model.get_model()
+    inner.pad_token_id = 2
+    beats = _attach_tiny_encoders(me, inner, D_MODEL)
+    inner.seg_module = me.SegModule(d_model=D_MODEL, vit_image_embedding_dim=128, prompt_embed_dim=256, image_scale_nums=2, mask_decoder_transformer_depth=2,
+                                    token_nums_per_scale=3, avs_query_num=300, num_classes=1, query_generator_num_layers=2, image_size=224, patch_size=14,
+                                    image_embedding_size=16)
+    inner.low_res_mask_size = 112
+    tok = _Tok(TINY_DEC["vocab_size"] - 17)
+    base_vocab = len(tok)
+    model.base_model.model.initialize_MM_tokenizer(tok, mask_token_nums=6, use_vqgan=False)
+    model.eval()
+    alias = [("base_model.model.model.audio_encoder.audio_encoder." + c, ["base_model.model.model.audio_encoder.audio_encoder." + o for o in os_])
+             for c, os_ in beats_alias(beats)]
+    table = load_synth(model, "", alias_groups=alias)
+    um = model.base_model.model
+    sp = um.SPECIAL_TOKEN_2_IDS
+    spec = [(3, 24, 's4'), (3, 24, 'avss'), (3, 24, 'ms3'), (5, 21, 's4'), (6, 27, 'avss')]          # (clip, prompt tokens, task)
+    samples = []
+    for c, nt, task in spec:
+        ids = synth.synth_prompt_ids(nt, base_vocab, dict(sp), seed=SEED, clip=c)
+        for a_, b_ in (("<video_start>", "<image_start>"), ("<video>", "<image>"), ("<video_end>", "<image_end>")):
+            ids[ids == sp[a_]] = sp[b_]
+        mods = {'<image>': synth.synth_video(1, seed=SEED, clip=c), '<audio>': synth.synth_audio(3, 98, seed=SEED, clip=c), '<mask>': torch.zeros(1, 224, 224)}
+        samples.append(dict(batch_input_ids=[ids], batch_labels=[torch.full_like(ids, -100)], batch_X_modals=[mods], batch_task_names=[task]))
+    real_prepare = um.prepare_multimodal_inputs
+    prepared = [real_prepare(batch_input_ids=s_["batch_input_ids"], batch_labels=s_["batch_labels"], batch_X_modals=s_["batch_X_modals"],
+                             return_multi_scale_features=True, return_gt_mask=True, batch_task_names=s_["batch_task_names"]) for s_ in samples]
+    gen_kw = dict(use_cache=True, max_new_tokens=new, do_sample=False, pad_token_id=2, eos_token_id=None)
+    r0 = super(type(um), um).generate(inputs_embeds=prepared[0]["inputs_embeds"], output_hidden_states=True, output_logits=True, return_dict_in_generate=True, **gen_kw)
+    for st in range(new):                                   # hs[step][-1] is the post-final-norm state: lm_head of its last row reproduces the step's logits
+        d_ = float((um.lm_head(r0.hidden_states[st][-1][:, -1]) - r0.logits[st]).abs().max())
+        assert d_ < 1e-4, (st, d_)
+    row = r0.sequences[0].tolist()
+    for i in range(6):
+        sp[f'<mask_{i}>'] = row[1 + i]
+    out, metas = {}, []
+    for i, s_ in enumerate(samples):
+        um.prepare_multimodal_inputs = (lambda i=i: (lambda **kw: prepared[i]))()
+        try:
+            r = um.generate_avs(**s_, **gen_kw)
+        finally:
+            um.prepare_multimodal_inputs = real_prepare
+        out[f"ids_{i}"] = r["output_ids"]
+        has = "pred_masks" in r
+        m = dict(clip=spec[i][0], prompt_tokens=spec[i][1], task=spec[i][2], has_masks=has)
+        if has:
+            pm = r["pred_masks"][0]
+            m["shape"], m["cks"] = list(pm.shape), synth.checksum(pm)
+            out[f"mask_sub_{i}"] = (pm[:, 3::8, 5::8] if pm.shape[0] > 1 else pm[:, 1::2, ::2]).contiguous()
+        metas.append(m)
+        print("avs_loop sample", i, m["task"], "ids", r["output_ids"][0].tolist(), "masks", has)
+    assert sum(m["has_masks"] for m in metas) >= 3 and not all(m["has_masks"] for m in metas), metas
+    meta = dict(seed=SEED, dec=TINY_DEC, clip=TINY_CLIP, select=TINY_CLIP_SELECT, beats=TINY_BEATS, qf=TINY_QF, d_model=D_MODEL, base_vocab=base_vocab,
+                pad_token_id=2, special=dict(sp), table=table, new_tokens=new, samples=metas, t_a=3, l_a=98,
+                note="mask ids re-pointed at the tokens sample 0 emits at steps 1..6")
+    save("avs_loop_tiny", meta, **out)
+
+
 def golden_holes(me):
     """forward() with a 2-D attention_mask that is NOT left padding (HF's mask utilities accept any mask - the padding
     mask is AND-ed with the causal one): the hyper-LoRA tiny Llama decoder alone on seeded embeddings [2, 21, D]; row 0 has two interior

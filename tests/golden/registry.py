@@ -27,6 +27,7 @@ GENERATORS = {
     "id_stats": ("ref", "golden_id_stats", ["id_stats_tiny_llama"]),
     "holes": ("ref", "golden_holes", ["forward_holes_tiny_llama"]),
     "sharp": ("ref", "golden_sharp", ["sharp_tiny_llama"]),
+    "avs_loop": ("ref", "golden_avs_loop", ["avs_loop_tiny"]),
     "metrics": ("ref", "golden_metrics", ["seg_metrics"]),
     # full-width, shallow (r06): the benchmarked kernel instantiations pinned to the reference
     "llama_layer_wide": ("ref", "golden_llama_layer_wide", ["llama_layer_wide"]),

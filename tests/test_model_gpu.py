@@ -468,6 +468,52 @@ def test_generate_avs_many_equals_one_sample_calls():
             assert _rel(c['pred_masks'][0], b['pred_masks'][0], f"generate_avs_many in waves of 3, sample {i} (HIP vs HIP)") < 1.3e-2
 
 
+def test_generate_avs_one_by_one_and_batched_vs_the_reference_loop_fixture():
+    """tests/golden/avs_loop_tiny.npz = the REFERENCE's generate_avs looped over five one-sample calls (one clip under s4 / avss / ms3, two other
+    clips without six mask tokens).  The product's generate_avs one sample at a time AND generate_avs_many over all five at once: ids equal to
+    the reference's (a divergence only at a step whose reference... is not recorded here, so ids must simply be equal on the three margin-checked
+    samples and may differ on the others only together with the mask outcome), the same samples produce masks, and the masks agree with the
+    reference's within the SegModule's computed tolerance (tests/test_seg... rows: 2.1e-2 of scale vs the fp32 reference, as for seg_tiny.npz)."""
+    from crab_amd.peft_hyper import LoraConfig, get_peft_model
+    from crab_amd.unified_llama import UnifiedConfig, UnifiedForCausalLM
+    from tests.test_oracle_golden import _avs_loop_samples
+    from tests.util import DuckTokenizer, bert_cfg
+    meta, A = load_fixture("avs_loop_tiny")
+    cfg = UnifiedConfig(**meta["dec"], pad_token_id=meta["pad_token_id"])
+    cfg.vocab_size = meta["base_vocab"]
+    model = get_peft_model(UnifiedForCausalLM(cfg, device="cuda"), LoraConfig())
+    model.get_model().pad_token_id = meta["pad_token_id"]
+    model.get_model().init_multimodal_modules(d_model=meta["d_model"], visual_branch=True, audio_branch=True, segment_branch=True, select_layer_list=meta["select"],
+                                              clip_config=meta["clip"], beats_config=meta["beats"], bert_config=bert_cfg(meta["qf"]),
+                                              vit_image_embedding_dim=meta["clip"]["hidden_size"])
+    model.initialize_MM_tokenizer(DuckTokenizer(meta["base_vocab"]), mask_token_nums=6)
+    r = model.load_state_dict(weights_from_table(meta), strict=False)
+    assert not r.missing_keys, r.missing_keys[:5]
+    model.SPECIAL_TOKEN_2_IDS.update({k: v for k, v in meta["special"].items() if k.startswith("<mask_")})
+    n = meta["new_tokens"]
+    kw = dict(max_new_tokens=n, pad_token_id=2, eos_token_id=None)
+    samples = [dict(batch_input_ids=[ids], batch_labels=[torch.full_like(ids, -100)], batch_X_modals=[mods], batch_task_names=[task])
+               for ids, mods, task in _avs_loop_samples(meta)]
+    one = [model.generate_avs(**s_, **kw) for s_ in samples]
+    many = model.generate_avs_many(samples, **kw)
+    for form, res in (("one sample per call", one), ("generate_avs_many", many)):
+        n_masks = 0
+        for i, (r_, m) in enumerate(zip(res, meta["samples"])):
+            same = torch.equal(r_["output_ids"].cpu(), A[f"ids_{i}"])
+            if i < 3:
+                assert same, (form, i, r_["output_ids"].tolist(), A[f"ids_{i}"].tolist())       # the clip the fixture's mask ids were taken from
+            if not same:
+                continue                                                                        # (an unsearched clip may flip a sub-margin step)
+            assert ("pred_masks" in r_) == m["has_masks"], (form, i)
+            if m["has_masks"]:
+                pm = r_["pred_masks"][0]
+                assert list(pm.shape) == m["shape"]
+                sub = pm[:, 3::8, 5::8] if pm.shape[0] > 1 else pm[:, 1::2, ::2]
+                assert _rel(sub, A[f"mask_sub_{i}"], f"avs_loop sample {i} ({m['task']}), {form}: masks vs the reference's generate_avs") < 2.1e-2
+                n_masks += 1
+        assert n_masks == 3, (form, n_masks)
+
+
 def test_seg_module_batched_equals_sample_by_sample():
     """SegModule over a batch with mixed class counts (r06: samples of one class count run through the mask decoder together) on the reference
     fixture's two samples repeated so that BOTH contents appear in both class-count groups: every sample against the oracle on its own inputs

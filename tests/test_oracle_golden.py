@@ -372,3 +372,43 @@ def test_sharp_margin_clips_ids_and_logits():
             Ws = stored_params(W)
             emb = O.prepare_multimodal_inputs([ids], [{k: v.to(torch.bfloat16).float() for k, v in mods[0].items()}], Ws, cfg, torch.bfloat16)["inputs_embeds"]
             assert torch.equal(O.greedy_generate(emb, Ws, cfg.decoder, n, emulate=torch.bfloat16)[0][0], A["ids"][i]), "storage emulation flips an id"
+
+
+def _avs_loop_samples(meta):
+    """The five one-sample calls of tests/golden/avs_loop_tiny.npz, regenerated (make_golden.golden_avs_loop)."""
+    from crab_amd import synth
+    sp = meta["special"]                                    # as recorded: the six <mask_i> ids re-pointed at the tokens sample 0 emits
+    out = []
+    for m in meta["samples"]:
+        base = dict(sp)
+        ids = synth.synth_prompt_ids(m["prompt_tokens"], meta["base_vocab"], base, seed=meta["seed"], clip=m["clip"])
+        for a_, b_ in (("<video_start>", "<image_start>"), ("<video>", "<image>"), ("<video_end>", "<image_end>")):
+            ids[ids == sp[a_]] = sp[b_]
+        mods = {'<image>': synth.synth_video(1, seed=meta["seed"], clip=m["clip"]), '<audio>': synth.synth_audio(meta["t_a"], meta["l_a"], seed=meta["seed"], clip=m["clip"])}
+        out.append((ids, mods, m["task"]))
+    return out
+
+
+def test_avs_loop_fixture_generate_avs_one_sample_at_a_time():
+    """tests/golden/avs_loop_tiny.npz (r06): the reference's generate_avs (models/unified_llama.py:270-361) looped over five one-sample calls - ids,
+    which samples produce masks (six mask tokens) and which do not, the masks of one clip under three tasks (1 and 71 class planes).  The oracle
+    pipeline (prepare_multimodal_inputs -> greedy loop with per-step post-norm hidden states -> per-row picks -> seg_module) reproduces all of it."""
+    from crab_amd import synth
+    meta, A = load_fixture("avs_loop_tiny")
+    W = O.strip_peft_prefix(weights_from_table(meta))
+    cfg = _full_cfg(meta)
+    n = meta["new_tokens"]
+    seg_ids = {meta["special"][f"<mask_{i}>"] for i in range(6)}
+    for i, ((ids, mods, task), m) in enumerate(zip(_avs_loop_samples(meta), meta["samples"])):
+        inp = O.prepare_multimodal_inputs([ids], [mods], W, cfg)
+        oids, _, ohid = O.greedy_generate(inp["inputs_embeds"], W, cfg.decoder, n, pad_token_id=2, return_hidden=True)
+        assert torch.equal(oids, A[f"ids_{i}"]), i
+        row = oids[0].tolist()
+        picks = [j for j in range(n - 1) if row[j + 1] in seg_ids]
+        assert (len(picks) >= 6) == m["has_masks"], (i, picks)
+        if m["has_masks"]:
+            feats = O.visual_encoder(mods['<image>'][None], W, cfg.clip)
+            pm = O.seg_module(torch.stack([ohid[:, j] for j in picks[-6:]], 1), feats[:2], [task], W)[0]
+            assert list(pm.shape) == m["shape"]
+            _close(pm[:, 3::8, 5::8] if pm.shape[0] > 1 else pm[:, 1::2, ::2], A[f"mask_sub_{i}"], 5e-4)
+            assert abs(synth.checksum(pm) - m["cks"]) <= 2e-4 * max(1.0, abs(m["cks"]))
