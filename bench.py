@@ -331,7 +331,7 @@ def operating_points(model, um, args, eos, t_step):
     # needs the Qwen2 variant and the CPU sample: the first group leaves room for the CPU sample only (the Qwen2 block is itself admitted against what
     # is left), the second group leaves room for both
     gco = max(2, min(args.clips, 256) // 8)      # r06: 32 eval batches = 256 rows (r05: 56 = 448 rows; the point then cost 2 x 15 s and pushed the later ones out of the budget)
-    nb = min(args.clips, 128)                    # the two points that need their own input synthesis (0.04 s per clip on the host) run at 128 clips
+    nb = min(args.clips, 96)                     # the two points that need their own input synthesis (0.04 s per clip on the host) run at 96 clips (r06 probe at 128: 15.5 s each)
     A, Bq = CPU_RESERVE_S, CPU_RESERVE_S + QWEN_RESERVE_S
     n = admit("single_clip", 1.0, 1, A)
     if n:
