@@ -1158,6 +1158,62 @@ def golden_llama_layer_wide():
     _wide_layer(layer, c["hidden_size"], 32, 32, 128, "llama_layer_wide", dict(seed=SEED, cfg=c, table=table), Cache(), SEED + 101, WIDE_SHAPE["llama"])
 
 
+DECODE_REGIME_SHAPE = (512, 8)                      # sequences x prompt rows of the decode-regime fixture
+
+
+def decode_regime_seqs(B=DECODE_REGIME_SHAPE[0]):
+    """The sequences whose outputs the decode-regime fixture stores: 0 .. 7 (the reference's own eval batch) and every 13th after them - so that a
+    test may run ANY first-B' sequences (1, 8, 48, 100, 256, 512: one per kernel regime of the decode projections) and find stored rows among them."""
+    return list(range(8)) + list(range(8 + 5, B, 13)) + ([B - 1] if (B - 1 - 13) % 13 else [])
+
+
+def golden_llama_decode_regimes_wide():
+    """ONE reference run that pins every decode regime of the projections (beyond the five instantiations it names): the
+    hyper-LoRA Llama-2-7B-wide layer of golden_llama_layer_wide on 512 independent sequences of 8 prompt rows, then ONE cached decode step for all
+    512.  Sequences do not interact, so the stored rows of the first B' sequences are the reference values of a B'-row decode step whatever B' is:
+    the GPU test decodes B' = 1 / 8 (gemm_skinny_dma_kernel + rowfin tails + the fused small-batch attention), 48 (64-row split-K), 100 (panel
+    kernel above the 64-row floor), 256 (gemm_dec_ws_kernel) and 512 rows (gemm_dec2_kernel, the benchmark's regime) against them."""
+    import types as _t
+    import transformers.utils.import_utils as iu
+    if not hasattr(iu, "is_torch_fx_available"):
+        iu.is_torch_fx_available = lambda: False
+    import models.modeling_llama as ML
+    from peft_hyper.tuners.lora import Linear as HyperLinear
+    c = WIDE_LLAMA
+    cfg = _t.SimpleNamespace(**c, max_position_embeddings=64, rope_scaling=None, attention_bias=False, attention_dropout=0.0, hidden_act="silu",
+                             pretraining_tp=1, _attn_implementation="eager")
+    layer = ML.LlamaDecoderLayer(cfg, 0)
+    for mod, names in ((layer.self_attn, ("q_proj", "k_proj", "v_proj", "o_proj")), (layer.mlp, ("gate_proj", "up_proj", "down_proj"))):
+        for n in names:
+            old = getattr(mod, n)
+            setattr(mod, n, HyperLinear(old.in_features, old.out_features, r=8, lora_alpha=16, lora_nums=3, lora_dropout=0.05, bias=False))
+    layer.eval()
+    table = load_synth(layer, "model.layers.0.")                     # the same weights as llama_layer_wide.npz (same names, same seed)
+    B, S = DECODE_REGIME_SHAPE
+    D = c["hidden_size"]
+    x, xs = wide_inputs(D, SEED + 103, B, S, steps=1)
+    mask = torch.full((S, S), torch.finfo(torch.float32).min).triu(1)[None, None].expand(B, 1, S, S)
+
+    class Cache:
+        def __init__(self):
+            self.k, self.v = None, None
+
+        def get_usable_length(self, new_len, layer_idx=0):
+            return 0 if self.k is None else self.k.shape[-2]
+
+        def update(self, k, v, layer_idx, cache_kwargs=None):
+            self.k = k if self.k is None else torch.cat([self.k, k], dim=-2)
+            self.v = v if self.v is None else torch.cat([self.v, v], dim=-2)
+            return self.k, self.v
+    cache = Cache()
+    y = layer(x, attention_mask=mask, position_ids=torch.arange(S)[None].expand(B, S), past_key_value=cache, use_cache=True)[0][0]
+    y1 = layer(xs[0], attention_mask=torch.zeros(B, 1, 1, S + 1), position_ids=torch.full((B, 1), S), past_key_value=cache, use_cache=True)[0][0]
+    seqs = torch.tensor(decode_regime_seqs(B))
+    print(f"llama_decode_regimes_wide: {len(seqs)} of {B} sequences stored; |y1| max {float(y1.abs().max()):.3f}")
+    save("llama_decode_regimes_wide", dict(seed=SEED, cfg=c, table=table, B=B, S=S, steps=1, xseed=SEED + 103),
+         seqs=seqs, y_last=y[seqs, -1], y_step=y1[seqs, 0])
+
+
 def golden_qwen_layer_wide():
     """models/qwen/modeling_qwen2.py:712-809 (Qwen2DecoderLayer, eager GQA attention with q/k/v bias :202-317) with hyper-LoRA projections, at
     Qwen2-7B widths (3584 / 18944, 28 query heads / 4 kv heads x 128, theta 1e6, eps 1e-6)."""

@@ -32,6 +32,7 @@ GENERATORS = {
     # full-width, shallow (r06): the benchmarked kernel instantiations pinned to the reference
     "llama_layer_wide": ("ref", "golden_llama_layer_wide", ["llama_layer_wide"]),
     "qwen_layer_wide": ("ref", "golden_qwen_layer_wide", ["qwen_layer_wide"]),
+    "llama_decode_regimes_wide": ("ref", "golden_llama_decode_regimes_wide", ["llama_decode_regimes_wide"]),
     "clip_wide": ("ref", "golden_clip_wide", ["clip_wide"]),
     "beats_wide": ("ref", "golden_beats_wide", ["beats_wide"]),
     "projectors_wide": ("ref", "golden_projectors_wide", ["projectors_wide"]),
@@ -45,7 +46,7 @@ GENERATORS = {
 }
 
 # `make_golden.py fullwidth` = the six full-width generators
-GROUPS = {"fullwidth": ["llama_layer_wide", "qwen_layer_wide", "clip_wide", "beats_wide", "projectors_wide", "seg_wide"]}
+GROUPS = {"fullwidth": ["llama_layer_wide", "qwen_layer_wide", "llama_decode_regimes_wide", "clip_wide", "beats_wide", "projectors_wide", "seg_wide"]}
 
 
 def fixtures(optional: bool = False):

@@ -127,6 +127,74 @@ def test_qwen_layer_wide_vs_reference_fixture():
                 decode_kernels=("attn_decode_gqa_kernel<128,7>", "splitk_epilogue_rope_kernel"))
 
 
+@pytest.mark.parametrize("Bp,expect", [(1, ("gemm_skinny_dma_kernel", "rowfin_apply_kernel", "attn_decode_rope_kernel<128>")),
+                                       (8, ("gemm_skinny_dma_kernel", "rowfin_apply_kernel", "attn_decode_rope_kernel<128,32>")),
+                                       (48, ("gemm_bt_kernel(split-K)", "attn_decode_kernel<128>", "splitk_epilogue_rope_kernel")),
+                                       (100, ("gemm_dec_ws_kernel", "attn_decode_kernel<128>", "splitk_epilogue_norm_kernel")),
+                                       (256, ("gemm_dec_ws_kernel", "attn_decode_kernel<128>", "splitk_epilogue_norm_kernel")),
+                                       (512, ("gemm_dec2_kernel", "attn_decode_kernel<128>", "splitk_epilogue_norm_kernel"))])
+def test_llama_decode_regimes_vs_reference_fixture(Bp, expect):
+    """EVERY decode regime of the projections against the SAME reference run (tests/golden/llama_decode_regimes_wide.npz: the Llama-2-7B-wide
+    hyper-LoRA layer on 512 independent sequences of 8 prompt rows + one cached decode step): the first Bp sequences are prefilled and decoded
+    as a Bp-row batch - 1 and 8 rows (the reference's own batch sizes: LDS-DMA skinny kernel, row-owning tails, fused small-batch attention), 48
+    (64-row split-K kernels), 100 (the panel kernel above its 64-row floor, r06), 256 (panel kernel) and 512 rows (two-row-group panel kernel: the
+    benchmark's regime) - and the stored sequences among them are compared with the reference's values; bound = 1.5 x max(operand floor,
+    storage emulation) computed on those sequences; the launch trace proves the regime."""
+    from crab_amd import ops
+    from crab_amd.peft_hyper import LoraConfig, get_peft_model
+    from crab_amd.unified_llama import UnifiedConfig, UnifiedForCausalLM
+    from oracle import crab_oracle as O
+    from tests.util import stored_params, wide_layer_inputs
+    meta, A = load_fixture("llama_decode_regimes_wide")
+    c = dict(meta["cfg"])
+    c.update(num_hidden_layers=1, vocab_size=320, pad_token_id=2)
+    model = get_peft_model(UnifiedForCausalLM(UnifiedConfig(**c), device="cuda"), LoraConfig())
+    Wt = weights_from_table(meta)
+    r = model.load_state_dict({"base_model.model." + k_: v for k_, v in Wt.items()}, strict=False)
+    assert not r.unexpected_keys
+    eng = model.base_model.model._engine
+    x, xs = wide_layer_inputs(meta)
+    _, S, D = x.shape
+    stored = A["seqs"].tolist()
+    mine = [b for b in stored if b < Bp]
+    at = [stored.index(b) for b in mine]
+    assert len(mine) >= 1
+    # ---- the oracle on the stored sequences (fp32 must reproduce the fixture; floor and emulation give the bound)
+    dev = _odev()
+    ocfg = O.DecoderConfig(**{**meta["cfg"], "num_hidden_layers": 1, "vocab_size": 320})
+    runs = {}
+    for name, mode, W in (("fp32", None, Wt), ("floor", O.OPERANDS, Wt), ("emu", BF, stored_params(Wt))):
+        Wd = {k_: v.to(dev) for k_, v in W.items()}
+        cache = O.KVCache()
+        y = O.decoder_layer(x[mine].to(dev), Wd, 0, ocfg, cache, torch.arange(S, device=dev)[None].expand(len(mine), S), emulate=mode)[:, -1].cpu()
+        y1 = O.decoder_layer(xs[0][mine].to(dev), Wd, 0, ocfg, cache, torch.full((len(mine), 1), S, device=dev), emulate=mode)[:, 0].cpu()
+        runs[name] = (y, y1)
+        del Wd
+    assert _err(runs["fp32"][0], A["y_last"][at]) < 5e-4 and _err(runs["fp32"][1], A["y_step"][at]) < 5e-4
+    # ---- HIP: prefill of the first Bp sequences, then ONE decode step of Bp rows on a decode workspace (what generate() decodes with)
+    Tmax = 64
+    kc, vc = eng.alloc_cache(Bp, Tmax)
+    eng.prefill(x[:Bp].to(BF).cuda(), kc, vc, b0=0, all_logits=True)
+    ws = eng._workspace(Bp * S)
+    rows = torch.tensor([b * S + S - 1 for b in mine], device="cuda")
+    y_hip = ws.x[:Bp * S].float()[rows].cpu()
+    sc = A["y_last"].abs().max().item()
+    _bounded(f"llama decode regimes: prefill of {Bp} x {S} rows, last rows vs the reference fixture", _err(y_hip, A["y_last"][at]), _err(runs["floor"][0], A["y_last"][at]),
+             _err(runs["emu"][0], A["y_last"][at]), sc)
+    wsd = eng._workspace(Bp, 0, decode=True)
+    ops.cast_rows(xs[0][:Bp, 0].to(BF).cuda().contiguous(), wsd.x, Bp, D)
+    posd = torch.full((1,), S, device="cuda", dtype=torch.int32)
+    with ops.launch_trace() as tr:
+        xo, _ = eng._layers(wsd, Bp, 1, kc, vc, 0, Tmax, 0, posd, None)
+    for k_ in expect:
+        assert tr.launched(k_) >= 1, (Bp, k_, tr.counts)
+    got = xo[:Bp].float()[torch.tensor(mine, device="cuda")].cpu()
+    _bounded(f"llama decode regimes: decode step of {Bp} rows vs the reference fixture", _err(got, A["y_step"][at]), _err(runs["floor"][1], A["y_step"][at]),
+             _err(runs["emu"][1], A["y_step"][at]), A["y_step"].abs().max().item(), kernels=tr.counts)
+    del model, eng, kc, vc
+    torch.cuda.empty_cache()
+
+
 def test_clip_wide_vs_reference_fixture():
     """CLIP ViT-L/14 widths, 36 frames x 257 tokens (M = 9252: every projection on the ring kernel, K = 1024 and 4096; head_dim 64 flash forward)."""
     from crab_amd import ops
