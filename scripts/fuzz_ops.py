@@ -1,5 +1,6 @@
 """Differential fuzz of the row kernels around the GEMMs (RMSNorm / LayerNorm on bf16 and fp32 rows, embedding to bf16 / fp32 with skipped and clamped
-ids, row casts and copies, the stand-alone hyper-LoRA router, the SwiGLU pass, arg-max with a suppressed id) against torch, every output inside
+ids, row casts and copies, the stand-alone hyper-LoRA router, the SwiGLU pass, arg-max with a suppressed id; r06: the fp32 quantiser, the split-operand GEMM
+and the fp32 GroupNorm of the precise VQGAN encoder) against torch, every output inside
 sentinel guard rows / columns.   python scripts/fuzz_ops.py [cases] [seed]"""
 import os, random, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -25,7 +26,7 @@ def intact(buf, N):
 
 for case in range(NCASE):
     g = torch.Generator(device="cuda").manual_seed(case)
-    kind = rng.choice(["rmsnorm", "layernorm", "embedding", "cast", "copy", "route", "swiglu", "argmax"])
+    kind = rng.choice(["rmsnorm", "layernorm", "embedding", "cast", "copy", "route", "swiglu", "argmax", "vq_nearest", "split_gemm", "groupnorm_f32"])
     M = rng.choice([1, 2, 3, 5, 16, 17, 63, 64, 65, 256, 257, 700, 3001])
     gap = rng.choice([0, 8, 16])
     desc, err, tol, ok_guard = f"case {case}: {kind} M={M}", 0.0, 0.0, True
@@ -98,6 +99,43 @@ for case in range(NCASE):
             err, tol = float((out.float() - ref).abs().max()) / (float(ref.abs().max()) + 1e-9), 1.0e-2
             desc += f" I={I}"
             ok_guard = intact(buf, I)
+        elif kind == "vq_nearest":
+            # r06: the fp32 quantiser (crab_vq_nearest_f32) against torch's fp32 expression of quantize.py:286-290; ids equal wherever the top-2 gap is above fp32 noise
+            D, N = rng.choice([4, 32, 64, 256]), rng.choice([1, 63, 64, 65, 1000, 16384])
+            Mq = min(M, 700)
+            e = torch.randn(N, D, device="cuda", generator=g)
+            z = torch.randn(Mq, D, device="cuda", generator=g)
+            if N > 8:
+                e[N // 2] = e[1]                                        # a duplicate entry: the first index must win
+                z[0] = e[1]
+            idx = ops.vq_nearest_f32(z, e, ops.row_sqnorm_f32(e), offset=7)
+            d = (z ** 2).sum(1, keepdim=True) + (e ** 2).sum(1) - 2 * z @ e.t()
+            want = torch.argmin(d, 1) + 7
+            top2 = d.topk(min(2, N), dim=1, largest=False).values
+            near = (top2[:, -1] - top2[:, 0]) < 1e-4 * (1 + d.abs().max()) if N > 1 else torch.zeros(Mq, dtype=torch.bool, device="cuda")
+            err = float(((idx != want) & ~near).sum()) + (0.0 if N <= 8 or int(idx[0]) == 1 + 7 else 1.0)
+            tol = 0.0
+            desc += f" rows={Mq} N={N} D={D}"
+        elif kind == "split_gemm":
+            # r06: x . w^T through split-bf16 operands (hi.hi + lo.hi + hi.lo over 3K) against an fp64 product
+            K_, N_ = rng.choice([8, 24, 200, 1152]), rng.choice([8, 96, 257])
+            Ms = min(M, 700)
+            x = torch.randn(Ms, K_, device="cuda", generator=g) * rng.choice([0.1, 1.0, 20.0])
+            w = torch.randn(N_, K_, device="cuda", generator=g) * K_ ** -0.5
+            y = ops.gemm(ops.split3(x, 0), ops.split3(w, 1), out_fp32=True)
+            ref = (x.double() @ w.double().t()).float()
+            err, tol = float((y - ref).abs().max()) / (float(ref.abs().max()) + 1e-9), 5e-5
+            desc += f" rows={Ms} N={N_} K={K_}"
+        elif kind == "groupnorm_f32":
+            Cg, HW, Bn = rng.choice([32, 64, 128, 512]), rng.choice([1, 7, 64, 256, 1000]), rng.choice([1, 2, 3])
+            x = torch.randn(Bn * HW, Cg, device="cuda", generator=g) * rng.choice([0.3, 2.0]) + rng.choice([0.0, 1.0])
+            wt, bs = 1 + 0.2 * torch.randn(Cg, device="cuda", generator=g), 0.1 * torch.randn(Cg, device="cuda", generator=g)
+            sw = rng.random() < 0.5
+            y = ops.groupnorm_f32(x, Bn, HW, 32, wt, bs, 1e-6, sw)
+            r_ = F.group_norm(x.view(Bn, HW, Cg).permute(0, 2, 1), 32, wt, bs, 1e-6).permute(0, 2, 1).reshape(Bn * HW, Cg)
+            ref = r_ * torch.sigmoid(r_) if sw else r_
+            err, tol = float((y - ref).abs().max()) / (float(ref.abs().max()) + 1e-9), 2e-5
+            desc += f" B={Bn} HW={HW} C={Cg} swish={sw}"
         else:
             V = rng.choice([5, 320, 32017, 152064])
             Mv = min(M, 300)
