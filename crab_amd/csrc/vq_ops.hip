@@ -37,14 +37,22 @@ __global__ __launch_bounds__(256) void groupnorm_stats_kernel(const void* __rest
     __shared__ float cs[GN_MAXC], cq[GN_MAXC];
     const int tid = threadIdx.x, b = blockIdx.y, ch = blockIdx.x;
     const int p0 = ch * rows_per_chunk, p1 = min(HW, p0 + rows_per_chunk);
-    float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+    float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f}, k[4] = {0.f, 0.f, 0.f, 0.f};
     const long base = (long)b * HW * C;
+    const int cpg_ = C / G;
+    // r06 (found by scripts/fuzz_ops.py on groups of 2..4 values): sums are taken of x - k, k = the group's first value of the image, so that
+    // var = E[(x-k)^2] - E[x-k]^2 does not cancel when the group's spread is small against its mean (shifted-data form; k is the same for every chunk)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = tid + j * 256;
+        if (c < C) k[j] = XF ? ((const float*)x_)[base + (c / cpg_) * cpg_] : bf2f(((const bf16_t*)x_)[base + (c / cpg_) * cpg_]);
+    }
     for (int p = p0; p < p1; ++p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int c = tid + j * 256;
             if (c < C) {
-                const float v = XF ? ((const float*)x_)[base + (long)p * C + c] : bf2f(((const bf16_t*)x_)[base + (long)p * C + c]);
+                const float v = (XF ? ((const float*)x_)[base + (long)p * C + c] : bf2f(((const bf16_t*)x_)[base + (long)p * C + c])) - k[j];
                 s[j] += v; q[j] += v * v;
             }
         }
@@ -58,6 +66,9 @@ __global__ __launch_bounds__(256) void groupnorm_stats_kernel(const void* __rest
         for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { a += cs[c]; bq += cq[c]; }
         float* o = partial + (((long)b * gridDim.x + ch) * G + tid) * 2;
         o[0] = a; o[1] = bq;
+        if (ch == 0)                                     // the shift, after the partial sums of all images: [B * chunks * G * 2 | B * G]
+            partial[(long)gridDim.y * gridDim.x * G * 2 + (long)b * G + tid] =
+                XF ? ((const float*)x_)[base + tid * cpg] : bf2f(((const bf16_t*)x_)[base + tid * cpg]);
     }
 }
 
@@ -75,7 +86,7 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const bf16_t* __re
         const float n = (float)HW * (float)(C / G);
         const float m = a / n;
         const float var = fmaxf(q / n - m * m, 0.f);
-        mean_s[tid] = m; rstd_s[tid] = rsqrtf(var + eps);
+        mean_s[tid] = m + partial[(long)gridDim.y * chunks * G * 2 + (long)b * G + tid]; rstd_s[tid] = rsqrtf(var + eps);
     }
     __syncthreads();
     const long v8 = (long)blockIdx.x * 256 + tid;
@@ -320,7 +331,7 @@ __global__ __launch_bounds__(256) void groupnorm_f32_apply_kernel(const float* _
         const float n = (float)HW * (float)(C / G);
         const float m = a / n;
         const float var = fmaxf(q / n - m * m, 0.f);
-        mean_s[tid] = m; rstd_s[tid] = rsqrtf(var + eps);
+        mean_s[tid] = m + partial[(long)gridDim.y * chunks * G * 2 + (long)b * G + tid]; rstd_s[tid] = rsqrtf(var + eps);
     }
     __syncthreads();
     const long i = (long)blockIdx.x * 256 + tid;
@@ -378,7 +389,7 @@ extern "C" int crab_im2col3x3_strided(crab_ctx* ctx, void* stream, const void* i
 extern "C" int64_t crab_groupnorm_workspace(int B, int HW, int G) {
     int chunks = (HW + 63) / 64;
     if (chunks > 64) chunks = 64;
-    return (int64_t)B * chunks * G * 2 * (int64_t)sizeof(float);
+    return ((int64_t)B * chunks * G * 2 + (int64_t)B * G) * (int64_t)sizeof(float);          // partial {sum, sum of squares} per chunk + the shift per (image, group)
 }
 
 extern "C" int crab_groupnorm_p(crab_ctx* ctx, void* stream, const void* x, void* out, int B, int HW, int C, int G, float eps, const void* weight,

@@ -558,7 +558,8 @@ int crab_kaldi_fbank(crab_ctx* ctx, void* stream, const float* wave, int64_t ldw
  *  im2col3x3_strided : out[(b,oy,ox), (ky*3+kx)*C + c] = in[b, oy*stride+ky-pad_top, ox*stride+kx-pad_left, c] (0 outside);
  *                      Downsample (modules.py:66-72: F.pad (0,1,0,1) + Conv2d(k3, s2)) is stride 2, pads 0.
  *  groupnorm         : GroupNorm(G, C, eps) over (h*w, C/G) per (b, g) (+ x*sigmoid(x) when swish): Normalize / nonlinearity
- *                      (modules.py:29-35); workspace = crab_groupnorm_workspace bytes (fixed-order partial sums).
+ *                      (modules.py:29-35); workspace = crab_groupnorm_workspace bytes (fixed-order partial sums of x - k, k = the group's first
+ *                      value of the image: the shifted-data variance, exact to fp32 rounding for groups of any size and spread; may run in place).
  *  upsample_nearest2x: F.interpolate(scale_factor=2, mode="nearest") (modules.py:50).
  *  softmax_rows      : out bf16 = softmax(scale * in fp32) per row (AttnBlock, modules.py:176-178).
  *  row_sqnorm        : out[n] = sum_d e[n,d]^2 (codebook norms, quantize.py:287).

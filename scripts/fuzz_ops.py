@@ -131,11 +131,21 @@ for case in range(NCASE):
             x = torch.randn(Bn * HW, Cg, device="cuda", generator=g) * rng.choice([0.3, 2.0]) + rng.choice([0.0, 1.0])
             wt, bs = 1 + 0.2 * torch.randn(Cg, device="cuda", generator=g), 0.1 * torch.randn(Cg, device="cuda", generator=g)
             sw = rng.random() < 0.5
-            y = ops.groupnorm_f32(x, Bn, HW, 32, wt, bs, 1e-6, sw)
-            r_ = F.group_norm(x.view(Bn, HW, Cg).permute(0, 2, 1), 32, wt, bs, 1e-6).permute(0, 2, 1).reshape(Bn * HW, Cg)
+            form = rng.choice(["f32", "bf16, fp32 params", "bf16, bf16 params", "bf16, in place"])
+            if form == "f32":
+                y = ops.groupnorm_f32(x, Bn, HW, 32, wt, bs, 1e-6, sw)
+            else:                                                      # the decoder-side kernels: bf16 rows (the error is the output rounding), parameters in either format
+                x = x.to(BF)
+                if form != "bf16, fp32 params": wt, bs = wt.to(BF), bs.to(BF)
+                xin = x.clone()
+                y = ops.groupnorm(xin, Bn, HW, 32, wt, bs, 1e-6, sw, out=xin if form.endswith("in place") else None).float()
+                x, wt, bs = x.float(), wt.float(), bs.float()
+            xg = x.double().view(Bn, HW, 32, Cg // 32)                  # (by hand in fp64: F.group_norm refuses a single value per group, the kernel does not)
+            mu, var = xg.mean((1, 3), keepdim=True), xg.var((1, 3), unbiased=False, keepdim=True)
+            r_ = (((xg - mu) / (var + 1e-6).sqrt()).view(Bn * HW, Cg) * wt.double() + bs.double()).float()
             ref = r_ * torch.sigmoid(r_) if sw else r_
-            err, tol = float((y - ref).abs().max()) / (float(ref.abs().max()) + 1e-9), 2e-5
-            desc += f" B={Bn} HW={HW} C={Cg} swish={sw}"
+            err, tol = float((y - ref).abs().max()) / (float(ref.abs().max()) + 1e-9), (2e-5 if form == "f32" else 4.5e-3)
+            desc += f" B={Bn} HW={HW} C={Cg} swish={sw} {form}"
         else:
             V = rng.choice([5, 320, 32017, 152064])
             Mv = min(M, 300)
