@@ -119,7 +119,7 @@ __global__ void mask_labels_kernel(const float* __restrict__ pred, int C, long h
     int bi = 0;
     for (int c = 1; c < C; ++c) {
         const float v = pred[(long)c * hw + i];
-        if (v > best) { best = v; bi = c; }
+        if (v > best || (v != v && best == best)) { best = v; bi = c; }      // NaN counts as the maximum, first one wins (torch.argmax; as class_areas_kernel)
     }
     out[i] = (uint8_t)bi;
 }
