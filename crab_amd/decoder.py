@@ -752,9 +752,12 @@ class GenerationEngine:
         except torch.cuda.OutOfMemoryError:
             if not (self._kv or self._dec or self._ws):
                 raise
-            self.invalidate()
-            torch.cuda.empty_cache()
-            return fn(*a, **k)
+        # the retry runs OUTSIDE the except clause: inside it the exception's traceback keeps the failed attempt's frames - and the tensors they hold - alive
+        import gc
+        self.invalidate()
+        gc.collect()
+        torch.cuda.empty_cache()
+        return fn(*a, **k)
 
     @torch.no_grad()
     def generate(self, embeds: torch.Tensor, max_new_tokens: int, eos_token_id: Optional[int] = None,
