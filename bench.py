@@ -471,7 +471,9 @@ def avss_pixel_path(model, um, args):
         for name, buf in inner.seg_module.named_buffers():          # the SAM-style random Fourier matrices are buffers the reference never saves
             if name.endswith("positional_encoding_gaussian_matrix"):
                 buf.normal_(generator=g)
-    N, NEW, NT = 256, 100, 48          # 256 rows: the decode projections' panel regime (128 < M <= 256); at 128 rows a step costs 8.2 ms, at 256 ~6
+    # samples per call (CRAB_BENCH_AVS_SAMPLES): 512 = CRAB_DECODE_MAX_ROWS, the headline's decode batch.  Measured r06: 128 samples 115.7 samples/s (8.2 ms per
+    # decode step), 256 159.7 (10.4 ms), 512 181.7 (17.2 ms; it first failed with "hyperlora_route: workspace too small" - the non-monotone workspace query, fixed)
+    N, NEW, NT = int(os.environ.get("CRAB_BENCH_AVS_SAMPLES", "512")), 100, 48
     sp = um.SPECIAL_TOKEN_2_IDS
     samples, gts = [], []
     gg = torch.Generator().manual_seed(9)
@@ -527,7 +529,7 @@ def avss_pixel_path(model, um, args):
     um._engine.invalidate()
     torch.cuda.empty_cache()
     return {"workload": "AVSS pixel-level path, Llama-2-7B + CLIP ViT-L/14 (multi-scale) + BEATs + SegModule, bf16 (BASELINE configs[4]); one image + one "
-                        "1-s audio window + 48..52-token prompt per sample, 100 new tokens, 192 binary + 64 avss (71-class) samples per call",
+                        "1-s audio window + 48..52-token prompt per sample, 100 new tokens, " + f"{N - N // 4} binary + {N // 4} avss (71-class) samples per call",
             "samples_per_call": N, "new_tokens": NEW, "prefill_len": f"{S_ - 4}..{S_}", "samples_per_s": round(N / dt, 2),
             "ms_per_call": [round(x * 1e3, 1) for x in ts], "ms_per_sample": round(dt * 1e3 / N, 3),
             "pixel_head_ms_per_sample": round(sum(seg_ms) / len(seg_ms) / N, 3), "labels_and_metrics_ms_per_sample": round(sum(met_ms) / len(met_ms) / N, 3),

@@ -759,10 +759,16 @@ static void route_cfg(int M, int K, int* MT, int* nslices) {
     *nslices = route_slices(*MT == 4 ? (M + 3) / 4 : M, K);       // (slice, row block) pairs for ~4 blocks per CU
 }
 
+// r06: the query is MONOTONE in M and K - callers size one workspace for their largest chunk and reuse it for smaller ones, and slices * M is not monotone
+// (M = 57 344: 5 slices = 286 720 partial rows; M = 50 000: 6 slices = 300 000 - generate_avs_many with 512 samples failed with "workspace too small" on the
+// last chunk of its merged prefill).  Bound of route_cfg's slices * M over every m <= M: slices <= min(16, ceil(K / 128)) and slices <= 1024 / row blocks + 1
+// with >= m / 256 row blocks, i.e. slices * m <= 262 144 + m.
 extern "C" int64_t crab_hyperlora_route_workspace(int M, int K, int tcols) {
-    int MT, ns;
-    route_cfg(M, K, &MT, &ns);
-    return (int64_t)ns * M * tcols * (int64_t)sizeof(float);
+    if (M <= 0 || K <= 0 || tcols <= 0) return 0;
+    const int64_t maxs = (K + 127) / 128 < 16 ? (K + 127) / 128 : 16;
+    int64_t rows = maxs * (int64_t)M;
+    if (rows > 262144 + (int64_t)M) rows = 262144 + (int64_t)M;
+    return rows * tcols * (int64_t)sizeof(float);
 }
 
 extern "C" int crab_hyperlora_route(crab_ctx* ctx, void* stream, const void* X, int64_t ldx, const void* RA, int64_t ldra, int M, int K,

@@ -467,7 +467,14 @@ static int vq_nsplit(int M, int N) {
     return ns < 1 ? 1 : ns;
 }
 
-extern "C" int64_t crab_vq_nearest_f32_workspace(int M, int N) { return (int64_t)M * vq_nsplit(M, N) * 8; }
+// monotone in M and N (one workspace sized for the largest call serves smaller ones): splits * M <= min(64, column tiles) * M and <= 16 384 + M
+extern "C" int64_t crab_vq_nearest_f32_workspace(int M, int N) {
+    if (M <= 0 || N <= 0) return 0;
+    const int64_t nt = (N + VQ_NT - 1) / VQ_NT;
+    int64_t rows = (nt < 64 ? nt : 64) * (int64_t)M;
+    if (rows > 16384 + (int64_t)M) rows = 16384 + (int64_t)M;
+    return rows * 8;
+}
 
 extern "C" int crab_vq_nearest_f32(crab_ctx* ctx, void* stream, const float* z, int64_t ldz, const float* e, int64_t lde, const float* e2, int M, int N,
                                    int D, int64_t* idx, int64_t offset, void* workspace, int64_t workspace_bytes) {

@@ -55,3 +55,29 @@ def test_retry_gives_up_when_nothing_is_cached_and_after_a_second_failure():
     with pytest.raises(torch.cuda.OutOfMemoryError):
         decoder.GenerationEngine._retry_after_eviction(eng, always)                # one retry, then the caller's
     assert eng.invalidated == 1
+
+
+def test_workspace_queries_are_monotone_so_that_one_buffer_serves_every_smaller_call():
+    """r06: callers size ONE workspace for their largest chunk (decoder._Workspace.t for the prefill chunk) and reuse it for the smaller last chunk.
+    crab_hyperlora_route_workspace used to return slices(M) * M, which is not monotone (M = 57 344: 5 slices, M = 50 000: 6 -> 5 % more), and
+    generate_avs_many with 512 samples failed with "hyperlora_route: workspace too small".  Every query is now non-decreasing in every argument."""
+    from crab_amd import _lib
+    lib = _lib.load()
+    for K in (768, 4096, 11008, 18944):
+        prev = 0
+        for M in list(range(1, 5000, 7)) + list(range(5000, 400000, 997)):
+            w = lib.crab_hyperlora_route_workspace(M, K, 48)
+            assert w >= prev, (M, K, w, prev)
+            prev = w
+        assert lib.crab_hyperlora_route_workspace(50000, K, 48) <= lib.crab_hyperlora_route_workspace(57344, K, 48)
+    assert lib.crab_hyperlora_route_workspace(4096, 4096, 48) <= lib.crab_hyperlora_route_workspace(4096, 11008, 48)
+    for N in (1, 64, 1000, 16384):
+        prev = 0
+        for M in range(1, 40000, 13):
+            w = lib.crab_vq_nearest_f32_workspace(M, N)
+            assert w >= prev, (M, N, w, prev)
+            prev = w
+    for q, args in ((lib.crab_rowfin_workspace, [(m, 4096) for m in range(1, 17)]), (lib.crab_attn_decode_rope_workspace, [(b, 32, 128) for b in range(1, 64)]),
+                    (lib.crab_groupnorm_workspace, [(2, hw, 32) for hw in range(1, 70000, 101)])):
+        vals = [q(*a) for a in args]
+        assert vals == sorted(vals)

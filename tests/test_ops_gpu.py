@@ -480,6 +480,29 @@ def test_hyperlora_route_matches_gemm_plus_mix(M, K, nproj):
     assert (u1[:, nproj * 24:] == 0).all()
 
 
+def test_hyperlora_route_in_a_workspace_sized_for_a_larger_chunk():
+    """r06: one workspace sized by the query for the LARGEST chunk serves every smaller one.  The slice count rises as M falls (57 344 rows: 5 K slices,
+    50 000 rows: 6), so slices * M is not monotone and the old query handed the last chunk of a merged prefill a buffer 5 % short (generate_avs_many
+    with 512 samples: "hyperlora_route: workspace too small" from the layer sequencer, which cannot reallocate)."""
+    from crab_amd import ops, _lib
+    K, nproj, tcols, ucols = 4096, 3, 48, 96
+    big, small = 57344, 50000
+    ws = torch.empty((ops.hyperlora_route_workspace(big, K, tcols),), device="cuda", dtype=torch.uint8)
+    assert ws.numel() >= 6 * small * tcols * 4                       # what the six-slice launch of the smaller call writes
+    x = _rand(small, K, seed=11).cuda()
+    ra = _rand(tcols, K, seed=12, scale=K ** -0.5)
+    ra[nproj * 11:] = 0
+    rad = ra.cuda()
+    u_own = ops.hyperlora_route(x, rad, nproj, 3, 8, ucols, 2.0)
+    u = torch.empty_like(u_own)
+    lib = _lib.load()
+    rc = lib.crab_hyperlora_route(_lib.ctx(0), None, x.data_ptr(), x.stride(0), rad.data_ptr(), rad.stride(0), small, K, nproj, 3, 8, u.data_ptr(), u.stride(0),
+                                  ucols, 2.0, ws.data_ptr(), ws.numel())
+    _lib.check(rc, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(u, u_own)
+
+
 @pytest.mark.parametrize("M", [1, 8, 17, 33, 64, 100, 128])
 def test_gemm_skinny_regime(M):
     """M <= 128 dispatches to the weight-streaming kernel (all MT variants, N tail, K tail, second segment)."""
