@@ -161,6 +161,7 @@ class GenerationEngine:
         self._ws = {}
         self._kv = {}
         self._dec = {}                 # slot -> persistent decode state (+ captured graph)
+        self._attn_ws = {}             # B -> scratch of the fused small-batch attention for calls that run in the SHARED prefill workspace (_attn_scratch)
         self.kv_budget_bytes = None    # None: ask the device (hipMemGetInfo); an int caps what generate() may plan with (tests)
         self.last_plan = None          # what the last generate() decided: {"B", "groups", "bytes_per_seq", "budget"}
 
@@ -173,6 +174,7 @@ class GenerationEngine:
         self._dec = {}
         self._ws = {}
         self._kv = {}
+        self._attn_ws = {}
         self._table = None
 
     def _rope_tab(self, need: int) -> torch.Tensor:
@@ -180,6 +182,25 @@ class GenerationEngine:
             n = max(need, 1024)
             self._rope = ops.rope_table(n, self.cfg.head_dim, self.cfg.rope_theta, self.device)
         return self._rope
+
+    def _attn_scratch(self, ws: _Workspace, B: int):
+        """Scratch (split-context partials + arrival counters) of the fused RoPE + append + attention launch of a B-row step, or None when B rows
+        do not take that launch.  A decode workspace is made for exactly its B rows and owns its scratch (captured graphs bake the pointer).  The
+        SHARED prefill workspace - which forward()'s one-token shortcut runs in - is grow-only and serves any B <= its M, and the launch places its
+        counters right behind the partials of ITS B: r06 (scripts/fuzz_engine_state.py) - (1) whether the step fused depended on how large an
+        earlier prefill had made that workspace (state, not shape: a 1-ulp difference in the logits, and at the real width never fused at all), and
+        (2) a 4-row step followed by a 2-row step in the same buffer would have found the 4-row partials where its zeroed counters belong.  Such
+        calls get a zero-filled scratch per B from the engine instead."""
+        c = self.cfg
+        H, d = c.num_attention_heads, c.head_dim
+        if B * H >= ops.ATTN_SPLIT_BELOW or d not in (64, 128):
+            return None
+        if ws.M == B and ws.attn_ws is not None:
+            return ws.attn_ws
+        buf = self._attn_ws.get(B)
+        if buf is None or buf.device != self.device:
+            buf = self._attn_ws[B] = ops.attn_decode_rope_workspace(B, H, d, self.device)
+        return buf
 
     def _workspace(self, M: int, slot: int = 0, decode: bool = False) -> _Workspace:
         """Activation buffers for M rows.
@@ -403,8 +424,9 @@ class GenerationEngine:
         if vt is not None:
             io.vt, io.vt_ld = vt.data_ptr(), vt.stride(-2)
         io.pos_dev = pos_dev.data_ptr() if pos_dev is not None else None
-        if ws.attn_ws is not None and vt is None:
-            io.attn_ws, io.attn_ws_bytes = ws.attn_ws.data_ptr(), ws.attn_ws.numel()
+        aw = self._attn_scratch(ws, B) if vt is None else None
+        if aw is not None:
+            io.attn_ws, io.attn_ws_bytes = aw.data_ptr(), aw.numel()
         io.B, io.S, io.Tmax, io.pos0, io.u_qkv_ready = B, S, Tmax, pos0, 0
         io.x_fp32 = 1 if ws.x.dtype == torch.float32 else 0
         io.last_rows_only = 1 if last_rows else 0
@@ -455,8 +477,8 @@ class GenerationEngine:
             return x, h
         u_qkv = None                                   # router output for the q|k|v group when a producer epilogue made it
         # small batch: the projection leaves its raw row, ONE launch does RoPE + KV append + split-context attention (as csrc/llama_layer.hip)
-        fuse_attn = (vt is None and S == 1 and not masked and row_off is None and ws.attn_ws is not None and B * H < ops.ATTN_SPLIT_BELOW and contig and
-                     ws.attn_ws.numel() >= ops.attn_decode_rope_bytes(B, H, d))
+        aw = self._attn_scratch(ws, B) if (vt is None and S == 1 and not masked and row_off is None and contig) else None
+        fuse_attn = aw is not None and aw.numel() >= ops.attn_decode_rope_bytes(B, H, d)
         for li, layer in enumerate(layers):
             a, m = layer.self_attn, layer.mlp
             kcl, vcl = kc[li, b0:b0 + B], vc[li, b0:b0 + B]
@@ -491,7 +513,7 @@ class GenerationEngine:
                              vt_strides=(Hk * d * Sp, d * Sp, Sp), o_strides=(S * H * d, H * d), B=B, H=H, Hk=Hk, Sq=S,
                              Skv=pos0 + S, head_dim=d, scale=scale, causal=True, kv_start=kv_start, key_mask=key_mask)
             elif fuse_attn:
-                ops.attn_decode_rope(qkv, tab, kcl, vcl, att, B, H, Hk, d, Tmax, pos0, scale, pos_dev=pos_dev, workspace=ws.attn_ws)
+                ops.attn_decode_rope(qkv, tab, kcl, vcl, att, B, H, Hk, d, Tmax, pos0, scale, pos_dev=pos_dev, workspace=aw)
             else:
                 ops.attn_decode(qkv, kcl, vcl, att, B, H, Hk, d, Tmax, pos0 + 1, scale, ctx_dev=pos_dev,
                                 kv_start=kv_start if row_off is None else row_off, key_mask=key_mask)

@@ -1366,3 +1366,45 @@ def test_prefill_last_rows_only_equals_the_full_last_layer(fixture):
     for on in (True, False):
         err = _check_ids(outs[on][0], A["ids_bs2"], A["logits_bs2"], outs[on][1])
         assert err < PB.bound(f"{fixture}: end to end") * A["logits_bs2"].abs().max().item(), (on, err)
+
+
+def test_one_token_shortcut_takes_the_fused_attention_by_shape_not_by_engine_state():
+    """r06 (scripts/fuzz_engine_state.py): forward()'s one-token shortcut runs in the engine's SHARED, grow-only prefill workspace.  Whether its attention
+    took the fused RoPE + append + split-context launch used to depend on how large an earlier prefill had made that workspace (its scratch was sized - or
+    omitted - for the workspace's rows, not the call's), and a 4-row step followed by a 2-row step in one scratch would have found partials where the 2-row
+    launch keeps its zeroed arrival counters.  Now: the same call gives the same bits whatever ran before, and the launch trace shows the fused kernel."""
+    import os, runpy
+    from crab_amd import ops
+    ns = runpy.run_path(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "fuzz_engine_state.py"), run_name="lib")
+    model = ns["build"](False)
+    um = model.base_model.model
+    eng = um._engine
+    hid = um.config.hidden_size
+    g = torch.Generator().manual_seed(5)
+    mk = lambda B, S: (torch.randn(B, S, hid, generator=g) * 0.5).to(BF).cuda()
+    e2, e4, big = mk(2, 40), mk(4, 5), mk(65, 33)
+
+    def call(emb, steps=2):
+        o = um(inputs_embeds=emb, use_cache=True)
+        outs, pkv, lg = [o.logits.clone()], o.past_key_values, o.logits
+        for _ in range(steps):
+            st = um(input_ids=lg[:, -1].argmax(-1)[:, None], past_key_values=pkv)
+            outs.append(st.logits.clone())
+            pkv, lg = st.past_key_values, st.logits
+        return outs
+
+    eng.invalidate()
+    fresh2 = call(e2)
+    eng.invalidate()
+    fresh4 = call(e4)
+    eng.invalidate()
+    eng.generate(big, 3, eos_token_id=None, pad_token_id=2)                  # the prefill workspace is now 2145 rows
+    with ops.launch_trace() as tr:
+        after_big = call(e2)
+    assert tr.launched("attn_decode_rope_kernel<128>") >= 2 * len(um.model.layers), tr.counts      # fused at 2 rows x 2 heads, as in the fresh state
+    assert all(torch.equal(a, b) for a, b in zip(after_big, fresh2))
+    eng.invalidate()
+    call(mk(4, 17))                                                          # a small shared workspace (68 rows) that both calls below run in
+    a4, a2, b4 = call(e4), call(e2), call(e4)                                # 4-row steps, then 2-row steps, then 4 again: one scratch per row count
+    assert all(torch.equal(a, b) for a, b in zip(a4, fresh4)) and all(torch.equal(a, b) for a, b in zip(b4, fresh4))
+    assert all(torch.equal(a, b) for a, b in zip(a2, fresh2))
