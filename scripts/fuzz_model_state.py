@@ -1,5 +1,5 @@
 """Stateful fuzz at the MODEL level (r06, next to fuzz_engine_state.py): a random sequence of UnifiedForCausalLM calls - prepare_multimodal_inputs, generate,
-generate_batches in flight and coalesced - with changing batch sizes, frame counts, audio windows (1-s and 2-s), modality subsets and ragged prompts on ONE
+generate_batches in flight and coalesced, the pixel loops' generate_avs_many halves (ragged decode with hidden states + the batched SegModule) - with changing batch sizes, frame counts, audio windows (1-s and 2-s), modality subsets and ragged prompts on ONE
 tiny Crab (CLIP tower + BEATs + both Q-Former projectors + hyper-LoRA decoder), whose encoders, projectors and engine keep workspaces, tables and graphs between
 calls.  Three executions of the same sequence must agree BIT FOR BIT: a freshly built model per call, one model straight through, and one model straight
 through on a side HIP stream.   python scripts/fuzz_model_state.py [calls] [seed]"""
@@ -7,7 +7,6 @@ import os, random, sys, warnings
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from crab_amd import synth
-from tests.util import build_tiny_crab
 
 BF = torch.bfloat16
 warnings.filterwarnings("ignore", category=RuntimeWarning)
@@ -26,9 +25,25 @@ META = dict(
     qf=dict(hidden=128, heads=2, inter=136), d_model=128, base_vocab=303, pad_token_id=2, qkv_bias=False)
 
 
+def build():
+    """tests/util.build_tiny_crab + the SegModule (scripts/quick_start.py:505-529 with segment_branch)"""
+    from crab_amd.peft_hyper import LoraConfig, get_peft_model
+    from crab_amd.unified_llama import UnifiedConfig, UnifiedForCausalLM
+    from tests.util import DuckTokenizer, bert_cfg
+    cfg = UnifiedConfig(**META["dec"], pad_token_id=META["pad_token_id"])
+    cfg.vocab_size = META["base_vocab"]
+    model = get_peft_model(UnifiedForCausalLM(cfg, device="cuda"), LoraConfig())
+    model.get_model().pad_token_id = META["pad_token_id"]
+    model.get_model().init_multimodal_modules(d_model=META["d_model"], visual_branch=True, audio_branch=True, segment_branch=True, select_layer_list=META["select"],
+                                              clip_config=META["clip"], beats_config=META["beats"], bert_config=bert_cfg(META["qf"]),
+                                              vit_image_embedding_dim=META["clip"]["hidden_size"])
+    model.initialize_MM_tokenizer(DuckTokenizer(META["base_vocab"]), mask_token_nums=6)
+    return model
+
+
 def weights():
     torch.manual_seed(900)
-    model = build_tiny_crab(META)
+    model = build()
     W = {}
     for k, v in model.state_dict().items():
         if not v.dtype.is_floating_point:
@@ -48,7 +63,7 @@ def weights():
 
 
 def new_model(W):
-    model = build_tiny_crab(META)
+    model = build()
     r = model.load_state_dict(W, strict=False)
     assert not r.missing_keys, r.missing_keys[:4]
     return model
@@ -57,10 +72,12 @@ def new_model(W):
 def make_calls(n):
     calls = []
     for i in range(n):
-        kind = rng.choice(["prepare", "generate", "generate", "batches"])
+        kind = rng.choice(["prepare", "generate", "generate", "batches", "avs"])
         c = dict(kind=kind, seed=i, tv=rng.choice([1, 2, 4, 8]), ta=rng.choice([1, 3, 10]), la=rng.choice([98, 198]), mods=rng.choice(["va", "va", "va", "v", "a", "none", "image"]),
                  n=rng.choice([1, 3, 5]))
-        if kind == "batches":
+        if kind == "avs":
+            c.update(N=rng.choice([1, 2, 3, 5]), max_rows=rng.choice([None, None, 2]), mods="image_a", n=8)
+        elif kind == "batches":
             c.update(sizes=[rng.choice([1, 2, 3]) for _ in range(rng.choice([1, 2, 4]))], coalesce=rng.random() < 0.6, max_rows=rng.choice([None, None, 3]))
         else:
             c.update(B=rng.choice([1, 2, 3, 5]))
@@ -77,18 +94,30 @@ def sample(um, c, clip):
     for t in drop:
         ids = ids[ids != sp[t]]
     mods = {}
-    if c["mods"] == "image":
+    if c["mods"] in ("image", "image_a"):
         for a_, b_ in (("<video_start>", "<image_start>"), ("<video>", "<image>"), ("<video_end>", "<image_end>")):
             ids[ids == sp[a_]] = sp[b_]
         mods['<image>'] = synth.synth_video(1, seed=c["seed"], clip=clip)
     if c["mods"] in ("va", "v"): mods['<video>'] = synth.synth_video(c["tv"], seed=c["seed"], clip=clip)
-    if c["mods"] in ("va", "a"): mods['<audio>'] = synth.synth_audio(c["ta"], c["la"], seed=c["seed"], clip=clip)
+    if c["mods"] in ("va", "a", "image_a"): mods['<audio>'] = synth.synth_audio(c["ta"], c["la"], seed=c["seed"], clip=clip)
     return ids, mods
 
 
 def run(model, c):
     um = model.base_model.model
     kw = dict(max_new_tokens=c["n"], min_new_tokens=c["n"], pad_token_id=2, eos_token_id=None, use_cache=True)
+    if c["kind"] == "avs":                                  # the pixel loops: N one-sample calls as one ragged batch, masks from the last six steps (bench.py's pick rule)
+        smp = []
+        for j in range(c["N"]):
+            ids, mods = sample(um, c, j)
+            smp.append(dict(batch_input_ids=[ids], batch_labels=[torch.full_like(ids, -100)], batch_X_modals=[mods],
+                            batch_task_names=['avss' if (j + c["seed"]) % 3 == 0 else ('s4', 'ms3', 'ref-avs')[j % 3]]))
+        inputs, outs = um._avs_generate(smp, c["max_rows"], kw)
+        res = um._avs_segment(smp, inputs, outs, [(g_, 0, list(range(c["n"] - 7, c["n"] - 1))) for g_ in range(c["N"])])
+        out = []
+        for r_ in res:
+            out += [r_['output_ids'].clone(), r_['pred_masks'][0].clone()]
+        return out
     if c["kind"] == "batches":
         batches, clip = [], 0
         for b in c["sizes"]:
