@@ -1,7 +1,7 @@
 """Stateful fuzz of the generation engine (r06): the other generators give every call a fresh engine state (`eng._dec.clear()`), so nothing exercised what a
 long evaluation does - hundreds of calls of changing shape on ONE engine that keeps KV slots, decode workspaces, captured HIP graphs and a grow-only prefill
 workspace between them (and evicts them lazily).  Here a random SEQUENCE of calls - generate() at batch sizes across the decode regimes with and without
-EOS / min_new_tokens / hidden states / step logits / two decode streams / a KV budget that forces groups, generate_batches in flight and coalesced (ragged
+EOS / min_new_tokens / hidden states / step logits / sample mode / two decode streams / a KV budget that forces groups, generate_batches in flight and coalesced (ragged
 waves), forward(use_cache) + the one-token shortcut - runs twice on the same tiny model: once with the engine invalidated before every call (fresh state),
 once straight through (carried state, shapes revisited with new data so that cached graphs and buffers are reused).  Every result must be BIT-IDENTICAL:
 the kernels chosen depend on the shapes only, never on what the engine holds.   python scripts/fuzz_engine_state.py [calls] [seed]"""
@@ -45,7 +45,8 @@ def make_calls(n, hid, V):
         if kind == "generate":
             c.update(B=rng.choice([1, 2, 8, 16, 17, 40, 65, 130, 260]), S=rng.choice([1, 6, 33]), n=rng.choice([1, 2, 3, 5]),
                      graph=rng.random() < 0.8, streams=rng.choice([1, 1, 1, 2]), eos=rng.choice([None, None, "pick"]), min_new=rng.choice([0, 0, 2]),
-                     extra=rng.choice([None, None, "hidden", "logits", "first"]), budget=rng.choice([None, None, None, "tight"]))
+                     extra=rng.choice([None, None, "hidden", "logits", "first"]), budget=rng.choice([None, None, None, "tight"]),
+                     sampling=rng.choice([None, None, None, (0.7, 20, 0.9), (1.3, 0, 0.5), (0.6, 5, 1.0)]))
         elif kind == "batches":
             c.update(sizes=[rng.choice([1, 2, 3, 8]) for _ in range(rng.choice([1, 2, 3, 5]))], S=[rng.choice([2, 5, 9, 20]) for _ in range(5)],
                      n=rng.choice([1, 3, 4]), coalesce=rng.random() < 0.6, max_rows=rng.choice([None, None, 4, 9]))
@@ -70,6 +71,7 @@ def run(model, c, hid, V):
         if c["budget"] == "tight" and c["B"] >= 8:
             eng.kv_budget_bytes = int(eng.fixed_bytes(c["B"], c["S"]) / 0.94 + 0.6 * c["B"] * eng.bytes_per_sequence(c["S"], c["n"]) / 0.94)      # ~2 groups
         kw = dict(eos_token_id=eos, pad_token_id=2, min_new_tokens=c["min_new"], use_graph=c["graph"], decode_streams=c["streams"])
+        if c["sampling"] is not None: kw["sampling"] = c["sampling"] + (c["seed"],)          # HF sample mode (temperature, top_k, top_p, seed): the seed is baked into the graph
         if c["extra"] == "hidden": kw["return_hidden"] = True
         if c["extra"] == "logits": kw["return_step_logits"] = True
         if c["extra"] == "first": kw["return_first_logits"] = True
