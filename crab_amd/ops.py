@@ -728,12 +728,14 @@ def upsample_nearest2x(x: torch.Tensor, B: int, h: int, w: int) -> torch.Tensor:
     return out
 
 
-def softmax_rows(x: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
-    """x fp32 [M,N] -> bf16 softmax(scale * x) per row."""
+def softmax_rows(x: torch.Tensor, scale: float = 1.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x fp32 [M,N] -> bf16 softmax(scale * x) per row (out: a [M, N] view of a wider buffer, unit column stride)."""
     d = _dev(x)
     assert x.dtype == torch.float32 and x.stride(1) == 1
     M, N = x.shape
-    out = torch.empty((M, N), device=x.device, dtype=BF16)
+    if out is None:
+        out = torch.empty((M, N), device=x.device, dtype=BF16)
+    assert out.dtype == BF16 and tuple(out.shape) == (M, N) and out.stride(1) == 1
     _lib.check(_lib.load().crab_softmax_rows(_lib.ctx(d), _stream(), _p(x), x.stride(0), _p(out), out.stride(0), M, N, scale), d)
     return out
 

@@ -164,12 +164,17 @@ class AttnBlock(nn.Module):
         k = _conv1x1(hn, self.k)
         wv = self.v.packed()
         o = torch.empty((B * HW, C), device=x.device, dtype=BF16)
+        HWp = (HW + 7) // 8 * 8                                                   # P . V^T contracts over the pixels: the GEMM's K is a multiple of 8, so a map whose
+        pad = HWp != HW                                                           # pixel count is not (masks off the 16-pixel grid) runs on zero-padded P / V^T columns
+        if pad:
+            pbuf = torch.zeros((HW, HWp), device=x.device, dtype=BF16)
+            vbuf = torch.zeros((C, HWp), device=x.device, dtype=BF16)
         for b in range(B):
             sl = slice(b * HW, (b + 1) * HW)
             scores = ops.gemm(q[sl], k[sl], out_fp32=True)                        # [HW, HW] = q . k^T
-            p = ops.softmax_rows(scores, float(int(C) ** (-0.5)))
-            vt = ops.gemm(wv, hn[sl])                                             # V^T [C, HW] (bias added after P.V)
-            ops.gemm(p, vt, bias=self.v.bias16(), out=o[sl])
+            p = ops.softmax_rows(scores, float(int(C) ** (-0.5)), out=pbuf[:, :HW] if pad else None)
+            vt = ops.gemm(wv, hn[sl], out=vbuf[:, :HW] if pad else None)          # V^T [C, HW] (bias added after P.V)
+            ops.gemm(pbuf if pad else p, vbuf if pad else vt, bias=self.v.bias16(), out=o[sl])
         return _conv1x1(o, self.proj_out, residual=x)
 
 

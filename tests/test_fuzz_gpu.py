@@ -1,4 +1,4 @@
-"""Differential fuzz through the C-ABI at random shapes around every dispatch boundary - short fixed-seed runs of the ten generators under scripts/
+"""Differential fuzz through the C-ABI at random shapes around every dispatch boundary - short fixed-seed runs of the eleven generators under scripts/
 (one process: scripts/fuzz_all.py; the cases are the same on every run):
   fuzz_gemm.py           the GEMM regimes x epilogues against fp32 torch on the same bf16 operands,
   fuzz_attn.py           the attention entry points x masks,
@@ -12,7 +12,8 @@
                          GEMM, GroupNorm in its four forms,
   fuzz_seg.py            r06: the SegModule helpers, the remaining VQGAN helpers and the eval loops' metrics (counts equal to oracle/metrics_oracle.py),
   fuzz_engine_state.py   r06: random SEQUENCES of generate / generate_many / forward calls on one engine, carried state against fresh state, bit for bit,
-  fuzz_model_state.py    r06: the same at the model level (encoders, projectors, splice, engine; changing frames / windows / modality subsets; a side stream).
+  fuzz_model_state.py    r06: the same at the model level (encoders, projectors, splice, engine; changing frames / windows / modality subsets; a side stream),
+  fuzz_vqgan.py          r06: the VQGAN mask tokenizer at random batch and mask sizes against oracle/vqgan_oracle.py (ids equal outside the oracle's own margin).
 (r05: half the r04 case count here - the suite has a time limit; tests/test_slow_gpu.py runs 8x that (scale 4) under `-m gpu_slow`.)
 A combination outside a stated limit must be REJECTED (CRAB_E_INVALID / CRAB_E_UNSUPPORTED), never computed wrong; outputs sit inside sentinel guards."""
 import os
@@ -23,7 +24,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FUZZERS = ["fuzz_gemm.py", "fuzz_attn.py", "fuzz_decoder.py", "fuzz_multimodal.py", "fuzz_rope_epilogue.py", "fuzz_frontend.py", "fuzz_ops.py", "fuzz_seg.py", "fuzz_engine_state.py", "fuzz_model_state.py"]
+FUZZERS = ["fuzz_gemm.py", "fuzz_attn.py", "fuzz_decoder.py", "fuzz_multimodal.py", "fuzz_rope_epilogue.py", "fuzz_frontend.py", "fuzz_ops.py", "fuzz_seg.py", "fuzz_engine_state.py", "fuzz_model_state.py", "fuzz_vqgan.py"]
 
 
 def test_differential_fuzz():

@@ -1,7 +1,7 @@
 """Long GPU soaks, kept out of `-m gpu` so that the driver's suite stays well inside its time limit (580 s of 1200): run with
     python -m pytest tests/test_slow_gpu.py -m gpu_slow -q
 on a GPU box.  r05 results on MI355X: profiles/r05_slow_suite.log.
-  * the ten differential fuzzers at 8x the case count of the `-m gpu` run (3 min 40 s on the r05 box; their decoder / multimodal cases
+  * the eleven differential fuzzers at 8x the case count of the `-m gpu` run (3 min 40 s on the r05 box; their decoder / multimodal cases
     run the CPU oracle on the host)."""
 import os
 import subprocess
