@@ -62,7 +62,7 @@ for ci in range(NCFG):
                             base_vocab=303, pad_token_id=2)
         um = model.base_model.model
         B = rng.choice([1, 2, 3])
-        tv, ta, la = rng.choice([1, 2, 3]), rng.choice([1, 2, 3]), rng.choice([98, 198])
+        tv, ta, la = rng.choice([1, 2, 3, 5]), rng.choice([1, 2, 3, 7]), rng.choice([98, 198, 98, 198, 16, 47, 130, 400])      # r06: window lengths off the two the datasets use
         ids = [synth.synth_prompt_ids(12 + 5 * i + rng.randrange(4), 303, um.SPECIAL_TOKEN_2_IDS, seed=ci, clip=i) for i in range(B)]
         mods = [{'<video>': synth.synth_video(tv, seed=ci, clip=i), '<audio>': synth.synth_audio(ta, la, seed=ci, clip=i)} for i in range(B)]
         lab = [torch.full_like(i, -100) for i in ids]
