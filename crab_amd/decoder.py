@@ -637,11 +637,18 @@ class GenerationEngine:
         graph captured over them.  Kept per slot and reused by every call whose shapes, flags and buffers are the same: the key holds
         everything the captured launches bake in (pointers included).  ragged: the state of a coalesced batch (generate_many(coalesce=True)) -
         it owns a row_off word per row (first cache slot of the row's sequence) that the captured decode step reads."""
+        if int(max_new_tokens) < 1:                             # HF: GenerationConfig.validate() - "`max_new_tokens` must be greater than 0"; here the first token's slot would not exist
+            raise ValueError(f"`max_new_tokens` must be greater than 0, but is {max_new_tokens}.")
         dev = self.device
         D = self.cfg.hidden_size
         Tmax = _round_up(S + max_new_tokens, 64)
         kc, vc = self.alloc_cache(B, Tmax, slot=slot)
         V = self.lm_head.weight.shape[0]
+        if isinstance(eos_token_id, (list, tuple)):            # HF accepts a list of stop ids (Qwen2-7B-Instruct's generation_config holds two); the device loop carries one
+            if len(set(int(e) for e in eos_token_id)) > 1:
+                raise NotImplementedError(f"eos_token_id = {list(eos_token_id)}: the device-resident decode loop stops on ONE id (pass the chat end token, e.g. "
+                                          "<|im_end|>; the reference's own Qwen path never reaches HF generate, SURVEY.md 2)")
+            eos_token_id = eos_token_id[0] if len(eos_token_id) else None
         eos = -1 if eos_token_id is None else int(eos_token_id)
         pad = int(pad_token_id) if pad_token_id is not None else (eos if eos >= 0 else 0)
         ws = self._workspace(B, slot, decode=True)

@@ -1408,3 +1408,25 @@ def test_one_token_shortcut_takes_the_fused_attention_by_shape_not_by_engine_sta
     a4, a2, b4 = call(e4), call(e2), call(e4)                                # 4-row steps, then 2-row steps, then 4 again: one scratch per row count
     assert all(torch.equal(a, b) for a, b in zip(a4, fresh4)) and all(torch.equal(a, b) for a, b in zip(b4, fresh4))
     assert all(torch.equal(a, b) for a, b in zip(a2, fresh2))
+
+
+def test_generate_argument_edges_follow_hf_or_say_why_not():
+    """max_new_tokens < 1 is HF's ValueError (GenerationConfig.validate), not a write past the id buffer; a one-element eos list is that id; a list of
+    several stop ids - HF accepts one - is refused by name (the device-resident loop carries one id)."""
+    import os, runpy
+    ns = runpy.run_path(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "fuzz_engine_state.py"), run_name="lib")
+    model = ns["build"](False)
+    eng = model.base_model.model._engine
+    emb = (torch.randn(3, 5, model.base_model.model.config.hidden_size) * 0.5).to(BF).cuda()
+    for n in (0, -2):
+        with pytest.raises(ValueError, match="max_new_tokens"):
+            eng.generate(emb, n, eos_token_id=None, pad_token_id=2)
+        with pytest.raises(ValueError, match="max_new_tokens"):
+            eng.generate_many([emb, emb[:1]], n, eos_token_id=None, pad_token_id=2, coalesce=True)
+    free = eng.generate(emb, 6, eos_token_id=None, pad_token_id=2)
+    eos = int(free[1, 2])
+    a = eng.generate(emb, 6, eos_token_id=eos, pad_token_id=2)
+    b = eng.generate(emb, 6, eos_token_id=[eos], pad_token_id=2)
+    assert torch.equal(a, b) and a.shape[1] <= 6 and int(a[1, 2]) == eos and (a.shape[1] == 3 or bool((a[1, 3:] == 2).all()))
+    with pytest.raises(NotImplementedError, match="ONE id"):
+        eng.generate(emb, 6, eos_token_id=[eos, eos + 1], pad_token_id=2)
