@@ -239,6 +239,7 @@ class UnifiedForCausalLM(nn.Module, UnifiedMetaForCausalLM):
         pad_token_id, use_cache, do_sample (+ temperature, top_k, top_p, seed), output_logits / return_dict_in_generate (parity audits),
         output_first_logits (ids + the fp32 logits of the first generated position, [B, V]: the record the multi-GPU eval gathers),
         inputs_embeds (skip prepare_multimodal_inputs)."""
+        self._check_generate_kwargs(kwargs)
         sampling = self._sampling(kwargs)
         embeds = kwargs.pop("inputs_embeds", None)
         if ops.PROFILER is not None:
@@ -286,6 +287,7 @@ class UnifiedForCausalLM(nn.Module, UnifiedMetaForCausalLM):
             if kwargs.get(k) is not None and kwargs.get(k) is not False:
                 raise NotImplementedError(f"generate_batches returns token ids only: {k} is a generate() argument")
         want_first = bool(kwargs.get("output_first_logits"))
+        self._check_generate_kwargs(kwargs)
         sampling = self._sampling(kwargs)
         if ops.PROFILER is not None:
             ops.PROFILER.mark("encode_begin")
@@ -304,6 +306,27 @@ class UnifiedForCausalLM(nn.Module, UnifiedMetaForCausalLM):
         return self._engine.generate_many(embeds, int(kwargs.get("max_new_tokens", 20)), eos_token_id=eos, pad_token_id=pad,
                                           min_new_tokens=int(kwargs.get("min_new_tokens", 0) or 0), use_graph=kwargs.get("use_graph", True),
                                           sampling=sampling, return_first_logits=want_first, coalesce=coalesce, max_rows=max_rows)
+
+    # HF generate() arguments that would CHANGE what is decoded and that this path does not implement: refused by name instead of ignored
+    # (name -> the value that means "off").  Everything the reference's loops pass (use_cache, max_new_tokens; do_sample & co. from the
+    # checkpoint's generation_config) is implemented; unknown names that cannot alter the ids (output_attentions = False, ...) pass through.
+    _UNSUPPORTED = {"num_beams": 1, "num_beam_groups": 1, "num_return_sequences": 1, "repetition_penalty": 1.0, "no_repeat_ngram_size": 0,
+                    "encoder_repetition_penalty": 1.0, "length_penalty": 1.0, "penalty_alpha": None, "bad_words_ids": None, "force_words_ids": None,
+                    "logits_processor": None, "stopping_criteria": None, "prefix_allowed_tokens_fn": None, "constraints": None, "typical_p": 1.0,
+                    "epsilon_cutoff": 0.0, "eta_cutoff": 0.0, "diversity_penalty": 0.0, "suppress_tokens": None, "begin_suppress_tokens": None,
+                    "forced_bos_token_id": None, "forced_eos_token_id": None, "assistant_model": None, "streamer": None, "max_time": None,
+                    "stop_strings": None, "min_p": None, "guidance_scale": None, "sequence_bias": None}
+
+    @classmethod
+    def _check_generate_kwargs(cls, kwargs):
+        for k, off in cls._UNSUPPORTED.items():
+            v = kwargs.get(k, off)
+            if v is None or v == off or (isinstance(v, (list, tuple)) and len(v) == 0):
+                continue
+            raise NotImplementedError(f"generate({k}={v!r}): not implemented on this path (greedy and HF sample mode with temperature / top_k / top_p are); "
+                                      "it would change the decoded ids, so it is refused rather than ignored")
+        if "max_length" in kwargs and kwargs.get("max_length") is not None and kwargs.get("max_new_tokens") is None:
+            raise NotImplementedError("generate(max_length=...): with inputs_embeds only HF counts new tokens alone - pass max_new_tokens")
 
     @staticmethod
     def _sampling(kwargs):
@@ -381,6 +404,7 @@ class UnifiedForCausalLM(nn.Module, UnifiedMetaForCausalLM):
 
     def _avs_generate(self, samples, max_rows, kwargs):
         """First half of generate_avs_many: inputs of every call (multi-scale CLIP features kept) and the ragged decode with per-step hidden states."""
+        self._check_generate_kwargs(kwargs)
         sampling = self._sampling(kwargs)
         if ops.PROFILER is not None:
             ops.PROFILER.mark("encode_begin")

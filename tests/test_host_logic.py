@@ -167,3 +167,17 @@ def test_encoder_chunks_fill_whole_tile_rounds():
     assert plan_enc_chunks(448, 8 * 257, 96) == [95, 95, 95, 95, 68]
     assert plan_enc_chunks(448, 8 * 257, 64) == [63] * 7 + [7]
     assert plan_enc_chunks(0, 100, 96) == [] and plan_enc_chunks(5, 100, 2) == [2, 2, 1]
+
+
+def test_generate_refuses_hf_arguments_it_would_otherwise_ignore():
+    """A drop-in must not silently decode something else: HF arguments that change the ids and are not implemented (beam search, penalties, processors,
+    stopping criteria, max_length) raise by name; their neutral values and everything the reference's loops pass go through."""
+    import pytest
+    from crab_amd.unified_llama import UnifiedForCausalLM as U
+    U._check_generate_kwargs(dict(max_new_tokens=500, use_cache=True, do_sample=True, temperature=0.6, top_k=50, top_p=0.9, num_beams=1,
+                                  repetition_penalty=1.0, bad_words_ids=[], logits_processor=None, output_logits=True, return_dict_in_generate=True,
+                                  max_length=20))                                      # max_length next to max_new_tokens: HF lets max_new_tokens win
+    for kw in (dict(num_beams=4), dict(repetition_penalty=1.2), dict(no_repeat_ngram_size=3), dict(stopping_criteria=[object()]), dict(penalty_alpha=0.6),
+               dict(num_return_sequences=2), dict(max_length=64), dict(typical_p=0.9)):
+        with pytest.raises(NotImplementedError, match=list(kw)[0]):
+            U._check_generate_kwargs(kw)
