@@ -1,8 +1,8 @@
 """Stateful fuzz at the MODEL level (r06, next to fuzz_engine_state.py): a random sequence of UnifiedForCausalLM calls - prepare_multimodal_inputs, generate,
 generate_batches in flight and coalesced, the pixel loops' generate_avs_many halves (ragged decode with hidden states + the batched SegModule) - with changing batch sizes, frame counts, audio windows (1-s and 2-s), modality subsets and ragged prompts on ONE
 tiny Crab (CLIP tower + BEATs + both Q-Former projectors + hyper-LoRA decoder), whose encoders, projectors and engine keep workspaces, tables and graphs between
-calls.  Three executions of the same sequence must agree BIT FOR BIT: a freshly built model per call, one model straight through, and one model straight
-through on a side HIP stream.   python scripts/fuzz_model_state.py [calls] [seed]"""
+calls.  Two checkpoints alternate: the carried model reloads (load_state_dict) whenever a call names the other one.  Three executions of the same sequence must
+agree BIT FOR BIT: a freshly built model per call, one model straight through, and one model straight through on a side HIP stream.   python scripts/fuzz_model_state.py [calls] [seed]"""
 import os, random, sys, warnings
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -41,8 +41,8 @@ def build():
     return model
 
 
-def weights():
-    torch.manual_seed(900)
+def weights(seed=900):
+    torch.manual_seed(seed)
     model = build()
     W = {}
     for k, v in model.state_dict().items():
@@ -74,7 +74,7 @@ def make_calls(n):
     for i in range(n):
         kind = rng.choice(["prepare", "generate", "generate", "batches", "avs"])
         c = dict(kind=kind, seed=i, tv=rng.choice([1, 2, 4, 8]), ta=rng.choice([1, 3, 10]), la=rng.choice([98, 198]), mods=rng.choice(["va", "va", "va", "v", "a", "none", "image"]),
-                 n=rng.choice([1, 3, 5]))
+                 n=rng.choice([1, 3, 5]), wset=int(i >= n // 3) ^ int(rng.random() < 0.15))      # the checkpoint in force: mostly the first, then mostly the second
         if kind == "avs":
             c.update(N=rng.choice([1, 2, 3, 5]), max_rows=rng.choice([None, None, 2]), mods="image_a", n=8)
         elif kind == "batches":
@@ -143,24 +143,28 @@ def same(a, b):
 
 if __name__ == "__main__":
     bad = []
-    W = weights()
-    calls = make_calls(NCALL)
+    WS = [weights(900), weights(901)]                      # two checkpoints: the carried model RELOADS (load_state_dict) when a call names the other one -
+    calls = make_calls(NCALL)                              # packed q|k|v / [W | B] / norm copies, tables and graphs made from the old weights must not survive
     fresh = []
     for c in calls:
-        m = new_model(W)
+        m = new_model(WS[c["wset"]])
         try:
             fresh.append(run(m, c))
         except Exception as e:      # noqa: BLE001
             fresh.append(e)
         del m
     for label, stream in (("carried", None), ("carried, side stream", torch.cuda.Stream())):
-        m = new_model(W)
+        m, cur, reloads = new_model(WS[0]), 0, 0
         n_same = 0
         ctx = torch.cuda.stream(stream) if stream is not None else torch.cuda.stream(torch.cuda.current_stream())
         with ctx:
             for i, c in enumerate(calls):
                 desc = f"{label}: call {i}: {c}"
                 try:
+                    if c["wset"] != cur:
+                        r_ = m.load_state_dict(WS[c["wset"]], strict=False)
+                        assert not r_.missing_keys
+                        cur, reloads = c["wset"], reloads + 1
                     got = run(m, c)
                 except Exception as e:      # noqa: BLE001
                     if not isinstance(fresh[i], Exception) or type(fresh[i]) is not type(e):
@@ -174,7 +178,7 @@ if __name__ == "__main__":
                 if same(got, fresh[i]): n_same += 1
                 else: bad.append(desc + f" -> results {[k for k, (a, b) in enumerate(zip(got, fresh[i])) if a.shape != b.shape or not torch.equal(a, b)]} differ from the fresh model's")
         torch.cuda.synchronize()
-        print(f"{label}: {n_same} of {len(calls)} calls bit-identical to a freshly built model ({sum(isinstance(f, Exception) for f in fresh)} calls raise on both)", flush=True)
+        print(f"{label}: {n_same} of {len(calls)} calls bit-identical to a freshly built model ({reloads} checkpoint reloads on the way; {sum(isinstance(f, Exception) for f in fresh)} calls raise on both)", flush=True)
         del m
     print(f"{3 * NCALL} calls computed, {len(bad)} failures")
     for b_ in bad[:40]: print("FAIL", b_)
