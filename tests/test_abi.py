@@ -115,3 +115,43 @@ def test_bench_flop_and_byte_accounting_matches_survey():
     b1 = bench.decode_bytes_per_step(1, 830)
     assert 13.5e9 < b1 < 14.2e9
     assert bench.decode_bytes_per_step(256, 830) - bench.decode_bytes_per_step(256, 829) == 256 * 2 * 32 * 4096 * 2
+
+
+def _prototypes():
+    """name -> (return type, [parameter types]) of every function declared in include/*.h, each reduced to its ctypes kind"""
+    def kind(t):
+        t = t.strip()
+        if "*" in t or t.endswith("]"):
+            return "ptr"
+        t = re.sub(r"\b(const|unsigned|signed)\b", "", t).split()
+        base = t[0] if t else "int"                                  # "unsigned" alone
+        return {"int": "i32", "int32_t": "i32", "int64_t": "i64", "uint64_t": "i64", "long": "i64", "float": "f32", "double": "f64", "void": "void",
+                "char": "ptr", "uint32_t": "i32", "size_t": "i64"}[base]
+    out = {}
+    for f in os.listdir(os.path.join(ROOT, "include")):
+        txt = re.sub(r"/\*.*?\*/", " ", open(os.path.join(ROOT, "include", f)).read(), flags=re.S)
+        txt = re.sub(r"//[^\n]*", " ", txt)
+        for m in re.finditer(r"(?:^|[;}\n])\s*((?:const\s+)?(?:int|int64_t|void|char\s*\*|float\s*\*?)\s*\*?)\s*(crab_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", txt, flags=re.S):
+            ret, name, params = m.group(1), m.group(2), m.group(3).strip()
+            ps = [] if params in ("", "void") else [re.sub(r"\s+[A-Za-z_][A-Za-z0-9_]*\s*(\[\s*\])?\s*$", lambda mm: " *" if mm.group(1) else "", p.strip()) if not p.strip().endswith("*") else p
+                                                    for p in params.split(",")]
+            out[name] = (kind(ret), [kind(p) for p in ps])
+    return out
+
+
+def test_ctypes_signatures_match_the_header_prototypes():
+    """r06: a binding whose argtypes drift from the prototype (an int for an int64_t stride, a float for a double) does not fail - it passes garbage.
+    Every entry of crab_amd/_lib.py SYMBOLS is compared, parameter by parameter, with the declaration in include/crab_hip.h."""
+    import ctypes as C
+    protos = _prototypes()
+    k = {C.c_void_p: "ptr", C.c_char_p: "ptr", C.c_int: "i32", C.c_int32: "i32", C.c_uint32: "i32", C.c_int64: "i64", C.c_uint64: "i64", C.c_long: "i64",
+         C.c_float: "f32", C.c_double: "f64", None: "void"}
+    checked = 0
+    for name, (res, args) in _lib.SYMBOLS.items():
+        assert name in protos, f"{name} bound in _lib.py but not declared in include/"
+        pres, pargs = protos[name]
+        got = [k.get(a, "ptr") for a in args]                        # POINTER(struct) and friends are pointers
+        assert got == pargs, f"{name}: ctypes {got} vs header {pargs}"
+        assert k.get(res, "ptr") == pres or (pres == "ptr" and k.get(res, "ptr") == "ptr"), f"{name}: restype {res} vs header {pres}"
+        checked += 1
+    assert checked >= 100
