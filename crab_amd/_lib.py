@@ -264,6 +264,10 @@ def load() -> C.CDLL:
         if not os.path.isfile(LIB_PATH):
             raise CrabHipError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                "(crab_amd/csrc/build.sh). There is no fallback path.")
+        # torch FIRST: libcrab_hip.so needs libamdhip64, and PyTorch-ROCm bundles its own.  Whichever is loaded first serves the whole process (same
+        # SONAME); with the library loaded before torch (r06: build() followed by smoke() in one process) the library talked to /opt/rocm's runtime and
+        # torch to its own - crab_ctx_create then saw no device (hipGetDeviceCount of the other runtime) while torch.cuda.is_available() was True
+        import torch  # noqa: F401
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(lib, name, None)

@@ -340,3 +340,25 @@ def test_c_caller_of_the_segmentation_metrics_matches_the_python_mirror(tmp_path
     assert np.array_equal(areas, dd["areas"].numpy()) and np.array_equal(areas, MO.class_areas(cp, ct)) and np.array_equal(iou_fc, dd["iou_fc"].numpy())
     assert np.array_equal(ious, mi.cpu().numpy()) and np.array_equal(fsc, fs.cpu().numpy()) and np.array_equal(cls, cc.cpu().numpy())
     assert np.array_equal(vid, torch.stack(vd).cpu().numpy(), equal_nan=True)
+
+
+def test_library_loaded_before_torch_still_shares_its_hip_runtime():
+    """r06: `build()` followed by `smoke()` in ONE process failed on the GPU box - build() loaded libcrab_hip.so before anything had imported torch, the
+    library bound /opt/rocm's libamdhip64 and torch then brought its own: two HIP runtimes, crab_ctx_create saw no device while torch did.  _lib.load()
+    now imports torch first; in a fresh interpreter the library-first order must work end to end."""
+    import subprocess
+    import sys
+    code = ("from crab_amd import _lib\n"
+            "import sys\n"
+            "assert 'torch' not in sys.modules\n"
+            "lib = _lib.load()\n"
+            "assert 'torch' in sys.modules\n"
+            "assert _lib.ctx(0)\n"
+            "import torch\n"
+            "from crab_amd import ops\n"
+            "x = torch.randn(4, 64, device='cuda')\n"
+            "y = ops.cast_bf16(x)\n"
+            "assert torch.equal(y, x.to(torch.bfloat16))\n"
+            "print('OK')\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "OK" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
